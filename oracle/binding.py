@@ -1,0 +1,143 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+All field elements are numpy uint64 arrays of shape (..., 4): Montgomery form, little-endian limbs --
+byte-identical to halo2's raw-bytes encoding (SURVEY.md §8(b) representation contract)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    return C.CDLL(_SO)
+
+
+lib = _load()
+_p = C.c_void_p
+
+
+def _ptr(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_p)
+
+
+def _fe(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 4
+    return a
+
+
+def fr_mul(a, b):
+    a, b = _fe(a), _fe(b); o = np.empty(4, np.uint64); lib.oracle_fr_mul(_ptr(a), _ptr(b), _ptr(o)); return o
+
+
+def fq_mul(a, b):
+    a, b = _fe(a), _fe(b); o = np.empty(4, np.uint64); lib.oracle_fq_mul(_ptr(a), _ptr(b), _ptr(o)); return o
+
+
+def fr_inv(a):
+    a = _fe(a); o = np.empty(4, np.uint64); lib.oracle_fr_inv(_ptr(a), _ptr(o)); return o
+
+
+def omega(k):
+    o = np.empty(4, np.uint64); lib.oracle_omega(C.c_uint(k), _ptr(o)); return o
+
+
+def g1_mul(p, s):
+    p, s = np.ascontiguousarray(p, np.uint64), _fe(s); o = np.empty(8, np.uint64)
+    lib.oracle_g1_mul(_ptr(p), _ptr(s), _ptr(o)); return o
+
+
+def g1_add(p, q):
+    p, q = np.ascontiguousarray(p, np.uint64), np.ascontiguousarray(q, np.uint64); o = np.empty(8, np.uint64)
+    lib.oracle_g1_add_affine(_ptr(p), _ptr(q), _ptr(o)); return o
+
+
+def g1_on_curve(p):
+    p = np.ascontiguousarray(p, np.uint64); return bool(lib.oracle_g1_on_curve(_ptr(p)))
+
+
+def msm(scalars, bases, naive=False):
+    """scalars (n,4) u64 Montgomery Fr; bases (n,8) u64 affine Montgomery Fq -> (8,) affine"""
+    s, b = _fe(scalars), np.ascontiguousarray(bases, np.uint64)
+    n = s.shape[0]; assert b.shape == (n, 8)
+    o = np.empty(8, np.uint64)
+    (lib.oracle_msm_naive if naive else lib.oracle_msm)(_ptr(s), _ptr(b), C.c_size_t(n), _ptr(o))
+    return o
+
+
+def fft(a, log_n, omega_mont):
+    a = _fe(a).copy(); assert a.shape == (1 << log_n, 4)
+    w = _fe(omega_mont)
+    lib.oracle_fft(_ptr(a), C.c_uint(log_n), _ptr(w)); return a
+
+
+def lagrange_to_coeff(a, k):
+    a = _fe(a).copy(); lib.oracle_lagrange_to_coeff(_ptr(a), C.c_uint(k)); return a
+
+
+def coeff_to_lagrange(a, k):
+    a = _fe(a).copy(); lib.oracle_coeff_to_lagrange(_ptr(a), C.c_uint(k)); return a
+
+
+def coeff_to_extended(a, k, ext_k):
+    a = _fe(a); o = np.empty((1 << ext_k, 4), np.uint64)
+    lib.oracle_coeff_to_extended(_ptr(a), C.c_uint(k), C.c_uint(ext_k), _ptr(o)); return o
+
+
+def extended_to_coeff(a, ext_k):
+    a = _fe(a).copy(); lib.oracle_extended_to_coeff(_ptr(a), C.c_uint(ext_k)); return a
+
+
+def divide_by_vanishing(a, k, ext_k):
+    a = _fe(a).copy(); lib.oracle_divide_by_vanishing(_ptr(a), C.c_uint(k), C.c_uint(ext_k)); return a
+
+
+def batch_invert(a):
+    a = _fe(a).copy(); lib.oracle_batch_invert(_ptr(a), C.c_size_t(a.shape[0])); return a
+
+
+def vec_op(name, a, b):
+    a, b = _fe(a), _fe(b); o = np.empty_like(a)
+    getattr(lib, "oracle_vec_" + name)(_ptr(a), _ptr(b), _ptr(o), C.c_size_t(a.shape[0])); return o
+
+
+class _Prog(C.Structure):
+    _fields_ = [("code", _p), ("n_instr", C.c_uint32), ("n_intermediates", C.c_uint32),
+                ("constants", _p), ("n_constants", C.c_uint32),
+                ("rotations", _p), ("n_rotations", C.c_uint32),
+                ("columns", _p), ("n_columns", C.c_uint32),
+                ("challenges", _p), ("n_challenges", C.c_uint32),
+                ("k", C.c_uint32), ("ext_k", C.c_uint32)]
+
+
+def eval_program(code, n_intermediates, constants, rotations, columns, challenges, k, ext_k, previous=None):
+    code = np.ascontiguousarray(code, np.uint32).reshape(-1, 8)
+    constants = _fe(np.asarray(constants, np.uint64).reshape(-1, 4))
+    challenges = _fe(np.asarray(challenges, np.uint64).reshape(-1, 4))
+    rotations = np.ascontiguousarray(rotations, np.int32)
+    cols = [_fe(c) for c in columns]
+    ne = 1 << ext_k
+    for c in cols:
+        assert c.shape == (ne, 4)
+    ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols])
+    out = np.zeros((ne, 4), np.uint64) if previous is None else _fe(previous).copy()
+    pr = _Prog(_ptr(code), code.shape[0], n_intermediates, _ptr(constants), constants.shape[0],
+               _ptr(rotations), rotations.shape[0], C.cast(ptrs, _p), len(cols),
+               _ptr(challenges), challenges.shape[0], k, ext_k)
+    lib.oracle_eval_program(C.byref(pr), _ptr(out))
+    return out
+
+
+def num_threads():
+    return int(lib.oracle_num_threads())

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Extract small golden fixtures from the reference's own test assets.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+    python tests/golden/make_golden.py
+Outputs (committed): tests/golden/kzg_k6.srs, kzg_k1_public.srs, vk_k6.key, pk_k6_subset.npz
+
+Sources (read-only, data not code): /root/reference/tests/assets/{kzg,kzg1.srs,vk.key,pk.key}.
+What they pin:
+  * kzg (k=6 test SRS)        : sum(g_lagrange)==g[0]; MSM(v,g_lagrange)==MSM(iNTT(v),g)
+  * kzg1.srs (public k=1 SRS) : vk permutation commitments of identity sigma columns == delta^j * sG
+  * pk.key                    : fixed_polys==iNTT_64(fixed_values); fixed_cosets==coeff_to_extended(polys);
+                                l0/l_last/l_active_row extended forms; permutation polys/cosets likewise
+pk.key is 1.4 MB, so only a subset of columns is kept (every stored column is kept whole).
+"""
+import os, shutil, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+from pyref import parse_pk  # noqa: E402
+
+A = "/root/reference/tests/assets/"
+shutil.copyfile(A + "kzg", os.path.join(HERE, "kzg_k6.srs"))
+shutil.copyfile(A + "kzg1.srs", os.path.join(HERE, "kzg_k1_public.srs"))
+shutil.copyfile(A + "vk.key", os.path.join(HERE, "vk_k6.key"))
+pk = parse_pk(open(A + "pk.key", "rb").read(), n_perm=32, n_sel=80)
+u8 = lambda b: np.frombuffer(b, dtype=np.uint8)
+FIXED = [0, 1, 5, 17, 37]
+PERM = [0, 3, 20, 31]
+out = dict(k=np.array([pk["k"]]), ext_k=np.array([9]), fixed_idx=np.array(FIXED), perm_idx=np.array(PERM),
+           l0=u8(pk["l0"]), l_last=u8(pk["l_last"]), l_active_row=u8(pk["l_active_row"]))
+for name, idx in (("fixed_values", FIXED), ("fixed_polys", FIXED), ("fixed_cosets", FIXED),
+                  ("permutations", PERM), ("perm_polys", PERM), ("perm_cosets", PERM)):
+    out[name] = np.stack([u8(pk[name][i]) for i in idx])
+np.savez_compressed(os.path.join(HERE, "pk_k6_subset.npz"), **out)
+print({k: v.shape for k, v in out.items()})
