@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference interface for the prove hot path, on top of the C ABI.
+
+Names follow halo2 (the reference's proving stack):
+  ParamsKZG.commit_lagrange / commit      <- halo2_proofs::poly::kzg::commitment::ParamsKZG (A10;
+                                             call site /root/reference/src/circuit/modules/polycommit.rs:71)
+  EvaluationDomain.{lagrange_to_coeff, coeff_to_lagrange, coeff_to_extended, extended_to_coeff,
+                    divide_by_vanishing_poly}  <- halo2_proofs::poly::EvaluationDomain (A11)
+  GraphProgram.evaluate_h                 <- plonk::evaluation::GraphEvaluator / evaluate_h (A12)
+All field data are numpy uint64 arrays (..., 4) in Montgomery form = the bytes halo2 holds in memory.
+"""
+import ctypes as C
+import numpy as np
+from . import lib as _l
+
+_vp = C.c_void_p
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _fe(a, shape_last=4):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.shape[-1] != shape_last:
+        raise ValueError("expected trailing dimension %d" % shape_last)
+    return a
+
+
+def init(device=-1):
+    _l.check(_l.load().ezkl_hip_init(C.c_int(device)), "ezkl_hip_init")
+
+
+def device_count():
+    return int(_l.load().ezkl_hip_device_count())
+
+
+def _stream_ptr(stream):
+    return _vp(stream) if stream else _vp(None)
+
+
+class DeviceBuffer:
+    """A library-owned HBM allocation (resident column / scalar vector)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = _vp()
+        _l.check(_l.load().ezkl_hip_malloc(C.byref(p), C.c_size_t(self.nbytes)), "ezkl_hip_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        _l.check(_l.load().ezkl_hip_memcpy_h2d(_vp(b.ptr), _p(a), C.c_size_t(a.nbytes)), "h2d")
+        return b
+
+    def to_numpy(self, dtype=np.uint64, shape=None):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _l.check(_l.load().ezkl_hip_memcpy_d2h(_p(out), _vp(self.ptr), C.c_size_t(self.nbytes)), "d2h")
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            _l.load().ezkl_hip_free(_vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _Bases:
+    def __init__(self, pts):
+        pts = _fe(pts, 8)
+        self.n = pts.shape[0]
+        h = _vp()
+        _l.check(_l.load().ezkl_hip_bases_upload(_p(pts), C.c_size_t(self.n), C.byref(h)), "ezkl_hip_bases_upload")
+        self.h = h
+
+    @classmethod
+    def generate(cls, seed, n, first=0):
+        self = cls.__new__(cls)
+        self.n = n
+        h = _vp()
+        _l.check(_l.load().ezkl_hip_bases_generate(C.c_uint64(seed), C.c_size_t(first), C.c_size_t(n), C.byref(h)),
+                 "ezkl_hip_bases_generate")
+        self.h = h
+        return self
+
+    def download(self):
+        out = np.empty((self.n, 8), np.uint64)
+        _l.check(_l.load().ezkl_hip_bases_download(self.h, _p(out)), "ezkl_hip_bases_download")
+        return out
+
+    def free(self):
+        if self.h:
+            _l.load().ezkl_hip_bases_free(self.h)
+            self.h = None
+
+
+Bases = _Bases
+
+
+def msm_g1_dev(bases, scalars_ptr, n, offset=0, stream=None):
+    out = np.zeros(8, np.uint64)
+    _l.check(_l.load().ezkl_hip_msm_g1_dev(bases.h, C.c_size_t(offset), _vp(scalars_ptr), C.c_size_t(n), _p(out),
+                                            _stream_ptr(stream)), "ezkl_hip_msm_g1_dev")
+    return out
+
+
+def msm_g1(bases, scalars):
+    """sum_i scalars[i]*bases[i]; scalars numpy (n,4) or a DeviceBuffer-resident vector via msm_dev."""
+    s = _fe(scalars)
+    out = np.zeros(8, np.uint64)
+    _l.check(_l.load().ezkl_hip_msm_g1(bases.h, _p(s), C.c_size_t(s.shape[0]), _p(out)), "ezkl_hip_msm_g1")
+    return out
+
+
+class ParamsKZG:
+    """KZG SRS with both base sets resident in HBM (g: coefficient basis, g_lagrange: Lagrange basis)."""
+
+    def __init__(self, k, g, g_lagrange):
+        self.k, self.n = k, 1 << k
+        self._g = _Bases(g)
+        self._gl = _Bases(g_lagrange)
+
+    @classmethod
+    def read(cls, buf):
+        """raw-bytes SRS file: u32 LE k | 2^k G1 g | 2^k G1 g_lagrange | g2 | s_g2 (SURVEY.md §8(c) item 1;
+        the reader being mirrored is /root/reference/src/pfsys/srs.rs:40-47 -> ParamsKZG::read)."""
+        k = int.from_bytes(buf[0:4], "little")
+        n = 1 << k
+        if len(buf) != 4 + 2 * 64 * n + 256:
+            raise ValueError("bad SRS length")
+        g = np.frombuffer(buf, np.uint64, count=8 * n, offset=4).reshape(n, 8)
+        gl = np.frombuffer(buf, np.uint64, count=8 * n, offset=4 + 64 * n).reshape(n, 8)
+        return cls(k, g, gl)
+
+    def commit_lagrange(self, poly):
+        """MSM against g_lagrange; returns the canonical affine point (8 x u64). Blind is ignored by KZG."""
+        return msm_g1(self._gl, poly)
+
+    def commit(self, poly):
+        return msm_g1(self._g, poly)
+
+    def commit_dev(self, scalars_dev, n, lagrange=True, offset=0, stream=None):
+        out = np.zeros(8, np.uint64)
+        b = self._gl if lagrange else self._g
+        _l.check(_l.load().ezkl_hip_msm_g1_dev(b.h, C.c_size_t(offset), _vp(scalars_dev), C.c_size_t(n), _p(out),
+                                                _stream_ptr(stream)), "ezkl_hip_msm_g1_dev")
+        return out
+
+    def free(self):
+        self._g.free()
+        self._gl.free()
+
+
+def g1_add_affine(a, b):
+    a, b = _fe(a, 8), _fe(b, 8)
+    out = np.zeros(8, np.uint64)
+    _l.check(_l.load().ezkl_hip_g1_add_affine(_p(a), _p(b), _p(out)), "ezkl_hip_g1_add_affine")
+    return out
+
+
+def ntt(a, log_n, omega, inverse=False):
+    """best_fft(a, omega, log_n) on a host array (copy in, transform, copy out)."""
+    a = _fe(a).copy()
+    w = _fe(omega)
+    _l.check(_l.load().ezkl_hip_ntt(_p(a), C.c_uint32(log_n), _p(w), C.c_int(1 if inverse else 0)), "ezkl_hip_ntt")
+    return a
+
+
+def ntt_dev(ptr, log_n, omega, inverse=False, batch=1, stride=None, stream=None):
+    w = _fe(omega)
+    stride = (1 << log_n) if stride is None else stride
+    _l.check(_l.load().ezkl_hip_ntt_dev(_vp(ptr), C.c_uint32(log_n), _p(w), C.c_int(1 if inverse else 0),
+                                         C.c_size_t(batch), C.c_size_t(stride), _stream_ptr(stream)), "ezkl_hip_ntt_dev")
+
+
+def vec_op(op, a_ptr, b_ptr, out_ptr, n, stream=None):
+    code = {"add": 0, "sub": 1, "mul": 2}[op]
+    _l.check(_l.load().ezkl_hip_vec_op_dev(C.c_int(code), _vp(a_ptr), _vp(b_ptr), _vp(out_ptr), C.c_size_t(n),
+                                            _stream_ptr(stream)), "ezkl_hip_vec_op_dev")
+
+
+# Montgomery constants needed host-side (derived, not copied: tools/gen_constants.py)
+_R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+_MONT = 1 << 256
+
+
+def _to_mont(x):
+    return np.frombuffer((x * _MONT % _R).to_bytes(32, "little"), np.uint64).copy()
+
+
+class EvaluationDomain:
+    """halo2 EvaluationDomain(j, k): n = 2^k, extended domain 2^ext_k with ext_k = k + ceil(log2(j-1))."""
+
+    ROOT = pow(7, (_R - 1) >> 28, _R)
+
+    def __init__(self, j, k):
+        self.k = k
+        quotient_poly_degree = j - 1
+        self.ext_k = k
+        while (1 << self.ext_k) < (1 << k) * quotient_poly_degree:
+            self.ext_k += 1
+        self.n, self.ne = 1 << k, 1 << self.ext_k
+        w = pow(self.ROOT, 1 << (28 - k), _R)
+        we = pow(self.ROOT, 1 << (28 - self.ext_k), _R)
+        self.omega, self.omega_inv = _to_mont(w), _to_mont(pow(w, -1, _R))
+        self.extended_omega, self.extended_omega_inv = _to_mont(we), _to_mont(pow(we, -1, _R))
+
+    def lagrange_to_coeff(self, a):
+        return ntt(a, self.k, self.omega_inv, inverse=True)
+
+    def coeff_to_lagrange(self, a):
+        return ntt(a, self.k, self.omega, inverse=False)
+
+    def _coset(self, cols, inverse):
+        cols = [_fe(c) for c in cols]
+        nout = self.ne
+        outs = [np.empty((nout, 4), np.uint64) for _ in cols]
+        ins = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        ous = (C.c_void_p * len(cols))(*[o.ctypes.data for o in outs])
+        _l.check(_l.load().ezkl_hip_coset_ntt_batch(ins, ous, C.c_size_t(len(cols)), C.c_uint32(self.k),
+                                                     C.c_uint32(self.ext_k), C.c_int(1 if inverse else 0)),
+                 "ezkl_hip_coset_ntt_batch")
+        return outs
+
+    def coeff_to_extended(self, a):
+        return self._coset([a], False)[0]
+
+    def extended_to_coeff(self, a):
+        return self._coset([a], True)[0]
+
+    def divide_by_vanishing_poly(self, a):
+        buf = DeviceBuffer.from_numpy(_fe(a))
+        _l.check(_l.load().ezkl_hip_divide_by_vanishing_dev(_vp(buf.ptr), C.c_uint32(self.k), C.c_uint32(self.ext_k),
+                                                             _vp(None)), "ezkl_hip_divide_by_vanishing_dev")
+        out = buf.to_numpy(shape=(self.ne, 4))
+        buf.free()
+        return out
+
+
+class _Prog(C.Structure):
+    _fields_ = [("code", _vp), ("n_instr", C.c_uint32), ("n_intermediates", C.c_uint32),
+                ("constants", _vp), ("n_constants", C.c_uint32),
+                ("rotations", _vp), ("n_rotations", C.c_uint32),
+                ("columns", _vp), ("n_columns", C.c_uint32),
+                ("challenges", _vp), ("n_challenges", C.c_uint32),
+                ("k", C.c_uint32), ("ext_k", C.c_uint32)]
+
+
+OPS = dict(add=0, sub=1, mul=2, square=3, double=4, negate=5, store=6, horner_step=7)
+CONST, INTERMEDIATE, COLUMN, CHALLENGE, PREVIOUS = range(5)
+
+
+class GraphProgram:
+    """Builder for the straight-line program a GraphEvaluator holds (constants, rotations, calculations).
+
+    add_calculation mirrors GraphEvaluator::add_calculation: returns the ValueSource of the result.
+    Horner(start, parts, factor) is lowered to store + horner_step, the body of Calculation::Horner."""
+
+    def __init__(self, k, ext_k):
+        self.k, self.ext_k = k, ext_k
+        self.code, self.constants, self.rotations = [], [], []
+        self.n_intermediates = 0
+
+    def constant(self, fe_mont):
+        fe_mont = np.asarray(fe_mont, np.uint64)
+        for i, c in enumerate(self.constants):
+            if (c == fe_mont).all():
+                return (CONST, i, 0)
+        self.constants.append(fe_mont)
+        return (CONST, len(self.constants) - 1, 0)
+
+    def rotation(self, rot):
+        if rot not in self.rotations:
+            self.rotations.append(rot)
+        return self.rotations.index(rot)
+
+    def column(self, idx, rot=0):
+        return (COLUMN, idx, self.rotation(rot))
+
+    def challenge(self, idx):
+        return (CHALLENGE, idx, 0)
+
+    def previous(self):
+        return (PREVIOUS, 0, 0)
+
+    def calc(self, op, s0, s1=(CONST, 0, 0), target=None):
+        if target is None:
+            target = self.n_intermediates
+            self.n_intermediates += 1
+        self.code.append([OPS[op], target, *s0, *s1])
+        return (INTERMEDIATE, target, 0)
+
+    def horner(self, start, parts, factor):
+        t = self.calc("store", start)
+        for p in parts:
+            self.calc("horner_step", p, factor, target=t[1])
+        return t
+
+    def arrays(self):
+        code = np.asarray(self.code, np.uint32).reshape(-1, 8)
+        consts = np.asarray(self.constants, np.uint64).reshape(-1, 4)
+        rots = np.asarray(self.rotations, np.int32)
+        return code, consts, rots
+
+    def evaluate_h(self, column_ptrs, challenges, out_ptr, stream=None):
+        """Run on device-resident columns (list of device pointers); out_ptr holds PreviousValue on entry."""
+        code, consts, rots = self.arrays()
+        ch = _fe(np.asarray(challenges, np.uint64).reshape(-1, 4))
+        cols = (C.c_void_p * max(1, len(column_ptrs)))(*column_ptrs)
+        pr = _Prog(_p(code), code.shape[0], self.n_intermediates, _p(consts), consts.shape[0], _p(rots), rots.shape[0],
+                   C.cast(cols, _vp), len(column_ptrs), _p(ch), ch.shape[0], self.k, self.ext_k)
+        _l.check(_l.load().ezkl_hip_eval_h_dev(C.byref(pr), _vp(out_ptr), _stream_ptr(stream)), "ezkl_hip_eval_h_dev")
+
+
+def last_kernel_ms(which):
+    ms = C.c_float(0)
+    _l.check(_l.load().ezkl_hip_last_kernel_ms(which.encode(), C.byref(ms)), "ezkl_hip_last_kernel_ms")
+    return float(ms.value)
+
+
+def ubench(which):
+    out = C.c_double(0)
+    _l.check(_l.load().ezkl_hip_ubench(which.encode(), C.byref(out)), "ezkl_hip_ubench")
+    return float(out.value)

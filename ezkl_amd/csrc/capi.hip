@@ -1,0 +1,343 @@
+// capi.hip -- the extern "C" surface of libezkl_hip.so (include/ezkl_hip.h) and the library context.
+#include "common.hpp"
+#include <string.h>
+#include <atomic>
+
+namespace ezkl {
+
+static std::mutex g_init_mu;
+static Ctx* g_ctx = nullptr;
+static std::atomic<int> g_last_hip_err{0};
+
+int set_hip_error(hipError_t e, const char* what, const char* file, int line) {
+    g_last_hip_err.store((int)e);
+    fprintf(stderr, "[ezkl_hip] HIP error %d (%s) at %s:%d in %s\n", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? EZKL_ERR_NOMEM : EZKL_ERR_HIP;
+}
+
+int ctx_init(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_ctx) return (device < 0 || g_ctx->device == device) ? EZKL_OK : EZKL_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_last_hip_err.store((int)e);
+        (void)hipGetLastError();
+        return EZKL_ERR_NO_DEVICE;
+    }
+    if (device < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        device = lr ? atoi(lr) % n : 0;
+    }
+    if (device >= n) return EZKL_ERR_INVALID;
+    EZ_HIP(hipSetDevice(device));
+    Ctx* c = new Ctx();
+    c->device = device;
+    EZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    EZ_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    g_ctx = c;
+    return EZKL_OK;
+}
+
+Ctx* ctx() {
+    if (!g_ctx) {
+        if (ctx_init(-1) != EZKL_OK) return nullptr;
+    }
+    return g_ctx;
+}
+
+int scratch_reserve(Ctx* c, size_t bytes, void** out) {
+    if (bytes > c->scratch_bytes) {
+        if (c->scratch) {
+            EZ_HIP(hipDeviceSynchronize());
+            EZ_HIP(hipFree(c->scratch));
+            c->scratch = nullptr;
+            c->scratch_bytes = 0;
+        }
+        size_t want = bytes + (bytes >> 3);
+        EZ_HIP(hipMalloc(&c->scratch, want));
+        c->scratch_bytes = want;
+    }
+    *out = c->scratch;
+    return EZKL_OK;
+}
+
+int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1) {
+    auto it = c->events.find(key);
+    if (it == c->events.end()) {
+        hipEvent_t a, b;
+        EZ_HIP(hipEventCreate(&a));
+        EZ_HIP(hipEventCreate(&b));
+        it = c->events.emplace(key, std::make_pair(a, b)).first;
+    }
+    *e0 = it->second.first;
+    *e1 = it->second.second;
+    return EZKL_OK;
+}
+
+// calls made on the library stream are synchronous; calls on a caller stream are stream-ordered
+static int finish(Ctx* c, hipStream_t st, void* user_stream) {
+    if (!user_stream) EZ_HIP(hipStreamSynchronize(st));
+    return EZKL_OK;
+}
+
+}  // namespace ezkl
+
+using namespace ezkl;
+
+extern "C" {
+
+int ezkl_hip_init(int device) { return ctx_init(device); }
+
+int ezkl_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int ezkl_hip_synchronize(void) {
+    EZ_CTX(c);
+    EZ_HIP(hipDeviceSynchronize());
+    return EZKL_OK;
+}
+
+int ezkl_hip_warmup(void) {
+    EZ_CTX(c);
+    // touch the stream + allocator once, as icicle's warmup(stream) does (src/execute.rs:89)
+    void* p = nullptr;
+    EZ_HIP(hipMalloc(&p, 1 << 20));
+    EZ_HIP(hipMemsetAsync(p, 0, 1 << 20, c->stream));
+    EZ_HIP(hipStreamSynchronize(c->stream));
+    EZ_HIP(hipFree(p));
+    return EZKL_OK;
+}
+
+const char* ezkl_hip_strerror(int code) {
+    switch (code) {
+    case EZKL_OK: return "ok";
+    case EZKL_ERR_NO_DEVICE: return "no HIP device visible (libezkl_hip has no CPU fallback)";
+    case EZKL_ERR_HIP: return "HIP runtime error (see ezkl_hip_last_hip_error)";
+    case EZKL_ERR_INVALID: return "invalid argument";
+    case EZKL_ERR_NOMEM: return "out of device memory";
+    case EZKL_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown error";
+    }
+}
+int ezkl_hip_last_hip_error(void) { return g_last_hip_err.load(); }
+const char* ezkl_hip_version(void) { return "ezkl_hip 0.1 (gfx950)"; }
+
+int ezkl_hip_malloc(void** dptr, size_t bytes) {
+    if (!dptr) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    EZ_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return EZKL_OK;
+}
+int ezkl_hip_free(void* dptr) {
+    EZ_CTX(c);
+    EZ_HIP(hipFree(dptr));
+    return EZKL_OK;
+}
+int ezkl_hip_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    EZ_CTX(c);
+    EZ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return EZKL_OK;
+}
+int ezkl_hip_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    EZ_CTX(c);
+    EZ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return EZKL_OK;
+}
+
+/* ------------------------------------------------------------------ MSM -------------------- */
+int ezkl_hip_bases_upload(const void* pts, size_t n, ezkl_bases_t* out) {
+    if (!pts || !out || n == 0) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    Bases* b = new Bases();
+    b->n = n;
+    EZ_HIP(hipMalloc(&b->pts, n * 64));
+    EZ_HIP(hipMemcpy(b->pts, pts, n * 64, hipMemcpyHostToDevice));
+    *out = reinterpret_cast<ezkl_bases_t>(b);
+    return EZKL_OK;
+}
+int ezkl_hip_bases_free(ezkl_bases_t h) {
+    if (!h) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    Bases* b = reinterpret_cast<Bases*>(h);
+    msm_table_drop(b);
+    EZ_HIP(hipFree(b->pts));
+    delete b;
+    return EZKL_OK;
+}
+int ezkl_hip_bases_generate(uint64_t seed, size_t first, size_t n, ezkl_bases_t* out) {
+    if (!out || n == 0) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    Bases* b = new Bases();
+    b->n = n;
+    EZ_HIP(hipMalloc(&b->pts, n * 64));
+    int rc = gen_bases(c, c->stream, seed, first, n, b->pts);
+    if (rc) { (void)hipFree(b->pts); delete b; return rc; }
+    *out = reinterpret_cast<ezkl_bases_t>(b);
+    return EZKL_OK;
+}
+int ezkl_hip_bases_download(ezkl_bases_t h, void* out_host) {
+    if (!h || !out_host) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    Bases* b = reinterpret_cast<Bases*>(h);
+    EZ_HIP(hipMemcpy(out_host, b->pts, b->n * 64, hipMemcpyDeviceToHost));
+    return EZKL_OK;
+}
+size_t ezkl_hip_bases_len(ezkl_bases_t h) { return h ? reinterpret_cast<Bases*>(h)->n : 0; }
+
+int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, void* out, void* stream) {
+    if (!h || !out || (!scalars_dev && n)) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (base_offset + n > b->n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_run(c, pick_stream(c, stream), b, base_offset, (const fe_t*)scalars_dev, n, out);
+}
+int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out) {
+    if (!h || !out || (!scalars && n)) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (n > b->n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (n == 0) { memset(out, 0, 64); return EZKL_OK; }
+    fe_t* d = nullptr;
+    EZ_HIP(hipMalloc(&d, n * 32));
+    hipError_t e = hipMemcpyAsync(d, scalars, n * 32, hipMemcpyHostToDevice, c->stream);
+    int rc = e == hipSuccess ? msm_run(c, c->stream, b, 0, d, n, out) : set_hip_error(e, "memcpy", __FILE__, __LINE__);
+    (void)hipFree(d);
+    return rc;
+}
+int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t batch, size_t n, void* out) {
+    if (!scalars || !out) return EZKL_ERR_INVALID;
+    for (size_t i = 0; i < batch; i++) {
+        int rc = ezkl_hip_msm_g1(h, scalars[i], n, (uint8_t*)out + 64 * i);
+        if (rc) return rc;
+    }
+    return EZKL_OK;
+}
+int ezkl_hip_g1_add_affine(const void* a, const void* b, void* out) {
+    if (!a || !b || !out) return EZKL_ERR_INVALID;
+    g1_add_affine_host(a, b, out);
+    return EZKL_OK;
+}
+
+/* ------------------------------------------------------------------ NTT -------------------- */
+int ezkl_hip_ntt_dev(void* data, uint32_t log_n, const void* omega, int inverse, size_t batch, size_t stride, void* stream) {
+    if (!data || !omega || batch == 0) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    fe_t w;
+    memcpy(&w, omega, 32);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = ntt_run(c, st, (const fe_t*)data, (fe_t*)data, log_n, w, inverse != 0, batch, stride, stride, log_n, 0);
+    if (rc) return rc;
+    return finish(c, st, stream);
+}
+int ezkl_hip_ntt(void* data, uint32_t log_n, const void* omega, int inverse) {
+    if (!data || !omega || log_n > 28) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    size_t bytes = (size_t)32 << log_n;
+    fe_t* d = nullptr;
+    EZ_HIP(hipMalloc(&d, bytes));
+    int rc = EZKL_OK;
+    hipError_t e = hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) rc = set_hip_error(e, "h2d", __FILE__, __LINE__);
+    if (!rc) rc = ezkl_hip_ntt_dev(d, log_n, omega, inverse, 1, (size_t)1 << log_n, nullptr);
+    if (!rc) {
+        e = hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_hip_error(e, "d2h", __FILE__, __LINE__);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+static fe_t domain_omega(uint32_t k, bool inverse) {
+    fe_t w = fr_const(FrConst::ROOT);
+    for (uint32_t i = k; i < 28; i++) w = Fr::sqr(w);
+    return inverse ? Fr::inv(w) : w;
+}
+
+int ezkl_hip_coset_ntt_dev(const void* in, void* out, size_t batch, size_t in_stride, size_t out_stride,
+                           uint32_t log_n, uint32_t log_n_ext, int inverse, void* stream) {
+    if (!in || !out || batch == 0 || log_n > log_n_ext || log_n_ext > 28) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    fe_t w = domain_omega(log_n_ext, inverse != 0);
+    int rc;
+    if (!inverse)
+        rc = ntt_run(c, st, (const fe_t*)in, (fe_t*)out, log_n_ext, w, false, batch, in_stride, out_stride, log_n, 1);
+    else
+        rc = ntt_run(c, st, (const fe_t*)in, (fe_t*)out, log_n_ext, w, true, batch, in_stride, out_stride, log_n_ext, 2);
+    if (rc) return rc;
+    return finish(c, st, stream);
+}
+int ezkl_hip_coset_ntt_batch(const void* const* in, void* const* out, size_t batch, uint32_t log_n, uint32_t log_n_ext, int inverse) {
+    if (!in || !out || log_n > log_n_ext || log_n_ext > 28) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    const size_t ne = (size_t)1 << log_n_ext, nin = inverse ? ne : ((size_t)1 << log_n);
+    fe_t *din = nullptr, *dout = nullptr;
+    EZ_HIP(hipMalloc(&din, nin * 32));
+    EZ_HIP(hipMalloc(&dout, ne * 32));
+    int rc = EZKL_OK;
+    for (size_t b = 0; b < batch && !rc; b++) {
+        hipError_t e = hipMemcpyAsync(din, in[b], nin * 32, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = set_hip_error(e, "h2d", __FILE__, __LINE__); break; }
+        rc = ezkl_hip_coset_ntt_dev(din, dout, 1, nin, ne, log_n, log_n_ext, inverse, nullptr);
+        if (rc) break;
+        e = hipMemcpy(out[b], dout, ne * 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_hip_error(e, "d2h", __FILE__, __LINE__);
+    }
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ vec ops ---------------- */
+int ezkl_hip_vec_op_dev(int op, const void* a, const void* b, void* o, size_t n, void* stream) {
+    if (!a || !b || !o || op < 0 || op > 2) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return vec_op(c, pick_stream(c, stream), op, (const fe_t*)a, (const fe_t*)b, (fe_t*)o, n);
+}
+int ezkl_hip_vec_scale_dev(const void* a, const void* s, void* o, size_t n, void* stream) {
+    if (!a || !s || !o) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    fe_t sc;
+    memcpy(&sc, s, 32);
+    return vec_scale(c, pick_stream(c, stream), (const fe_t*)a, sc, (fe_t*)o, n);
+}
+int ezkl_hip_divide_by_vanishing_dev(void* a, uint32_t k, uint32_t ext_k, void* stream) {
+    if (!a || k > ext_k || ext_k > 28) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return divide_by_vanishing(c, pick_stream(c, stream), (fe_t*)a, k, ext_k);
+}
+int ezkl_hip_batch_invert_dev(void* a, size_t n, void* stream) {
+    if (!a) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return batch_invert(c, pick_stream(c, stream), (fe_t*)a, n);
+}
+
+int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out, void* stream) {
+    if (!prog || !out) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return eval_program(c, pick_stream(c, stream), prog, (fe_t*)out);
+}
+
+int ezkl_hip_last_kernel_ms(const char* which, float* out_ms) {
+    if (!which || !out_ms) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    auto it = c->events.find(which);
+    if (it == c->events.end()) return EZKL_ERR_INVALID;
+    EZ_HIP(hipEventSynchronize(it->second.second));
+    EZ_HIP(hipEventElapsedTime(out_ms, it->second.first, it->second.second));
+    return EZKL_OK;
+}
+int ezkl_hip_ubench(const char* which, double* out) {
+    if (!which || !out) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return ubench(c, which, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// common.hpp -- library context, error plumbing, launch helpers (host side of libezkl_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/ezkl_hip.h"
+#include "field.hpp"
+
+namespace ezkl {
+
+struct Ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;     // library stream (used when the caller passes NULL)
+    int num_cus = 256;
+    std::recursive_mutex mu;          // serialises calls on this device (halo2 calls from rayon workers)
+    // HIP event pairs recorded on the stream the kernels run on, one pair per measured region
+    // ("ntt", "coset_ntt", "msm", "msm_accumulate", ...); read back by ezkl_hip_last_kernel_ms
+    std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
+    // scratch arena reused across calls (grown on demand, never shrunk)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+Ctx* ctx();                 // lazily initialised singleton (nullptr + last error set if no device)
+int ctx_init(int device);
+int set_hip_error(hipError_t e, const char* what, const char* file, int line);
+int scratch_reserve(Ctx* c, size_t bytes, void** out);
+int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1);
+
+#define EZ_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t _e = (call);                                                   \
+        if (_e != hipSuccess) return ::ezkl::set_hip_error(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define EZ_CTX(c)                                   \
+    ::ezkl::Ctx* c = ::ezkl::ctx();                 \
+    if (!c) return EZKL_ERR_NO_DEVICE;              \
+    std::lock_guard<std::recursive_mutex> _lk(c->mu); \
+    EZ_HIP(hipSetDevice(c->device))
+
+static inline hipStream_t pick_stream(Ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// -------- module entry points implemented in the .hip files --------
+struct Bases {
+    fe_t* pts = nullptr;   // n x (x,y) affine
+    size_t n = 0;
+};
+
+int ntt_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
+            size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode);
+int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* scalars_dev, size_t n,
+            void* out_affine_host);
+int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o, size_t n);
+int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, size_t n);
+int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
+int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
+int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
+int ubench(Ctx* c, const char* which, double* out);
+void msm_table_drop(const Bases* b);
+int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, void* out_dev);
+void g1_add_affine_host(const void* a, const void* b, void* out);
+
+}  // namespace ezkl

@@ -1,0 +1,310 @@
+// ntt.hip -- radix-2^r multi-pass NTT over BN254 Fr for gfx950.
+//
+// Replaces halo2curves::fft::best_fft and the EvaluationDomain wrappers around it (SURVEY.md §8(a) A11;
+// type used in-tree at /root/reference/src/circuit/modules/polycommit.rs:52).  Natural order in and out.
+//
+// Decomposition (decimation in frequency, N = R_1 * ... * R_P, R_p = 2^r_p <= 256):
+//   pass p works on contiguous blocks of size M_p = N / (R_1..R_{p-1}); inside a block, index
+//   i = i1 * S + i2 (S = M_p / R_p).  A workgroup owns a TILE of C = TILE/R_p adjacent columns i2 (so each
+//   global row segment is C*32 B contiguous -> coalesced), loads it into LDS as 4 planes of 8-byte limb
+//   pairs (conflict-free ds_read_b64), runs the r_p butterfly stages there with the R_p/2 local twiddles
+//   staged in LDS, multiplies by the inter-pass twiddle w_M^(i2*k1) (table streamed alongside the data) and
+//   writes back in place.  The last pass (S = 1) owns C whole blocks chosen with consecutive leading digit
+//   so that its digit-reversed (natural-order) output is written C*32 B at a time as well.
+// HBM traffic per element: P x (32 B read + 32 B write) + 32 B twiddle in non-last passes; algorithmic
+// minimum is 64 B.  Arithmetic: (log2 N)/2 + (P-1) Montgomery products per element --
+// the kernel is integer-VALU bound, not HBM bound.
+#include "common.hpp"
+#include <string.h>
+
+namespace ezkl {
+
+static constexpr int NTT_THREADS = 256;
+static constexpr uint32_t NTT_LOG_TILE = 11;   // 2048 elements = 64 KiB of LDS
+
+struct PassArgs {
+    const fe_t* in;
+    fe_t* out;
+    size_t in_stride, out_stride;
+    const fe_t* tw_local;   // R/2 entries: w_R^j
+    const fe_t* tw_inter;   // M entries: w_M^(i2*k1) at k1*S + i2 (null in last pass)
+    uint32_t log_n, log_r, log_m, log_tile;
+    uint32_t last, first;
+    uint32_t in_log_len;    // first pass: elements at index >= 2^in_log_len read as zero
+    uint32_t coset_pre;     // first pass: multiply element i by zeta^(i mod 3)
+    uint32_t post;          // last pass: multiply output i by post_c[i mod 3]
+    uint32_t npass, log_radix[4];
+    uint32_t k1_major;      // last pass: tile owns C blocks with consecutive leading digit
+    fe_t zeta[2];           // zeta, zeta^2
+    fe_t post_c[3];
+};
+
+EZ_D void lds_put(uint2* d, uint32_t tile, uint32_t e, const fe_t& x) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) d[q * tile + e] = make_uint2(x.v[2 * q], x.v[2 * q + 1]);
+}
+EZ_D fe_t lds_get(const uint2* d, uint32_t tile, uint32_t e) {
+    fe_t x;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint2 t = d[q * tile + e];
+        x.v[2 * q] = t.x;
+        x.v[2 * q + 1] = t.y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t TILE = 1u << a.log_tile, R = 1u << a.log_r;
+    const uint32_t logC = a.log_tile - a.log_r, C = 1u << logC;
+    const uint32_t log_s = a.log_m - a.log_r, S = 1u << log_s;
+    uint2* data = reinterpret_cast<uint2*>(smem);
+    fe_t* tloc = reinterpret_cast<fe_t*>(smem + 32u * TILE);
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const fe_t* in = a.in + (size_t)blockIdx.y * a.in_stride;
+    fe_t* out = a.out + (size_t)blockIdx.y * a.out_stride;
+
+    for (uint32_t j = tid; j < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(a.tw_local + j);
+
+    // ---- block / column geometry of this tile ----
+    // non-last: colid = tile*C + c ; base(c) = (colid >> log_s) * M + (colid & (S-1)), rows strided by S
+    // last    : blk(c) ; base(c) = blk * R, rows contiguous
+    uint32_t n_blocks = 1u << (a.log_n - a.log_r);               // last pass only
+    uint32_t sblk = a.npass >= 2 ? (n_blocks >> a.log_radix[0]) : 1u;
+    auto col_base = [&](uint32_t c) -> size_t {
+        if (!a.last) {
+            uint32_t colid = tile * C + c;
+            return ((size_t)(colid >> log_s) << a.log_m) + (colid & (S - 1));
+        }
+        uint32_t blk;
+        if (a.k1_major) {
+            uint32_t rest = tile % sblk, k10 = (tile / sblk) * C;
+            blk = (k10 + c) * sblk + rest;
+        } else {
+            blk = tile * C + c;
+        }
+        return (size_t)blk << a.log_r;
+    };
+
+    // ---- load tile (lanes run over c first: C*32 B contiguous per row) ----
+    const size_t in_len = (size_t)1 << a.in_log_len;
+    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+        uint32_t c = e & (C - 1), i1 = e >> logC;
+        size_t addr = col_base(c) + ((size_t)i1 << log_s);
+        fe_t x;
+        if (!a.first || addr < in_len) {
+            x = ld_fe(in + addr);
+            if (a.first && a.coset_pre) {
+                uint32_t m3 = (uint32_t)(addr % 3);
+                if (m3) x = Fr::mul(x, a.zeta[m3 - 1]);
+            }
+        } else {
+            x = Fr::zero();
+        }
+        lds_put(data, TILE, e, x);     // LDS index = i1*C + c
+    }
+    __syncthreads();
+
+    // ---- r radix-2 DIF stages in LDS ----
+    for (uint32_t s = 0; s < a.log_r; s++) {
+        const uint32_t lh = a.log_r - 1 - s;            // log2(half), half = rows between partners
+        const bool need_tw = (lh != 0);
+        for (uint32_t b = tid; b < (TILE >> 1); b += NTT_THREADS) {
+            uint32_t c = b & (C - 1), q = b >> logC;
+            uint32_t j = q & ((1u << lh) - 1), blk = q >> lh;
+            uint32_t lo = (((blk << (lh + 1)) + j) << logC) + c, hi = lo + (C << lh);
+            fe_t u = lds_get(data, TILE, lo), v = lds_get(data, TILE, hi);
+            fe_t sum = Fr::add(u, v), dif = Fr::sub(u, v);
+            if (need_tw) dif = Fr::mul(dif, tloc[j << s]);
+            lds_put(data, TILE, lo, sum);
+            lds_put(data, TILE, hi, dif);
+        }
+        __syncthreads();
+    }
+
+    // ---- store: y[k1] sits at row bitrev(k1) ----
+    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+        uint32_t c = e & (C - 1), k1 = e >> logC;
+        uint32_t row = a.log_r ? (__brev(k1) >> (32 - a.log_r)) : 0u;
+        fe_t x = lds_get(data, TILE, (row << logC) + c);
+        if (!a.last) {
+            uint32_t colid = tile * C + c;
+            uint32_t pos = (k1 << log_s) + (colid & (S - 1));        // position inside the block
+            x = Fr::mul(x, ld_fe(a.tw_inter + pos));
+            st_fe(out + (((size_t)(colid >> log_s) << a.log_m) + pos), x);
+        } else {
+            uint32_t blk = (uint32_t)(col_base(c) >> a.log_r);
+            // digits of blk (most significant first) are k_1..k_{P-1}; natural index = sum k_p * (R_1..R_{p-1})
+            size_t oidx = 0;
+            uint32_t rem = blk, lw = a.log_n - a.log_r, shift = 0;
+            for (uint32_t p = 0; p + 1 < a.npass; p++) {
+                lw -= a.log_radix[p];
+                uint32_t kp = rem >> lw;
+                rem &= (1u << lw) - 1;
+                oidx += (size_t)kp << shift;
+                shift += a.log_radix[p];
+            }
+            oidx += (size_t)k1 << shift;
+            if (a.post) x = Fr::mul(x, a.post_c[oidx % 3]);
+            st_fe(out + oidx, x);
+        }
+    }
+}
+
+// out[idx] = w^(e(idx)):  mode 0: e = idx * mult ;  mode 1: idx = k1*S + i2, e = i2 * k1 * mult  (mod 2^log_n)
+__global__ void ntt_twiddle_kernel(fe_t* out, uint32_t count, uint64_t mult, uint32_t log_n, uint32_t log_s,
+                                   int mode, const fe_t* pow2tab) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    uint64_t e;
+    if (mode == 0) e = (uint64_t)idx * mult;
+    else e = (uint64_t)(idx & ((1u << log_s) - 1)) * (uint64_t)(idx >> log_s) * mult;
+    e &= ((uint64_t)1 << log_n) - 1;
+    fe_t acc = Fr::one();
+    for (uint32_t b = 0; b < log_n; b++)
+        if ((e >> b) & 1) acc = Fr::mul(acc, ld_fe(pow2tab + b));
+    st_fe(out + idx, acc);
+}
+
+__global__ void ntt_copy_scale_kernel(const fe_t* in, fe_t* out, size_t n, int post, fe_t c0) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t x = ld_fe(in + i);
+    if (post) x = Fr::mul(x, c0);
+    st_fe(out + i, x);
+}
+
+struct NttPlan {
+    uint32_t log_n = 0;
+    int npass = 0;
+    uint32_t log_radix[4] = {0, 0, 0, 0};
+    fe_t* tw_local[4] = {nullptr, nullptr, nullptr, nullptr};
+    fe_t* tw_inter[4] = {nullptr, nullptr, nullptr, nullptr};
+    fe_t n_inv;
+};
+
+static std::map<std::string, NttPlan*> g_plans;   // guarded by the ctx mutex
+
+static void plan_radices(uint32_t log_n, NttPlan* p) {
+    if (log_n <= NTT_LOG_TILE) {
+        p->npass = 1;
+        p->log_radix[0] = log_n;
+        return;
+    }
+    int np = (int)((log_n + 7) / 8);
+    if (np < 2) np = 2;
+    p->npass = np;
+    uint32_t base = log_n / np, extra = log_n % np;
+    for (int i = 0; i < np; i++) p->log_radix[i] = base + ((uint32_t)i < extra ? 1 : 0);
+}
+
+static int plan_get(Ctx* c, hipStream_t st, uint32_t log_n, const fe_t& omega, NttPlan** out) {
+    std::string key((const char*)&omega, sizeof(fe_t));
+    key.push_back((char)log_n);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) { *out = it->second; return EZKL_OK; }
+    NttPlan* p = new NttPlan();
+    p->log_n = log_n;
+    plan_radices(log_n, p);
+    // host: omega^(2^b), n^-1
+    std::vector<fe_t> pow2(log_n ? log_n : 1);
+    fe_t w = omega;
+    for (uint32_t b = 0; b < log_n; b++) { pow2[b] = w; w = Fr::sqr(w); }
+    p->n_inv = Fr::inv(Fr::from_u64((uint64_t)1 << log_n));
+    fe_t* d_pow2 = nullptr;
+    EZ_HIP(hipMalloc(&d_pow2, sizeof(fe_t) * pow2.size()));
+    EZ_HIP(hipMemcpyAsync(d_pow2, pow2.data(), sizeof(fe_t) * pow2.size(), hipMemcpyHostToDevice, st));
+    uint32_t log_m = log_n;
+    for (int i = 0; i < p->npass; i++) {
+        uint32_t lr = p->log_radix[i];
+        uint32_t half = lr ? (1u << (lr - 1)) : 1u;
+        EZ_HIP(hipMalloc(&p->tw_local[i], sizeof(fe_t) * half));
+        hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(cdiv(half, 256)), dim3(256), 0, st, p->tw_local[i], half,
+                           (uint64_t)1 << (log_n - lr), log_n, 0u, 0, d_pow2);
+        if (i + 1 < p->npass) {
+            uint32_t cnt = 1u << log_m;
+            EZ_HIP(hipMalloc(&p->tw_inter[i], sizeof(fe_t) * (size_t)cnt));
+            hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, st, p->tw_inter[i], cnt,
+                               (uint64_t)1 << (log_n - log_m), log_n, log_m - lr, 1, d_pow2);
+        }
+        log_m -= lr;
+    }
+    EZ_HIP(hipGetLastError());
+    EZ_HIP(hipStreamSynchronize(st));
+    EZ_HIP(hipFree(d_pow2));
+    g_plans[key] = p;
+    *out = p;
+    return EZKL_OK;
+}
+
+// coset_mode: 0 plain; 1 coeff_to_extended (pre-multiply zeta^i, zero-pad from 2^in_log_len);
+//             2 extended_to_coeff (post-multiply zeta^-i; implies inverse_scale)
+int ntt_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
+            size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode) {
+    if (log_n > 28 || in_log_len > log_n || batch == 0) return EZKL_ERR_INVALID;
+    NttPlan* p = nullptr;
+    int rc = plan_get(c, st, log_n, omega, &p);
+    if (rc) return rc;
+    const size_t n = (size_t)1 << log_n;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    fe_t* work = nullptr;
+    if (p->npass > 1) {
+        rc = scratch_reserve(c, batch * n * sizeof(fe_t), (void**)&work);
+        if (rc) return rc;
+    }
+    const fe_t zeta = fr_const(FrConst::ZETA), zeta2 = fr_const(FrConst::ZETA2);
+    uint32_t log_m = log_n;
+    hipEvent_t e0, e1;
+    rc = ev_pair(c, coset_mode ? "coset_ntt" : "ntt", &e0, &e1);
+    if (rc) return rc;
+    EZ_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < p->npass; i++) {
+        PassArgs a;
+        memset(&a, 0, sizeof a);
+        const bool first = (i == 0), last = (i + 1 == p->npass);
+        a.in = first ? in : work;
+        a.in_stride = first ? in_stride : n;
+        a.out = last ? out : work;
+        a.out_stride = last ? out_stride : n;
+        a.tw_local = p->tw_local[i];
+        a.tw_inter = p->tw_inter[i];
+        a.log_n = log_n;
+        a.log_r = p->log_radix[i];
+        a.log_m = log_m;
+        a.log_tile = log_n < NTT_LOG_TILE ? log_n : NTT_LOG_TILE;
+        if (a.log_tile < a.log_r) a.log_tile = a.log_r;
+        a.first = first;
+        a.last = last;
+        a.in_log_len = first ? in_log_len : log_n;
+        a.coset_pre = (first && coset_mode == 1);
+        a.npass = (uint32_t)p->npass;
+        for (int q = 0; q < 4; q++) a.log_radix[q] = p->log_radix[q];
+        a.zeta[0] = zeta;
+        a.zeta[1] = zeta2;
+        if (last) {
+            uint32_t logC = a.log_tile - a.log_r;
+            a.k1_major = (p->npass >= 2 && p->log_radix[0] >= logC) ? 1u : 0u;
+            if (inverse_scale || coset_mode == 2) {
+                a.post = 1;
+                fe_t s = inverse_scale || coset_mode == 2 ? p->n_inv : Fr::one();
+                a.post_c[0] = s;
+                a.post_c[1] = coset_mode == 2 ? Fr::mul(s, zeta2) : s;   // zeta^-1 = zeta^2
+                a.post_c[2] = coset_mode == 2 ? Fr::mul(s, zeta) : s;    // zeta^-2 = zeta
+            }
+        }
+        const uint32_t tiles = 1u << (log_n - a.log_tile);
+        const size_t lds = 32u * ((size_t)1 << a.log_tile) + 32u * (a.log_r ? ((size_t)1 << (a.log_r - 1)) : 1);
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, a);
+        log_m -= a.log_r;
+    }
+    EZ_HIP(hipGetLastError());
+    EZ_HIP(hipEventRecord(e1, st));
+    return EZKL_OK;
+}
+
+}  // namespace ezkl

@@ -1,0 +1,98 @@
+// ubench.hip -- on-device microbenchmarks that give the roofline its compute-side context:
+// Montgomery products/s (the real ceiling of MSM/NTT), v_mad_u64_u32 issue rate, and HBM copy GB/s.
+#include "common.hpp"
+#include <string.h>
+
+namespace ezkl {
+
+__global__ __launch_bounds__(256) void ub_modmul_kernel(fe_t* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe_t a = ld_fe(io + i), b = a, c = Fr::add(a, a), d = c;
+    b.v[0] ^= 5;  b = Fr::reduce_once(b);
+    for (int k = 0; k < iters; k++) {      // two independent chains for ILP
+        a = Fr::mul(a, b);
+        c = Fr::mul(c, d);
+        b = Fr::mul(b, a);
+        d = Fr::mul(d, c);
+    }
+    st_fe(io + i, Fr::add(Fr::add(a, b), Fr::add(c, d)));
+}
+__global__ __launch_bounds__(256) void ub_mad64_kernel(uint64_t* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = io[i];
+    uint64_t a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+    uint32_t m = (uint32_t)x | 1u, q = (uint32_t)(x >> 32) | 3u;
+    for (int k = 0; k < iters; k++) {
+        a0 = mad_wide(m, (uint32_t)a0, a0); a1 = mad_wide(q, (uint32_t)a1, a1);
+        a2 = mad_wide(m, (uint32_t)a2, a2); a3 = mad_wide(q, (uint32_t)a3, a3);
+        a4 = mad_wide(m, (uint32_t)a4, a4); a5 = mad_wide(q, (uint32_t)a5, a5);
+        a6 = mad_wide(m, (uint32_t)a6, a6); a7 = mad_wide(q, (uint32_t)a7, a7);
+    }
+    io[i] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+__global__ __launch_bounds__(256) void ub_dfma_kernel(double* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double x = io[i];
+    double a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+    const double m = 1.0000001, q = 0.9999999;
+    for (int k = 0; k < iters; k++) {
+        a0 = __builtin_fma(a0, m, q); a1 = __builtin_fma(a1, q, m);
+        a2 = __builtin_fma(a2, m, q); a3 = __builtin_fma(a3, q, m);
+        a4 = __builtin_fma(a4, m, q); a5 = __builtin_fma(a5, q, m);
+        a6 = __builtin_fma(a6, m, q); a7 = __builtin_fma(a7, q, m);
+    }
+    io[i] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+__global__ __launch_bounds__(256) void ub_copy_kernel(const uint4* in, uint4* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+int ubench(Ctx* c, const char* which, double* out) {
+    hipStream_t st = c->stream;
+    hipEvent_t e0, e1;
+    int rc = ev_pair(c, "ubench", &e0, &e1);
+    if (rc) return rc;
+    const int blocks = c->num_cus * 16, threads = 256;
+    const size_t nthreads = (size_t)blocks * threads;
+    float ms = 0.f;
+    if (!strcmp(which, "modmul") || !strcmp(which, "mad64") || !strcmp(which, "dfma")) {
+        void* buf = nullptr;
+        EZ_HIP(hipMalloc(&buf, nthreads * 32));
+        EZ_HIP(hipMemsetAsync(buf, 0x11, nthreads * 32, st));
+        const int iters = !strcmp(which, "modmul") ? 256 : 4096;
+        for (int rep = 0; rep < 2; rep++) {     // rep 0 = warm-up
+            EZ_HIP(hipEventRecord(e0, st));
+            if (!strcmp(which, "modmul")) hipLaunchKernelGGL(ub_modmul_kernel, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            else if (!strcmp(which, "mad64")) hipLaunchKernelGGL(ub_mad64_kernel, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
+            else hipLaunchKernelGGL(ub_dfma_kernel, dim3(blocks), dim3(threads), 0, st, (double*)buf, iters);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        EZ_HIP(hipFree(buf));
+        const double per_thread = !strcmp(which, "modmul") ? 4.0 * iters : 8.0 * iters;
+        *out = per_thread * (double)nthreads / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strcmp(which, "copy")) {
+        const size_t bytes = (size_t)1 << 30;
+        void *a = nullptr, *b = nullptr;
+        EZ_HIP(hipMalloc(&a, bytes));
+        EZ_HIP(hipMalloc(&b, bytes));
+        EZ_HIP(hipMemsetAsync(a, 1, bytes, st));
+        for (int rep = 0; rep < 3; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(ub_copy_kernel, dim3(c->num_cus * 8), dim3(256), 0, st, (const uint4*)a, (uint4*)b, bytes / 16);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        EZ_HIP(hipFree(a));
+        EZ_HIP(hipFree(b));
+        *out = 2.0 * (double)bytes / (ms * 1e-3);    // read + write bytes per second
+        return EZKL_OK;
+    }
+    return EZKL_ERR_INVALID;
+}
+
+}  // namespace ezkl

@@ -1,0 +1,50 @@
+"""ctypes loader for libezkl_hip.so.  Fails loudly: no CPU fallback exists (and none may be added)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/ezkl_hip.h declares (tests assert the .so exports all of them)
+SYMBOLS = [
+    "ezkl_hip_init", "ezkl_hip_warmup", "ezkl_hip_device_count", "ezkl_hip_synchronize", "ezkl_hip_strerror",
+    "ezkl_hip_last_hip_error", "ezkl_hip_version", "ezkl_hip_malloc", "ezkl_hip_free", "ezkl_hip_memcpy_h2d",
+    "ezkl_hip_memcpy_d2h", "ezkl_hip_bases_upload", "ezkl_hip_bases_free", "ezkl_hip_bases_len", "ezkl_hip_bases_generate",
+    "ezkl_hip_bases_download", "ezkl_hip_msm_g1",
+    "ezkl_hip_msm_g1_dev", "ezkl_hip_msm_g1_batch", "ezkl_hip_g1_add_affine", "ezkl_hip_ntt", "ezkl_hip_ntt_dev",
+    "ezkl_hip_coset_ntt_batch", "ezkl_hip_coset_ntt_dev", "ezkl_hip_vec_op_dev", "ezkl_hip_vec_scale_dev",
+    "ezkl_hip_divide_by_vanishing_dev", "ezkl_hip_batch_invert_dev", "ezkl_hip_eval_h_dev",
+    "ezkl_hip_last_kernel_ms", "ezkl_hip_ubench",
+]
+
+
+class EzklHipError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        msg = load().ezkl_hip_strerror(code).decode() if _LIB is not None else "library not loaded"
+        super().__init__("%s failed: %d (%s)" % (what, code, msg))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libezkl_hip.so")
+
+
+def load():
+    """Load the in-tree HIP library.  Raises if it has not been built (python __graft_entry__.py)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("libezkl_hip.so missing at %s -- build it with `make -C ezkl_amd/csrc` "
+                               "(there is no CPU fallback)" % path)
+        lib = C.CDLL(path)
+        lib.ezkl_hip_strerror.restype = C.c_char_p
+        lib.ezkl_hip_version.restype = C.c_char_p
+        lib.ezkl_hip_bases_len.restype = C.c_size_t
+        _LIB = lib
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EzklHipError(rc, what)

@@ -1,0 +1,129 @@
+/*
+ * ezkl_hip.h -- C ABI of libezkl_hip.so, the MI355X (gfx950) backend for the `ezkl prove` hot path.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b): the functions below are what the halo2 fork's
+ * `halo2_proofs::icicle` glue asks of the icicle runtime today (gate: cargo feature `gpu-accelerated`,
+ * /root/reference/Cargo.toml:259; runtime gate ENABLE_ICICLE_GPU / ICICLE_SMALL_K,
+ * /root/reference/README.md:106-122; device selection /root/reference/src/execute.rs:84-97).
+ * Plain pointers and sizes only; no C++/torch types; never throws or unwinds across the boundary.
+ *
+ * Representation contract (fixture-verified, SURVEY.md §8(b,c)):
+ *   Fr / Fq element : 32 bytes, 4 x u64 little-endian limbs, Montgomery form (R = 2^256), fully reduced
+ *   G1 affine point : 64 bytes, x || y (Fq), identity encoded as (0,0)  -- the raw-bytes SRS layout
+ * Results are canonical (fully reduced, affine), so equality with the CPU prover is byte equality.
+ *
+ * Threading: every entry point is callable from any host thread (halo2 calls from rayon workers);
+ * the library lazily initialises on first use (the Python bindings never call set_device(),
+ * /root/reference/src/bindings/python.rs:1056-1075) and serialises per device internally.
+ */
+#ifndef EZKL_HIP_H
+#define EZKL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (0 = ok, negative = error; see ezkl_hip_strerror) ---- */
+#define EZKL_OK 0
+#define EZKL_ERR_NO_DEVICE (-1)   /* no HIP device visible: the product path fails loudly, no CPU fallback */
+#define EZKL_ERR_HIP (-2)         /* a HIP runtime call failed; ezkl_hip_last_hip_error() has the code */
+#define EZKL_ERR_INVALID (-3)     /* bad argument (null pointer, size out of range, bad program) */
+#define EZKL_ERR_NOMEM (-4)
+#define EZKL_ERR_UNSUPPORTED (-5)
+
+typedef struct ezkl_bases_s* ezkl_bases_t;     /* device-resident G1 base set (SRS g or g_lagrange) */
+
+/* ---- device management: replaces icicle try_load_and_set_backend_device("CUDA") + warmup(),
+ *      /root/reference/src/execute.rs:88-95 ---- */
+int ezkl_hip_init(int device);                 /* idempotent, thread-safe; device = ordinal (LOCAL_RANK) */
+int ezkl_hip_warmup(void);
+int ezkl_hip_device_count(void);
+int ezkl_hip_synchronize(void);
+const char* ezkl_hip_strerror(int code);
+int ezkl_hip_last_hip_error(void);
+const char* ezkl_hip_version(void);
+
+/* ---- raw device memory for resident columns (library-owned until freed) ---- */
+int ezkl_hip_malloc(void** dptr, size_t bytes);
+int ezkl_hip_free(void* dptr);
+int ezkl_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int ezkl_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- MSM: replaces ParamsKZG::commit / commit_lagrange -> halo2curves::msm (CPU) / icicle msm (GPU);
+ *      in-tree call site /root/reference/src/circuit/modules/polycommit.rs:71 ---- */
+/* bases: n affine points, host pointer, copied to HBM once (SRS load time, src/pfsys/srs.rs:40-47) */
+int ezkl_hip_bases_upload(const void* affine_pts, size_t n, ezkl_bases_t* out_handle);
+int ezkl_hip_bases_free(ezkl_bases_t h);
+size_t ezkl_hip_bases_len(ezkl_bases_t h);
+/* synthetic base set for benchmarks/tests (no public SRS without network, src/pfsys/srs.rs:10-11):
+ * n deterministic curve points by try-and-increment, generated on the device */
+int ezkl_hip_bases_generate(uint64_t seed, size_t first, size_t n, ezkl_bases_t* out_handle);
+int ezkl_hip_bases_download(ezkl_bases_t h, void* out_host /* n x 64 B */);
+/* sum_i scalars[i] * bases[offset + i], i < n.  scalars: n x 32 B Montgomery Fr (host pointer, borrowed).
+ * out_affine: 64 B, caller-allocated, canonical affine ((0,0) if the sum is the identity). */
+int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out_affine);
+/* same with scalars already resident in HBM; `stream` is a hipStream_t or NULL (library stream).
+ * The result is written to host memory and the call returns after the stream has drained. */
+int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n,
+                        void* out_affine, void* stream);
+/* batch of `batch` scalar vectors against the same bases (one commit per advice column) */
+int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t batch, size_t n, void* out_affine);
+/* out = a + b on affine points (host, used to fold per-GPU partial sums after the all-gather) */
+int ezkl_hip_g1_add_affine(const void* a, const void* b, void* out);
+
+/* ---- NTT: replaces halo2curves::fft::best_fft / EvaluationDomain::{ifft, coeff_to_extended,
+ *      extended_to_coeff} (type used in-tree at /root/reference/src/circuit/modules/polycommit.rs:52) ---- */
+/* best_fft(data, omega, log_n): natural order in and out; if `inverse`, additionally scales by 1/n
+ * (omega is then the inverse root, as EvaluationDomain::ifft passes it).  Host buffer, in place. */
+int ezkl_hip_ntt(void* data, uint32_t log_n, const void* omega, int inverse);
+/* device-resident batch: `batch` columns of 2^log_n elements, column b at data_dev + b*stride_elems*32 */
+int ezkl_hip_ntt_dev(void* data_dev, uint32_t log_n, const void* omega, int inverse,
+                     size_t batch, size_t stride_elems, void* stream);
+/* coeff_to_extended (inverse = 0): in[b] has 2^log_n coefficients, out[b] gets 2^log_n_ext evaluations on
+ * the zeta-coset.  extended_to_coeff (inverse = 1): in[b] has 2^log_n_ext evaluations, out[b] receives
+ * 2^log_n_ext coefficients (caller truncates).  Host pointers.  in == out allowed when sizes match. */
+int ezkl_hip_coset_ntt_batch(const void* const* in, void* const* out, size_t batch,
+                             uint32_t log_n, uint32_t log_n_ext, int inverse);
+int ezkl_hip_coset_ntt_dev(const void* in_dev, void* out_dev, size_t batch, size_t in_stride_elems,
+                           size_t out_stride_elems, uint32_t log_n, uint32_t log_n_ext, int inverse, void* stream);
+
+/* ---- element-wise Fr vector ops (icicle vec-ops surface) on device-resident data ---- */
+#define EZKL_VEC_ADD 0
+#define EZKL_VEC_SUB 1
+#define EZKL_VEC_MUL 2
+int ezkl_hip_vec_op_dev(int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);
+int ezkl_hip_vec_scale_dev(const void* a_dev, const void* scalar_host, void* out_dev, size_t n, void* stream);
+/* a[i] *= t[i mod 2^(ext_k-k)], t = 1/((zeta*omega_ext^j)^n - 1): EvaluationDomain::divide_by_vanishing_poly */
+int ezkl_hip_divide_by_vanishing_dev(void* a_dev, uint32_t k, uint32_t ext_k, void* stream);
+/* Montgomery batch inversion (zeros stay zero), in place */
+int ezkl_hip_batch_invert_dev(void* a_dev, size_t n, void* stream);
+
+/* ---- quotient numerator: replaces plonk::evaluation::Evaluator::evaluate_h's row sweep
+ *      (GraphEvaluator::evaluate; icicle "gate_eval" program on the GPU build) ---- */
+/* instruction = 8 x u32: [op, target, s0.kind, s0.idx, s0.rot, s1.kind, s1.idx, s1.rot] */
+enum { EZKL_OP_ADD = 0, EZKL_OP_SUB, EZKL_OP_MUL, EZKL_OP_SQUARE, EZKL_OP_DOUBLE, EZKL_OP_NEGATE,
+       EZKL_OP_STORE, EZKL_OP_HORNER_STEP /* target = target*s1 + s0 */ };
+enum { EZKL_SRC_CONST = 0, EZKL_SRC_INTERMEDIATE, EZKL_SRC_COLUMN, EZKL_SRC_CHALLENGE, EZKL_SRC_PREVIOUS };
+typedef struct {
+    const uint32_t* code;       uint32_t n_instr;  uint32_t n_intermediates;
+    const void* constants;      uint32_t n_constants;     /* n x 32 B Fr, host */
+    const int32_t* rotations;   uint32_t n_rotations;     /* in rows of the 2^k domain */
+    const void* const* columns; uint32_t n_columns;       /* DEVICE pointers, each 2^ext_k x 32 B */
+    const void* challenges;     uint32_t n_challenges;    /* n x 32 B Fr, host */
+    uint32_t k, ext_k;
+} ezkl_program_t;
+/* out_dev[r] = program(row r) with ValueSource::PreviousValue = old out_dev[r]; 2^ext_k rows */
+int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out_dev, void* stream);
+
+/* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
+/* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */
+int ezkl_hip_last_kernel_ms(const char* which, float* out_ms);
+/* microbenchmarks: which = "modmul" (Montgomery products/s), "mad64" (v_mad_u64_u32/s),
+ * "copy" (HBM float4 copy bytes/s); result in *out (per second) */
+int ezkl_hip_ubench(const char* which, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -141,3 +141,8 @@ def eval_program(code, n_intermediates, constants, rotations, columns, challenge
 
 def num_threads():
     return int(lib.oracle_num_threads())
+
+
+def gen_bases(seed, n, first=0):
+    o = np.empty((n, 8), np.uint64)
+    lib.oracle_gen_bases(C.c_uint64(seed), C.c_size_t(first), C.c_size_t(n), _ptr(o)); return o

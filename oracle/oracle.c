@@ -448,3 +448,29 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ synthetic inputs -------- */
+/* Deterministic G1 points for tests/bench (try-and-increment on y^2 = x^3 + 3).
+ * x0 = 4 splitmix64 words keyed by (seed, i), masked to 254 bits, reduced once, read as a Montgomery
+ * residue; x += 1 until x^3 + 3 is a square; y = rhs^((q+1)/4), negated if its low Montgomery limb is odd.
+ * The HIP library has the same generator (ezkl_hip_gen_bases) so the two can be byte-compared. */
+static inline uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31);
+}
+void oracle_gen_bases(uint64_t seed, size_t first, size_t n, g1a *out) {
+    static const uint64_t sqrt_e[4] = BN64_FQ_SQRT_EXP_INIT;
+#pragma omp parallel for schedule(static)
+    for (size_t k = 0; k < n; k++) {
+        uint64_t st = seed ^ ((uint64_t)(first + k) * 0xd1342543de82ef95ull);
+        fe x; for (int j = 0; j < 4; j++) x.v[j] = splitmix64(&st);
+        x.v[3] &= 0x3fffffffffffffffull;
+        if (f_geq(&x, &FQ.mod)) sub4(&x, &x, &FQ.mod);
+        for (;;) {
+            fe rhs, y, yy; f_sqr(&rhs, &x, &FQ); f_mul(&rhs, &rhs, &x, &FQ); f_add(&rhs, &rhs, &FQ_B3, &FQ);
+            f_pow(&y, &rhs, sqrt_e, &FQ); f_sqr(&yy, &y, &FQ);
+            if (f_eq(&yy, &rhs) && !f_is_zero(&y)) { if (y.v[0] & 1) f_neg(&y, &y, &FQ); out[k].x = x; out[k].y = y; break; }
+            f_add(&x, &x, &FQ.one, &FQ);
+        }
+    }
+}

@@ -1,0 +1,72 @@
+"""GPU parity: vec-ops, batch inversion and the quotient-sweep program interpreter vs the oracle."""
+import numpy as np
+import pytest
+from conftest import R, fe_from_int, rand_fr
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 1 << 16])
+def test_vec_ops(hip, n):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n)
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    da, db, do = B.DeviceBuffer.from_numpy(a), B.DeviceBuffer.from_numpy(b), B.DeviceBuffer(n * 32)
+    for op in ("add", "sub", "mul"):
+        B.vec_op(op, da.ptr, db.ptr, do.ptr, n)
+        assert (do.to_numpy(shape=(n, 4)) == ob.vec_op(op, a, b)).all()
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 1000, 1 << 15])
+def test_batch_invert(hip, n):
+    import ctypes as C
+    from ezkl_amd import backend as B, lib as L
+    rng = np.random.default_rng(n)
+    a = rand_fr(rng, n)
+    a[::7] = 0
+    d = B.DeviceBuffer.from_numpy(a)
+    L.check(L.load().ezkl_hip_batch_invert_dev(C.c_void_p(d.ptr), C.c_size_t(n), C.c_void_p(None)), "batch_invert")
+    assert (d.to_numpy(shape=(n, 4)) == ob.batch_invert(a)).all()
+
+
+def _gate_program(B, k, ek):
+    """a small ezkl-like gate set: sel*(out - a*b) (chip.rs:344-393), a rotation -1 accumulator
+    (chip.rs:352-425), folded with y by Horner exactly as evaluate_h does"""
+    prog = B.GraphProgram(k, ek)
+    sel, a, b, out = prog.column(0), prog.column(1), prog.column(2), prog.column(3)
+    prev_out = prog.column(3, -1)
+    nxt = prog.column(1, 1)
+    g1 = prog.calc("mul", sel, prog.calc("sub", out, prog.calc("mul", a, b)))
+    acc = prog.calc("add", prev_out, prog.calc("mul", a, b))
+    g2 = prog.calc("mul", sel, prog.calc("sub", out, acc))
+    g3 = prog.calc("mul", prog.calc("square", nxt), prog.constant(fe_from_int(R - 2)))
+    g4 = prog.calc("negate", prog.calc("double", prog.calc("add", g3, prog.challenge(0))))
+    prog.horner(prog.previous(), [g1, g2, g3, g4], prog.challenge(1))
+    return prog
+
+
+@pytest.mark.parametrize("k,ek", [(3, 5), (8, 10), (12, 15)])
+def test_eval_h_program(hip, k, ek):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(k)
+    ne = 1 << ek
+    cols = [rand_fr(rng, ne) for _ in range(4)]
+    chal = rand_fr(rng, 2)
+    prev = rand_fr(rng, ne)
+    prog = _gate_program(B, k, ek)
+    code, consts, rots = prog.arrays()
+    want = ob.eval_program(code, prog.n_intermediates, consts, rots, cols, chal, k, ek, previous=prev)
+    dcols = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    dout = B.DeviceBuffer.from_numpy(prev)
+    prog.evaluate_h([d.ptr for d in dcols], chal, dout.ptr)
+    assert (dout.to_numpy(shape=(ne, 4)) == want).all()
+
+
+def test_eval_h_rejects_bad_program(hip):
+    from ezkl_amd import backend as B
+    prog = B.GraphProgram(3, 5)
+    prog.calc("add", prog.column(5), prog.column(0))      # column index out of range
+    d = B.DeviceBuffer(32 << 5)
+    with pytest.raises(hip.EzklHipError):
+        prog.evaluate_h([d.ptr], np.zeros((1, 4), np.uint64), d.ptr)

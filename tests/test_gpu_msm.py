@@ -1,0 +1,101 @@
+"""GPU parity: HIP fixed-base Pippenger MSM (through the C ABI) vs the oracle and the golden SRS."""
+import numpy as np
+import pytest
+from conftest import R, Q, SEED, fe_from_int, rand_fr, witness_like
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gen_bases_matches_oracle(hip):
+    from ezkl_amd import backend as B
+    b = B.Bases.generate(SEED, 5000)
+    got = b.download()
+    assert (got == ob.gen_bases(SEED, 5000)).all()
+    b.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 100, 1000, 4096, 1 << 14, 1 << 16])
+def test_uniform_scalars_match_oracle(hip, n):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n)
+    pts = ob.gen_bases(SEED, n)
+    bases = B.Bases(pts)
+    s = rand_fr(rng, n)
+    assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all()
+    bases.free()
+
+
+def test_golden_srs_commitments(hip, golden_srs, golden_pk):
+    """reference fixture (k=6 SRS): commit_lagrange(v) == commit(iNTT(v)); sum(g_lagrange) == g[0]"""
+    params = hip.ParamsKZG.read(golden_srs["buf"])
+    assert params.k == 6
+    ones = np.tile(fe_from_int(1), (64, 1))
+    assert (params.commit_lagrange(ones) == golden_srs["g"][0]).all()
+    for v, p in zip(golden_pk["fixed_values"], golden_pk["fixed_polys"]):
+        a = params.commit_lagrange(v)
+        assert (a == params.commit(p)).all()
+        assert (a == ob.msm(v, golden_srs["g_lagrange"])).all()
+    params.free()
+
+
+def test_edge_cases(hip):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(11)
+    n = 512
+    pts = ob.gen_bases(SEED, n)
+    pts[30] = 0                                   # identity base
+    pts[21] = pts[20]                             # duplicate point: P + P inside a bucket
+    pts[41] = pts[40]
+    pts[41, 4:] = np.frombuffer(((Q - int.from_bytes(pts[40, 4:].tobytes(), "little")) % Q).to_bytes(32, "little"), np.uint64)
+    bases = B.Bases(pts)
+    s = rand_fr(rng, n)
+    s[:8] = 0
+    s[8] = fe_from_int(R - 1); s[9] = fe_from_int(1); s[10] = fe_from_int((R - 1) // 2); s[11] = fe_from_int((R + 1) // 2)
+    s[20] = s[21] = fe_from_int(12345)            # same scalar, same point -> doubling path
+    s[40] = s[41] = fe_from_int(777)              # P and -P with the same scalar -> inverse path
+    assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all()
+    assert (B.msm_g1(bases, np.zeros((n, 4), np.uint64)) == 0).all()             # all-zero scalars -> identity
+    same = np.tile(fe_from_int(3), (n, 1))                                        # every point in ONE bucket (heavy path)
+    assert (B.msm_g1(bases, same) == ob.msm(same, pts)).all()
+    short = s[:100]                                                               # ragged: fewer scalars than bases
+    assert (B.msm_g1(bases, short) == ob.msm(short, pts[:100])).all()
+    bases.free()
+
+
+def test_witness_like_scalars(hip):
+    """skewed distribution of real witnesses (src/fieldutils.rs:9-17): small signed values, zeros"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(12)
+    n = 1 << 15
+    pts = ob.gen_bases(SEED, n)
+    bases = B.Bases(pts)
+    s = witness_like(rng, n)
+    assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all()
+    bases.free()
+
+
+def test_full_size_2_20(hip):
+    """BASELINE configs[1]: 2^20 points.  Oracle check on the full size (a few CPU-seconds) + linearity."""
+    from ezkl_amd import backend as B
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    bases = B.Bases.generate(SEED, n)
+    pts = bases.download()
+    assert all(ob.g1_on_curve(p) for p in pts[:: 1 << 12])
+    s1, s2 = rand_fr(rng, n), rand_fr(rng, n)
+    a = B.msm_g1(bases, s1)
+    assert (a == ob.msm(s1, pts)).all()
+    b = B.msm_g1(bases, s2)
+    # linearity: msm(s1 + s2) == msm(s1) + msm(s2)
+    b1, b2 = B.DeviceBuffer.from_numpy(s1), B.DeviceBuffer.from_numpy(s2)
+    B.vec_op("add", b1.ptr, b2.ptr, b1.ptr, n)
+    c = B.msm_g1_dev(bases, b1.ptr, n)
+    assert (c == B.g1_add_affine(a, b)).all()
+    # sharded evaluation (the multi-GPU decomposition) gives the same point
+    half = n // 2
+    p0 = B.msm_g1_dev(bases, b1.ptr, half, offset=0)
+    b1hi = B.DeviceBuffer.from_numpy(b1.to_numpy(shape=(n, 4))[half:])
+    p1 = B.msm_g1_dev(bases, b1hi.ptr, half, offset=half)
+    assert (B.g1_add_affine(p0, p1) == c).all()
+    bases.free()

@@ -1,0 +1,106 @@
+"""GPU parity: HIP NTT (through the C ABI) vs the oracle and the reference's golden pk.key vectors."""
+import numpy as np
+import pytest
+from conftest import R, SEED, fe_from_int, fe_to_int, rand_fr
+from oracle import binding as ob, pyref as pr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k", list(range(0, 15)) + [16, 17, 18])
+def test_forward_matches_oracle(hip, k):
+    rng = np.random.default_rng(100 + k)
+    a = rand_fr(rng, 1 << k)
+    w = ob.omega(k)
+    got = hip.ntt(a, k, w)
+    assert (got == ob.fft(a, k, w)).all()
+
+
+@pytest.mark.parametrize("k", [1, 4, 9, 12, 13, 17])
+def test_inverse_scaled_matches_oracle(hip, k):
+    rng = np.random.default_rng(200 + k)
+    a = rand_fr(rng, 1 << k)
+    d = hip.EvaluationDomain(2, k)
+    got = d.lagrange_to_coeff(a)
+    assert (got == ob.lagrange_to_coeff(a, k)).all()
+    assert (d.coeff_to_lagrange(got) == a).all()
+
+
+def test_edge_inputs(hip):
+    k = 10
+    w = ob.omega(k)
+    z = np.zeros((1 << k, 4), np.uint64)
+    assert (hip.ntt(z, k, w) == 0).all()
+    one = np.zeros((1 << k, 4), np.uint64); one[0] = fe_from_int(1)
+    assert (hip.ntt(one, k, w) == np.tile(fe_from_int(1), (1 << k, 1))).all()       # delta -> all ones
+    top = np.tile(fe_from_int(R - 1), (1 << k, 1))                                    # maximum residues
+    assert (hip.ntt(top, k, w) == ob.fft(top, k, w)).all()
+
+
+def test_golden_pk_vectors(hip, golden_pk):
+    """reference fixture: fixed_polys == iNTT(fixed_values), fixed_cosets == coeff_to_extended(polys)"""
+    d = hip.EvaluationDomain(9, 6)      # degree 9 -> ext_k = 9 as in tests/assets/pk.key
+    assert d.ext_k == 9
+    for nv, npoly, nc in (("fixed_values", "fixed_polys", "fixed_cosets"), ("permutations", "perm_polys", "perm_cosets")):
+        for v, p, c in zip(golden_pk[nv], golden_pk[npoly], golden_pk[nc]):
+            assert (d.lagrange_to_coeff(v) == p).all()
+            assert (d.coeff_to_extended(p) == c).all()
+            back = d.extended_to_coeff(c)
+            assert (back[:64] == p).all() and (back[64:] == 0).all()
+    one = fe_from_int(1)
+    e0 = np.zeros((64, 4), np.uint64); e0[0] = one
+    assert (d.coeff_to_extended(d.lagrange_to_coeff(e0)) == golden_pk["l0"]).all()
+
+
+@pytest.mark.parametrize("k,ek", [(3, 5), (8, 10), (10, 13), (12, 14)])
+def test_coset_and_vanishing_match_oracle(hip, k, ek):
+    rng = np.random.default_rng(300 + k)
+    d = hip.EvaluationDomain((1 << (ek - k)) + 1, k)
+    assert d.ext_k == ek
+    p = rand_fr(rng, 1 << k)
+    ext = d.coeff_to_extended(p)
+    assert (ext == ob.coeff_to_extended(p, k, ek)).all()
+    assert (d.extended_to_coeff(ext) == ob.extended_to_coeff(ext, ek)).all()
+    assert (d.divide_by_vanishing_poly(ext) == ob.divide_by_vanishing(ext, k, ek)).all()
+
+
+def test_batch_device_resident(hip):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(7)
+    k, batch = 11, 5
+    a = rand_fr(rng, batch << k).reshape(batch, 1 << k, 4)
+    w = ob.omega(k)
+    buf = B.DeviceBuffer.from_numpy(a)
+    B.ntt_dev(buf.ptr, k, w, batch=batch)
+    got = buf.to_numpy(shape=a.shape)
+    for b in range(batch):
+        assert (got[b] == ob.fft(a[b], k, w)).all()
+
+
+def test_full_size_2_22_properties(hip):
+    """BASELINE configs[1] size: round trip, linearity and a spot check against the defining sum"""
+    from ezkl_amd import backend as B
+    k = 22
+    n = 1 << k
+    rng = np.random.default_rng(22)
+    a, b = rand_fr(rng, n), rand_fr(rng, n)
+    d = hip.EvaluationDomain(2, k)
+    fa = hip.ntt(a, k, d.omega)
+    assert (hip.ntt(fa, k, d.omega_inv, inverse=True) == a).all()              # iNTT(NTT(a)) == a
+    fb = hip.ntt(b, k, d.omega)
+    bufa, bufb = B.DeviceBuffer.from_numpy(a), B.DeviceBuffer.from_numpy(b)
+    B.vec_op("add", bufa.ptr, bufb.ptr, bufa.ptr, n)
+    s = bufa.to_numpy(shape=(n, 4))
+    fs = hip.ntt(s, k, d.omega)
+    bufa2, bufb2 = B.DeviceBuffer.from_numpy(fa), B.DeviceBuffer.from_numpy(fb)
+    B.vec_op("add", bufa2.ptr, bufb2.ptr, bufa2.ptr, n)
+    assert (fs == bufa2.to_numpy(shape=(n, 4))).all()                           # NTT(a+b) == NTT(a)+NTT(b)
+    # X[0] = sum a_i ; X[n/2] = sum (-1)^i a_i : checked with exact integer arithmetic on the host
+    ints = [fe_to_int(x) for x in a[: 1 << 12]]   # spot check uses a short-prefix input
+    short = np.zeros((n, 4), np.uint64); short[: 1 << 12] = a[: 1 << 12]
+    f = hip.ntt(short, k, d.omega)
+    assert fe_to_int(f[0]) == sum(ints) % R
+    assert fe_to_int(f[n // 2]) == sum(v if i % 2 == 0 else -v for i, v in enumerate(ints)) % R
+    w = pr.omega(k)
+    j = 123457
+    assert fe_to_int(f[j]) == sum(v * pow(w, i * j, R) for i, v in enumerate(ints)) % R
