@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json configs[1]: 2^20-point BN254 G1 MSM + 2^22 Fr NTT microbench per MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+one 2^20-point MSM (uniform scalars) against this rank's slice of a fixed base set -- the metric's
+`value` is whole-job MSM points/s.  The 2^22 NTT is timed in a second region of the same K steps and
+reported under "extra" (elems/s).  Multi-GPU (weak scaling): every rank owns its own
+2^20-point slice; each step ends with an RCCL all_gather of the 64-byte partial points and a host fold,
+the only exchange the path has.  NTT columns are independent per rank (no collective).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LOG_MSM = 20
+LOG_NTT = 22
+SEED = 0x657a6b6c
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+MSM_BYTES_PER_POINT = 96       # 64 B base + 32 B scalar, each read once
+NTT_BYTES_PER_ELEM = 64        # read once + write once
+
+
+def rand_fr(rng, n):
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 61) - 1)     # 253 random bits < r: uniform Montgomery residues
+    return a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import ezkl_amd
+    from ezkl_amd import backend as B
+    from ezkl_amd import dist as D
+    ezkl_amd.init(local_rank)
+
+    n_msm, n_ntt = 1 << LOG_MSM, 1 << LOG_NTT
+    rng = np.random.default_rng(SEED + rank)
+    # ---- synthetic inputs, resident in HBM before any timed region ----
+    bases = B.Bases.generate(SEED, n_msm, first=rank * n_msm)       # this rank's slice of the base set
+    scalars = B.DeviceBuffer.from_numpy(rand_fr(rng, n_msm))
+    dom = ezkl_amd.EvaluationDomain(2, LOG_NTT)
+    col = B.DeviceBuffer.from_numpy(rand_fr(rng, n_ntt))
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        ezkl_amd.backend.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def msm_step():
+        part = B.msm_g1_dev(bases, scalars.ptr, n_msm)
+        return D.fold_partials(part, dist, dev)
+
+    def ntt_step():
+        B.ntt_dev(col.ptr, LOG_NTT, dom.omega)
+
+    acc_ms, msm_ms = [], []
+    for _ in range(args.warmup):
+        msm_step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = msm_step()
+        acc_ms.append(B.last_kernel_ms("msm_accumulate"))
+        msm_ms.append(B.last_kernel_ms("msm"))
+    barrier_sync()
+    t_msm = time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        ntt_step()
+    barrier_sync()
+    ntt_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ntt_step()
+        ntt_ms.append(B.last_kernel_ms("ntt"))
+    barrier_sync()
+    t_ntt = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([t_msm, t_ntt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_msm, t_ntt = float(t[0]), float(t[1])
+
+    if rank == 0:
+        modmul = B.ubench("modmul")
+        copy_bps = B.ubench("copy")
+        acc_avg_ms = float(np.mean(acc_ms))
+        achieved = MSM_BYTES_PER_POINT * n_msm / (acc_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("msm_accumulate_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "BN254 G1 MSM pts/s (2^20 points per GPU; NTT 2^22 elems/s in extra)",
+            "value": world * n_msm * args.steps / t_msm,
+            "unit": "pts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t_msm / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (254-bit modular integer, Montgomery)",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: standalone 2^20-point BN254 G1 MSM (uniform scalars, try-and-increment bases) "
+                                   "+ 2^22 scalar-field NTT per GPU", "msm_points_per_gpu": n_msm, "ntt_elems_per_gpu": n_ntt,
+                       "parallelism": "points sharded across %d rank(s); all_gather of 64-B partials + host fold" % world},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": acc_avg_ms,
+                         "note": "integer-VALU bound, not HBM bound: see extra.modmul_per_s (DESIGN.md §roofline)"},
+            "extra": {"msm_device_ms": float(np.mean(msm_ms)), "ntt_elems_per_s": world * n_ntt * args.steps / t_ntt,
+                      "ntt_ms_per_step": t_ntt / args.steps * 1e3, "ntt_device_ms": float(np.mean(ntt_ms)),
+                      "ntt_achieved_GBs": NTT_BYTES_PER_ELEM * n_ntt / (float(np.mean(ntt_ms)) * 1e-3) / 1e9,
+                      "modmul_per_s": modmul, "hbm_copy_GBs": copy_bps / 1e9,
+                      "result_x_limb0": int(result[0])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(bases, scalars, n, gpu_result):
+    """The C oracle (oracle/oracle.c: the CPU restatement of halo2curves' Pippenger, NOT halo2curves) timed on
+    the host cores of this box on the same 2^20-point input; also the last parity check of the run."""
+    from oracle import binding as ob
+    pts = bases.download()
+    sc = scalars.to_numpy(shape=(n, 4))
+    t0 = time.perf_counter()
+    want = ob.msm(sc, pts)
+    dt = time.perf_counter() - t0
+    if not (want == gpu_result).all():
+        raise SystemExit("bench: GPU MSM result differs from the CPU oracle")
+    return {"value": n / dt, "unit": "pts/s", "cores": ob.num_threads(), "kind": "port",
+            "sample": "the full 2^20-point MSM of the timed workload, once (%.2f s of CPU wall)" % dt,
+            "matches_gpu_result": True}
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,10 @@ def init(device=-1):
     _l.check(_l.load().ezkl_hip_init(C.c_int(device)), "ezkl_hip_init")
 
 
+def synchronize():
+    _l.check(_l.load().ezkl_hip_synchronize(), "ezkl_hip_synchronize")
+
+
 def device_count():
     return int(_l.load().ezkl_hip_device_count())
 

@@ -299,14 +299,18 @@ int ezkl_hip_coset_ntt_batch(const void* const* in, void* const* out, size_t bat
 int ezkl_hip_vec_op_dev(int op, const void* a, const void* b, void* o, size_t n, void* stream) {
     if (!a || !b || !o || op < 0 || op > 2) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    return vec_op(c, pick_stream(c, stream), op, (const fe_t*)a, (const fe_t*)b, (fe_t*)o, n);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = vec_op(c, st, op, (const fe_t*)a, (const fe_t*)b, (fe_t*)o, n);
+    return rc ? rc : finish(c, st, stream);
 }
 int ezkl_hip_vec_scale_dev(const void* a, const void* s, void* o, size_t n, void* stream) {
     if (!a || !s || !o) return EZKL_ERR_INVALID;
     EZ_CTX(c);
     fe_t sc;
     memcpy(&sc, s, 32);
-    return vec_scale(c, pick_stream(c, stream), (const fe_t*)a, sc, (fe_t*)o, n);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = vec_scale(c, st, (const fe_t*)a, sc, (fe_t*)o, n);
+    return rc ? rc : finish(c, st, stream);
 }
 int ezkl_hip_divide_by_vanishing_dev(void* a, uint32_t k, uint32_t ext_k, void* stream) {
     if (!a || k > ext_k || ext_k > 28) return EZKL_ERR_INVALID;
