@@ -21,6 +21,7 @@ namespace ezkl {
 struct alignas(16) fe_t {
     uint32_t v[8];
 };
+#define EZKL_FE_DEFINED 1
 
 struct FqP {
     static constexpr uint32_t MOD[8] = BN32_FQ_MOD_INIT;
@@ -36,6 +37,18 @@ struct FrP {
 };
 
 EZ_HD uint64_t mad_wide(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// carry chains: lower to v_add_co_u32 / v_addc_co_u32 / v_subb_co_u32 on gfx950
+EZ_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& c) {
+    uint32_t co, r = __builtin_addc(a, b, c, &co);
+    c = co;
+    return r;
+}
+EZ_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& br) {
+    uint32_t bo, r = __builtin_subc(a, b, br, &bo);
+    br = bo;
+    return r;
+}
+template <class P> __device__ __forceinline__ fe_t mont_mul_asm(const fe_t& a, const fe_t& b);
 
 template <class P>
 struct Field {
@@ -72,13 +85,9 @@ struct Field {
     // r = a - MOD if a >= MOD else a  (a < 2*MOD)
     EZ_HD static fe_t reduce_once(const fe_t& a) {
         fe_t d;
-        uint64_t br = 0;
+        uint32_t br = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t t = (uint64_t)a.v[i] - P::MOD[i] - br;
-            d.v[i] = (uint32_t)t;
-            br = (t >> 63) & 1;
-        }
+        for (int i = 0; i < 8; i++) d.v[i] = subb32(a.v[i], P::MOD[i], br);
         fe_t r;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
@@ -86,44 +95,29 @@ struct Field {
     }
     EZ_HD static fe_t add(const fe_t& a, const fe_t& b) {
         fe_t s;
-        uint64_t c = 0;
+        uint32_t c = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)a.v[i] + b.v[i];
-            s.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
+        for (int i = 0; i < 8; i++) s.v[i] = addc32(a.v[i], b.v[i], c);
         return reduce_once(s);   // a + b < 2p < 2^255, no carry out of limb 7
     }
     EZ_HD static fe_t sub(const fe_t& a, const fe_t& b) {
         fe_t d;
-        uint64_t br = 0;
+        uint32_t br = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
-            d.v[i] = (uint32_t)t;
-            br = (t >> 63) & 1;
-        }
-        uint32_t mask = (uint32_t)0 - (uint32_t)br;
-        uint64_t c = 0;
+        for (int i = 0; i < 8; i++) d.v[i] = subb32(a.v[i], b.v[i], br);
+        const uint32_t mask = (uint32_t)0 - br;
+        uint32_t c = 0;
         fe_t r;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)d.v[i] + (P::MOD[i] & mask);
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
+        for (int i = 0; i < 8; i++) r.v[i] = addc32(d.v[i], P::MOD[i] & mask, c);
         return r;
     }
     EZ_HD static fe_t neg(const fe_t& a) {
         fe_t d;
-        uint64_t br = 0;
-        uint32_t nz = 0;
+        uint32_t br = 0, nz = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            uint64_t t = (uint64_t)P::MOD[i] - a.v[i] - br;
-            d.v[i] = (uint32_t)t;
-            br = (t >> 63) & 1;
+            d.v[i] = subb32(P::MOD[i], a.v[i], br);
             nz |= a.v[i];
         }
         fe_t r;
@@ -162,6 +156,13 @@ struct Field {
         return r;
     }
     EZ_HD static fe_t mul_inl(const fe_t& a, const fe_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mont_mul_asm<P>(a, b);      // montmul_gen.hpp: v_mad_u64_u32 + v_addc_co_u32 columns
+#else
+        return mul_portable(a, b);
+#endif
+    }
+    EZ_HD static fe_t mul_portable(const fe_t& a, const fe_t& b) {
         uint32_t t[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) t[i] = 0;
@@ -229,6 +230,9 @@ struct Field {
     }
 };
 
+}  // namespace ezkl
+namespace ezkl {
+#include "montmul_gen.hpp"
 using Fr = Field<FrP>;
 using Fq = Field<FqP>;
 

@@ -5,16 +5,22 @@
 
 namespace ezkl {
 
+template <int VARIANT>   // 0: shipped path (noinline call of the asm product), 1: portable C product, 2: asm inlined
 __global__ __launch_bounds__(256) void ub_modmul_kernel(fe_t* io, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     fe_t a = ld_fe(io + i), b = a, c = Fr::add(a, a), d = c;
     b.v[0] ^= 5;  b = Fr::reduce_once(b);
     for (int k = 0; k < iters; k++) {      // two independent chains for ILP
-        a = Fr::mul(a, b);
-        c = Fr::mul(c, d);
-        b = Fr::mul(b, a);
-        d = Fr::mul(d, c);
+        if (VARIANT == 0) { a = Fr::mul(a, b); c = Fr::mul(c, d); b = Fr::mul(b, a); d = Fr::mul(d, c); }
+        else if (VARIANT == 1) { a = Fr::mul_portable(a, b); c = Fr::mul_portable(c, d); b = Fr::mul_portable(b, a); d = Fr::mul_portable(d, c); }
+        else { a = Fr::mul_inl(a, b); c = Fr::mul_inl(c, d); b = Fr::mul_inl(b, a); d = Fr::mul_inl(d, c); }
     }
+    st_fe(io + i, Fr::add(Fr::add(a, b), Fr::add(c, d)));
+}
+__global__ __launch_bounds__(256) void ub_addsub_kernel(fe_t* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe_t a = ld_fe(io + i), b = Fr::reduce_once(a), c = Fr::add(b, b), d = c;
+    for (int k = 0; k < iters; k++) { b = Fr::add(b, c); c = Fr::sub(c, d); d = Fr::add(d, b); c = Fr::sub(c, b); }
     st_fe(io + i, Fr::add(Fr::add(a, b), Fr::add(c, d)));
 }
 __global__ __launch_bounds__(256) void ub_mad64_kernel(uint64_t* io, int iters) {
@@ -55,14 +61,18 @@ int ubench(Ctx* c, const char* which, double* out) {
     const int blocks = c->num_cus * 16, threads = 256;
     const size_t nthreads = (size_t)blocks * threads;
     float ms = 0.f;
-    if (!strcmp(which, "modmul") || !strcmp(which, "mad64") || !strcmp(which, "dfma")) {
+    const bool is_mm = !strncmp(which, "modmul", 6);
+    if (is_mm || !strcmp(which, "mad64") || !strcmp(which, "dfma") || !strcmp(which, "addsub")) {
         void* buf = nullptr;
         EZ_HIP(hipMalloc(&buf, nthreads * 32));
         EZ_HIP(hipMemsetAsync(buf, 0x11, nthreads * 32, st));
-        const int iters = !strcmp(which, "modmul") ? 256 : 4096;
+        const int iters = is_mm ? 256 : 4096;
         for (int rep = 0; rep < 2; rep++) {     // rep 0 = warm-up
             EZ_HIP(hipEventRecord(e0, st));
-            if (!strcmp(which, "modmul")) hipLaunchKernelGGL(ub_modmul_kernel, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            if (!strcmp(which, "modmul")) hipLaunchKernelGGL(ub_modmul_kernel<0>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            else if (!strcmp(which, "modmul_c")) hipLaunchKernelGGL(ub_modmul_kernel<1>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            else if (!strcmp(which, "modmul_inl")) hipLaunchKernelGGL(ub_modmul_kernel<2>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            else if (!strcmp(which, "addsub")) hipLaunchKernelGGL(ub_addsub_kernel, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
             else if (!strcmp(which, "mad64")) hipLaunchKernelGGL(ub_mad64_kernel, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
             else hipLaunchKernelGGL(ub_dfma_kernel, dim3(blocks), dim3(threads), 0, st, (double*)buf, iters);
             EZ_HIP(hipEventRecord(e1, st));
@@ -70,7 +80,7 @@ int ubench(Ctx* c, const char* which, double* out) {
             EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
         }
         EZ_HIP(hipFree(buf));
-        const double per_thread = !strcmp(which, "modmul") ? 4.0 * iters : 8.0 * iters;
+        const double per_thread = (is_mm || !strcmp(which, "addsub")) ? 4.0 * iters : 8.0 * iters;
         *out = per_thread * (double)nthreads / (ms * 1e-3);
         return EZKL_OK;
     }

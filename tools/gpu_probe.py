@@ -7,7 +7,7 @@ import ezkl_amd
 from ezkl_amd import backend as B
 ezkl_amd.init(0)
 out = {}
-for w in ("modmul", "mad64", "dfma", "copy"):
+for w in ("modmul", "modmul_c", "modmul_inl", "addsub", "mad64", "dfma", "copy"):
     out[w] = B.ubench(w)
 print(json.dumps(out))
 rng = np.random.default_rng(1)
