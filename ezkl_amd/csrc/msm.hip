@@ -21,14 +21,14 @@
 // Order of additions differs from the CPU Pippenger, the group element (and its canonical affine bytes) does not.
 #include "common.hpp"
 #include "curve.hpp"
-#include <hipcub/hipcub.hpp>
+#include "host64.hpp"
 #include <string.h>
 
 namespace ezkl {
 
-static constexpr uint32_t MSM_SKIP = 0xffffffffu;
-static constexpr uint32_t MSM_HEAVY = 192;       // runs longer than this go to the workgroup kernel
-static constexpr uint32_t MSM_CHUNK = 8;         // buckets per running-sum chunk in the reduce phase
+static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
+static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets spanning more lanes than this are folded by a workgroup
+static constexpr uint32_t MSM_DIGIT_E = 16;         // serial elements per lane in the digit-sum reduction
 
 struct MsmTable {
     g1a_t* tab = nullptr;    // W x n affine
@@ -58,26 +58,14 @@ __global__ __launch_bounds__(256) void msm_precompute_kernel(const g1a_t* prev, 
     st_g1a(next + i, g1x_to_affine(a));
 }
 
-// ---- digits ------------------------------------------------------------------------------------
-// half = (r-1)/2 as plain integer limbs
-__device__ __forceinline__ bool gt_half_r(const fe_t& s) {
-    // r = FrP::MOD ; compare s > (r-1)/2  <=>  2s > r - 1  <=> 2s >= r
-    uint64_t c = 0;
-    uint32_t d[9];
+// ---- signed-digit decomposition ------------------------------------------------------------------
+__device__ __forceinline__ bool gt_half_r(const fe_t& s) {      // s > (r-1)/2  <=>  2s >= r
+    uint32_t d[8], c = 0, br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)s.v[i] * 2;
-        d[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    d[8] = (uint32_t)c;
-    uint64_t br = 0;
+    for (int i = 0; i < 8; i++) d[i] = addc32(s.v[i], s.v[i], c);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)d[i] - FrP::MOD[i] - br;
-        br = (t >> 63) & 1;
-    }
-    return d[8] != 0 || br == 0;
+    for (int i = 0; i < 8; i++) (void)subb32(d[i], FrP::MOD[i], br);
+    return c != 0 || br == 0;
 }
 __device__ __forceinline__ uint32_t get_bits(const fe_t& s, uint32_t lo, uint32_t c) {
     if (lo >= 256) return 0;
@@ -86,141 +74,301 @@ __device__ __forceinline__ uint32_t get_bits(const fe_t& s, uint32_t lo, uint32_
     if (w + 1 < 8) x |= (uint64_t)s.v[w + 1] << 32;
     return (uint32_t)((x >> sh) & (((uint64_t)1 << c) - 1));
 }
-
-__global__ __launch_bounds__(256) void msm_digits_kernel(const fe_t* scalars, size_t n, uint32_t c, uint32_t W,
-                                                         uint32_t* keys, uint32_t* hist) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// canonical scalar, negated into [0, (r-1)/2] when that is shorter: s*P = (r-s)*(-P).  Small negative
+// witness values (src/fieldutils.rs:9-17) thereby become single-digit scalars.
+__device__ __forceinline__ fe_t msm_canon(const fe_t* scalars, size_t i, uint32_t& neg) {
     fe_t s = Fr::from_mont(ld_fe(scalars + i));
-    uint32_t neg = 0;
-    if (gt_half_r(s)) {          // s*P = (r-s)*(-P)
-        uint64_t br = 0;
+    neg = 0;
+    if (gt_half_r(s)) {
+        uint32_t br = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint64_t t = (uint64_t)FrP::MOD[k] - s.v[k] - br;
-            s.v[k] = (uint32_t)t;
-            br = (t >> 63) & 1;
-        }
+        for (int k = 0; k < 8; k++) s.v[k] = subb32(FrP::MOD[k], s.v[k], br);
         neg = 1;
     }
+    return s;
+}
+// calls f(w, bucket, sign) for every non-zero signed c-bit digit (bucket = |digit| - 1)
+template <class F>
+__device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, uint32_t c, uint32_t W, F&& f) {
     const uint32_t half = 1u << (c - 1);
     uint32_t carry = 0;
     for (uint32_t w = 0; w < W; w++) {
         uint32_t raw = get_bits(s, w * c, c) + carry;
-        uint32_t key = MSM_SKIP;
-        if (raw > half) {
+        if (raw > half) {                       // negative digit raw - 2^c, carry into the next window
             carry = 1;
-            uint32_t mag = (1u << c) - raw;           // digit = -(mag)
-            key = (mag - 1) | ((neg ^ 1u) << 31);
+            if (raw != (1u << c)) f(w, (1u << c) - raw - 1u, neg ^ 1u);   // raw == 2^c: digit 0 with a carry
         } else {
             carry = 0;
-            if (raw) key = (raw - 1) | (neg << 31);
+            if (raw) f(w, raw - 1u, neg);
         }
-        keys[(size_t)w * n + i] = key;
-        if (key != MSM_SKIP) atomicAdd(&hist[key & 0x7fffffffu], 1u);
     }
 }
 
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* keys, size_t n, uint32_t W, size_t base_offset,
-                                                          size_t tab_stride, uint32_t* cursor, uint32_t* vals) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * W) return;
-    uint32_t key = keys[idx];
-    if (key == MSM_SKIP) return;
-    size_t w = idx / n, i = idx - w * n;
-    uint32_t pos = atomicAdd(&cursor[key & 0x7fffffffu], 1u);
-    vals[pos] = (uint32_t)(w * tab_stride + base_offset + i) | (key & 0x80000000u);
+// ---- sort pass 1: partition (bucket, payload) pairs by the top bits of the bucket id -------------
+// Global atomics are per (workgroup, partition), not per pair: a workgroup histograms its slice of scalars
+// in LDS, reserves one range per partition, then ranks its pairs with LDS atomics.
+__global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, uint32_t c, uint32_t W,
+                                                       uint32_t LB, uint32_t NP, uint32_t* part_count) {
+    __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
+    for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
+    __syncthreads();
+    size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        uint32_t neg;
+        fe_t s = msm_canon(scalars, i, neg);
+        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket >> LB], 1u); });
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < NP; p += 256)
+        if (lh[p]) atomicAdd(&part_count[p], lh[p]);
+}
+// exclusive scan of <= 1024 partition counts; also seeds the reservation cursors
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NP, uint32_t* part_base,
+                                                             uint32_t* part_cursor) {
+    __shared__ uint32_t sh[1024];
+    uint32_t t = threadIdx.x, v = t < NP ? part_count[t] : 0;
+    sh[t] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = t >= d ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += x;
+        __syncthreads();
+    }
+    if (t < NP) {
+        part_base[t] = sh[t] - v;
+        part_cursor[t] = sh[t] - v;
+    }
+    if (t == NP - 1) part_base[NP] = sh[t];
+}
+__global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, uint32_t c, uint32_t W,
+                                                            uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
+                                                            uint32_t* part_cursor, uint2* entries) {
+    __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
+    __shared__ uint32_t lbase[1u << MSM_MAX_PART_BITS];
+    for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
+    __syncthreads();
+    size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        uint32_t neg;
+        fe_t s = msm_canon(scalars, i, neg);
+        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket >> LB], 1u); });
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < NP; p += 256) {
+        uint32_t cnt = lh[p];
+        lbase[p] = cnt ? atomicAdd(&part_cursor[p], cnt) : 0u;
+        lh[p] = 0;
+    }
+    __syncthreads();
+    const uint32_t lmask = (1u << LB) - 1u;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        uint32_t neg;
+        fe_t s = msm_canon(scalars, i, neg);
+        msm_foreach_digit(s, neg, c, W, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
+            uint32_t p = bucket >> LB;
+            uint32_t r = atomicAdd(&lh[p], 1u);
+            entries[lbase[p] + r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket & lmask);
+        });
+    }
+}
+// ---- sort pass 2: one workgroup per partition, counting sort on the low bucket bits in LDS ---------
+__global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
+                                                          uint32_t* offsets, uint32_t* vals) {
+    __shared__ uint32_t cnt[2048];
+    __shared__ uint32_t tsum[512];
+    const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
+    const uint32_t beg = part_base[p], end = part_base[p + 1];
+    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
+    __syncthreads();
+    for (uint32_t e = beg + t; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
+    __syncthreads();
+    // exclusive scan of cnt[0..nbins): 4 consecutive bins per thread
+    uint32_t loc[4], s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t j = t * 4 + q;
+        loc[q] = j < nbins ? cnt[j] : 0;
+        s += loc[q];
+    }
+    tsum[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 512; d <<= 1) {
+        uint32_t x = t >= d ? tsum[t - d] : 0;
+        __syncthreads();
+        tsum[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = tsum[t] - s;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t j = t * 4 + q;
+        if (j < nbins) {
+            cnt[j] = run;
+            offsets[(size_t)p * nbins + j] = beg + run;
+        }
+        run += loc[q];
+    }
+    if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
+    __syncthreads();
+    for (uint32_t e = beg + t; e < end; e += 512) {
+        uint2 v = entries[e];
+        uint32_t pos = atomicAdd(&cnt[v.y], 1u);
+        vals[beg + pos] = v.x;
+    }
 }
 
 // ---- bucket accumulation (dominant kernel) ------------------------------------------------------
+// Perfectly balanced segmented accumulation: lane t owns sorted pairs [t*L, (t+1)*L) regardless of bucket
+// boundaries.  A bucket that lies inside one lane's range is written directly; a bucket cut by a lane
+// boundary leaves partial sums in tail[t] (continues into lane t+1) / head[t] (started before lane t), which
+// msm_fixup_kernel folds.  Each pair costs one 64-byte gather from T and one mixed add (8M + 2S).
+__device__ __forceinline__ g1a_t msm_fetch(const g1a_t* tab, uint32_t v) {
+    g1a_t p = ld_g1a(tab + (v & 0x7fffffffu));
+    if (v >> 31) p.y = Fq::neg(p.y);
+    return p;
+}
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
-                                                             uint32_t nb, g1x_t* buckets, uint32_t* heavy_list,
-                                                             uint32_t* heavy_count) {
+                                                             uint32_t nb, uint32_t L, g1x_t* buckets, g1x_t* head, g1x_t* tail) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = offsets[nb];
+    const uint64_t k0w = (uint64_t)t * L;
+    if (k0w >= total) return;
+    const uint32_t k0 = (uint32_t)k0w;
+    const uint32_t k1 = (uint64_t)k0 + L < total ? k0 + L : total;
+    uint32_t lo = 0, hi = nb;                   // offsets[lo] <= k0 < offsets[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= k0) lo = mid; else hi = mid;
+    }
+    uint32_t b = lo, bin_end = offsets[b + 1];
+    bool started_before = offsets[b] < k0;
+    g1x_t acc = g1x_identity();
+    g1a_t nxt = msm_fetch(tab, vals[k0]);
+    for (uint32_t k = k0; k < k1; k++) {
+        if (k == bin_end) {                     // bucket b is finished inside this lane
+            if (started_before) st_g1x(head + t, acc); else st_g1x(buckets + b, acc);
+            acc = g1x_identity();
+            started_before = false;
+            do { b++; bin_end = offsets[b + 1]; } while (bin_end == k);
+        }
+        g1a_t cur = nxt;
+        if (k + 1 < k1) nxt = msm_fetch(tab, vals[k + 1]);   // prefetch: the gather latency hides under the add
+        acc = g1x_add_mixed(acc, cur);
+    }
+    if (k1 == bin_end) {
+        if (started_before) st_g1x(head + t, acc); else st_g1x(buckets + b, acc);
+    } else {
+        if (started_before) st_g1x(head + t, acc); else st_g1x(tail + t, acc);
+    }
+}
+// bucket b cut by lane boundaries: tail[t1] + head[t1+1 .. t2]
+__global__ __launch_bounds__(256) void msm_fixup_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, const g1x_t* head,
+                                                        const g1x_t* tail, g1x_t* buckets, uint32_t* heavy_list, uint32_t* heavy_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t beg = offsets[b], end = offsets[b + 1];
-    if (end - beg > MSM_HEAVY) {
+    if (end == beg) return;
+    uint32_t t1 = beg / L, t2 = (end - 1) / L;
+    if (t1 == t2) return;
+    if (t2 - t1 > MSM_SPAN_HEAVY) {
         heavy_list[atomicAdd(heavy_count, 1u)] = b;
         return;
     }
-    g1x_t acc = g1x_identity();
-    for (uint32_t k = beg; k < end; k++) {
-        uint32_t v = vals[k];
-        g1a_t p = ld_g1a(tab + (v & 0x7fffffffu));
-        if (v >> 31) p.y = Fq::neg(p.y);
-        acc = g1x_add_mixed(acc, p);
-    }
+    g1x_t acc = ld_g1x(tail + t1);
+    for (uint32_t t = t1 + 1; t <= t2; t++) acc = g1x_add(acc, ld_g1x(head + t));
     st_g1x(buckets + b, acc);
 }
-
-// one workgroup per heavy bucket: strided accumulation, then an LDS tree of XYZZ adds
-__global__ __launch_bounds__(256) void msm_heavy_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
-                                                        const uint32_t* heavy_list, const uint32_t* heavy_count,
-                                                        g1x_t* buckets) {
+// heavily skewed buckets (e.g. thousands of equal witness values): one workgroup folds the lane partials
+__global__ __launch_bounds__(256) void msm_fixup_heavy_kernel(const uint32_t* offsets, uint32_t L, const g1x_t* head, const g1x_t* tail,
+                                                              const uint32_t* heavy_list, const uint32_t* heavy_count, g1x_t* buckets) {
     __shared__ g1x_t sh[256];
-  for (uint32_t h = blockIdx.x; h < *heavy_count; h += gridDim.x) {
-    uint32_t b = heavy_list[h];
-    uint32_t beg = offsets[b], end = offsets[b + 1];
-    g1x_t acc = g1x_identity();
-    for (uint32_t k = beg + threadIdx.x; k < end; k += 256) {
-        uint32_t v = vals[k];
-        g1a_t p = ld_g1a(tab + (v & 0x7fffffffu));
-        if (v >> 31) p.y = Fq::neg(p.y);
-        acc = g1x_add_mixed(acc, p);
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    for (uint32_t h = blockIdx.x; h < *heavy_count; h += gridDim.x) {
+        uint32_t b = heavy_list[h];
+        uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
+        g1x_t acc = threadIdx.x == 0 ? ld_g1x(tail + t1) : g1x_identity();
+        for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256) acc = g1x_add(acc, ld_g1x(head + t));
+        sh[threadIdx.x] = acc;
         __syncthreads();
-    }
-    if (threadIdx.x == 0) st_g1x(buckets + b, sh[0]);
-    __syncthreads();
-  }
-}
-
-// ---- reduce: sum_b (b+1) * B_b -------------------------------------------------------------------
-// thread t owns buckets [t*m, t*m + m): L = sum_j (j+1) * B_{tm+j} (running sums), A = sum_j B_{tm+j};
-// contribution = L + (t*m) * A, the small multiple by double-and-add.
-__global__ __launch_bounds__(256) void msm_chunk_reduce_kernel(const g1x_t* buckets, uint32_t nb, g1x_t* out, uint32_t nchunks) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nchunks) return;
-    uint32_t lo = t * MSM_CHUNK, hi = lo + MSM_CHUNK;
-    if (hi > nb) hi = nb;
-    g1x_t run = g1x_identity(), acc = g1x_identity();
-    for (uint32_t b = hi; b-- > lo;) {
-        run = g1x_add(run, ld_g1x(buckets + b));
-        acc = g1x_add(acc, run);
-    }
-    // (t*m) * run
-    uint32_t k = lo;
-    if (k && !g1x_is_id(run)) {
-        g1x_t m = g1x_identity();
-        for (int bit = 31 - __clz(k); bit >= 0; bit--) {
-            m = g1x_double(m);
-            if ((k >> bit) & 1) m = g1x_add(m, run);
+        for (uint32_t s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+            __syncthreads();
         }
-        acc = g1x_add(acc, m);
+        if (threadIdx.x == 0) st_g1x(buckets + b, sh[0]);
+        __syncthreads();
     }
-    st_g1x(out + t, acc);
 }
-// out[blockIdx] = sum of in[blockIdx*256*per .. ) : per-thread serial partial, then LDS tree
-__global__ __launch_bounds__(256) void msm_sum_kernel(const g1x_t* in, uint32_t n, g1x_t* out, uint32_t per) {
-    __shared__ g1x_t sh[256];
-    uint32_t base = (blockIdx.x * 256 + threadIdx.x) * per;
+
+// ---- reduce: sum_b (b+1) * B_b ------------------------------------------------------------------
+// Write b = d0 + d1*2^a0 + d2*2^(a0+a1).  Then sum_b (b+1) B_b = TOTAL + sum_q 2^(s_q) sum_d d * S_q[d] with
+// S_q[d] = sum of the buckets whose q-th digit is d: three plain (unweighted) reductions, each a shallow tree,
+// instead of running sums whose dependent chains are latency-bound on a GPU.
+struct DigitGeom {
+    uint32_t a[3], s[3];     // width and shift of each digit
+    uint32_t G[3], E[3];     // groups / elements per lane for the first reduction stage
+    uint32_t poff[3];        // offset of digit q's partials, in g1x_t units
+    uint32_t soff[3];        // offset of digit q's sums S_q[.] in the sums array
+};
+__global__ __launch_bounds__(256) void msm_digitsum_kernel(const g1x_t* buckets, DigitGeom g, g1x_t* partial) {
+    const uint32_t q = blockIdx.y;
+    const uint32_t nvals = 1u << g.a[q];
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g.a[q] == 0 || idx >= nvals * g.G[q]) return;
+    const uint32_t d = idx & (nvals - 1), grp = idx >> g.a[q];
+    const uint32_t sq = g.s[q], lowmask = (1u << sq) - 1u;
     g1x_t acc = g1x_identity();
-    for (uint32_t k = 0; k < per; k++)
-        if (base + k < n) acc = g1x_add(acc, ld_g1x(in + base + k));
+    for (uint32_t e = 0; e < g.E[q]; e++) {
+        uint32_t r = grp * g.E[q] + e;
+        uint32_t b = ((r >> sq) << (sq + g.a[q])) | (d << sq) | (r & lowmask);
+        acc = g1x_add(acc, ld_g1x(buckets + b));
+    }
+    st_g1x(partial + g.poff[q] + (size_t)d * g.G[q] + grp, acc);
+}
+// S_q[d] = sum_g partial[q][d][g]: one workgroup per (q, d)
+__global__ __launch_bounds__(256) void msm_digitsum2_kernel(const g1x_t* partial, DigitGeom g, g1x_t* sums) {
+    __shared__ g1x_t sh[256];
+    uint32_t blk = blockIdx.x, q = 0;
+    while (q < 3 && blk >= (g.a[q] ? (1u << g.a[q]) : 0u)) { blk -= g.a[q] ? (1u << g.a[q]) : 0u; q++; }
+    const uint32_t d = blk, G = g.G[q];
+    const g1x_t* src = partial + g.poff[q] + (size_t)d * G;
+    g1x_t acc = g1x_identity();
+    for (uint32_t i = threadIdx.x; i < G; i += 256) acc = g1x_add(acc, ld_g1x(src + i));
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) st_g1x(out + blockIdx.x, sh[0]);
+    if (threadIdx.x == 0) st_g1x(sums + g.soff[q] + d, sh[0]);
 }
-__global__ void msm_finalize_kernel(const g1x_t* in, g1a_t* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) st_g1a(out, g1x_to_affine(ld_g1x(in)));
+// plane sums: planes[0] = TOTAL = sum_d S_0[d]; planes[1 + s_q + j] += sum_{d: bit j of d} S_q[d].
+// 8 lanes per plane, then a 3-step LDS tree.  The final 2^k-weighted Horner over the planes is ~40 dependent
+// point operations and runs on the host (host64.hpp).
+__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* sums, DigitGeom g, g1x_t* planes) {
+    __shared__ g1x_t sh[256];
+    const uint32_t grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    // plane id -> (q, j): id 0 = TOTAL, then digit 0's bits, digit 1's bits, digit 2's bits
+    uint32_t q = 0, j = 0;
+    bool total = grp == 0, valid = true;
+    if (!total) {
+        uint32_t id = grp - 1;
+        while (q < 3 && id >= g.a[q]) { id -= g.a[q]; q++; }
+        valid = q < 3;
+        j = id;
+    }
+    g1x_t acc = g1x_identity();
+    if (valid) {
+        const uint32_t nvals = 1u << g.a[q];
+        for (uint32_t d = sub; d < nvals; d += 8)
+            if (total || ((d >> j) & 1)) acc = g1x_add(acc, ld_g1x(sums + g.soff[q] + d));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 4; s > 0; s >>= 1) {
+        if (sub < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (valid && sub == 0) st_g1x(planes + (total ? 0u : 1u + g.s[q] + j), sh[threadIdx.x]);
 }
 
 static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
@@ -255,76 +403,115 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     MsmTable* T = nullptr;
     int rc = table_get(c, st, b, &T);
     if (rc) return rc;
-    const uint32_t cw = T->c, W = T->W;
-    const uint32_t nb = 1u << (cw - 1);
+    const uint32_t cw = T->c, W = T->W, bits = cw - 1;
+    const uint32_t nb = 1u << bits;
     const size_t npairs = n * W;
-    const uint32_t nchunks = cdiv(nb, MSM_CHUNK);
+    const uint32_t PB = bits < MSM_MAX_PART_BITS ? bits : MSM_MAX_PART_BITS, LB = bits - PB, NP = 1u << PB;
+    // ---- lane length for the accumulate kernel: fill the resident lanes an integer number of times ----
+    static int acc_blocks_per_cu = 0;
+    if (!acc_blocks_per_cu) {
+        EZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&acc_blocks_per_cu, msm_accumulate_kernel, 256, 0));
+        if (acc_blocks_per_cu < 1) acc_blocks_per_cu = 1;
+    }
+    const size_t resident = (size_t)acc_blocks_per_cu * 256 * c->num_cus;
+    size_t rounds = (npairs + resident * 48 - 1) / (resident * 48);
+    uint32_t L = (uint32_t)((npairs + resident * rounds - 1) / (resident * rounds));
+    if (L < 8) L = 8;
+    const uint32_t nlanes = cdiv(npairs, L);
+    // ---- digit geometry of the reduce phase ----
+    DigitGeom dg;
+    memset(&dg, 0, sizeof dg);
+    {
+        uint32_t rem = bits, sh = 0, po = 0, so = 0;
+        for (int q = 0; q < 3; q++) {
+            uint32_t a = (rem + (3 - q) - 1) / (3 - q);
+            dg.a[q] = a; dg.s[q] = sh;
+            uint32_t rest = nb >> a;
+            dg.E[q] = rest < MSM_DIGIT_E ? rest : MSM_DIGIT_E;
+            dg.G[q] = rest / dg.E[q];
+            dg.poff[q] = po; dg.soff[q] = so;
+            if (a) { po += (1u << a) * dg.G[q]; so += 1u << a; }
+            rem -= a; sh += a;
+        }
+    }
+    uint32_t n_part = 0, n_sums = 0, max_dthreads = 0, sum_blocks = 0;
+    for (int q = 0; q < 3; q++)
+        if (dg.a[q]) {
+            n_part += (1u << dg.a[q]) * dg.G[q];
+            n_sums += 1u << dg.a[q];
+            sum_blocks += 1u << dg.a[q];
+            uint32_t th = (1u << dg.a[q]) * dg.G[q];
+            if (th > max_dthreads) max_dthreads = th;
+        }
+    const uint32_t nplanes = 1 + bits;
     // ---- carve scratch ----
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o_keys = 0;
-    size_t o_vals = o_keys + al(npairs * 4);
-    size_t o_hist = o_vals + al(npairs * 4);
-    size_t o_offs = o_hist + al(((size_t)nb + 1) * 4);
-    size_t o_curs = o_offs + al(((size_t)nb + 1) * 4);
-    size_t o_heavy = o_curs + al(((size_t)nb + 1) * 4);
-    size_t o_hcnt = o_heavy + al((size_t)nb * 4);
-    size_t o_bkt = o_hcnt + al(256);
-    size_t o_red = o_bkt + al((size_t)nb * sizeof(g1x_t));
-    size_t o_red2 = o_red + al((size_t)nchunks * sizeof(g1x_t));
-    size_t o_out = o_red2 + al((size_t)nchunks * sizeof(g1x_t));
-    size_t cub_bytes = 0;
-    EZ_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(nb + 1), st));
-    size_t o_cub = o_out + al(256);
-    size_t total = o_cub + al(cub_bytes);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
+    size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_pcur = carve((NP + 1) * 4);
+    size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256);
+    size_t o_bkt = carve((size_t)nb * sizeof(g1x_t));
+    size_t o_head = carve((size_t)nlanes * sizeof(g1x_t)), o_tail = carve((size_t)nlanes * sizeof(g1x_t));
+    size_t o_part = carve((size_t)n_part * sizeof(g1x_t)), o_sums = carve((size_t)n_sums * sizeof(g1x_t));
+    size_t o_planes = carve((size_t)nplanes * sizeof(g1x_t));
     uint8_t* S = nullptr;
-    rc = scratch_reserve(c, total, (void**)&S);
+    rc = scratch_reserve(c, off, (void**)&S);
     if (rc) return rc;
-    uint32_t* keys = (uint32_t*)(S + o_keys);
+    uint2* entries = (uint2*)(S + o_ent);
     uint32_t* vals = (uint32_t*)(S + o_vals);
-    uint32_t* hist = (uint32_t*)(S + o_hist);
     uint32_t* offs = (uint32_t*)(S + o_offs);
-    uint32_t* curs = (uint32_t*)(S + o_curs);
-    uint32_t* heavy = (uint32_t*)(S + o_heavy);
-    uint32_t* hcnt = (uint32_t*)(S + o_hcnt);
-    g1x_t* bkt = (g1x_t*)(S + o_bkt);
-    g1x_t* red = (g1x_t*)(S + o_red);
-    g1x_t* red2 = (g1x_t*)(S + o_red2);
-    g1a_t* dout = (g1a_t*)(S + o_out);
+    uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *pcur = (uint32_t*)(S + o_pcur);
+    uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt);
+    g1x_t *bkt = (g1x_t*)(S + o_bkt), *head = (g1x_t*)(S + o_head), *tail = (g1x_t*)(S + o_tail);
+    g1x_t *part = (g1x_t*)(S + o_part), *sums = (g1x_t*)(S + o_sums), *planes = (g1x_t*)(S + o_planes);
 
     hipEvent_t m0, m1, a0, a1;
     if ((rc = ev_pair(c, "msm", &m0, &m1))) return rc;
     if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
     EZ_HIP(hipEventRecord(m0, st));
-    EZ_HIP(hipMemsetAsync(hist, 0, ((size_t)nb + 1) * 4, st));
+    EZ_HIP(hipMemsetAsync(pcnt, 0, (NP + 1) * 4, st));
     EZ_HIP(hipMemsetAsync(hcnt, 0, 4, st));
-    hipLaunchKernelGGL(msm_digits_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scalars, n, cw, W, keys, hist);
-    EZ_HIP(hipcub::DeviceScan::ExclusiveSum(S + o_cub, cub_bytes, hist, offs, (int)(nb + 1), st));
-    EZ_HIP(hipMemcpyAsync(curs, offs, ((size_t)nb + 1) * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(cdiv(npairs, 256)), dim3(256), 0, st, keys, n, W, base_offset, T->n, curs, vals);
+    EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x_t), st));          // empty buckets = identity (ZZ = 0)
+    EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x_t), st));
+    // sort
+    unsigned sgrid = (unsigned)c->num_cus * 4;
+    if ((size_t)sgrid * 256 > n) sgrid = cdiv(n, 256);
+    size_t per_block = ((n + sgrid - 1) / sgrid + 255) / 256 * 256;
+    sgrid = cdiv(n, per_block);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, cw, W, LB, NP, pcnt);
+    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase, pcur);
+    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, cw, W, LB, NP, base_offset, T->n,
+                       pcur, entries);
+    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals);
+    // accumulate
     EZ_HIP(hipEventRecord(a0, st));
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, bkt, heavy, hcnt);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail);
     EZ_HIP(hipEventRecord(a1, st));
-    {   // heavy buckets (skewed witnesses): block-stride over the device-side list, no host round trip
-        size_t max_heavy = npairs / MSM_HEAVY + 1;
+    hipLaunchKernelGGL(msm_fixup_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, offs, nb, L, head, tail, bkt, heavy, hcnt);
+    {
+        size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_heavy_kernel, dim3(hb), dim3(256), 0, st, T->tab, offs, vals, heavy, hcnt, bkt);
+        hipLaunchKernelGGL(msm_fixup_heavy_kernel, dim3(hb), dim3(256), 0, st, offs, L, head, tail, heavy, hcnt, bkt);
     }
-    hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(cdiv(nchunks, 256)), dim3(256), 0, st, bkt, nb, red, nchunks);
-    // tree-sum nchunks partials down to one
-    g1x_t *src = red, *dst = red2;
-    uint32_t cur = nchunks;
-    while (cur > 1) {
-        uint32_t per = cur >= 256 * 64 ? 8 : (cur > 256 ? 2 : 1);
-        uint32_t blocks = cdiv(cur, 256 * per);
-        hipLaunchKernelGGL(msm_sum_kernel, dim3(blocks), dim3(256), 0, st, src, cur, dst, per);
-        g1x_t* tmp = src; src = dst; dst = tmp;
-        cur = blocks;
-    }
-    hipLaunchKernelGGL(msm_finalize_kernel, dim3(1), dim3(64), 0, st, src, dout);
+    // reduce
+    hipLaunchKernelGGL(msm_digitsum_kernel, dim3(cdiv(max_dthreads, 256), 3), dim3(256), 0, st, bkt, dg, part);
+    hipLaunchKernelGGL(msm_digitsum2_kernel, dim3(sum_blocks), dim3(256), 0, st, part, dg, sums);
+    hipLaunchKernelGGL(msm_planes_kernel, dim3(1), dim3(256), 0, st, sums, dg, planes);
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(m1, st));
-    EZ_HIP(hipMemcpyAsync(out_host, dout, 64, hipMemcpyDeviceToHost, st));
+    std::vector<h64::xyzz> hp(nplanes);
+    EZ_HIP(hipMemcpyAsync(hp.data(), planes, (size_t)nplanes * sizeof(g1x_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipStreamSynchronize(st));
+    // host: result = TOTAL + sum_k 2^k * plane[1+k]  (Horner from the top bit), then canonical affine
+    h64::xyzz acc = h64::identity();
+    for (int k = (int)bits - 1; k >= 0; k--) {
+        acc = h64::dbl(acc);
+        acc = h64::add(acc, hp[1 + k]);
+    }
+    acc = h64::add(acc, hp[0]);
+    h64::aff r = h64::to_affine(acc);
+    memcpy(out_host, &r, 64);
     return EZKL_OK;
 }
 
@@ -376,10 +563,10 @@ int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, voi
 }
 
 void g1_add_affine_host(const void* a, const void* b, void* out) {
-    g1a_t p, q;
+    h64::aff p, q;
     memcpy(&p, a, 64);
     memcpy(&q, b, 64);
-    g1a_t r = g1x_to_affine(g1x_add_mixed(g1x_from_affine(p), q));
+    h64::aff r = h64::to_affine(h64::add(h64::from_affine(p), h64::from_affine(q)));
     memcpy(out, &r, 64);
 }
 

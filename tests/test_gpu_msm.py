@@ -52,6 +52,9 @@ def test_edge_cases(hip):
     s = rand_fr(rng, n)
     s[:8] = 0
     s[8] = fe_from_int(R - 1); s[9] = fe_from_int(1); s[10] = fe_from_int((R - 1) // 2); s[11] = fe_from_int((R + 1) // 2)
+    for j, kbits in enumerate((200, 253, 64, 20, 19, 21, 40)):      # runs of one-bits: a digit of 2^c - 1 plus a carry
+        s[50 + j] = fe_from_int((1 << kbits) - 1)                     # makes raw == 2^c (digit 0, carry 1)
+        s[60 + j] = fe_from_int(R - ((1 << kbits) - 1))
     s[20] = s[21] = fe_from_int(12345)            # same scalar, same point -> doubling path
     s[40] = s[41] = fe_from_int(777)              # P and -P with the same scalar -> inverse path
     assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all()
