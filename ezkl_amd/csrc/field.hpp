@@ -49,6 +49,7 @@ EZ_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& br) {
     return r;
 }
 template <class P> __device__ __forceinline__ fe_t mont_mul_asm(const fe_t& a, const fe_t& b);
+template <class P> __device__ __forceinline__ void mont_mul_single(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t (&r)[8]);
 
 template <class P>
 struct Field {
@@ -139,7 +140,13 @@ struct Field {
         fe_t x, y;
 #pragma unroll
         for (int i = 0; i < 8; i++) { x.v[i] = a[i]; y.v[i] = b[i]; }
-        fe_t r = mul_inl(x, y);
+#if defined(__HIP_DEVICE_COMPILE__)
+        fe_t t;
+        mont_mul_single<P>(x.v, y.v, t.v);      // montmul_gen.hpp: the whole product as one asm statement
+        fe_t r = reduce_once(t);
+#else
+        fe_t r = mul_portable(x, y);
+#endif
         u32x8 o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o[i] = r.v[i];
@@ -233,6 +240,8 @@ struct Field {
 }  // namespace ezkl
 namespace ezkl {
 #include "montmul_gen.hpp"
+template <> __device__ __forceinline__ void mont_mul_single<FqP>(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t (&r)[8]) { mont_mul_asm1_fq(a, b, r); }
+template <> __device__ __forceinline__ void mont_mul_single<FrP>(const uint32_t (&a)[8], const uint32_t (&b)[8], uint32_t (&r)[8]) { mont_mul_asm1_fr(a, b, r); }
 using Fr = Field<FrP>;
 using Fq = Field<FqP>;
 
