@@ -53,6 +53,20 @@ __global__ __launch_bounds__(256) void ub_copy_kernel(const uint4* in, uint4* ou
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
+// random 64-byte record gathers (the access pattern of msm_accumulate_kernel's table reads)
+__global__ __launch_bounds__(256) void ub_gather_kernel(const uint4* table, uint32_t mask, uint4* out, int iters) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = tid * 2654435761u + 12345u;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int k = 0; k < iters; k++) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const uint4* p = table + (size_t)(x & mask) * 4;
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc.x ^= a.x ^ b.y ^ c.z ^ d.w; acc.y += a.y + b.x; acc.z ^= c.x + d.y; acc.w += a.w ^ d.z;
+    }
+    out[tid] = acc;
+}
+
 int ubench(Ctx* c, const char* which, double* out) {
     hipStream_t st = c->stream;
     hipEvent_t e0, e1;
@@ -82,6 +96,25 @@ int ubench(Ctx* c, const char* which, double* out) {
         EZ_HIP(hipFree(buf));
         const double per_thread = (is_mm || !strcmp(which, "addsub")) ? 4.0 * iters : 8.0 * iters;
         *out = per_thread * (double)nthreads / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strcmp(which, "gather64")) {
+        const size_t recs = (size_t)1 << 24;                 // 1 GiB table, far beyond L2 + MALL
+        void *tab = nullptr, *o = nullptr;
+        EZ_HIP(hipMalloc(&tab, recs * 64));
+        EZ_HIP(hipMalloc(&o, nthreads * 16));
+        EZ_HIP(hipMemsetAsync(tab, 3, recs * 64, st));
+        const int iters = 32;
+        for (int rep = 0; rep < 2; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(ub_gather_kernel, dim3(blocks), dim3(threads), 0, st, (const uint4*)tab, (uint32_t)(recs - 1), (uint4*)o, iters);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        EZ_HIP(hipFree(tab));
+        EZ_HIP(hipFree(o));
+        *out = 64.0 * iters * (double)nthreads / (ms * 1e-3);     // gathered bytes per second
         return EZKL_OK;
     }
     if (!strcmp(which, "copy")) {
