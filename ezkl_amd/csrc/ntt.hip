@@ -20,7 +20,8 @@
 namespace ezkl {
 
 static constexpr int NTT_THREADS = 256;
-static constexpr uint32_t NTT_LOG_TILE = 11;   // 2048 elements = 64 KiB of LDS
+static constexpr uint32_t NTT_LOG_TILE = 10;   // multi-pass tile: 1024 elements = 32 KiB of LDS -> 4 workgroups (16 waves) per CU
+static constexpr uint32_t NTT_LOG_SINGLE = 11; // a transform up to 2^11 runs as ONE pass in a 64 KiB tile
 
 struct PassArgs {
     const fe_t* in;
@@ -52,6 +53,42 @@ EZ_D fe_t lds_get(const uint2* d, uint32_t tile, uint32_t e) {
         x.v[2 * q + 1] = t.y;
     }
     return x;
+}
+
+// G consecutive DIF stages (s .. s+G-1) of the R-point column FFTs on 2^G elements held in registers.
+// Group members are rows r0 + i*hG (hG = R >> (s+G)); at sub-stage t the partner distance is 2^(G-1-t) members
+// and the low element at in-block position pos = j + (i & (half-1))*hG takes twiddle w_R^(pos << (s+t)).
+template <int G>
+__device__ __forceinline__ void ntt_superstage(uint2* data, const fe_t* tloc, uint32_t TILE, uint32_t logC, uint32_t log_r,
+                                               uint32_t s, uint32_t tid) {
+    constexpr uint32_t M = 1u << G;
+    const uint32_t C = 1u << logC;
+    const uint32_t lhG = log_r - s - G, hG = 1u << lhG;        // rows between adjacent group members
+    const uint32_t ngroups = TILE >> G;
+    for (uint32_t gid = tid; gid < ngroups; gid += NTT_THREADS) {
+        const uint32_t c = gid & (C - 1), q = gid >> logC;
+        const uint32_t j = q & (hG - 1), blk = q >> lhG;
+        const uint32_t r0 = (blk << (log_r - s)) + j;
+        fe_t x[M];
+#pragma unroll
+        for (uint32_t i = 0; i < M; i++) x[i] = lds_get(data, TILE, ((r0 + i * hG) << logC) + c);
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const uint32_t half = 1u << (G - 1 - t);
+            const bool need_tw = (s + t + 1 != log_r);            // last stage of the column FFT: twiddle = 1
+#pragma unroll
+            for (uint32_t i = 0; i < M; i++) {
+                if (i & half) continue;
+                fe_t u = x[i], v = x[i + half];
+                x[i] = Fr::add(u, v);
+                fe_t d = Fr::sub(u, v);
+                if (need_tw) d = Fr::mul(d, tloc[(j + (i & (half - 1)) * hG) << (s + t)]);
+                x[i + half] = d;
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < M; i++) lds_put(data, TILE, ((r0 + i * hG) << logC) + c, x[i]);
+    }
 }
 
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
@@ -106,21 +143,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     }
     __syncthreads();
 
-    // ---- r radix-2 DIF stages in LDS ----
-    for (uint32_t s = 0; s < a.log_r; s++) {
-        const uint32_t lh = a.log_r - 1 - s;            // log2(half), half = rows between partners
-        const bool need_tw = (lh != 0);
-        for (uint32_t b = tid; b < (TILE >> 1); b += NTT_THREADS) {
-            uint32_t c = b & (C - 1), q = b >> logC;
-            uint32_t j = q & ((1u << lh) - 1), blk = q >> lh;
-            uint32_t lo = (((blk << (lh + 1)) + j) << logC) + c, hi = lo + (C << lh);
-            fe_t u = lds_get(data, TILE, lo), v = lds_get(data, TILE, hi);
-            fe_t sum = Fr::add(u, v), dif = Fr::sub(u, v);
-            if (need_tw) dif = Fr::mul(dif, tloc[j << s]);
-            lds_put(data, TILE, lo, sum);
-            lds_put(data, TILE, hi, dif);
-        }
+    // ---- r DIF stages, up to three at a time in registers (radix-8 groups), one LDS round trip per group ----
+    for (uint32_t s = 0; s < a.log_r;) {
+        const uint32_t g = a.log_r - s >= 2 ? 2u : a.log_r - s;      // radix-4 groups: 32 data VGPRs, 4 waves/SIMD
+        if (g == 2) ntt_superstage<2>(data, tloc, TILE, logC, a.log_r, s, tid);
+        else ntt_superstage<1>(data, tloc, TILE, logC, a.log_r, s, tid);
         __syncthreads();
+        s += g;
     }
 
     // ---- store: y[k1] sits at row bitrev(k1) ----
@@ -187,7 +216,7 @@ struct NttPlan {
 static std::map<std::string, NttPlan*> g_plans;   // guarded by the ctx mutex
 
 static void plan_radices(uint32_t log_n, NttPlan* p) {
-    if (log_n <= NTT_LOG_TILE) {
+    if (log_n <= NTT_LOG_SINGLE) {
         p->npass = 1;
         p->log_radix[0] = log_n;
         return;
@@ -276,7 +305,7 @@ int ntt_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, c
         a.log_n = log_n;
         a.log_r = p->log_radix[i];
         a.log_m = log_m;
-        a.log_tile = log_n < NTT_LOG_TILE ? log_n : NTT_LOG_TILE;
+        a.log_tile = p->npass == 1 ? log_n : NTT_LOG_TILE;
         if (a.log_tile < a.log_r) a.log_tile = a.log_r;
         a.first = first;
         a.last = last;
