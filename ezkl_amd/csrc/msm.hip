@@ -28,7 +28,7 @@ namespace ezkl {
 
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets spanning more lanes than this are folded by a workgroup
-static constexpr uint32_t MSM_DIGIT_E = 16;         // serial elements per lane in the digit-sum reduction
+static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
 
 struct MsmTable {
     g1a_t* tab = nullptr;    // W x n affine
@@ -104,7 +104,10 @@ __device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, u
     }
 }
 
-// ---- sort pass 1: partition (bucket, payload) pairs by the top bits of the bucket id -------------
+// ---- sort pass 1: partition (bucket, payload) pairs by the LOW bits of the bucket id -------------
+// (low bits are uniformly populated even when the top window or a skewed witness concentrates the bucket
+// values in a small numeric range, so the partitions stay balanced).  Buckets are stored at position
+// pos = (bucket & (NP-1)) * 2^LB + (bucket >> PB); the reduce phase weights positions accordingly.
 // Global atomics are per (workgroup, partition), not per pair: a workgroup histograms its slice of scalars
 // in LDS, reserves one range per partition, then ranks its pairs with LDS atomics.
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, uint32_t c, uint32_t W,
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket >> LB], 1u); });
+        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < NP; p += 256)
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars,
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket >> LB], 1u); });
+        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < NP; p += 256) {
@@ -161,14 +164,14 @@ __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars,
         lh[p] = 0;
     }
     __syncthreads();
-    const uint32_t lmask = (1u << LB) - 1u;
+    const uint32_t PB = 31 - __clz(NP);
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
         msm_foreach_digit(s, neg, c, W, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
-            uint32_t p = bucket >> LB;
+            uint32_t p = bucket & (NP - 1);
             uint32_t r = atomicAdd(&lh[p], 1u);
-            entries[lbase[p] + r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket & lmask);
+            entries[lbase[p] + r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket >> PB);
         });
     }
 }
@@ -228,7 +231,7 @@ __device__ __forceinline__ g1a_t msm_fetch(const g1a_t* tab, uint32_t v) {
     if (v >> 31) p.y = Fq::neg(p.y);
     return p;
 }
-__global__ __launch_bounds__(256) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
+__global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
                                                              uint32_t nb, uint32_t L, g1x_t* buckets, g1x_t* head, g1x_t* tail) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[nb];
@@ -299,76 +302,81 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy_kernel(const uint32_t* of
     }
 }
 
-// ---- reduce: sum_b (b+1) * B_b ------------------------------------------------------------------
-// Write b = d0 + d1*2^a0 + d2*2^(a0+a1).  Then sum_b (b+1) B_b = TOTAL + sum_q 2^(s_q) sum_d d * S_q[d] with
-// S_q[d] = sum of the buckets whose q-th digit is d: three plain (unweighted) reductions, each a shallow tree,
-// instead of running sums whose dependent chains are latency-bound on a GPU.
-struct DigitGeom {
-    uint32_t a[3], s[3];     // width and shift of each digit
-    uint32_t G[3], E[3];     // groups / elements per lane for the first reduction stage
-    uint32_t poff[3];        // offset of digit q's partials, in g1x_t units
-    uint32_t soff[3];        // offset of digit q's sums S_q[.] in the sums array
+// ---- reduce: sum_pos weight(pos) * B_pos ---------------------------------------------------------
+// A bucket position splits into three bit-fields A (lowest), B, C; its weight is 1 + dA*2^wsA + dB*2^wsB +
+// dC*2^wsC.  So the weighted sum is TOTAL + sum over fields of 2^ws * sum_d d * S_field[d], with S_field[d] the
+// plain sum of the buckets whose field equals d.  S_A comes from column sums; S_B and S_C come from the row
+// sums T[dC,dB] = sum_dA B: two passes over the buckets, each a shallow reduction (no running sums, whose
+// dependent chains are latency-bound on a GPU), then per-bit plane sums; the final Horner over <= 22 planes
+// runs on the host.
+struct ReduceGeom {
+    uint32_t wA, wB, wC;          // field widths (pos bits: A = [0,wA), B = [wA,wA+wB), C = rest)
+    uint32_t wsA, wsB, wsC;       // weight shifts of the fields
+    uint32_t EA, GA, ET, GT;      // serial elements per lane / groups for column sums (A) and row sums (T)
 };
-__global__ __launch_bounds__(256) void msm_digitsum_kernel(const g1x_t* buckets, DigitGeom g, g1x_t* partial) {
-    const uint32_t q = blockIdx.y;
-    const uint32_t nvals = 1u << g.a[q];
+__global__ __launch_bounds__(256, 4) void msm_reduce1_kernel(const g1x_t* buckets, ReduceGeom g, g1x_t* partA, g1x_t* partT) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g.a[q] == 0 || idx >= nvals * g.G[q]) return;
-    const uint32_t d = idx & (nvals - 1), grp = idx >> g.a[q];
-    const uint32_t sq = g.s[q], lowmask = (1u << sq) - 1u;
     g1x_t acc = g1x_identity();
-    for (uint32_t e = 0; e < g.E[q]; e++) {
-        uint32_t r = grp * g.E[q] + e;
-        uint32_t b = ((r >> sq) << (sq + g.a[q])) | (d << sq) | (r & lowmask);
-        acc = g1x_add(acc, ld_g1x(buckets + b));
+    if (blockIdx.y == 0) {            // column sums: S_A[dA] partials
+        if (idx >= (g.GA << g.wA)) return;
+        const uint32_t dA = idx & ((1u << g.wA) - 1u), grp = idx >> g.wA;
+        for (uint32_t e = 0; e < g.EA; e++) acc = g1x_add(acc, ld_g1x(buckets + ((((size_t)grp * g.EA + e) << g.wA) | dA)));
+        st_g1x(partA + (size_t)dA * g.GA + grp, acc);
+    } else {                          // row sums: T[t] partials
+        const uint32_t nT = 1u << (g.wB + g.wC);
+        if (idx >= nT * g.GT) return;
+        const uint32_t grp = idx % g.GT, t = idx / g.GT;
+        for (uint32_t e = 0; e < g.ET; e++) acc = g1x_add(acc, ld_g1x(buckets + (((size_t)t << g.wA) | (grp * g.ET + e))));
+        st_g1x(partT + (size_t)t * g.GT + grp, acc);
     }
-    st_g1x(partial + g.poff[q] + (size_t)d * g.G[q] + grp, acc);
 }
-// S_q[d] = sum_g partial[q][d][g]: one workgroup per (q, d)
-__global__ __launch_bounds__(256) void msm_digitsum2_kernel(const g1x_t* partial, DigitGeom g, g1x_t* sums) {
-    __shared__ g1x_t sh[256];
-    uint32_t blk = blockIdx.x, q = 0;
-    while (q < 3 && blk >= (g.a[q] ? (1u << g.a[q]) : 0u)) { blk -= g.a[q] ? (1u << g.a[q]) : 0u; q++; }
-    const uint32_t d = blk, G = g.G[q];
-    const g1x_t* src = partial + g.poff[q] + (size_t)d * G;
+// one wave per output: S_A[d] = sum_g partA[d][g] (blocks [0, 2^wA)),  T[t] = sum_g partT[t][g] (the rest)
+__global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x_t* partA, const g1x_t* partT, ReduceGeom g, g1x_t* SA, g1x_t* T) {
+    __shared__ g1x_t sh[64];
+    const uint32_t nA = 1u << g.wA;
+    const bool isA = blockIdx.x < nA;
+    const uint32_t o = isA ? blockIdx.x : blockIdx.x - nA, G = isA ? g.GA : g.GT;
+    const g1x_t* src = (isA ? partA : partT) + (size_t)o * G;
     g1x_t acc = g1x_identity();
-    for (uint32_t i = threadIdx.x; i < G; i += 256) acc = g1x_add(acc, ld_g1x(src + i));
+    for (uint32_t i = threadIdx.x; i < G; i += 64) acc = g1x_add(acc, ld_g1x(src + i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 32; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_g1x((isA ? SA : T) + o, sh[0]);
+}
+// one workgroup per plane: planes[0] = TOTAL; planes[1 + ws + j] = sum of the field sums whose digit has bit j
+__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* SA, const g1x_t* T, ReduceGeom g, g1x_t* planes) {
+    __shared__ g1x_t sh[256];
+    uint32_t id = blockIdx.x, field = 0, j = 0;      // field 0: TOTAL, 1: A, 2: B, 3: C
+    if (id > 0) {
+        id -= 1;
+        if (id < g.wA) { field = 1; j = id; }
+        else if (id < g.wA + g.wB) { field = 2; j = id - g.wA; }
+        else { field = 3; j = id - g.wA - g.wB; }
+    }
+    const uint32_t nA = 1u << g.wA, nT = 1u << (g.wB + g.wC);
+    g1x_t acc = g1x_identity();
+    if (field <= 1) {
+        for (uint32_t d = threadIdx.x; d < nA; d += 256)
+            if (field == 0 || ((d >> j) & 1)) acc = g1x_add(acc, ld_g1x(SA + d));
+    } else {
+        const uint32_t sh_bits = field == 2 ? j : g.wB + j;          // t = (dC << wB) | dB
+        for (uint32_t t = threadIdx.x; t < nT; t += 256)
+            if ((t >> sh_bits) & 1) acc = g1x_add(acc, ld_g1x(T + t));
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) st_g1x(sums + g.soff[q] + d, sh[0]);
-}
-// plane sums: planes[0] = TOTAL = sum_d S_0[d]; planes[1 + s_q + j] += sum_{d: bit j of d} S_q[d].
-// 8 lanes per plane, then a 3-step LDS tree.  The final 2^k-weighted Horner over the planes is ~40 dependent
-// point operations and runs on the host (host64.hpp).
-__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* sums, DigitGeom g, g1x_t* planes) {
-    __shared__ g1x_t sh[256];
-    const uint32_t grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    // plane id -> (q, j): id 0 = TOTAL, then digit 0's bits, digit 1's bits, digit 2's bits
-    uint32_t q = 0, j = 0;
-    bool total = grp == 0, valid = true;
-    if (!total) {
-        uint32_t id = grp - 1;
-        while (q < 3 && id >= g.a[q]) { id -= g.a[q]; q++; }
-        valid = q < 3;
-        j = id;
+    if (threadIdx.x == 0) {
+        const uint32_t ws = field == 1 ? g.wsA : field == 2 ? g.wsB : g.wsC;
+        st_g1x(planes + (field == 0 ? 0u : 1u + ws + j), sh[0]);
     }
-    g1x_t acc = g1x_identity();
-    if (valid) {
-        const uint32_t nvals = 1u << g.a[q];
-        for (uint32_t d = sub; d < nvals; d += 8)
-            if (total || ((d >> j) & 1)) acc = g1x_add(acc, ld_g1x(sums + g.soff[q] + d));
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = 4; s > 0; s >>= 1) {
-        if (sub < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (valid && sub == 0) st_g1x(planes + (total ? 0u : 1u + g.s[q] + j), sh[threadIdx.x]);
 }
 
 static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
@@ -414,35 +422,31 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
         if (acc_blocks_per_cu < 1) acc_blocks_per_cu = 1;
     }
     const size_t resident = (size_t)acc_blocks_per_cu * 256 * c->num_cus;
-    size_t rounds = (npairs + resident * 48 - 1) / (resident * 48);
+    size_t rounds = npairs / (resident * 40);          // 40..80 pairs per lane: few cut buckets, whole waves of work
+    if (rounds < 1) rounds = 1;
     uint32_t L = (uint32_t)((npairs + resident * rounds - 1) / (resident * rounds));
     if (L < 8) L = 8;
+    if (const char* e = getenv("EZKL_MSM_L")) L = (uint32_t)atoi(e);   // tuning knob (tools/gpu_probe.py)
     const uint32_t nlanes = cdiv(npairs, L);
-    // ---- digit geometry of the reduce phase ----
-    DigitGeom dg;
-    memset(&dg, 0, sizeof dg);
-    {
-        uint32_t rem = bits, sh = 0, po = 0, so = 0;
-        for (int q = 0; q < 3; q++) {
-            uint32_t a = (rem + (3 - q) - 1) / (3 - q);
-            dg.a[q] = a; dg.s[q] = sh;
-            uint32_t rest = nb >> a;
-            dg.E[q] = rest < MSM_DIGIT_E ? rest : MSM_DIGIT_E;
-            dg.G[q] = rest / dg.E[q];
-            dg.poff[q] = po; dg.soff[q] = so;
-            if (a) { po += (1u << a) * dg.G[q]; so += 1u << a; }
-            rem -= a; sh += a;
-        }
+    // ---- field geometry of the reduce phase (positions: pos = (bucket & (NP-1)) << LB | bucket >> PB) ----
+    ReduceGeom rg;
+    memset(&rg, 0, sizeof rg);
+    if (LB > 0) {
+        rg.wA = LB; rg.wsA = PB;                          // A = high bucket bits
+        rg.wB = (PB + 1) / 2; rg.wsB = 0;                 // B, C = low bucket bits
+        rg.wC = PB - rg.wB; rg.wsC = rg.wB;
+    } else {                                              // small MSM: pos == bucket
+        rg.wA = (bits + 2) / 3; rg.wsA = 0;
+        rg.wB = (bits - rg.wA + 1) / 2; rg.wsB = rg.wA;
+        rg.wC = bits - rg.wA - rg.wB; rg.wsC = rg.wA + rg.wB;
     }
-    uint32_t n_part = 0, n_sums = 0, max_dthreads = 0, sum_blocks = 0;
-    for (int q = 0; q < 3; q++)
-        if (dg.a[q]) {
-            n_part += (1u << dg.a[q]) * dg.G[q];
-            n_sums += 1u << dg.a[q];
-            sum_blocks += 1u << dg.a[q];
-            uint32_t th = (1u << dg.a[q]) * dg.G[q];
-            if (th > max_dthreads) max_dthreads = th;
-        }
+    {
+        const uint32_t rows = 1u << (rg.wB + rg.wC), cols = 1u << rg.wA;
+        rg.EA = rows < MSM_DIGIT_E ? rows : MSM_DIGIT_E; rg.GA = rows / rg.EA;
+        rg.ET = cols < MSM_DIGIT_E ? cols : MSM_DIGIT_E; rg.GT = cols / rg.ET;
+    }
+    const uint32_t nA = 1u << rg.wA, nT = 1u << (rg.wB + rg.wC);
+    const uint32_t n_partA = nA * rg.GA, n_partT = nT * rg.GT;
     const uint32_t nplanes = 1 + bits;
     // ---- carve scratch ----
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -453,7 +457,8 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x_t));
     size_t o_head = carve((size_t)nlanes * sizeof(g1x_t)), o_tail = carve((size_t)nlanes * sizeof(g1x_t));
-    size_t o_part = carve((size_t)n_part * sizeof(g1x_t)), o_sums = carve((size_t)n_sums * sizeof(g1x_t));
+    size_t o_partA = carve((size_t)n_partA * sizeof(g1x_t)), o_partT = carve((size_t)n_partT * sizeof(g1x_t));
+    size_t o_SA = carve((size_t)nA * sizeof(g1x_t)), o_T = carve((size_t)nT * sizeof(g1x_t));
     size_t o_planes = carve((size_t)nplanes * sizeof(g1x_t));
     uint8_t* S = nullptr;
     rc = scratch_reserve(c, off, (void**)&S);
@@ -464,7 +469,8 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *pcur = (uint32_t*)(S + o_pcur);
     uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt);
     g1x_t *bkt = (g1x_t*)(S + o_bkt), *head = (g1x_t*)(S + o_head), *tail = (g1x_t*)(S + o_tail);
-    g1x_t *part = (g1x_t*)(S + o_part), *sums = (g1x_t*)(S + o_sums), *planes = (g1x_t*)(S + o_planes);
+    g1x_t *partA = (g1x_t*)(S + o_partA), *partT = (g1x_t*)(S + o_partT), *SA = (g1x_t*)(S + o_SA), *TT = (g1x_t*)(S + o_T);
+    g1x_t* planes = (g1x_t*)(S + o_planes);
 
     hipEvent_t m0, m1, a0, a1;
     if ((rc = ev_pair(c, "msm", &m0, &m1))) return rc;
@@ -495,9 +501,12 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
         hipLaunchKernelGGL(msm_fixup_heavy_kernel, dim3(hb), dim3(256), 0, st, offs, L, head, tail, heavy, hcnt, bkt);
     }
     // reduce
-    hipLaunchKernelGGL(msm_digitsum_kernel, dim3(cdiv(max_dthreads, 256), 3), dim3(256), 0, st, bkt, dg, part);
-    hipLaunchKernelGGL(msm_digitsum2_kernel, dim3(sum_blocks), dim3(256), 0, st, part, dg, sums);
-    hipLaunchKernelGGL(msm_planes_kernel, dim3(1), dim3(256), 0, st, sums, dg, planes);
+    {
+        const uint32_t th = n_partA > n_partT ? n_partA : n_partT;
+        hipLaunchKernelGGL(msm_reduce1_kernel, dim3(cdiv(th, 256), 2), dim3(256), 0, st, bkt, rg, partA, partT);
+        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(nA + nT), dim3(64), 0, st, partA, partT, rg, SA, TT);
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes), dim3(256), 0, st, SA, TT, rg, planes);
+    }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(m1, st));
     std::vector<h64::xyzz> hp(nplanes);
