@@ -312,6 +312,15 @@ class GraphProgram:
         rots = np.asarray(self.rotations, np.int32)
         return code, consts, rots
 
+    def check_compiles(self, n_columns):
+        """host-only: lower the program to HIP source and compile it for gfx950 with hiprtc (no GPU needed)"""
+        code, consts, rots = self.arrays()
+        cols = (C.c_void_p * max(1, n_columns))()
+        ch = np.zeros((1, 4), np.uint64)
+        pr = _Prog(_p(code), code.shape[0], self.n_intermediates, _p(consts), consts.shape[0], _p(rots), rots.shape[0],
+                   C.cast(cols, _vp), n_columns, _p(ch), 1, self.k, self.ext_k)
+        _l.check(_l.load().ezkl_hip_eval_h_check(C.byref(pr)), "ezkl_hip_eval_h_check")
+
     def evaluate_h(self, column_ptrs, challenges, out_ptr, stream=None):
         """Run on device-resident columns (list of device pointers); out_ptr holds PreviousValue on entry."""
         code, consts, rots = self.arrays()

@@ -329,6 +329,11 @@ int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out, void* stream) {
     return eval_program(c, pick_stream(c, stream), prog, (fe_t*)out);
 }
 
+int ezkl_hip_eval_h_check(const ezkl_program_t* prog) {
+    if (!prog || !prog->code || prog->n_instr == 0) return EZKL_ERR_INVALID;
+    return eval_jit_compile_only(prog);        // host-only: hiprtc cross-compiles for gfx950 without a GPU
+}
+
 int ezkl_hip_last_kernel_ms(const char* which, float* out_ms) {
     if (!which || !out_ms) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -61,6 +61,7 @@ int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, siz
 int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
+int eval_jit_compile_only(const ezkl_program_t* p);
 int ubench(Ctx* c, const char* which, double* out);
 void msm_table_drop(const Bases* b);
 int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, void* out_dev);

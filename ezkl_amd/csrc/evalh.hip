@@ -9,40 +9,62 @@
 // wave-uniform (scalar loads); intermediates live in an HBM scratch laid out [slot][thread] so they
 // stream as well.  Algorithmic bytes: 32*(C+1) per row.
 #include "common.hpp"
+#include "embedded_src.hpp"
+#include <hip/hiprtc.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <functional>
 
 namespace ezkl {
 
+static constexpr uint32_t EV_NREG = 8;       // intermediates kept in VGPRs (wave-uniform register-file switch)
+
 struct EvalArgs {
-    const uint32_t* code;
+    const uint32_t* code;           // rewritten program: intermediate indices are slots (slot < EV_NREG: register)
     uint32_t n_instr;
     const fe_t* constants;
     const uint32_t* rot_off;        // rotation already scaled and reduced mod 2^ext_k
     const fe_t* const* columns;
     const fe_t* challenges;
-    fe_t* interm;                   // [n_intermediates][T]
+    fe_t* interm;                   // spilled slots: [slot - EV_NREG][T]
     fe_t* out;
     uint32_t ne_mask;
     uint32_t T;
+    uint32_t last_slot;
 };
+
+// The slot index is wave-uniform (it comes from the instruction stream), so these switches are scalar
+// branches around 8 v_mov: ~30 cycles against the ~1000 of a Montgomery product.
+#define EV_RD(dst, idx)                                                         \
+    switch (idx) {                                                              \
+    case 0: dst = r0; break; case 1: dst = r1; break; case 2: dst = r2; break; case 3: dst = r3; break; \
+    case 4: dst = r4; break; case 5: dst = r5; break; case 6: dst = r6; break; default: dst = r7; break; }
+#define EV_WR(idx, src)                                                         \
+    switch (idx) {                                                              \
+    case 0: r0 = src; break; case 1: r1 = src; break; case 2: r2 = src; break; case 3: r3 = src; break; \
+    case 4: r4 = src; break; case 5: r5 = src; break; case 6: r6 = src; break; default: r7 = src; break; }
 
 __global__ __launch_bounds__(256) void eval_program_kernel(EvalArgs a) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ne = a.ne_mask + 1;
     for (uint32_t r = tid; r < ne; r += a.T) {
         const fe_t prev = ld_fe(a.out + r);
-        uint32_t last = 0;
+        fe_t r0 = Fr::zero(), r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0, r6 = r0, r7 = r0;
         for (uint32_t ii = 0; ii < a.n_instr; ii++) {
             const uint32_t* I = a.code + 8 * (size_t)ii;
             const uint32_t op = I[0], target = I[1];
+            const bool unary = (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE);
             fe_t s[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
+                if (q == 1 && unary) break;
                 const uint32_t kind = I[2 + 3 * q], idx = I[3 + 3 * q], rot = I[4 + 3 * q];
-                if (q == 1 && (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE)) break;
                 switch (kind) {
                 case EZKL_SRC_CONST: s[q] = ld_fe(a.constants + idx); break;
-                case EZKL_SRC_INTERMEDIATE: s[q] = ld_fe(a.interm + (size_t)idx * a.T + tid); break;
+                case EZKL_SRC_INTERMEDIATE:
+                    if (idx < EV_NREG) { EV_RD(s[q], idx) } else s[q] = ld_fe(a.interm + (size_t)(idx - EV_NREG) * a.T + tid);
+                    break;
                 case EZKL_SRC_COLUMN: s[q] = ld_fe(a.columns[idx] + ((r + a.rot_off[rot]) & a.ne_mask)); break;
                 case EZKL_SRC_CHALLENGE: s[q] = ld_fe(a.challenges + idx); break;
                 default: s[q] = prev; break;
@@ -57,13 +79,205 @@ __global__ __launch_bounds__(256) void eval_program_kernel(EvalArgs a) {
             case EZKL_OP_DOUBLE: t = Fr::dbl(s[0]); break;
             case EZKL_OP_NEGATE: t = Fr::neg(s[0]); break;
             case EZKL_OP_STORE: t = s[0]; break;
-            default: t = Fr::add(Fr::mul(ld_fe(a.interm + (size_t)target * a.T + tid), s[1]), s[0]); break;
+            default: {   // HORNER_STEP: target = target * s1 + s0
+                fe_t cur;
+                if (target < EV_NREG) { EV_RD(cur, target) } else cur = ld_fe(a.interm + (size_t)(target - EV_NREG) * a.T + tid);
+                t = Fr::add(Fr::mul(cur, s[1]), s[0]);
+            } break;
             }
-            st_fe(a.interm + (size_t)target * a.T + tid, t);
-            last = target;
+            if (target < EV_NREG) { EV_WR(target, t) } else st_fe(a.interm + (size_t)(target - EV_NREG) * a.T + tid, t);
         }
-        if (a.n_instr) st_fe(a.out + r, ld_fe(a.interm + (size_t)last * a.T + tid));
+        if (a.n_instr) {
+            fe_t res;
+            if (a.last_slot < EV_NREG) { EV_RD(res, a.last_slot) } else res = ld_fe(a.interm + (size_t)(a.last_slot - EV_NREG) * a.T + tid);
+            st_fe(a.out + r, res);
+        }
     }
+}
+
+// Host-side register allocation: intermediates -> slots by linear scan over the straight-line program.
+// A slot is released after the last read of its value; the EV_NREG lowest slots live in VGPRs, the rest spill
+// to the HBM scratch.  Returns the rewritten code and the number of slots.
+static uint32_t allocate_slots(const ezkl_program_t* p, std::vector<uint32_t>& code) {
+    const uint32_t n = p->n_instr, ni = p->n_intermediates;
+    code.assign(p->code, p->code + 8 * (size_t)n);
+    auto n_src = [](uint32_t op) { return (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE) ? 1 : 2; };
+    // pass 1: value versions.  A non-Horner write creates version i of its target; a Horner step updates
+    // the current version in place.  last_use[ver] = index of the last instruction reading that version.
+    std::vector<int64_t> cur_ver(ni, -1), last_use(n, -1);
+    std::vector<int64_t> src_ver(2 * (size_t)n, -1), tgt_ver(n, -1);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* I = &code[8 * (size_t)i];
+        for (int q = 0; q < n_src(I[0]); q++)
+            if (I[2 + 3 * q] == EZKL_SRC_INTERMEDIATE) {
+                int64_t v = cur_ver[I[3 + 3 * q]];
+                src_ver[2 * (size_t)i + q] = v;            // -1: read of a never-written intermediate (reads zero)
+                if (v >= 0) last_use[v] = i;
+            }
+        if (I[0] == EZKL_OP_HORNER_STEP && cur_ver[I[1]] >= 0) {
+            tgt_ver[i] = cur_ver[I[1]];
+            last_use[tgt_ver[i]] = i;
+        } else {
+            cur_ver[I[1]] = i;
+            tgt_ver[i] = i;
+        }
+    }
+    if (n) last_use[tgt_ver[n - 1]] = (int64_t)n;            // the result stays live to the end
+    // pass 2: linear scan.  Sources are read into temporaries before the target is written, so a slot whose
+    // value dies at instruction i can be reused by i's own target.
+    std::vector<int64_t> slot_of(n, -1);
+    std::vector<uint32_t> free_slots;
+    uint32_t n_slots = 0;
+    auto release = [&](int64_t ver) {
+        if (ver >= 0 && slot_of[ver] >= 0) {
+            free_slots.push_back((uint32_t)slot_of[ver]);
+            slot_of[ver] = -2;
+        }
+    };
+    auto acquire = [&]() -> uint32_t {
+        if (free_slots.empty()) return n_slots++;
+        auto it = std::min_element(free_slots.begin(), free_slots.end());   // lowest slot first: registers before spills
+        uint32_t sl = *it;
+        free_slots.erase(it);
+        return sl;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t* I = &code[8 * (size_t)i];
+        for (int q = 0; q < n_src(I[0]); q++)
+            if (I[2 + 3 * q] == EZKL_SRC_INTERMEDIATE) {
+                int64_t v = src_ver[2 * (size_t)i + q];
+                if (v < 0) {                      // read of an intermediate no instruction has written: reject
+                    return 0xffffffffu;
+                } else {
+                    I[3 + 3 * q] = (uint32_t)slot_of[v];
+                }
+            }
+        const int64_t tv = tgt_ver[i];
+        const bool in_place = (tv != (int64_t)i);
+        for (int q = 0; q < n_src(I[0]); q++) {
+            int64_t v = src_ver[2 * (size_t)i + q];
+            if (v >= 0 && v != tv && last_use[v] == (int64_t)i) release(v);
+        }
+        if (!in_place) slot_of[tv] = (int64_t)acquire();
+        I[1] = (uint32_t)slot_of[tv];
+        if (last_use[tv] <= (int64_t)i && last_use[tv] != (int64_t)n) release(tv);    // dead after this instruction
+    }
+    return n_slots;
+}
+
+// ---- JIT path: the gate program becomes straight-line HIP source, compiled once per program with hiprtc ----
+// An interpreter stalls on every instruction (decode -> dependent column load -> compute: ~2.4 us per
+// instruction measured); in straight-line code the compiler hoists the column loads of a whole row ahead of
+// the arithmetic and keeps every intermediate in VGPRs.  The kernel is cached by a hash of the program.
+struct JitKernel {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+};
+static std::map<uint64_t, JitKernel> g_jit;    // guarded by the ctx mutex
+
+static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+    const uint8_t* p = (const uint8_t*)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_t>& rot) {
+    std::string s;
+    s.reserve(256 + (size_t)p->n_instr * 96);
+    s += "#include \"field.hpp\"\nusing namespace ezkl;\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
+         "    const fe_t* __restrict__ chal, fe_t* __restrict__ out, uint32_t ne_mask, uint32_t T) {\n"
+         "  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;\n"
+         "  for (uint32_t r = tid; r <= ne_mask; r += T) {\n"
+         "    const fe_t prev = ld_fe(out + r);\n";
+    auto n_src = [](uint32_t op) { return (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE) ? 1 : 2; };
+    std::vector<int64_t> cur_ver(p->n_intermediates, -1);
+    auto src = [&](const uint32_t* I, int q) -> std::string {
+        const uint32_t kind = I[2 + 3 * q], idx = I[3 + 3 * q], ro = I[4 + 3 * q];
+        char b[96];
+        switch (kind) {
+        case EZKL_SRC_CONST: snprintf(b, sizeof b, "ld_fe(consts + %u)", idx); break;
+        case EZKL_SRC_INTERMEDIATE: snprintf(b, sizeof b, "v%lld", (long long)cur_ver[idx]); break;
+        case EZKL_SRC_COLUMN: snprintf(b, sizeof b, "ld_fe(cols[%u] + ((r + %uu) & ne_mask))", idx, rot[ro]); break;
+        case EZKL_SRC_CHALLENGE: snprintf(b, sizeof b, "ld_fe(chal + %u)", idx); break;
+        default: snprintf(b, sizeof b, "prev"); break;
+        }
+        return b;
+    };
+    long long last = -1;
+    for (uint32_t i = 0; i < p->n_instr; i++) {
+        const uint32_t* I = p->code + 8 * (size_t)i;
+        std::string a = src(I, 0), b = n_src(I[0]) == 2 ? src(I, 1) : std::string();
+        char lhs[48];
+        if (I[0] == EZKL_OP_HORNER_STEP && cur_ver[I[1]] >= 0) {
+            snprintf(lhs, sizeof lhs, "    v%lld = ", (long long)cur_ver[I[1]]);
+            s += lhs;
+            s += "Fr::add(Fr::mul(v" + std::to_string(cur_ver[I[1]]) + ", " + b + "), " + a + ");\n";
+            last = cur_ver[I[1]];
+            continue;
+        }
+        cur_ver[I[1]] = i;
+        last = i;
+        snprintf(lhs, sizeof lhs, "    fe_t v%u = ", i);
+        s += lhs;
+        switch (I[0]) {
+        case EZKL_OP_ADD: s += "Fr::add(" + a + ", " + b + ");\n"; break;
+        case EZKL_OP_SUB: s += "Fr::sub(" + a + ", " + b + ");\n"; break;
+        case EZKL_OP_MUL: s += "Fr::mul(" + a + ", " + b + ");\n"; break;
+        case EZKL_OP_SQUARE: s += "Fr::sqr(" + a + ");\n"; break;
+        case EZKL_OP_DOUBLE: s += "Fr::dbl(" + a + ");\n"; break;
+        case EZKL_OP_NEGATE: s += "Fr::neg(" + a + ");\n"; break;
+        case EZKL_OP_STORE: s += a + ";\n"; break;
+        default: s += "Fr::add(Fr::mul(Fr::zero(), " + b + "), " + a + ");\n"; break;   // Horner on an unwritten target
+        }
+    }
+    s += "    st_fe(out + r, v" + std::to_string(last) + ");\n  }\n}\n";
+    return s;
+}
+static int jit_get(const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
+    uint64_t h = fnv1a(p->code, (size_t)p->n_instr * 32, 1469598103934665603ull);
+    h = fnv1a(rot.data(), rot.size() * 4, h);
+    auto it = g_jit.find(h);
+    if (it != g_jit.end()) { *fn = it->second.fn; return EZKL_OK; }
+    std::string src = jit_source(p, rot);
+    const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
+    const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 3, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, 0);
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        fprintf(stderr, "[ezkl_hip] eval_h JIT compile failed (%d):\n%.2000s\n", (int)r, log.c_str());
+        hiprtcDestroyProgram(&prog);
+        return EZKL_ERR_HIP;
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    std::vector<char> bin(cs);
+    hiprtcGetCode(prog, bin.data());
+    hiprtcDestroyProgram(&prog);
+    JitKernel k;
+    EZ_HIP(hipModuleLoadData(&k.mod, bin.data()));
+    EZ_HIP(hipModuleGetFunction(&k.fn, k.mod, "evalh_jit"));
+    g_jit[h] = k;
+    *fn = k.fn;
+    return EZKL_OK;
+}
+// offline self-check used by build(): does the JIT source for a program compile for gfx950? (no GPU needed)
+int eval_jit_compile_only(const ezkl_program_t* p) {
+    std::vector<uint32_t> rot(p->n_rotations ? p->n_rotations : 1, 0);
+    std::string src = jit_source(p, rot);
+    const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
+    const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 3, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    hiprtcDestroyProgram(&prog);
+    return r == HIPRTC_SUCCESS ? EZKL_OK : EZKL_ERR_HIP;
 }
 
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
@@ -84,6 +298,10 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
             if (kind == EZKL_SRC_CHALLENGE && idx >= p->n_challenges) return EZKL_ERR_INVALID;
         }
     }
+    std::vector<uint32_t> code;
+    const uint32_t n_slots = allocate_slots(p, code);
+    if (n_slots == 0xffffffffu) return EZKL_ERR_INVALID;
+    const uint32_t n_spill = n_slots > EV_NREG ? n_slots - EV_NREG : 0;
     size_t T = (size_t)c->num_cus * 256 * 4;
     if (T > ne) T = ne;
     std::vector<uint32_t> rot(p->n_rotations ? p->n_rotations : 1, 0);
@@ -100,11 +318,11 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     size_t o_cols = o_rot + al(rot.size() * 4);
     size_t o_chal = o_cols + al((size_t)(p->n_columns ? p->n_columns : 1) * 8);
     size_t o_int = o_chal + al((size_t)(p->n_challenges ? p->n_challenges : 1) * 32);
-    size_t total = o_int + al((size_t)p->n_intermediates * T * 32);
+    size_t total = o_int + al((size_t)(n_spill ? n_spill : 1) * T * 32);
     uint8_t* S = nullptr;
     int rc = scratch_reserve(c, total, (void**)&S);
     if (rc) return rc;
-    EZ_HIP(hipMemcpyAsync(S + o_code, p->code, (size_t)p->n_instr * 32, hipMemcpyHostToDevice, st));
+    EZ_HIP(hipMemcpyAsync(S + o_code, code.data(), (size_t)p->n_instr * 32, hipMemcpyHostToDevice, st));
     if (p->n_constants) EZ_HIP(hipMemcpyAsync(S + o_const, p->constants, (size_t)p->n_constants * 32, hipMemcpyHostToDevice, st));
     EZ_HIP(hipMemcpyAsync(S + o_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice, st));
     if (p->n_columns) EZ_HIP(hipMemcpyAsync(S + o_cols, p->columns, (size_t)p->n_columns * 8, hipMemcpyHostToDevice, st));
@@ -120,10 +338,24 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     a.out = out;
     a.ne_mask = (uint32_t)(ne - 1);
     a.T = (uint32_t)T;
+    a.last_slot = code[8 * (size_t)(p->n_instr - 1) + 1];
     hipEvent_t e0, e1;
     if ((rc = ev_pair(c, "eval_h", &e0, &e1))) return rc;
+    const char* mode = getenv("EZKL_EVALH_MODE");                 // "interp" forces the interpreter
+    hipFunction_t jfn = nullptr;
+    const bool use_jit = !(mode && !strcmp(mode, "interp")) && jit_get(p, rot, &jfn) == EZKL_OK;
     EZ_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(eval_program_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, a);
+    if (use_jit) {
+        const fe_t* const* d_cols = a.columns;
+        const fe_t* d_consts = a.constants;
+        const fe_t* d_chal = a.challenges;
+        fe_t* d_out = out;
+        uint32_t ne_mask = a.ne_mask, Tj = a.T;
+        void* args[] = {&d_cols, &d_consts, &d_chal, &d_out, &ne_mask, &Tj};
+        EZ_HIP(hipModuleLaunchKernel(jfn, cdiv(T, 256), 1, 1, 256, 1, 1, 0, st, args, nullptr));
+    } else {
+        hipLaunchKernelGGL(eval_program_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, a);
+    }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
     EZ_HIP(hipStreamSynchronize(st));   // the host-side program arrays are borrowed only for the call

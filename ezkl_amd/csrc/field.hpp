@@ -9,8 +9,14 @@
 // fully unrolled so the 8 limbs of every operand live in VGPRs and the modulus limbs become SGPR/literal
 // operands.  No MFMA: this is modular integer arithmetic (BASELINE.json north_star).
 #pragma once
+#ifndef __HIPCC_RTC__            // hiprtc (the eval_h JIT) supplies the HIP builtins itself
 #include <stdint.h>
 #include <hip/hip_runtime.h>
+#else
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#endif
 #include "bn254_constants.h"
 
 #define EZ_HD __host__ __device__ __forceinline__

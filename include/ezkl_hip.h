@@ -115,6 +115,9 @@ typedef struct {
 } ezkl_program_t;
 /* out_dev[r] = program(row r) with ValueSource::PreviousValue = old out_dev[r]; 2^ext_k rows */
 int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out_dev, void* stream);
+/* the sweep is JIT-compiled (hiprtc) into straight-line gfx950 code, once per program; this host-only call
+ * checks that a program lowers and compiles (column pointers are not dereferenced; no GPU needed) */
+int ezkl_hip_eval_h_check(const ezkl_program_t* prog);
 
 /* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
 /* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */

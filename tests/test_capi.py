@@ -61,3 +61,15 @@ def test_host_side_point_add_matches_oracle():
     neg[4:] = np.frombuffer(((Q - y) % Q).to_bytes(32, "little"), np.uint64)
     assert (g1_add_affine(b[3], neg) == 0).all()                                 # P + (-P) = identity
     assert (g1_add_affine(np.zeros(8, np.uint64), b[4]) == b[4]).all()
+
+
+def test_eval_h_program_jit_compiles_offline():
+    """the quotient-sweep JIT: a gate program lowers to HIP source and hiprtc compiles it for gfx950 here"""
+    from ezkl_amd import backend as B
+    from conftest import fe_from_int
+    prog = B.GraphProgram(4, 6)
+    a, b, o = prog.column(0), prog.column(1, 1), prog.column(2, -1)
+    g = prog.calc("mul", prog.column(3), prog.calc("sub", o, prog.calc("mul", a, b)))
+    h = prog.calc("negate", prog.calc("double", prog.calc("square", prog.calc("add", g, prog.constant(fe_from_int(5))))))
+    prog.horner(prog.previous(), [g, h], prog.challenge(0))
+    prog.check_compiles(4)

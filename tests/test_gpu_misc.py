@@ -46,15 +46,61 @@ def _gate_program(B, k, ek):
     return prog
 
 
+@pytest.mark.parametrize("mode", ["jit", "interp"])
 @pytest.mark.parametrize("k,ek", [(3, 5), (8, 10), (12, 15)])
-def test_eval_h_program(hip, k, ek):
+def test_eval_h_program(hip, k, ek, mode, monkeypatch):
     from ezkl_amd import backend as B
+    monkeypatch.setenv("EZKL_EVALH_MODE", mode)
     rng = np.random.default_rng(k)
     ne = 1 << ek
     cols = [rand_fr(rng, ne) for _ in range(4)]
     chal = rand_fr(rng, 2)
     prev = rand_fr(rng, ne)
     prog = _gate_program(B, k, ek)
+    code, consts, rots = prog.arrays()
+    want = ob.eval_program(code, prog.n_intermediates, consts, rots, cols, chal, k, ek, previous=prev)
+    dcols = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    dout = B.DeviceBuffer.from_numpy(prev)
+    prog.evaluate_h([d.ptr for d in dcols], chal, dout.ptr)
+    assert (dout.to_numpy(shape=(ne, 4)) == want).all()
+
+
+def _random_program(B, rng, k, ek, ncols, ninstr):
+    """a random straight-line DAG with long- and short-lived values: exercises slot reuse and spilling"""
+    prog = B.GraphProgram(k, ek)
+    vals = []
+    ops2, ops1 = ["add", "sub", "mul"], ["square", "double", "negate"]
+    for _ in range(ninstr):
+        def src():
+            r = rng.random()
+            if vals and r < 0.55:
+                # bias to recent values, but keep some old ones alive
+                return vals[-1 - int(rng.integers(0, min(len(vals), 6)))] if rng.random() < 0.7 else vals[int(rng.integers(0, len(vals)))]
+            if r < 0.85:
+                return prog.column(int(rng.integers(0, ncols)), int(rng.integers(-2, 3)))
+            if r < 0.93:
+                return prog.challenge(int(rng.integers(0, 3)))
+            return prog.constant(fe_from_int(int(rng.integers(1, 1 << 30))))
+        if rng.random() < 0.8:
+            vals.append(prog.calc(ops2[int(rng.integers(0, 3))], src(), src()))
+        else:
+            vals.append(prog.calc(ops1[int(rng.integers(0, 3))], src()))
+    prog.horner(prog.previous(), vals[-40:], prog.challenge(0))
+    return prog
+
+
+@pytest.mark.parametrize("mode", ["jit", "interp"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_eval_h_random_dag(hip, seed, mode, monkeypatch):
+    from ezkl_amd import backend as B
+    monkeypatch.setenv("EZKL_EVALH_MODE", mode)
+    rng = np.random.default_rng(seed)
+    k, ek, ncols = 9, 11, 12
+    ne = 1 << ek
+    cols = [rand_fr(rng, ne) for _ in range(ncols)]
+    chal = rand_fr(rng, 3)
+    prev = rand_fr(rng, ne)
+    prog = _random_program(B, rng, k, ek, ncols, 300)
     code, consts, rots = prog.arrays()
     want = ob.eval_program(code, prog.n_intermediates, consts, rots, cols, chal, k, ek, previous=prev)
     dcols = [B.DeviceBuffer.from_numpy(c) for c in cols]
