@@ -189,6 +189,16 @@ def vec_op(op, a_ptr, b_ptr, out_ptr, n, stream=None):
                                             _stream_ptr(stream)), "ezkl_hip_vec_op_dev")
 
 
+def prefix_scan(op, in_ptr, out_ptr, n, exclusive=False, stream=None):
+    code = {"add": 0, "mul": 2}[op]
+    _l.check(_l.load().ezkl_hip_prefix_scan_dev(C.c_int(code), C.c_int(1 if exclusive else 0), _vp(in_ptr), _vp(out_ptr),
+                                                 C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_prefix_scan_dev")
+
+
+def batch_invert(ptr, n, stream=None):
+    _l.check(_l.load().ezkl_hip_batch_invert_dev(_vp(ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_batch_invert_dev")
+
+
 # Montgomery constants needed host-side (derived, not copied: tools/gen_constants.py)
 _R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 _MONT = 1 << 256
@@ -341,3 +351,77 @@ def ubench(which):
     out = C.c_double(0)
     _l.check(_l.load().ezkl_hip_ubench(which.encode(), C.byref(out)), "ezkl_hip_ubench")
     return float(out.value)
+
+
+# ---------------------------------------------------------------------------------------------------
+# A13 helpers composed from the kernels above ([UPSTREAM] halo2 permutation::prover::commit
+# and mv_lookup::prover::commit_grand_sum).  Everything stays resident; blinding rows / RNG stay with the caller.
+_DELTA = pow(7, 1 << 28, _R)
+
+
+def omega_powers_column(k):
+    """device column X[i] = omega_k^i (built with an exclusive product scan of a constant column)"""
+    n = 1 << k
+    w = pow(EvaluationDomain.ROOT, 1 << (28 - k), _R)
+    col = DeviceBuffer.from_numpy(np.tile(_to_mont(w), (n, 1)))
+    prefix_scan("mul", col.ptr, col.ptr, n, exclusive=True)
+    return col
+
+
+def permutation_grand_product(k, value_cols, sigma_cols, beta, gamma, omega_col=None, first_column_index=0, z0=None):
+    """z[0] = z0 (1), z[i+1] = z[i] * prod_j (v_j[i] + beta*delta^(j0+j)*omega^i + gamma) / (v_j[i] + beta*sigma_j[i] + gamma)
+    for one chunk of permutation columns.  value_cols / sigma_cols: lists of device pointers (n rows each).
+    Returns a DeviceBuffer with z[0..n) (the caller overwrites the blinding rows)."""
+    n = 1 << k
+    m = len(value_cols)
+    omega_col = omega_col or omega_powers_column(k)
+    beta_i, gamma_i = _from_mont_int(beta), _from_mont_int(gamma)
+    # denominators and numerators as two straight-line programs over [values..., sigmas..., X]
+    cols = list(value_cols) + list(sigma_cols) + [omega_col.ptr]
+    chal = [_to_mont(beta_i), _to_mont(gamma_i)] + [_to_mont(beta_i * pow(_DELTA, first_column_index + j, _R) % _R) for j in range(m)]
+    den = GraphProgram(k, k)
+    acc = None
+    for j in range(m):
+        t = den.calc("add", den.calc("add", den.calc("mul", den.challenge(0), den.column(m + j)), den.challenge(1)), den.column(j))
+        acc = t if acc is None else den.calc("mul", acc, t)
+    num = GraphProgram(k, k)
+    accn = None
+    for j in range(m):
+        t = num.calc("add", num.calc("add", num.calc("mul", num.challenge(2 + j), num.column(2 * m)), num.challenge(1)), num.column(j))
+        accn = t if accn is None else num.calc("mul", accn, t)
+    d_den, d_num = DeviceBuffer(n * 32), DeviceBuffer(n * 32)
+    den.evaluate_h(cols, chal, d_den.ptr)
+    num.evaluate_h(cols, chal, d_num.ptr)
+    batch_invert(d_den.ptr, n)
+    vec_op("mul", d_num.ptr, d_den.ptr, d_num.ptr, n)                   # ratio[i]
+    prefix_scan("mul", d_num.ptr, d_num.ptr, n, exclusive=True)          # z[i] = prod_{r<i} ratio[r]
+    if z0 is not None:
+        _l.check(_l.load().ezkl_hip_vec_scale_dev(_vp(d_num.ptr), _p(_fe(z0)), _vp(d_num.ptr), C.c_size_t(n), _vp(None)), "vec_scale")
+    d_den.free()
+    return d_num
+
+
+def lookup_grand_sum(k, input_cols, table_col, m_col, beta):
+    """phi[0] = 0, phi[i+1] = phi[i] + sum_j 1/(f_j[i] + beta) - m[i]/(t[i] + beta)   (mv-lookup / logUp running sum)"""
+    n = 1 << k
+    nin = len(input_cols)
+    chal = [_fe(beta)]
+    acc = DeviceBuffer.from_numpy(np.zeros((n, 4), np.uint64))
+    tmp = DeviceBuffer(n * 32)
+    shift = GraphProgram(k, k)
+    shift.calc("add", shift.column(0), shift.challenge(0))
+    for j in range(nin):
+        shift.evaluate_h([input_cols[j]], chal, tmp.ptr)
+        batch_invert(tmp.ptr, n)
+        vec_op("add", acc.ptr, tmp.ptr, acc.ptr, n)
+    shift.evaluate_h([table_col], chal, tmp.ptr)
+    batch_invert(tmp.ptr, n)
+    vec_op("mul", tmp.ptr, m_col, tmp.ptr, n)
+    vec_op("sub", acc.ptr, tmp.ptr, acc.ptr, n)
+    prefix_scan("add", acc.ptr, acc.ptr, n, exclusive=True)
+    tmp.free()
+    return acc
+
+
+def _from_mont_int(a):
+    return int.from_bytes(np.ascontiguousarray(a, np.uint64).tobytes(), "little") * pow(_MONT, -1, _R) % _R

@@ -323,6 +323,12 @@ int ezkl_hip_batch_invert_dev(void* a, size_t n, void* stream) {
     return batch_invert(c, pick_stream(c, stream), (fe_t*)a, n);
 }
 
+int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in, void* out, size_t n, void* stream) {
+    if (!in || !out || (op != EZKL_VEC_ADD && op != EZKL_VEC_MUL)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return prefix_scan(c, pick_stream(c, stream), op, exclusive, (const fe_t*)in, (fe_t*)out, n);
+}
+
 int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out, void* stream) {
     if (!prog || !out) return EZKL_ERR_INVALID;
     EZ_CTX(c);

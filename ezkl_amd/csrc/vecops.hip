@@ -108,4 +108,80 @@ int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n) {
     return EZKL_OK;
 }
 
+// ---- prefix scan over Fr (grand product of the permutation argument, grand sum of mv-lookup: SURVEY §8(a) A13) ----
+// Three-phase scan: each workgroup scans a 2048-element chunk (8 consecutive elements per lane serially, lane
+// totals by a Hillis-Steele scan in LDS), chunk totals are scanned recursively, then chunk prefixes are applied.
+// 3 field operations per element; for the product scan that is 3 Montgomery products per element.
+static constexpr uint32_t SCAN_E = 8, SCAN_CHUNK = 256 * SCAN_E;
+
+template <int OP> EZ_D fe_t scan_op(const fe_t& a, const fe_t& b) { return OP == EZKL_VEC_ADD ? Fr::add(a, b) : Fr::mul(a, b); }
+template <int OP> EZ_D fe_t scan_id() { return OP == EZKL_VEC_ADD ? Fr::zero() : Fr::one(); }
+
+template <int OP>
+__global__ __launch_bounds__(256) void scan_chunk_kernel(const fe_t* in, fe_t* out, size_t n, fe_t* totals, int exclusive) {
+    __shared__ fe_t sh[256];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_E;
+    fe_t x[SCAN_E];
+    fe_t run = scan_id<OP>();
+#pragma unroll
+    for (uint32_t e = 0; e < SCAN_E; e++) {
+        x[e] = base + e < n ? ld_fe(in + base + e) : scan_id<OP>();
+        run = scan_op<OP>(run, x[e]);
+        x[e] = run;                                    // inclusive within the lane
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {           // inclusive Hillis-Steele over lane totals
+        fe_t v = sh[threadIdx.x];
+        if (threadIdx.x >= d) v = scan_op<OP>(sh[threadIdx.x - d], v);
+        __syncthreads();
+        sh[threadIdx.x] = v;
+        __syncthreads();
+    }
+    const fe_t lane_prefix = threadIdx.x ? sh[threadIdx.x - 1] : scan_id<OP>();
+    if (threadIdx.x == 255) st_fe(totals + blockIdx.x, sh[255]);
+    fe_t prev = lane_prefix;
+#pragma unroll
+    for (uint32_t e = 0; e < SCAN_E; e++) {
+        fe_t inc = scan_op<OP>(lane_prefix, x[e]);
+        if (base + e < n) st_fe(out + base + e, exclusive ? prev : inc);
+        prev = inc;
+    }
+}
+template <int OP>
+__global__ __launch_bounds__(256) void scan_apply_kernel(fe_t* out, size_t n, const fe_t* chunk_prefix) {
+    const size_t chunk = blockIdx.x + 1;               // chunk 0 needs no prefix
+    const fe_t p = ld_fe(chunk_prefix + chunk);
+    for (uint32_t e = threadIdx.x; e < SCAN_CHUNK; e += 256) {
+        size_t i = chunk * SCAN_CHUNK + e;
+        if (i < n) st_fe(out + i, scan_op<OP>(p, ld_fe(out + i)));
+    }
+}
+template <int OP>
+static int scan_rec(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, size_t n, int exclusive, fe_t* scratch) {
+    const unsigned chunks = cdiv(n, SCAN_CHUNK);
+    fe_t* totals = scratch;                            // chunks entries, then exclusive-scanned in place
+    hipLaunchKernelGGL(scan_chunk_kernel<OP>, dim3(chunks), dim3(256), 0, st, in, out, n, totals, exclusive);
+    if (chunks > 1) {
+        int rc = scan_rec<OP>(c, st, totals, totals, chunks, 1, scratch + (((size_t)chunks + 63) & ~(size_t)63));
+        if (rc) return rc;
+        hipLaunchKernelGGL(scan_apply_kernel<OP>, dim3(chunks - 1), dim3(256), 0, st, out, n, totals);
+    }
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, fe_t* out, size_t n) {
+    if (n == 0) return EZKL_OK;
+    size_t need = 0;
+    for (size_t m = n; m > 1;) { m = (m + SCAN_CHUNK - 1) / SCAN_CHUNK; need += (m + 63) & ~(size_t)63; }
+    fe_t* scratch = nullptr;
+    EZ_HIP(hipMalloc(&scratch, (need + 64) * sizeof(fe_t)));
+    int rc = op == EZKL_VEC_ADD ? scan_rec<EZKL_VEC_ADD>(c, st, in, out, n, exclusive, scratch)
+                                : scan_rec<EZKL_VEC_MUL>(c, st, in, out, n, exclusive, scratch);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+    if (!rc && e != hipSuccess) rc = set_hip_error(e, "scan sync", __FILE__, __LINE__);
+    return rc;
+}
+
 }  // namespace ezkl

@@ -96,6 +96,10 @@ int ezkl_hip_vec_op_dev(int op, const void* a_dev, const void* b_dev, void* out_
 int ezkl_hip_vec_scale_dev(const void* a_dev, const void* scalar_host, void* out_dev, size_t n, void* stream);
 /* a[i] *= t[i mod 2^(ext_k-k)], t = 1/((zeta*omega_ext^j)^n - 1): EvaluationDomain::divide_by_vanishing_poly */
 int ezkl_hip_divide_by_vanishing_dev(void* a_dev, uint32_t k, uint32_t ext_k, void* stream);
+/* running sum (EZKL_VEC_ADD) / running product (EZKL_VEC_MUL): out[i] = in[0] o ... o in[i] (inclusive) or
+ * o in[i-1] with out[0] = identity (exclusive): the grand sum of mv-lookup::commit_grand_sum and the grand
+ * product z(X) of permutation::commit.  in == out allowed. */
+int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in_dev, void* out_dev, size_t n, void* stream);
 /* Montgomery batch inversion (zeros stay zero), in place */
 int ezkl_hip_batch_invert_dev(void* a_dev, size_t n, void* stream);
 

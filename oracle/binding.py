@@ -107,6 +107,12 @@ def batch_invert(a):
     a = _fe(a).copy(); lib.oracle_batch_invert(_ptr(a), C.c_size_t(a.shape[0])); return a
 
 
+def prefix_scan(a, op, exclusive=False):
+    a = _fe(a); o = np.empty_like(a)
+    lib.oracle_prefix_scan(_ptr(a), _ptr(o), C.c_size_t(a.shape[0]), C.c_int({"add": 0, "mul": 2}[op]), C.c_int(1 if exclusive else 0))
+    return o
+
+
 def vec_op(name, a, b):
     a, b = _fe(a), _fe(b); o = np.empty_like(a)
     getattr(lib, "oracle_vec_" + name)(_ptr(a), _ptr(b), _ptr(o), C.c_size_t(a.shape[0])); return o

@@ -377,6 +377,17 @@ void oracle_batch_invert(fe *a, size_t n) {
     free(pre);
 }
 
+/* running sum / product (permutation grand product z, mv-lookup grand sum phi); op 0 = add, 2 = mul */
+void oracle_prefix_scan(const fe *in, fe *out, size_t n, int op, int exclusive) {
+    fe acc = op == 0 ? (fe){{0, 0, 0, 0}} : FR.one;
+    for (size_t i = 0; i < n; i++) {
+        fe x = in[i];
+        if (exclusive) out[i] = acc;
+        if (op == 0) f_add(&acc, &acc, &x, &FR); else f_mul(&acc, &acc, &x, &FR);
+        if (!exclusive) out[i] = acc;
+    }
+}
+
 /* ------------------------------------------------------------------ GraphEvaluator ---------- */
 /* Program format (shared with include/ezkl_hip.h): 8 x u32 per instruction
  *   [op, target, s0.kind, s0.idx, s0.rot, s1.kind, s1.idx, s1.rot]

@@ -30,6 +30,22 @@ def test_batch_invert(hip, n):
     assert (d.to_numpy(shape=(n, 4)) == ob.batch_invert(a)).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 255, 2048, 2049, 5000, 1 << 16, (1 << 22) + 3])
+@pytest.mark.parametrize("op", ["add", "mul"])
+def test_prefix_scan(hip, n, op):
+    """grand sum / grand product building block (mv-lookup commit_grand_sum, permutation commit)"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n)
+    a = rand_fr(rng, n)
+    d = B.DeviceBuffer.from_numpy(a)
+    o = B.DeviceBuffer(n * 32)
+    for excl in (False, True):
+        B.prefix_scan(op, d.ptr, o.ptr, n, exclusive=excl)
+        assert (o.to_numpy(shape=(n, 4)) == ob.prefix_scan(a, op, exclusive=excl)).all()
+    B.prefix_scan(op, d.ptr, d.ptr, n)                         # in place
+    assert (d.to_numpy(shape=(n, 4)) == ob.prefix_scan(a, op)).all()
+
+
 def _gate_program(B, k, ek):
     """a small ezkl-like gate set: sel*(out - a*b) (chip.rs:344-393), a rotation -1 accumulator
     (chip.rs:352-425), folded with y by Horner exactly as evaluate_h does"""
@@ -116,3 +132,43 @@ def test_eval_h_rejects_bad_program(hip):
     d = B.DeviceBuffer(32 << 5)
     with pytest.raises(hip.EzklHipError):
         prog.evaluate_h([d.ptr], np.zeros((1, 4), np.uint64), d.ptr)
+
+
+def test_permutation_grand_product_and_lookup_sum(hip):
+    """A13: z(X) of the permutation argument and phi(X) of mv-lookup, composed from eval/batch-invert/scan
+    kernels, against a direct big-int evaluation of the defining recurrences"""
+    from ezkl_amd import backend as B
+    from conftest import fe_to_int
+    from oracle import pyref as pr
+    rng = np.random.default_rng(9)
+    k, m = 6, 3
+    n = 1 << k
+    vals = [rand_fr(rng, n) for _ in range(m)]
+    sigmas = [rand_fr(rng, n) for _ in range(m)]
+    beta, gamma = rand_fr(rng, 1)[0], rand_fr(rng, 1)[0]
+    dv = [B.DeviceBuffer.from_numpy(v) for v in vals]
+    ds = [B.DeviceBuffer.from_numpy(v) for v in sigmas]
+    z = B.permutation_grand_product(k, [d.ptr for d in dv], [d.ptr for d in ds], beta, gamma, first_column_index=2).to_numpy(shape=(n, 4))
+    b, g, w = fe_to_int(beta), fe_to_int(gamma), pr.omega(k)
+    V = [[fe_to_int(x) for x in v] for v in vals]
+    S = [[fe_to_int(x) for x in v] for v in sigmas]
+    acc = 1
+    for i in range(n):
+        assert fe_to_int(z[i]) == acc
+        num = den = 1
+        for j in range(m):
+            num = num * (V[j][i] + b * pow(pr.DELTA, 2 + j, R) * pow(w, i, R) + g) % R
+            den = den * (V[j][i] + b * S[j][i] + g) % R
+        acc = acc * num * pow(den, -1, R) % R
+    # mv-lookup running sum
+    f = [rand_fr(rng, n) for _ in range(2)]
+    t, mm = rand_fr(rng, n), rand_fr(rng, n)
+    df = [B.DeviceBuffer.from_numpy(v) for v in f]
+    dt, dm = B.DeviceBuffer.from_numpy(t), B.DeviceBuffer.from_numpy(mm)
+    phi = B.lookup_grand_sum(k, [d.ptr for d in df], dt.ptr, dm.ptr, beta).to_numpy(shape=(n, 4))
+    F = [[fe_to_int(x) for x in v] for v in f]
+    T, M = [fe_to_int(x) for x in t], [fe_to_int(x) for x in mm]
+    acc = 0
+    for i in range(n):
+        assert fe_to_int(phi[i]) == acc
+        acc = (acc + sum(pow(F[j][i] + b, -1, R) for j in range(2)) - M[i] * pow(T[i] + b, -1, R)) % R
