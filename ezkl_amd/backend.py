@@ -114,6 +114,15 @@ def msm_g1_dev(bases, scalars_ptr, n, offset=0, stream=None):
     return out
 
 
+def msm_g1_batch_dev(bases, scalar_ptrs, n, offset=0, stream=None):
+    """batch of MSMs over resident scalar vectors (one commit phase); returns (batch, 8) affine points"""
+    out = np.zeros((len(scalar_ptrs), 8), np.uint64)
+    arr = (C.c_void_p * len(scalar_ptrs))(*scalar_ptrs)
+    _l.check(_l.load().ezkl_hip_msm_g1_batch_dev(bases.h, C.c_size_t(offset), arr, C.c_size_t(len(scalar_ptrs)), C.c_size_t(n),
+                                                  _p(out), _stream_ptr(stream)), "ezkl_hip_msm_g1_batch_dev")
+    return out
+
+
 def msm_g1(bases, scalars):
     """sum_i scalars[i]*bases[i]; scalars numpy (n,4) or a DeviceBuffer-resident vector via msm_dev."""
     s = _fe(scalars)

@@ -211,13 +211,36 @@ int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out) {
     (void)hipFree(d);
     return rc;
 }
+int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* const* scalars_dev, size_t batch, size_t n,
+                              void* out, void* stream) {
+    if (!h || !scalars_dev || !out) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (base_offset + n > b->n) return EZKL_ERR_INVALID;
+    for (size_t i = 0; i < batch; i++)
+        if (!scalars_dev[i] && n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_run_batch(c, pick_stream(c, stream), b, base_offset, (const fe_t* const*)scalars_dev, batch, n, out);
+}
 int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t batch, size_t n, void* out) {
-    if (!scalars || !out) return EZKL_ERR_INVALID;
-    for (size_t i = 0; i < batch; i++) {
-        int rc = ezkl_hip_msm_g1(h, scalars[i], n, (uint8_t*)out + 64 * i);
-        if (rc) return rc;
+    if (!h || !scalars || !out) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (n > b->n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (n == 0 || batch == 0) { memset(out, 0, 64 * batch); return EZKL_OK; }
+    // stage the host columns in HBM (one allocation), then run the pipelined device batch
+    fe_t* d = nullptr;
+    EZ_HIP(hipMalloc(&d, batch * n * 32));
+    std::vector<const void*> ptrs(batch);
+    int rc = EZKL_OK;
+    for (size_t i = 0; i < batch && !rc; i++) {
+        if (!scalars[i]) { rc = EZKL_ERR_INVALID; break; }
+        hipError_t e = hipMemcpyAsync(d + i * n, scalars[i], n * 32, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = set_hip_error(e, "h2d", __FILE__, __LINE__);
+        ptrs[i] = d + i * n;
     }
-    return EZKL_OK;
+    if (!rc) rc = msm_run_batch(c, c->stream, b, 0, (const fe_t* const*)ptrs.data(), batch, n, out);
+    (void)hipFree(d);
+    return rc;
 }
 int ezkl_hip_g1_add_affine(const void* a, const void* b, void* out) {
     if (!a || !b || !out) return EZKL_ERR_INVALID;

@@ -406,11 +406,58 @@ void msm_table_drop(const Bases* b) {
     }
 }
 
-int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {
-    if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
-    MsmTable* T = nullptr;
-    int rc = table_get(c, st, b, &T);
-    if (rc) return rc;
+// One in-flight MSM: its own scratch arena, a pinned landing buffer for the plane sums and a completion event.
+// A batch (one commit phase of the prover) is pipelined over MSM_SLOTS of these on separate streams so that the
+// latency-bound sort / reduce tails of one MSM and the host Horner overlap the accumulate kernel of the next.
+static constexpr int MSM_SLOTS = 3;
+struct MsmSlot {
+    hipStream_t st = nullptr;
+    uint8_t* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    h64::xyzz* pinned = nullptr;      // 1 + 22 planes
+    hipEvent_t done = nullptr;
+    uint32_t bits = 0;
+    bool busy = false;
+};
+static MsmSlot g_slots[MSM_SLOTS];
+
+static int slot_prepare(MsmSlot& sl, size_t bytes) {
+    if (!sl.st) {
+        EZ_HIP(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        EZ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        EZ_HIP(hipHostMalloc((void**)&sl.pinned, 32 * sizeof(h64::xyzz), hipHostMallocDefault));
+    }
+    if (bytes > sl.scratch_bytes) {
+        if (sl.scratch) {
+            EZ_HIP(hipStreamSynchronize(sl.st));
+            EZ_HIP(hipFree(sl.scratch));
+            sl.scratch = nullptr;
+            sl.scratch_bytes = 0;
+        }
+        size_t want = bytes + (bytes >> 4);
+        EZ_HIP(hipMalloc((void**)&sl.scratch, want));
+        sl.scratch_bytes = want;
+    }
+    return EZKL_OK;
+}
+// host tail: result = TOTAL + sum_k 2^k * plane[1+k] (Horner from the top bit), then canonical affine
+static int msm_finish(MsmSlot& sl, void* out_host) {
+    EZ_HIP(hipEventSynchronize(sl.done));
+    const h64::xyzz* hp = sl.pinned;
+    h64::xyzz acc = h64::identity();
+    for (int k = (int)sl.bits - 1; k >= 0; k--) {
+        acc = h64::dbl(acc);
+        acc = h64::add(acc, hp[1 + k]);
+    }
+    acc = h64::add(acc, hp[0]);
+    h64::aff r = h64::to_affine(acc);
+    memcpy(out_host, &r, 64);
+    sl.busy = false;
+    return EZKL_OK;
+}
+
+static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t base_offset, const fe_t* scalars, size_t n, bool timed) {
+    int rc = EZKL_OK;
     const uint32_t cw = T->c, W = T->W, bits = cw - 1;
     const uint32_t nb = 1u << bits;
     const size_t npairs = n * W;
@@ -460,9 +507,9 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     size_t o_partA = carve((size_t)n_partA * sizeof(g1x_t)), o_partT = carve((size_t)n_partT * sizeof(g1x_t));
     size_t o_SA = carve((size_t)nA * sizeof(g1x_t)), o_T = carve((size_t)nT * sizeof(g1x_t));
     size_t o_planes = carve((size_t)nplanes * sizeof(g1x_t));
-    uint8_t* S = nullptr;
-    rc = scratch_reserve(c, off, (void**)&S);
+    rc = slot_prepare(sl, off);
     if (rc) return rc;
+    uint8_t* S = sl.scratch;
     uint2* entries = (uint2*)(S + o_ent);
     uint32_t* vals = (uint32_t*)(S + o_vals);
     uint32_t* offs = (uint32_t*)(S + o_offs);
@@ -472,10 +519,12 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     g1x_t *partA = (g1x_t*)(S + o_partA), *partT = (g1x_t*)(S + o_partT), *SA = (g1x_t*)(S + o_SA), *TT = (g1x_t*)(S + o_T);
     g1x_t* planes = (g1x_t*)(S + o_planes);
 
-    hipEvent_t m0, m1, a0, a1;
-    if ((rc = ev_pair(c, "msm", &m0, &m1))) return rc;
-    if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
-    EZ_HIP(hipEventRecord(m0, st));
+    hipEvent_t m0 = nullptr, m1 = nullptr, a0 = nullptr, a1 = nullptr;
+    if (timed) {
+        if ((rc = ev_pair(c, "msm", &m0, &m1))) return rc;
+        if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
+        EZ_HIP(hipEventRecord(m0, st));
+    }
     EZ_HIP(hipMemsetAsync(pcnt, 0, (NP + 1) * 4, st));
     EZ_HIP(hipMemsetAsync(hcnt, 0, 4, st));
     EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x_t), st));          // empty buckets = identity (ZZ = 0)
@@ -491,9 +540,9 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
                        pcur, entries);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals);
     // accumulate
-    EZ_HIP(hipEventRecord(a0, st));
+    if (timed) EZ_HIP(hipEventRecord(a0, st));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail);
-    EZ_HIP(hipEventRecord(a1, st));
+    if (timed) EZ_HIP(hipEventRecord(a1, st));
     hipLaunchKernelGGL(msm_fixup_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, offs, nb, L, head, tail, bkt, heavy, hcnt);
     {
         size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
@@ -508,19 +557,46 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
         hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes), dim3(256), 0, st, SA, TT, rg, planes);
     }
     EZ_HIP(hipGetLastError());
-    EZ_HIP(hipEventRecord(m1, st));
-    std::vector<h64::xyzz> hp(nplanes);
-    EZ_HIP(hipMemcpyAsync(hp.data(), planes, (size_t)nplanes * sizeof(g1x_t), hipMemcpyDeviceToHost, st));
-    EZ_HIP(hipStreamSynchronize(st));
-    // host: result = TOTAL + sum_k 2^k * plane[1+k]  (Horner from the top bit), then canonical affine
-    h64::xyzz acc = h64::identity();
-    for (int k = (int)bits - 1; k >= 0; k--) {
-        acc = h64::dbl(acc);
-        acc = h64::add(acc, hp[1 + k]);
+    if (timed) EZ_HIP(hipEventRecord(m1, st));
+    EZ_HIP(hipMemcpyAsync(sl.pinned, planes, (size_t)nplanes * sizeof(g1x_t), hipMemcpyDeviceToHost, st));
+    EZ_HIP(hipEventRecord(sl.done, st));
+    sl.bits = bits;
+    sl.busy = true;
+    return EZKL_OK;
+}
+
+int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {
+    if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
+    MsmTable* T = nullptr;
+    int rc = table_get(c, st, b, &T);
+    if (rc) return rc;
+    MsmSlot& sl = g_slots[0];
+    if (sl.busy) return EZKL_ERR_INVALID;
+    if ((rc = msm_enqueue(c, sl, st, T, base_offset, scalars, n, true))) return rc;
+    return msm_finish(sl, out_host);
+}
+
+// `batch` independent MSMs against the same bases (the advice-column commits of one prover phase), pipelined
+// over MSM_SLOTS streams.  `st` orders the batch after prior work on the caller's stream.
+int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
+                  void* out_host) {
+    if (batch == 0) return EZKL_OK;
+    if (n == 0) { memset(out_host, 0, 64 * batch); return EZKL_OK; }
+    MsmTable* T = nullptr;
+    int rc = table_get(c, st, b, &T);
+    if (rc) return rc;
+    EZ_HIP(hipStreamSynchronize(st));          // inputs produced on the caller's stream are complete
+    for (size_t j = 0; j < batch + MSM_SLOTS; j++) {
+        if (j >= MSM_SLOTS) {                  // retire the MSM that used this slot MSM_SLOTS iterations ago
+            size_t done = j - MSM_SLOTS;
+            if (done < batch && (rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done))) return rc;
+        }
+        if (j < batch) {
+            MsmSlot& sl = g_slots[j % MSM_SLOTS];
+            if ((rc = slot_prepare(sl, 0))) return rc;
+            if ((rc = msm_enqueue(c, sl, sl.st, T, base_offset, scalars[j], n, false))) return rc;
+        }
     }
-    acc = h64::add(acc, hp[0]);
-    h64::aff r = h64::to_affine(acc);
-    memcpy(out_host, &r, 64);
     return EZKL_OK;
 }
 

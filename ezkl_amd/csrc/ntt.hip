@@ -269,9 +269,27 @@ static int plan_get(Ctx* c, hipStream_t st, uint32_t log_n, const fe_t& omega, N
 
 // coset_mode: 0 plain; 1 coeff_to_extended (pre-multiply zeta^i, zero-pad from 2^in_log_len);
 //             2 extended_to_coeff (post-multiply zeta^-i; implies inverse_scale)
+static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
+                         size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode);
+
+// columns are transformed in groups so that the ping-pong work buffer stays <= 4 GiB and gridDim.y <= 65535
 int ntt_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
             size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode) {
     if (log_n > 28 || in_log_len > log_n || batch == 0) return EZKL_ERR_INVALID;
+    size_t group = ((size_t)4 << 30) / ((size_t)32 << log_n);
+    if (group < 1) group = 1;
+    if (group > 32768) group = 32768;
+    for (size_t b0 = 0; b0 < batch; b0 += group) {
+        size_t nb = batch - b0 < group ? batch - b0 : group;
+        int rc = ntt_run_chunk(c, st, in + b0 * in_stride, out + b0 * out_stride, log_n, omega, inverse_scale, nb, in_stride, out_stride,
+                               in_log_len, coset_mode);
+        if (rc) return rc;
+    }
+    return EZKL_OK;
+}
+
+static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
+                         size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode) {
     NttPlan* p = nullptr;
     int rc = plan_get(c, st, log_n, omega, &p);
     if (rc) return rc;

@@ -69,6 +69,10 @@ int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_
                         void* out_affine, void* stream);
 /* batch of `batch` scalar vectors against the same bases (one commit per advice column) */
 int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t batch, size_t n, void* out_affine);
+/* the same with every scalar vector resident in HBM (array of DEVICE pointers held in host memory); the MSMs are
+ * pipelined over several streams so the short reduce/sort kernels of one overlap the accumulation of the next */
+int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* const* scalars_dev, size_t batch, size_t n,
+                              void* out_affine, void* stream);
 /* out = a + b on affine points (host, used to fold per-GPU partial sums after the all-gather) */
 int ezkl_hip_g1_add_affine(const void* a, const void* b, void* out);
 

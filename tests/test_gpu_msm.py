@@ -102,3 +102,26 @@ def test_full_size_2_20(hip):
     p1 = B.msm_g1_dev(bases, b1hi.ptr, half, offset=half)
     assert (B.g1_add_affine(p0, p1) == c).all()
     bases.free()
+
+
+@pytest.mark.parametrize("n,batch", [(1000, 7), (1 << 14, 5), (1 << 18, 4)])
+def test_batch_pipelined_matches_single(hip, n, batch):
+    """one commit phase: `batch` columns against the same bases, pipelined over streams"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n + batch)
+    pts = ob.gen_bases(SEED, n)
+    bases = B.Bases(pts)
+    cols = [rand_fr(rng, n) for _ in range(batch)]
+    cols[1] = witness_like(rng, n) if n <= (1 << 14) else cols[1]
+    dcols = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    got = B.msm_g1_batch_dev(bases, [d.ptr for d in dcols], n)
+    for j in range(batch):
+        assert (got[j] == ob.msm(cols[j], pts)).all()
+    # host-pointer batch entry point (what commit of a Vec<Polynomial> binds)
+    import ctypes as C
+    from ezkl_amd import lib as L
+    out = np.zeros((batch, 8), np.uint64)
+    arr = (C.c_void_p * batch)(*[c.ctypes.data for c in cols])
+    L.check(L.load().ezkl_hip_msm_g1_batch(bases.h, arr, C.c_size_t(batch), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "batch")
+    assert (out == got).all()
+    bases.free()
