@@ -104,3 +104,23 @@ def test_full_size_2_22_properties(hip):
     w = pr.omega(k)
     j = 123457
     assert fe_to_int(f[j]) == sum(v * pow(w, i * j, R) for i, v in enumerate(ints)) % R
+
+
+def test_device_resident_pk_columns(hip, golden_pk):
+    """pk columns loaded into HBM; the coset NTT of the resident fixed polys reproduces the
+    resident fixed cosets of the reference's pk.key"""
+    import ctypes as C
+    from ezkl_amd import backend as B, codecs, lib as L
+    vk = dict(k=6, compress_selectors=True, fixed_commitments=np.zeros((0, 8), np.uint64),
+              permutation_commitments=np.zeros((0, 8), np.uint64), selectors=np.zeros((0, 64), bool))
+    pk = dict(vk=vk, l0=golden_pk["l0"], l_last=golden_pk["l_last"], l_active_row=golden_pk["l_active_row"],
+              fixed_values=list(golden_pk["fixed_values"]), fixed_polys=list(golden_pk["fixed_polys"]),
+              fixed_cosets=list(golden_pk["fixed_cosets"]), permutations=list(golden_pk["permutations"]),
+              perm_polys=list(golden_pk["perm_polys"]), perm_cosets=list(golden_pk["perm_cosets"]))
+    dev = codecs.ProvingKeyDevice(pk)
+    assert dev.ext_k == 9 and dev.nbytes() > 0
+    out = B.DeviceBuffer(512 * 32)
+    for poly, coset in list(zip(dev.fixed_polys, dev.fixed_cosets)) + list(zip(dev.perm_polys, dev.perm_cosets)):
+        L.check(L.load().ezkl_hip_coset_ntt_dev(C.c_void_p(poly.ptr), C.c_void_p(out.ptr), C.c_size_t(1), C.c_size_t(64), C.c_size_t(512),
+                                                C.c_uint32(6), C.c_uint32(9), C.c_int(0), C.c_void_p(None)), "coset")
+        assert (out.to_numpy() == coset.to_numpy()).all()
