@@ -38,12 +38,16 @@ struct MsmTable {
 static std::map<const Bases*, MsmTable> g_tables;   // guarded by the ctx mutex
 
 static uint32_t pick_window(size_t n) {
-    // aim at ~24 points per bucket: n*W / 2^(c-1) ~ 24, W = ceil(255/c)
+    // aim at ~24 points per bucket: n*W / 2^(c-1) ~ 24, W = ceil(255/c).  After the r - s fold every scalar is
+    // < 2^253, so the top window only holds tb = 253 - (W-1)*c bits; a tiny top window would pour n / 2^tb pairs
+    // into each of a handful of buckets (c = 18: ONE bucket with n/2 pairs), so such widths are skipped.
     uint32_t best = 2;
     for (uint32_t c = 2; c <= 22; c++) {
-        double W = (255 + c - 1) / c;
-        double per = (double)n * W / (double)((size_t)1 << (c - 1));
-        if (per >= 20.0) best = c;
+        const uint32_t W = (255 + c - 1) / c;
+        const int tb = 253 - (int)((W - 1) * c);
+        const double per = (double)n * W / (double)((size_t)1 << (c - 1));
+        const bool top_ok = tb <= 0 || tb >= 8 || ((double)n / (double)(1u << (tb > 0 ? tb : 0))) <= 256.0;
+        if (per >= 20.0 && top_ok) best = c;
     }
     return best;
 }

@@ -82,7 +82,10 @@ __device__ __forceinline__ void ntt_superstage(uint2* data, const fe_t* tloc, ui
                 fe_t u = x[i], v = x[i + half];
                 x[i] = Fr::add(u, v);
                 fe_t d = Fr::sub(u, v);
-                if (need_tw) d = Fr::mul(d, tloc[(j + (i & (half - 1)) * hG) << (s + t)]);
+                // twiddle exponent (j + (i & (half-1))*hG) << (s+t); in the last group hG == 1 and j == 0, so the
+                // members with (i & (half-1)) == 0 multiply by w^0 = 1: skipped (wave-uniform condition)
+                const bool unit = (hG == 1) && ((i & (half - 1)) == 0);
+                if (need_tw && !unit) d = Fr::mul(d, tloc[(j + (i & (half - 1)) * hG) << (s + t)]);
                 x[i + half] = d;
             }
         }
@@ -125,21 +128,36 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     };
 
     // ---- load tile (lanes run over c first: C*32 B contiguous per row) ----
+    // All of a lane's global loads are issued before the first LDS write (4 per lane for the 1024-element
+    // tile), so one HBM latency is paid per phase instead of one per element.
     const size_t in_len = (size_t)1 << a.in_log_len;
-    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+    auto load_one = [&](uint32_t e, size_t& addr_out) -> fe_t {
         uint32_t c = e & (C - 1), i1 = e >> logC;
         size_t addr = col_base(c) + ((size_t)i1 << log_s);
-        fe_t x;
-        if (!a.first || addr < in_len) {
-            x = ld_fe(in + addr);
-            if (a.first && a.coset_pre) {
-                uint32_t m3 = (uint32_t)(addr % 3);
-                if (m3) x = Fr::mul(x, a.zeta[m3 - 1]);
-            }
-        } else {
-            x = Fr::zero();
+        addr_out = addr;
+        if (!a.first || addr < in_len) return ld_fe(in + addr);
+        return Fr::zero();
+    };
+    auto put_one = [&](uint32_t e, size_t addr, fe_t x) {
+        if (a.first && a.coset_pre && addr < in_len) {
+            uint32_t m3 = (uint32_t)(addr % 3);
+            if (m3) x = Fr::mul(x, a.zeta[m3 - 1]);
         }
         lds_put(data, TILE, e, x);     // LDS index = i1*C + c
+    };
+    if (TILE == 4 * NTT_THREADS) {
+        fe_t x[4];
+        size_t ad[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = load_one(tid + i * NTT_THREADS, ad[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) put_one(tid + i * NTT_THREADS, ad[i], x[i]);
+    } else {
+        for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+            size_t ad;
+            fe_t x = load_one(e, ad);
+            put_one(e, ad, x);
+        }
     }
     __syncthreads();
 
@@ -153,14 +171,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     }
 
     // ---- store: y[k1] sits at row bitrev(k1) ----
-    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+    auto store_one = [&](uint32_t e, const fe_t* twp) {
         uint32_t c = e & (C - 1), k1 = e >> logC;
         uint32_t row = a.log_r ? (__brev(k1) >> (32 - a.log_r)) : 0u;
         fe_t x = lds_get(data, TILE, (row << logC) + c);
         if (!a.last) {
             uint32_t colid = tile * C + c;
             uint32_t pos = (k1 << log_s) + (colid & (S - 1));        // position inside the block
-            x = Fr::mul(x, ld_fe(a.tw_inter + pos));
+            x = Fr::mul(x, twp ? *twp : ld_fe(a.tw_inter + pos));
             st_fe(out + (((size_t)(colid >> log_s) << a.log_m) + pos), x);
         } else {
             uint32_t blk = (uint32_t)(col_base(c) >> a.log_r);
@@ -178,6 +196,18 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
             if (a.post) x = Fr::mul(x, a.post_c[oidx % 3]);
             st_fe(out + oidx, x);
         }
+    };
+    if (TILE == 4 * NTT_THREADS && !a.last) {
+        fe_t tw[4];                       // the four inter-pass twiddles of this lane, fetched together
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t e = tid + i * NTT_THREADS, c = e & (C - 1), k1 = e >> logC;
+            tw[i] = ld_fe(a.tw_inter + ((k1 << log_s) + ((tile * C + c) & (S - 1))));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) store_one(tid + i * NTT_THREADS, &tw[i]);
+    } else {
+        for (uint32_t e = tid; e < TILE; e += NTT_THREADS) store_one(e, nullptr);
     }
 }
 
