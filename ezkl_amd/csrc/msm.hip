@@ -413,7 +413,7 @@ void msm_table_drop(const Bases* b) {
 // One in-flight MSM: its own scratch arena, a pinned landing buffer for the plane sums and a completion event.
 // A batch (one commit phase of the prover) is pipelined over MSM_SLOTS of these on separate streams so that the
 // latency-bound sort / reduce tails of one MSM and the host Horner overlap the accumulate kernel of the next.
-static constexpr int MSM_SLOTS = 3;
+static constexpr int MSM_SLOTS = 6;
 struct MsmSlot {
     hipStream_t st = nullptr;
     uint8_t* scratch = nullptr;
