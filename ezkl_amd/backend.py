@@ -170,6 +170,26 @@ class ParamsKZG:
         self._gl.free()
 
 
+def polycommit_commit(message, num_unusable_rows, params):
+    """PolyCommitChip::commit (/root/reference/src/circuit/modules/polycommit.rs:46-81): pad the message into
+    ceil-ish(len / (2^k - u)) Lagrange-basis columns (num_poly = len / n + 1 as the reference computes it), leave
+    the u unusable rows at Blind::default().0 (= Fr::ONE in halo2, passed here as `blind`), commit each column with
+    commit_lagrange and return the normalised affine points.  The batch goes through the pipelined MSM path."""
+    message = _fe(message)
+    n_rows = 1 << params.k
+    n = n_rows - num_unusable_rows
+    num_poly = message.shape[0] // n + 1
+    polys = np.zeros((num_poly, n_rows, 4), np.uint64)
+    polys[:, n:, :] = _to_mont(1)                       # Blind::default() == Blind(Fr::ONE)
+    for i in range(message.shape[0]):
+        polys[i // n, i % n] = message[i]
+    out = np.zeros((num_poly, 8), np.uint64)
+    arr = (C.c_void_p * num_poly)(*[polys[j].ctypes.data for j in range(num_poly)])
+    _l.check(_l.load().ezkl_hip_msm_g1_batch(params._gl.h, arr, C.c_size_t(num_poly), C.c_size_t(n_rows), _p(out)),
+             "ezkl_hip_msm_g1_batch")
+    return out
+
+
 def g1_add_affine(a, b):
     a, b = _fe(a, 8), _fe(b, 8)
     out = np.zeros(8, np.uint64)

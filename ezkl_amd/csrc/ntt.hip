@@ -226,13 +226,6 @@ __global__ void ntt_twiddle_kernel(fe_t* out, uint32_t count, uint64_t mult, uin
     st_fe(out + idx, acc);
 }
 
-__global__ void ntt_copy_scale_kernel(const fe_t* in, fe_t* out, size_t n, int post, fe_t c0) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    fe_t x = ld_fe(in + i);
-    if (post) x = Fr::mul(x, c0);
-    st_fe(out + i, x);
-}
 
 struct NttPlan {
     uint32_t log_n = 0;

@@ -172,3 +172,55 @@ def test_permutation_grand_product_and_lookup_sum(hip):
     for i in range(n):
         assert fe_to_int(phi[i]) == acc
         acc = (acc + sum(pow(F[j][i] + b, -1, R) for j in range(2)) - M[i] * pow(T[i] + b, -1, R)) % R
+
+
+def test_error_paths_are_status_codes(hip):
+    """bad arguments come back as EZKL_ERR_INVALID (-3): nothing throws or unwinds across the C ABI"""
+    import ctypes as C
+    from ezkl_amd import backend as B, lib as L
+    lib = L.load()
+    pts = ob.gen_bases(1, 16)
+    bases = B.Bases(pts)
+    out = np.zeros(8, np.uint64)
+    s = rand_fr(np.random.default_rng(0), 32)
+    vp = C.c_void_p
+    assert lib.ezkl_hip_msm_g1(bases.h, s.ctypes.data_as(vp), C.c_size_t(32), out.ctypes.data_as(vp)) == -3      # more scalars than bases
+    assert lib.ezkl_hip_msm_g1(None, s.ctypes.data_as(vp), C.c_size_t(4), out.ctypes.data_as(vp)) == -3
+    assert lib.ezkl_hip_msm_g1(bases.h, None, C.c_size_t(4), out.ctypes.data_as(vp)) == -3
+    assert lib.ezkl_hip_msm_g1(bases.h, s.ctypes.data_as(vp), C.c_size_t(0), out.ctypes.data_as(vp)) == 0 and not out.any()   # empty input -> identity
+    w = ob.omega(4)
+    assert lib.ezkl_hip_ntt(s.ctypes.data_as(vp), C.c_uint32(29), w.ctypes.data_as(vp), 0) == -3
+    assert lib.ezkl_hip_ntt(None, C.c_uint32(4), w.ctypes.data_as(vp), 0) == -3
+    d = B.DeviceBuffer(32 * 16)
+    assert lib.ezkl_hip_coset_ntt_dev(vp(d.ptr), vp(d.ptr), C.c_size_t(1), C.c_size_t(16), C.c_size_t(16), C.c_uint32(5), C.c_uint32(4), 0, vp(None)) == -3
+    assert lib.ezkl_hip_vec_op_dev(7, vp(d.ptr), vp(d.ptr), vp(d.ptr), C.c_size_t(16), vp(None)) == -3
+    assert lib.ezkl_hip_prefix_scan_dev(1, 0, vp(d.ptr), vp(d.ptr), C.c_size_t(16), vp(None)) == -3              # sub is not a scan op
+    assert b"invalid" in lib.ezkl_hip_strerror(-3)
+    bases.free()
+
+
+def test_concurrent_host_threads(hip):
+    """halo2 calls the backend from rayon worker threads: concurrent MSM / NTT / vec calls must serialise correctly"""
+    import threading
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(4)
+    n, k = 1 << 12, 12
+    pts = ob.gen_bases(9, n)
+    bases = B.Bases(pts)
+    w = ob.omega(k)
+    jobs = [(rand_fr(rng, n), rand_fr(rng, n)) for _ in range(6)]
+    want = [(ob.msm(a, pts), ob.fft(b, k, w)) for a, b in jobs]
+    got = [None] * len(jobs)
+
+    def work(i):
+        a, b = jobs[i]
+        got[i] = (B.msm_g1(bases, a), hip.ntt(b, k, w))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g, wv in zip(got, want):
+        assert (g[0] == wv[0]).all() and (g[1] == wv[1]).all()
+    bases.free()

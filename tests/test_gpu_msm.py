@@ -125,3 +125,51 @@ def test_batch_pipelined_matches_single(hip, n, batch):
     L.check(L.load().ezkl_hip_msm_g1_batch(bases.h, arr, C.c_size_t(batch), C.c_size_t(n), out.ctypes.data_as(C.c_void_p)), "batch")
     assert (out == got).all()
     bases.free()
+
+
+def test_polycommit_chip_commit(hip, golden_srs):
+    """mirror of PolyCommitChip::commit (src/circuit/modules/polycommit.rs:46-81) on the reference's k=6 SRS:
+    message split into Lagrange columns, unusable rows = Blind::default(), one commit_lagrange per column"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(77)
+    params = hip.ParamsKZG.read(golden_srs["buf"])
+    u = 6                                            # blinding 5 + 1 (src/tensor/var.rs:57-60)
+    msg = rand_fr(rng, 100)                          # 100 values over 58 usable rows -> 2 columns
+    got = B.polycommit_commit(msg, u, params)
+    assert got.shape == (100 // 58 + 1, 8)
+    one = fe_from_int(1)
+    for j in range(got.shape[0]):
+        col = np.zeros((64, 4), np.uint64)
+        col[58:] = one
+        chunk = msg[j * 58:(j + 1) * 58]
+        col[:chunk.shape[0]] = chunk
+        assert (got[j] == ob.msm(col, golden_srs["g_lagrange"])).all()
+    params.free()
+
+
+def test_c5_size_2_22_properties(hip):
+    """BASELINE configs[4] SRS size (k = 22): linearity and shard-and-fold at 4M points (no oracle at this size)"""
+    from ezkl_amd import backend as B
+    n = 1 << 22
+    rng = np.random.default_rng(22)
+    bases = B.Bases.generate(SEED + 1, n)
+    s1, s2 = rand_fr(rng, n), witness_like(np.random.default_rng(5), 1 << 12)
+    s2 = np.tile(s2, (n >> 12, 1))                   # skewed column: the same 4096 witness-like values repeated
+    d1, d2 = B.DeviceBuffer.from_numpy(s1), B.DeviceBuffer.from_numpy(s2)
+    a, b = B.msm_g1_dev(bases, d1.ptr, n), B.msm_g1_dev(bases, d2.ptr, n)
+    B.vec_op("add", d1.ptr, d2.ptr, d1.ptr, n)
+    c = B.msm_g1_dev(bases, d1.ptr, n)
+    assert (c == B.g1_add_affine(a, b)).all()
+    q = n // 4
+    parts = []
+    host = d1.to_numpy(shape=(n, 4))
+    for r in range(4):
+        dq = B.DeviceBuffer.from_numpy(host[r * q:(r + 1) * q])
+        parts.append(B.msm_g1_dev(bases, dq.ptr, q, offset=r * q))
+    from ezkl_amd import dist as D
+    assert (D.fold_points(parts) == c).all()
+    # spot check against the oracle on a prefix (the first 2^14 points with the rest zero)
+    z = np.zeros((n, 4), np.uint64); z[: 1 << 14] = s1[: 1 << 14]
+    pts = bases.download()[: 1 << 14]
+    assert (B.msm_g1(bases, z) == ob.msm(s1[: 1 << 14], pts)).all()
+    bases.free()

@@ -124,3 +124,38 @@ def test_device_resident_pk_columns(hip, golden_pk):
         L.check(L.load().ezkl_hip_coset_ntt_dev(C.c_void_p(poly.ptr), C.c_void_p(out.ptr), C.c_size_t(1), C.c_size_t(64), C.c_size_t(512),
                                                 C.c_uint32(6), C.c_uint32(9), C.c_int(0), C.c_void_p(None)), "coset")
         assert (out.to_numpy() == coset.to_numpy()).all()
+
+
+def test_extended_domain_size_2_25(hip):
+    """largest extended domain of the BASELINE configs (k = 22, ext_k = 25: 1 GiB per column): round trip of the
+    coset pair and of a plain transform, plus the defining sum at two positions for a sparse input"""
+    from ezkl_amd import backend as B
+    import ctypes as C
+    from ezkl_amd import lib as L
+    k, ek = 22, 25
+    n, ne = 1 << k, 1 << ek
+    rng = np.random.default_rng(25)
+    a = rand_fr(rng, n)
+    da = B.DeviceBuffer.from_numpy(a)
+    dext = B.DeviceBuffer(ne * 32)
+    lib = L.load()
+    L.check(lib.ezkl_hip_coset_ntt_dev(C.c_void_p(da.ptr), C.c_void_p(dext.ptr), C.c_size_t(1), C.c_size_t(n), C.c_size_t(ne),
+                                       C.c_uint32(k), C.c_uint32(ek), C.c_int(0), C.c_void_p(None)), "coset")
+    L.check(lib.ezkl_hip_coset_ntt_dev(C.c_void_p(dext.ptr), C.c_void_p(dext.ptr), C.c_size_t(1), C.c_size_t(ne), C.c_size_t(ne),
+                                       C.c_uint32(k), C.c_uint32(ek), C.c_int(1), C.c_void_p(None)), "icoset")
+    back = dext.to_numpy(shape=(ne, 4))
+    assert (back[:n] == a).all() and not back[n:].any()
+    d = hip.EvaluationDomain(2, ek)
+    sparse = np.zeros((ne, 4), np.uint64)
+    idx = [0, 1, 12345, ne - 1]
+    vals = rand_fr(rng, 4)
+    sparse[idx] = vals
+    ds = B.DeviceBuffer.from_numpy(sparse)
+    B.ntt_dev(ds.ptr, ek, d.omega)
+    f = ds.to_numpy(shape=(ne, 4))
+    w = pr.omega(ek)
+    for j in (0, 7, ne // 2 + 3):
+        want = sum(fe_to_int(v) * pow(w, i * j, R) for i, v in zip(idx, vals)) % R
+        assert fe_to_int(f[j]) == want
+    B.ntt_dev(ds.ptr, ek, d.omega_inv, inverse=True)
+    assert (ds.to_numpy(shape=(ne, 4)) == sparse).all()
