@@ -224,6 +224,14 @@ def prefix_scan(op, in_ptr, out_ptr, n, exclusive=False, stream=None):
                                                  C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_prefix_scan_dev")
 
 
+def eval_polynomial(coeffs_ptr, n, x, stream=None):
+    """halo2 eval_polynomial on a resident coefficient vector"""
+    out = np.zeros(4, np.uint64)
+    _l.check(_l.load().ezkl_hip_eval_poly_dev(_vp(coeffs_ptr), C.c_size_t(n), _p(_fe(x)), _p(out), _stream_ptr(stream)),
+             "ezkl_hip_eval_poly_dev")
+    return out
+
+
 def batch_invert(ptr, n, stream=None):
     _l.check(_l.load().ezkl_hip_batch_invert_dev(_vp(ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_batch_invert_dev")
 

@@ -346,6 +346,14 @@ int ezkl_hip_batch_invert_dev(void* a, size_t n, void* stream) {
     return batch_invert(c, pick_stream(c, stream), (fe_t*)a, n);
 }
 
+int ezkl_hip_eval_poly_dev(const void* coeffs, size_t n, const void* x, void* out, void* stream) {
+    if ((!coeffs && n) || !x || !out) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    fe_t xx;
+    memcpy(&xx, x, 32);
+    return eval_poly(c, pick_stream(c, stream), (const fe_t*)coeffs, n, xx, out);
+}
+
 int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in, void* out, size_t n, void* stream) {
     if (!in || !out || (op != EZKL_VEC_ADD && op != EZKL_VEC_MUL)) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -4,6 +4,7 @@
 // All are streaming kernels: one 32-byte element per lane per access (2 x global_load_dwordx4),
 // grid-stride, HBM-bound except batch inversion.
 #include "common.hpp"
+#include <string.h>
 
 namespace ezkl {
 
@@ -182,6 +183,66 @@ int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, f
     (void)hipFree(scratch);
     if (!rc && e != hipSuccess) rc = set_hip_error(e, "scan sync", __FILE__, __LINE__);
     return rc;
+}
+
+// ---- polynomial evaluation at a point (halo2 eval_polynomial: hundreds of O(n) Horner reductions per proof,
+//      create_proof step 10 in SURVEY.md §3.1; A14) ----
+// lane t evaluates its 32-coefficient segment by Horner, scales it by x^(32 t) (square-and-multiply on the lane
+// index), workgroups tree-sum in LDS; a second launch of the same tree folds the per-workgroup partials.
+static constexpr uint32_t EVP_SEG = 32;
+__global__ __launch_bounds__(256) void eval_poly_kernel(const fe_t* coeffs, size_t n, fe_t x, const fe_t* xpow2, uint32_t npow, fe_t* partial) {
+    __shared__ fe_t sh[256];
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, base = t * EVP_SEG;
+    fe_t acc = Fr::zero();
+    if (base < n) {
+        const uint32_t m = n - base < EVP_SEG ? (uint32_t)(n - base) : EVP_SEG;
+        acc = ld_fe(coeffs + base + m - 1);
+        for (uint32_t j = m - 1; j-- > 0;) acc = Fr::add(Fr::mul(acc, x), ld_fe(coeffs + base + j));
+        // x^(32 t): bits of t select precomputed x^(32 * 2^b)
+        for (uint32_t b = 0; b < npow; b++)
+            if ((t >> b) & 1) acc = Fr::mul(acc, ld_fe(xpow2 + b));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_fe(partial + blockIdx.x, sh[0]);
+}
+__global__ __launch_bounds__(256) void sum_kernel(const fe_t* in, size_t n, fe_t* out) {
+    __shared__ fe_t sh[256];
+    fe_t acc = Fr::zero();
+    for (size_t i = threadIdx.x; i < n; i += 256) acc = Fr::add(acc, ld_fe(in + i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_fe(out, sh[0]);
+}
+int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& x, void* out_host) {
+    if (n == 0) { memset(out_host, 0, 32); return EZKL_OK; }
+    const size_t nseg = (n + EVP_SEG - 1) / EVP_SEG;
+    const unsigned blocks = cdiv(nseg, 256);
+    uint32_t npow = 0;
+    while (((size_t)1 << npow) < nseg) npow++;
+    std::vector<fe_t> pw(npow ? npow : 1);
+    fe_t p = x;
+    for (int i = 0; i < 5; i++) p = Fr::sqr(p);          // x^32
+    for (uint32_t b = 0; b < npow; b++) { pw[b] = p; p = Fr::sqr(p); }
+    fe_t* d = nullptr;
+    EZ_HIP(hipMalloc(&d, (pw.size() + blocks + 1) * sizeof(fe_t)));
+    fe_t *d_pw = d, *d_part = d + pw.size(), *d_out = d_part + blocks;
+    EZ_HIP(hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(eval_poly_kernel, dim3(blocks), dim3(256), 0, st, coeffs, n, x, d_pw, npow, d_part);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, d_part, (size_t)blocks, d_out);
+    hipError_t e = hipMemcpyAsync(out_host, d_out, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_hip_error(e, "eval_poly", __FILE__, __LINE__);
+    return EZKL_OK;
 }
 
 }  // namespace ezkl

@@ -104,6 +104,9 @@ int ezkl_hip_divide_by_vanishing_dev(void* a_dev, uint32_t k, uint32_t ext_k, vo
  * o in[i-1] with out[0] = identity (exclusive): the grand sum of mv-lookup::commit_grand_sum and the grand
  * product z(X) of permutation::commit.  in == out allowed. */
 int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in_dev, void* out_dev, size_t n, void* stream);
+/* halo2 eval_polynomial(poly, x): sum_i coeffs[i] * x^i for a resident coefficient vector; x and the 32-byte result
+ * are host memory (create_proof evaluates every queried (column, rotation) this way before SHPLONK) */
+int ezkl_hip_eval_poly_dev(const void* coeffs_dev, size_t n, const void* x_host, void* out_host, void* stream);
 /* Montgomery batch inversion (zeros stay zero), in place */
 int ezkl_hip_batch_invert_dev(void* a_dev, size_t n, void* stream);
 

@@ -107,6 +107,11 @@ def batch_invert(a):
     a = _fe(a).copy(); lib.oracle_batch_invert(_ptr(a), C.c_size_t(a.shape[0])); return a
 
 
+def eval_poly(c, x):
+    c, x = _fe(c), _fe(x); o = np.empty(4, np.uint64)
+    lib.oracle_eval_poly(_ptr(c), C.c_size_t(c.shape[0]), _ptr(x), _ptr(o)); return o
+
+
 def prefix_scan(a, op, exclusive=False):
     a = _fe(a); o = np.empty_like(a)
     lib.oracle_prefix_scan(_ptr(a), _ptr(o), C.c_size_t(a.shape[0]), C.c_int({"add": 0, "mul": 2}[op]), C.c_int(1 if exclusive else 0))

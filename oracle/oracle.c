@@ -377,6 +377,13 @@ void oracle_batch_invert(fe *a, size_t n) {
     free(pre);
 }
 
+/* eval_polynomial(poly, x): Horner from the top coefficient */
+void oracle_eval_poly(const fe *c, size_t n, const fe *x, fe *out) {
+    fe acc = {{0, 0, 0, 0}};
+    for (size_t i = n; i-- > 0;) { f_mul(&acc, &acc, x, &FR); f_add(&acc, &acc, &c[i], &FR); }
+    *out = acc;
+}
+
 /* running sum / product (permutation grand product z, mv-lookup grand sum phi); op 0 = add, 2 = mul */
 void oracle_prefix_scan(const fe *in, fe *out, size_t n, int op, int exclusive) {
     fe acc = op == 0 ? (fe){{0, 0, 0, 0}} : FR.one;

@@ -224,3 +224,12 @@ def test_concurrent_host_threads(hip):
     for g, wv in zip(got, want):
         assert (g[0] == wv[0]).all() and (g[1] == wv[1]).all()
     bases.free()
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 1000, 8192, 8193, 1 << 16, (1 << 20) + 5])
+def test_eval_polynomial(hip, n):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n)
+    c, x = rand_fr(rng, n), rand_fr(rng, 1)[0]
+    d = B.DeviceBuffer.from_numpy(c)
+    assert (B.eval_polynomial(d.ptr, n, x) == ob.eval_poly(c, x)).all()
