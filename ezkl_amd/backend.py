@@ -224,6 +224,17 @@ def prefix_scan(op, in_ptr, out_ptr, n, exclusive=False, stream=None):
                                                  C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_prefix_scan_dev")
 
 
+def lookup_multiplicity(input_ptrs, table_ptr, n_rows, usable_rows, stream=None):
+    """m(X) of mv-lookup: returns (DeviceBuffer with the Fr column, number of input values missing from the table)"""
+    out = DeviceBuffer(n_rows * 32)
+    miss = C.c_uint32(0)
+    arr = (C.c_void_p * max(1, len(input_ptrs)))(*input_ptrs)
+    _l.check(_l.load().ezkl_hip_lookup_multiplicity_dev(arr, C.c_uint32(len(input_ptrs)), _vp(table_ptr), C.c_uint32(n_rows),
+                                                         C.c_uint32(usable_rows), _vp(out.ptr), C.byref(miss), _stream_ptr(stream)),
+             "ezkl_hip_lookup_multiplicity_dev")
+    return out, int(miss.value)
+
+
 def eval_polynomial(coeffs_ptr, n, x, stream=None):
     """halo2 eval_polynomial on a resident coefficient vector"""
     out = np.zeros(4, np.uint64)

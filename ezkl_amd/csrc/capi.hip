@@ -346,6 +346,16 @@ int ezkl_hip_batch_invert_dev(void* a, size_t n, void* stream) {
     return batch_invert(c, pick_stream(c, stream), (fe_t*)a, n);
 }
 
+int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
+                                     uint32_t usable_rows, void* m_out_dev, uint32_t* out_missing, void* stream) {
+    if (!table_dev || !m_out_dev || (n_inputs && !inputs_dev)) return EZKL_ERR_INVALID;
+    for (uint32_t j = 0; j < n_inputs; j++)
+        if (!inputs_dev[j]) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return lookup_multiplicity(c, pick_stream(c, stream), (const fe_t* const*)inputs_dev, n_inputs, (const fe_t*)table_dev, n_rows,
+                               usable_rows, (fe_t*)m_out_dev, out_missing);
+}
+
 int ezkl_hip_eval_poly_dev(const void* coeffs, size_t n, const void* x, void* out, void* stream) {
     if ((!coeffs && n) || !x || !out) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -62,6 +62,8 @@ int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o
 int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, size_t n);
 int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
+int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
+                        uint32_t usable, fe_t* m_out, uint32_t* missing_host);
 int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& x, void* out_host);
 int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, fe_t* out, size_t n);
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);

@@ -185,6 +185,78 @@ int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, f
     return rc;
 }
 
+// ---- mv-lookup multiplicities (A13: [UPSTREAM] mv_lookup::prover::prepare builds m(X) with a BTreeMap from table
+//      value to its FIRST row, then counts every input occurrence) ----
+// Open-addressing hash table over 256-bit keys in HBM: slot = first table row holding the key (atomicCAS to claim,
+// atomicMin among equal keys); inputs probe the same sequence and atomically count into the owning row.
+static constexpr uint32_t HT_EMPTY = 0xffffffffu;
+EZ_D uint32_t ht_hash(const fe_t& v, uint32_t mask) {
+    uint32_t h = v.v[0] * 0x9e3779b1u ^ v.v[1] * 0x85ebca77u ^ v.v[2] * 0xc2b2ae3du ^ v.v[3] * 0x27d4eb2fu ^ v.v[5] * 0x165667b1u ^ v.v[7];
+    h ^= h >> 15;
+    return h & mask;
+}
+__global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* table, uint32_t usable, uint32_t* slots, uint32_t mask) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= usable) return;
+    const fe_t key = ld_fe(table + i);
+    uint32_t h = ht_hash(key, mask);
+    for (;;) {
+        uint32_t cur = slots[h];
+        if (cur == HT_EMPTY) {
+            cur = atomicCAS(&slots[h], HT_EMPTY, i);
+            if (cur == HT_EMPTY) return;                 // claimed
+        }
+        if (Fr::eq(ld_fe(table + cur), key)) {           // same value already present: keep the first row
+            atomicMin(&slots[h], i);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+}
+__global__ __launch_bounds__(256) void ht_count_kernel(const fe_t* input, uint32_t rows, const fe_t* table, const uint32_t* slots,
+                                                       uint32_t mask, uint32_t* counts, uint32_t* missing) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const fe_t key = ld_fe(input + i);
+    uint32_t h = ht_hash(key, mask);
+    for (;;) {
+        uint32_t cur = slots[h];
+        if (cur == HT_EMPTY) { atomicAdd(missing, 1u); return; }
+        if (Fr::eq(ld_fe(table + cur), key)) { atomicAdd(&counts[cur], 1u); return; }
+        h = (h + 1) & mask;
+    }
+}
+__global__ __launch_bounds__(256) void counts_to_fr_kernel(const uint32_t* counts, uint32_t n, fe_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t t = Fr::zero();
+    t.v[0] = counts[i];
+    st_fe(out + i, counts[i] ? Fr::to_mont(t) : t);
+}
+int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
+                        uint32_t usable, fe_t* m_out, uint32_t* missing_host) {
+    if (usable > n_rows) return EZKL_ERR_INVALID;
+    uint32_t cap = 16;
+    while (cap < 2 * (usable ? usable : 1)) cap <<= 1;
+    uint32_t* d = nullptr;
+    EZ_HIP(hipMalloc(&d, ((size_t)cap + n_rows + 1) * 4));
+    uint32_t *slots = d, *counts = d + cap, *missing = counts + n_rows;
+    EZ_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, st));
+    EZ_HIP(hipMemsetAsync(counts, 0, ((size_t)n_rows + 1) * 4, st));
+    if (usable) hipLaunchKernelGGL(ht_build_kernel, dim3(cdiv(usable, 256)), dim3(256), 0, st, table, usable, slots, cap - 1);
+    for (uint32_t j = 0; j < n_inputs; j++)
+        if (usable) hipLaunchKernelGGL(ht_count_kernel, dim3(cdiv(usable, 256)), dim3(256), 0, st, inputs[j], usable, table, slots, cap - 1, counts, missing);
+    hipLaunchKernelGGL(counts_to_fr_kernel, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, counts, n_rows, m_out);
+    hipError_t e = hipGetLastError();
+    uint32_t miss = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&miss, missing, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return set_hip_error(e, "lookup_multiplicity", __FILE__, __LINE__);
+    if (missing_host) *missing_host = miss;
+    return EZKL_OK;
+}
+
 // ---- polynomial evaluation at a point (halo2 eval_polynomial: hundreds of O(n) Horner reductions per proof,
 //      create_proof step 10 in SURVEY.md §3.1; A14) ----
 // lane t evaluates its 32-coefficient segment by Horner, scales it by x^(32 t) (square-and-multiply on the lane

@@ -104,6 +104,11 @@ int ezkl_hip_divide_by_vanishing_dev(void* a_dev, uint32_t k, uint32_t ext_k, vo
  * o in[i-1] with out[0] = identity (exclusive): the grand sum of mv-lookup::commit_grand_sum and the grand
  * product z(X) of permutation::commit.  in == out allowed. */
 int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in_dev, void* out_dev, size_t n, void* stream);
+/* mv-lookup multiplicities m(X) (mv_lookup::prover::prepare): for every usable row r of every (theta-compressed) input
+ * column, the FIRST usable table row holding the same value gets +1; m_out is an n_rows Fr column (rows >= usable
+ * are 0).  *out_missing (may be NULL) = number of input values absent from the table (a failing witness). */
+int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
+                                     uint32_t usable_rows, void* m_out_dev, uint32_t* out_missing, void* stream);
 /* halo2 eval_polynomial(poly, x): sum_i coeffs[i] * x^i for a resident coefficient vector; x and the 32-byte result
  * are host memory (create_proof evaluates every queried (column, rotation) this way before SHPLONK) */
 int ezkl_hip_eval_poly_dev(const void* coeffs_dev, size_t n, const void* x_host, void* out_host, void* stream);

@@ -233,3 +233,36 @@ def test_eval_polynomial(hip, n):
     c, x = rand_fr(rng, n), rand_fr(rng, 1)[0]
     d = B.DeviceBuffer.from_numpy(c)
     assert (B.eval_polynomial(d.ptr, n, x) == ob.eval_poly(c, x)).all()
+
+
+@pytest.mark.parametrize("k,ninputs", [(4, 1), (10, 3), (16, 2)])
+def test_lookup_multiplicity(hip, k, ninputs):
+    """m(X) of mv-lookup against a dict-based restatement of mv_lookup::prover::prepare (first table row wins)"""
+    from ezkl_amd import backend as B
+    from conftest import fe_to_int
+    rng = np.random.default_rng(k)
+    n = 1 << k
+    usable = n - 6
+    distinct = max(2, n // 3)
+    pool = rand_fr(rng, distinct)
+    table = pool[rng.integers(0, distinct, size=n)]            # duplicates in the table on purpose
+    inputs = [table[rng.integers(0, usable, size=n)] for _ in range(ninputs)]
+    inputs[0][3] = rand_fr(rng, 1)[0]                          # one value that is not in the table
+    dt = B.DeviceBuffer.from_numpy(table)
+    di = [B.DeviceBuffer.from_numpy(x) for x in inputs]
+    m_dev, missing = B.lookup_multiplicity([d.ptr for d in di], dt.ptr, n, usable)
+    first = {}
+    for i in range(usable):
+        first.setdefault(table[i].tobytes(), i)
+    want = np.zeros(n, np.int64)
+    miss = 0
+    for x in inputs:
+        for r in range(usable):
+            idx = first.get(x[r].tobytes())
+            if idx is None:
+                miss += 1
+            else:
+                want[idx] += 1
+    got = m_dev.to_numpy(shape=(n, 4))
+    assert missing == miss
+    assert [fe_to_int(g) for g in got] == [int(w) for w in want]
