@@ -49,19 +49,28 @@ Ctx* ctx() {
     return g_ctx;
 }
 
-int scratch_reserve(Ctx* c, size_t bytes, void** out) {
-    if (bytes > c->scratch_bytes) {
-        if (c->scratch) {
+int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out) {
+    if (!a.last_event) EZ_HIP(hipEventCreateWithFlags(&a.last_event, hipEventDisableTiming));
+    if (bytes > a.bytes) {
+        if (a.ptr) {
             EZ_HIP(hipDeviceSynchronize());
-            EZ_HIP(hipFree(c->scratch));
-            c->scratch = nullptr;
-            c->scratch_bytes = 0;
+            EZ_HIP(hipFree(a.ptr));
+            a.ptr = nullptr;
+            a.bytes = 0;
+            a.in_use = false;
         }
-        size_t want = bytes + (bytes >> 3);
-        EZ_HIP(hipMalloc(&c->scratch, want));
-        c->scratch_bytes = want;
+        size_t want = bytes + (bytes >> 3) + 256;
+        EZ_HIP(hipMalloc(&a.ptr, want));
+        a.bytes = want;
     }
-    *out = c->scratch;
+    if (a.in_use && a.last_stream != st) EZ_HIP(hipStreamWaitEvent(st, a.last_event, 0));
+    *out = a.ptr;
+    return EZKL_OK;
+}
+int arena_done(Ctx::Arena& a, hipStream_t st) {
+    EZ_HIP(hipEventRecord(a.last_event, st));
+    a.last_stream = st;
+    a.in_use = true;
     return EZKL_OK;
 }
 
@@ -343,7 +352,9 @@ int ezkl_hip_divide_by_vanishing_dev(void* a, uint32_t k, uint32_t ext_k, void* 
 int ezkl_hip_batch_invert_dev(void* a, size_t n, void* stream) {
     if (!a) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    return batch_invert(c, pick_stream(c, stream), (fe_t*)a, n);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = batch_invert(c, st, (fe_t*)a, n);
+    return rc ? rc : finish(c, st, stream);
 }
 
 int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
@@ -367,7 +378,9 @@ int ezkl_hip_eval_poly_dev(const void* coeffs, size_t n, const void* x, void* ou
 int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in, void* out, size_t n, void* stream) {
     if (!in || !out || (op != EZKL_VEC_ADD && op != EZKL_VEC_MUL)) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    return prefix_scan(c, pick_stream(c, stream), op, exclusive, (const fe_t*)in, (fe_t*)out, n);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = prefix_scan(c, st, op, exclusive, (const fe_t*)in, (fe_t*)out, n);
+    return rc ? rc : finish(c, st, stream);
 }
 
 int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out, void* stream) {

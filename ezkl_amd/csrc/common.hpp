@@ -20,15 +20,25 @@ struct Ctx {
     // HIP event pairs recorded on the stream the kernels run on, one pair per measured region
     // ("ntt", "coset_ntt", "msm", "msm_accumulate", ...); read back by ezkl_hip_last_kernel_ms
     std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
-    // scratch arena reused across calls (grown on demand, never shrunk)
-    void* scratch = nullptr;
-    size_t scratch_bytes = 0;
+    // Device arenas reused across calls (grown on demand, never shrunk).  `scratch` backs the NTT ping-pong buffer and
+    // the sweep's spill area; `aux` backs the small helpers.  An arena remembers the stream and an event of its last
+    // user: the next user on a DIFFERENT stream waits for that event first, so stream-ordered calls on caller streams
+    // never race on shared scratch.
+    struct Arena {
+        void* ptr = nullptr;
+        size_t bytes = 0;
+        hipStream_t last_stream = nullptr;
+        hipEvent_t last_event = nullptr;
+        bool in_use = false;
+    };
+    Arena scratch, aux;
 };
 
 Ctx* ctx();                 // lazily initialised singleton (nullptr + last error set if no device)
 int ctx_init(int device);
 int set_hip_error(hipError_t e, const char* what, const char* file, int line);
-int scratch_reserve(Ctx* c, size_t bytes, void** out);
+int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out);   // acquire for work on stream st
+int arena_done(Ctx::Arena& a, hipStream_t st);                               // mark the end of that work
 int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1);
 
 #define EZ_HIP(call)                                                              \

@@ -320,7 +320,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     size_t o_int = o_chal + al((size_t)(p->n_challenges ? p->n_challenges : 1) * 32);
     size_t total = o_int + al((size_t)(n_spill ? n_spill : 1) * T * 32);
     uint8_t* S = nullptr;
-    int rc = scratch_reserve(c, total, (void**)&S);
+    int rc = arena_reserve(c->scratch, total, st, (void**)&S);
     if (rc) return rc;
     EZ_HIP(hipMemcpyAsync(S + o_code, code.data(), (size_t)p->n_instr * 32, hipMemcpyHostToDevice, st));
     if (p->n_constants) EZ_HIP(hipMemcpyAsync(S + o_const, p->constants, (size_t)p->n_constants * 32, hipMemcpyHostToDevice, st));
@@ -358,6 +358,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
+    if ((rc = arena_done(c->scratch, st))) return rc;
     EZ_HIP(hipStreamSynchronize(st));   // the host-side program arrays are borrowed only for the call
     return EZKL_OK;
 }

@@ -324,7 +324,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     }
     fe_t* work = nullptr;
     if (p->npass > 1) {
-        rc = scratch_reserve(c, batch * n * sizeof(fe_t), (void**)&work);
+        rc = arena_reserve(c->scratch, batch * n * sizeof(fe_t), st, (void**)&work);
         if (rc) return rc;
     }
     const fe_t zeta = fr_const(FrConst::ZETA), zeta2 = fr_const(FrConst::ZETA2);
@@ -374,6 +374,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
+    if (work) return arena_done(c->scratch, st);
     return EZKL_OK;
 }
 

@@ -61,12 +61,13 @@ int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ex
         cur = Fr::mul(cur, w);
     }
     fe_t* dt = nullptr;
-    EZ_HIP(hipMalloc(&dt, period * sizeof(fe_t)));
+    int rc = arena_reserve(c->aux, period * sizeof(fe_t), st, (void**)&dt);
+    if (rc) return rc;
     EZ_HIP(hipMemcpyAsync(dt, t.data(), period * sizeof(fe_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(vec_periodic_mul_kernel, dim3(stream_grid(c, ne)), dim3(256), 0, st, a, dt, (uint32_t)(period - 1), ne);
     EZ_HIP(hipGetLastError());
-    EZ_HIP(hipStreamSynchronize(st));
-    EZ_HIP(hipFree(dt));
+    if ((rc = arena_done(c->aux, st))) return rc;
+    EZ_HIP(hipStreamSynchronize(st));          // `t` (pageable host memory) is copied asynchronously
     return EZKL_OK;
 }
 
@@ -101,12 +102,11 @@ int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n) {
     if (T > cap) T = cap;
     if (T < 1) T = 1;
     fe_t* pre = nullptr;
-    EZ_HIP(hipMalloc(&pre, n * sizeof(fe_t)));
+    int rc = arena_reserve(c->aux, n * sizeof(fe_t), st, (void**)&pre);
+    if (rc) return rc;
     hipLaunchKernelGGL(batch_invert_kernel, dim3(cdiv(T, 256)), dim3(256), 0, st, a, pre, n, T);
     EZ_HIP(hipGetLastError());
-    EZ_HIP(hipStreamSynchronize(st));
-    EZ_HIP(hipFree(pre));
-    return EZKL_OK;
+    return arena_done(c->aux, st);
 }
 
 // ---- prefix scan over Fr (grand product of the permutation argument, grand sum of mv-lookup: SURVEY §8(a) A13) ----
@@ -176,13 +176,12 @@ int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, f
     size_t need = 0;
     for (size_t m = n; m > 1;) { m = (m + SCAN_CHUNK - 1) / SCAN_CHUNK; need += (m + 63) & ~(size_t)63; }
     fe_t* scratch = nullptr;
-    EZ_HIP(hipMalloc(&scratch, (need + 64) * sizeof(fe_t)));
-    int rc = op == EZKL_VEC_ADD ? scan_rec<EZKL_VEC_ADD>(c, st, in, out, n, exclusive, scratch)
-                                : scan_rec<EZKL_VEC_MUL>(c, st, in, out, n, exclusive, scratch);
-    hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(scratch);
-    if (!rc && e != hipSuccess) rc = set_hip_error(e, "scan sync", __FILE__, __LINE__);
-    return rc;
+    int rc = arena_reserve(c->aux, (need + 64) * sizeof(fe_t), st, (void**)&scratch);
+    if (rc) return rc;
+    rc = op == EZKL_VEC_ADD ? scan_rec<EZKL_VEC_ADD>(c, st, in, out, n, exclusive, scratch)
+                            : scan_rec<EZKL_VEC_MUL>(c, st, in, out, n, exclusive, scratch);
+    if (rc) return rc;
+    return arena_done(c->aux, st);
 }
 
 // ---- mv-lookup multiplicities (A13: [UPSTREAM] mv_lookup::prover::prepare builds m(X) with a BTreeMap from table
@@ -239,7 +238,8 @@ int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint3
     uint32_t cap = 16;
     while (cap < 2 * (usable ? usable : 1)) cap <<= 1;
     uint32_t* d = nullptr;
-    EZ_HIP(hipMalloc(&d, ((size_t)cap + n_rows + 1) * 4));
+    int rc = arena_reserve(c->aux, ((size_t)cap + n_rows + 1) * 4, st, (void**)&d);
+    if (rc) return rc;
     uint32_t *slots = d, *counts = d + cap, *missing = counts + n_rows;
     EZ_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, st));
     EZ_HIP(hipMemsetAsync(counts, 0, ((size_t)n_rows + 1) * 4, st));
@@ -251,8 +251,8 @@ int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint3
     uint32_t miss = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&miss, missing, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d);
     if (e != hipSuccess) return set_hip_error(e, "lookup_multiplicity", __FILE__, __LINE__);
+    if ((rc = arena_done(c->aux, st))) return rc;
     if (missing_host) *missing_host = miss;
     return EZKL_OK;
 }
@@ -305,16 +305,16 @@ int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& 
     for (int i = 0; i < 5; i++) p = Fr::sqr(p);          // x^32
     for (uint32_t b = 0; b < npow; b++) { pw[b] = p; p = Fr::sqr(p); }
     fe_t* d = nullptr;
-    EZ_HIP(hipMalloc(&d, (pw.size() + blocks + 1) * sizeof(fe_t)));
+    int rc = arena_reserve(c->aux, (pw.size() + blocks + 1) * sizeof(fe_t), st, (void**)&d);
+    if (rc) return rc;
     fe_t *d_pw = d, *d_part = d + pw.size(), *d_out = d_part + blocks;
     EZ_HIP(hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(eval_poly_kernel, dim3(blocks), dim3(256), 0, st, coeffs, n, x, d_pw, npow, d_part);
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, d_part, (size_t)blocks, d_out);
     hipError_t e = hipMemcpyAsync(out_host, d_out, 32, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d);
     if (e != hipSuccess) return set_hip_error(e, "eval_poly", __FILE__, __LINE__);
-    return EZKL_OK;
+    return arena_done(c->aux, st);
 }
 
 }  // namespace ezkl
