@@ -30,13 +30,21 @@ def fold_points(points):
     return acc
 
 
+_bufs = {}
+
+
 def fold_partials(partial, dist, device):
-    """all_gather the per-rank 64-byte partial sums and fold them; every rank returns the full sum"""
+    """all_gather the per-rank 64-byte partial sums and fold them; every rank returns the full sum.
+    Send/receive tensors are allocated once per (device, world size) and reused every step."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return partial
     import torch
-    t = torch.from_numpy(np.ascontiguousarray(partial).view(np.uint8).copy()).to(device)
-    out = torch.empty(dist.get_world_size() * 64, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(out, t)
-    parts = out.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    world = dist.get_world_size()
+    key = (str(device), world)
+    if key not in _bufs:
+        _bufs[key] = (torch.empty(64, dtype=torch.uint8, device=device), torch.empty(world * 64, dtype=torch.uint8, device=device))
+    send, recv = _bufs[key]
+    send.copy_(torch.from_numpy(np.ascontiguousarray(partial).view(np.uint8)))
+    dist.all_gather_into_tensor(recv, send)
+    parts = recv.cpu().numpy().view(np.uint64).reshape(-1, 8)
     return fold_points(parts)
