@@ -218,6 +218,34 @@ def vec_op(op, a_ptr, b_ptr, out_ptr, n, stream=None):
                                             _stream_ptr(stream)), "ezkl_hip_vec_op_dev")
 
 
+def vec_scale(a_ptr, scalar, out_ptr, n, stream=None):
+    _l.check(_l.load().ezkl_hip_vec_scale_dev(_vp(a_ptr), _p(_fe(scalar)), _vp(out_ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_vec_scale_dev")
+
+
+def coset_ntt_dev(in_ptr, out_ptr, k, ext_k, inverse=False, in_len=None, batch=1, stream=None):
+    """coeff_to_extended (inverse=False: 2^k coefficients in, 2^ext_k evaluations out) / extended_to_coeff on resident columns"""
+    nin = (1 << ext_k) if inverse else (1 << k)
+    _l.check(_l.load().ezkl_hip_coset_ntt_dev(_vp(in_ptr), _vp(out_ptr), C.c_size_t(batch), C.c_size_t(nin), C.c_size_t(1 << ext_k),
+                                               C.c_uint32(k), C.c_uint32(ext_k), C.c_int(1 if inverse else 0), _stream_ptr(stream)),
+             "ezkl_hip_coset_ntt_dev")
+
+
+def divide_by_vanishing_dev(ptr, k, ext_k, stream=None):
+    _l.check(_l.load().ezkl_hip_divide_by_vanishing_dev(_vp(ptr), C.c_uint32(k), C.c_uint32(ext_k), _stream_ptr(stream)),
+             "ezkl_hip_divide_by_vanishing_dev")
+
+
+def memcpy_h2d(dst_ptr, arr):
+    arr = np.ascontiguousarray(arr)
+    _l.check(_l.load().ezkl_hip_memcpy_h2d(_vp(dst_ptr), _p(arr), C.c_size_t(arr.nbytes)), "h2d")
+
+
+def memcpy_d2h(src_ptr, nbytes):
+    out = np.empty(nbytes, np.uint8)
+    _l.check(_l.load().ezkl_hip_memcpy_d2h(_p(out), _vp(src_ptr), C.c_size_t(nbytes)), "d2h")
+    return out
+
+
 def prefix_scan(op, in_ptr, out_ptr, n, exclusive=False, stream=None):
     code = {"add": 0, "mul": 2}[op]
     _l.check(_l.load().ezkl_hip_prefix_scan_dev(C.c_int(code), C.c_int(1 if exclusive else 0), _vp(in_ptr), _vp(out_ptr),

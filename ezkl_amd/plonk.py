@@ -1,0 +1,524 @@
+"""A halo2-shaped KZG/SHPLONK prover driving the HIP kernels end to end.
+
+This is the host side of `create_proof` ([UPSTREAM] halo2_proofs::plonk::prover, called from
+/root/reference/src/pfsys/mod.rs:456-463) restated in Python over a small column-handle backend interface: every
+O(n) step (commitments = MSM, iNTT / coset NTT, the quotient sweep, grand products, polynomial evaluation, SHPLONK
+quotients) runs in the kernels of libezkl_hip.so on resident columns; the host owns the transcript, the RNG and the
+scalar glue, exactly the split the north-star describes.  Round order follows SURVEY.md §3.1: advice commits ->
+beta, gamma -> permutation products -> random poly -> y -> quotient pieces -> x -> evaluations -> SHPLONK.
+
+What it is NOT: a byte-compatible re-implementation of the zkonduit halo2 fork (its source is not on disk, so the
+exact query order / vk digest cannot be pinned).  The proof format is the EvmTranscript layout of the reference's
+proofs (points 64 B BE, scalars 32 B BE); acceptance is decided by an independent pairing verifier
+(oracle/verifier.py), which is how the reference itself validates proofs.
+
+Not covered yet: instance columns, mv-lookup arguments, multi-phase challenges.
+"""
+import numpy as np
+from .transcript import EvmTranscript, keccak256, R
+from . import backend as _b
+
+ROOT = pow(7, (R - 1) >> 28, R)
+DELTA = pow(7, 1 << 28, R)
+ZETA = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+MONT = 1 << 256
+RINV = pow(MONT, -1, R)
+Q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+QINV = pow(MONT, -1, Q)
+BLINDING = 5                        # as in ezkl (src/graph/mod.rs:100): the last BLINDING+1 rows are unusable
+
+
+def to_mont(x):
+    return np.frombuffer((x % R * MONT % R).to_bytes(32, "little"), np.uint64).copy()
+
+
+def from_mont(a):
+    return int.from_bytes(np.ascontiguousarray(a, np.uint64).tobytes(), "little") * RINV % R
+
+
+def point_to_ints(p):
+    """affine 8 x u64 Montgomery -> (x, y) standard ints, identity -> None"""
+    b = np.ascontiguousarray(p, np.uint64).tobytes()
+    x, y = int.from_bytes(b[:32], "little") * QINV % Q, int.from_bytes(b[32:], "little") * QINV % Q
+    return None if (x == 0 and y == 0) else (x, y)
+
+
+# ------------------------------------------------------------------ expressions
+class Expr:
+    """polynomial expression over column queries; node = (op, ...)"""
+
+    def __init__(self, node):
+        self.node = node
+
+    def _w(self, o):
+        return o if isinstance(o, Expr) else Expr(("const", int(o) % R))
+
+    def __add__(self, o): return Expr(("add", self, self._w(o)))
+    def __radd__(self, o): return self._w(o) + self
+    def __sub__(self, o): return Expr(("sub", self, self._w(o)))
+    def __rsub__(self, o): return self._w(o) - self
+    def __mul__(self, o): return Expr(("mul", self, self._w(o)))
+    def __rmul__(self, o): return self._w(o) * self
+    def __neg__(self): return Expr(("neg", self))
+
+
+def adv(col, rot=0): return Expr(("adv", col, rot))
+def fix(col, rot=0): return Expr(("fix", col, rot))
+def const(v): return Expr(("const", int(v) % R))
+
+
+def degree(e):
+    op = e.node[0]
+    if op == "const": return 0
+    if op in ("adv", "fix"): return 1
+    if op == "neg": return degree(e.node[1])
+    if op in ("add", "sub"): return max(degree(e.node[1]), degree(e.node[2]))
+    return degree(e.node[1]) + degree(e.node[2])
+
+
+def queries(e, out):
+    op = e.node[0]
+    if op in ("adv", "fix"):
+        out.add((op, e.node[1], e.node[2]))
+    elif op != "const":
+        for c in e.node[1:]:
+            queries(c, out)
+    return out
+
+
+def evaluate(e, q):
+    """verifier side: q(kind, col, rot) -> int"""
+    op = e.node[0]
+    if op == "const": return e.node[1]
+    if op in ("adv", "fix"): return q(op, e.node[1], e.node[2])
+    if op == "neg": return (-evaluate(e.node[1], q)) % R
+    a, b = evaluate(e.node[1], q), evaluate(e.node[2], q)
+    return (a + b) % R if op == "add" else (a - b) % R if op == "sub" else a * b % R
+
+
+def lower(e, prog, col_index, memo):
+    """emit the expression into a GraphProgram; col_index(kind, col) -> column slot of the program"""
+    key = id(e)
+    if key in memo: return memo[key]
+    op = e.node[0]
+    if op == "const": r = prog.constant(to_mont(e.node[1]))
+    elif op in ("adv", "fix"): r = prog.column(col_index(op, e.node[1]), e.node[2])
+    elif op == "neg": r = prog.calc("negate", lower(e.node[1], prog, col_index, memo))
+    else: r = prog.calc(op, lower(e.node[1], prog, col_index, memo), lower(e.node[2], prog, col_index, memo))
+    memo[key] = r
+    return r
+
+
+class ConstraintSystem:
+    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns):
+        self.k, self.n = k, 1 << k
+        self.n_advice, self.n_fixed = n_advice, n_fixed
+        self.gates = list(gates)
+        self.perm = list(permutation_columns)             # [("adv"|"fix", col)]
+        self.usable = self.n - BLINDING - 1               # row index of l_last; rows [0, usable) carry the witness
+        d = max([degree(g) for g in self.gates] + [3])
+        self.degree = d
+        self.chunk = d - 2
+        self.ext_k = k
+        while (1 << self.ext_k) < self.n * (d - 1):
+            self.ext_k += 1
+        qs = set()
+        for g in self.gates:
+            queries(g, qs)
+        for kind, c in self.perm:
+            qs.add((kind, c, 0))
+        self.advice_queries = sorted((c, r) for kd, c, r in qs if kd == "adv")
+        self.fixed_queries = sorted((c, r) for kd, c, r in qs if kd == "fix")
+        self.n_chunks = -(-len(self.perm) // self.chunk) if self.perm else 0
+
+    def perm_chunks(self):
+        return [self.perm[i:i + self.chunk] for i in range(0, len(self.perm), self.chunk)]
+
+
+def omega(k): return pow(ROOT, 1 << (28 - k), R)
+
+
+# ------------------------------------------------------------------ GPU backend (column handles = DeviceBuffer)
+class GpuBackend:
+    """every column is a resident HBM buffer; scalars cross the ABI as 32-byte Montgomery values"""
+    name = "hip"
+
+    def __init__(self, params_g, params_g_lagrange, k):
+        self.k, self.n = k, 1 << k
+        self.g = _b.Bases(params_g)
+        self.gl = _b.Bases(params_g_lagrange)
+        self._dom = {}
+
+    def dom(self, degree):
+        if degree not in self._dom:
+            self._dom[degree] = _b.EvaluationDomain(degree, self.k)
+        return self._dom[degree]
+
+    def upload(self, a): return _b.DeviceBuffer.from_numpy(np.ascontiguousarray(a, np.uint64))
+    def download(self, h, n): return h.to_numpy()[: 4 * n].reshape(n, 4)
+    def clone(self, h):
+        o = _b.DeviceBuffer(h.nbytes)
+        _b.vec_scale(h.ptr, to_mont(1), o.ptr, h.nbytes // 32)
+        return o
+    def commit_lagrange(self, hs): return [point_to_ints(p) for p in _b.msm_g1_batch_dev(self.gl, [h.ptr for h in hs], self.n)]
+    def commit(self, hs): return [point_to_ints(p) for p in _b.msm_g1_batch_dev(self.g, [h.ptr for h in hs], self.n)]
+    def lagrange_to_coeff(self, h):
+        o = self.clone(h)
+        d = self.dom(3)
+        _b.ntt_dev(o.ptr, self.k, d.omega_inv, inverse=True)
+        return o
+    def coeff_to_extended(self, h, ext_k):
+        o = _b.DeviceBuffer(32 << ext_k)
+        _b.coset_ntt_dev(h.ptr, o.ptr, self.k, ext_k, inverse=False)
+        return o
+    def extended_to_coeff(self, h, ext_k):
+        _b.coset_ntt_dev(h.ptr, h.ptr, self.k, ext_k, inverse=True, in_len=1 << ext_k)
+        return h
+    def divide_by_vanishing(self, h, ext_k): _b.divide_by_vanishing_dev(h.ptr, self.k, ext_k)
+    def eval_program(self, prog, cols, challenges, out): prog.evaluate_h([c.ptr for c in cols], [to_mont(c) for c in challenges], out.ptr)
+    def zeros(self, n): return _b.DeviceBuffer.from_numpy(np.zeros((n, 4), np.uint64))
+    def eval_poly(self, h, n, x, offset=0): return from_mont(_b.eval_polynomial(h.ptr + 32 * offset, n, to_mont(x)))
+    def slice_copy(self, h, offset, n):
+        o = _b.DeviceBuffer(32 * n)
+        _b.vec_scale(h.ptr + 32 * offset, to_mont(1), o.ptr, n)
+        return o
+    def axpy(self, acc, s, h, n):
+        """acc += s * h over n elements"""
+        t = _b.DeviceBuffer(32 * n)
+        _b.vec_scale(h.ptr, to_mont(s), t.ptr, n)
+        _b.vec_op("add", acc.ptr, t.ptr, acc.ptr, n)
+    def sub_low(self, h, coeffs):
+        """h[i] -= coeffs[i] for the few lowest coefficients"""
+        m = len(coeffs)
+        t = self.upload(np.stack([to_mont(c) for c in coeffs]))
+        _b.vec_op("sub", h.ptr, t.ptr, h.ptr, m)
+    def scale(self, h, s, n): _b.vec_scale(h.ptr, to_mont(s), h.ptr, n)
+    def permutation_product(self, value_cols, sigma_cols, beta, gamma, first_index, z0, omega_col):
+        return _b.permutation_grand_product(self.k, [c.ptr for c in value_cols], [c.ptr for c in sigma_cols], to_mont(beta), to_mont(gamma),
+                                            omega_col=omega_col, first_column_index=first_index, z0=None if z0 is None else to_mont(z0))
+    def omega_powers(self): return _b.omega_powers_column(self.k)
+    def set_rows(self, h, start, values):
+        """overwrite rows [start, start+len) (blinding rows) with host values"""
+        v = np.stack([to_mont(x) for x in values])
+        _b.memcpy_h2d(h.ptr + 32 * start, v)
+    def get_row(self, h, i): return from_mont(_b.memcpy_d2h(h.ptr + 32 * i, 32).view(np.uint64))
+    def kate_div(self, h, z, n):
+        """q(X) = p(X) / (X - z) for p(z) = 0, in place: q_i = z^-(i+1) * sum_{j>i} p_j z^j, via scans"""
+        zp = self.upload(np.tile(to_mont(z), (n, 1)))
+        _b.prefix_scan("mul", zp.ptr, zp.ptr, n, exclusive=True)               # z^j
+        zi = self.upload(np.tile(to_mont(pow(z, -1, R)), (n, 1)))
+        _b.prefix_scan("mul", zi.ptr, zi.ptr, n, exclusive=False)              # z^-(j+1)
+        _b.vec_op("mul", h.ptr, zp.ptr, h.ptr, n)                               # w_j = p_j z^j
+        _b.prefix_scan("add", h.ptr, h.ptr, n, exclusive=False)                # P_i = sum_{j<=i} w_j ; P_{n-1} = p(z) = 0
+        _b.vec_scale(h.ptr, to_mont(R - 1), h.ptr, n)                           # -P_i = sum_{j>i} w_j
+        _b.vec_op("mul", h.ptr, zi.ptr, h.ptr, n)
+        return h
+
+
+# ------------------------------------------------------------------ keygen
+class ProvingKey:
+    pass
+
+
+def keygen(cs, backend, fixed_values, copies):
+    """fixed_values: list of (n,4) Montgomery arrays; copies: list of ((colpos, row), (colpos, row)) equalities where
+    colpos indexes cs.perm.  Returns the proving key (resident polys / cosets) and the verifying key."""
+    n, k = cs.n, cs.k
+    w = omega(k)
+    pk = ProvingKey()
+    pk.cs = cs
+    pk.fixed_values = [backend.upload(v) for v in fixed_values]
+    pk.fixed_polys = [backend.lagrange_to_coeff(h) for h in pk.fixed_values]
+    pk.fixed_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in pk.fixed_polys]
+    # permutation: cycle structure over (colpos, row) cells; sigma[colpos][row] = delta^colpos' * omega^row'
+    m = len(cs.perm)
+    mapping = {(c, r): (c, r) for c in range(m) for r in range(n)}
+    aux = {(c, r): (c, r) for c in range(m) for r in range(n)}
+    sizes = {(c, r): 1 for c in range(m) for r in range(n)}
+    for a, b2 in copies:
+        if aux[a] == aux[b2]:
+            continue
+        if sizes[aux[a]] < sizes[aux[b2]]:
+            a, b2 = b2, a
+        ra, rb = aux[a], aux[b2]
+        sizes[ra] += sizes[rb]
+        cur = b2
+        while True:                                   # relabel the smaller cycle
+            aux[cur] = ra
+            cur = mapping[cur]
+            if cur == b2:
+                break
+        mapping[a], mapping[b2] = mapping[b2], mapping[a]
+    wpow = [1] * n
+    for i in range(1, n):
+        wpow[i] = wpow[i - 1] * w % R
+    sig = []
+    for c in range(m):
+        col = np.empty((n, 4), np.uint64)
+        for r in range(n):
+            c2, r2 = mapping[(c, r)]
+            col[r] = to_mont(pow(DELTA, c2, R) * wpow[r2] % R)
+        sig.append(col)
+    pk.sigma_values = [backend.upload(s) for s in sig]
+    pk.sigma_polys = [backend.lagrange_to_coeff(h) for h in pk.sigma_values]
+    pk.sigma_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in pk.sigma_polys]
+    # l0, l_last, l_active_row
+    def lag(rows):
+        v = np.zeros((n, 4), np.uint64)
+        for r in rows:
+            v[r] = to_mont(1)
+        return backend.coeff_to_extended(backend.lagrange_to_coeff(backend.upload(v)), cs.ext_k)
+    pk.l0 = lag([0])
+    pk.l_last = lag([cs.usable])
+    pk.l_active = lag(range(cs.usable))
+    # the identity column X on the extended coset: zeta * omega_ext^i, as a resident column (from coefficients [0, 1, 0...])
+    xcoef = np.zeros((n, 4), np.uint64)
+    xcoef[1] = to_mont(1)
+    pk.x_coset = backend.coeff_to_extended(backend.upload(xcoef), cs.ext_k)
+    pk.omega_col = backend.omega_powers()
+    vk = VerifyingKey()
+    vk.cs = cs
+    vk.fixed_commitments = backend.commit(pk.fixed_polys) if pk.fixed_polys else []
+    vk.sigma_commitments = backend.commit(pk.sigma_polys) if pk.sigma_polys else []
+    vk.digest = vk_digest(vk)
+    pk.vk = vk
+    return pk, vk
+
+
+class VerifyingKey:
+    pass
+
+
+def vk_digest(vk):
+    t = bytearray([vk.cs.k, vk.cs.n_advice, vk.cs.n_fixed, vk.cs.degree, len(vk.cs.perm)])
+    for p in list(vk.fixed_commitments) + list(vk.sigma_commitments):
+        x, y = (0, 0) if p is None else p
+        t += x.to_bytes(32, "big") + y.to_bytes(32, "big")
+    return int.from_bytes(keccak256(bytes(t)), "big") % R
+
+
+# ------------------------------------------------------------------ prover
+def create_proof(pk, backend, advice_values, rng):
+    """advice_values: list of (n,4) Montgomery arrays (rows >= usable are overwritten with blinding randomness).
+    rng() -> random field element (int).  Returns proof bytes (EvmTranscript layout)."""
+    cs = pk.cs
+    n, k, u = cs.n, cs.k, cs.usable
+    T = EvmTranscript()
+    T.common_scalar(pk.vk.digest)
+    # 1. advice columns
+    adv_cols = []
+    for v in advice_values:
+        v = np.array(v, np.uint64, copy=True)
+        for r in range(u, n):
+            v[r] = to_mont(rng())
+        adv_cols.append(backend.upload(v))
+    for p in backend.commit_lagrange(adv_cols):
+        T.write_point(p)
+    # 3. beta, gamma
+    beta, gamma = T.squeeze_challenge(), T.squeeze_challenge()
+    # 4. permutation grand products, chained across chunks
+    def col_handle(kind, c): return adv_cols[c] if kind == "adv" else pk.fixed_values[c]
+    zs, last = [], None
+    pos = 0
+    for chunk in cs.perm_chunks():
+        vals = [col_handle(kd, c) for kd, c in chunk]
+        sigs = pk.sigma_values[pos:pos + len(chunk)]
+        z = backend.permutation_product(vals, sigs, beta, gamma, pos, last, pk.omega_col)
+        last = backend.get_row(z, u)
+        backend.set_rows(z, u + 1, [rng() for _ in range(n - u - 1)])
+        zs.append(z)
+        pos += len(chunk)
+    for p in backend.commit_lagrange(zs) if zs else []:
+        T.write_point(p)
+    # 5. vanishing argument: random polynomial
+    rnd = backend.upload(np.stack([to_mont(rng()) for _ in range(n)]))
+    T.write_point(backend.commit([rnd])[0])
+    # 6. y
+    y = T.squeeze_challenge()
+    # 7. quotient
+    adv_polys = [backend.lagrange_to_coeff(h) for h in adv_cols]
+    z_polys = [backend.lagrange_to_coeff(h) for h in zs]
+    adv_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in adv_polys]
+    z_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in z_polys]
+    prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y)
+    hnum = backend.zeros(1 << cs.ext_k)
+    backend.eval_program(prog, cols, chal, hnum)
+    backend.divide_by_vanishing(hnum, cs.ext_k)
+    hcoef = backend.extended_to_coeff(hnum, cs.ext_k)
+    npieces = cs.degree - 1
+    pieces = [backend.slice_copy(hcoef, i * n, n) for i in range(npieces)]
+    for p in backend.commit(pieces):
+        T.write_point(p)
+    # 8. x
+    x = T.squeeze_challenge()
+    w = omega(k)
+    def rot_point(r): return x * pow(w, r % n if r >= 0 else n + r, R) % R
+    # 9. evaluations
+    evals = {}
+    for c, r in cs.advice_queries:
+        evals[("adv", c, r)] = backend.eval_poly(adv_polys[c], n, rot_point(r)); T.write_scalar(evals[("adv", c, r)])
+    for c, r in cs.fixed_queries:
+        evals[("fix", c, r)] = backend.eval_poly(pk.fixed_polys[c], n, rot_point(r)); T.write_scalar(evals[("fix", c, r)])
+    random_eval = backend.eval_poly(rnd, n, x); T.write_scalar(random_eval)
+    sigma_evals = [backend.eval_poly(h, n, x) for h in pk.sigma_polys]
+    for e in sigma_evals: T.write_scalar(e)
+    z_evals = []
+    for j, zp in enumerate(z_polys):
+        e0, e1 = backend.eval_poly(zp, n, x), backend.eval_poly(zp, n, rot_point(1))
+        T.write_scalar(e0); T.write_scalar(e1)
+        e2 = None
+        if j + 1 < len(z_polys):
+            e2 = backend.eval_poly(zp, n, rot_point(u)); T.write_scalar(e2)
+        z_evals.append((e0, e1, e2))
+    # 10. multiopen (SHPLONK)
+    xn = pow(x, n, R)
+    hcomb = backend.zeros(n)
+    for i in reversed(range(npieces)):
+        backend.scale(hcomb, xn, n)
+        backend.axpy(hcomb, 1, pieces[i], n)
+    h_eval = backend.eval_poly(hcomb, n, x)
+    qs = []   # (key, poly handle, point, eval) -- the verifier rebuilds the same list with commitments for handles
+    for c, r in cs.advice_queries: qs.append((("adv", c), adv_polys[c], rot_point(r), evals[("adv", c, r)]))
+    for c, r in cs.fixed_queries: qs.append((("fix", c), pk.fixed_polys[c], rot_point(r), evals[("fix", c, r)]))
+    qs.append((("h",), hcomb, x, h_eval))
+    qs.append((("rnd",), rnd, x, random_eval))
+    for i, (h, e) in enumerate(zip(pk.sigma_polys, sigma_evals)): qs.append((("sigma", i), h, x, e))
+    for j, zp in enumerate(z_polys):
+        qs.append((("z", j), zp, x, z_evals[j][0])); qs.append((("z", j), zp, rot_point(1), z_evals[j][1]))
+        if z_evals[j][2] is not None: qs.append((("z", j), zp, rot_point(u), z_evals[j][2]))
+    shplonk_prove(backend, T, qs, n)
+    return bytes(T.proof)
+
+
+def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y):
+    """the numerator of h(X) as ONE straight-line program over the extended-coset columns: custom gates, then the
+    permutation constraints, folded with y (value = value*y + constraint), as evaluate_h does"""
+    prog = _b.GraphProgram(cs.k, cs.ext_k)
+    cols, index = [], {}
+    def slot(name, handle):
+        if name not in index:
+            index[name] = len(cols); cols.append(handle)
+        return index[name]
+    def col_index(kind, c): return slot((kind, c), adv_cosets[c] if kind == "adv" else pk.fixed_cosets[c])
+    chal = [y, beta, gamma]
+    Y, BETA, GAMMA = prog.challenge(0), prog.challenge(1), prog.challenge(2)
+    terms, memo = [], {}
+    for g in cs.gates:
+        terms.append(lower(g, prog, col_index, memo))
+    if cs.perm:
+        l0 = prog.column(slot("l0", pk.l0)); llast = prog.column(slot("l_last", pk.l_last)); lact = prog.column(slot("l_active", pk.l_active))
+        X = prog.column(slot("X", pk.x_coset))
+        one = prog.constant(to_mont(1))
+        nz = len(z_cosets)
+        zc = [slot(("z", j), z_cosets[j]) for j in range(nz)]
+        terms.append(prog.calc("mul", l0, prog.calc("sub", one, prog.column(zc[0]))))
+        zl = prog.column(zc[nz - 1])
+        terms.append(prog.calc("mul", llast, prog.calc("sub", prog.calc("square", zl), zl)))
+        for j in range(1, nz):
+            terms.append(prog.calc("mul", l0, prog.calc("sub", prog.column(zc[j]), prog.column(zc[j - 1], cs.usable))))
+        pos = 0
+        for j, chunk in enumerate(cs.perm_chunks()):
+            left, right = prog.column(zc[j], 1), prog.column(zc[j])
+            for i, (kd, c) in enumerate(chunk):
+                v = prog.column(col_index(kd, c))
+                sg = prog.column(slot(("sigma", pos + i), pk.sigma_cosets[pos + i]))
+                left = prog.calc("mul", left, prog.calc("add", prog.calc("add", v, prog.calc("mul", BETA, sg)), GAMMA))
+                chal.append(beta * pow(DELTA, pos + i, R) % R)
+                bd = prog.challenge(len(chal) - 1)
+                right = prog.calc("mul", right, prog.calc("add", prog.calc("add", v, prog.calc("mul", bd, X)), GAMMA))
+            terms.append(prog.calc("mul", lact, prog.calc("sub", left, right)))
+            pos += len(chunk)
+    prog.horner(prog.previous(), terms, Y)
+    return prog, cols, chal
+
+
+# ------------------------------------------------------------------ SHPLONK (BDFG20) multi-point opening
+def group_queries(qs):
+    """group (key, poly, point, eval) by polynomial key, then polynomials by their point set
+    -> [(points tuple, [(poly, {pt: eval})])] in order of first appearance"""
+    by_poly, order = {}, []
+    for kp, p, z, e in qs:
+        if kp not in by_poly:
+            by_poly[kp] = (p, {}); order.append(kp)
+        by_poly[kp][1][z] = e
+    sets, sorder = {}, []
+    for kp in order:
+        p, ev = by_poly[kp]
+        pts = tuple(sorted(ev))
+        if pts not in sets:
+            sets[pts] = []; sorder.append(pts)
+        sets[pts].append((p, ev))
+    return [(pts, sets[pts]) for pts in sorder]
+
+
+def interpolate(points, values):
+    """coefficients (low first) of the polynomial of degree < len(points) through (points, values)"""
+    m = len(points)
+    coeffs = [0] * m
+    for i in range(m):
+        num, den = [1], 1
+        for j in range(m):
+            if j == i: continue
+            num = [(a - points[j] * b) % R for a, b in zip([0] + num, num + [0])]
+            den = den * (points[i] - points[j]) % R
+        s = values[i] * pow(den, -1, R) % R
+        for t in range(len(num)):
+            coeffs[t] = (coeffs[t] + s * num[t]) % R
+    return coeffs
+
+
+def eval_small(coeffs, x):
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % R
+    return acc
+
+
+def shplonk_prove(backend, T, qs, n):
+    groups = group_queries(qs)
+    ys = T.squeeze_challenge()
+    all_pts = sorted({z for pts, _ in groups for z in pts})
+    combos = []
+    for pts, polys in groups:
+        q = backend.zeros(n)
+        evs = {z: 0 for z in pts}
+        pw = 1
+        for p, ev in polys:
+            backend.axpy(q, pw, p, n)
+            for z in pts:
+                evs[z] = (evs[z] + pw * ev[z]) % R
+            pw = pw * ys % R
+        r = interpolate(list(pts), [evs[z] for z in pts])
+        combos.append((pts, q, r))
+    v = T.squeeze_challenge()
+    h = backend.zeros(n)
+    pw = 1
+    quot = []
+    for pts, q, r in combos:
+        t = backend.clone(q)
+        backend.sub_low(t, r)
+        for z in pts:
+            backend.kate_div(t, z, n)
+        backend.axpy(h, pw, t, n)
+        quot.append(t)
+        pw = pw * v % R
+    T.write_point(backend.commit([h])[0])
+    u = T.squeeze_challenge()
+    zt_u = 1
+    for z in all_pts:
+        zt_u = zt_u * (u - z) % R
+    L = backend.zeros(n)
+    pw = 1
+    const_term = 0
+    for pts, q, r in combos:
+        zdiff = 1
+        for z in all_pts:
+            if z not in pts:
+                zdiff = zdiff * (u - z) % R
+        backend.axpy(L, pw * zdiff % R, q, n)
+        const_term = (const_term + pw * zdiff % R * eval_small(r, u)) % R
+        pw = pw * v % R
+    backend.sub_low(L, [const_term])
+    backend.axpy(L, (-zt_u) % R, h, n)
+    backend.kate_div(L, u, n)
+    T.write_point(backend.commit([L])[0])

@@ -107,6 +107,16 @@ def batch_invert(a):
     a = _fe(a).copy(); lib.oracle_batch_invert(_ptr(a), C.c_size_t(a.shape[0])); return a
 
 
+def kate_div(a, z):
+    a, z = _fe(a).copy(), _fe(z)
+    lib.oracle_kate_div(_ptr(a), C.c_size_t(a.shape[0]), _ptr(z)); return a
+
+
+def vec_scale(a, s):
+    a, s = _fe(a), _fe(s); o = np.empty_like(a)
+    lib.oracle_vec_scale(_ptr(a), _ptr(s), _ptr(o), C.c_size_t(a.shape[0])); return o
+
+
 def eval_poly(c, x):
     c, x = _fe(c), _fe(x); o = np.empty(4, np.uint64)
     lib.oracle_eval_poly(_ptr(c), C.c_size_t(c.shape[0]), _ptr(x), _ptr(o)); return o

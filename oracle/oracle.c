@@ -377,6 +377,17 @@ void oracle_batch_invert(fe *a, size_t n) {
     free(pre);
 }
 
+/* q(X) = p(X) / (X - z) for p(z) = 0 (synthetic division), in place; the top coefficient becomes 0 */
+void oracle_kate_div(fe *a, size_t n, const fe *z) {
+    fe carry = {{0, 0, 0, 0}};
+    for (size_t i = n; i-- > 0;) {
+        fe cur = a[i];            /* q_{i-1} = p_i + z * q_i */
+        a[i] = carry;
+        f_mul(&carry, &carry, z, &FR);
+        f_add(&carry, &carry, &cur, &FR);
+    }
+}
+
 /* eval_polynomial(poly, x): Horner from the top coefficient */
 void oracle_eval_poly(const fe *c, size_t n, const fe *x, fe *out) {
     fe acc = {{0, 0, 0, 0}};

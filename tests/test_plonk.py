@@ -1,0 +1,93 @@
+"""End-to-end: the halo2-shaped prover (ezkl_amd/plonk.py) makes a proof that the independent pairing verifier
+accepts (the reference's own acceptance criterion), on the reference's k=6 SRS fixture.
+CPU: protocol logic on the oracle backend.  GPU: the same proof BYTES from the HIP kernels."""
+import numpy as np
+import pytest
+from conftest import fe_from_int, R
+from ezkl_amd import plonk as P
+from oracle import pairing as E, pyref as pr, verifier as V
+
+
+def mul_add_circuit(k):
+    """a small ezkl-flavoured circuit: per row  sel_mul*(c - a*b) = 0  and  sel_acc*(c - c[-1] - a*b) = 0
+    (MULT and DOT-style gates, src/circuit/ops/chip.rs:344-425), with copy constraints chaining rows"""
+    a, b, c = P.adv(0), P.adv(1), P.adv(2)
+    sel_mul, sel_acc = P.fix(0), P.fix(1)
+    gates = [sel_mul * (c - a * b), sel_acc * (c - P.adv(2, -1) - a * b)]
+    perm = [("adv", 0), ("adv", 1), ("adv", 2), ("fix", 2)]
+    return P.ConstraintSystem(k, 3, 3, gates, perm)
+
+
+def witness(cs, seed):
+    rng = np.random.default_rng(seed)
+    n, u = cs.n, cs.usable
+    A = [[0] * n for _ in range(3)]
+    F = [[0] * n for _ in range(3)]
+    copies = []
+    half = u // 2
+    for r in range(half):                      # MULT rows
+        x, y = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1 << 30))
+        A[0][r], A[1][r], A[2][r] = x, y, x * y % R
+        F[0][r] = 1
+    A[2][half] = 0                              # accumulator start (c[half] is a free cell constrained via copy to constant 0)
+    F[2][half] = 0
+    copies.append(((2, half), (3, half)))       # adv2[half] == fix2[half] (= 0)
+    for r in range(half + 1, u):               # DOT rows: c = c[-1] + a*b, inputs copied from the MULT rows
+        src = r - half - 1
+        A[0][r], A[1][r] = A[0][src], A[1][src]
+        copies.append(((0, r), (0, src)))
+        copies.append(((1, r), (1, src)))
+        A[2][r] = (A[2][r - 1] + A[0][r] * A[1][r]) % R
+        F[1][r] = 1
+    to_col = lambda col: np.stack([fe_from_int(v) for v in col])
+    return [to_col(c) for c in A], [to_col(c) for c in F], copies
+
+
+def det_rng(seed):
+    st = np.random.default_rng(seed)
+    return lambda: int.from_bytes(st.bytes(40), "little") % R
+
+
+def setup(golden_srs):
+    srs = pr.parse_srs(golden_srs["buf"])
+    g2, s_g2 = E.g2_from_bytes(srs["g2"]), E.g2_from_bytes(srs["s_g2"])
+    g1 = pr.g1_from_bytes(srs["g"][0])
+    return g1, g2, s_g2
+
+
+def test_prove_verify_oracle_backend(golden_srs):
+    from oracle.cpu_backend import OracleBackend
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 1)
+    be = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk, vk = P.keygen(cs, be, fixed, copies)
+    proof = P.create_proof(pk, be, adv, det_rng(7))
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk, g1, g2, s_g2, proof)
+    # tampering: any flipped byte, or a witness that violates a gate / a copy constraint, must be rejected
+    bad = bytearray(proof); bad[len(bad) // 2] ^= 1
+    assert not V.verify(vk, g1, g2, s_g2, bytes(bad))
+    adv_bad = [a.copy() for a in adv]; adv_bad[2][3] = fe_from_int(12345)          # breaks c = a*b on row 3
+    assert not V.verify(vk, g1, g2, s_g2, P.create_proof(pk, be, adv_bad, det_rng(7)))
+    adv_bad = [a.copy() for a in adv]; adv_bad[0][cs.usable - 1] = adv_bad[0][0]    # breaks a copy constraint, keeps the gate consistent
+    r = cs.usable - 1
+    adv_bad[2][r] = fe_from_int((P.from_mont(adv_bad[2][r - 1]) + P.from_mont(adv_bad[0][r]) * P.from_mont(adv_bad[1][r])) % R)
+    assert not V.verify(vk, g1, g2, s_g2, P.create_proof(pk, be, adv_bad, det_rng(7)))
+
+
+@pytest.mark.gpu
+def test_gpu_proof_is_bit_identical_to_cpu_proof(hip, golden_srs):
+    """north-star: proofs bit-identical to the CPU prover on the same SRS / witness / randomness"""
+    from oracle.cpu_backend import OracleBackend
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 2)
+    cpu = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk_c, vk_c = P.keygen(cs, cpu, fixed, copies)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    assert vk_c.digest == vk_g.digest and vk_c.fixed_commitments == vk_g.fixed_commitments
+    proof_c = P.create_proof(pk_c, cpu, adv, det_rng(11))
+    proof_g = P.create_proof(pk_g, gpu, adv, det_rng(11))
+    assert proof_g == proof_c
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk_g, g1, g2, s_g2, proof_g)
