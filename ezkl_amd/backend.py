@@ -93,6 +93,17 @@ class _Bases:
         self.h = h
         return self
 
+    @classmethod
+    def from_scalars(cls, base_point, scalars_ptr, n):
+        """bases[i] = scalars[i] * base_point (SRS generation)"""
+        self = cls.__new__(cls)
+        self.n = n
+        h = _vp()
+        _l.check(_l.load().ezkl_hip_bases_from_scalars(_p(_fe(base_point, 8)), _vp(scalars_ptr), C.c_size_t(n), C.byref(h)),
+                 "ezkl_hip_bases_from_scalars")
+        self.h = h
+        return self
+
     def download(self):
         out = np.empty((self.n, 8), np.uint64)
         _l.check(_l.load().ezkl_hip_bases_download(self.h, _p(out)), "ezkl_hip_bases_download")
@@ -222,6 +233,10 @@ def vec_scale(a_ptr, scalar, out_ptr, n, stream=None):
     _l.check(_l.load().ezkl_hip_vec_scale_dev(_vp(a_ptr), _p(_fe(scalar)), _vp(out_ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_vec_scale_dev")
 
 
+def vec_fill(out_ptr, value, n, stream=None):
+    _l.check(_l.load().ezkl_hip_vec_fill_dev(_vp(out_ptr), _p(_fe(value)), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_vec_fill_dev")
+
+
 def coset_ntt_dev(in_ptr, out_ptr, k, ext_k, inverse=False, in_len=None, batch=1, stream=None):
     """coeff_to_extended (inverse=False: 2^k coefficients in, 2^ext_k evaluations out) / extended_to_coeff on resident columns"""
     nin = (1 << ext_k) if inverse else (1 << k)
@@ -274,6 +289,30 @@ def eval_polynomial(coeffs_ptr, n, x, stream=None):
 def batch_invert(ptr, n, stream=None):
     _l.check(_l.load().ezkl_hip_batch_invert_dev(_vp(ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_batch_invert_dev")
 
+
+def gen_srs(k, s):
+    """test SRS with a KNOWN secret s (insecure, like the reference's gen_srs, src/pfsys/srs.rs:13-16):
+    g[i] = s^i G, g_lagrange[i] = L_i(s) G with L_i(s) = (s^n - 1) w^i / (n (s - w^i)); everything on the device.
+    Returns (g, g_lagrange) as Bases."""
+    n = 1 << k
+    w = pow(EvaluationDomain.ROOT, 1 << (28 - k), _R)
+    G = np.frombuffer((_MONT % _Q).to_bytes(32, "little") + (2 * _MONT % _Q).to_bytes(32, "little"), np.uint64).copy()
+    spow = DeviceBuffer(n * 32)
+    vec_fill(spow.ptr, _to_mont(s), n)
+    prefix_scan("mul", spow.ptr, spow.ptr, n, exclusive=True)                 # s^i
+    g = _Bases.from_scalars(G, spow.ptr, n)
+    wp = omega_powers_column(k)                                               # w^i
+    den = DeviceBuffer(n * 32)
+    vec_fill(den.ptr, _to_mont(s), n)
+    vec_op("sub", den.ptr, wp.ptr, den.ptr, n)                                # s - w^i
+    batch_invert(den.ptr, n)
+    vec_op("mul", den.ptr, wp.ptr, den.ptr, n)
+    vec_scale(den.ptr, _to_mont((pow(s, n, _R) - 1) * pow(n, -1, _R) % _R), den.ptr, n)
+    gl = _Bases.from_scalars(G, den.ptr, n)
+    return g, gl
+
+
+_Q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
 
 # Montgomery constants needed host-side (derived, not copied: tools/gen_constants.py)
 _R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
@@ -439,7 +478,8 @@ def omega_powers_column(k):
     """device column X[i] = omega_k^i (built with an exclusive product scan of a constant column)"""
     n = 1 << k
     w = pow(EvaluationDomain.ROOT, 1 << (28 - k), _R)
-    col = DeviceBuffer.from_numpy(np.tile(_to_mont(w), (n, 1)))
+    col = DeviceBuffer(n * 32)
+    vec_fill(col.ptr, _to_mont(w), n)
     prefix_scan("mul", col.ptr, col.ptr, n, exclusive=True)
     return col
 

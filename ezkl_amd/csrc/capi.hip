@@ -198,6 +198,21 @@ int ezkl_hip_bases_download(ezkl_bases_t h, void* out_host) {
     EZ_HIP(hipMemcpy(out_host, b->pts, b->n * 64, hipMemcpyDeviceToHost));
     return EZKL_OK;
 }
+int ezkl_hip_bases_from_scalars(const void* base_point, const void* scalars_dev, size_t n, ezkl_bases_t* out) {
+    if (!base_point || !scalars_dev || !out || n == 0) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    Bases* b = new Bases();
+    b->n = n;
+    EZ_HIP(hipMalloc(&b->pts, n * 64));
+    int rc = g1_mul_fixed(c, c->stream, base_point, (const fe_t*)scalars_dev, n, b->pts);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = set_hip_error(e, "g1_mul_fixed", __FILE__, __LINE__);
+    }
+    if (rc) { (void)hipFree(b->pts); delete b; return rc; }
+    *out = reinterpret_cast<ezkl_bases_t>(b);
+    return EZKL_OK;
+}
 size_t ezkl_hip_bases_len(ezkl_bases_t h) { return h ? reinterpret_cast<Bases*>(h)->n : 0; }
 
 int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, void* out, void* stream) {
@@ -333,6 +348,15 @@ int ezkl_hip_vec_op_dev(int op, const void* a, const void* b, void* o, size_t n,
     EZ_CTX(c);
     hipStream_t st = pick_stream(c, stream);
     int rc = vec_op(c, st, op, (const fe_t*)a, (const fe_t*)b, (fe_t*)o, n);
+    return rc ? rc : finish(c, st, stream);
+}
+int ezkl_hip_vec_fill_dev(void* o, const void* v, size_t n, void* stream) {
+    if (!o || !v) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    fe_t val;
+    memcpy(&val, v, 32);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = vec_fill(c, st, (fe_t*)o, val, n);
     return rc ? rc : finish(c, st, stream);
 }
 int ezkl_hip_vec_scale_dev(const void* a, const void* s, void* o, size_t n, void* stream) {

@@ -69,6 +69,7 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
 int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
                   void* out_host);
 int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o, size_t n);
+int vec_fill(Ctx* c, hipStream_t st, fe_t* o, const fe_t& v, size_t n);
 int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, size_t n);
 int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
@@ -80,6 +81,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
 int eval_jit_compile_only(const ezkl_program_t* p);
 int ubench(Ctx* c, const char* which, double* out);
 void msm_table_drop(const Bases* b);
+int g1_mul_fixed(Ctx* c, hipStream_t st, const void* base_host, const fe_t* scalars, size_t n, void* out_dev);
 int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, void* out_dev);
 void g1_add_affine_host(const void* a, const void* b, void* out);
 

@@ -651,6 +651,32 @@ int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, voi
     return EZKL_OK;
 }
 
+// ---- out[i] = scalars[i] * P for one fixed point P (SRS generation: g[i] = s^i G, g_lagrange[i] = L_i(s) G;
+//      the reference's gen_srs -> ParamsKZG::setup, /root/reference/src/pfsys/srs.rs:14-16) ----
+__global__ __launch_bounds__(256) void g1_mul_fixed_kernel(g1a_t base, const fe_t* scalars, size_t n, g1a_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t s = Fr::from_mont(ld_fe(scalars + i));
+    g1x_t acc = g1x_identity();
+    bool started = false;
+    for (int b = 253; b >= 0; b--) {
+        if (started) acc = g1x_double(acc);
+        if ((s.v[b >> 5] >> (b & 31)) & 1) {
+            acc = g1x_add_mixed(acc, base);
+            started = true;
+        }
+    }
+    st_g1a(out + i, g1x_to_affine(acc));
+}
+int g1_mul_fixed(Ctx* c, hipStream_t st, const void* base_host, const fe_t* scalars, size_t n, void* out_dev) {
+    if (n == 0) return EZKL_OK;
+    g1a_t b;
+    memcpy(&b, base_host, 64);
+    hipLaunchKernelGGL(g1_mul_fixed_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, b, scalars, n, (g1a_t*)out_dev);
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+
 void g1_add_affine_host(const void* a, const void* b, void* out) {
     h64::aff p, q;
     memcpy(&p, a, 64);

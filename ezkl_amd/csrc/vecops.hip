@@ -25,6 +25,10 @@ __global__ __launch_bounds__(256) void vec_periodic_mul_kernel(fe_t* a, const fe
         st_fe(a + i, Fr::mul(ld_fe(a + i), ld_fe(t + (i & mask))));
 }
 
+__global__ __launch_bounds__(256) void vec_fill_kernel(fe_t* o, fe_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fe(o + i, v);
+}
+
 static unsigned stream_grid(Ctx* c, size_t n) {
     size_t want = (n + 255) / 256, cap = (size_t)c->num_cus * 8;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
@@ -36,6 +40,12 @@ int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o
     if (op == EZKL_VEC_ADD) hipLaunchKernelGGL(vec_op_kernel<EZKL_VEC_ADD>, g, blk, 0, st, a, b, o, n);
     else if (op == EZKL_VEC_SUB) hipLaunchKernelGGL(vec_op_kernel<EZKL_VEC_SUB>, g, blk, 0, st, a, b, o, n);
     else hipLaunchKernelGGL(vec_op_kernel<EZKL_VEC_MUL>, g, blk, 0, st, a, b, o, n);
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+int vec_fill(Ctx* c, hipStream_t st, fe_t* o, const fe_t& v, size_t n) {
+    if (n == 0) return EZKL_OK;
+    hipLaunchKernelGGL(vec_fill_kernel, dim3(stream_grid(c, n)), dim3(256), 0, st, o, v, n);
     EZ_HIP(hipGetLastError());
     return EZKL_OK;
 }

@@ -148,6 +148,7 @@ class GpuBackend:
         self.g = _b.Bases(params_g)
         self.gl = _b.Bases(params_g_lagrange)
         self._dom = {}
+        self._zpow = {}
 
     def dom(self, degree):
         if degree not in self._dom:
@@ -176,7 +177,10 @@ class GpuBackend:
         return h
     def divide_by_vanishing(self, h, ext_k): _b.divide_by_vanishing_dev(h.ptr, self.k, ext_k)
     def eval_program(self, prog, cols, challenges, out): prog.evaluate_h([c.ptr for c in cols], [to_mont(c) for c in challenges], out.ptr)
-    def zeros(self, n): return _b.DeviceBuffer.from_numpy(np.zeros((n, 4), np.uint64))
+    def zeros(self, n):
+        o = _b.DeviceBuffer(32 * n)
+        _b.vec_fill(o.ptr, np.zeros(4, np.uint64), n)
+        return o
     def eval_poly(self, h, n, x, offset=0): return from_mont(_b.eval_polynomial(h.ptr + 32 * offset, n, to_mont(x)))
     def slice_copy(self, h, offset, n):
         o = _b.DeviceBuffer(32 * n)
@@ -197,22 +201,41 @@ class GpuBackend:
         return _b.permutation_grand_product(self.k, [c.ptr for c in value_cols], [c.ptr for c in sigma_cols], to_mont(beta), to_mont(gamma),
                                             omega_col=omega_col, first_column_index=first_index, z0=None if z0 is None else to_mont(z0))
     def omega_powers(self): return _b.omega_powers_column(self.k)
-    def set_rows(self, h, start, values):
-        """overwrite rows [start, start+len) (blinding rows) with host values"""
-        v = np.stack([to_mont(x) for x in values])
-        _b.memcpy_h2d(h.ptr + 32 * start, v)
+    def set_rows(self, h, start, mont_rows):
+        """overwrite rows [start, start+len) (blinding rows) with host values (Montgomery (m,4) array)"""
+        _b.memcpy_h2d(h.ptr + 32 * start, np.ascontiguousarray(mont_rows, np.uint64))
     def get_row(self, h, i): return from_mont(_b.memcpy_d2h(h.ptr + 32 * i, 32).view(np.uint64))
     def kate_div(self, h, z, n):
         """q(X) = p(X) / (X - z) for p(z) = 0, in place: q_i = z^-(i+1) * sum_{j>i} p_j z^j, via scans"""
-        zp = self.upload(np.tile(to_mont(z), (n, 1)))
-        _b.prefix_scan("mul", zp.ptr, zp.ptr, n, exclusive=True)               # z^j
-        zi = self.upload(np.tile(to_mont(pow(z, -1, R)), (n, 1)))
-        _b.prefix_scan("mul", zi.ptr, zi.ptr, n, exclusive=False)              # z^-(j+1)
+        key = (z, n)
+        if key not in self._zpow:                                               # z^j and z^-(j+1), cached per opening point
+            zp, zi = _b.DeviceBuffer(32 * n), _b.DeviceBuffer(32 * n)
+            _b.vec_fill(zp.ptr, to_mont(z), n)
+            _b.prefix_scan("mul", zp.ptr, zp.ptr, n, exclusive=True)
+            _b.vec_fill(zi.ptr, to_mont(pow(z, -1, R)), n)
+            _b.prefix_scan("mul", zi.ptr, zi.ptr, n, exclusive=False)
+            if len(self._zpow) > 8:
+                self._zpow.clear()
+            self._zpow[key] = (zp, zi)
+        zp, zi = self._zpow[key]
         _b.vec_op("mul", h.ptr, zp.ptr, h.ptr, n)                               # w_j = p_j z^j
         _b.prefix_scan("add", h.ptr, h.ptr, n, exclusive=False)                # P_i = sum_{j<=i} w_j ; P_{n-1} = p(z) = 0
         _b.vec_scale(h.ptr, to_mont(R - 1), h.ptr, n)                           # -P_i = sum_{j>i} w_j
         _b.vec_op("mul", h.ptr, zi.ptr, h.ptr, n)
         return h
+
+
+class Rng:
+    """prover randomness (blinding rows, the vanishing argument's random polynomial).  Seeded = the reference's
+    `det-prove` feature (src/pfsys/mod.rs:436-439); unseeded draws from the OS."""
+
+    def __init__(self, seed=None):
+        self.g = np.random.default_rng(seed)
+
+    def vec(self, m):
+        a = self.g.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * np.uint64(2) + self.g.integers(0, 2, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 61) - 1)          # 253 uniform bits < r, read as Montgomery residues
+        return a
 
 
 # ------------------------------------------------------------------ keygen
@@ -232,41 +255,51 @@ def keygen(cs, backend, fixed_values, copies):
     pk.fixed_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in pk.fixed_polys]
     # permutation: cycle structure over (colpos, row) cells; sigma[colpos][row] = delta^colpos' * omega^row'
     m = len(cs.perm)
-    mapping = {(c, r): (c, r) for c in range(m) for r in range(n)}
-    aux = {(c, r): (c, r) for c in range(m) for r in range(n)}
-    sizes = {(c, r): 1 for c in range(m) for r in range(n)}
-    for a, b2 in copies:
-        if aux[a] == aux[b2]:
+    # cells are numbered c * n + r; `nxt` is the cycle successor, `root` a cycle label, `size` the cycle length
+    nxt = np.arange(m * n, dtype=np.int64)
+    root = np.arange(m * n, dtype=np.int64)
+    size = np.ones(m * n, dtype=np.int64)
+    for (ca, ra), (cb, rb) in copies:
+        a, b2 = ca * n + ra, cb * n + rb
+        if root[a] == root[b2]:
             continue
-        if sizes[aux[a]] < sizes[aux[b2]]:
+        if size[root[a]] < size[root[b2]]:
             a, b2 = b2, a
-        ra, rb = aux[a], aux[b2]
-        sizes[ra] += sizes[rb]
+        ra_, rb_ = root[a], root[b2]
+        size[ra_] += size[rb_]
         cur = b2
         while True:                                   # relabel the smaller cycle
-            aux[cur] = ra
-            cur = mapping[cur]
+            root[cur] = ra_
+            cur = nxt[cur]
             if cur == b2:
                 break
-        mapping[a], mapping[b2] = mapping[b2], mapping[a]
-    wpow = [1] * n
-    for i in range(1, n):
-        wpow[i] = wpow[i - 1] * w % R
-    sig = []
+        nxt[a], nxt[b2] = nxt[b2], nxt[a]
+    # sigma[c][r] = delta^c' * omega^r' for (c', r') = mapping[(c, r)]: gather from the m columns delta^c * omega^row
+    pk.omega_col = backend.omega_powers()
+    if pk.omega_col is not None:
+        wcol = backend.download(pk.omega_col, n).copy()
+    else:
+        wcol = np.empty((n, 4), np.uint64)
+        acc = 1
+        for i in range(n):
+            wcol[i] = to_mont(acc)
+            acc = acc * w % R
+    dcols = []
     for c in range(m):
-        col = np.empty((n, 4), np.uint64)
-        for r in range(n):
-            c2, r2 = mapping[(c, r)]
-            col[r] = to_mont(pow(DELTA, c2, R) * wpow[r2] % R)
-        sig.append(col)
+        h = backend.upload(wcol)
+        backend.scale(h, pow(DELTA, c, R), n)
+        dcols.append(backend.download(h, n).copy())
+    mc = (nxt // n).reshape(m, n)
+    mr = (nxt % n).reshape(m, n)
+    dstack = np.stack(dcols) if m else np.zeros((0, n, 4), np.uint64)
+    sig = [dstack[mc[c], mr[c]] for c in range(m)]
     pk.sigma_values = [backend.upload(s) for s in sig]
     pk.sigma_polys = [backend.lagrange_to_coeff(h) for h in pk.sigma_values]
     pk.sigma_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in pk.sigma_polys]
     # l0, l_last, l_active_row
     def lag(rows):
         v = np.zeros((n, 4), np.uint64)
-        for r in rows:
-            v[r] = to_mont(1)
+        v[list(rows)] = to_mont(1)
         return backend.coeff_to_extended(backend.lagrange_to_coeff(backend.upload(v)), cs.ext_k)
     pk.l0 = lag([0])
     pk.l_last = lag([cs.usable])
@@ -275,7 +308,6 @@ def keygen(cs, backend, fixed_values, copies):
     xcoef = np.zeros((n, 4), np.uint64)
     xcoef[1] = to_mont(1)
     pk.x_coset = backend.coeff_to_extended(backend.upload(xcoef), cs.ext_k)
-    pk.omega_col = backend.omega_powers()
     vk = VerifyingKey()
     vk.cs = cs
     vk.fixed_commitments = backend.commit(pk.fixed_polys) if pk.fixed_polys else []
@@ -300,7 +332,7 @@ def vk_digest(vk):
 # ------------------------------------------------------------------ prover
 def create_proof(pk, backend, advice_values, rng):
     """advice_values: list of (n,4) Montgomery arrays (rows >= usable are overwritten with blinding randomness).
-    rng() -> random field element (int).  Returns proof bytes (EvmTranscript layout)."""
+    rng.vec(m) -> (m,4) uniformly random Montgomery residues.  Returns proof bytes (EvmTranscript layout)."""
     cs = pk.cs
     n, k, u = cs.n, cs.k, cs.usable
     T = EvmTranscript()
@@ -309,8 +341,7 @@ def create_proof(pk, backend, advice_values, rng):
     adv_cols = []
     for v in advice_values:
         v = np.array(v, np.uint64, copy=True)
-        for r in range(u, n):
-            v[r] = to_mont(rng())
+        v[u:] = rng.vec(n - u)
         adv_cols.append(backend.upload(v))
     for p in backend.commit_lagrange(adv_cols):
         T.write_point(p)
@@ -325,13 +356,13 @@ def create_proof(pk, backend, advice_values, rng):
         sigs = pk.sigma_values[pos:pos + len(chunk)]
         z = backend.permutation_product(vals, sigs, beta, gamma, pos, last, pk.omega_col)
         last = backend.get_row(z, u)
-        backend.set_rows(z, u + 1, [rng() for _ in range(n - u - 1)])
+        backend.set_rows(z, u + 1, rng.vec(n - u - 1))
         zs.append(z)
         pos += len(chunk)
     for p in backend.commit_lagrange(zs) if zs else []:
         T.write_point(p)
     # 5. vanishing argument: random polynomial
-    rnd = backend.upload(np.stack([to_mont(rng()) for _ in range(n)]))
+    rnd = backend.upload(rng.vec(n))
     T.write_point(backend.commit([rnd])[0])
     # 6. y
     y = T.squeeze_challenge()

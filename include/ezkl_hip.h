@@ -60,6 +60,10 @@ size_t ezkl_hip_bases_len(ezkl_bases_t h);
  * n deterministic curve points by try-and-increment, generated on the device */
 int ezkl_hip_bases_generate(uint64_t seed, size_t first, size_t n, ezkl_bases_t* out_handle);
 int ezkl_hip_bases_download(ezkl_bases_t h, void* out_host /* n x 64 B */);
+/* base set bases[i] = scalars[i] * P for one point P (64 B affine, host) and n resident Montgomery scalars: SRS
+ * generation for tests (gen_srs -> ParamsKZG::setup, /root/reference/src/pfsys/srs.rs:14-16): g[i] = s^i G,
+ * g_lagrange[i] = L_i(s) G */
+int ezkl_hip_bases_from_scalars(const void* base_point, const void* scalars_dev, size_t n, ezkl_bases_t* out_handle);
 /* sum_i scalars[i] * bases[offset + i], i < n.  scalars: n x 32 B Montgomery Fr (host pointer, borrowed).
  * out_affine: 64 B, caller-allocated, canonical affine ((0,0) if the sum is the identity). */
 int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out_affine);
@@ -98,6 +102,7 @@ int ezkl_hip_coset_ntt_dev(const void* in_dev, void* out_dev, size_t batch, size
 #define EZKL_VEC_MUL 2
 int ezkl_hip_vec_op_dev(int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);
 int ezkl_hip_vec_scale_dev(const void* a_dev, const void* scalar_host, void* out_dev, size_t n, void* stream);
+int ezkl_hip_vec_fill_dev(void* out_dev, const void* value_host, size_t n, void* stream);   /* out[i] = value */
 /* a[i] *= t[i mod 2^(ext_k-k)], t = 1/((zeta*omega_ext^j)^n - 1): EvaluationDomain::divide_by_vanishing_poly */
 int ezkl_hip_divide_by_vanishing_dev(void* a_dev, uint32_t k, uint32_t ext_k, void* stream);
 /* running sum (EZKL_VEC_ADD) / running product (EZKL_VEC_MUL): out[i] = in[0] o ... o in[i] (inclusive) or

@@ -58,9 +58,8 @@ class OracleBackend:
         if z0 is not None:
             z = ob.vec_scale(z, to_mont(z0))
         return z
-    def set_rows(self, h, start, values):
-        for i, v in enumerate(values):
-            h[start + i] = to_mont(v)
+    def set_rows(self, h, start, mont_rows):
+        h[start:start + len(mont_rows)] = mont_rows
     def get_row(self, h, i): return from_mont(h[i])
     def kate_div(self, h, z, n):
         h[:n] = ob.kate_div(h[:n], to_mont(z))

@@ -173,3 +173,21 @@ def test_c5_size_2_22_properties(hip):
     pts = bases.download()[: 1 << 14]
     assert (B.msm_g1(bases, z) == ob.msm(s1[: 1 << 14], pts)).all()
     bases.free()
+
+
+def test_gen_srs_structure(hip):
+    """device-side SRS generation (gen_srs): g[i] = s^i G against the oracle's double-and-add, and the KZG
+    self-consistency the reference fixture satisfies: sum(g_lagrange) == g[0], MSM(v, g_lagrange) == MSM(iNTT(v), g)"""
+    from ezkl_amd import backend as B
+    from conftest import fe_to_int
+    k, s = 7, 0x1234567890abcdef1234567890abcdef
+    n = 1 << k
+    g, gl = B.gen_srs(k, s)
+    G, GL = g.download(), gl.download()
+    gen = G[0]
+    for i in (0, 1, 2, 57, n - 1):
+        assert (G[i] == ob.g1_mul(gen, fe_from_int(pow(s, i, R)))).all()
+    ones = np.tile(fe_from_int(1), (n, 1))
+    assert (B.msm_g1(gl, ones) == G[0]).all()
+    v = rand_fr(np.random.default_rng(3), n)
+    assert (B.msm_g1(gl, v) == B.msm_g1(g, ob.lagrange_to_coeff(v, k))).all()

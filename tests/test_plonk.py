@@ -44,8 +44,7 @@ def witness(cs, seed):
 
 
 def det_rng(seed):
-    st = np.random.default_rng(seed)
-    return lambda: int.from_bytes(st.bytes(40), "little") % R
+    return P.Rng(seed)
 
 
 def setup(golden_srs):
