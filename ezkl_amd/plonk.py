@@ -12,7 +12,8 @@ exact query order / vk digest cannot be pinned).  The proof format is the EvmTra
 proofs (points 64 B BE, scalars 32 B BE); acceptance is decided by an independent pairing verifier
 (oracle/verifier.py), which is how the reference itself validates proofs.
 
-Not covered yet: instance columns, mv-lookup arguments, multi-phase challenges.
+Covered: custom gates, the permutation argument (chunked), mv-lookup (logUp) arguments with theta-compressed tuples.
+Not covered yet: instance columns, multi-phase (second-phase advice + challenges).
 """
 import numpy as np
 from .transcript import EvmTranscript, keccak256, R
@@ -110,13 +111,19 @@ def lower(e, prog, col_index, memo):
 
 
 class ConstraintSystem:
-    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns):
+    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns, lookups=()):
+        """lookups: [(input_tuples, table_tuple)]: every input tuple (list of Expr) of a lookup must appear as a row of
+        the table tuple (list of Expr of the same arity) on the usable rows -- the mv-lookup (logUp) argument the
+        zkonduit halo2 fork uses (cargo feature `mv-lookup`, /root/reference/Cargo.toml:255)."""
         self.k, self.n = k, 1 << k
         self.n_advice, self.n_fixed = n_advice, n_fixed
         self.gates = list(gates)
         self.perm = list(permutation_columns)             # [("adv"|"fix", col)]
+        self.lookups = [([list(t) for t in ins], list(tab)) for ins, tab in lookups]
         self.usable = self.n - BLINDING - 1               # row index of l_last; rows [0, usable) carry the witness
         d = max([degree(g) for g in self.gates] + [3])
+        for ins, tab in self.lookups:                     # l_active * phi * prod(f_j + beta) * (t + beta)
+            d = max(d, 2 + sum(max(degree(e) for e in t) for t in ins) + max(degree(e) for e in tab))
         self.degree = d
         self.chunk = d - 2
         self.ext_k = k
@@ -127,6 +134,10 @@ class ConstraintSystem:
             queries(g, qs)
         for kind, c in self.perm:
             qs.add((kind, c, 0))
+        for ins, tab in self.lookups:
+            for t in ins + [tab]:
+                for e in t:
+                    queries(e, qs)
         self.advice_queries = sorted((c, r) for kd, c, r in qs if kd == "adv")
         self.fixed_queries = sorted((c, r) for kd, c, r in qs if kd == "fix")
         self.n_chunks = -(-len(self.perm) // self.chunk) if self.perm else 0
@@ -201,6 +212,11 @@ class GpuBackend:
         return _b.permutation_grand_product(self.k, [c.ptr for c in value_cols], [c.ptr for c in sigma_cols], to_mont(beta), to_mont(gamma),
                                             omega_col=omega_col, first_column_index=first_index, z0=None if z0 is None else to_mont(z0))
     def omega_powers(self): return _b.omega_powers_column(self.k)
+    def lookup_multiplicity(self, inputs, table, usable):
+        m, missing = _b.lookup_multiplicity([h.ptr for h in inputs], table.ptr, self.n, usable)
+        return m, missing
+    def lookup_grand_sum(self, inputs, table, m, beta):
+        return _b.lookup_grand_sum(self.k, [h.ptr for h in inputs], table.ptr, m.ptr, to_mont(beta))
     def set_rows(self, h, start, mont_rows):
         """overwrite rows [start, start+len) (blinding rows) with host values (Montgomery (m,4) array)"""
         _b.memcpy_h2d(h.ptr + 32 * start, np.ascontiguousarray(mont_rows, np.uint64))
@@ -345,10 +361,21 @@ def create_proof(pk, backend, advice_values, rng):
         adv_cols.append(backend.upload(v))
     for p in backend.commit_lagrange(adv_cols):
         T.write_point(p)
+    def col_handle(kind, c): return adv_cols[c] if kind == "adv" else pk.fixed_values[c]
+    # 2. theta; mv-lookup multiplicities m(X)
+    theta, lk = None, []
+    if cs.lookups:
+        theta = T.squeeze_challenge()
+        for ins, tab in cs.lookups:
+            comp = [compress_column(cs, backend, t, theta, col_handle) for t in ins + [tab]]
+            m, _missing = backend.lookup_multiplicity(comp[:-1], comp[-1], u)
+            backend.set_rows(m, u, rng.vec(n - u))
+            lk.append({"inputs": comp[:-1], "table": comp[-1], "m": m})
+        for d_, p in zip(lk, backend.commit_lagrange([d_["m"] for d_ in lk])):
+            T.write_point(p)
     # 3. beta, gamma
     beta, gamma = T.squeeze_challenge(), T.squeeze_challenge()
     # 4. permutation grand products, chained across chunks
-    def col_handle(kind, c): return adv_cols[c] if kind == "adv" else pk.fixed_values[c]
     zs, last = [], None
     pos = 0
     for chunk in cs.perm_chunks():
@@ -361,6 +388,13 @@ def create_proof(pk, backend, advice_values, rng):
         pos += len(chunk)
     for p in backend.commit_lagrange(zs) if zs else []:
         T.write_point(p)
+    # 4b. mv-lookup running sums phi(X)
+    for d_ in lk:
+        phi = backend.lookup_grand_sum(d_["inputs"], d_["table"], d_["m"], beta)
+        backend.set_rows(phi, u + 1, rng.vec(n - u - 1))
+        d_["phi"] = phi
+    for p in backend.commit_lagrange([d_["phi"] for d_ in lk]) if lk else []:
+        T.write_point(p)
     # 5. vanishing argument: random polynomial
     rnd = backend.upload(rng.vec(n))
     T.write_point(backend.commit([rnd])[0])
@@ -371,7 +405,11 @@ def create_proof(pk, backend, advice_values, rng):
     z_polys = [backend.lagrange_to_coeff(h) for h in zs]
     adv_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in adv_polys]
     z_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in z_polys]
-    prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y)
+    m_polys = [backend.lagrange_to_coeff(d_["m"]) for d_ in lk]
+    phi_polys = [backend.lagrange_to_coeff(d_["phi"]) for d_ in lk]
+    m_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in m_polys]
+    phi_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in phi_polys]
+    prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets)
     hnum = backend.zeros(1 << cs.ext_k)
     backend.eval_program(prog, cols, chal, hnum)
     backend.divide_by_vanishing(hnum, cs.ext_k)
@@ -401,6 +439,11 @@ def create_proof(pk, backend, advice_values, rng):
         if j + 1 < len(z_polys):
             e2 = backend.eval_poly(zp, n, rot_point(u)); T.write_scalar(e2)
         z_evals.append((e0, e1, e2))
+    lk_evals = []
+    for mp, pp in zip(m_polys, phi_polys):
+        e = (backend.eval_poly(mp, n, x), backend.eval_poly(pp, n, x), backend.eval_poly(pp, n, rot_point(1)))
+        for v_ in e: T.write_scalar(v_)
+        lk_evals.append(e)
     # 10. multiopen (SHPLONK)
     xn = pow(x, n, R)
     hcomb = backend.zeros(n)
@@ -417,11 +460,38 @@ def create_proof(pk, backend, advice_values, rng):
     for j, zp in enumerate(z_polys):
         qs.append((("z", j), zp, x, z_evals[j][0])); qs.append((("z", j), zp, rot_point(1), z_evals[j][1]))
         if z_evals[j][2] is not None: qs.append((("z", j), zp, rot_point(u), z_evals[j][2]))
+    for i, (mp, pp) in enumerate(zip(m_polys, phi_polys)):
+        qs.append((("m", i), mp, x, lk_evals[i][0]))
+        qs.append((("phi", i), pp, x, lk_evals[i][1])); qs.append((("phi", i), pp, rot_point(1), lk_evals[i][2]))
     shplonk_prove(backend, T, qs, n)
     return bytes(T.proof)
 
 
-def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y):
+def compress_exprs(prog, tuple_exprs, theta_src, col_index, memo):
+    """theta-compression of a tuple of expressions: ((e0*theta + e1)*theta + e2)... (halo2 compress_expressions)"""
+    acc = lower(tuple_exprs[0], prog, col_index, memo)
+    for e in tuple_exprs[1:]:
+        acc = prog.calc("add", prog.calc("mul", acc, theta_src), lower(e, prog, col_index, memo))
+    return acc
+
+
+def compress_column(cs, backend, tuple_exprs, theta, col_handle):
+    """the theta-compressed lookup column over the n rows of the Lagrange domain (a gate program with ext_k = k)"""
+    prog = _b.GraphProgram(cs.k, cs.k)
+    cols, index = [], {}
+    def col_index(kind, c):
+        if (kind, c) not in index:
+            index[(kind, c)] = len(cols); cols.append(col_handle(kind, c))
+        return index[(kind, c)]
+    r = compress_exprs(prog, tuple_exprs, prog.challenge(0), col_index, {})
+    if r[0] != _b.INTERMEDIATE:                       # a bare column / constant: materialise it
+        r = prog.calc("store", r)
+    out = backend.zeros(cs.n)
+    backend.eval_program(prog, cols, [theta], out)
+    return out
+
+
+def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m_cosets=(), phi_cosets=()):
     """the numerator of h(X) as ONE straight-line program over the extended-coset columns: custom gates, then the
     permutation constraints, folded with y (value = value*y + constraint), as evaluate_h does"""
     prog = _b.GraphProgram(cs.k, cs.ext_k)
@@ -459,6 +529,31 @@ def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y):
                 right = prog.calc("mul", right, prog.calc("add", prog.calc("add", v, prog.calc("mul", bd, X)), GAMMA))
             terms.append(prog.calc("mul", lact, prog.calc("sub", left, right)))
             pos += len(chunk)
+    if cs.lookups:
+        l0 = prog.column(slot("l0", pk.l0)); llast = prog.column(slot("l_last", pk.l_last)); lact = prog.column(slot("l_active", pk.l_active))
+        chal.append(theta)
+        THETA = prog.challenge(len(chal) - 1)
+        for i, (ins, tab) in enumerate(cs.lookups):
+            phi_s, m_s = slot(("phi", i), phi_cosets[i]), slot(("m", i), m_cosets[i])
+            phi, phi_next, mcol = prog.column(phi_s), prog.column(phi_s, 1), prog.column(m_s)
+            fb = [prog.calc("add", compress_exprs(prog, t, THETA, col_index, memo), BETA) for t in ins]
+            tb = prog.calc("add", compress_exprs(prog, tab, THETA, col_index, memo), BETA)
+            prodf = fb[0]
+            for f in fb[1:]:
+                prodf = prog.calc("mul", prodf, f)
+            ssum = None                                           # sum_j prod_{i != j} (f_i + beta)
+            for j in range(len(fb)):
+                pj = None
+                for i2, f in enumerate(fb):
+                    if i2 != j:
+                        pj = f if pj is None else prog.calc("mul", pj, f)
+                pj = prog.constant(to_mont(1)) if pj is None else pj
+                ssum = pj if ssum is None else prog.calc("add", ssum, pj)
+            lhs = prog.calc("mul", prog.calc("mul", prog.calc("sub", phi_next, phi), prodf), tb)
+            rhs = prog.calc("sub", prog.calc("mul", ssum, tb), prog.calc("mul", mcol, prodf))
+            terms.append(prog.calc("mul", l0, phi))
+            terms.append(prog.calc("mul", llast, phi))
+            terms.append(prog.calc("mul", lact, prog.calc("sub", lhs, rhs)))
     prog.horner(prog.previous(), terms, Y)
     return prog, cols, chal
 

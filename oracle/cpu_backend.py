@@ -58,6 +58,30 @@ class OracleBackend:
         if z0 is not None:
             z = ob.vec_scale(z, to_mont(z0))
         return z
+    def lookup_multiplicity(self, inputs, table, usable):
+        first = {}
+        for i in range(usable):
+            first.setdefault(table[i].tobytes(), i)
+        m = np.zeros((self.n, 4), np.uint64)
+        cnt, missing = {}, 0
+        for x in inputs:
+            for r in range(usable):
+                idx = first.get(x[r].tobytes())
+                if idx is None: missing += 1
+                else: cnt[idx] = cnt.get(idx, 0) + 1
+        for idx, c in cnt.items():
+            m[idx] = to_mont(c)
+        return m, missing
+    def lookup_grand_sum(self, inputs, table, m, beta):
+        n = self.n
+        b = to_mont(beta)
+        acc = np.zeros((n, 4), np.uint64)
+        bcol = np.tile(b, (n, 1))
+        for x in inputs:
+            acc = ob.vec_op("add", acc, ob.batch_invert(ob.vec_op("add", x[:n], bcol)))
+        tinv = ob.batch_invert(ob.vec_op("add", table[:n], bcol))
+        acc = ob.vec_op("sub", acc, ob.vec_op("mul", tinv, m[:n]))
+        return ob.prefix_scan(acc, "add", exclusive=True)
     def set_rows(self, h, start, mont_rows):
         h[start:start + len(mont_rows)] = mont_rows
     def get_row(self, h, i): return from_mont(h[i])

@@ -24,8 +24,13 @@ def verify(vk, g1_gen, g2, s_g2, proof):
         T = EvmTranscript(proof)
         T.common_scalar(vk.digest)
         adv_c = [T.read_point() for _ in range(cs.n_advice)]
+        theta, m_c = None, []
+        if cs.lookups:
+            theta = T.squeeze_challenge()
+            m_c = [T.read_point() for _ in cs.lookups]
         beta, gamma = T.squeeze_challenge(), T.squeeze_challenge()
         z_c = [T.read_point() for _ in range(cs.n_chunks)]
+        phi_c = [T.read_point() for _ in cs.lookups]
         rnd_c = T.read_point()
         y = T.squeeze_challenge()
         h_c = [T.read_point() for _ in range(cs.degree - 1)]
@@ -40,6 +45,7 @@ def verify(vk, g1_gen, g2, s_g2, proof):
             e0, e1 = T.read_scalar(), T.read_scalar()
             e2 = T.read_scalar() if j + 1 < cs.n_chunks else None
             z_ev.append((e0, e1, e2))
+        lk_ev = [(T.read_scalar(), T.read_scalar(), T.read_scalar()) for _ in cs.lookups]
     except ValueError:
         return False
     w = P.omega(k)
@@ -64,6 +70,26 @@ def verify(vk, g1_gen, g2, s_g2, proof):
                 right = right * (v + beta * pow(P.DELTA, pos + i, R) % R * x + gamma) % R
             terms.append(lact * (left - right) % R)
             pos += len(chunk)
+    q = lambda kd, c, r: ev[(kd, c, r)]
+    def compress(tup):
+        acc = P.evaluate(tup[0], q)
+        for e in tup[1:]:
+            acc = (acc * theta + P.evaluate(e, q)) % R
+        return acc
+    for (ins, tab), (m_e, phi_e, phi_n) in zip(cs.lookups, lk_ev):
+        fb = [(compress(t) + beta) % R for t in ins]
+        tb = (compress(tab) + beta) % R
+        prodf = 1
+        for f in fb: prodf = prodf * f % R
+        ssum = 0
+        for j in range(len(fb)):
+            pj = 1
+            for i2, f in enumerate(fb):
+                if i2 != j: pj = pj * f % R
+            ssum = (ssum + pj) % R
+        lhs = (phi_n - phi_e) * prodf % R * tb % R
+        rhs = (ssum * tb - m_e * prodf) % R
+        terms += [l0 * phi_e % R, llast * phi_e % R, lact * (lhs - rhs) % R]
     num = 0
     for t in terms:
         num = (num * y + t) % R
@@ -82,6 +108,9 @@ def verify(vk, g1_gen, g2, s_g2, proof):
     for j in range(cs.n_chunks):
         qs.append((("z", j), z_c[j], x, z_ev[j][0])); qs.append((("z", j), z_c[j], rot_point(1), z_ev[j][1]))
         if z_ev[j][2] is not None: qs.append((("z", j), z_c[j], rot_point(u), z_ev[j][2]))
+    for i, (m_e, phi_e, phi_n) in enumerate(lk_ev):
+        qs.append((("m", i), m_c[i], x, m_e))
+        qs.append((("phi", i), phi_c[i], x, phi_e)); qs.append((("phi", i), phi_c[i], rot_point(1), phi_n))
     # ---- SHPLONK
     groups = P.group_queries(qs)
     ys = T.squeeze_challenge()

@@ -43,6 +43,72 @@ def witness(cs, seed):
     return [to_col(c) for c in A], [to_col(c) for c in F], copies
 
 
+def lookup_circuit(k):
+    """matmul-style gate + a two-column lookup (x, relu(x - 8)) in (table_in, table_out): the shape of ezkl's
+    nonlinearity lookups (src/circuit/ops/chip.rs:484-599) with a theta-compressed 2-tuple, plus a second
+    single-column input set sharing a range table"""
+    a, b, c, o = P.adv(0), P.adv(1), P.adv(2), P.adv(3)
+    sel = P.fix(0)
+    gates = [sel * (c - a * b)]
+    lookups = [([[sel * a, sel * o]], [P.fix(1), P.fix(2)]),            # (a, o) in {(x, relu(x-8))} on selected rows, (0,0) elsewhere
+               ([[sel * b], [sel * a]], [P.fix(1)])]                    # b and a in the range table: two input sets, one table
+    perm = [("adv", 0), ("adv", 3)]
+    return P.ConstraintSystem(k, 4, 3, gates, perm, lookups)
+
+
+def lookup_witness(cs, seed, bad=None):
+    rng = np.random.default_rng(seed)
+    n, u = cs.n, cs.usable
+    A = [[0] * n for _ in range(4)]
+    F = [[0] * n for _ in range(3)]
+    T = 16
+    for r in range(u):                                 # table rows: x = r mod 16, relu(x - 8); row (0, 0) included
+        x = r % T
+        F[1][r], F[2][r] = x, max(x - 8, 0)
+    for r in range(u // 2):
+        x, y = int(rng.integers(0, T)), int(rng.integers(0, T))
+        A[0][r], A[1][r], A[2][r], A[3][r] = x, y, x * y, max(x - 8, 0)
+        F[0][r] = 1
+    copies = [((0, 1), (0, 0))] if A[0][1] == A[0][0] else []
+    if bad == "lookup":
+        A[3][2] = (A[3][2] + 1) % R                    # (a, o) no longer in the table
+    if bad == "range":
+        A[1][4] = 99                                   # b out of range (and c adjusted so the gate still holds)
+        A[2][4] = A[0][4] * 99
+    to_col = lambda col: np.stack([fe_from_int(v) for v in col])
+    return [to_col(c) for c in A], [to_col(c) for c in F], copies
+
+
+def test_lookup_argument_oracle_backend(golden_srs):
+    from oracle.cpu_backend import OracleBackend
+    cs = lookup_circuit(6)
+    assert cs.degree == 7 and cs.ext_k == 9      # l_active * phi * (sel*b + beta)(sel*a + beta) * (t + beta)
+    be = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    g1, g2, s_g2 = setup(golden_srs)
+    adv, fixed, copies = lookup_witness(cs, 3)
+    pk, vk = P.keygen(cs, be, fixed, copies)
+    assert V.verify(vk, g1, g2, s_g2, P.create_proof(pk, be, adv, det_rng(1)))
+    for bad in ("lookup", "range"):
+        adv_b, _, _ = lookup_witness(cs, 3, bad=bad)
+        assert not V.verify(vk, g1, g2, s_g2, P.create_proof(pk, be, adv_b, det_rng(1)))
+
+
+@pytest.mark.gpu
+def test_gpu_lookup_proof_bit_identical(hip, golden_srs):
+    from oracle.cpu_backend import OracleBackend
+    cs = lookup_circuit(6)
+    adv, fixed, copies = lookup_witness(cs, 4)
+    cpu = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk_c, vk_c = P.keygen(cs, cpu, fixed, copies)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    proof_c = P.create_proof(pk_c, cpu, adv, det_rng(2))
+    proof_g = P.create_proof(pk_g, gpu, adv, det_rng(2))
+    assert proof_g == proof_c
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk_g, g1, g2, s_g2, proof_g)
+
+
 def det_rng(seed):
     return P.Rng(seed)
 
