@@ -196,6 +196,7 @@ def cpu_baseline(bases, scalars, n, gpu_result):
     from oracle import binding as ob
     pts = bases.download()
     sc = scalars.to_numpy(shape=(n, 4))
+    ob.msm(sc[:4096], pts[:4096])              # start the OpenMP pool outside the timed call
     t0 = time.perf_counter()
     want = ob.msm(sc, pts)
     dt = time.perf_counter() - t0

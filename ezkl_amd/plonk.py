@@ -346,9 +346,14 @@ def vk_digest(vk):
 
 
 # ------------------------------------------------------------------ prover
-def create_proof(pk, backend, advice_values, rng):
+def create_proof(pk, backend, advice_values, rng, timings=None):
     """advice_values: list of (n,4) Montgomery arrays (rows >= usable are overwritten with blinding randomness).
     rng.vec(m) -> (m,4) uniformly random Montgomery residues.  Returns proof bytes (EvmTranscript layout)."""
+    import time as _time
+    _t = [_time.perf_counter()]
+    def lap(name):
+        if timings is not None:
+            now = _time.perf_counter(); timings[name] = timings.get(name, 0.0) + now - _t[0]; _t[0] = now
     cs = pk.cs
     n, k, u = cs.n, cs.k, cs.usable
     T = EvmTranscript()
@@ -361,6 +366,7 @@ def create_proof(pk, backend, advice_values, rng):
         adv_cols.append(backend.upload(v))
     for p in backend.commit_lagrange(adv_cols):
         T.write_point(p)
+    lap("advice_commit")
     def col_handle(kind, c): return adv_cols[c] if kind == "adv" else pk.fixed_values[c]
     # 2. theta; mv-lookup multiplicities m(X)
     theta, lk = None, []
@@ -373,6 +379,7 @@ def create_proof(pk, backend, advice_values, rng):
             lk.append({"inputs": comp[:-1], "table": comp[-1], "m": m})
         for d_, p in zip(lk, backend.commit_lagrange([d_["m"] for d_ in lk])):
             T.write_point(p)
+    lap("lookup_m")
     # 3. beta, gamma
     beta, gamma = T.squeeze_challenge(), T.squeeze_challenge()
     # 4. permutation grand products, chained across chunks
@@ -388,6 +395,7 @@ def create_proof(pk, backend, advice_values, rng):
         pos += len(chunk)
     for p in backend.commit_lagrange(zs) if zs else []:
         T.write_point(p)
+    lap("permutation_z")
     # 4b. mv-lookup running sums phi(X)
     for d_ in lk:
         phi = backend.lookup_grand_sum(d_["inputs"], d_["table"], d_["m"], beta)
@@ -395,11 +403,13 @@ def create_proof(pk, backend, advice_values, rng):
         d_["phi"] = phi
     for p in backend.commit_lagrange([d_["phi"] for d_ in lk]) if lk else []:
         T.write_point(p)
+    lap("lookup_phi")
     # 5. vanishing argument: random polynomial
     rnd = backend.upload(rng.vec(n))
     T.write_point(backend.commit([rnd])[0])
     # 6. y
     y = T.squeeze_challenge()
+    lap("random_poly")
     # 7. quotient
     adv_polys = [backend.lagrange_to_coeff(h) for h in adv_cols]
     z_polys = [backend.lagrange_to_coeff(h) for h in zs]
@@ -409,15 +419,18 @@ def create_proof(pk, backend, advice_values, rng):
     phi_polys = [backend.lagrange_to_coeff(d_["phi"]) for d_ in lk]
     m_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in m_polys]
     phi_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in phi_polys]
+    lap("intt_and_coset_ntt")
     prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets)
     hnum = backend.zeros(1 << cs.ext_k)
     backend.eval_program(prog, cols, chal, hnum)
+    lap("quotient_sweep")
     backend.divide_by_vanishing(hnum, cs.ext_k)
     hcoef = backend.extended_to_coeff(hnum, cs.ext_k)
     npieces = cs.degree - 1
     pieces = [backend.slice_copy(hcoef, i * n, n) for i in range(npieces)]
     for p in backend.commit(pieces):
         T.write_point(p)
+    lap("h_split_commit")
     # 8. x
     x = T.squeeze_challenge()
     w = omega(k)
@@ -444,6 +457,7 @@ def create_proof(pk, backend, advice_values, rng):
         e = (backend.eval_poly(mp, n, x), backend.eval_poly(pp, n, x), backend.eval_poly(pp, n, rot_point(1)))
         for v_ in e: T.write_scalar(v_)
         lk_evals.append(e)
+    lap("evaluations")
     # 10. multiopen (SHPLONK)
     xn = pow(x, n, R)
     hcomb = backend.zeros(n)
@@ -464,6 +478,7 @@ def create_proof(pk, backend, advice_values, rng):
         qs.append((("m", i), mp, x, lk_evals[i][0]))
         qs.append((("phi", i), pp, x, lk_evals[i][1])); qs.append((("phi", i), pp, rot_point(1), lk_evals[i][2]))
     shplonk_prove(backend, T, qs, n)
+    lap("shplonk")
     return bytes(T.proof)
 
 

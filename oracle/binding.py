@@ -23,6 +23,29 @@ def _load():
 
 
 lib = _load()
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container that sees
+    256 hardware threads but has a 16-CPU quota must not run 256 OpenMP threads: they would be throttled)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
+if "OMP_NUM_THREADS" not in os.environ:
+    lib.oracle_set_threads(C.c_int(effective_cpus()))
 _p = C.c_void_p
 
 

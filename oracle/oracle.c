@@ -286,22 +286,47 @@ void oracle_msm(const fe *scalars, const g1a *bases, size_t n, g1a *out) {
 static inline uint32_t bitrev(uint32_t x, unsigned bits) {
     uint32_t r = 0; for (unsigned i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r;
 }
-/* best_fft(a, omega, log_n): in place, natural order in and out, no scaling */
+/* best_fft(a, omega, log_n): in place, natural order in and out, no scaling.
+ * Same dataflow as halo2curves' serial path (bit reversal, then log_n radix-2 DIT stages over a table of
+ * omega powers); the loops are spread over the host cores so that it is a fair CPU baseline. */
 void oracle_fft(fe *a, unsigned log_n, const fe *omega) {
     size_t n = (size_t)1 << log_n;
+#pragma omp parallel for schedule(static) if (n >= 65536)
     for (size_t i = 0; i < n; i++) { size_t j = bitrev((uint32_t)i, log_n); if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; } }
     if (log_n == 0) return;
     fe *tw = (fe *)malloc((n / 2) * sizeof(fe));
-    tw[0] = FR.one;
-    for (size_t i = 1; i < n / 2; i++) f_mul(&tw[i], &tw[i - 1], omega, &FR);
+    {   /* twiddles in independent chunks: each chunk starts from omega^(start) by square-and-multiply */
+        size_t half = n / 2, chunk = half < 4096 ? half : 4096, nchunks = (half + chunk - 1) / chunk;
+#pragma omp parallel for schedule(static) if (nchunks > 1)
+        for (size_t c = 0; c < nchunks; c++) {
+            size_t lo = c * chunk, hi = lo + chunk < half ? lo + chunk : half;
+            uint64_t e[4] = {lo, 0, 0, 0};
+            fe cur; f_pow(&cur, omega, e, &FR);
+            for (size_t i = lo; i < hi; i++) { tw[i] = cur; f_mul(&cur, &cur, omega, &FR); }
+        }
+    }
     for (size_t m = 1; m < n; m <<= 1) {
-        size_t step = n / (2 * m);
+        size_t step = n / (2 * m), nblk = n / (2 * m);
+        if (nblk >= 64) {                       /* many small blocks: one thread per run of blocks */
 #pragma omp parallel for schedule(static) if (n >= 4096)
-        for (size_t idx = 0; idx < n / 2; idx++) {
-            size_t blk = idx / m, j = idx % m, lo = blk * 2 * m + j, hi = lo + m;
-            fe t; if (j == 0) t = a[hi]; else f_mul(&t, &a[hi], &tw[j * step], &FR);
-            fe u = a[lo];
-            f_add(&a[lo], &u, &t, &FR); f_sub(&a[hi], &u, &t, &FR);
+            for (size_t blk = 0; blk < nblk; blk++) {
+                fe *lo = a + blk * 2 * m, *hi = lo + m;
+                for (size_t j = 0; j < m; j++) {
+                    fe t; if (j == 0) t = hi[0]; else f_mul(&t, &hi[j], &tw[j * step], &FR);
+                    fe u = lo[j];
+                    f_add(&lo[j], &u, &t, &FR); f_sub(&hi[j], &u, &t, &FR);
+                }
+            }
+        } else {                                /* few large blocks: split the butterflies of each block */
+            for (size_t blk = 0; blk < nblk; blk++) {
+                fe *lo = a + blk * 2 * m, *hi = lo + m;
+#pragma omp parallel for schedule(static) if (m >= 4096)
+                for (size_t j = 0; j < m; j++) {
+                    fe t; if (j == 0) t = hi[0]; else f_mul(&t, &hi[j], &tw[j * step], &FR);
+                    fe u = lo[j];
+                    f_add(&lo[j], &u, &t, &FR); f_sub(&hi[j], &u, &t, &FR);
+                }
+            }
         }
     }
     free(tw);
@@ -318,12 +343,14 @@ void oracle_lagrange_to_coeff(fe *a, unsigned k) {
     oracle_fft(a, k, &wi);
     f_from_u64(&ninv, (uint64_t)1 << k, &FR); f_inv(&ninv, &ninv, &FR);
     size_t n = (size_t)1 << k;
+#pragma omp parallel for schedule(static) if (n >= 65536)
     for (size_t i = 0; i < n; i++) f_mul(&a[i], &a[i], &ninv, &FR);
 }
 void oracle_coeff_to_lagrange(fe *a, unsigned k) { fe w; fr_omega(&w, k); oracle_fft(a, k, &w); }
 /* EvaluationDomain::coeff_to_extended: in[n] coeffs -> out[2^ext_k] evaluations on the zeta-coset */
 void oracle_coeff_to_extended(const fe *in, unsigned k, unsigned ext_k, fe *out) {
     size_t n = (size_t)1 << k, ne = (size_t)1 << ext_k;
+#pragma omp parallel for schedule(static) if (n >= 65536)
     for (size_t i = 0; i < n; i++) {
         switch (i % 3) { case 0: out[i] = in[i]; break; case 1: f_mul(&out[i], &in[i], &FR_ZETA, &FR); break;
                          default: f_mul(&out[i], &in[i], &FR_ZETA2, &FR); }
@@ -470,6 +497,13 @@ void oracle_eval_program(const oracle_program *p, fe *out) {
     }
 }
 
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

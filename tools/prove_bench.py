@@ -37,7 +37,15 @@ for b in range(blocks):
     gates.append(P.fix(2 * b) * (acc_ - a_ * b_))
     gates.append(P.fix(2 * b + 1) * (acc_ - P.adv(3 * b + 2, -1) - a_ * b_))
     perm += [("adv", 3 * b), ("adv", 3 * b + 1)]
-cs = P.ConstraintSystem(k, 3 * blocks, 2 * blocks, gates, perm)
+# one ReLU-style nonlinearity as a two-column mv-lookup: (sel*pre, sel*post) in {(x, relu(x))}, x in [-2^(T-1), 2^(T-1))
+relu = os.environ.get("RELU", "1") == "1"
+tbits = min(15, k - 2)
+lookups = []
+if relu:
+    pre_c, post_c, sel_c, tin_c, tout_c = 3 * blocks, 3 * blocks + 1, 2 * blocks, 2 * blocks + 1, 2 * blocks + 2
+    lookups = [([[P.fix(sel_c) * P.adv(pre_c), P.fix(sel_c) * P.adv(post_c)]], [P.fix(tin_c), P.fix(tout_c)])]
+    perm += [("adv", post_c)]
+cs = P.ConstraintSystem(k, 3 * blocks + (2 if relu else 0), 2 * blocks + (3 if relu else 0), gates, perm, lookups)
 u = cs.usable
 rng = np.random.default_rng(1)
 def canon_col(v64):
@@ -67,19 +75,64 @@ for b in range(blocks):
         copies.append(((2 * b, u // 2 + r), (2 * b, r)))
         copies.append(((2 * b + 1, u // 2 + r), (2 * b + 1, r)))
 
+if relu:
+    half = 1 << (tbits - 1)
+    def signed_to_canon_limbs(v):                       # integer_rep_to_felt (src/fieldutils.rs:9-17): negatives are r - |x|
+        out = np.zeros((n, 4), np.uint64)
+        neg = v < 0
+        out[~neg, 0] = v[~neg].astype(np.uint64)
+        rl = np.frombuffer(R.to_bytes(32, "little"), np.uint64)
+        mag = (-v[neg]).astype(np.uint64)
+        out[neg] = rl
+        out[neg, 0] = rl[0] - mag                       # r - |x| for |x| < 2^32 (no borrow: low limb of r is large)
+        return out
+    def to_mont_dev_limbs(c):
+        d = B.DeviceBuffer.from_numpy(c)
+        B.vec_scale(d.ptr, R2, d.ptr, n)
+        return d.to_numpy(shape=(n, 4))
+    pre = rng.integers(-half, half, size=n); pre[u:] = 0
+    post = np.maximum(pre, 0)
+    sel = (rows < u).astype(np.int64)
+    tin = np.zeros(n, np.int64); tin[: 2 * half] = np.arange(-half, half); tin[2 * half:] = 0
+    tout = np.maximum(tin, 0)
+    assert 2 * half < u
+    adv += [to_mont_dev_limbs(signed_to_canon_limbs(pre * sel)), to_mont_dev_limbs(signed_to_canon_limbs(post * sel))]
+    fixed += [to_mont_dev_limbs(signed_to_canon_limbs(sel)), to_mont_dev_limbs(signed_to_canon_limbs(tin)), to_mont_dev_limbs(signed_to_canon_limbs(tout))]
+
 def run(backend_name):
     be = P.GpuBackend(g, gl, k) if backend_name == "hip" else __import__("oracle.cpu_backend", fromlist=["OracleBackend"]).OracleBackend(g, gl, k)
     t0 = time.time(); pk, vk = P.keygen(cs, be, fixed, copies); t_keygen = time.time() - t0
     P.create_proof(pk, be, adv, P.Rng(5))      # warm-up (window tables, twiddles, JIT)
-    t0 = time.time(); proof = P.create_proof(pk, be, adv, P.Rng(5)); t_prove = time.time() - t0
+    tm = {}
+    t0 = time.time(); proof = P.create_proof(pk, be, adv, P.Rng(5), timings=tm); t_prove = time.time() - t0
+    run.timings = {a: round(b, 4) for a, b in tm.items()}
     return vk, proof, t_keygen, t_prove
 
 vk, proof, t_keygen, t_prove = run("hip")
 t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof); t_verify = time.time() - t0
-out = {"what": "ezkl_amd.plonk prove (gates + permutation, KZG/SHPLONK, Keccak EVM transcript) on a matmul-accumulation circuit",
+out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLONK, Keccak EVM transcript): matmul-accumulation blocks + ReLU lookup",
+       "lookups": len(lookups), "lookup_table_rows": (1 << tbits) if relu else 0,
        "k": k, "advice_columns": cs.n_advice, "fixed_columns": cs.n_fixed, "degree": cs.degree, "ext_k": cs.ext_k, "copies": len(copies),
        "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "keygen_seconds_gpu": round(t_keygen, 3),
-       "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
+       "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
+if "--cpu-kernels" in sys.argv:
+    # the C oracle (OpenMP, all host cores) timed on ONE instance of each kernel class at this size, scaled by the call
+    # counts the prover actually issued: a bounded CPU sample, not a CPU prover
+    nz, nl = cs.n_chunks, len(cs.lookups)
+    counts = {"msm": cs.n_advice + nl + nz + nl + 1 + (cs.degree - 1) + 2,
+              "intt": cs.n_advice + nz + 2 * nl, "coset_ntt": cs.n_advice + nz + 2 * nl + 1}
+    rs = np.random.default_rng(3)
+    col = rs.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); col[:, 3] &= np.uint64((1 << 61) - 1)
+    ob.msm(col[:4096], gl[:4096]); ob.lagrange_to_coeff(col[: 1 << 12], 12)      # warm the OpenMP pool
+    cf = ob.lagrange_to_coeff(col, k); ob.coeff_to_extended(cf, k, cs.ext_k)        # and the page cache of the work buffers
+    t0 = time.time(); ob.msm(col, gl); t_msm = time.time() - t0
+    t0 = time.time(); cf = ob.lagrange_to_coeff(col, k); t_intt = time.time() - t0
+    t0 = time.time(); ob.coeff_to_extended(cf, k, cs.ext_k); t_coset = time.time() - t0
+    est = counts["msm"] * t_msm + counts["intt"] * t_intt + counts["coset_ntt"] * t_coset
+    out["cpu_kernel_sample"] = {"threads": ob.num_threads(), "one_msm_s": round(t_msm, 3), "one_intt_s": round(t_intt, 3),
+                                "one_coset_ntt_s": round(t_coset, 3), "call_counts": counts,
+                                "msm_plus_ntt_seconds_at_call_counts": round(est, 2),
+                                "note": "C restatement kernels only (no sweep, no scans, no host work): a lower bound for a CPU prove of this circuit"}
 if "--cpu" in sys.argv:
     vk2, proof2, _, t_cpu = run("oracle")
     out["prove_seconds_cpu_oracle"] = round(t_cpu, 3); out["cpu_threads"] = ob.num_threads(); out["proofs_identical"] = proof2 == proof
