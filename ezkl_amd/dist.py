@@ -48,3 +48,24 @@ def fold_partials(partial, dist, device):
     dist.all_gather_into_tensor(recv, send)
     parts = recv.cpu().numpy().view(np.uint64).reshape(-1, 8)
     return fold_points(parts)
+
+
+def allgather_points(partials, dist, device):
+    """all_gather a (b, 8) array of per-rank partial points -> (world, b, 8); one collective per commit batch"""
+    partials = np.ascontiguousarray(partials, np.uint64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return partials[None]
+    import torch
+    world = dist.get_world_size()
+    send = torch.from_numpy(partials.view(np.uint8).reshape(-1).copy()).to(device)
+    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    return recv.cpu().numpy().view(np.uint64).reshape(world, partials.shape[0], 8)
+
+
+def fold_columns(gathered):
+    """(world, b, 8) partials -> (b, 8) sums"""
+    out = np.zeros((gathered.shape[1], 8), np.uint64)
+    for j in range(gathered.shape[1]):
+        out[j] = fold_points(gathered[:, j])
+    return out

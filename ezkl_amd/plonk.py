@@ -254,6 +254,33 @@ class Rng:
         return a
 
 
+class DistGpuBackend(GpuBackend):
+    """BASELINE configs[3]: the MSMs of a proof sharded across the GPUs of a node.  Every rank runs
+    the same deterministic prover on replicated columns but holds only its contiguous slice of the SRS (base-set memory
+    and MSM work divide by the world size); each commit batch ends with ONE all_gather of the 64-byte partials (RCCL
+    over xGMI) and a host fold, so all ranks derive identical transcripts.  NTTs / the sweep stay replicated here."""
+    name = "hip-dist"
+
+    def __init__(self, params_g, params_g_lagrange, k, dist, device):
+        from . import dist as D
+        self.D, self.dist, self.device = D, dist, device
+        world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        self.lo, self.hi = D.shard_range(1 << k, rank, world)
+        self.k, self.n = k, 1 << k
+        self.g = _b.Bases(np.ascontiguousarray(params_g[self.lo:self.hi]))
+        self.gl = _b.Bases(np.ascontiguousarray(params_g_lagrange[self.lo:self.hi]))
+        self._dom, self._zpow = {}, {}
+
+    def _commit(self, bases, hs):
+        part = _b.msm_g1_batch_dev(bases, [h.ptr + 32 * self.lo for h in hs], self.hi - self.lo)
+        full = self.D.fold_columns(self.D.allgather_points(part, self.dist, self.device))
+        return [point_to_ints(p) for p in full]
+
+    def commit_lagrange(self, hs): return self._commit(self.gl, hs) if hs else []
+    def commit(self, hs): return self._commit(self.g, hs) if hs else []
+
+
 # ------------------------------------------------------------------ keygen
 class ProvingKey:
     pass

@@ -156,3 +156,22 @@ def test_gpu_proof_is_bit_identical_to_cpu_proof(hip, golden_srs):
     assert proof_g == proof_c
     g1, g2, s_g2 = setup(golden_srs)
     assert V.verify(vk_g, g1, g2, s_g2, proof_g)
+
+
+@pytest.mark.gpu
+def test_msm_sharded_prover_two_ranks_same_proof(hip):
+    """BASELINE configs[3] plumbing on one GPU: two ranks (gloo, both on GPU 0) each hold half of the SRS, shard every
+    MSM of the proof by points, all_gather the partials; the proof equals the single-rank proof and verifies"""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, K="12", BLOCKS="1")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py")], env=env, capture_output=True, text=True, timeout=600)
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert lines, two.stderr[-2000:]
+    j2 = json.loads(lines[-1])
+    assert j1["verifier_accepts"] and j2["verifier_accepts"]
+    assert j2["n_gpus"] == 2 and j1["proof_sha256"] == j2["proof_sha256"]

@@ -16,7 +16,20 @@ from oracle import pairing as E, binding as ob, verifier as V
 k = int(os.environ.get("K", "16")); blocks = int(os.environ.get("BLOCKS", "2")); seg = 256
 n = 1 << k
 R = P.R
-ezkl_amd.init(0)
+# multi-GPU (torchrun): the MSMs of the proof are sharded by points across the ranks (BASELINE configs[3])
+world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+dist, ddev = None, None
+if world > 1:
+    import torch, torch.distributed as dist
+    if "--share-device" in sys.argv:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "--gloo" in sys.argv:
+        dist.init_process_group(backend="gloo"); ddev = torch.device("cpu")
+    else:
+        ddev = torch.device("cuda", local_rank); dist.init_process_group(backend="nccl", device_id=ddev)
+ezkl_amd.init(local_rank)
 
 # ---- test SRS with a known secret s, generated on the device (insecure, like gen_srs)
 s = 0x1234567890abcdef1234567890abcdef % R
@@ -100,7 +113,7 @@ if relu:
     fixed += [to_mont_dev_limbs(signed_to_canon_limbs(sel)), to_mont_dev_limbs(signed_to_canon_limbs(tin)), to_mont_dev_limbs(signed_to_canon_limbs(tout))]
 
 def run(backend_name):
-    be = P.GpuBackend(g, gl, k) if backend_name == "hip" else __import__("oracle.cpu_backend", fromlist=["OracleBackend"]).OracleBackend(g, gl, k)
+    be = (P.DistGpuBackend(g, gl, k, dist, ddev) if world > 1 else P.GpuBackend(g, gl, k)) if backend_name == "hip" else __import__("oracle.cpu_backend", fromlist=["OracleBackend"]).OracleBackend(g, gl, k)
     t0 = time.time(); pk, vk = P.keygen(cs, be, fixed, copies); t_keygen = time.time() - t0
     P.create_proof(pk, be, adv, P.Rng(5))      # warm-up (window tables, twiddles, JIT)
     tm = {}
@@ -109,9 +122,20 @@ def run(backend_name):
     return vk, proof, t_keygen, t_prove
 
 vk, proof, t_keygen, t_prove = run("hip")
+if world > 1:
+    import hashlib, torch
+    hs_ = torch.tensor(list(hashlib.sha256(proof).digest()), dtype=torch.uint8, device=ddev)
+    all_h = [torch.empty_like(hs_) for _ in range(world)]
+    dist.all_gather(all_h, hs_)
+    assert all(bool((h == all_h[0]).all()) for h in all_h), "ranks produced different proofs"
+    tt = torch.tensor([t_prove], dtype=torch.float64, device=ddev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_prove = float(tt[0])
+    if rank != 0:
+        dist.barrier(); dist.destroy_process_group(); sys.exit(0)
 t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof); t_verify = time.time() - t0
 out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLONK, Keccak EVM transcript): matmul-accumulation blocks + ReLU lookup",
        "lookups": len(lookups), "lookup_table_rows": (1 << tbits) if relu else 0,
+       "n_gpus": world, "msm_sharding": "points across %d rank(s), all_gather of 64-B partials per commit batch" % world,
+       "proof_sha256": __import__("hashlib").sha256(proof).hexdigest()[:16],
        "k": k, "advice_columns": cs.n_advice, "fixed_columns": cs.n_fixed, "degree": cs.degree, "ext_k": cs.ext_k, "copies": len(copies),
        "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "keygen_seconds_gpu": round(t_keygen, 3),
        "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
@@ -137,3 +161,5 @@ if "--cpu" in sys.argv:
     vk2, proof2, _, t_cpu = run("oracle")
     out["prove_seconds_cpu_oracle"] = round(t_cpu, 3); out["cpu_threads"] = ob.num_threads(); out["proofs_identical"] = proof2 == proof
 print(json.dumps(out))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
