@@ -12,8 +12,8 @@ exact query order / vk digest cannot be pinned).  The proof format is the EvmTra
 proofs (points 64 B BE, scalars 32 B BE); acceptance is decided by an independent pairing verifier
 (oracle/verifier.py), which is how the reference itself validates proofs.
 
-Covered: custom gates, the permutation argument (chunked), mv-lookup (logUp) arguments with theta-compressed tuples.
-Not covered yet: instance columns, multi-phase (second-phase advice + challenges).
+Covered: custom gates, the permutation argument (chunked), mv-lookup (logUp) arguments with theta-compressed tuples,
+instance columns (hashed, not committed; evaluated by the verifier), second-phase advice with post-commitment challenges.
 """
 import numpy as np
 from .transcript import EvmTranscript, keccak256, R
@@ -65,13 +65,15 @@ class Expr:
 
 def adv(col, rot=0): return Expr(("adv", col, rot))
 def fix(col, rot=0): return Expr(("fix", col, rot))
+def inst(col, rot=0): return Expr(("inst", col, rot))
+def chal(idx): return Expr(("chal", idx))
 def const(v): return Expr(("const", int(v) % R))
 
 
 def degree(e):
     op = e.node[0]
-    if op == "const": return 0
-    if op in ("adv", "fix"): return 1
+    if op in ("const", "chal"): return 0
+    if op in ("adv", "fix", "inst"): return 1
     if op == "neg": return degree(e.node[1])
     if op in ("add", "sub"): return max(degree(e.node[1]), degree(e.node[2]))
     return degree(e.node[1]) + degree(e.node[2])
@@ -79,19 +81,20 @@ def degree(e):
 
 def queries(e, out):
     op = e.node[0]
-    if op in ("adv", "fix"):
+    if op in ("adv", "fix", "inst"):
         out.add((op, e.node[1], e.node[2]))
-    elif op != "const":
+    elif op not in ("const", "chal"):
         for c in e.node[1:]:
             queries(c, out)
     return out
 
 
 def evaluate(e, q):
-    """verifier side: q(kind, col, rot) -> int"""
+    """verifier side: q(kind, col, rot) -> int  (kind "chal": q("chal", idx, 0))"""
     op = e.node[0]
     if op == "const": return e.node[1]
-    if op in ("adv", "fix"): return q(op, e.node[1], e.node[2])
+    if op == "chal": return q("chal", e.node[1], 0)
+    if op in ("adv", "fix", "inst"): return q(op, e.node[1], e.node[2])
     if op == "neg": return (-evaluate(e.node[1], q)) % R
     a, b = evaluate(e.node[1], q), evaluate(e.node[2], q)
     return (a + b) % R if op == "add" else (a - b) % R if op == "sub" else a * b % R
@@ -103,7 +106,8 @@ def lower(e, prog, col_index, memo):
     if key in memo: return memo[key]
     op = e.node[0]
     if op == "const": r = prog.constant(to_mont(e.node[1]))
-    elif op in ("adv", "fix"): r = prog.column(col_index(op, e.node[1]), e.node[2])
+    elif op == "chal": r = col_index("chal", e.node[1])
+    elif op in ("adv", "fix", "inst"): r = prog.column(col_index(op, e.node[1]), e.node[2])
     elif op == "neg": r = prog.calc("negate", lower(e.node[1], prog, col_index, memo))
     else: r = prog.calc(op, lower(e.node[1], prog, col_index, memo), lower(e.node[2], prog, col_index, memo))
     memo[key] = r
@@ -111,14 +115,18 @@ def lower(e, prog, col_index, memo):
 
 
 class ConstraintSystem:
-    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns, lookups=()):
+    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns, lookups=(), n_instance=0, advice_phase=None, n_challenges=0):
         """lookups: [(input_tuples, table_tuple)]: every input tuple (list of Expr) of a lookup must appear as a row of
         the table tuple (list of Expr of the same arity) on the usable rows -- the mv-lookup (logUp) argument the
         zkonduit halo2 fork uses (cargo feature `mv-lookup`, /root/reference/Cargo.toml:255)."""
         self.k, self.n = k, 1 << k
-        self.n_advice, self.n_fixed = n_advice, n_fixed
+        self.n_advice, self.n_fixed, self.n_instance = n_advice, n_fixed, n_instance
+        # second-phase advice (ezkl's Freivalds einsum, src/circuit/ops/chip/einsum/mod.rs:67-76,716): columns with phase 1 are
+        # committed after `n_challenges` challenges have been squeezed from the first-phase commitments
+        self.advice_phase = list(advice_phase) if advice_phase is not None else [0] * n_advice
+        self.n_challenges = n_challenges
         self.gates = list(gates)
-        self.perm = list(permutation_columns)             # [("adv"|"fix", col)]
+        self.perm = list(permutation_columns)             # [("adv"|"fix"|"inst", col)]
         self.lookups = [([list(t) for t in ins], list(tab)) for ins, tab in lookups]
         self.usable = self.n - BLINDING - 1               # row index of l_last; rows [0, usable) carry the witness
         d = max([degree(g) for g in self.gates] + [3])
@@ -140,6 +148,7 @@ class ConstraintSystem:
                     queries(e, qs)
         self.advice_queries = sorted((c, r) for kd, c, r in qs if kd == "adv")
         self.fixed_queries = sorted((c, r) for kd, c, r in qs if kd == "fix")
+        self.instance_queries = sorted((c, r) for kd, c, r in qs if kd == "inst")
         self.n_chunks = -(-len(self.perm) // self.chunk) if self.perm else 0
 
     def perm_chunks(self):
@@ -365,7 +374,8 @@ class VerifyingKey:
 
 
 def vk_digest(vk):
-    t = bytearray([vk.cs.k, vk.cs.n_advice, vk.cs.n_fixed, vk.cs.degree, len(vk.cs.perm)])
+    t = bytearray([vk.cs.k, vk.cs.n_advice, vk.cs.n_fixed, vk.cs.degree, len(vk.cs.perm), vk.cs.n_instance, vk.cs.n_challenges,
+                   len(vk.cs.lookups)] + list(vk.cs.advice_phase))
     for p in list(vk.fixed_commitments) + list(vk.sigma_commitments):
         x, y = (0, 0) if p is None else p
         t += x.to_bytes(32, "big") + y.to_bytes(32, "big")
@@ -373,8 +383,11 @@ def vk_digest(vk):
 
 
 # ------------------------------------------------------------------ prover
-def create_proof(pk, backend, advice_values, rng, timings=None):
-    """advice_values: list of (n,4) Montgomery arrays (rows >= usable are overwritten with blinding randomness).
+def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
+    """advice_values: list of (n,4) Montgomery arrays (rows >= usable are overwritten with blinding randomness), or a
+    callable advice_values(phase, challenges) -> {column: array} for circuits with second-phase advice.
+    instances: list (one per instance column) of lists of public field elements (ints); they are hashed into the
+    transcript, not committed (halo2 KZG: QUERY_INSTANCE = false).
     rng.vec(m) -> (m,4) uniformly random Montgomery residues.  Returns proof bytes (EvmTranscript layout)."""
     import time as _time
     _t = [_time.perf_counter()]
@@ -385,22 +398,40 @@ def create_proof(pk, backend, advice_values, rng, timings=None):
     n, k, u = cs.n, cs.k, cs.usable
     T = EvmTranscript()
     T.common_scalar(pk.vk.digest)
-    # 1. advice columns
-    adv_cols = []
-    for v in advice_values:
-        v = np.array(v, np.uint64, copy=True)
-        v[u:] = rng.vec(n - u)
-        adv_cols.append(backend.upload(v))
-    for p in backend.commit_lagrange(adv_cols):
-        T.write_point(p)
+    # 0. instances: absorbed, never committed
+    inst_cols = []
+    for vals in instances:
+        for v in vals:
+            T.common_scalar(v)
+        col = np.zeros((n, 4), np.uint64)
+        for i, v in enumerate(vals):
+            col[i] = to_mont(v)
+        inst_cols.append(backend.upload(col))
+    assert len(inst_cols) == cs.n_instance
+    # 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges
+    adv_cols = [None] * cs.n_advice
+    user_chal = []
+    for phase in (0, 1):
+        idxs = [c for c in range(cs.n_advice) if cs.advice_phase[c] == phase]
+        if not idxs:
+            continue
+        vals = advice_values(phase, list(user_chal)) if callable(advice_values) else {c: advice_values[c] for c in idxs}
+        for c in idxs:
+            v = np.array(vals[c], np.uint64, copy=True)
+            v[u:] = rng.vec(n - u)
+            adv_cols[c] = backend.upload(v)
+        for p in backend.commit_lagrange([adv_cols[c] for c in idxs]):
+            T.write_point(p)
+        if phase == 0:
+            user_chal = [T.squeeze_challenge() for _ in range(cs.n_challenges)]
     lap("advice_commit")
-    def col_handle(kind, c): return adv_cols[c] if kind == "adv" else pk.fixed_values[c]
+    def col_handle(kind, c): return adv_cols[c] if kind == "adv" else inst_cols[c] if kind == "inst" else pk.fixed_values[c]
     # 2. theta; mv-lookup multiplicities m(X)
     theta, lk = None, []
     if cs.lookups:
         theta = T.squeeze_challenge()
         for ins, tab in cs.lookups:
-            comp = [compress_column(cs, backend, t, theta, col_handle) for t in ins + [tab]]
+            comp = [compress_column(cs, backend, t, theta, col_handle, user_chal) for t in ins + [tab]]
             m, _missing = backend.lookup_multiplicity(comp[:-1], comp[-1], u)
             backend.set_rows(m, u, rng.vec(n - u))
             lk.append({"inputs": comp[:-1], "table": comp[-1], "m": m})
@@ -439,6 +470,7 @@ def create_proof(pk, backend, advice_values, rng, timings=None):
     lap("random_poly")
     # 7. quotient
     adv_polys = [backend.lagrange_to_coeff(h) for h in adv_cols]
+    inst_cosets = [backend.coeff_to_extended(backend.lagrange_to_coeff(h), cs.ext_k) for h in inst_cols]
     z_polys = [backend.lagrange_to_coeff(h) for h in zs]
     adv_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in adv_polys]
     z_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in z_polys]
@@ -447,7 +479,7 @@ def create_proof(pk, backend, advice_values, rng, timings=None):
     m_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in m_polys]
     phi_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in phi_polys]
     lap("intt_and_coset_ntt")
-    prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets)
+    prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal)
     hnum = backend.zeros(1 << cs.ext_k)
     backend.eval_program(prog, cols, chal, hnum)
     lap("quotient_sweep")
@@ -517,11 +549,13 @@ def compress_exprs(prog, tuple_exprs, theta_src, col_index, memo):
     return acc
 
 
-def compress_column(cs, backend, tuple_exprs, theta, col_handle):
+def compress_column(cs, backend, tuple_exprs, theta, col_handle, user_chal=()):
     """the theta-compressed lookup column over the n rows of the Lagrange domain (a gate program with ext_k = k)"""
     prog = _b.GraphProgram(cs.k, cs.k)
     cols, index = [], {}
     def col_index(kind, c):
+        if kind == "chal":
+            return prog.challenge(1 + c)
         if (kind, c) not in index:
             index[(kind, c)] = len(cols); cols.append(col_handle(kind, c))
         return index[(kind, c)]
@@ -529,11 +563,11 @@ def compress_column(cs, backend, tuple_exprs, theta, col_handle):
     if r[0] != _b.INTERMEDIATE:                       # a bare column / constant: materialise it
         r = prog.calc("store", r)
     out = backend.zeros(cs.n)
-    backend.eval_program(prog, cols, [theta], out)
+    backend.eval_program(prog, cols, [theta] + list(user_chal), out)
     return out
 
 
-def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m_cosets=(), phi_cosets=()):
+def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m_cosets=(), phi_cosets=(), inst_cosets=(), user_chal=()):
     """the numerator of h(X) as ONE straight-line program over the extended-coset columns: custom gates, then the
     permutation constraints, folded with y (value = value*y + constraint), as evaluate_h does"""
     prog = _b.GraphProgram(cs.k, cs.ext_k)
@@ -542,8 +576,11 @@ def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m
         if name not in index:
             index[name] = len(cols); cols.append(handle)
         return index[name]
-    def col_index(kind, c): return slot((kind, c), adv_cosets[c] if kind == "adv" else pk.fixed_cosets[c])
-    chal = [y, beta, gamma]
+    chal = [y, beta, gamma] + list(user_chal)
+    def col_index(kind, c):
+        if kind == "chal":
+            return prog.challenge(3 + c)
+        return slot((kind, c), adv_cosets[c] if kind == "adv" else inst_cosets[c] if kind == "inst" else pk.fixed_cosets[c])
     Y, BETA, GAMMA = prog.challenge(0), prog.challenge(1), prog.challenge(2)
     terms, memo = [], {}
     for g in cs.gates:

@@ -17,13 +17,25 @@ def _lagrange_evals(k, x, rows):
     return {i: pow(w, i, R) * zx % R * ninv % R * pow((x - pow(w, i, R)) % R, -1, R) % R for i in rows}
 
 
-def verify(vk, g1_gen, g2, s_g2, proof):
+def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
     cs = vk.cs
     n, k, u = cs.n, cs.k, cs.usable
     try:
         T = EvmTranscript(proof)
         T.common_scalar(vk.digest)
-        adv_c = [T.read_point() for _ in range(cs.n_advice)]
+        if len(instances) != cs.n_instance:
+            return False
+        for vals in instances:
+            for v_ in vals:
+                T.common_scalar(v_)
+        adv_c = [None] * cs.n_advice
+        user_chal = []
+        for phase in (0, 1):
+            idxs = [c for c in range(cs.n_advice) if cs.advice_phase[c] == phase]
+            for c in idxs:
+                adv_c[c] = T.read_point()
+            if phase == 0 and idxs:
+                user_chal = [T.squeeze_challenge() for _ in range(cs.n_challenges)]
         theta, m_c = None, []
         if cs.lookups:
             theta = T.squeeze_challenge()
@@ -51,6 +63,19 @@ def verify(vk, g1_gen, g2, s_g2, proof):
     w = P.omega(k)
     def rot_point(r): return x * pow(w, r % n, R) % R
     # ---- expected quotient evaluation
+    # instance evaluations from the public values: inst(z) = sum_i v_i * l_i(z)
+    zx_cache = {}
+    def inst_eval(c, r):
+        z = rot_point(r)
+        vals = instances[c]
+        if not vals:
+            return 0
+        le = _lagrange_evals(k, z, range(len(vals)))
+        return sum(v_ * le[i] for i, v_ in enumerate(vals)) % R
+    for c, r in cs.instance_queries:
+        ev[("inst", c, r)] = inst_eval(c, r)
+    for i_, cval in enumerate(user_chal):
+        ev[("chal", i_, 0)] = cval
     lag = _lagrange_evals(k, x, [0] + list(range(u, n)))
     l0, llast = lag[0], lag[u]
     lact = (1 - sum(lag[i] for i in range(u, n))) % R

@@ -109,6 +109,69 @@ def test_gpu_lookup_proof_bit_identical(hip, golden_srs):
     assert V.verify(vk_g, g1, g2, s_g2, proof_g)
 
 
+def instance_phase_circuit(k):
+    """public output through an instance column (as ezkl exposes model outputs, src/graph/mod.rs:1411-1446) and a
+    second-phase advice column constrained with a post-commitment challenge (the Freivalds / RLC pattern of
+    src/circuit/ops/chip/einsum/mod.rs:715-783): c = a + r*b with r squeezed after a, b are committed"""
+    a, b, c, acc = P.adv(0), P.adv(1), P.adv(2), P.adv(3)
+    sel = P.fix(0)
+    gates = [sel * (c - a - P.chal(0) * b),                       # phase-1 column against the challenge
+             sel * (acc - P.adv(3, -1) - a * b) + (1 - sel) * 0]   # running dot product on selected rows (row 0 starts from acc[-1])
+    perm = [("adv", 3), ("inst", 0), ("adv", 0)]
+    return P.ConstraintSystem(k, 4, 1, gates, perm, n_instance=1, advice_phase=[0, 0, 1, 0], n_challenges=1)
+
+
+def instance_phase_witness(cs, seed):
+    rng = np.random.default_rng(seed)
+    n, u = cs.n, cs.usable
+    a = [int(rng.integers(1, 1 << 20)) for _ in range(n)]
+    b = [int(rng.integers(1, 1 << 20)) for _ in range(n)]
+    acc = [0] * n
+    sel = [0] * n
+    for r in range(1, u):
+        sel[r] = 1
+        acc[r] = (acc[r - 1] + a[r] * b[r]) % R
+    public = acc[u - 1]
+    to_col = lambda col: np.stack([fe_from_int(v) for v in col])
+    cols0 = {0: to_col(a), 1: to_col(b), 3: to_col(acc)}
+    def advice(phase, challenges):
+        if phase == 0:
+            return cols0
+        r_ = challenges[0]
+        return {2: to_col([(a[i] + r_ * b[i]) % R for i in range(n)])}
+    copies = [((0, u - 1), (1, 0))]                      # adv3[u-1] == inst0[0]
+    return advice, [to_col(sel)], copies, [[public]]
+
+
+def test_instance_and_second_phase_oracle_backend(golden_srs):
+    from oracle.cpu_backend import OracleBackend
+    cs = instance_phase_circuit(6)
+    be = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    g1, g2, s_g2 = setup(golden_srs)
+    advice, fixed, copies, inst = instance_phase_witness(cs, 5)
+    pk, vk = P.keygen(cs, be, fixed, copies)
+    proof = P.create_proof(pk, be, advice, det_rng(3), instances=inst)
+    assert V.verify(vk, g1, g2, s_g2, proof, instances=inst)
+    assert not V.verify(vk, g1, g2, s_g2, proof, instances=[[(inst[0][0] + 1) % R]])      # wrong public output
+    assert not V.verify(vk, g1, g2, s_g2, proof)                                            # missing instances
+
+
+@pytest.mark.gpu
+def test_gpu_instance_second_phase_bit_identical(hip, golden_srs):
+    from oracle.cpu_backend import OracleBackend
+    cs = instance_phase_circuit(6)
+    advice, fixed, copies, inst = instance_phase_witness(cs, 6)
+    cpu = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk_c, _ = P.keygen(cs, cpu, fixed, copies)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    proof_c = P.create_proof(pk_c, cpu, advice, det_rng(4), instances=inst)
+    proof_g = P.create_proof(pk_g, gpu, advice, det_rng(4), instances=inst)
+    assert proof_g == proof_c
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk_g, g1, g2, s_g2, proof_g, instances=inst)
+
+
 def det_rng(seed):
     return P.Rng(seed)
 
