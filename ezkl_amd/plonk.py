@@ -258,7 +258,7 @@ class Rng:
         self.g = np.random.default_rng(seed)
 
     def vec(self, m):
-        a = self.g.integers(0, 1 << 63, size=(m, 4), dtype=np.uint64) * np.uint64(2) + self.g.integers(0, 2, size=(m, 4), dtype=np.uint64)
+        a = np.frombuffer(self.g.bytes(32 * m), np.uint64).reshape(m, 4).copy()
         a[:, 3] &= np.uint64((1 << 61) - 1)          # 253 uniform bits < r, read as Montgomery residues
         return a
 
@@ -373,6 +373,28 @@ class VerifyingKey:
     pass
 
 
+def export_keys(pk, backend):
+    """the proving / verifying key in the raw-bytes layout of halo2's ProvingKey::write (the format of the reference's
+    pk.key / vk.key, SURVEY.md §8(c) item 3, written by /root/reference/src/pfsys/mod.rs:638-683 save_pk / save_vk):
+    returns (vk_bytes, pk_bytes).  Selectors are plain fixed columns here, so the selector section is empty."""
+    from . import codecs
+    cs = pk.cs
+    def pt(p):
+        x, y = (0, 0) if p is None else p
+        return np.frombuffer((x * MONT % Q).to_bytes(32, "little") + (y * MONT % Q).to_bytes(32, "little"), np.uint64)
+    vk = dict(k=cs.k, compress_selectors=True,
+              fixed_commitments=np.stack([pt(p) for p in pk.vk.fixed_commitments]) if pk.vk.fixed_commitments else np.zeros((0, 8), np.uint64),
+              permutation_commitments=np.stack([pt(p) for p in pk.vk.sigma_commitments]) if pk.vk.sigma_commitments else np.zeros((0, 8), np.uint64),
+              selectors=np.zeros((0, cs.n), bool))
+    ne = 1 << cs.ext_k
+    dl = lambda h, m: np.array(backend.download(h, m), np.uint64, copy=True)
+    d = dict(vk=vk, l0=dl(pk.l0, ne), l_last=dl(pk.l_last, ne), l_active_row=dl(pk.l_active, ne),
+             fixed_values=[dl(h, cs.n) for h in pk.fixed_values], fixed_polys=[dl(h, cs.n) for h in pk.fixed_polys],
+             fixed_cosets=[dl(h, ne) for h in pk.fixed_cosets], permutations=[dl(h, cs.n) for h in pk.sigma_values],
+             perm_polys=[dl(h, cs.n) for h in pk.sigma_polys], perm_cosets=[dl(h, ne) for h in pk.sigma_cosets])
+    return codecs.write_vk(vk), codecs.write_pk(d)
+
+
 def vk_digest(vk):
     t = bytearray([vk.cs.k, vk.cs.n_advice, vk.cs.n_fixed, vk.cs.degree, len(vk.cs.perm), vk.cs.n_instance, vk.cs.n_challenges,
                    len(vk.cs.lookups)] + list(vk.cs.advice_phase))
@@ -417,9 +439,8 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
             continue
         vals = advice_values(phase, list(user_chal)) if callable(advice_values) else {c: advice_values[c] for c in idxs}
         for c in idxs:
-            v = np.array(vals[c], np.uint64, copy=True)
-            v[u:] = rng.vec(n - u)
-            adv_cols[c] = backend.upload(v)
+            adv_cols[c] = backend.upload(vals[c])                    # witness column -> HBM, then blind rows [u, n) in place
+            backend.set_rows(adv_cols[c], u, rng.vec(n - u))
         for p in backend.commit_lagrange([adv_cols[c] for c in idxs]):
             T.write_point(p)
         if phase == 0:

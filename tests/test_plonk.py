@@ -203,6 +203,25 @@ def test_prove_verify_oracle_backend(golden_srs):
     assert not V.verify(vk, g1, g2, s_g2, P.create_proof(pk, be, adv_bad, det_rng(7)))
 
 
+def test_export_keys_in_halo2_layout(golden_srs):
+    """keygen output serialises to the vk.key / pk.key raw-bytes layout and parses back"""
+    from oracle.cpu_backend import OracleBackend
+    from ezkl_amd import codecs
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 1)
+    be = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk, vk = P.keygen(cs, be, fixed, copies)
+    vkb, pkb = P.export_keys(pk, be)
+    assert pkb.startswith(vkb) and vkb[0] == 3 and vkb[1] == 6
+    back = codecs.read_pk(pkb, n_perm=len(cs.perm), n_selectors=0)
+    assert len(back["fixed_polys"]) == cs.n_fixed and back["l0"].shape == (1 << cs.ext_k, 4)
+    assert (back["perm_cosets"][1] == be.download(pk.sigma_cosets[1], 1 << cs.ext_k)).all()
+    # the permutation polynomials of the identity part are the (0, delta^j, 0, ...) vectors the reference's pk.key shows
+    ident = [j for j, col in enumerate(back["perm_polys"]) if not col[2:].any() and not col[0].any()]
+    for j in ident:
+        assert P.from_mont(back["perm_polys"][j][1]) == pow(P.DELTA, j, R)
+
+
 @pytest.mark.gpu
 def test_gpu_proof_is_bit_identical_to_cpu_proof(hip, golden_srs):
     """north-star: proofs bit-identical to the CPU prover on the same SRS / witness / randomness"""
