@@ -138,14 +138,52 @@ const char* ezkl_hip_strerror(int code) {
 int ezkl_hip_last_hip_error(void) { return g_last_hip_err.load(); }
 const char* ezkl_hip_version(void) { return "ezkl_hip 0.1 (gfx950)"; }
 
+// Column buffers are recycled: hipMalloc / hipFree cost ~0.2 ms each (hipFree synchronises the device) and a prover
+// allocates and drops hundreds of same-sized columns per proof.  Freed blocks are parked per exact size (up to
+// POOL_CAP bytes) and handed out again; work on a recycled block is ordered by the device-wide sync hipFree would have
+// implied only when the pool actually returns memory to the driver.
+namespace {
+std::map<size_t, std::vector<void*>> g_pool;          // guarded by the ctx mutex
+std::map<void*, size_t> g_sizes;
+size_t g_pool_bytes = 0;
+const size_t POOL_CAP = (size_t)48 << 30;
+}
 int ezkl_hip_malloc(void** dptr, size_t bytes) {
     if (!dptr) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    EZ_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    if (!bytes) bytes = 1;
+    auto it = g_pool.find(bytes);
+    if (it != g_pool.end() && !it->second.empty()) {
+        *dptr = it->second.back();
+        it->second.pop_back();
+        g_pool_bytes -= bytes;
+        // the previous owner's kernels may still be running on another stream: order them before the new owner's
+        EZ_HIP(hipDeviceSynchronize());
+        return EZKL_OK;
+    }
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory && g_pool_bytes) {      // give the parked blocks back and retry once
+        (void)hipGetLastError();
+        for (auto& kv : g_pool) for (void* p : kv.second) { (void)hipFree(p); g_sizes.erase(p); }
+        g_pool.clear();
+        g_pool_bytes = 0;
+        e = hipMalloc(dptr, bytes);
+    }
+    if (e != hipSuccess) return set_hip_error(e, "hipMalloc", __FILE__, __LINE__);
+    g_sizes[*dptr] = bytes;
     return EZKL_OK;
 }
 int ezkl_hip_free(void* dptr) {
+    if (!dptr) return EZKL_OK;
     EZ_CTX(c);
+    auto it = g_sizes.find(dptr);
+    if (it == g_sizes.end()) { EZ_HIP(hipFree(dptr)); return EZKL_OK; }
+    if (g_pool_bytes + it->second <= POOL_CAP) {
+        g_pool[it->second].push_back(dptr);
+        g_pool_bytes += it->second;
+        return EZKL_OK;
+    }
+    g_sizes.erase(it);
     EZ_HIP(hipFree(dptr));
     return EZKL_OK;
 }

@@ -257,7 +257,19 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab
             if (started_before) st_g1x(head + t, acc); else st_g1x(buckets + b, acc);
             acc = g1x_identity();
             started_before = false;
-            do { b++; bin_end = offsets[b + 1]; } while (bin_end == k);
+            // next non-empty bucket: a few linear probes (the common case), then a binary search -- a sparse column
+            // (e.g. m(X): a handful of blinding rows scattered over 2^19 buckets) must not walk every empty bucket
+            uint32_t probes = 0;
+            do { b++; bin_end = offsets[b + 1]; } while (bin_end == k && ++probes < 4);
+            if (bin_end == k) {
+                uint32_t lo2 = b + 1, hi2 = nb;          // offsets[lo2] == k, offsets[hi2] = total > k
+                while (hi2 - lo2 > 1) {
+                    uint32_t mid = (lo2 + hi2) >> 1;
+                    if (offsets[mid] <= k) lo2 = mid; else hi2 = mid;
+                }
+                b = lo2;
+                bin_end = offsets[b + 1];
+            }
         }
         g1a_t cur = nxt;
         if (k + 1 < k1) nxt = msm_fetch(tab, vals[k + 1]);   // prefetch: the gather latency hides under the add

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* table, uint32
             if (cur == HT_EMPTY) return;                 // claimed
         }
         if (Fr::eq(ld_fe(table + cur), key)) {           // same value already present: keep the first row
-            atomicMin(&slots[h], i);
+            if (i < cur) atomicMin(&slots[h], i);        // (a table padded with one repeated value must not serialise here)
             return;
         }
         h = (h + 1) & mask;

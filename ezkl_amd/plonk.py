@@ -258,7 +258,7 @@ class Rng:
         self.g = np.random.default_rng(seed)
 
     def vec(self, m):
-        a = np.frombuffer(self.g.bytes(32 * m), np.uint64).reshape(m, 4).copy()
+        a = self.g.bit_generator.random_raw(4 * m).astype(np.uint64, copy=False).reshape(m, 4)
         a[:, 3] &= np.uint64((1 << 61) - 1)          # 253 uniform bits < r, read as Montgomery residues
         return a
 

@@ -191,3 +191,25 @@ def test_gen_srs_structure(hip):
     assert (B.msm_g1(gl, ones) == G[0]).all()
     v = rand_fr(np.random.default_rng(3), n)
     assert (B.msm_g1(gl, v) == B.msm_g1(g, ob.lagrange_to_coeff(v, k))).all()
+
+
+def test_sparse_column_is_fast_and_correct(hip):
+    """a column with a few thousand equal small values plus a handful of full-width blinding rows (the shape of the
+    mv-lookup m(X) column): entries are scattered over ~2^19 mostly empty buckets"""
+    import time
+    from ezkl_amd import backend as B
+    n = 1 << 18
+    rng = np.random.default_rng(8)
+    bases = B.Bases.generate(SEED, n)
+    pts = bases.download()
+    s = np.zeros((n, 4), np.uint64)
+    s[:4096] = fe_from_int(33)
+    s[n - 6:] = rand_fr(rng, 6)
+    d = B.DeviceBuffer.from_numpy(s)
+    B.msm_g1_dev(bases, d.ptr, n)
+    t0 = time.perf_counter()
+    got = B.msm_g1_dev(bases, d.ptr, n)
+    dt = time.perf_counter() - t0
+    assert (got == ob.msm(s, pts)).all()
+    assert dt < 0.01, "sparse MSM took %.1f ms" % (dt * 1e3)
+    bases.free()
