@@ -184,10 +184,31 @@ def main():
                                  "batch_matches_single": bool((bres[0] == B.msm_g1_dev(bases, scalars.ptr, n_msm)).all())})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
+            out["prove"] = prove_leg()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def prove_leg():
+    """End-to-end `prove` of a k = 20 matmul + ReLU-lookup circuit (tools/prove_bench.py) in a CHILD process, so that
+    the per-kernel averages rocprofv3 reports for this process stay those of the timed MSM / NTT regions.  Part of the
+    checker leg: the child verifies the proof with the oracle's pairing verifier and times the C oracle's MSM / NTT
+    kernels at the proof's call counts."""
+    import subprocess
+    env = dict(os.environ, K="20", BLOCKS="4")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py"), "--cpu-kernels"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
+                "prove_seconds_gpu": j["prove_seconds_gpu"], "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
+                "breakdown_seconds": j["prove_breakdown_seconds"],
+                "cpu_msm_plus_ntt_seconds_at_call_counts": j["cpu_kernel_sample"]["msm_plus_ntt_seconds_at_call_counts"],
+                "cpu_threads": j["cpu_kernel_sample"]["threads"]}
+    except Exception as e:          # the headline line must still be printed
+        return {"error": repr(e)[:200]}
 
 
 def cpu_baseline(bases, scalars, n, gpu_result):
