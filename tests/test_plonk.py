@@ -172,6 +172,98 @@ def test_gpu_instance_second_phase_bit_identical(hip, golden_srs):
     assert V.verify(vk_g, g1, g2, s_g2, proof_g, instances=inst)
 
 
+def random_circuit(seed, k=6):
+    """random gate set  sel_g * (out_g - f_g(inputs))  with f_g a random polynomial of degree <= 3 over rotated advice
+    cells (always satisfiable: out is computed from f), random copy constraints between equal cells, a random
+    single-column range lookup"""
+    rng = np.random.default_rng(seed)
+    n_in, n_gates = 3, int(rng.integers(1, 4))
+    n = 1 << k
+    u = n - P.BLINDING - 1
+
+    def rand_poly():
+        terms = []
+        for _ in range(int(rng.integers(1, 4))):
+            deg = int(rng.integers(1, 4))
+            factors = [(int(rng.integers(0, n_in)), int(rng.integers(-1, 2))) for _ in range(deg)]
+            terms.append((int(rng.integers(1, 1000)), factors))
+        return terms
+
+    polys = [rand_poly() for _ in range(n_gates)]
+    gates = []
+    for g, terms in enumerate(polys):
+        e = P.const(0)
+        for coef, factors in terms:
+            t = P.const(coef)
+            for c, r in factors:
+                t = t * P.adv(c, r)
+            e = e + t
+        gates.append(P.fix(g) * (P.adv(n_in + g) - e))
+    lookups = [([[P.fix(n_gates) * P.adv(0)]], [P.fix(n_gates + 1)])]
+    perm = [("adv", c) for c in range(n_in)] + [("fix", n_gates + 2)]
+    cs = P.ConstraintSystem(k, n_in + n_gates, n_gates + 3, gates, perm, lookups)
+    # witness
+    A = [[0] * n for _ in range(n_in + n_gates)]
+    F = [[0] * n for _ in range(n_gates + 3)]
+    T = 32
+    for c in range(n_in):
+        for r in range(n):
+            A[c][r] = int(rng.integers(0, T))
+    copies, used = [], set()
+    while len(copies) < 6:                                # tie random (distinct) cells of the input columns together
+        c1, c2 = int(rng.integers(0, n_in)), int(rng.integers(0, n_in))
+        r1, r2 = int(rng.integers(1, u - 1)), int(rng.integers(1, u - 1))
+        if (c1, r1) in used or (c2, r2) in used or (c1, r1) == (c2, r2):
+            continue
+        used.update([(c1, r1), (c2, r2)])
+        A[c2][r2] = A[c1][r1]
+        copies.append(((c1, r1), (c2, r2)))
+    for r in range(u):
+        F[n_gates + 1][r] = r % T                         # range table 0..31
+    for r in range(1, u - 1):
+        F[n_gates][r] = 1                                 # lookup selector
+        for g, terms in enumerate(polys):
+            F[g][r] = 1
+            acc = 0
+            for coef, factors in terms:
+                t = coef
+                for c, rot in factors:
+                    t = t * A[c][(r + rot) % n] % R
+                acc = (acc + t) % R
+            A[n_in + g][r] = acc
+    to_col = lambda col: np.stack([fe_from_int(v) for v in col])
+    return cs, [to_col(c) for c in A], [to_col(c) for c in F], copies
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_circuits_oracle_backend(golden_srs, seed):
+    from oracle.cpu_backend import OracleBackend
+    cs, adv, fixed, copies = random_circuit(seed)
+    be = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    g1, g2, s_g2 = setup(golden_srs)
+    pk, vk = P.keygen(cs, be, fixed, copies)
+    proof = P.create_proof(pk, be, adv, det_rng(seed))
+    assert V.verify(vk, g1, g2, s_g2, proof)
+    bad = [a.copy() for a in adv]
+    bad[cs.n_advice - 1][5] = fe_from_int((P.from_mont(bad[cs.n_advice - 1][5]) + 1) % R)     # break the last gate on row 5
+    assert not V.verify(vk, g1, g2, s_g2, P.create_proof(pk, be, bad, det_rng(seed)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_circuits_gpu_bit_identical(hip, golden_srs, seed):
+    from oracle.cpu_backend import OracleBackend
+    cs, adv, fixed, copies = random_circuit(seed)
+    cpu = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk_c, _ = P.keygen(cs, cpu, fixed, copies)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    pc, pg = P.create_proof(pk_c, cpu, adv, det_rng(seed)), P.create_proof(pk_g, gpu, adv, det_rng(seed))
+    assert pc == pg
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk_g, g1, g2, s_g2, pg)
+
+
 def det_rng(seed):
     return P.Rng(seed)
 
