@@ -1,0 +1,1182 @@
+// Native host prover: halo2-shaped keygen + create_proof (KZG / SHPLONK, EvmTranscript) over the C ABI of
+// include/ezkl_hip.h.  Every O(n) step -- commitments (MSM), iNTT / coset NTT, the quotient sweep, grand products /
+// sums, polynomial evaluation, the SHPLONK quotients -- is a kernel of libezkl_hip.so on resident columns; this file
+// owns the transcript, the randomness and the O(1) scalar glue.  Round order follows SURVEY.md §3.1 ([UPSTREAM]
+// halo2_proofs::plonk::prover::create_proof, called at /root/reference/src/pfsys/mod.rs:456-463): advice commits ->
+// (theta, m) -> beta, gamma -> permutation products -> lookup sums -> random poly -> y -> quotient pieces -> x ->
+// evaluations -> SHPLONK.  The Python restatement ezkl_amd/plonk.py is the executable spec: both emit identical bytes.
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <map>
+#include <memory>
+#include <random>
+#include <set>
+#include <unordered_map>
+#include "ezkl_hip.hpp"
+#include "ezkl_prover.h"
+#include "hostfield.hpp"
+#include "transcript.hpp"
+
+namespace ezkl_prover {
+using ezkl_hip::check;
+using ezkl_hip::DeviceColumn;
+using ezkl_hip::Error;
+using Col = std::shared_ptr<DeviceColumn>;
+
+static thread_local std::string g_last_error;
+constexpr uint32_t BLINDING = 5;      // as in ezkl (/root/reference/src/graph/mod.rs:100): the last BLINDING+1 rows are unusable
+
+// ------------------------------------------------------------------ constraint system
+enum NodeOp : uint32_t { N_CONST = 0, N_ADV, N_FIX, N_INST, N_CHAL, N_NEG, N_ADD, N_SUB, N_MUL };
+struct Node {
+    uint32_t op, a, b;
+    Fe c;
+};
+struct Query {
+    uint32_t col;
+    int32_t rot;
+    bool operator<(const Query& o) const { return col != o.col ? col < o.col : rot < o.rot; }
+    bool operator==(const Query& o) const { return col == o.col && rot == o.rot; }
+};
+struct Lookup {
+    std::vector<std::vector<uint32_t>> inputs;
+    std::vector<uint32_t> table;
+};
+struct ConstraintSystem {
+    uint32_t k = 0, n = 0, n_advice = 0, n_fixed = 0, n_instance = 0, n_challenges = 0;
+    std::vector<uint32_t> advice_phase;
+    std::vector<Node> nodes;
+    std::vector<uint32_t> gates;
+    std::vector<std::pair<uint32_t, uint32_t>> perm;      // (kind = N_ADV | N_FIX | N_INST, col)
+    std::vector<Lookup> lookups;
+    uint32_t usable = 0, degree = 0, chunk = 0, ext_k = 0, n_chunks = 0;
+    std::vector<Query> advice_queries, fixed_queries, instance_queries;
+    std::vector<uint32_t> deg_memo;
+
+    uint32_t deg(uint32_t id) {
+        if (deg_memo[id] != UINT32_MAX) return deg_memo[id];
+        const Node& nd = nodes[id];
+        uint32_t d;
+        switch (nd.op) {
+        case N_CONST: case N_CHAL: d = 0; break;
+        case N_ADV: case N_FIX: case N_INST: d = 1; break;
+        case N_NEG: d = deg(nd.a); break;
+        case N_ADD: case N_SUB: d = std::max(deg(nd.a), deg(nd.b)); break;
+        default: d = deg(nd.a) + deg(nd.b); break;
+        }
+        return deg_memo[id] = d;
+    }
+    void collect(uint32_t id, std::set<Query> out[3], std::vector<uint8_t>& seen) const {
+        if (seen[id]) return;
+        seen[id] = 1;
+        const Node& nd = nodes[id];
+        if (nd.op == N_ADV || nd.op == N_FIX || nd.op == N_INST) out[nd.op - N_ADV].insert(Query{nd.a, (int32_t)nd.b});
+        else if (nd.op == N_NEG) collect(nd.a, out, seen);
+        else if (nd.op >= N_ADD) { collect(nd.a, out, seen); collect(nd.b, out, seen); }
+    }
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> perm_chunks() const {
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> out;
+        for (size_t i = 0; i < perm.size(); i += chunk) out.emplace_back(perm.begin() + i, perm.begin() + std::min(perm.size(), i + chunk));
+        return out;
+    }
+    void finalize() {
+        n = 1u << k;
+        usable = n - BLINDING - 1;
+        deg_memo.assign(nodes.size(), UINT32_MAX);
+        uint32_t d = 3;
+        for (uint32_t g : gates) d = std::max(d, deg(g));
+        for (auto& l : lookups) {                          // l_active * phi * prod(f_j + beta) * (t + beta)
+            uint32_t s = 2, tmax = 0;
+            for (auto& t : l.inputs) {
+                uint32_t m = 0;
+                for (uint32_t e : t) m = std::max(m, deg(e));
+                s += m;
+            }
+            for (uint32_t e : l.table) tmax = std::max(tmax, deg(e));
+            d = std::max(d, s + tmax);
+        }
+        degree = d;
+        chunk = d - 2;
+        ext_k = k;
+        while ((1ull << ext_k) < (uint64_t)n * (d - 1)) ext_k++;
+        std::set<Query> qs[3];
+        std::vector<uint8_t> seen(nodes.size(), 0);
+        for (uint32_t g : gates) collect(g, qs, seen);
+        for (auto& pc : perm) qs[pc.first - N_ADV].insert(Query{pc.second, 0});
+        for (auto& l : lookups) {
+            for (auto& t : l.inputs)
+                for (uint32_t e : t) collect(e, qs, seen);
+            for (uint32_t e : l.table) collect(e, qs, seen);
+        }
+        advice_queries.assign(qs[0].begin(), qs[0].end());
+        fixed_queries.assign(qs[1].begin(), qs[1].end());
+        instance_queries.assign(qs[2].begin(), qs[2].end());
+        n_chunks = perm.empty() ? 0 : (uint32_t)((perm.size() + chunk - 1) / chunk);
+    }
+};
+
+struct Reader {
+    const uint8_t* p;
+    size_t left;
+    uint32_t u32() {
+        if (left < 4) throw Error(EZKL_ERR_INVALID, "constraint system blob truncated");
+        uint32_t v;
+        std::memcpy(&v, p, 4);
+        p += 4; left -= 4;
+        return v;
+    }
+    void bytes(void* out, size_t m) {
+        if (left < m) throw Error(EZKL_ERR_INVALID, "constraint system blob truncated");
+        std::memcpy(out, p, m);
+        p += m; left -= m;
+    }
+};
+static void invalid(bool cond, const char* what) {
+    if (cond) throw Error(EZKL_ERR_INVALID, what);
+}
+static std::unique_ptr<ConstraintSystem> parse_cs(const void* blob, size_t len) {
+    Reader r{(const uint8_t*)blob, len};
+    invalid(r.u32() != 0x53435a45u, "bad magic");
+    invalid(r.u32() != 1, "unsupported version");
+    auto cs = std::make_unique<ConstraintSystem>();
+    cs->k = r.u32(); cs->n_advice = r.u32(); cs->n_fixed = r.u32(); cs->n_instance = r.u32(); cs->n_challenges = r.u32();
+    invalid(cs->k < 4 || cs->k > 28, "k out of range");
+    invalid(cs->n_advice > (1u << 16) || cs->n_fixed > (1u << 16) || cs->n_instance > (1u << 16) || cs->n_challenges > (1u << 16), "column count out of range");
+    for (uint32_t i = 0; i < cs->n_advice; i++) {
+        cs->advice_phase.push_back(r.u32());
+        invalid(cs->advice_phase.back() > 1, "advice phase must be 0 or 1");
+    }
+    const uint32_t nn = r.u32();
+    invalid((size_t)nn * 48 > r.left, "node table truncated");
+    for (uint32_t i = 0; i < nn; i++) {
+        Node nd;
+        nd.op = r.u32(); nd.a = r.u32(); nd.b = r.u32();
+        r.u32();
+        r.bytes(nd.c.v.data(), 32);
+        invalid(nd.op > N_MUL, "bad node op");
+        if (nd.op == N_CONST) invalid(cmp(nd.c.v, FR.p) >= 0, "non-canonical constant");
+        if (nd.op == N_ADV) invalid(nd.a >= cs->n_advice, "advice column out of range");
+        if (nd.op == N_FIX) invalid(nd.a >= cs->n_fixed, "fixed column out of range");
+        if (nd.op == N_INST) invalid(nd.a >= cs->n_instance, "instance column out of range");
+        if (nd.op == N_CHAL) invalid(nd.a >= cs->n_challenges, "challenge index out of range");
+        if (nd.op >= N_NEG) invalid(nd.a >= i, "child must precede parent");
+        if (nd.op >= N_ADD) invalid(nd.b >= i, "child must precede parent");
+        cs->nodes.push_back(nd);
+    }
+    auto node_list = [&](std::vector<uint32_t>& out) {
+        const uint32_t m = r.u32();
+        invalid((size_t)m * 4 > r.left, "list truncated");
+        for (uint32_t i = 0; i < m; i++) {
+            out.push_back(r.u32());
+            invalid(out.back() >= nn, "node id out of range");
+        }
+    };
+    node_list(cs->gates);
+    const uint32_t np = r.u32();
+    invalid((size_t)np * 8 > r.left, "permutation list truncated");
+    for (uint32_t i = 0; i < np; i++) {
+        uint32_t kind = r.u32(), col = r.u32();
+        invalid(kind < N_ADV || kind > N_INST, "bad permutation column kind");
+        invalid(col >= (kind == N_ADV ? cs->n_advice : kind == N_FIX ? cs->n_fixed : cs->n_instance), "permutation column out of range");
+        cs->perm.emplace_back(kind, col);
+    }
+    const uint32_t nl = r.u32();
+    for (uint32_t i = 0; i < nl; i++) {
+        Lookup l;
+        const uint32_t ni = r.u32();
+        invalid(ni == 0 || (size_t)ni * 4 > r.left, "lookup without inputs");
+        for (uint32_t j = 0; j < ni; j++) {
+            l.inputs.emplace_back();
+            node_list(l.inputs.back());
+            invalid(l.inputs.back().empty(), "empty lookup tuple");
+        }
+        node_list(l.table);
+        for (auto& t : l.inputs) invalid(t.size() != l.table.size(), "lookup arity mismatch");
+        cs->lookups.push_back(std::move(l));
+    }
+    invalid(r.left != 0, "trailing bytes");
+    cs->finalize();
+    return cs;
+}
+
+// ------------------------------------------------------------------ gate programs (GraphEvaluator)
+struct Src {
+    uint32_t kind, idx, rot;
+};
+struct Program {
+    uint32_t k, ext_k;
+    std::vector<uint32_t> code;
+    std::vector<U256> constants;
+    std::vector<int32_t> rotations;
+    uint32_t n_int = 0;
+    Program(uint32_t k_, uint32_t e_) : k(k_), ext_k(e_) {}
+    Src constant(const Fe& c) {
+        for (size_t i = 0; i < constants.size(); i++)
+            if (constants[i] == c.v) return Src{EZKL_SRC_CONST, (uint32_t)i, 0};
+        constants.push_back(c.v);
+        return Src{EZKL_SRC_CONST, (uint32_t)constants.size() - 1, 0};
+    }
+    uint32_t rotation(int32_t r) {
+        for (size_t i = 0; i < rotations.size(); i++)
+            if (rotations[i] == r) return (uint32_t)i;
+        rotations.push_back(r);
+        return (uint32_t)rotations.size() - 1;
+    }
+    Src column(uint32_t idx, int32_t rot = 0) { return Src{EZKL_SRC_COLUMN, idx, rotation(rot)}; }
+    Src challenge(uint32_t idx) const { return Src{EZKL_SRC_CHALLENGE, idx, 0}; }
+    Src previous() const { return Src{EZKL_SRC_PREVIOUS, 0, 0}; }
+    Src calc(uint32_t op, Src s0, Src s1 = Src{EZKL_SRC_CONST, 0, 0}, int64_t target = -1) {
+        const uint32_t t = target < 0 ? n_int++ : (uint32_t)target;
+        const uint32_t w[8] = {op, t, s0.kind, s0.idx, s0.rot, s1.kind, s1.idx, s1.rot};
+        code.insert(code.end(), w, w + 8);
+        return Src{EZKL_SRC_INTERMEDIATE, t, 0};
+    }
+    Src add(Src a, Src b) { return calc(EZKL_OP_ADD, a, b); }
+    Src sub(Src a, Src b) { return calc(EZKL_OP_SUB, a, b); }
+    Src mul(Src a, Src b) { return calc(EZKL_OP_MUL, a, b); }
+    Src horner(Src start, const std::vector<Src>& parts, Src factor) {
+        Src t = calc(EZKL_OP_STORE, start);
+        for (auto& p : parts) calc(EZKL_OP_HORNER_STEP, p, factor, t.idx);
+        return t;
+    }
+    void run(const std::vector<Col>& cols, const std::vector<Fe>& chal, void* out) const {
+        std::vector<const void*> ptrs;
+        for (auto& c : cols) ptrs.push_back(c->ptr());
+        if (ptrs.empty()) ptrs.push_back(nullptr);
+        ezkl_program_t p{};
+        p.code = code.data();
+        p.n_instr = (uint32_t)(code.size() / 8);
+        p.n_intermediates = n_int;
+        p.constants = constants.data();
+        p.n_constants = (uint32_t)constants.size();
+        p.rotations = rotations.data();
+        p.n_rotations = (uint32_t)rotations.size();
+        p.columns = ptrs.data();
+        p.n_columns = (uint32_t)cols.size();
+        p.challenges = chal.data();
+        p.n_challenges = (uint32_t)chal.size();
+        p.k = k;
+        p.ext_k = ext_k;
+        check(ezkl_hip_eval_h_dev(&p, out, nullptr), "ezkl_hip_eval_h_dev");
+    }
+};
+// emit an expression into a program; col_slot(kind, col) -> column slot, chal_src(idx) -> source of user challenge idx
+struct Lowering {
+    const ConstraintSystem& cs;
+    Program& prog;
+    std::function<uint32_t(uint32_t, uint32_t)> col_slot;
+    std::function<Src(uint32_t)> chal_src;
+    std::unordered_map<uint32_t, Src> memo;
+    Src lower(uint32_t id) {
+        auto it = memo.find(id);
+        if (it != memo.end()) return it->second;
+        const Node& nd = cs.nodes[id];
+        Src r;
+        switch (nd.op) {
+        case N_CONST: r = prog.constant(nd.c); break;
+        case N_CHAL: r = chal_src(nd.a); break;
+        case N_ADV: case N_FIX: case N_INST: r = prog.column(col_slot(nd.op, nd.a), (int32_t)nd.b); break;
+        case N_NEG: r = prog.calc(EZKL_OP_NEGATE, lower(nd.a)); break;
+        default: {
+            Src a = lower(nd.a), b = lower(nd.b);
+            r = prog.calc(nd.op == N_ADD ? EZKL_OP_ADD : nd.op == N_SUB ? EZKL_OP_SUB : EZKL_OP_MUL, a, b);
+        } break;
+        }
+        memo[id] = r;
+        return r;
+    }
+    // theta-compression of a tuple of expressions: ((e0*theta + e1)*theta + e2)...  (halo2 compress_expressions)
+    Src compress(const std::vector<uint32_t>& tuple, Src theta) {
+        Src acc = lower(tuple[0]);
+        for (size_t i = 1; i < tuple.size(); i++) {
+            Src m = prog.mul(acc, theta);
+            acc = prog.add(m, lower(tuple[i]));
+        }
+        return acc;
+    }
+};
+
+// ------------------------------------------------------------------ resident-column helpers (each = one or a few C-ABI calls)
+struct Backend {
+    uint32_t k, n;
+    ezkl_bases_t g, gl;
+    Fe one = Fe::one();
+    std::map<U256, std::pair<Col, Col>> zpow;       // kate_div: z^j and z^-(j+1) columns per opening point
+    Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_) : k(k_), n(n_), g(g_), gl(gl_) {}
+
+    Col alloc(size_t m) const { return std::make_shared<DeviceColumn>(m); }
+    Col upload(const void* host, size_t m) const {
+        Col c = alloc(m);
+        check(ezkl_hip_memcpy_h2d(c->ptr(), host, m * 32), "ezkl_hip_memcpy_h2d");
+        return c;
+    }
+    Col upload(const std::vector<U256>& v) const { return upload(v.data(), v.size()); }
+    std::vector<U256> download(const Col& c, size_t m) const {
+        std::vector<U256> v(m);
+        check(ezkl_hip_memcpy_d2h(v.data(), c->ptr(), m * 32), "ezkl_hip_memcpy_d2h");
+        return v;
+    }
+    static void* at(const Col& c, size_t off) { return (uint8_t*)c->ptr() + 32 * off; }
+    void scale_into(const void* src, const Fe& s, void* dst, size_t m) const { check(ezkl_hip_vec_scale_dev(src, s.v.data(), dst, m, nullptr), "ezkl_hip_vec_scale_dev"); }
+    void vec(int op, const void* a, const void* b, void* o, size_t m) const { check(ezkl_hip_vec_op_dev(op, a, b, o, m, nullptr), "ezkl_hip_vec_op_dev"); }
+    void fill(void* dst, const Fe& v, size_t m) const { check(ezkl_hip_vec_fill_dev(dst, v.v.data(), m, nullptr), "ezkl_hip_vec_fill_dev"); }
+    void scan(int op, bool exclusive, const void* in, void* out, size_t m) const { check(ezkl_hip_prefix_scan_dev(op, exclusive ? 1 : 0, in, out, m, nullptr), "ezkl_hip_prefix_scan_dev"); }
+    void invert(void* a, size_t m) const { check(ezkl_hip_batch_invert_dev(a, m, nullptr), "ezkl_hip_batch_invert_dev"); }
+    Col clone(const Col& h) const {
+        Col o = alloc(h->len());
+        scale_into(h->ptr(), one, o->ptr(), h->len());
+        return o;
+    }
+    Col zeros(size_t m) const {
+        Col o = alloc(m);
+        fill(o->ptr(), Fe::zero(), m);
+        return o;
+    }
+    std::vector<G1> commit_with(ezkl_bases_t b, const std::vector<Col>& hs) const {
+        std::vector<G1> out(hs.size());
+        if (hs.empty()) return out;
+        std::vector<const void*> ptrs;
+        for (auto& h : hs) ptrs.push_back(h->ptr());
+        check(ezkl_hip_msm_g1_batch_dev(b, 0, ptrs.data(), ptrs.size(), n, out.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+        return out;
+    }
+    std::vector<G1> commit_lagrange(const std::vector<Col>& hs) const { return commit_with(gl, hs); }
+    std::vector<G1> commit(const std::vector<Col>& hs) const { return commit_with(g, hs); }
+    Col lagrange_to_coeff(const Col& h) const {
+        Col o = clone(h);
+        const Fe winv = omega(k).inv();
+        check(ezkl_hip_ntt_dev(o->ptr(), k, winv.v.data(), 1, 1, n, nullptr), "ezkl_hip_ntt_dev");
+        return o;
+    }
+    Col coeff_to_extended(const Col& h, uint32_t ext_k) const {
+        Col o = alloc((size_t)1 << ext_k);
+        check(ezkl_hip_coset_ntt_dev(h->ptr(), o->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, 0, nullptr), "ezkl_hip_coset_ntt_dev");
+        return o;
+    }
+    void extended_to_coeff(const Col& h, uint32_t ext_k) const {
+        check(ezkl_hip_coset_ntt_dev(h->ptr(), h->ptr(), 1, (size_t)1 << ext_k, (size_t)1 << ext_k, k, ext_k, 1, nullptr), "ezkl_hip_coset_ntt_dev");
+    }
+    void divide_by_vanishing(const Col& h, uint32_t ext_k) const { check(ezkl_hip_divide_by_vanishing_dev(h->ptr(), k, ext_k, nullptr), "ezkl_hip_divide_by_vanishing_dev"); }
+    Fe eval_poly(const Col& h, size_t m, const Fe& x) const {
+        Fe out;
+        check(ezkl_hip_eval_poly_dev(h->ptr(), m, x.v.data(), out.v.data(), nullptr), "ezkl_hip_eval_poly_dev");
+        return out;
+    }
+    Col slice_copy(const Col& h, size_t off, size_t m) const {
+        Col o = alloc(m);
+        scale_into(at(h, off), one, o->ptr(), m);
+        return o;
+    }
+    void axpy(const Col& acc, const Fe& s, const Col& h, size_t m) const {       // acc += s * h
+        Col t = alloc(m);
+        scale_into(h->ptr(), s, t->ptr(), m);
+        vec(EZKL_VEC_ADD, acc->ptr(), t->ptr(), acc->ptr(), m);
+    }
+    void sub_low(const Col& h, const std::vector<Fe>& coeffs) const {           // h[i] -= coeffs[i] for the lowest coefficients
+        std::vector<U256> v;
+        for (auto& c : coeffs) v.push_back(c.v);
+        Col t = upload(v);
+        vec(EZKL_VEC_SUB, h->ptr(), t->ptr(), h->ptr(), v.size());
+    }
+    void scale(const Col& h, const Fe& s, size_t m) const { scale_into(h->ptr(), s, h->ptr(), m); }
+    void set_rows(const Col& h, size_t start, const std::vector<U256>& rows) const {
+        if (!rows.empty()) check(ezkl_hip_memcpy_h2d(at(h, start), rows.data(), rows.size() * 32), "ezkl_hip_memcpy_h2d");
+    }
+    Fe get_row(const Col& h, size_t i) const {
+        Fe out;
+        check(ezkl_hip_memcpy_d2h(out.v.data(), at(h, i), 32), "ezkl_hip_memcpy_d2h");
+        return out;
+    }
+    Col omega_powers() const {                                                    // X[i] = omega^i
+        Col c = alloc(n);
+        fill(c->ptr(), omega(k), n);
+        scan(EZKL_VEC_MUL, true, c->ptr(), c->ptr(), n);
+        return c;
+    }
+    // z[0] = z0 (1), z[i+1] = z[i] * prod_j (v_j[i] + beta*delta^(j0+j)*omega^i + gamma) / (v_j[i] + beta*sigma_j[i] + gamma)
+    // for one chunk of permutation columns (permutation::prover::commit)
+    Col permutation_product(const std::vector<Col>& values, const std::vector<Col>& sigmas, const Fe& beta, const Fe& gamma, uint32_t first_index,
+                            const Fe* z0, const Col& omega_col) const {
+        const uint32_t m = (uint32_t)values.size();
+        std::vector<Col> cols(values);
+        cols.insert(cols.end(), sigmas.begin(), sigmas.end());
+        cols.push_back(omega_col);
+        std::vector<Fe> chal = {beta, gamma};
+        const Fe delta{FR_DELTA};
+        Fe dp = delta.pow(first_index);
+        for (uint32_t j = 0; j < m; j++) { chal.push_back(beta * dp); dp = dp * delta; }
+        Program den(k, k), num(k, k);
+        Src acc{}, accn{};
+        for (uint32_t j = 0; j < m; j++) {
+            Src t = den.add(den.add(den.mul(den.challenge(0), den.column(m + j)), den.challenge(1)), den.column(j));
+            acc = j == 0 ? t : den.mul(acc, t);
+            Src tn = num.add(num.add(num.mul(num.challenge(2 + j), num.column(2 * m)), num.challenge(1)), num.column(j));
+            accn = j == 0 ? tn : num.mul(accn, tn);
+        }
+        Col d_den = alloc(n), d_num = alloc(n);
+        den.run(cols, chal, d_den->ptr());
+        num.run(cols, chal, d_num->ptr());
+        invert(d_den->ptr(), n);
+        vec(EZKL_VEC_MUL, d_num->ptr(), d_den->ptr(), d_num->ptr(), n);
+        scan(EZKL_VEC_MUL, true, d_num->ptr(), d_num->ptr(), n);
+        if (z0) scale(d_num, *z0, n);
+        return d_num;
+    }
+    // phi[0] = 0, phi[i+1] = phi[i] + sum_j 1/(f_j[i] + beta) - m[i]/(t[i] + beta)   (mv_lookup::prover::commit_grand_sum)
+    Col lookup_grand_sum(const std::vector<Col>& inputs, const Col& table, const Col& m, const Fe& beta) const {
+        Col acc = zeros(n), tmp = alloc(n);
+        Program shift(k, k);
+        shift.add(shift.column(0), shift.challenge(0));
+        for (auto& in : inputs) {
+            shift.run({in}, {beta}, tmp->ptr());
+            invert(tmp->ptr(), n);
+            vec(EZKL_VEC_ADD, acc->ptr(), tmp->ptr(), acc->ptr(), n);
+        }
+        shift.run({table}, {beta}, tmp->ptr());
+        invert(tmp->ptr(), n);
+        vec(EZKL_VEC_MUL, tmp->ptr(), m->ptr(), tmp->ptr(), n);
+        vec(EZKL_VEC_SUB, acc->ptr(), tmp->ptr(), acc->ptr(), n);
+        scan(EZKL_VEC_ADD, true, acc->ptr(), acc->ptr(), n);
+        return acc;
+    }
+    Col lookup_multiplicity(const std::vector<Col>& inputs, const Col& table, uint32_t usable) const {
+        Col out = alloc(n);
+        std::vector<const void*> ptrs;
+        for (auto& c : inputs) ptrs.push_back(c->ptr());
+        uint32_t missing = 0;
+        check(ezkl_hip_lookup_multiplicity_dev(ptrs.data(), (uint32_t)ptrs.size(), table->ptr(), n, usable, out->ptr(), &missing, nullptr), "ezkl_hip_lookup_multiplicity_dev");
+        return out;
+    }
+    // q(X) = p(X) / (X - z) for p(z) = 0, in place: q_i = z^-(i+1) * sum_{j>i} p_j z^j, via scans
+    void kate_div(const Col& h, const Fe& z, size_t m) {
+        const U256 key = z.canonical();
+        auto it = zpow.find(key);
+        if (it == zpow.end()) {
+            if (zpow.size() > 8) zpow.clear();
+            Col zp = alloc(m), zi = alloc(m);
+            fill(zp->ptr(), z, m);
+            scan(EZKL_VEC_MUL, true, zp->ptr(), zp->ptr(), m);
+            fill(zi->ptr(), z.inv(), m);
+            scan(EZKL_VEC_MUL, false, zi->ptr(), zi->ptr(), m);
+            it = zpow.emplace(key, std::make_pair(zp, zi)).first;
+        }
+        vec(EZKL_VEC_MUL, h->ptr(), it->second.first->ptr(), h->ptr(), m);         // w_j = p_j z^j
+        scan(EZKL_VEC_ADD, false, h->ptr(), h->ptr(), m);                          // P_i = sum_{j<=i} w_j ; P_{n-1} = p(z) = 0
+        scale(h, -Fe::one(), m);                                                   // -P_i = sum_{j>i} w_j
+        vec(EZKL_VEC_MUL, h->ptr(), it->second.second->ptr(), h->ptr(), m);
+    }
+};
+
+// ------------------------------------------------------------------ keys
+struct ProvingKey {
+    ConstraintSystem* cs = nullptr;
+    std::vector<Col> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
+    Col omega_col, l0, l_last, l_active, x_coset;
+    std::vector<G1> fixed_commitments, sigma_commitments;
+    Fe digest;
+};
+static Fe vk_digest(const ProvingKey& pk) {
+    const ConstraintSystem& cs = *pk.cs;
+    std::vector<uint8_t> t = {(uint8_t)cs.k, (uint8_t)cs.n_advice, (uint8_t)cs.n_fixed, (uint8_t)cs.degree, (uint8_t)cs.perm.size(),
+                              (uint8_t)cs.n_instance, (uint8_t)cs.n_challenges, (uint8_t)cs.lookups.size()};
+    for (uint32_t p : cs.advice_phase) t.push_back((uint8_t)p);
+    auto put = [&](const G1& p) {
+        U256 x, y;
+        p.canonical(x, y);
+        uint8_t b[64];
+        to_be32(x, b);
+        to_be32(y, b + 32);
+        t.insert(t.end(), b, b + 64);
+    };
+    for (auto& p : pk.fixed_commitments) put(p);
+    for (auto& p : pk.sigma_commitments) put(p);
+    auto h = keccak256(t.data(), t.size());
+    return Fe::from_canonical(reduce_fr(from_be32(h.data())));
+}
+static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies) {
+    // the vk digest packs these counts into single bytes (as the Python restatement does)
+    invalid(cs.n_advice > 255 || cs.n_fixed > 255 || cs.perm.size() > 255 || cs.n_instance > 255 || cs.n_challenges > 255 || cs.lookups.size() > 255 || cs.degree > 255,
+            "column / argument counts above 255 are not supported by the vk digest");
+    const uint32_t n = cs.n, k = cs.k;
+    Backend be(k, n, g, nullptr);
+    auto pk = std::make_unique<ProvingKey>();
+    pk->cs = &cs;
+    for (uint32_t c = 0; c < cs.n_fixed; c++) {
+        pk->fixed_values.push_back(be.upload(fixed_values[c], n));
+        pk->fixed_polys.push_back(be.lagrange_to_coeff(pk->fixed_values.back()));
+        pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
+    }
+    // permutation: cycle structure over (colpos, row) cells numbered c * n + r; `nxt` is the cycle successor, `root` a
+    // cycle label, `size` the cycle length (halo2 permutation::keygen::Assembly::copy)
+    const size_t m = cs.perm.size(), cells = m * n;
+    std::vector<uint32_t> nxt(cells), root(cells), size(cells, 1);
+    for (size_t i = 0; i < cells; i++) nxt[i] = root[i] = (uint32_t)i;
+    for (size_t i = 0; i < n_copies; i++) {
+        const uint32_t* cp = copies + 4 * i;
+        invalid(cp[0] >= m || cp[2] >= m || cp[1] >= n || cp[3] >= n, "copy constraint out of range");
+        uint32_t a = cp[0] * n + cp[1], b = cp[2] * n + cp[3];
+        if (root[a] == root[b]) continue;
+        if (size[root[a]] < size[root[b]]) std::swap(a, b);
+        const uint32_t ra = root[a], rb = root[b];
+        size[ra] += size[rb];
+        uint32_t cur = b;
+        do {                                     // relabel the smaller cycle
+            root[cur] = ra;
+            cur = nxt[cur];
+        } while (cur != b);
+        std::swap(nxt[a], nxt[b]);
+    }
+    // sigma[c][r] = delta^c' * omega^r' for (c', r') = nxt[(c, r)]: gather from the m columns delta^c * omega^row
+    pk->omega_col = be.omega_powers();
+    const std::vector<U256> wcol = be.download(pk->omega_col, n);
+    std::vector<std::vector<U256>> dcols(m);
+    const Fe delta{FR_DELTA};
+    Fe dp = Fe::one();
+    for (size_t c = 0; c < m; c++) {
+        Col h = be.upload(wcol);
+        be.scale(h, dp, n);
+        dcols[c] = be.download(h, n);
+        dp = dp * delta;
+    }
+    for (size_t c = 0; c < m; c++) {
+        std::vector<U256> sig(n);
+        for (uint32_t r = 0; r < n; r++) {
+            const uint32_t t = nxt[c * n + r];
+            sig[r] = dcols[t / n][t % n];
+        }
+        pk->sigma_values.push_back(be.upload(sig));
+        pk->sigma_polys.push_back(be.lagrange_to_coeff(pk->sigma_values.back()));
+        pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+    }
+    // l0, l_last, l_active_row on the extended coset
+    auto lag = [&](uint32_t lo, uint32_t hi) {
+        std::vector<U256> v(n, U256{0, 0, 0, 0});
+        for (uint32_t r = lo; r < hi; r++) v[r] = FR.one;
+        return be.coeff_to_extended(be.lagrange_to_coeff(be.upload(v)), cs.ext_k);
+    };
+    pk->l0 = lag(0, 1);
+    pk->l_last = lag(cs.usable, cs.usable + 1);
+    pk->l_active = lag(0, cs.usable);
+    // the identity column X on the extended coset (from coefficients [0, 1, 0, ...])
+    std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
+    xcoef[1] = FR.one;
+    pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
+    pk->fixed_commitments = be.commit(pk->fixed_polys);
+    pk->sigma_commitments = be.commit(pk->sigma_polys);
+    pk->digest = vk_digest(*pk);
+    return pk;
+}
+
+// ------------------------------------------------------------------ randomness
+struct Xoshiro {
+    uint64_t s[4];
+    explicit Xoshiro(uint64_t seed) {
+        if (seed == 0) {
+            std::random_device rd;
+            seed = ((uint64_t)rd() << 32) ^ rd() ^ ((uint64_t)rd() << 17);
+        }
+        for (auto& w : s) {                      // splitmix64 expansion
+            seed += 0x9e3779b97f4a7c15ull;
+            uint64_t z = seed;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            w = z ^ (z >> 31);
+        }
+    }
+    uint64_t next() {
+        const uint64_t r = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl64(s[3], 45);
+        return r;
+    }
+};
+struct Rng {
+    ezkl_rng_fn fn;
+    void* user;
+    Xoshiro x;
+    std::vector<U256> vec(size_t m) {
+        std::vector<U256> out(m);
+        if (m == 0) return out;
+        if (fn) {
+            fn(user, out.data(), m);
+            for (auto& e : out) invalid(cmp(e, FR.p) >= 0, "rng callback returned a non-canonical residue");
+        } else {
+            for (auto& e : out) {
+                for (auto& l : e) l = x.next();
+                e[3] &= (1ull << 61) - 1;        // 253 uniform bits < r, read as Montgomery residues
+            }
+        }
+        return out;
+    }
+};
+
+// ------------------------------------------------------------------ SHPLONK (BDFG20) multi-point opening
+struct OpenQuery {
+    std::vector<uint32_t> key;       // polynomial identity (kind, index)
+    Col poly;
+    Fe point, eval;
+};
+struct PolyEvals {
+    Col poly;
+    std::map<U256, std::pair<Fe, Fe>> ev;      // canonical point -> (point, eval)
+};
+static bool u256_less(const U256& a, const U256& b) { return cmp(a, b) < 0; }
+// coefficients (low first) of the polynomial of degree < len(points) through (points, values)
+static std::vector<Fe> interpolate(const std::vector<Fe>& pts, const std::vector<Fe>& vals) {
+    const size_t m = pts.size();
+    std::vector<Fe> coeffs(m, Fe::zero());
+    for (size_t i = 0; i < m; i++) {
+        std::vector<Fe> num = {Fe::one()};
+        Fe den = Fe::one();
+        for (size_t j = 0; j < m; j++) {
+            if (j == i) continue;
+            std::vector<Fe> nn(num.size() + 1, Fe::zero());
+            for (size_t t = 0; t < num.size(); t++) {            // num * (X - pts[j])
+                nn[t + 1] = nn[t + 1] + num[t];
+                nn[t] = nn[t] - pts[j] * num[t];
+            }
+            num = nn;
+            den = den * (pts[i] - pts[j]);
+        }
+        const Fe s = vals[i] * den.inv();
+        for (size_t t = 0; t < num.size(); t++) coeffs[t] = coeffs[t] + s * num[t];
+    }
+    return coeffs;
+}
+static Fe eval_small(const std::vector<Fe>& c, const Fe& x) {
+    Fe acc = Fe::zero();
+    for (size_t i = c.size(); i-- > 0;) acc = acc * x + c[i];
+    return acc;
+}
+static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQuery>& qs, uint32_t n) {
+    // group queries by polynomial (first appearance), then polynomials by their point set (first appearance)
+    std::vector<PolyEvals> polys;
+    std::map<std::vector<uint32_t>, size_t> by_key;
+    for (auto& q : qs) {
+        auto it = by_key.find(q.key);
+        if (it == by_key.end()) {
+            it = by_key.emplace(q.key, polys.size()).first;
+            polys.push_back(PolyEvals{q.poly, {}});
+        }
+        polys[it->second].ev[q.point.canonical()] = {q.point, q.eval};
+    }
+    struct Group {
+        std::vector<U256> pts;                 // sorted canonical points
+        std::vector<Fe> pts_fe;
+        std::vector<size_t> members;
+    };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < polys.size(); i++) {
+        std::vector<U256> pts;
+        for (auto& e : polys[i].ev) pts.push_back(e.first);      // std::map<U256>: lexicographic on LE limbs, re-sort numerically
+        std::sort(pts.begin(), pts.end(), u256_less);
+        size_t gi = 0;
+        for (; gi < groups.size(); gi++)
+            if (groups[gi].pts == pts) break;
+        if (gi == groups.size()) {
+            Group gnew;
+            gnew.pts = pts;
+            for (auto& p : pts) gnew.pts_fe.push_back(polys[i].ev[p].first);
+            groups.push_back(gnew);
+        }
+        groups[gi].members.push_back(i);
+    }
+    const Fe ys = T.squeeze_challenge();
+    std::vector<U256> all_pts;
+    for (auto& gr : groups)
+        for (auto& p : gr.pts) all_pts.push_back(p);
+    std::sort(all_pts.begin(), all_pts.end(), u256_less);
+    all_pts.erase(std::unique(all_pts.begin(), all_pts.end()), all_pts.end());
+    std::map<U256, Fe> pt_fe;
+    for (auto& gr : groups)
+        for (size_t i = 0; i < gr.pts.size(); i++) pt_fe[gr.pts[i]] = gr.pts_fe[i];
+    struct Combo {
+        Col q;
+        std::vector<Fe> r;
+    };
+    std::vector<Combo> combos;
+    for (auto& gr : groups) {
+        Col q = be.zeros(n);
+        std::vector<Fe> evs(gr.pts.size(), Fe::zero());
+        Fe pw = Fe::one();
+        for (size_t mi : gr.members) {
+            be.axpy(q, pw, polys[mi].poly, n);
+            for (size_t i = 0; i < gr.pts.size(); i++) evs[i] = evs[i] + pw * polys[mi].ev[gr.pts[i]].second;
+            pw = pw * ys;
+        }
+        combos.push_back(Combo{q, interpolate(gr.pts_fe, evs)});
+    }
+    const Fe v = T.squeeze_challenge();
+    Col h = be.zeros(n);
+    Fe pw = Fe::one();
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        Col t = be.clone(combos[gi].q);
+        be.sub_low(t, combos[gi].r);
+        for (auto& z : groups[gi].pts_fe) be.kate_div(t, z, n);
+        be.axpy(h, pw, t, n);
+        pw = pw * v;
+    }
+    T.write_point(be.commit({h})[0]);
+    const Fe u = T.squeeze_challenge();
+    Fe zt_u = Fe::one();
+    for (auto& z : all_pts) zt_u = zt_u * (u - pt_fe[z]);
+    Col L = be.zeros(n);
+    pw = Fe::one();
+    Fe const_term = Fe::zero();
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        Fe zdiff = Fe::one();
+        for (auto& z : all_pts)
+            if (!std::binary_search(groups[gi].pts.begin(), groups[gi].pts.end(), z, u256_less)) zdiff = zdiff * (u - pt_fe[z]);
+        be.axpy(L, pw * zdiff, combos[gi].q, n);
+        const_term = const_term + pw * zdiff * eval_small(combos[gi].r, u);
+        pw = pw * v;
+    }
+    be.sub_low(L, {const_term});
+    be.axpy(L, -zt_u, h, n);
+    be.kate_div(L, u, n);
+    T.write_point(be.commit({L})[0]);
+}
+
+// ------------------------------------------------------------------ the numerator of h(X)
+struct Quotient {
+    Program prog;
+    std::vector<Col> cols;
+    std::vector<Fe> chal;
+};
+// ONE straight-line program over the extended-coset columns: custom gates, then the permutation and lookup
+// constraints, folded with y (value = value*y + constraint), as Evaluator::evaluate_h does
+static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& pk, const std::vector<Col>& adv_cosets, const std::vector<Col>& z_cosets,
+                                 const Fe& beta, const Fe& gamma, const Fe& y, const Fe& theta, const std::vector<Col>& m_cosets,
+                                 const std::vector<Col>& phi_cosets, const std::vector<Col>& inst_cosets, const std::vector<Fe>& user_chal) {
+    Quotient Q{Program(cs.k, cs.ext_k), {}, {y, beta, gamma}};
+    Program& prog = Q.prog;
+    Q.chal.insert(Q.chal.end(), user_chal.begin(), user_chal.end());
+    std::map<std::vector<uint32_t>, uint32_t> index;
+    auto slot = [&](std::vector<uint32_t> name, const Col& h) {
+        auto it = index.find(name);
+        if (it != index.end()) return it->second;
+        index[name] = (uint32_t)Q.cols.size();
+        Q.cols.push_back(h);
+        return (uint32_t)Q.cols.size() - 1;
+    };
+    enum : uint32_t { S_L0 = 100, S_LLAST, S_LACT, S_X, S_Z, S_SIGMA, S_PHI, S_M };
+    Lowering low{cs, prog,
+                 [&](uint32_t kind, uint32_t c) { return slot({kind, c}, kind == N_ADV ? adv_cosets[c] : kind == N_INST ? inst_cosets[c] : pk.fixed_cosets[c]); },
+                 [&](uint32_t idx) { return prog.challenge(3 + idx); },
+                 {}};
+    const Src Y = prog.challenge(0), BETA = prog.challenge(1), GAMMA = prog.challenge(2);
+    std::vector<Src> terms;
+    for (uint32_t g : cs.gates) terms.push_back(low.lower(g));
+    if (!cs.perm.empty()) {
+        const Src l0 = prog.column(slot({S_L0}, pk.l0)), llast = prog.column(slot({S_LLAST}, pk.l_last)), lact = prog.column(slot({S_LACT}, pk.l_active));
+        const Src X = prog.column(slot({S_X}, pk.x_coset));
+        const Src one = prog.constant(Fe::one());
+        const uint32_t nz = (uint32_t)z_cosets.size();
+        std::vector<uint32_t> zc;
+        for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j]));
+        terms.push_back(prog.mul(l0, prog.sub(one, prog.column(zc[0]))));
+        const Src zl = prog.column(zc[nz - 1]);
+        terms.push_back(prog.mul(llast, prog.sub(prog.calc(EZKL_OP_SQUARE, zl), zl)));
+        for (uint32_t j = 1; j < nz; j++) terms.push_back(prog.mul(l0, prog.sub(prog.column(zc[j]), prog.column(zc[j - 1], (int32_t)cs.usable))));
+        uint32_t pos = 0;
+        const Fe delta{FR_DELTA};
+        uint32_t j = 0;
+        for (auto& chunk : cs.perm_chunks()) {
+            Src left = prog.column(zc[j], 1), right = prog.column(zc[j]);
+            for (uint32_t i = 0; i < chunk.size(); i++) {
+                const Src vv = prog.column(low.col_slot(chunk[i].first, chunk[i].second));
+                const Src sg = prog.column(slot({S_SIGMA, pos + i}, pk.sigma_cosets[pos + i]));
+                left = prog.mul(left, prog.add(prog.add(vv, prog.mul(BETA, sg)), GAMMA));
+                Q.chal.push_back(beta * delta.pow(pos + i));
+                const Src bd = prog.challenge((uint32_t)Q.chal.size() - 1);
+                right = prog.mul(right, prog.add(prog.add(vv, prog.mul(bd, X)), GAMMA));
+            }
+            terms.push_back(prog.mul(lact, prog.sub(left, right)));
+            pos += (uint32_t)chunk.size();
+            j++;
+        }
+    }
+    if (!cs.lookups.empty()) {
+        const Src l0 = prog.column(slot({S_L0}, pk.l0)), llast = prog.column(slot({S_LLAST}, pk.l_last)), lact = prog.column(slot({S_LACT}, pk.l_active));
+        Q.chal.push_back(theta);
+        const Src THETA = prog.challenge((uint32_t)Q.chal.size() - 1);
+        for (uint32_t i = 0; i < cs.lookups.size(); i++) {
+            const Lookup& lk = cs.lookups[i];
+            const uint32_t phi_s = slot({S_PHI, i}, phi_cosets[i]), m_s = slot({S_M, i}, m_cosets[i]);
+            const Src phi = prog.column(phi_s), phi_next = prog.column(phi_s, 1), mcol = prog.column(m_s);
+            std::vector<Src> fb;
+            for (auto& t : lk.inputs) fb.push_back(prog.add(low.compress(t, THETA), BETA));
+            const Src tb = prog.add(low.compress(lk.table, THETA), BETA);
+            Src prodf = fb[0];
+            for (size_t f = 1; f < fb.size(); f++) prodf = prog.mul(prodf, fb[f]);
+            Src ssum{};                                       // sum_j prod_{i != j} (f_i + beta)
+            for (size_t jj = 0; jj < fb.size(); jj++) {
+                bool have = false;
+                Src pj{};
+                for (size_t i2 = 0; i2 < fb.size(); i2++) {
+                    if (i2 == jj) continue;
+                    pj = have ? prog.mul(pj, fb[i2]) : fb[i2];
+                    have = true;
+                }
+                if (!have) pj = prog.constant(Fe::one());
+                ssum = jj == 0 ? pj : prog.add(ssum, pj);
+            }
+            const Src lhs = prog.mul(prog.mul(prog.sub(phi_next, phi), prodf), tb);
+            const Src rhs = prog.sub(prog.mul(ssum, tb), prog.mul(mcol, prodf));
+            terms.push_back(prog.mul(l0, phi));
+            terms.push_back(prog.mul(llast, phi));
+            terms.push_back(prog.mul(lact, prog.sub(lhs, rhs)));
+        }
+    }
+    prog.horner(prog.previous(), terms, Y);
+    return Q;
+}
+// the theta-compressed lookup column over the n rows of the Lagrange domain (a gate program with ext_k = k)
+static Col compress_column(const ConstraintSystem& cs, const Backend& be, const std::vector<uint32_t>& tuple, const Fe& theta,
+                           const std::function<Col(uint32_t, uint32_t)>& col_handle, const std::vector<Fe>& user_chal) {
+    Program prog(cs.k, cs.k);
+    std::vector<Col> cols;
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> index;
+    Lowering low{cs, prog,
+                 [&](uint32_t kind, uint32_t c) {
+                     auto key = std::make_pair(kind, c);
+                     auto it = index.find(key);
+                     if (it != index.end()) return it->second;
+                     index[key] = (uint32_t)cols.size();
+                     cols.push_back(col_handle(kind, c));
+                     return (uint32_t)cols.size() - 1;
+                 },
+                 [&](uint32_t idx) { return prog.challenge(1 + idx); },
+                 {}};
+    Src r = low.compress(tuple, prog.challenge(0));
+    if (r.kind != EZKL_SRC_INTERMEDIATE) prog.calc(EZKL_OP_STORE, r);        // a bare column / constant: materialise it
+    Col out = be.zeros(cs.n);
+    std::vector<Fe> chal = {theta};
+    chal.insert(chal.end(), user_chal.begin(), user_chal.end());
+    prog.run(cols, chal, out->ptr());
+    return out;
+}
+
+// ------------------------------------------------------------------ create_proof
+struct Stopwatch {
+    double* out;
+    std::chrono::steady_clock::time_point t0, start;
+    explicit Stopwatch(double* o) : out(o), t0(std::chrono::steady_clock::now()), start(t0) {
+        if (out) std::fill(out, out + 12, 0.0);
+    }
+    void lap(int i) {
+        auto now = std::chrono::steady_clock::now();
+        if (out) out[i] += std::chrono::duration<double>(now - t0).count();
+        t0 = now;
+    }
+    void total() {
+        if (out) out[10] = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    }
+};
+static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_bases_t gl, const void* const* advice, ezkl_advice_fn advice_fn, void* advice_user,
+                                         const void* const* instances, const uint32_t* instance_lens, Rng& rng, double* timings) {
+    ConstraintSystem& cs = *pk.cs;
+    const uint32_t n = cs.n, k = cs.k, u = cs.usable;
+    Backend be(k, n, g, gl);
+    Stopwatch sw(timings);
+    EvmTranscript T;
+    T.common_scalar(pk.digest);
+    // 0. instances: absorbed, never committed (halo2 KZG: QUERY_INSTANCE = false)
+    std::vector<Col> inst_cols;
+    for (uint32_t i = 0; i < cs.n_instance; i++) {
+        invalid(instance_lens[i] > u, "too many instance values");
+        std::vector<U256> col(n, U256{0, 0, 0, 0});
+        for (uint32_t j = 0; j < instance_lens[i]; j++) {
+            std::memcpy(col[j].data(), (const uint8_t*)instances[i] + 32 * j, 32);
+            invalid(cmp(col[j], FR.p) >= 0, "non-canonical instance value");
+            T.common_scalar(Fe{col[j]});
+        }
+        inst_cols.push_back(be.upload(col));
+    }
+    // 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges
+    std::vector<Col> adv_cols(cs.n_advice);
+    std::vector<Fe> user_chal;
+    for (uint32_t phase = 0; phase < 2; phase++) {
+        std::vector<uint32_t> idxs;
+        for (uint32_t c = 0; c < cs.n_advice; c++)
+            if (cs.advice_phase[c] == phase) idxs.push_back(c);
+        if (idxs.empty()) continue;
+        std::vector<std::vector<U256>> host;
+        std::vector<const void*> src(cs.n_advice, nullptr);
+        if (advice_fn) {
+            host.resize(cs.n_advice);
+            std::vector<void*> dst(cs.n_advice, nullptr);
+            for (uint32_t c : idxs) {
+                host[c].assign(n, U256{0, 0, 0, 0});
+                dst[c] = host[c].data();
+            }
+            std::vector<U256> ch;
+            for (auto& f : user_chal) ch.push_back(f.v);
+            invalid(advice_fn(advice_user, phase, ch.data(), (uint32_t)ch.size(), dst.data()) != 0, "advice callback failed");
+            for (uint32_t c : idxs) src[c] = host[c].data();
+        } else {
+            invalid(advice == nullptr, "no advice columns");
+            for (uint32_t c : idxs) src[c] = advice[c];
+        }
+        std::vector<Col> batch;
+        for (uint32_t c : idxs) {
+            invalid(src[c] == nullptr, "missing advice column");
+            adv_cols[c] = be.upload(src[c], n);                 // witness column -> HBM, then blind rows [u, n) in place
+            be.set_rows(adv_cols[c], u, rng.vec(n - u));
+            batch.push_back(adv_cols[c]);
+        }
+        for (auto& p : be.commit_lagrange(batch)) T.write_point(p);
+        if (phase == 0)
+            for (uint32_t i = 0; i < cs.n_challenges; i++) user_chal.push_back(T.squeeze_challenge());
+    }
+    sw.lap(0);
+    auto col_handle = [&](uint32_t kind, uint32_t c) -> Col { return kind == N_ADV ? adv_cols[c] : kind == N_INST ? inst_cols[c] : pk.fixed_values[c]; };
+    // 2. theta; mv-lookup multiplicities m(X)
+    Fe theta = Fe::zero();
+    struct LookupState {
+        std::vector<Col> inputs;
+        Col table, m, phi;
+    };
+    std::vector<LookupState> lk;
+    if (!cs.lookups.empty()) {
+        theta = T.squeeze_challenge();
+        for (auto& l : cs.lookups) {
+            LookupState st;
+            for (auto& t : l.inputs) st.inputs.push_back(compress_column(cs, be, t, theta, col_handle, user_chal));
+            st.table = compress_column(cs, be, l.table, theta, col_handle, user_chal);
+            st.m = be.lookup_multiplicity(st.inputs, st.table, u);
+            be.set_rows(st.m, u, rng.vec(n - u));
+            lk.push_back(st);
+        }
+        std::vector<Col> ms;
+        for (auto& st : lk) ms.push_back(st.m);
+        for (auto& p : be.commit_lagrange(ms)) T.write_point(p);
+    }
+    sw.lap(1);
+    // 3. beta, gamma
+    const Fe beta = T.squeeze_challenge(), gamma = T.squeeze_challenge();
+    // 4. permutation grand products, chained across chunks
+    std::vector<Col> zs;
+    {
+        bool have_last = false;
+        Fe last;
+        uint32_t pos = 0;
+        for (auto& chunk : cs.perm_chunks()) {
+            std::vector<Col> vals, sigs;
+            for (auto& pc : chunk) vals.push_back(col_handle(pc.first, pc.second));
+            for (size_t i = 0; i < chunk.size(); i++) sigs.push_back(pk.sigma_values[pos + i]);
+            Col z = be.permutation_product(vals, sigs, beta, gamma, pos, have_last ? &last : nullptr, pk.omega_col);
+            last = be.get_row(z, u);
+            have_last = true;
+            be.set_rows(z, u + 1, rng.vec(n - u - 1));
+            zs.push_back(z);
+            pos += (uint32_t)chunk.size();
+        }
+        for (auto& p : be.commit_lagrange(zs)) T.write_point(p);
+    }
+    sw.lap(2);
+    // 4b. mv-lookup running sums phi(X)
+    {
+        std::vector<Col> phis;
+        for (auto& st : lk) {
+            st.phi = be.lookup_grand_sum(st.inputs, st.table, st.m, beta);
+            be.set_rows(st.phi, u + 1, rng.vec(n - u - 1));
+            phis.push_back(st.phi);
+        }
+        for (auto& p : be.commit_lagrange(phis)) T.write_point(p);
+    }
+    sw.lap(3);
+    // 5. vanishing argument: random polynomial;  6. y
+    Col rnd = be.upload(rng.vec(n));
+    T.write_point(be.commit({rnd})[0]);
+    const Fe y = T.squeeze_challenge();
+    sw.lap(4);
+    // 7. quotient
+    std::vector<Col> adv_polys, inst_cosets, z_polys, adv_cosets, z_cosets, m_polys, phi_polys, m_cosets, phi_cosets;
+    for (auto& h : adv_cols) adv_polys.push_back(be.lagrange_to_coeff(h));
+    for (auto& h : inst_cols) inst_cosets.push_back(be.coeff_to_extended(be.lagrange_to_coeff(h), cs.ext_k));
+    for (auto& h : zs) z_polys.push_back(be.lagrange_to_coeff(h));
+    for (auto& h : adv_polys) adv_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
+    for (auto& h : z_polys) z_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
+    for (auto& st : lk) m_polys.push_back(be.lagrange_to_coeff(st.m));
+    for (auto& st : lk) phi_polys.push_back(be.lagrange_to_coeff(st.phi));
+    for (auto& h : m_polys) m_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
+    for (auto& h : phi_polys) phi_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
+    sw.lap(5);
+    Col hnum = be.zeros((size_t)1 << cs.ext_k);
+    {
+        Quotient Q = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal);
+        Q.prog.run(Q.cols, Q.chal, hnum->ptr());
+    }
+    sw.lap(6);
+    adv_cosets.clear(); z_cosets.clear(); m_cosets.clear(); phi_cosets.clear(); inst_cosets.clear();
+    be.divide_by_vanishing(hnum, cs.ext_k);
+    be.extended_to_coeff(hnum, cs.ext_k);
+    const uint32_t npieces = cs.degree - 1;
+    std::vector<Col> pieces;
+    for (uint32_t i = 0; i < npieces; i++) pieces.push_back(be.slice_copy(hnum, (size_t)i * n, n));
+    for (auto& p : be.commit(pieces)) T.write_point(p);
+    hnum.reset();
+    sw.lap(7);
+    // 8. x
+    const Fe x = T.squeeze_challenge();
+    const Fe w = omega(k);
+    auto rot_point = [&](int32_t r) { return x * w.pow((uint64_t)(r >= 0 ? (uint32_t)r % n : n - ((uint32_t)(-r) % n))); };
+    // 9. evaluations
+    std::map<std::pair<uint32_t, int32_t>, Fe> adv_evals, fix_evals;
+    for (auto& q : cs.advice_queries) {
+        Fe e = be.eval_poly(adv_polys[q.col], n, rot_point(q.rot));
+        adv_evals[{q.col, q.rot}] = e;
+        T.write_scalar(e);
+    }
+    for (auto& q : cs.fixed_queries) {
+        Fe e = be.eval_poly(pk.fixed_polys[q.col], n, rot_point(q.rot));
+        fix_evals[{q.col, q.rot}] = e;
+        T.write_scalar(e);
+    }
+    const Fe random_eval = be.eval_poly(rnd, n, x);
+    T.write_scalar(random_eval);
+    std::vector<Fe> sigma_evals;
+    for (auto& h : pk.sigma_polys) sigma_evals.push_back(be.eval_poly(h, n, x));
+    for (auto& e : sigma_evals) T.write_scalar(e);
+    struct ZEval {
+        Fe e0, e1, e2;
+        bool has2;
+    };
+    std::vector<ZEval> z_evals;
+    for (size_t j = 0; j < z_polys.size(); j++) {
+        ZEval ze{be.eval_poly(z_polys[j], n, x), be.eval_poly(z_polys[j], n, rot_point(1)), Fe::zero(), false};
+        T.write_scalar(ze.e0);
+        T.write_scalar(ze.e1);
+        if (j + 1 < z_polys.size()) {
+            ze.e2 = be.eval_poly(z_polys[j], n, rot_point((int32_t)u));
+            ze.has2 = true;
+            T.write_scalar(ze.e2);
+        }
+        z_evals.push_back(ze);
+    }
+    std::vector<std::array<Fe, 3>> lk_evals;
+    for (size_t i = 0; i < lk.size(); i++) {
+        std::array<Fe, 3> e = {be.eval_poly(m_polys[i], n, x), be.eval_poly(phi_polys[i], n, x), be.eval_poly(phi_polys[i], n, rot_point(1))};
+        for (auto& v_ : e) T.write_scalar(v_);
+        lk_evals.push_back(e);
+    }
+    sw.lap(8);
+    // 10. multiopen (SHPLONK)
+    const Fe xn = x.pow((uint64_t)n);
+    Col hcomb = be.zeros(n);
+    for (uint32_t i = npieces; i-- > 0;) {
+        be.scale(hcomb, xn, n);
+        be.axpy(hcomb, Fe::one(), pieces[i], n);
+    }
+    const Fe h_eval = be.eval_poly(hcomb, n, x);
+    enum : uint32_t { K_ADV = 1, K_FIX, K_H, K_RND, K_SIGMA, K_Z, K_M, K_PHI };
+    std::vector<OpenQuery> qs;     // the verifier rebuilds the same list with commitments for polynomials
+    for (auto& q : cs.advice_queries) qs.push_back({{K_ADV, q.col}, adv_polys[q.col], rot_point(q.rot), adv_evals[{q.col, q.rot}]});
+    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, pk.fixed_polys[q.col], rot_point(q.rot), fix_evals[{q.col, q.rot}]});
+    qs.push_back({{K_H}, hcomb, x, h_eval});
+    qs.push_back({{K_RND}, rnd, x, random_eval});
+    for (uint32_t i = 0; i < pk.sigma_polys.size(); i++) qs.push_back({{K_SIGMA, i}, pk.sigma_polys[i], x, sigma_evals[i]});
+    for (uint32_t j = 0; j < z_polys.size(); j++) {
+        qs.push_back({{K_Z, j}, z_polys[j], x, z_evals[j].e0});
+        qs.push_back({{K_Z, j}, z_polys[j], rot_point(1), z_evals[j].e1});
+        if (z_evals[j].has2) qs.push_back({{K_Z, j}, z_polys[j], rot_point((int32_t)u), z_evals[j].e2});
+    }
+    for (uint32_t i = 0; i < lk.size(); i++) {
+        qs.push_back({{K_M, i}, m_polys[i], x, lk_evals[i][0]});
+        qs.push_back({{K_PHI, i}, phi_polys[i], x, lk_evals[i][1]});
+        qs.push_back({{K_PHI, i}, phi_polys[i], rot_point(1), lk_evals[i][2]});
+    }
+    shplonk_prove(be, T, qs, n);
+    sw.lap(9);
+    sw.total();
+    return T.proof();
+}
+
+}  // namespace ezkl_prover
+
+// ------------------------------------------------------------------ C ABI
+using namespace ezkl_prover;
+struct ezkl_prover_cs {
+    std::unique_ptr<ConstraintSystem> cs;
+};
+struct ezkl_prover_pk {
+    std::unique_ptr<ProvingKey> pk;
+};
+template <class F>
+static int guarded(F&& f) {
+    try {
+        g_last_error.clear();
+        f();
+        return EZKL_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "host allocation failed";
+        return EZKL_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return EZKL_ERR_INVALID;
+    }
+}
+extern "C" {
+int ezkl_prover_cs_parse(const void* blob, size_t len, ezkl_cs_t* out) {
+    if (!blob || !out) return EZKL_ERR_INVALID;
+    return guarded([&] { *out = new ezkl_prover_cs{parse_cs(blob, len)}; });
+}
+int ezkl_prover_cs_free(ezkl_cs_t cs) {
+    delete cs;
+    return EZKL_OK;
+}
+int ezkl_prover_cs_info(ezkl_cs_t h, uint32_t out[8]) {
+    if (!h || !out) return EZKL_ERR_INVALID;
+    const ConstraintSystem& cs = *h->cs;
+    const uint32_t v[8] = {cs.degree, cs.ext_k, cs.chunk, cs.n_chunks, cs.usable, (uint32_t)cs.advice_queries.size(), (uint32_t)cs.fixed_queries.size(),
+                           (uint32_t)cs.instance_queries.size()};
+    std::memcpy(out, v, sizeof v);
+    return EZKL_OK;
+}
+int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies, ezkl_pk_t* out) {
+    if (!cs || !g || !out || (cs->cs->n_fixed && !fixed_values) || (n_copies && !copies)) return EZKL_ERR_INVALID;
+    return guarded([&] {
+        invalid(ezkl_hip_bases_len(g) < cs->cs->n, "SRS smaller than 2^k");
+        *out = new ezkl_prover_pk{keygen(*cs->cs, g, fixed_values, copies, n_copies)};
+    });
+}
+int ezkl_prover_pk_free(ezkl_pk_t pk) {
+    delete pk;
+    return EZKL_OK;
+}
+int ezkl_prover_vk(ezkl_pk_t h, void* fixed_commitments, void* permutation_commitments, void* digest) {
+    if (!h) return EZKL_ERR_INVALID;
+    const ProvingKey& pk = *h->pk;
+    if (fixed_commitments && !pk.fixed_commitments.empty()) std::memcpy(fixed_commitments, pk.fixed_commitments.data(), pk.fixed_commitments.size() * 64);
+    if (permutation_commitments && !pk.sigma_commitments.empty()) std::memcpy(permutation_commitments, pk.sigma_commitments.data(), pk.sigma_commitments.size() * 64);
+    if (digest) std::memcpy(digest, pk.digest.v.data(), 32);
+    return EZKL_OK;
+}
+int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, ezkl_advice_fn advice_fn, void* advice_user,
+                             const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng, void* rng_user, uint64_t seed, void* proof_out,
+                             size_t cap, size_t* proof_len, double* timings) {
+    if (!pk || !g || !g_lagrange || !proof_len) return EZKL_ERR_INVALID;
+    if (pk->pk->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
+    return guarded([&] {
+        invalid(ezkl_hip_bases_len(g) < pk->pk->cs->n || ezkl_hip_bases_len(g_lagrange) != pk->pk->cs->n, "SRS size does not match 2^k");
+        Rng r{rng, rng_user, Xoshiro(rng ? 1 : seed)};
+        std::vector<uint8_t> proof = create_proof(*pk->pk, g, g_lagrange, advice, advice_fn, advice_user, instances, instance_lens, r, timings);
+        *proof_len = proof.size();
+        if (proof.size() > cap || !proof_out) throw Error(EZKL_ERR_NOMEM, "proof buffer too small");
+        std::memcpy(proof_out, proof.data(), proof.size());
+    });
+}
+int ezkl_prover_keccak256(const void* data, size_t len, void* out32) {
+    if ((!data && len) || !out32) return EZKL_ERR_INVALID;
+    auto h = keccak256((const uint8_t*)data, len);
+    std::memcpy(out32, h.data(), 32);
+    return EZKL_OK;
+}
+const char* ezkl_prover_last_error(void) { return g_last_error.c_str(); }
+}

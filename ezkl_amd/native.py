@@ -1,0 +1,200 @@
+"""ctypes binding of the native host prover (libezkl_prover.so, include/ezkl_prover.h): halo2-shaped keygen and
+create_proof written in C++ over the C ABI of libezkl_hip.so.  This module only serialises a `plonk.ConstraintSystem`
+into the flat description the library parses and marshals pointers; it computes nothing itself."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+from . import lib as _l
+from . import plonk as _pl
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_vk",
+           "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
+ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
+RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+STAGES = ["advice_commit", "lookup_m", "permutation_z", "lookup_phi", "random_poly", "intt_and_coset_ntt", "quotient_sweep", "h_split_commit",
+          "evaluations", "shplonk", "total"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libezkl_prover.so")
+
+
+def load():
+    """Fails loudly: there is no Python fallback for the native prover."""
+    global _lib
+    if _lib is None:
+        _l.load()                                    # libezkl_hip.so first (the prover links it)
+        if not os.path.exists(lib_path()):
+            raise RuntimeError("libezkl_prover.so missing at %s -- build it with `make -C ezkl_amd/csrc`" % lib_path())
+        L = C.CDLL(lib_path())
+        L.ezkl_prover_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, load().ezkl_prover_last_error().decode(), rc))
+
+
+def keccak256(data):
+    out = (C.c_uint8 * 32)()
+    _check(load().ezkl_prover_keccak256(bytes(data), C.c_size_t(len(data)), out), "ezkl_prover_keccak256")
+    return bytes(out)
+
+
+_OPS = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "chal": 4, "neg": 5, "add": 6, "sub": 7, "mul": 8}
+_KINDS = {"adv": 1, "fix": 2, "inst": 3}
+
+
+def serialize_cs(cs):
+    """plonk.ConstraintSystem -> the blob of include/ezkl_prover.h (expression DAG with shared sub-expressions kept shared)"""
+    nodes, ids = [], {}
+
+    def visit(e):
+        if id(e) in ids:
+            return ids[id(e)]
+        op = e.node[0]
+        a = b = 0
+        const = bytes(32)
+        if op == "const":
+            const = _pl.to_mont(e.node[1]).tobytes()
+        elif op in ("adv", "fix", "inst"):
+            a, b = e.node[1], e.node[2] & 0xffffffff
+        elif op == "chal":
+            a = e.node[1]
+        elif op == "neg":
+            a = visit(e.node[1])
+        else:
+            a, b = visit(e.node[1]), visit(e.node[2])
+        nodes.append(struct.pack("<4I", _OPS[op], a, b, 0) + const)
+        ids[id(e)] = len(nodes) - 1
+        return ids[id(e)]
+
+    gates = [visit(g) for g in cs.gates]
+    lookups = [([[visit(e) for e in t] for t in ins], [visit(e) for e in tab]) for ins, tab in cs.lookups]
+    out = bytearray(struct.pack("<7I", 0x53435a45, 1, cs.k, cs.n_advice, cs.n_fixed, cs.n_instance, cs.n_challenges))
+    out += struct.pack("<%dI" % cs.n_advice, *cs.advice_phase)
+    out += struct.pack("<I", len(nodes)) + b"".join(nodes)
+    out += struct.pack("<I%dI" % len(gates), len(gates), *gates)
+    out += struct.pack("<I", len(cs.perm))
+    for kind, col in cs.perm:
+        out += struct.pack("<2I", _KINDS[kind], col)
+    out += struct.pack("<I", len(lookups))
+    for ins, tab in lookups:
+        out += struct.pack("<I", len(ins))
+        for t in ins + [tab]:
+            out += struct.pack("<I%dI" % len(t), len(t), *t)
+    return bytes(out)
+
+
+def _ptr_array(arrays):
+    arr = (C.c_void_p * max(1, len(arrays)))()
+    for i, a in enumerate(arrays):
+        arr[i] = a.ctypes.data
+    return arr
+
+
+class NativeCircuit:
+    def __init__(self, cs):
+        self.cs = cs
+        blob = serialize_cs(cs)
+        self.h = C.c_void_p()
+        _check(load().ezkl_prover_cs_parse(blob, C.c_size_t(len(blob)), C.byref(self.h)), "ezkl_prover_cs_parse")
+
+    def info(self):
+        out = (C.c_uint32 * 8)()
+        _check(load().ezkl_prover_cs_info(self.h, out), "ezkl_prover_cs_info")
+        return dict(zip(["degree", "ext_k", "chunk", "n_chunks", "usable", "n_advice_queries", "n_fixed_queries", "n_instance_queries"], list(out)))
+
+    def free(self):
+        if self.h:
+            load().ezkl_prover_cs_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class NativeProvingKey:
+    """keygen_vk + keygen_pk on the GPU; `g` is a backend.Bases handle of the coefficient-basis SRS"""
+
+    def __init__(self, circuit, g, fixed_values, copies):
+        self.circuit = circuit
+        fixed = [np.ascontiguousarray(v, np.uint64) for v in fixed_values]
+        cp = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4))
+        self.h = C.c_void_p()
+        _check(load().ezkl_prover_keygen(circuit.h, g.h, _ptr_array(fixed), cp.ctypes.data_as(C.c_void_p), C.c_size_t(cp.shape[0]), C.byref(self.h)),
+               "ezkl_prover_keygen")
+
+    def vk(self):
+        """(fixed commitments (F,8) u64, permutation commitments (P,8) u64, digest as a canonical int)"""
+        cs = self.circuit.cs
+        fc, pc, dg = np.zeros((cs.n_fixed, 8), np.uint64), np.zeros((len(cs.perm), 8), np.uint64), np.zeros(4, np.uint64)
+        _check(load().ezkl_prover_vk(self.h, fc.ctypes.data_as(C.c_void_p), pc.ctypes.data_as(C.c_void_p), dg.ctypes.data_as(C.c_void_p)), "ezkl_prover_vk")
+        return fc, pc, _pl.from_mont(dg)
+
+    def free(self):
+        if self.h:
+            load().ezkl_prover_pk_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(), timings=None):
+    """advice_values: list of (n,4) Montgomery arrays, or a callable advice_values(phase, challenges) -> {column: array}
+    (second-phase advice); rng: object with .vec(m) -> (m,4) u64 Montgomery residues (None = the library's own
+    generator, seeded with `seed`, 0 = OS entropy); instances: list of lists of ints.  Returns the proof bytes."""
+    cs = pk.circuit.cs
+    n = cs.n
+    keep = []
+    adv_arr, adv_cb = None, C.cast(None, ADVICE_FN)
+    if callable(advice_values):
+        def _cb(_user, phase, chal_ptr, n_chal, cols_ptr):
+            try:
+                ch = np.ctypeslib.as_array(C.cast(chal_ptr, C.POINTER(C.c_uint64)), shape=(n_chal, 4)) if n_chal else np.zeros((0, 4), np.uint64)
+                vals = advice_values(int(phase), [_pl.from_mont(c) for c in ch])
+                for c, a in vals.items():
+                    if cs.advice_phase[c] != phase:
+                        continue
+                    C.memmove(cols_ptr[c], np.ascontiguousarray(a, np.uint64).ctypes.data, 32 * n)
+                return 0
+            except Exception:                         # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        adv_cb = ADVICE_FN(_cb)
+    else:
+        keep = [np.ascontiguousarray(a, np.uint64) for a in advice_values]
+        adv_arr = _ptr_array(keep)
+    rng_cb = C.cast(None, RNG_FN)
+    if rng is not None:
+        def _rng(_user, out_ptr, m):
+            a = np.ascontiguousarray(rng.vec(int(m)), np.uint64)
+            C.memmove(out_ptr, a.ctypes.data, 32 * int(m))
+        rng_cb = RNG_FN(_rng)
+    inst = [np.stack([_pl.to_mont(v) for v in vals]) if len(vals) else np.zeros((0, 4), np.uint64) for vals in instances]
+    lens = (C.c_uint32 * max(1, len(inst)))(*[a.shape[0] for a in inst])
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)()
+    plen = C.c_size_t(0)
+    tm = (C.c_double * 12)()
+    _check(load().ezkl_prover_create_proof(pk.h, g.h, g_lagrange.h, adv_arr, adv_cb, None, _ptr_array(inst), lens, rng_cb, None, C.c_uint64(seed),
+                                           buf, C.c_size_t(cap), C.byref(plen), tm), "ezkl_prover_create_proof")
+    if timings is not None:
+        timings.update(dict(zip(STAGES, list(tm))))
+    return bytes(buf[:plen.value])

@@ -1,0 +1,82 @@
+/* ezkl_prover.h -- C ABI of the native host prover (libezkl_prover.so): halo2-shaped keygen + create_proof driving the
+ * kernels of libezkl_hip.so (include/ezkl_hip.h) on resident columns.  SURVEY.md §8(f) items 3-4.
+ *
+ * What it replaces in the reference: halo2_proofs::plonk::{keygen_vk, keygen_pk, create_proof} as called from
+ * /root/reference/src/pfsys/mod.rs:376-400 (create_keys) and :404-489 (create_proof_circuit: RNG choice :436-439,
+ * instances :441-445, create_proof :456-463, transcript finalize), with the EvmTranscript of
+ * /root/reference/src/execute.rs:1608-1609.  The circuit-specific part of halo2 (Circuit::configure / synthesize) stays
+ * on the caller's side: the constraint system arrives as a flat description, the witness as host columns.
+ *
+ * The library is a pure CLIENT of include/ezkl_hip.h (it links libezkl_hip.so and calls nothing else on the GPU), so
+ * it doubles as the proof that the drop-in boundary is sufficient for a complete prover.  No CPU fallback: without a
+ * GPU every call that touches columns returns EZKL_ERR_NO_DEVICE.  Status codes are those of ezkl_hip.h; nothing
+ * unwinds across the ABI.
+ *
+ * Not byte-compatible with the zkonduit halo2 fork's proofs (its source is not on disk, so query order / vk digest
+ * cannot be pinned): the proof LAYOUT is the reference's (points 64 B BE, scalars 32 B BE), acceptance
+ * is decided by the independent pairing verifier in oracle/verifier.py, and the bytes are identical to those of the
+ * Python restatement ezkl_amd/plonk.py under the same randomness (tests/test_native_prover.py).
+ */
+#ifndef EZKL_PROVER_H
+#define EZKL_PROVER_H
+#include <stddef.h>
+#include <stdint.h>
+#include "ezkl_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constraint system ----
+ * blob (little-endian u32 words unless noted):
+ *   magic 0x53435a45 ("EZCS"), version 1, k, n_advice, n_fixed, n_instance, n_challenges, advice_phase[n_advice],
+ *   n_nodes, nodes[n_nodes] of 48 B: {u32 op, u32 a, u32 b, u32 0, u8 constant[32] (Montgomery Fr)}
+ *       op 0 CONST | 1 ADVICE(col a, rotation (i32) b) | 2 FIXED | 3 INSTANCE | 4 CHALLENGE(index a)
+ *          | 5 NEG(node a) | 6 ADD(node a, node b) | 7 SUB | 8 MUL        (children precede parents)
+ *   n_gates, gate_node[n_gates]                              -- the polynomials of ConstraintSystem::gates
+ *   n_perm, {u32 kind (1 advice, 2 fixed, 3 instance), u32 col}[n_perm]   -- permutation::Argument columns, in order
+ *   n_lookups, per lookup: n_inputs, per input {arity, node[arity]}, table {arity, node[arity]}   -- mv-lookup arguments
+ */
+typedef struct ezkl_prover_cs* ezkl_cs_t;
+typedef struct ezkl_prover_pk* ezkl_pk_t;
+int ezkl_prover_cs_parse(const void* blob, size_t len, ezkl_cs_t* out);
+int ezkl_prover_cs_free(ezkl_cs_t cs);
+/* out[0..8) = degree, extended_k, permutation chunk length, #z polynomials, usable rows, #advice queries,
+ * #fixed queries, #instance queries */
+int ezkl_prover_cs_info(ezkl_cs_t cs, uint32_t out[8]);
+
+/* ---- keygen (keygen_vk + keygen_pk): fixed columns and copy constraints -> resident proving key ----
+ * fixed_values: n_fixed host pointers, 2^k x 32 B Montgomery Fr each.  copies: n_copies x {colpos_a, row_a, colpos_b, row_b}
+ * with colpos indexing the permutation column list.  g = the SRS in coefficient basis (ParamsKZG::g).  The cs handle is
+ * borrowed and must outlive the pk. */
+int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies, ezkl_pk_t* out);
+int ezkl_prover_pk_free(ezkl_pk_t pk);
+/* verifying key: n_fixed + n_perm affine commitments (64 B Montgomery each) and the 32-byte transcript digest
+ * (Montgomery Fr).  Any output pointer may be NULL. */
+int ezkl_prover_vk(ezkl_pk_t pk, void* fixed_commitments, void* permutation_commitments, void* digest);
+
+/* ---- create_proof ----
+ * advice: n_advice host pointers (2^k x 32 B Montgomery; rows >= usable are overwritten with blinding randomness on the
+ *   device copy).  For circuits with second-phase advice pass advice_fn instead (advice may then be NULL): it is called
+ *   once per phase with the challenges squeezed so far and fills columns[c] (host, 2^k x 32 B) for every column c of
+ *   that phase; a non-zero return aborts with EZKL_ERR_INVALID.
+ * instances: n_instance host pointers with instance_lens[i] Montgomery Fr each (hashed, not committed).
+ * rng: fills n_elems x 32 B with uniform Montgomery residues < r; NULL = the library's xoshiro256** seeded with `seed`
+ *   (the reference's det-prove feature, pfsys/mod.rs:436-439) or, if seed == 0, from the OS.
+ * proof_out / cap / proof_len: EvmTranscript bytes; EZKL_ERR_NOMEM with *proof_len set if cap is too small.
+ * timings (may be NULL): 12 doubles, seconds per prover stage in the order advice_commit, lookup_m, permutation_z,
+ *   lookup_phi, random_poly, intt_and_coset_ntt, quotient_sweep, h_split_commit, evaluations, shplonk, total, reserved. */
+typedef int (*ezkl_advice_fn)(void* user, uint32_t phase, const void* challenges, uint32_t n_challenges, void* const* columns);
+typedef void (*ezkl_rng_fn)(void* user, void* out, size_t n_elems);
+int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, ezkl_advice_fn advice_fn,
+                             void* advice_user, const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng, void* rng_user,
+                             uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings);
+
+/* keccak256 of a byte string (exposed so the transcript can be tested against the Python restatement without a GPU) */
+int ezkl_prover_keccak256(const void* data, size_t len, void* out32);
+/* last error text of the calling thread ("" if none) */
+const char* ezkl_prover_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

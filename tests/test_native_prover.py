@@ -1,0 +1,188 @@
+"""The native host prover (libezkl_prover.so, C++ over the C ABI).
+CPU: the library loads and exports what include/ezkl_prover.h declares; its Keccak and its constraint-system analysis
+agree with the Python restatement; malformed circuit descriptions are rejected.
+GPU: keygen and create_proof give the SAME BYTES as the Python prover on the HIP backend and as the CPU oracle backend
+(same SRS fixture / witness / randomness), and the independent pairing verifier accepts."""
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from ezkl_amd import native as N, plonk as P, transcript as TR
+from test_plonk import (det_rng, instance_phase_circuit, instance_phase_witness, lookup_circuit, lookup_witness, mul_add_circuit, random_circuit,
+                        setup, witness)
+
+
+def test_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "ezkl_prover.h")).read()
+    declared = sorted(set(re.findall(r"\b(ezkl_prover_\w+)\s*\(", hdr)))
+    assert declared == sorted(N.SYMBOLS)
+    L = N.load()
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_keccak_matches_python_restatement():
+    rng = np.random.default_rng(5)
+    for ln in (0, 1, 31, 32, 64, 135, 136, 137, 272, 1000):
+        data = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        assert N.keccak256(data) == TR.keccak256(data)
+    assert N.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"     # the well-known empty-input digest
+
+
+@pytest.mark.parametrize("make", [lambda: mul_add_circuit(6), lambda: lookup_circuit(6), lambda: instance_phase_circuit(6),
+                                  lambda: random_circuit(11)[0], lambda: random_circuit(12)[0], lambda: mul_add_circuit(10)])
+def test_constraint_system_analysis_matches_python(make):
+    cs = make()
+    info = N.NativeCircuit(cs).info()
+    assert info == dict(degree=cs.degree, ext_k=cs.ext_k, chunk=cs.chunk, n_chunks=cs.n_chunks, usable=cs.usable,
+                        n_advice_queries=len(cs.advice_queries), n_fixed_queries=len(cs.fixed_queries), n_instance_queries=len(cs.instance_queries))
+
+
+def test_malformed_circuit_descriptions_are_rejected():
+    import ctypes as C
+    good = N.serialize_cs(lookup_circuit(6))
+
+    def parse(blob):
+        h = C.c_void_p()
+        rc = N.load().ezkl_prover_cs_parse(bytes(blob), C.c_size_t(len(blob)), C.byref(h))
+        if rc == 0:
+            N.load().ezkl_prover_cs_free(h)
+        return rc
+    assert parse(good) == 0
+    assert parse(good[:-4]) == -3 and parse(good + b"\0\0\0\0") == -3          # truncated / trailing bytes
+    bad = bytearray(good); bad[0] ^= 1
+    assert parse(bad) == -3                                                    # magic
+    bad = bytearray(good); struct.pack_into("<I", bad, 8, 40)
+    assert parse(bad) == -3                                                    # k out of range
+    # first node referencing a later node (children must precede parents)
+    off = 4 * (7 + 4) + 4
+    bad = bytearray(good); struct.pack_into("<3I", bad, off, 6, 5, 7)
+    assert parse(bad) == -3
+    assert b"precede" in N.load().ezkl_prover_last_error() or b"range" in N.load().ezkl_prover_last_error()
+    # advice column index out of range
+    bad = bytearray(good); struct.pack_into("<3I", bad, off, 1, 99, 0)
+    assert parse(bad) == -3
+
+
+# ------------------------------------------------------------------ GPU
+def _native_setup(golden_srs, cs, fixed, copies):
+    from ezkl_amd import backend as B
+    g, gl = B.Bases(golden_srs["g"]), B.Bases(golden_srs["g_lagrange"])
+    circ = N.NativeCircuit(cs)
+    pk = N.NativeProvingKey(circ, g, fixed, copies)
+    return g, gl, pk
+
+
+def _pt(p):
+    x, y = (0, 0) if p is None else p
+    return np.frombuffer((x * P.MONT % P.Q).to_bytes(32, "little") + (y * P.MONT % P.Q).to_bytes(32, "little"), np.uint64)
+
+
+def _check_against_python(golden_srs, cs, adv, fixed, copies, seed, instances=()):
+    from oracle import verifier as V
+    from oracle.cpu_backend import OracleBackend
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], cs.k)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    fc, pc, digest = pk.vk()
+    assert digest == vk_g.digest
+    assert all((fc[i] == _pt(p)).all() for i, p in enumerate(vk_g.fixed_commitments))
+    assert all((pc[i] == _pt(p)).all() for i, p in enumerate(vk_g.sigma_commitments))
+    tm = {}
+    proof_n = N.create_proof(pk, g, gl, adv, rng=det_rng(seed), instances=instances, timings=tm)
+    proof_g = P.create_proof(pk_g, gpu, adv, det_rng(seed), instances=instances)
+    assert proof_n == proof_g
+    cpu = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], cs.k)
+    pk_c, _ = P.keygen(cs, cpu, fixed, copies)
+    assert proof_n == P.create_proof(pk_c, cpu, adv, det_rng(seed), instances=instances)
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk_g, g1, g2, s_g2, proof_n, instances=instances)
+    assert tm["total"] > 0 and abs(sum(tm[s] for s in N.STAGES[:-1]) - tm["total"]) < 0.05 * tm["total"] + 1e-3
+    return g, gl, pk, vk_g
+
+
+@pytest.mark.gpu
+def test_native_proof_bit_identical_gates_and_permutation(hip, golden_srs):
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 2)
+    _check_against_python(golden_srs, cs, adv, fixed, copies, 11)
+
+
+@pytest.mark.gpu
+def test_native_proof_bit_identical_lookups(hip, golden_srs):
+    cs = lookup_circuit(6)
+    adv, fixed, copies = lookup_witness(cs, 4)
+    _check_against_python(golden_srs, cs, adv, fixed, copies, 2)
+
+
+@pytest.mark.gpu
+def test_native_proof_bit_identical_instances_and_second_phase(hip, golden_srs):
+    cs = instance_phase_circuit(6)
+    advice, fixed, copies, inst = instance_phase_witness(cs, 6)
+    _check_against_python(golden_srs, cs, advice, fixed, copies, 4, instances=inst)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_native_proof_bit_identical_random_circuits(hip, golden_srs, seed):
+    cs, adv, fixed, copies = random_circuit(seed)
+    _check_against_python(golden_srs, cs, adv, fixed, copies, seed)
+
+
+@pytest.mark.gpu
+def test_native_library_rng_and_rejections(hip, golden_srs):
+    """the library's own generator (det-prove: seeded; default: OS entropy), a failing witness, a short proof buffer"""
+    import ctypes as C
+    from oracle import verifier as V
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 3)
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    _, vk = P.keygen(cs, gpu, fixed, copies)
+    g1, g2, s_g2 = setup(golden_srs)
+    p1, p2, p3 = N.create_proof(pk, g, gl, adv, seed=7), N.create_proof(pk, g, gl, adv, seed=7), N.create_proof(pk, g, gl, adv, seed=8)
+    assert p1 == p2 and p1 != p3 and len(p1) == len(p3)
+    assert V.verify(vk, g1, g2, s_g2, p1) and V.verify(vk, g1, g2, s_g2, p3)
+    p4, p5 = N.create_proof(pk, g, gl, adv), N.create_proof(pk, g, gl, adv)            # seed 0: OS entropy
+    assert p4 != p5 and V.verify(vk, g1, g2, s_g2, p4)
+    bad = [a.copy() for a in adv]
+    bad[2][3] = P.to_mont(12345)                                                         # breaks c = a*b on row 3: a proof is produced, the verifier rejects it
+    assert not V.verify(vk, g1, g2, s_g2, N.create_proof(pk, g, gl, bad, seed=7))
+    # proof buffer too small -> EZKL_ERR_NOMEM and the needed length
+    L = N.load()
+    keep = [np.ascontiguousarray(a, np.uint64) for a in adv]
+    arr = (C.c_void_p * len(keep))(*[a.ctypes.data for a in keep])
+    buf, plen = (C.c_uint8 * 16)(), C.c_size_t(0)
+    rc = L.ezkl_prover_create_proof(pk.h, g.h, gl.h, arr, C.cast(None, N.ADVICE_FN), None, None, None, C.cast(None, N.RNG_FN), None, C.c_uint64(7),
+                                    buf, C.c_size_t(16), C.byref(plen), None)
+    assert rc == -4 and plen.value == len(p1)
+    # SRS of the wrong size
+    from ezkl_amd import backend as B
+    half = B.Bases(golden_srs["g_lagrange"][:32])
+    with pytest.raises(RuntimeError):
+        N.create_proof(pk, g, half, adv, seed=7)
+
+
+@pytest.mark.gpu
+def test_native_prover_k12(hip):
+    """a larger domain (k = 12, generated SRS): native proof == Python-on-HIP proof, verifier accepts"""
+    from ezkl_amd import backend as B
+    from oracle import pairing as E, verifier as V
+    k = 12
+    s = 0x1234567
+    g, gl = B.gen_srs(k, s)
+    g_pts, gl_pts = g.download(), gl.download()
+    cs = mul_add_circuit(k)
+    adv, fixed, copies = witness(cs, 9)
+    pk = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    gpu = P.GpuBackend(g_pts, gl_pts, k)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    proof = N.create_proof(pk, g, gl, adv, rng=det_rng(5))
+    assert proof == P.create_proof(pk_g, gpu, adv, det_rng(5))
+    G2 = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
+          (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
+    assert V.verify(vk_g, (1, 2), G2, E.g2_mul(G2, s), proof)
