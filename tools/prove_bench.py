@@ -3,7 +3,9 @@
 DOT-style gates  s_init*(acc - a*b) = 0,  s_acc*(acc - acc[-1] - a*b) = 0  over B column blocks, plus a permutation
 argument tying repeated operands), proved by ezkl_amd.plonk on the GPU and checked by the independent pairing verifier.
 
-    K=16 BLOCKS=2 python tools/prove_bench.py [--cpu]      (--cpu also times the CPU oracle backend)
+    K=16 BLOCKS=2 python tools/prove_bench.py [--cpu] [--native]
+(--cpu also times the CPU oracle backend; --native also times the C++ host prover libezkl_prover.so on the same witness /
+randomness and requires its proof to be byte-identical)
 The SRS is generated here with a known secret (no public SRS without network, src/pfsys/srs.rs:10-11)."""
 import json, os, sys, time
 import numpy as np
@@ -139,6 +141,16 @@ out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLO
        "k": k, "advice_columns": cs.n_advice, "fixed_columns": cs.n_fixed, "degree": cs.degree, "ext_k": cs.ext_k, "copies": len(copies),
        "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "keygen_seconds_gpu": round(t_keygen, 3),
        "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
+if "--native" in sys.argv and world == 1:
+    from ezkl_amd import native as NV
+    gb_, glb_ = B.Bases(g), B.Bases(gl)
+    t0 = time.time(); npk = NV.NativeProvingKey(NV.NativeCircuit(cs), gb_, fixed, copies); t_nkeygen = time.time() - t0
+    NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5))            # warm-up
+    ntm = {}
+    t0 = time.time(); nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), timings=ntm); t_native = time.time() - t0
+    t0 = time.time(); NV.create_proof(npk, gb_, glb_, adv, seed=5); t_native_librng = time.time() - t0
+    out["native_prover"] = {"prove_seconds": round(t_native, 4), "prove_seconds_library_rng": round(t_native_librng, 4), "keygen_seconds": round(t_nkeygen, 3),
+                            "proof_identical_to_python_prover": nproof == proof, "breakdown_seconds": {a: round(b, 4) for a, b in ntm.items()}}
 if "--cpu-kernels" in sys.argv:
     # the C oracle (OpenMP, all host cores) timed on ONE instance of each kernel class at this size, scaled by the call
     # counts the prover actually issued: a bounded CPU sample, not a CPU prover
