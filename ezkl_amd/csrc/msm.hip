@@ -27,32 +27,41 @@
 namespace ezkl {
 
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
-static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets spanning more lanes than this are folded by a workgroup
+static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
 
+// Window plan: W signed-digit windows covering 254 bits (253-bit magnitudes after the r - s fold + the last carry),
+// the first `rem` windows base+1 bits wide, the others base bits.  Balanced widths instead of "c, c, ..., short top
+// window": a 14-bit top window under c = 20 pours 128 extra pairs into each of 2^13 buckets, which then get cut by
+// several lane boundaries of the accumulate kernel; with 7 x 20 + 6 x 19 bits no bucket outgrows a lane.
+struct WinPlan {
+    uint32_t W, base, rem;
+    __host__ __device__ uint32_t width(uint32_t w) const { return base + (w < rem ? 1u : 0u); }
+    __host__ __device__ uint32_t offset(uint32_t w) const { return w * base + (w < rem ? w : rem); }
+    __host__ __device__ uint32_t cmax() const { return base + (rem ? 1u : 0u); }
+};
 struct MsmTable {
-    g1a_t* tab = nullptr;    // W x n affine
-    uint32_t c = 0, W = 0;
+    g1a_t* tab = nullptr;    // W x n affine: T[w][i] = 2^offset(w) * P_i
+    WinPlan wp{0, 0, 0};
     size_t n = 0;
 };
 static std::map<const Bases*, MsmTable> g_tables;   // guarded by the ctx mutex
 
-static uint32_t pick_window(size_t n) {
-    // aim at ~24 points per bucket: n*W / 2^(c-1) ~ 24, W = ceil(255/c).  After the r - s fold every scalar is
-    // < 2^253, so the top window only holds tb = 253 - (W-1)*c bits; a tiny top window would pour n / 2^tb pairs
-    // into each of a handful of buckets (c = 18: ONE bucket with n/2 pairs), so such widths are skipped.
-    uint32_t best = 2;
-    for (uint32_t c = 2; c <= 22; c++) {
-        const uint32_t W = (255 + c - 1) / c;
-        const int tb = 253 - (int)((W - 1) * c);
-        const double per = (double)n * W / (double)((size_t)1 << (c - 1));
-        const bool top_ok = tb <= 0 || tb >= 8 || ((double)n / (double)(1u << (tb > 0 ? tb : 0))) <= 256.0;
-        if (per >= 20.0 && top_ok) best = c;
+static WinPlan pick_plan(size_t n) {
+    // cost model in point additions: n*W bucket additions + ~4 per bucket for the reduce phase (2^(cmax-1) buckets);
+    // ties go to the smaller W (fewer gathers, smaller table).  n = 2^20: W = 13 (7 x 20 + 6 x 19 bits, 26 pairs/bucket).
+    WinPlan best{0, 0, 0};
+    double best_cost = 0;
+    for (uint32_t W = 10; W <= 127; W++) {
+        WinPlan p{W, 254 / W, 254 % W};
+        if (p.cmax() > 23) continue;
+        const double cost = (double)n * W + 4.0 * (double)((size_t)1 << (p.cmax() - 1));
+        if (!best.W || cost < best_cost) { best = p; best_cost = cost; }
     }
     return best;
 }
 
-// ---- table precompute: T[w] = 2^c * T[w-1] ------------------------------------------------------
+// ---- table precompute: T[w] = 2^width(w-1) * T[w-1] --------------------------------------------
 __global__ __launch_bounds__(256) void msm_precompute_kernel(const g1a_t* prev, g1a_t* next, size_t n, uint32_t c) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -93,11 +102,12 @@ __device__ __forceinline__ fe_t msm_canon(const fe_t* scalars, size_t i, uint32_
 }
 // calls f(w, bucket, sign) for every non-zero signed c-bit digit (bucket = |digit| - 1)
 template <class F>
-__device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, uint32_t c, uint32_t W, F&& f) {
-    const uint32_t half = 1u << (c - 1);
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t raw = get_bits(s, w * c, c) + carry;
+__device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, const WinPlan& wp, F&& f) {
+    uint32_t carry = 0, off = 0;
+    for (uint32_t w = 0; w < wp.W; w++) {
+        const uint32_t c = wp.width(w), half = 1u << (c - 1);
+        uint32_t raw = get_bits(s, off, c) + carry;
+        off += c;
         if (raw > half) {                       // negative digit raw - 2^c, carry into the next window
             carry = 1;
             if (raw != (1u << c)) f(w, (1u << c) - raw - 1u, neg ^ 1u);   // raw == 2^c: digit 0 with a carry
@@ -114,7 +124,7 @@ __device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, u
 // pos = (bucket & (NP-1)) * 2^LB + (bucket >> PB); the reduce phase weights positions accordingly.
 // Global atomics are per (workgroup, partition), not per pair: a workgroup histograms its slice of scalars
 // in LDS, reserves one range per partition, then ranks its pairs with LDS atomics.
-__global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, uint32_t c, uint32_t W,
+__global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                        uint32_t LB, uint32_t NP, uint32_t* part_count) {
     __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
     for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
+        msm_foreach_digit(s, neg, wp, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < NP; p += 256)
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
     }
     if (t == NP - 1) part_base[NP] = sh[t];
 }
-__global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, uint32_t c, uint32_t W,
+__global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                             uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
                                                             uint32_t* part_cursor, uint2* entries) {
     __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars,
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, c, W, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
+        msm_foreach_digit(s, neg, wp, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < NP; p += 256) {
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars,
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, c, W, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
+        msm_foreach_digit(s, neg, wp, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
             uint32_t p = bucket & (NP - 1);
             uint32_t r = atomicAdd(&lh[p], 1u);
             entries[lbase[p] + r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket >> PB);
@@ -236,7 +246,8 @@ __device__ __forceinline__ g1a_t msm_fetch(const g1a_t* tab, uint32_t v) {
     return p;
 }
 __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
-                                                             uint32_t nb, uint32_t L, g1x_t* buckets, g1x_t* head, g1x_t* tail) {
+                                                             uint32_t nb, uint32_t L, g1x_t* buckets, g1x_t* head, g1x_t* tail,
+                                                             uint32_t* lane_first) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[nb];
     const uint64_t k0w = (uint64_t)t * L;
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab
         if (offsets[mid] <= k0) lo = mid; else hi = mid;
     }
     uint32_t b = lo, bin_end = offsets[b + 1];
+    lane_first[t] = b;                          // the bucket holding this lane's first pair (msm_fixup_boundary_kernel)
     bool started_before = offsets[b] < k0;
     g1x_t acc = g1x_identity();
     g1a_t nxt = msm_fetch(tab, vals[k0]);
@@ -281,21 +293,28 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab
         if (started_before) st_g1x(head + t, acc); else st_g1x(tail + t, acc);
     }
 }
-// bucket b cut by lane boundaries: tail[t1] + head[t1+1 .. t2]
-__global__ __launch_bounds__(256) void msm_fixup_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, const g1x_t* head,
-                                                        const g1x_t* tail, g1x_t* buckets, uint32_t* heavy_list, uint32_t* heavy_count) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    uint32_t beg = offsets[b], end = offsets[b + 1];
-    if (end == beg) return;
-    uint32_t t1 = beg / L, t2 = (end - 1) / L;
-    if (t1 == t2) return;
+// A bucket cut by lane boundaries is tail[t1] + head[t1+1 .. t2].  One thread per LANE BOUNDARY (not per bucket: with
+// ~26 pairs per bucket and ~52 per lane nearly every boundary cuts a bucket, so the waves are full).  The common case,
+// a bucket cut once, is one addition; a bucket cut a few times is folded serially by its first boundary; anything
+// longer (a skewed witness) is queued for msm_fixup_heavy_kernel.
+__global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, uint32_t nlanes,
+                                                                 const uint32_t* lane_first, const g1x_t* head, const g1x_t* tail, g1x_t* buckets,
+                                                                 uint32_t* heavy_list, uint32_t* heavy_count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
+    if (t >= nlanes) return;
+    const uint64_t k0 = (uint64_t)t * L;
+    if (k0 >= offsets[nb]) return;
+    const uint32_t b = lane_first[t];
+    const uint32_t beg = offsets[b], end = offsets[b + 1];
+    if (beg >= k0) return;                                                 // the bucket starts exactly on the boundary: not cut
+    const uint32_t t1 = beg / L, t2 = (end - 1) / L;
+    if (t != t1 + 1) return;                                               // a later boundary of a bucket cut several times
     if (t2 - t1 > MSM_SPAN_HEAVY) {
         heavy_list[atomicAdd(heavy_count, 1u)] = b;
         return;
     }
-    g1x_t acc = ld_g1x(tail + t1);
-    for (uint32_t t = t1 + 1; t <= t2; t++) acc = g1x_add(acc, ld_g1x(head + t));
+    g1x_t acc = g1x_add(ld_g1x(tail + t1), ld_g1x(head + t));
+    for (uint32_t u = t + 1; u <= t2; u++) acc = g1x_add(acc, ld_g1x(head + u));
     st_g1x(buckets + b, acc);
 }
 // heavily skewed buckets (e.g. thousands of equal witness values): one workgroup folds the lane partials
@@ -400,14 +419,13 @@ static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
     if (it != g_tables.end()) { *out = &it->second; return EZKL_OK; }
     MsmTable t;
     t.n = b->n;
-    t.c = pick_window(b->n);
-    t.W = (255 + t.c - 1) / t.c;
-    if ((size_t)t.W * t.n >= ((size_t)1 << 31)) return EZKL_ERR_UNSUPPORTED;
-    EZ_HIP(hipMalloc(&t.tab, (size_t)t.W * t.n * sizeof(g1a_t)));
+    t.wp = pick_plan(b->n);
+    if ((size_t)t.wp.W * t.n >= ((size_t)1 << 31)) return EZKL_ERR_UNSUPPORTED;
+    EZ_HIP(hipMalloc(&t.tab, (size_t)t.wp.W * t.n * sizeof(g1a_t)));
     EZ_HIP(hipMemcpyAsync(t.tab, b->pts, t.n * sizeof(g1a_t), hipMemcpyDeviceToDevice, st));
-    for (uint32_t w = 1; w < t.W; w++)
+    for (uint32_t w = 1; w < t.wp.W; w++)
         hipLaunchKernelGGL(msm_precompute_kernel, dim3(cdiv(t.n, 256)), dim3(256), 0, st, t.tab + (size_t)(w - 1) * t.n,
-                           t.tab + (size_t)w * t.n, t.n, t.c);
+                           t.tab + (size_t)w * t.n, t.n, t.wp.width(w - 1));
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipStreamSynchronize(st));
     g_tables[b] = t;
@@ -474,7 +492,8 @@ static int msm_finish(MsmSlot& sl, void* out_host) {
 
 static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t base_offset, const fe_t* scalars, size_t n, bool timed) {
     int rc = EZKL_OK;
-    const uint32_t cw = T->c, W = T->W, bits = cw - 1;
+    const WinPlan wp = T->wp;
+    const uint32_t W = wp.W, bits = wp.cmax() - 1;
     const uint32_t nb = 1u << bits;
     const size_t npairs = n * W;
     const uint32_t PB = bits < MSM_MAX_PART_BITS ? bits : MSM_MAX_PART_BITS, LB = bits - PB, NP = 1u << PB;
@@ -518,6 +537,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
     size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_pcur = carve((NP + 1) * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256);
+    size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x_t));
     size_t o_head = carve((size_t)nlanes * sizeof(g1x_t)), o_tail = carve((size_t)nlanes * sizeof(g1x_t));
     size_t o_partA = carve((size_t)n_partA * sizeof(g1x_t)), o_partT = carve((size_t)n_partT * sizeof(g1x_t));
@@ -531,6 +551,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     uint32_t* offs = (uint32_t*)(S + o_offs);
     uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *pcur = (uint32_t*)(S + o_pcur);
     uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt);
+    uint32_t* lfirst = (uint32_t*)(S + o_lfirst);
     g1x_t *bkt = (g1x_t*)(S + o_bkt), *head = (g1x_t*)(S + o_head), *tail = (g1x_t*)(S + o_tail);
     g1x_t *partA = (g1x_t*)(S + o_partA), *partT = (g1x_t*)(S + o_partT), *SA = (g1x_t*)(S + o_SA), *TT = (g1x_t*)(S + o_T);
     g1x_t* planes = (g1x_t*)(S + o_planes);
@@ -550,16 +571,19 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     if ((size_t)sgrid * 256 > n) sgrid = cdiv(n, 256);
     size_t per_block = ((n + sgrid - 1) / sgrid + 255) / 256 * 256;
     sgrid = cdiv(n, per_block);
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, cw, W, LB, NP, pcnt);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, pcnt);
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase, pcur);
-    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, cw, W, LB, NP, base_offset, T->n,
+    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, base_offset, T->n,
                        pcur, entries);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail,
+                       lfirst);
     if (timed) EZ_HIP(hipEventRecord(a1, st));
-    hipLaunchKernelGGL(msm_fixup_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, offs, nb, L, head, tail, bkt, heavy, hcnt);
+    if (nlanes > 1)
+        hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256)), dim3(256), 0, st, offs, nb, L, nlanes, lfirst, head, tail, bkt,
+                           heavy, hcnt);
     {
         size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
@@ -573,6 +597,12 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes), dim3(256), 0, st, SA, TT, rg, planes);
     }
     EZ_HIP(hipGetLastError());
+    if (getenv("EZKL_MSM_DEBUG")) {
+        uint32_t hc = 0;
+        EZ_HIP(hipMemcpyAsync(&hc, hcnt, 4, hipMemcpyDeviceToHost, st));
+        EZ_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[msm] n=%zu W=%u bits=%u L=%u nlanes=%u heavy=%u\n", n, W, bits, L, nlanes, hc);
+    }
     if (timed) EZ_HIP(hipEventRecord(m1, st));
     EZ_HIP(hipMemcpyAsync(sl.pinned, planes, (size_t)nplanes * sizeof(g1x_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipEventRecord(sl.done, st));

@@ -1,7 +1,10 @@
 // ubench.hip -- on-device microbenchmarks that give the roofline its compute-side context:
 // Montgomery products/s (the real ceiling of MSM/NTT), v_mad_u64_u32 issue rate, and HBM copy GB/s.
 #include "common.hpp"
+#include "curve.hpp"
 #include <string.h>
+#include <vector>
+#include <stdlib.h>
 
 namespace ezkl {
 
@@ -67,6 +70,14 @@ __global__ __launch_bounds__(256) void ub_gather_kernel(const uint4* table, uint
     out[tid] = acc;
 }
 
+// dependent chain of general XYZZ additions: launch latency / cold-instruction-fetch probe for the small tail kernels
+__global__ __launch_bounds__(256) void ub_ecadd_kernel(g1x_t* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    g1x_t a = ld_g1x(io + i), b = ld_g1x(io + i + 1);
+    for (int k = 0; k < iters; k++) a = g1x_add(a, b);
+    st_g1x(io + i, a);
+}
+
 int ubench(Ctx* c, const char* which, double* out) {
     hipStream_t st = c->stream;
     hipEvent_t e0, e1;
@@ -96,6 +107,34 @@ int ubench(Ctx* c, const char* which, double* out) {
         EZ_HIP(hipFree(buf));
         const double per_thread = (is_mm || !strcmp(which, "addsub")) ? 4.0 * iters : 8.0 * iters;
         *out = per_thread * (double)nthreads / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strncmp(which, "ecadd", 5)) {         // "ecadd<iters>[w|f]": microseconds of the 4th launch; w = one wave, f = full GPU
+        const int iters = atoi(which + 5);
+        const bool full = which[strlen(which) - 1] == 'f';
+        const int eb = full ? c->num_cus * 4 : 1, et = full ? 256 : 64;
+        void* buf = nullptr;
+        const size_t cnt = (size_t)eb * et + 1;
+        EZ_HIP(hipMalloc(&buf, cnt * sizeof(g1x_t)));
+        EZ_HIP(hipMemsetAsync(buf, 0, cnt * sizeof(g1x_t), st));
+        {   // a valid point (generator (1, 2), zz = zzz = 1 in Montgomery form) everywhere except slot 0 (identity): a += G repeatedly
+            std::vector<g1x_t> h(cnt);
+            g1x_t g;
+            g.x = Fq::one(); g.y = Fq::add(Fq::one(), Fq::one()); g.zz = Fq::one(); g.zzz = Fq::one();
+            for (size_t i = 0; i < cnt; i++) h[i] = g;
+            for (size_t i = 0; i + 1 < cnt; i += 2) h[i] = g1x_double(g);
+            EZ_HIP(hipMemcpyAsync(buf, h.data(), cnt * sizeof(g1x_t), hipMemcpyHostToDevice, st));
+            EZ_HIP(hipStreamSynchronize(st));
+        }
+        for (int rep = 0; rep < 4; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(ub_ecadd_kernel, dim3(eb), dim3(et), 0, st, (g1x_t*)buf, iters);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        EZ_HIP(hipFree(buf));
+        *out = ms * 1e3;
         return EZKL_OK;
     }
     if (!strcmp(which, "gather64")) {
