@@ -122,10 +122,10 @@ __device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, c
 // (low bits are uniformly populated even when the top window or a skewed witness concentrates the bucket
 // values in a small numeric range, so the partitions stay balanced).  Buckets are stored at position
 // pos = (bucket & (NP-1)) * 2^LB + (bucket >> PB); the reduce phase weights positions accordingly.
-// Global atomics are per (workgroup, partition), not per pair: a workgroup histograms its slice of scalars
-// in LDS, reserves one range per partition, then ranks its pairs with LDS atomics.
+// No global atomics: every workgroup histograms its slice of scalars in LDS and stores the row; a column scan turns the
+// rows into per-(workgroup, partition) start slots; the partition pass ranks its pairs with LDS atomics.
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
-                                                       uint32_t LB, uint32_t NP, uint32_t* part_count) {
+                                                       uint32_t LB, uint32_t NP, uint32_t* wg_hist) {
     __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
     for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
     __syncthreads();
@@ -136,12 +136,42 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
         msm_foreach_digit(s, neg, wp, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < NP; p += 256)
-        if (lh[p]) atomicAdd(&part_count[p], lh[p]);
+    for (uint32_t p = threadIdx.x; p < NP; p += 256) wg_hist[(size_t)blockIdx.x * NP + p] = lh[p];   // row of this workgroup, coalesced
 }
-// exclusive scan of <= 1024 partition counts; also seeds the reservation cursors
-__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NP, uint32_t* part_base,
-                                                             uint32_t* part_cursor) {
+// wg_hist[g][p] (G workgroups x NP partitions) -> in place, the exclusive prefix over g of column p; part_count[p] = column
+// total.  One workgroup per 32 columns: thread (c, j) sums the j-th chunk of G/32 rows of column c (a row segment of 32
+// columns is one 128-byte line), the 32 chunk sums of a column are scanned in LDS, then the rows are rewritten.
+__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count) {
+    __shared__ uint32_t sums[32][33];
+    const uint32_t c = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const uint32_t p = blockIdx.x * 32 + c;
+    const uint32_t chunk = (G + 31) / 32, g0 = j * chunk, g1 = g0 + chunk < G ? g0 + chunk : G;
+    uint32_t s = 0;
+    if (p < NP)
+        for (uint32_t g = g0; g < g1; g++) s += wg_hist[(size_t)g * NP + p];
+    sums[j][c] = s;
+    __syncthreads();
+    if (j == 0) {                                  // 32 threads, one per column: serial exclusive scan over the 32 chunks
+        uint32_t run = 0;
+        for (uint32_t q = 0; q < 32; q++) {
+            uint32_t v = sums[q][c];
+            sums[q][c] = run;
+            run += v;
+        }
+        if (p < NP) part_count[p] = run;
+    }
+    __syncthreads();
+    if (p < NP) {
+        uint32_t run = sums[j][c];
+        for (uint32_t g = g0; g < g1; g++) {
+            uint32_t v = wg_hist[(size_t)g * NP + p];
+            wg_hist[(size_t)g * NP + p] = run;
+            run += v;
+        }
+    }
+}
+// exclusive scan of <= 1024 partition counts
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NP, uint32_t* part_base) {
     __shared__ uint32_t sh[1024];
     uint32_t t = threadIdx.x, v = t < NP ? part_count[t] : 0;
     sh[t] = v;
@@ -152,40 +182,25 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
         sh[t] += x;
         __syncthreads();
     }
-    if (t < NP) {
-        part_base[t] = sh[t] - v;
-        part_cursor[t] = sh[t] - v;
-    }
+    if (t < NP) part_base[t] = sh[t] - v;
     if (t == NP - 1) part_base[NP] = sh[t];
 }
+// one pass: the slot of a pair is part_base[p] + (pairs of partition p in earlier workgroups) + its rank inside this
+// workgroup (LDS atomic) -- no global atomics, no second digit pass
 __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                             uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
-                                                            uint32_t* part_cursor, uint2* entries) {
-    __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
-    __shared__ uint32_t lbase[1u << MSM_MAX_PART_BITS];
-    for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
+                                                            const uint32_t* part_base, const uint32_t* wg_hist, uint2* entries) {
+    __shared__ uint32_t lcur[1u << MSM_MAX_PART_BITS];
+    for (uint32_t p = threadIdx.x; p < NP; p += 256) lcur[p] = part_base[p] + wg_hist[(size_t)blockIdx.x * NP + p];
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-        uint32_t neg;
-        fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, wp, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < NP; p += 256) {
-        uint32_t cnt = lh[p];
-        lbase[p] = cnt ? atomicAdd(&part_cursor[p], cnt) : 0u;
-        lh[p] = 0;
-    }
-    __syncthreads();
     const uint32_t PB = 31 - __clz(NP);
     for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
         msm_foreach_digit(s, neg, wp, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
-            uint32_t p = bucket & (NP - 1);
-            uint32_t r = atomicAdd(&lh[p], 1u);
-            entries[lbase[p] + r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket >> PB);
+            uint32_t slot = atomicAdd(&lcur[bucket & (NP - 1)], 1u);
+            entries[slot] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket >> PB);
         });
     }
 }
@@ -530,12 +545,17 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const uint32_t nA = 1u << rg.wA, nT = 1u << (rg.wB + rg.wC);
     const uint32_t n_partA = nA * rg.GA, n_partT = nT * rg.GT;
     const uint32_t nplanes = 1 + bits;
+    // ---- sort geometry: sgrid workgroups, each owning per_block consecutive scalars ----
+    unsigned sgrid = (unsigned)c->num_cus * 4;
+    if ((size_t)sgrid * 256 > n) sgrid = cdiv(n, 256);
+    const size_t per_block = ((n + sgrid - 1) / sgrid + 255) / 256 * 256;
+    sgrid = cdiv(n, per_block);
     // ---- carve scratch ----
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
-    size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_pcur = carve((NP + 1) * 4);
+    size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_wgh = carve((size_t)sgrid * NP * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256);
     size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x_t));
@@ -549,7 +569,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     uint2* entries = (uint2*)(S + o_ent);
     uint32_t* vals = (uint32_t*)(S + o_vals);
     uint32_t* offs = (uint32_t*)(S + o_offs);
-    uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *pcur = (uint32_t*)(S + o_pcur);
+    uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *wghist = (uint32_t*)(S + o_wgh);
     uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt);
     uint32_t* lfirst = (uint32_t*)(S + o_lfirst);
     g1x_t *bkt = (g1x_t*)(S + o_bkt), *head = (g1x_t*)(S + o_head), *tail = (g1x_t*)(S + o_tail);
@@ -562,19 +582,15 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
         EZ_HIP(hipEventRecord(m0, st));
     }
-    EZ_HIP(hipMemsetAsync(pcnt, 0, (NP + 1) * 4, st));
     EZ_HIP(hipMemsetAsync(hcnt, 0, 4, st));
     EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x_t), st));          // empty buckets = identity (ZZ = 0)
     EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x_t), st));
     // sort
-    unsigned sgrid = (unsigned)c->num_cus * 4;
-    if ((size_t)sgrid * 256 > n) sgrid = cdiv(n, 256);
-    size_t per_block = ((n + sgrid - 1) / sgrid + 255) / 256 * 256;
-    sgrid = cdiv(n, per_block);
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, pcnt);
-    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase, pcur);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NP, 32)), dim3(1024), 0, st, wghist, sgrid, NP, pcnt);
+    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase);
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, base_offset, T->n,
-                       pcur, entries);
+                       pbase, wghist, entries);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
