@@ -146,4 +146,58 @@ EZ_D void st_g1x(g1x_t* p, const g1x_t& v) {
     st_fe(&p->x, v.x); st_fe(&p->y, v.y); st_fe(&p->zz, v.zz); st_fe(&p->zzz, v.zzz);
 }
 
+// ---- moving points between lanes -------------------------------------------------------------------
+// A g1x_t is 128 bytes.  An LDS array of g1x_t makes lane i touch dwords 32i..32i+31: every lane of a wave lands in the
+// same banks and each 16-byte access serialises 64 ways -- measured: a 6-level LDS tree of additions took 4x the time of
+// the additions themselves.  So: inside a wave points move by lane shuffles; across waves they go through LDS in
+// "plane" layout, uint4 plane k of slot t at base[k * nslots + t] (consecutive lanes, consecutive 16-byte words).
+EZ_D g1x_t g1x_shfl_xor(const g1x_t& p, uint32_t mask) {
+    g1x_t r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        r.x.v[k] = __shfl_xor(p.x.v[k], mask);
+        r.y.v[k] = __shfl_xor(p.y.v[k], mask);
+        r.zz.v[k] = __shfl_xor(p.zz.v[k], mask);
+        r.zzz.v[k] = __shfl_xor(p.zzz.v[k], mask);
+    }
+    return r;
+}
+EZ_D void g1x_lds_store(uint4* base, uint32_t slot, uint32_t nslots, const g1x_t& p) {
+    const fe_t* f = &p.x;               // x, y, zz, zzz are contiguous fe_t
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        base[(2 * k) * nslots + slot] = make_uint4(f[k].v[0], f[k].v[1], f[k].v[2], f[k].v[3]);
+        base[(2 * k + 1) * nslots + slot] = make_uint4(f[k].v[4], f[k].v[5], f[k].v[6], f[k].v[7]);
+    }
+}
+EZ_D g1x_t g1x_lds_load(const uint4* base, uint32_t slot, uint32_t nslots) {
+    g1x_t r;
+    fe_t* f = &r.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint4 lo = base[(2 * k) * nslots + slot], hi = base[(2 * k + 1) * nslots + slot];
+        f[k].v[0] = lo.x; f[k].v[1] = lo.y; f[k].v[2] = lo.z; f[k].v[3] = lo.w;
+        f[k].v[4] = hi.x; f[k].v[5] = hi.y; f[k].v[6] = hi.z; f[k].v[7] = hi.w;
+    }
+    return r;
+}
+// Sum over each aligned group of `width` lanes (a power of two <= 64) as a butterfly: EVERY lane adds at every level
+// and every lane ends with the group total.  Deliberately not the usual halving tree: measured on MI355X, the same
+// dependent chain of additions runs 2.3x slower when most lanes are masked off than when all 64 lanes execute it
+// (tools/ec_probe.py, ecaddv vs ecaddx) -- the redundant lanes are free and keep the chain at full speed.
+EZ_D g1x_t g1x_group_sum(g1x_t acc, uint32_t width) {
+#pragma unroll 1
+    for (uint32_t s = width >> 1; s > 0; s >>= 1) acc = g1x_add(acc, g1x_shfl_xor(acc, s));
+    return acc;
+}
+// sum over the 256 threads of a workgroup, valid in every thread; sh: 8 * 4 uint4 (one slot per wave)
+EZ_D g1x_t g1x_block256_sum(g1x_t acc, uint4* sh) {
+    acc = g1x_group_sum(acc, 64);
+    if ((threadIdx.x & 63) == 0) g1x_lds_store(sh, threadIdx.x >> 6, 4, acc);
+    __syncthreads();
+    acc = g1x_lds_load(sh, threadIdx.x & 3, 4);
+    __syncthreads();
+    return g1x_group_sum(acc, 4);
+}
+
 }  // namespace ezkl

@@ -335,20 +335,14 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
 // heavily skewed buckets (e.g. thousands of equal witness values): one workgroup folds the lane partials
 __global__ __launch_bounds__(256) void msm_fixup_heavy_kernel(const uint32_t* offsets, uint32_t L, const g1x_t* head, const g1x_t* tail,
                                                               const uint32_t* heavy_list, const uint32_t* heavy_count, g1x_t* buckets) {
-    __shared__ g1x_t sh[256];
+    __shared__ uint4 sh[8 * 4];
     for (uint32_t h = blockIdx.x; h < *heavy_count; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
         g1x_t acc = threadIdx.x == 0 ? ld_g1x(tail + t1) : g1x_identity();
         for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256) acc = g1x_add(acc, ld_g1x(head + t));
-        sh[threadIdx.x] = acc;
-        __syncthreads();
-        for (uint32_t s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) st_g1x(buckets + b, sh[0]);
-        __syncthreads();
+        acc = g1x_block256_sum(acc, sh);
+        if (threadIdx.x == 0) st_g1x(buckets + b, acc);
     }
 }
 
@@ -380,26 +374,26 @@ __global__ __launch_bounds__(256, 4) void msm_reduce1_kernel(const g1x_t* bucket
         st_g1x(partT + (size_t)t * g.GT + grp, acc);
     }
 }
-// one wave per output: S_A[d] = sum_g partA[d][g] (blocks [0, 2^wA)),  T[t] = sum_g partT[t][g] (the rest)
-__global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x_t* partA, const g1x_t* partT, ReduceGeom g, g1x_t* SA, g1x_t* T) {
-    __shared__ g1x_t sh[64];
-    const uint32_t nA = 1u << g.wA;
-    const bool isA = blockIdx.x < nA;
-    const uint32_t o = isA ? blockIdx.x : blockIdx.x - nA, G = isA ? g.GA : g.GT;
-    const g1x_t* src = (isA ? partA : partT) + (size_t)o * G;
+// S_A[d] = sum_g partA[d][g] (blocks [0, blocksA)),  T[t] = sum_g partT[t][g] (the rest): `lanes` lanes of a wave per output
+// (a few serial additions, then a shuffle tree).  The lane counts are chosen by the host so that the launch has at most one
+// wave per SIMD: these chains are latency-bound, and a second wave on a SIMD doubles the latency of both.
+__global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x_t* partA, const g1x_t* partT, ReduceGeom g, g1x_t* SA, g1x_t* T, uint32_t lanesA,
+                                                         uint32_t lanesT, uint32_t blocksA) {
+    const bool isA = blockIdx.x < blocksA;
+    const uint32_t lanes = isA ? lanesA : lanesT, per = 64 / lanes;
+    const uint32_t o = (isA ? blockIdx.x : blockIdx.x - blocksA) * per + threadIdx.x / lanes, j = threadIdx.x % lanes;
+    const uint32_t nout = isA ? (1u << g.wA) : (1u << (g.wB + g.wC)), G = isA ? g.GA : g.GT;
     g1x_t acc = g1x_identity();
-    for (uint32_t i = threadIdx.x; i < G; i += 64) acc = g1x_add(acc, ld_g1x(src + i));
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = 32; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
-        __syncthreads();
+    if (o < nout) {
+        const g1x_t* src = (isA ? partA : partT) + (size_t)o * G;
+        for (uint32_t i = j; i < G; i += lanes) acc = g1x_add(acc, ld_g1x(src + i));
     }
-    if (threadIdx.x == 0) st_g1x((isA ? SA : T) + o, sh[0]);
+    acc = g1x_group_sum(acc, lanes);
+    if (j == 0 && o < nout) st_g1x((isA ? SA : T) + o, acc);
 }
 // one workgroup per plane: planes[0] = TOTAL; planes[1 + ws + j] = sum of the field sums whose digit has bit j
 __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* SA, const g1x_t* T, ReduceGeom g, g1x_t* planes) {
-    __shared__ g1x_t sh[256];
+    __shared__ uint4 sh[8 * 4];
     uint32_t id = blockIdx.x, field = 0, j = 0;      // field 0: TOTAL, 1: A, 2: B, 3: C
     if (id > 0) {
         id -= 1;
@@ -409,23 +403,21 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* SA, const 
     }
     const uint32_t nA = 1u << g.wA, nT = 1u << (g.wB + g.wC);
     g1x_t acc = g1x_identity();
-    if (field <= 1) {
-        for (uint32_t d = threadIdx.x; d < nA; d += 256)
-            if (field == 0 || ((d >> j) & 1)) acc = g1x_add(acc, ld_g1x(SA + d));
+    // every thread walks indices that HAVE the bit (k-th such index: k with a 1 inserted at the bit position), so no
+    // lane idles through the serial part
+    auto with_bit = [](uint32_t k, uint32_t bit) { return ((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)); };
+    if (field == 0) {
+        for (uint32_t d = threadIdx.x; d < nA; d += 256) acc = g1x_add(acc, ld_g1x(SA + d));
+    } else if (field == 1) {
+        for (uint32_t k = threadIdx.x; k < nA / 2; k += 256) acc = g1x_add(acc, ld_g1x(SA + with_bit(k, j)));
     } else {
         const uint32_t sh_bits = field == 2 ? j : g.wB + j;          // t = (dC << wB) | dB
-        for (uint32_t t = threadIdx.x; t < nT; t += 256)
-            if ((t >> sh_bits) & 1) acc = g1x_add(acc, ld_g1x(T + t));
+        for (uint32_t k = threadIdx.x; k < nT / 2; k += 256) acc = g1x_add(acc, ld_g1x(T + with_bit(k, sh_bits)));
     }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (uint32_t s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] = g1x_add(sh[threadIdx.x], sh[threadIdx.x + s]);
-        __syncthreads();
-    }
+    acc = g1x_block256_sum(acc, sh);
     if (threadIdx.x == 0) {
         const uint32_t ws = field == 1 ? g.wsA : field == 2 ? g.wsB : g.wsC;
-        st_g1x(planes + (field == 0 ? 0u : 1u + ws + j), sh[0]);
+        st_g1x(planes + (field == 0 ? 0u : 1u + ws + j), acc);
     }
 }
 
@@ -609,7 +601,14 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     {
         const uint32_t th = n_partA > n_partT ? n_partA : n_partT;
         hipLaunchKernelGGL(msm_reduce1_kernel, dim3(cdiv(th, 256), 2), dim3(256), 0, st, bkt, rg, partA, partT);
-        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(nA + nT), dim3(64), 0, st, partA, partT, rg, SA, TT);
+        auto pow2_le = [](uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; };
+        uint32_t lanesA = pow2_le(rg.GA < 64 ? rg.GA : 64), lanesT = pow2_le(rg.GT < 64 ? rg.GT : 64);
+        auto waves = [&](uint32_t nout, uint32_t lanes) { return cdiv(nout, 64 / lanes); };
+        while (waves(nA, lanesA) + waves(nT, lanesT) > (unsigned)c->num_cus * 4 && (lanesA > 1 || lanesT > 1)) {
+            if (lanesT > 1 && waves(nT, lanesT) >= waves(nA, lanesA)) lanesT >>= 1; else if (lanesA > 1) lanesA >>= 1; else lanesT >>= 1;
+        }
+        const uint32_t blocksA = waves(nA, lanesA);
+        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT)), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA);
         hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes), dim3(256), 0, st, SA, TT, rg, planes);
     }
     EZ_HIP(hipGetLastError());

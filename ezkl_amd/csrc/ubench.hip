@@ -78,6 +78,30 @@ __global__ __launch_bounds__(256) void ub_ecadd_kernel(g1x_t* io, int iters) {
     st_g1x(io + i, a);
 }
 
+// the shape of the reduce tail: one wave per block, a 6-level shuffle tree of general additions
+__global__ __launch_bounds__(64) void ub_ectree_kernel(g1x_t* io) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    g1x_t acc = g1x_group_sum(ld_g1x(io + i), 64);
+    if (threadIdx.x == 0) st_g1x(io + i, acc);
+}
+
+// variants that separate the cost of the lane exchange from the cost of the partial EXEC mask
+__global__ __launch_bounds__(64) void ub_ectree_u_kernel(g1x_t* io) {     // all lanes add at every level
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    g1x_t acc = ld_g1x(io + i);
+#pragma unroll 1
+    for (uint32_t s = 32; s > 0; s >>= 1) acc = g1x_add(acc, g1x_shfl_xor(acc, s ^ 63));
+    st_g1x(io + i, acc);
+}
+__global__ __launch_bounds__(64) void ub_ectree_v_kernel(g1x_t* io, uint32_t lim) {     // no exchange, partial EXEC mask only (lim = 0)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;                           // or the same branch with all lanes in (lim = 64)
+    g1x_t acc = ld_g1x(io + i), b = ld_g1x(io + i + 1);
+#pragma unroll 1
+    for (uint32_t s = 32; s > 0; s >>= 1)
+        if (threadIdx.x < (s | lim)) acc = g1x_add(acc, b);
+    st_g1x(io + i, acc);
+}
+
 int ubench(Ctx* c, const char* which, double* out) {
     hipStream_t st = c->stream;
     hipEvent_t e0, e1;
@@ -111,8 +135,9 @@ int ubench(Ctx* c, const char* which, double* out) {
     }
     if (!strncmp(which, "ecadd", 5)) {         // "ecadd<iters>[w|f]": microseconds of the 4th launch; w = one wave, f = full GPU
         const int iters = atoi(which + 5);
-        const bool full = which[strlen(which) - 1] == 'f';
-        const int eb = full ? c->num_cus * 4 : 1, et = full ? 256 : 64;
+        const char mode = which[strlen(which) - 1];       // w: one wave, f: 4 waves per SIMD, h: one wave per SIMD, q: one wave per CU
+        const bool full = mode == 'f';
+        const int eb = full ? c->num_cus * 4 : mode == 'h' ? c->num_cus * 4 : mode == 'q' ? c->num_cus : 1, et = full ? 256 : 64;
         void* buf = nullptr;
         const size_t cnt = (size_t)eb * et + 1;
         EZ_HIP(hipMalloc(&buf, cnt * sizeof(g1x_t)));
@@ -128,7 +153,11 @@ int ubench(Ctx* c, const char* which, double* out) {
         }
         for (int rep = 0; rep < 4; rep++) {
             EZ_HIP(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(ub_ecadd_kernel, dim3(eb), dim3(et), 0, st, (g1x_t*)buf, iters);
+            if (which[5] == 't') hipLaunchKernelGGL(ub_ectree_kernel, dim3(eb), dim3(64), 0, st, (g1x_t*)buf);
+            else if (which[5] == 'u') hipLaunchKernelGGL(ub_ectree_u_kernel, dim3(eb), dim3(64), 0, st, (g1x_t*)buf);
+            else if (which[5] == 'v') hipLaunchKernelGGL(ub_ectree_v_kernel, dim3(eb), dim3(64), 0, st, (g1x_t*)buf, 0u);
+            else if (which[5] == 'x') hipLaunchKernelGGL(ub_ectree_v_kernel, dim3(eb), dim3(64), 0, st, (g1x_t*)buf, 64u);
+            else hipLaunchKernelGGL(ub_ecadd_kernel, dim3(eb), dim3(et), 0, st, (g1x_t*)buf, iters);
             EZ_HIP(hipEventRecord(e1, st));
             EZ_HIP(hipStreamSynchronize(st));
             EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
