@@ -118,6 +118,23 @@ __device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, c
     }
 }
 
+// one window of the recoding above, for loops that interleave several scalars: returns whether the digit is non-zero
+__device__ __forceinline__ bool msm_digit_step(const fe_t& s, uint32_t neg, uint32_t off, uint32_t c, uint32_t& carry, uint32_t& bucket,
+                                               uint32_t& sign) {
+    const uint32_t half = 1u << (c - 1);
+    const uint32_t raw = get_bits(s, off, c) + carry;
+    if (raw > half) {
+        carry = 1;
+        bucket = (1u << c) - raw - 1u;
+        sign = neg ^ 1u;
+        return raw != (1u << c);
+    }
+    carry = 0;
+    bucket = raw - 1u;
+    sign = neg;
+    return raw != 0;
+}
+
 // ---- sort pass 1: partition (bucket, payload) pairs by the LOW bits of the bucket id -------------
 // (low bits are uniformly populated even when the top window or a skewed witness concentrates the bucket
 // values in a small numeric range, so the partitions stay balanced).  Buckets are stored at position
@@ -130,10 +147,25 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
     for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
-        uint32_t neg;
-        fe_t s = msm_canon(scalars, i, neg);
-        msm_foreach_digit(s, neg, wp, [&](uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&lh[bucket & (NP - 1)], 1u); });
+    for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * 256) {          // four scalars in flight per thread
+        fe_t s[4];
+        uint32_t neg[4], carry[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const size_t i = i0 + (size_t)q * 256;
+            if (i < hi) s[q] = msm_canon(scalars, i, neg[q]);
+            else { s[q] = Fr::zero(); neg[q] = 0; }
+        }
+        uint32_t off = 0;
+        for (uint32_t w = 0; w < wp.W; w++) {
+            const uint32_t c = wp.width(w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t bucket, sign;
+                if (msm_digit_step(s[q], neg[q], off, c, carry[q], bucket, sign)) atomicAdd(&lh[bucket & (NP - 1)], 1u);
+            }
+            off += c;
+        }
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < NP; p += 256) wg_hist[(size_t)blockIdx.x * NP + p] = lh[p];   // row of this workgroup, coalesced
@@ -213,7 +245,14 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
     const uint32_t beg = part_base[p], end = part_base[p + 1];
     for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
     __syncthreads();
-    for (uint32_t e = beg + t; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
+    {
+        uint32_t e = beg + t;
+        for (; e + 3 * 512 < end; e += 4 * 512) {
+            uint32_t y0 = entries[e].y, y1 = entries[e + 512].y, y2 = entries[e + 1024].y, y3 = entries[e + 1536].y;
+            atomicAdd(&cnt[y0], 1u); atomicAdd(&cnt[y1], 1u); atomicAdd(&cnt[y2], 1u); atomicAdd(&cnt[y3], 1u);
+        }
+        for (; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
+    }
     __syncthreads();
     // exclusive scan of cnt[0..nbins): 4 consecutive bins per thread
     uint32_t loc[4], s = 0;
@@ -243,7 +282,14 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
     }
     if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
     __syncthreads();
-    for (uint32_t e = beg + t; e < end; e += 512) {
+    // four entries in flight per thread: the returning LDS atomics and the stores that depend on them overlap
+    uint32_t e = beg + t;
+    for (; e + 3 * 512 < end; e += 4 * 512) {
+        uint2 v0 = entries[e], v1 = entries[e + 512], v2 = entries[e + 1024], v3 = entries[e + 1536];
+        uint32_t p0 = atomicAdd(&cnt[v0.y], 1u), p1 = atomicAdd(&cnt[v1.y], 1u), p2 = atomicAdd(&cnt[v2.y], 1u), p3 = atomicAdd(&cnt[v3.y], 1u);
+        vals[beg + p0] = v0.x; vals[beg + p1] = v1.x; vals[beg + p2] = v2.x; vals[beg + p3] = v3.x;
+    }
+    for (; e < end; e += 512) {
         uint2 v = entries[e];
         uint32_t pos = atomicAdd(&cnt[v.y], 1u);
         vals[beg + pos] = v.x;
