@@ -286,6 +286,35 @@ def eval_polynomial(coeffs_ptr, n, x, stream=None):
     return out
 
 
+def eval_polynomial_batch(coeff_ptrs, n, xs, stream=None):
+    """[eval_polynomial(poly_j, xs[j])] for resident polynomials, one round trip for the whole batch"""
+    m = len(coeff_ptrs)
+    out = np.zeros((m, 4), np.uint64)
+    if m == 0:
+        return out
+    arr = (C.c_void_p * m)(*coeff_ptrs)
+    x = _fe(np.asarray(xs, np.uint64).reshape(m, 4))
+    _l.check(_l.load().ezkl_hip_eval_poly_batch_dev(arr, _p(x), C.c_uint32(m), C.c_size_t(n), _p(out), _stream_ptr(stream)), "ezkl_hip_eval_poly_batch_dev")
+    return out
+
+
+def lincomb(input_ptrs, coeffs, out_ptr, n, accumulate=False, stream=None):
+    """out = (out if accumulate else 0) + sum_j coeffs[j] * inputs[j], fused"""
+    m = len(input_ptrs)
+    arr = (C.c_void_p * max(1, m))(*input_ptrs)
+    cf = _fe(np.asarray(coeffs, np.uint64).reshape(m, 4)) if m else np.zeros((1, 4), np.uint64)
+    _l.check(_l.load().ezkl_hip_lincomb_dev(arr, _p(cf), C.c_uint32(m), _vp(out_ptr), C.c_size_t(n), C.c_int(1 if accumulate else 0), _stream_ptr(stream)),
+             "ezkl_hip_lincomb_dev")
+
+
+def chacha20_fr(key32, stream_id, out_ptr, n, first=0, stream=None):
+    """n uniform Fr elements of ChaCha20 stream `stream_id` under the 32-byte key, starting at element `first`"""
+    key = np.frombuffer(bytes(key32), np.uint8)
+    assert key.size == 32
+    _l.check(_l.load().ezkl_hip_chacha20_fr_dev(_p(key), C.c_uint64(stream_id), C.c_size_t(first), _vp(out_ptr), C.c_size_t(n), _stream_ptr(stream)),
+             "ezkl_hip_chacha20_fr_dev")
+
+
 def batch_invert(ptr, n, stream=None):
     _l.check(_l.load().ezkl_hip_batch_invert_dev(_vp(ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_batch_invert_dev")
 

@@ -437,6 +437,32 @@ int ezkl_hip_eval_poly_dev(const void* coeffs, size_t n, const void* x, void* ou
     return eval_poly(c, pick_stream(c, stream), (const fe_t*)coeffs, n, xx, out);
 }
 
+int ezkl_hip_eval_poly_batch_dev(const void* const* coeffs, const void* xs, uint32_t m, size_t n, void* out, void* stream) {
+    if (m && (!coeffs || !xs || !out)) return EZKL_ERR_INVALID;
+    for (uint32_t j = 0; j < m; j++)
+        if (!coeffs[j] && n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return eval_poly_batch(c, pick_stream(c, stream), (const fe_t* const*)coeffs, (const fe_t*)xs, m, n, out);
+}
+int ezkl_hip_lincomb_dev(const void* const* inputs, const void* coeffs, uint32_t m, void* out, size_t n, int accumulate, void* stream) {
+    if (!out || (m && (!inputs || !coeffs))) return EZKL_ERR_INVALID;
+    for (uint32_t j = 0; j < m; j++)
+        if (!inputs[j]) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = lincomb(c, st, (const fe_t* const*)inputs, (const fe_t*)coeffs, m, (fe_t*)out, n, accumulate);
+    return rc ? rc : finish(c, st, stream);
+}
+int ezkl_hip_chacha20_fr_dev(const void* key32, uint64_t stream_id, size_t first, void* out, size_t n, void* stream) {
+    if (!key32 || (!out && n)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    uint32_t key[8];
+    memcpy(key, key32, 32);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = chacha20_fr(c, st, key, stream_id, first, (fe_t*)out, n);
+    return rc ? rc : finish(c, st, stream);
+}
+
 int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in, void* out, size_t n, void* stream) {
     if (!in || !out || (op != EZKL_VEC_ADD && op != EZKL_VEC_MUL)) return EZKL_ERR_INVALID;
     EZ_CTX(c);

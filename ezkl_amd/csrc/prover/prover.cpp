@@ -373,6 +373,24 @@ struct Backend {
         scale_into(h->ptr(), s, t->ptr(), m);
         vec(EZKL_VEC_ADD, acc->ptr(), t->ptr(), acc->ptr(), m);
     }
+    // out = (accumulate ? out : 0) + sum_j coeffs[j] * polys[j], one fused pass
+    void lincomb(const Col& out, const std::vector<Col>& polys, const std::vector<Fe>& coeffs, size_t m, bool accumulate) const {
+        std::vector<const void*> ptrs;
+        std::vector<U256> cf;
+        for (auto& p_ : polys) ptrs.push_back(p_->ptr());
+        for (auto& c_ : coeffs) cf.push_back(c_.v);
+        check(ezkl_hip_lincomb_dev(ptrs.data(), cf.data(), (uint32_t)ptrs.size(), out->ptr(), m, accumulate ? 1 : 0, nullptr), "ezkl_hip_lincomb_dev");
+    }
+    std::vector<Fe> eval_poly_batch(const std::vector<Col>& polys, const std::vector<Fe>& xs, size_t m) const {
+        std::vector<const void*> ptrs;
+        std::vector<U256> xv;
+        for (auto& p_ : polys) ptrs.push_back(p_->ptr());
+        for (auto& x_ : xs) xv.push_back(x_.v);
+        std::vector<Fe> out(polys.size());
+        if (!polys.empty())
+            check(ezkl_hip_eval_poly_batch_dev(ptrs.data(), xv.data(), (uint32_t)ptrs.size(), m, out.data(), nullptr), "ezkl_hip_eval_poly_batch_dev");
+        return out;
+    }
     void sub_low(const Col& h, const std::vector<Fe>& coeffs) const {           // h[i] -= coeffs[i] for the lowest coefficients
         std::vector<U256> v;
         for (auto& c : coeffs) v.push_back(c.v);
@@ -569,46 +587,75 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
 }
 
 // ------------------------------------------------------------------ randomness
-struct Xoshiro {
-    uint64_t s[4];
-    explicit Xoshiro(uint64_t seed) {
-        if (seed == 0) {
-            std::random_device rd;
-            seed = ((uint64_t)rd() << 32) ^ rd() ^ ((uint64_t)rd() << 17);
-        }
-        for (auto& w : s) {                      // splitmix64 expansion
-            seed += 0x9e3779b97f4a7c15ull;
-            uint64_t z = seed;
-            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-            w = z ^ (z >> 31);
-        }
+// Blinding rows and the vanishing argument's random polynomial.  With a caller-supplied generator (ezkl_rng_fn) the
+// elements come from the callback.  Otherwise they are ChaCha20 output under a 256-bit key -- OS entropy, or derived
+// from the seed (the reference's det-prove feature, /root/reference/src/pfsys/mod.rs:436-439) -- sampled uniformly on
+// [0, r) exactly as ezkl_hip_chacha20_fr_dev does (include/ezkl_hip.h): request number `calls` is stream `calls`, so a
+// short vector made on the host and a whole column expanded on the device are the same function of (key, calls, i).
+static void chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                            (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t x[16];
+    std::memcpy(x, s, sizeof s);
+    auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
     }
-    uint64_t next() {
-        const uint64_t r = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl64(s[3], 45);
-        return r;
-    }
-};
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
 struct Rng {
     ezkl_rng_fn fn;
     void* user;
-    Xoshiro x;
+    uint32_t key[8];
+    uint64_t calls = 0;
+    Rng(ezkl_rng_fn f, void* u, uint64_t seed) : fn(f), user(u) {
+        if (seed == 0) {
+            std::random_device rd;               // /dev/urandom
+            for (auto& w : key) w = rd();
+        } else {
+            uint8_t buf[26] = "ezkl_hip det-prove";
+            for (int i = 0; i < 8; i++) buf[18 + i] = (uint8_t)(seed >> (8 * i));
+            auto h = keccak256(buf, sizeof buf);
+            std::memcpy(key, h.data(), 32);
+        }
+    }
     std::vector<U256> vec(size_t m) {
-        std::vector<U256> out(m);
+        std::vector<U256> out(m, U256{0, 0, 0, 0});
         if (m == 0) return out;
         if (fn) {
             fn(user, out.data(), m);
             for (auto& e : out) invalid(cmp(e, FR.p) >= 0, "rng callback returned a non-canonical residue");
-        } else {
-            for (auto& e : out) {
-                for (auto& l : e) l = x.next();
-                e[3] &= (1ull << 61) - 1;        // 253 uniform bits < r, read as Montgomery residues
+            return out;
+        }
+        const uint64_t stream = calls++;
+        for (size_t i = 0; i < m; i++) {
+            bool done = false;
+            for (uint32_t b = 0; b < 16 && !done; b++) {
+                uint32_t blk[16];
+                chacha20_block(key, (uint64_t)i * 16 + b, stream, blk);
+                for (int h = 0; h < 2 && !done; h++) {
+                    U256 cand;
+                    for (int q = 0; q < 4; q++) cand[q] = (uint64_t)blk[8 * h + 2 * q] | ((uint64_t)blk[8 * h + 2 * q + 1] << 32);
+                    cand[3] &= 0x3fffffffffffffffull;
+                    if (cmp(cand, FR.p) < 0) { out[i] = cand; done = true; }
+                }
             }
         }
         return out;
+    }
+    // a whole column of randomness, made where it lives
+    Col column(const Backend& be, size_t m) {
+        if (fn) return be.upload(vec(m));
+        Col c = be.alloc(m);
+        check(ezkl_hip_chacha20_fr_dev(key, calls++, 0, c->ptr(), m, nullptr), "ezkl_hip_chacha20_fr_dev");
+        return c;
     }
 };
 
@@ -698,43 +745,59 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
     };
     std::vector<Combo> combos;
     for (auto& gr : groups) {
-        Col q = be.zeros(n);
-        std::vector<Fe> evs(gr.pts.size(), Fe::zero());
+        Col q = be.alloc(n);
+        std::vector<Fe> evs(gr.pts.size(), Fe::zero()), cf;
+        std::vector<Col> members;
         Fe pw = Fe::one();
         for (size_t mi : gr.members) {
-            be.axpy(q, pw, polys[mi].poly, n);
+            members.push_back(polys[mi].poly);
+            cf.push_back(pw);
             for (size_t i = 0; i < gr.pts.size(); i++) evs[i] = evs[i] + pw * polys[mi].ev[gr.pts[i]].second;
             pw = pw * ys;
         }
+        be.lincomb(q, members, cf, n, false);
         combos.push_back(Combo{q, interpolate(gr.pts_fe, evs)});
     }
     const Fe v = T.squeeze_challenge();
-    Col h = be.zeros(n);
+    Col h = be.alloc(n);
     Fe pw = Fe::one();
-    for (size_t gi = 0; gi < groups.size(); gi++) {
-        Col t = be.clone(combos[gi].q);
-        be.sub_low(t, combos[gi].r);
-        for (auto& z : groups[gi].pts_fe) be.kate_div(t, z, n);
-        be.axpy(h, pw, t, n);
-        pw = pw * v;
+    {
+        std::vector<Col> ts;
+        std::vector<Fe> cf;
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            Col t = be.clone(combos[gi].q);
+            be.sub_low(t, combos[gi].r);
+            for (auto& z : groups[gi].pts_fe) be.kate_div(t, z, n);
+            ts.push_back(t);
+            cf.push_back(pw);
+            pw = pw * v;
+        }
+        be.lincomb(h, ts, cf, n, false);
     }
     T.write_point(be.commit({h})[0]);
     const Fe u = T.squeeze_challenge();
     Fe zt_u = Fe::one();
     for (auto& z : all_pts) zt_u = zt_u * (u - pt_fe[z]);
-    Col L = be.zeros(n);
+    Col L = be.alloc(n);
     pw = Fe::one();
     Fe const_term = Fe::zero();
-    for (size_t gi = 0; gi < groups.size(); gi++) {
-        Fe zdiff = Fe::one();
-        for (auto& z : all_pts)
-            if (!std::binary_search(groups[gi].pts.begin(), groups[gi].pts.end(), z, u256_less)) zdiff = zdiff * (u - pt_fe[z]);
-        be.axpy(L, pw * zdiff, combos[gi].q, n);
-        const_term = const_term + pw * zdiff * eval_small(combos[gi].r, u);
-        pw = pw * v;
+    {
+        std::vector<Col> terms;
+        std::vector<Fe> cf;
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            Fe zdiff = Fe::one();
+            for (auto& z : all_pts)
+                if (!std::binary_search(groups[gi].pts.begin(), groups[gi].pts.end(), z, u256_less)) zdiff = zdiff * (u - pt_fe[z]);
+            terms.push_back(combos[gi].q);
+            cf.push_back(pw * zdiff);
+            const_term = const_term + pw * zdiff * eval_small(combos[gi].r, u);
+            pw = pw * v;
+        }
+        terms.push_back(h);
+        cf.push_back(-zt_u);
+        be.lincomb(L, terms, cf, n, false);
     }
     be.sub_low(L, {const_term});
-    be.axpy(L, -zt_u, h, n);
     be.kate_div(L, u, n);
     T.write_point(be.commit({L})[0]);
 }
@@ -989,7 +1052,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     }
     sw.lap(3);
     // 5. vanishing argument: random polynomial;  6. y
-    Col rnd = be.upload(rng.vec(n));
+    Col rnd = rng.column(be, n);
     T.write_point(be.commit({rnd})[0]);
     const Fe y = T.squeeze_challenge();
     sw.lap(4);
@@ -1024,54 +1087,63 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     const Fe x = T.squeeze_challenge();
     const Fe w = omega(k);
     auto rot_point = [&](int32_t r) { return x * w.pow((uint64_t)(r >= 0 ? (uint32_t)r % n : n - ((uint32_t)(-r) % n))); };
-    // 9. evaluations
+    // 9. evaluations: every (polynomial, point) of this round in ONE batched call, then written in transcript order
+    const Fe xn = x.pow((uint64_t)n);
+    Col hcomb = be.alloc(n);                       // h(X) = sum_i x^(n i) * piece_i(X): what the verifier reconstructs from the pieces
+    {
+        std::vector<Fe> cf;
+        Fe p = Fe::one();
+        for (uint32_t i = 0; i < npieces; i++) { cf.push_back(p); p = p * xn; }
+        be.lincomb(hcomb, pieces, cf, n, false);
+    }
+    std::vector<Col> ev_polys;
+    std::vector<Fe> ev_pts;
+    auto want = [&](const Col& poly, const Fe& pt) { ev_polys.push_back(poly); ev_pts.push_back(pt); return ev_polys.size() - 1; };
+    const Fe x_next = rot_point(1), x_last = rot_point((int32_t)u);
+    for (auto& q : cs.advice_queries) want(adv_polys[q.col], rot_point(q.rot));
+    for (auto& q : cs.fixed_queries) want(pk.fixed_polys[q.col], rot_point(q.rot));
+    want(rnd, x);
+    for (auto& h : pk.sigma_polys) want(h, x);
+    for (size_t j = 0; j < z_polys.size(); j++) {
+        want(z_polys[j], x);
+        want(z_polys[j], x_next);
+        if (j + 1 < z_polys.size()) want(z_polys[j], x_last);
+    }
+    for (size_t i = 0; i < lk.size(); i++) {
+        want(m_polys[i], x);
+        want(phi_polys[i], x);
+        want(phi_polys[i], x_next);
+    }
+    const size_t n_written = ev_polys.size();
+    const size_t h_slot = want(hcomb, x);          // not part of the proof: the verifier derives it
+    const std::vector<Fe> ev = be.eval_poly_batch(ev_polys, ev_pts, n);
+    for (size_t i = 0; i < n_written; i++) T.write_scalar(ev[i]);
+    size_t cursor = 0;
     std::map<std::pair<uint32_t, int32_t>, Fe> adv_evals, fix_evals;
-    for (auto& q : cs.advice_queries) {
-        Fe e = be.eval_poly(adv_polys[q.col], n, rot_point(q.rot));
-        adv_evals[{q.col, q.rot}] = e;
-        T.write_scalar(e);
-    }
-    for (auto& q : cs.fixed_queries) {
-        Fe e = be.eval_poly(pk.fixed_polys[q.col], n, rot_point(q.rot));
-        fix_evals[{q.col, q.rot}] = e;
-        T.write_scalar(e);
-    }
-    const Fe random_eval = be.eval_poly(rnd, n, x);
-    T.write_scalar(random_eval);
+    for (auto& q : cs.advice_queries) adv_evals[{q.col, q.rot}] = ev[cursor++];
+    for (auto& q : cs.fixed_queries) fix_evals[{q.col, q.rot}] = ev[cursor++];
+    const Fe random_eval = ev[cursor++];
     std::vector<Fe> sigma_evals;
-    for (auto& h : pk.sigma_polys) sigma_evals.push_back(be.eval_poly(h, n, x));
-    for (auto& e : sigma_evals) T.write_scalar(e);
+    for (size_t i = 0; i < pk.sigma_polys.size(); i++) sigma_evals.push_back(ev[cursor++]);
     struct ZEval {
         Fe e0, e1, e2;
         bool has2;
     };
     std::vector<ZEval> z_evals;
     for (size_t j = 0; j < z_polys.size(); j++) {
-        ZEval ze{be.eval_poly(z_polys[j], n, x), be.eval_poly(z_polys[j], n, rot_point(1)), Fe::zero(), false};
-        T.write_scalar(ze.e0);
-        T.write_scalar(ze.e1);
-        if (j + 1 < z_polys.size()) {
-            ze.e2 = be.eval_poly(z_polys[j], n, rot_point((int32_t)u));
-            ze.has2 = true;
-            T.write_scalar(ze.e2);
-        }
+        ZEval ze{ev[cursor], ev[cursor + 1], Fe::zero(), j + 1 < z_polys.size()};
+        cursor += 2;
+        if (ze.has2) ze.e2 = ev[cursor++];
         z_evals.push_back(ze);
     }
     std::vector<std::array<Fe, 3>> lk_evals;
     for (size_t i = 0; i < lk.size(); i++) {
-        std::array<Fe, 3> e = {be.eval_poly(m_polys[i], n, x), be.eval_poly(phi_polys[i], n, x), be.eval_poly(phi_polys[i], n, rot_point(1))};
-        for (auto& v_ : e) T.write_scalar(v_);
-        lk_evals.push_back(e);
+        lk_evals.push_back({ev[cursor], ev[cursor + 1], ev[cursor + 2]});
+        cursor += 3;
     }
+    const Fe h_eval = ev[h_slot];
     sw.lap(8);
     // 10. multiopen (SHPLONK)
-    const Fe xn = x.pow((uint64_t)n);
-    Col hcomb = be.zeros(n);
-    for (uint32_t i = npieces; i-- > 0;) {
-        be.scale(hcomb, xn, n);
-        be.axpy(hcomb, Fe::one(), pieces[i], n);
-    }
-    const Fe h_eval = be.eval_poly(hcomb, n, x);
     enum : uint32_t { K_ADV = 1, K_FIX, K_H, K_RND, K_SIGMA, K_Z, K_M, K_PHI };
     std::vector<OpenQuery> qs;     // the verifier rebuilds the same list with commitments for polynomials
     for (auto& q : cs.advice_queries) qs.push_back({{K_ADV, q.col}, adv_polys[q.col], rot_point(q.rot), adv_evals[{q.col, q.rot}]});
@@ -1165,7 +1237,7 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
     if (pk->pk->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
     return guarded([&] {
         invalid(ezkl_hip_bases_len(g) < pk->pk->cs->n || ezkl_hip_bases_len(g_lagrange) != pk->pk->cs->n, "SRS size does not match 2^k");
-        Rng r{rng, rng_user, Xoshiro(rng ? 1 : seed)};
+        Rng r(rng, rng_user, seed);
         std::vector<uint8_t> proof = create_proof(*pk->pk, g, g_lagrange, advice, advice_fn, advice_user, instances, instance_lens, r, timings);
         *proof_len = proof.size();
         if (proof.size() > cap || !proof_out) throw Error(EZKL_ERR_NOMEM, "proof buffer too small");

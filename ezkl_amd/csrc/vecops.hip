@@ -327,4 +327,119 @@ int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& 
     return arena_done(c->aux, st);
 }
 
+// m evaluations (polynomial j at point xs[j], all of length n) with ONE upload of the x-power tables, ONE download and
+// ONE stream synchronisation: create_proof step 10 issues dozens of these back to back
+int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_t* xs, uint32_t m, size_t n, void* out_host) {
+    if (m == 0) return EZKL_OK;
+    if (n == 0) { memset(out_host, 0, 32 * (size_t)m); return EZKL_OK; }
+    const size_t nseg = (n + EVP_SEG - 1) / EVP_SEG;
+    const unsigned blocks = cdiv(nseg, 256);
+    uint32_t npow = 0;
+    while (((size_t)1 << npow) < nseg) npow++;
+    const size_t pws = npow ? npow : 1;
+    std::vector<fe_t> pw(pws * m);
+    for (uint32_t j = 0; j < m; j++) {
+        fe_t p = xs[j];
+        for (int i = 0; i < 5; i++) p = Fr::sqr(p);          // x^32
+        for (uint32_t b = 0; b < npow; b++) { pw[j * pws + b] = p; p = Fr::sqr(p); }
+    }
+    fe_t* d = nullptr;
+    int rc = arena_reserve(c->aux, (pw.size() + (size_t)m * blocks + m) * sizeof(fe_t), st, (void**)&d);
+    if (rc) return rc;
+    fe_t *d_pw = d, *d_part = d + pw.size(), *d_out = d_part + (size_t)m * blocks;
+    EZ_HIP(hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    for (uint32_t j = 0; j < m; j++) {
+        hipLaunchKernelGGL(eval_poly_kernel, dim3(blocks), dim3(256), 0, st, coeffs[j], n, xs[j], d_pw + j * pws, npow, d_part + (size_t)j * blocks);
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, d_part + (size_t)j * blocks, (size_t)blocks, d_out + j);
+    }
+    hipError_t e = hipMemcpyAsync(out_host, d_out, 32 * (size_t)m, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return set_hip_error(e, "eval_poly_batch", __FILE__, __LINE__);
+    return arena_done(c->aux, st);
+}
+
+// ---- fused linear combination: out[i] (+)= sum_j coeff[j] * in_j[i]  (SHPLONK's per-rotation-set combinations and
+//      final L(X), the x^n-Horner over the quotient pieces): every input is read once, the output written once,
+//      instead of a scale + add pass (160 B of traffic per element) per term ----
+static constexpr uint32_t LINCOMB_MAX = 16;
+struct LincombArgs {
+    const fe_t* in[LINCOMB_MAX];
+    fe_t coeff[LINCOMB_MAX];
+    uint32_t m;
+    int accumulate;
+};
+__global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs a, fe_t* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        fe_t acc = a.accumulate ? ld_fe(out + i) : Fr::zero();
+        for (uint32_t j = 0; j < a.m; j++) acc = Fr::add(acc, Fr::mul(ld_fe(a.in[j] + i), a.coeff[j]));
+        st_fe(out + i, acc);
+    }
+}
+int lincomb(Ctx* c, hipStream_t st, const fe_t* const* in, const fe_t* coeffs, uint32_t m, fe_t* out, size_t n, int accumulate) {
+    if (n == 0) return EZKL_OK;
+    if (m == 0 && !accumulate) return vec_fill(c, st, out, Fr::zero(), n);
+    for (uint32_t j0 = 0; j0 < m; j0 += LINCOMB_MAX) {
+        LincombArgs a;
+        a.m = m - j0 < LINCOMB_MAX ? m - j0 : LINCOMB_MAX;
+        a.accumulate = (accumulate || j0 > 0) ? 1 : 0;
+        for (uint32_t j = 0; j < a.m; j++) { a.in[j] = in[j0 + j]; a.coeff[j] = coeffs[j0 + j]; }
+        hipLaunchKernelGGL(lincomb_kernel, dim3(stream_grid(c, n)), dim3(256), 0, st, a, out, n);
+    }
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+
+// ---- uniform field elements from ChaCha20 (blinding rows, the vanishing argument's random polynomial: halo2 draws them
+//      from OsRng on the host, 32 MiB per random polynomial at k = 20; here the host supplies a 256-bit key and the keystream
+//      is expanded where the column lives) ----
+// DJB layout: words 12,13 = 64-bit block counter, words 14,15 = 64-bit stream id.  Element i owns blocks 16 i .. 16 i + 15;
+// candidate j (0..31) = 8 words of block j >> 1 (upper half for odd j), top two bits cleared; the first candidate < r wins
+// (rejection sampling: uniform on [0, r), acceptance 0.76 per try; all 32 failing -- probability 1e-20 -- yields 0).
+__host__ __device__ inline void chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#define EZ_ROTL(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define EZ_QR(a, b, c, d) \
+    a += b; d ^= a; d = EZ_ROTL(d, 16); c += d; b ^= c; b = EZ_ROTL(b, 12); a += b; d ^= a; d = EZ_ROTL(d, 8); c += d; b ^= c; b = EZ_ROTL(b, 7);
+    for (int r = 0; r < 10; r++) {
+        EZ_QR(x[0], x[4], x[8], x[12]) EZ_QR(x[1], x[5], x[9], x[13]) EZ_QR(x[2], x[6], x[10], x[14]) EZ_QR(x[3], x[7], x[11], x[15])
+        EZ_QR(x[0], x[5], x[10], x[15]) EZ_QR(x[1], x[6], x[11], x[12]) EZ_QR(x[2], x[7], x[8], x[13]) EZ_QR(x[3], x[4], x[9], x[14])
+    }
+#undef EZ_QR
+#undef EZ_ROTL
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+struct ChachaKey {
+    uint32_t k[8];
+};
+__global__ __launch_bounds__(256) void chacha20_fr_kernel(ChachaKey key, uint64_t stream, size_t first, fe_t* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        fe_t v = Fr::zero();
+        bool done = false;
+        for (uint32_t b = 0; b < 16 && !done; b++) {
+            uint32_t blk[16];
+            chacha20_block(key.k, (uint64_t)(first + i) * 16 + b, stream, blk);
+            for (uint32_t h = 0; h < 2 && !done; h++) {
+                fe_t cand;
+                for (int q = 0; q < 8; q++) cand.v[q] = blk[8 * h + q];
+                cand.v[7] &= 0x3fffffffu;
+                uint32_t br = 0;
+                for (int q = 0; q < 8; q++) (void)subb32(cand.v[q], FrP::MOD[q], br);
+                if (br) { v = cand; done = true; }          // cand < r
+            }
+        }
+        st_fe(out + i, v);
+    }
+}
+int chacha20_fr(Ctx* c, hipStream_t st, const uint32_t key[8], uint64_t stream, size_t first, fe_t* out, size_t n) {
+    if (n == 0) return EZKL_OK;
+    ChachaKey k;
+    memcpy(k.k, key, 32);
+    hipLaunchKernelGGL(chacha20_fr_kernel, dim3(stream_grid(c, n)), dim3(256), 0, st, k, stream, first, out, n);
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+
 }  // namespace ezkl

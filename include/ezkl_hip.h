@@ -117,6 +117,21 @@ int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_i
 /* halo2 eval_polynomial(poly, x): sum_i coeffs[i] * x^i for a resident coefficient vector; x and the 32-byte result
  * are host memory (create_proof evaluates every queried (column, rotation) this way before SHPLONK) */
 int ezkl_hip_eval_poly_dev(const void* coeffs_dev, size_t n, const void* x_host, void* out_host, void* stream);
+/* m evaluations in one call: polynomial j (n coefficients, resident) at xs[j] (host, m x 32 B) -> out_host[j]; one upload,
+ * one download, one synchronisation for the whole batch of create_proof's step 10 */
+int ezkl_hip_eval_poly_batch_dev(const void* const* coeffs_dev, const void* xs_host, uint32_t m, size_t n, void* out_host, void* stream);
+/* out[i] = (accumulate ? out[i] : 0) + sum_j coeffs[j] * inputs[j][i]: the linear combinations of SHPLONK
+ * (ProverSHPLONK::create_proof) and the x^n-Horner over the quotient pieces, each input read once.  inputs: m DEVICE
+ * pointers in host memory; coeffs: m x 32 B host */
+int ezkl_hip_lincomb_dev(const void* const* inputs_dev, const void* coeffs_host, uint32_t m, void* out_dev, size_t n, int accumulate,
+                         void* stream);
+/* out[i] = uniform element of Fr, i < n, expanded from a 256-bit key with ChaCha20 (64-bit block counter, 64-bit stream
+ * id): element (first + i) owns blocks 16(first+i) .. +15; its 32 candidates are the 8-word halves of those blocks with
+ * the top two bits cleared; the first candidate < r is taken (rejection sampling => uniform on [0, r)).  Replaces the
+ * host-side OsRng loop of halo2 (blinding rows; vanishing::Argument::commit's random polynomial, 2^k elements) by a
+ * keystream expanded where the column lives; the caller provides the key (OS entropy, or a seed for det-prove,
+ * /root/reference/src/pfsys/mod.rs:436-439). */
+int ezkl_hip_chacha20_fr_dev(const void* key32, uint64_t stream_id, size_t first, void* out_dev, size_t n, void* stream);
 /* Montgomery batch inversion (zeros stay zero), in place */
 int ezkl_hip_batch_invert_dev(void* a_dev, size_t n, void* stream);
 

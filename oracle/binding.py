@@ -135,6 +135,11 @@ def kate_div(a, z):
     lib.oracle_kate_div(_ptr(a), C.c_size_t(a.shape[0]), _ptr(z)); return a
 
 
+def vec_add(a, b):
+    a, b = _fe(a), _fe(b); o = np.empty_like(a)
+    lib.oracle_vec_add(_ptr(a), _ptr(b), _ptr(o), C.c_size_t(a.shape[0])); return o
+
+
 def vec_scale(a, s):
     a, s = _fe(a), _fe(s); o = np.empty_like(a)
     lib.oracle_vec_scale(_ptr(a), _ptr(s), _ptr(o), C.c_size_t(a.shape[0])); return o
@@ -185,6 +190,16 @@ def eval_program(code, n_intermediates, constants, rotations, columns, challenge
 
 def num_threads():
     return int(lib.oracle_num_threads())
+
+
+def chacha20_block(key32, counter, stream):
+    key = np.frombuffer(bytes(key32), np.uint32).copy(); out = np.zeros(16, np.uint32)
+    lib.oracle_chacha20_block(_ptr(key), C.c_uint64(counter), C.c_uint64(stream), _ptr(out)); return out
+
+
+def chacha20_fr(key32, stream, n, first=0):
+    key = np.frombuffer(bytes(key32), np.uint32).copy(); out = np.zeros((n, 4), np.uint64)
+    lib.oracle_chacha20_fr(_ptr(key), C.c_uint64(stream), C.c_size_t(first), C.c_size_t(n), _ptr(out)); return out
 
 
 def gen_bases(seed, n, first=0):

@@ -497,6 +497,45 @@ void oracle_eval_program(const oracle_program *p, fe *out) {
     }
 }
 
+/* ------------------------------------------------------------------ ChaCha20 field sampler ---------- */
+/* ChaCha20 block function (D. J. Bernstein; RFC 8439 section 2.3 with the counter/nonce words regrouped as a 64-bit
+ * block counter in words 12,13 and a 64-bit stream id in words 14,15), pinned on the RFC 8439 2.3.2 test vector in
+ * tests/test_oracle.py.  The sampler restates ezkl_hip_chacha20_fr_dev (include/ezkl_hip.h): rejection sampling of
+ * 254-bit candidates against r. */
+void oracle_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                      (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    uint32_t x[16];
+    memcpy(x, s, sizeof s);
+#define ROTL(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define QR(a, b, c, d) a += b; d ^= a; d = ROTL(d, 16); c += d; b ^= c; b = ROTL(b, 12); a += b; d ^= a; d = ROTL(d, 8); c += d; b ^= c; b = ROTL(b, 7);
+    for (int r = 0; r < 10; r++) {
+        QR(x[0], x[4], x[8], x[12]) QR(x[1], x[5], x[9], x[13]) QR(x[2], x[6], x[10], x[14]) QR(x[3], x[7], x[11], x[15])
+        QR(x[0], x[5], x[10], x[15]) QR(x[1], x[6], x[11], x[12]) QR(x[2], x[7], x[8], x[13]) QR(x[3], x[4], x[9], x[14])
+    }
+#undef QR
+#undef ROTL
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+void oracle_chacha20_fr(const uint32_t key[8], uint64_t stream, size_t first, size_t n, fe *out) {
+    for (size_t i = 0; i < n; i++) {
+        fe v;
+        memset(&v, 0, sizeof v);
+        int done = 0;
+        for (uint32_t b = 0; b < 16 && !done; b++) {
+            uint32_t blk[16];
+            oracle_chacha20_block(key, (uint64_t)(first + i) * 16 + b, stream, blk);
+            for (int h = 0; h < 2 && !done; h++) {
+                fe cand;
+                for (int q = 0; q < 4; q++) cand.v[q] = (uint64_t)blk[8 * h + 2 * q] | ((uint64_t)blk[8 * h + 2 * q + 1] << 32);
+                cand.v[3] &= 0x3fffffffffffffffull;
+                if (!f_geq(&cand, &FR.mod)) { v = cand; done = 1; }
+            }
+        }
+        out[i] = v;
+    }
+}
+
 void oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

@@ -266,3 +266,45 @@ def test_lookup_multiplicity(hip, k, ninputs):
     got = m_dev.to_numpy(shape=(n, 4))
     assert missing == miss
     assert [fe_to_int(g) for g in got] == [int(w) for w in want]
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (33, 3), (1000, 17), (1 << 16, 5), ((1 << 18) + 3, 2)])
+def test_eval_polynomial_batch(hip, n, m):
+    """the batched form of create_proof's step 10: same values as one call per (polynomial, point)"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n + m)
+    cols = [rand_fr(rng, n) for _ in range(m)]
+    xs = rand_fr(rng, m)
+    devs = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    got = B.eval_polynomial_batch([d.ptr for d in devs], n, xs)
+    for j in range(m):
+        assert (got[j] == ob.eval_poly(cols[j], xs[j])).all()
+    assert B.eval_polynomial_batch([], n, np.zeros((0, 4), np.uint64)).shape == (0, 4)
+
+
+@pytest.mark.parametrize("n,m,acc", [(1, 1, False), (1000, 3, True), (4097, 16, False), (1 << 16, 17, True), (1 << 18, 40, False), (513, 0, True)])
+def test_lincomb(hip, n, m, acc):
+    """out (+)= sum_j c_j * in_j, fused (SHPLONK combinations) == the oracle's scale / add composition"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n * 31 + m)
+    cols = [rand_fr(rng, n) for _ in range(m)]
+    cf = rand_fr(rng, max(m, 1))[:m]
+    start = rand_fr(rng, n)
+    want = start.copy() if acc else np.zeros((n, 4), np.uint64)
+    for j in range(m):
+        want = ob.vec_add(want, ob.vec_scale(cols[j], cf[j]))
+    devs = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    out = B.DeviceBuffer.from_numpy(start)
+    B.lincomb([d.ptr for d in devs], cf, out.ptr, n, accumulate=acc)
+    assert (out.to_numpy(shape=(n, 4)) == want).all()
+
+
+@pytest.mark.parametrize("n,first", [(1, 0), (1000, 0), (5000, 123456), (1 << 18, 1 << 40)])
+def test_chacha20_field_sampler(hip, n, first):
+    """device keystream expansion == the C restatement (itself pinned on the RFC 8439 vector), element for element"""
+    from ezkl_amd import backend as B
+    key = bytes((7 * i + n) & 0xff for i in range(32))
+    out = B.DeviceBuffer(n * 32)
+    B.chacha20_fr(key, 0xabcdef0123 + n, out.ptr, n, first=first)
+    got = out.to_numpy(shape=(n, 4))
+    assert (got == ob.chacha20_fr(key, 0xabcdef0123 + n, n, first=first)).all()

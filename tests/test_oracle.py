@@ -155,3 +155,30 @@ def test_gen_bases_deterministic_on_curve():
     b = ob.gen_bases(SEED, 300)
     assert all(ob.g1_on_curve(p) for p in b)
     assert (ob.gen_bases(SEED, 100, first=200) == b[200:]).all()
+
+
+def test_chacha20_rfc8439_vector_and_sampler():
+    """the ChaCha20 block function behind ezkl_hip_chacha20_fr_dev, pinned on RFC 8439 section 2.3.2 (key 00..1f,
+    counter 1, nonce 00:00:00:09:00:00:00:4a:00:00:00:00 = our counter_hi / stream words), and the rejection sampler"""
+    blk = ob.chacha20_block(bytes(range(32)), 0x0900000000000001, 0x000000004a000000)
+    want = "e4e7f110 15593bd1 1fdd0f50 c47120a3 c7f4d1c7 0368c033 9aaa2204 4e6cd4c3 466482d2 09aa9f07 05d7c214 a2028bd9 d19c12b5 b94e16de e883d0cb 4e3c50a2"
+    assert " ".join("%08x" % x for x in blk) == want
+    key = bytes(range(100, 132))
+    a = ob.chacha20_fr(key, 3, 2000)
+    vals = [fe_to_int_raw(r) for r in a]
+    assert all(v < R for v in vals) and len(set(vals)) == 2000
+    assert 0.28 < sum(v >> 253 for v in vals) / 2000 < 0.40            # uniform on [0, r): (r - 2^253) / r = 0.34 of the mass above 2^253
+    assert (ob.chacha20_fr(key, 3, 50, first=1000) == a[1000:1050]).all()        # element i depends only on (key, stream, i)
+    assert not (ob.chacha20_fr(key, 4, 10) == a[:10]).all(axis=1).any()
+    # element 0 is the first candidate < r of blocks 0..15
+    cands = []
+    for b in range(16):
+        w = ob.chacha20_block(key, b, 3)
+        for h in range(2):
+            v = int.from_bytes(w[8 * h:8 * h + 8].tobytes(), "little") & ((1 << 254) - 1)
+            cands.append(v)
+    assert vals[0] == next(v for v in cands if v < R)
+
+
+def fe_to_int_raw(a):
+    return int.from_bytes(np.ascontiguousarray(a, np.uint64).tobytes(), "little")
