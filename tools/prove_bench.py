@@ -148,9 +148,12 @@ if "--native" in sys.argv and world == 1:
     NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5))            # warm-up
     ntm = {}
     t0 = time.time(); nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), timings=ntm); t_native = time.time() - t0
-    t0 = time.time(); NV.create_proof(npk, gb_, glb_, adv, seed=5); t_native_librng = time.time() - t0
+    ltm = {}
+    t0 = time.time(); lproof = NV.create_proof(npk, gb_, glb_, adv, seed=5, timings=ltm); t_native_librng = time.time() - t0
     out["native_prover"] = {"prove_seconds": round(t_native, 4), "prove_seconds_library_rng": round(t_native_librng, 4), "keygen_seconds": round(t_nkeygen, 3),
-                            "proof_identical_to_python_prover": nproof == proof, "breakdown_seconds": {a: round(b, 4) for a, b in ntm.items()}}
+                            "proof_identical_to_python_prover": nproof == proof, "library_rng_proof_verifies": bool(V.verify(vk, (1, 2), g2, s_g2, lproof)),
+                            "breakdown_seconds": {a: round(b, 4) for a, b in ntm.items()},
+                            "breakdown_seconds_library_rng": {a: round(b, 4) for a, b in ltm.items()}}
 if "--cpu-kernels" in sys.argv:
     # the C oracle (OpenMP, all host cores) timed on ONE instance of each kernel class at this size, scaled by the call
     # counts the prover actually issued: a bounded CPU sample, not a CPU prover
