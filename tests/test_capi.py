@@ -31,7 +31,7 @@ def test_product_path_does_not_import_oracle():
     """the product package must never reach into oracle/ (parity claims depend on it)"""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ezkl_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h")) or f == "Makefile":
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in src and "import oracle" not in src and "from oracle" not in src, f
 
