@@ -134,6 +134,27 @@ def msm_g1_batch_dev(bases, scalar_ptrs, n, offset=0, stream=None):
     return out
 
 
+class MsmBatch:
+    """incremental commit batch: push resident columns one at a time (uploads of the next column overlap the MSMs of
+    the previous ones), finish() -> (count, 8) affine points"""
+
+    def __init__(self, bases, n, offset=0):
+        self.h = _vp()
+        self.count = 0
+        _l.check(_l.load().ezkl_hip_msm_batch_begin(bases.h, C.c_size_t(offset), C.c_size_t(n), C.byref(self.h)), "ezkl_hip_msm_batch_begin")
+
+    def push(self, scalars_ptr):
+        _l.check(_l.load().ezkl_hip_msm_batch_push_dev(self.h, _vp(scalars_ptr)), "ezkl_hip_msm_batch_push_dev")
+        self.count += 1
+
+    def finish(self, capacity=None):
+        cap = self.count if capacity is None else capacity
+        out = np.zeros((max(cap, 1), 8), np.uint64)
+        h, self.h = self.h, None
+        _l.check(_l.load().ezkl_hip_msm_batch_finish(h, _p(out), C.c_size_t(cap)), "ezkl_hip_msm_batch_finish")
+        return out[:self.count]
+
+
 def msm_g1(bases, scalars):
     """sum_i scalars[i]*bases[i]; scalars numpy (n,4) or a DeviceBuffer-resident vector via msm_dev."""
     s = _fe(scalars)

@@ -304,6 +304,27 @@ int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t bat
     (void)hipFree(d);
     return rc;
 }
+int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_msm_batch_t* out) {
+    if (!h || !out) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (base_offset + n > b->n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    MsmBatch* mb = nullptr;
+    int rc = msm_batch_begin(c, c->stream, b, base_offset, n, &mb);
+    if (!rc) *out = reinterpret_cast<ezkl_msm_batch_t>(mb);
+    return rc;
+}
+int ezkl_hip_msm_batch_push_dev(ezkl_msm_batch_t batch, const void* scalars_dev) {
+    if (!batch || !scalars_dev) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    EZ_HIP(hipStreamSynchronize(c->stream));          // the column was produced on the library stream
+    return msm_batch_push(c, reinterpret_cast<MsmBatch*>(batch), (const fe_t*)scalars_dev);
+}
+int ezkl_hip_msm_batch_finish(ezkl_msm_batch_t batch, void* out, size_t capacity) {
+    if (!batch || (!out && capacity)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_batch_finish(c, reinterpret_cast<MsmBatch*>(batch), out, capacity);
+}
 int ezkl_hip_g1_add_affine(const void* a, const void* b, void* out) {
     if (!a || !b || !out) return EZKL_ERR_INVALID;
     g1_add_affine_host(a, b, out);

@@ -68,6 +68,10 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
             void* out_affine_host);
 int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
                   void* out_host);
+struct MsmBatch;
+int msm_batch_begin(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, size_t n, MsmBatch** out);
+int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev);
+int msm_batch_finish(Ctx* c, MsmBatch* mb, void* out_host, size_t capacity);
 int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o, size_t n);
 int vec_fill(Ctx* c, hipStream_t st, fe_t* o, const fe_t& v, size_t n);
 int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, size_t n);

@@ -672,7 +672,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     return EZKL_OK;
 }
 
+struct MsmBatch;
+static MsmBatch* g_open_batch_fwd();
 int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {
+    if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
     MsmTable* T = nullptr;
     int rc = table_get(c, st, b, &T);
@@ -687,6 +690,7 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
 // over MSM_SLOTS streams.  `st` orders the batch after prior work on the caller's stream.
 int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
                   void* out_host) {
+    if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (batch == 0) return EZKL_OK;
     if (n == 0) { memset(out_host, 0, 64 * batch); return EZKL_OK; }
     MsmTable* T = nullptr;
@@ -705,6 +709,70 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
         }
     }
     return EZKL_OK;
+}
+
+// The same pipeline fed one column at a time: the caller uploads column j+1 (a blocking PCIe copy) while the slots
+// run the MSMs of the columns pushed so far.  One batch may be open per device; other MSM entry points refuse
+// (EZKL_ERR_INVALID) until it is finished.
+struct MsmBatch {
+    const Bases* b = nullptr;
+    MsmTable* T = nullptr;
+    size_t base_offset = 0, n = 0, pushed = 0, retired = 0;
+    std::vector<h64::aff> results;
+};
+static MsmBatch* g_open_batch = nullptr;
+static MsmBatch* g_open_batch_fwd() { return g_open_batch; }
+bool msm_batch_is_open() { return g_open_batch != nullptr; }
+int msm_batch_begin(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, size_t n, MsmBatch** out) {
+    if (g_open_batch) return EZKL_ERR_INVALID;
+    for (auto& sl : g_slots)
+        if (sl.busy) return EZKL_ERR_INVALID;
+    MsmTable* T = nullptr;
+    int rc = n ? table_get(c, st, b, &T) : EZKL_OK;
+    if (rc) return rc;
+    MsmBatch* mb = new MsmBatch();
+    mb->b = b; mb->T = T; mb->base_offset = base_offset; mb->n = n;
+    g_open_batch = mb;
+    *out = mb;
+    return EZKL_OK;
+}
+static int msm_batch_retire_one(MsmBatch* mb) {
+    h64::aff r;
+    int rc = msm_finish(g_slots[mb->retired % MSM_SLOTS], &r);
+    if (rc) return rc;
+    mb->results.push_back(r);
+    mb->retired++;
+    return EZKL_OK;
+}
+int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev) {
+    if (mb != g_open_batch) return EZKL_ERR_INVALID;
+    if (mb->n == 0) { mb->pushed++; return EZKL_OK; }
+    int rc;
+    if (mb->pushed - mb->retired >= (size_t)MSM_SLOTS && (rc = msm_batch_retire_one(mb))) return rc;
+    MsmSlot& sl = g_slots[mb->pushed % MSM_SLOTS];
+    if ((rc = slot_prepare(sl, 0))) return rc;
+    if ((rc = msm_enqueue(c, sl, sl.st, mb->T, mb->base_offset, scalars_dev, mb->n, false))) return rc;
+    mb->pushed++;
+    return EZKL_OK;
+}
+// drains the pipeline, writes `pushed` affine results (capacity checked) and closes the batch -- also on error
+int msm_batch_finish(Ctx* c, MsmBatch* mb, void* out_host, size_t capacity) {
+    (void)c;
+    if (mb != g_open_batch) return EZKL_ERR_INVALID;
+    int rc = EZKL_OK;
+    if (mb->n == 0) {
+        if (capacity < mb->pushed) rc = EZKL_ERR_INVALID; else memset(out_host, 0, 64 * mb->pushed);
+    } else {
+        while (!rc && mb->retired < mb->pushed) rc = msm_batch_retire_one(mb);
+        if (!rc && capacity < mb->pushed) rc = EZKL_ERR_INVALID;
+        if (!rc && mb->pushed) memcpy(out_host, mb->results.data(), 64 * mb->pushed);
+        if (rc)                                              // leave no slot marked busy behind a failed batch
+            for (auto& sl : g_slots)
+                if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
+    }
+    g_open_batch = nullptr;
+    delete mb;
+    return rc;
 }
 
 // ---- synthetic bases (bench / tests): same deterministic function as oracle_gen_bases -----------

@@ -983,6 +983,8 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             invalid(advice == nullptr, "no advice columns");
             for (uint32_t c : idxs) src[c] = advice[c];
         }
+        // (measured: pushing each column into an incremental batch right after its upload is SLOWER, 36 vs 22 ms at k = 20 --
+        // a blocking copy from pageable memory queues behind the MSM kernels already in flight -- so: all uploads, then one batch)
         std::vector<Col> batch;
         for (uint32_t c : idxs) {
             invalid(src[c] == nullptr, "missing advice column");

@@ -213,3 +213,41 @@ def test_sparse_column_is_fast_and_correct(hip):
     assert (got == ob.msm(s, pts)).all()
     assert dt < 0.01, "sparse MSM took %.1f ms" % (dt * 1e3)
     bases.free()
+
+
+def test_incremental_commit_batch(hip):
+    """begin / push / finish == the one-shot batch; other MSM calls are refused while a batch is open"""
+    import ezkl_amd
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(77)
+    n = 1 << 12
+    pts = ob.gen_bases(5, n)
+    bases = B.Bases(pts)
+    cols = [rand_fr(rng, n) for _ in range(9)]          # more columns than pipeline slots
+    cols[3][:] = 0
+    devs = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    want = B.msm_g1_batch_dev(bases, [d.ptr for d in devs], n)
+    mb = B.MsmBatch(bases, n)
+    for d in devs[:4]:
+        mb.push(d.ptr)
+    with pytest.raises(ezkl_amd.EzklHipError):
+        B.msm_g1_dev(bases, devs[0].ptr, n)               # a batch is open
+    with pytest.raises(ezkl_amd.EzklHipError):
+        B.MsmBatch(bases, n)
+    for d in devs[4:]:
+        mb.push(d.ptr)
+    got = mb.finish()
+    assert got.shape == (9, 8) and (got == want).all()
+    assert (got[0] == ob.msm(cols[0], pts)).all() and not got[3].any()
+    # the pipeline is free again; a short result buffer is an error that still closes the batch
+    mb = B.MsmBatch(bases, n)
+    mb.push(devs[1].ptr); mb.push(devs[2].ptr)
+    with pytest.raises(ezkl_amd.EzklHipError):
+        mb.finish(capacity=1)
+    assert (B.msm_g1_dev(bases, devs[1].ptr, n) == want[1]).all()
+    # a sub-range of the base set and an empty batch
+    mb = B.MsmBatch(bases, n // 2, offset=n // 4)
+    mb.push(devs[0].ptr)
+    assert (mb.finish()[0] == ob.msm(cols[0][: n // 2], pts[n // 4: n // 4 + n // 2])).all()
+    assert B.MsmBatch(bases, n).finish().shape == (0, 8)
+    bases.free()
