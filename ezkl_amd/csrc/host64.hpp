@@ -144,6 +144,42 @@ static inline xyzz dbl(const xyzz& p) {
     r.zzz = mul(w, p.zzz);
     return r;
 }
+// a coordinate as the MSM kernels leave it (field29.hpp: 9 limbs of 29 bits, lazily reduced, Montgomery R' = 2^261)
+// -> canonical Montgomery R = 2^256: rebuild the integer, subtract q while >= q (values are < 32 q), multiply by 2^-5
+static inline fe from_limbs29(const uint32_t v[9]) {
+    uint64_t w[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, k = bit >> 6, sh = bit & 63;
+        u128 t = (u128)v[i] << sh;
+        u128 c = (u128)w[k] + (uint64_t)t;
+        w[k] = (uint64_t)c;
+        c = (c >> 64) + (uint64_t)(t >> 64);
+        for (int j = k + 1; j < 5 && c; j++) {
+            c += w[j];
+            w[j] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    for (;;) {
+        fe lo = {{w[0], w[1], w[2], w[3]}};
+        if (w[4] == 0 && !geq(lo, Q)) break;
+        fe d;
+        uint64_t br = sub4(d, lo, Q);
+        w[0] = d.v[0]; w[1] = d.v[1]; w[2] = d.v[2]; w[3] = d.v[3];
+        w[4] -= br;
+    }
+    const fe x = {{w[0], w[1], w[2], w[3]}}, c251 = {{0, 0, 0, (uint64_t)1 << 59}};
+    return mul(x, c251);                 // x * 2^251 / 2^256 = x * 2^-5
+}
+static inline xyzz from_limbs29_point(const uint32_t* p36) {
+    xyzz r;
+    r.x = from_limbs29(p36);
+    r.y = from_limbs29(p36 + 9);
+    r.zz = from_limbs29(p36 + 18);
+    r.zzz = from_limbs29(p36 + 27);
+    return r;
+}
+
 static inline xyzz add(const xyzz& a, const xyzz& b) {
     if (is_id(a)) return b;
     if (is_id(b)) return a;

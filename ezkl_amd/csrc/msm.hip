@@ -21,6 +21,7 @@
 // Order of additions differs from the CPU Pippenger, the group element (and its canonical affine bytes) does not.
 #include "common.hpp"
 #include "curve.hpp"
+#include "curve29.hpp"
 #include "host64.hpp"
 #include <string.h>
 
@@ -69,6 +70,21 @@ __global__ __launch_bounds__(256) void msm_precompute_kernel(const g1a_t* prev, 
     g1x_t a = g1x_from_affine(p);
     for (uint32_t k = 0; k < c; k++) a = g1x_double(a);
     st_g1a(next + i, g1x_to_affine(a));
+}
+
+// the accumulate kernel works in Montgomery form R' = 2^261 (field29.hpp); the table is private to the MSM, so it is
+// converted once: coordinate * (2^261 mod p) / 2^256 in the old arithmetic = the canonical value of x * 2^261
+__global__ __launch_bounds__(256) void msm_table_to_r261_kernel(g1a_t* tab, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    fe_t k;
+#pragma unroll
+    for (int q = 0; q < 8; q++) k.v[q] = Fq29C::R261_32[q];
+    g1a_t p = ld_g1a(tab + i);
+    if (g1a_is_id(p)) return;
+    p.x = Fq::mul(p.x, k);
+    p.y = Fq::mul(p.y, k);
+    st_g1a(tab + i, p);
 }
 
 // ---- signed-digit decomposition ------------------------------------------------------------------
@@ -301,13 +317,20 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
 // boundaries.  A bucket that lies inside one lane's range is written directly; a bucket cut by a lane
 // boundary leaves partial sums in tail[t] (continues into lane t+1) / head[t] (started before lane t), which
 // msm_fixup_kernel folds.  Each pair costs one 64-byte gather from T and one mixed add (8M + 2S).
-__device__ __forceinline__ g1a_t msm_fetch(const g1a_t* tab, uint32_t v) {
-    g1a_t p = ld_g1a(tab + (v & 0x7fffffffu));
-    if (v >> 31) p.y = Fq::neg(p.y);
-    return p;
+// a gathered table record: 64 bytes, canonical coordinates in R' = 2^261 Montgomery form (msm_table_to_r261_kernel); the
+// sign bit of the pair selects -P, applied inside the mixed addition
+struct MsmRec {
+    g1a_t p;
+    bool neg;
+};
+__device__ __forceinline__ MsmRec msm_fetch(const g1a_t* tab, uint32_t v) {
+    MsmRec r;
+    r.p = ld_g1a(tab + (v & 0x7fffffffu));
+    r.neg = (v >> 31) != 0;
+    return r;
 }
-__global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
-                                                             uint32_t nb, uint32_t L, g1x_t* buckets, g1x_t* head, g1x_t* tail,
+__global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
+                                                             uint32_t nb, uint32_t L, g1x29_t* buckets, g1x29_t* head, g1x29_t* tail,
                                                              uint32_t* lane_first) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[nb];
@@ -323,12 +346,12 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab
     uint32_t b = lo, bin_end = offsets[b + 1];
     lane_first[t] = b;                          // the bucket holding this lane's first pair (msm_fixup_boundary_kernel)
     bool started_before = offsets[b] < k0;
-    g1x_t acc = g1x_identity();
-    g1a_t nxt = msm_fetch(tab, vals[k0]);
+    g1x29_t acc = g1x29_identity();
+    MsmRec nxt = msm_fetch(tab, vals[k0]);
     for (uint32_t k = k0; k < k1; k++) {
         if (k == bin_end) {                     // bucket b is finished inside this lane
-            if (started_before) st_g1x(head + t, acc); else st_g1x(buckets + b, acc);
-            acc = g1x_identity();
+            if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
+            acc = g1x29_identity();
             started_before = false;
             // next non-empty bucket: a few linear probes (the common case), then a binary search -- a sparse column
             // (e.g. m(X): a handful of blinding rows scattered over 2^19 buckets) must not walk every empty bucket
@@ -344,14 +367,14 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab
                 bin_end = offsets[b + 1];
             }
         }
-        g1a_t cur = nxt;
+        const MsmRec cur = nxt;
         if (k + 1 < k1) nxt = msm_fetch(tab, vals[k + 1]);   // prefetch: the gather latency hides under the add
-        acc = g1x_add_mixed(acc, cur);
+        acc = g1x29_add_mixed(acc, g1a29_unpack(cur.p), cur.neg);
     }
     if (k1 == bin_end) {
-        if (started_before) st_g1x(head + t, acc); else st_g1x(buckets + b, acc);
+        if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
     } else {
-        if (started_before) st_g1x(head + t, acc); else st_g1x(tail + t, acc);
+        if (started_before) st_g1x29(head + t, acc); else st_g1x29(tail + t, acc);
     }
 }
 // A bucket cut by lane boundaries is tail[t1] + head[t1+1 .. t2].  One thread per LANE BOUNDARY (not per bucket: with
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(256, 4) void msm_accumulate_kernel(const g1a_t* tab
 // a bucket cut once, is one addition; a bucket cut a few times is folded serially by its first boundary; anything
 // longer (a skewed witness) is queued for msm_fixup_heavy_kernel.
 __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, uint32_t nlanes,
-                                                                 const uint32_t* lane_first, const g1x_t* head, const g1x_t* tail, g1x_t* buckets,
+                                                                 const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
                                                                  uint32_t* heavy_list, uint32_t* heavy_count) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
     if (t >= nlanes) return;
@@ -374,21 +397,21 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
         heavy_list[atomicAdd(heavy_count, 1u)] = b;
         return;
     }
-    g1x_t acc = g1x_add(ld_g1x(tail + t1), ld_g1x(head + t));
-    for (uint32_t u = t + 1; u <= t2; u++) acc = g1x_add(acc, ld_g1x(head + u));
-    st_g1x(buckets + b, acc);
+    g1x29_t acc = g1x29_add(ld_g1x29(tail + t1), ld_g1x29(head + t));
+    for (uint32_t u = t + 1; u <= t2; u++) acc = g1x29_add(acc, ld_g1x29(head + u));
+    st_g1x29(buckets + b, acc);
 }
 // heavily skewed buckets (e.g. thousands of equal witness values): one workgroup folds the lane partials
-__global__ __launch_bounds__(256) void msm_fixup_heavy_kernel(const uint32_t* offsets, uint32_t L, const g1x_t* head, const g1x_t* tail,
-                                                              const uint32_t* heavy_list, const uint32_t* heavy_count, g1x_t* buckets) {
-    __shared__ uint4 sh[8 * 4];
+__global__ __launch_bounds__(256) void msm_fixup_heavy_kernel(const uint32_t* offsets, uint32_t L, const g1x29_t* head, const g1x29_t* tail,
+                                                              const uint32_t* heavy_list, const uint32_t* heavy_count, g1x29_t* buckets) {
+    __shared__ uint4 sh[9 * 4];
     for (uint32_t h = blockIdx.x; h < *heavy_count; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
-        g1x_t acc = threadIdx.x == 0 ? ld_g1x(tail + t1) : g1x_identity();
-        for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256) acc = g1x_add(acc, ld_g1x(head + t));
-        acc = g1x_block256_sum(acc, sh);
-        if (threadIdx.x == 0) st_g1x(buckets + b, acc);
+        g1x29_t acc = threadIdx.x == 0 ? ld_g1x29(tail + t1) : g1x29_identity();
+        for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
+        acc = g1x29_block256_sum(acc, sh);
+        if (threadIdx.x == 0) st_g1x29(buckets + b, acc);
     }
 }
 
@@ -404,42 +427,42 @@ struct ReduceGeom {
     uint32_t wsA, wsB, wsC;       // weight shifts of the fields
     uint32_t EA, GA, ET, GT;      // serial elements per lane / groups for column sums (A) and row sums (T)
 };
-__global__ __launch_bounds__(256, 4) void msm_reduce1_kernel(const g1x_t* buckets, ReduceGeom g, g1x_t* partA, g1x_t* partT) {
+__global__ __launch_bounds__(256, 2) void msm_reduce1_kernel(const g1x29_t* buckets, ReduceGeom g, g1x29_t* partA, g1x29_t* partT) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    g1x_t acc = g1x_identity();
+    g1x29_t acc = g1x29_identity();
     if (blockIdx.y == 0) {            // column sums: S_A[dA] partials
         if (idx >= (g.GA << g.wA)) return;
         const uint32_t dA = idx & ((1u << g.wA) - 1u), grp = idx >> g.wA;
-        for (uint32_t e = 0; e < g.EA; e++) acc = g1x_add(acc, ld_g1x(buckets + ((((size_t)grp * g.EA + e) << g.wA) | dA)));
-        st_g1x(partA + (size_t)dA * g.GA + grp, acc);
+        for (uint32_t e = 0; e < g.EA; e++) acc = g1x29_add(acc, ld_g1x29(buckets + ((((size_t)grp * g.EA + e) << g.wA) | dA)));
+        st_g1x29(partA + (size_t)dA * g.GA + grp, acc);
     } else {                          // row sums: T[t] partials
         const uint32_t nT = 1u << (g.wB + g.wC);
         if (idx >= nT * g.GT) return;
         const uint32_t grp = idx % g.GT, t = idx / g.GT;
-        for (uint32_t e = 0; e < g.ET; e++) acc = g1x_add(acc, ld_g1x(buckets + (((size_t)t << g.wA) | (grp * g.ET + e))));
-        st_g1x(partT + (size_t)t * g.GT + grp, acc);
+        for (uint32_t e = 0; e < g.ET; e++) acc = g1x29_add(acc, ld_g1x29(buckets + (((size_t)t << g.wA) | (grp * g.ET + e))));
+        st_g1x29(partT + (size_t)t * g.GT + grp, acc);
     }
 }
 // S_A[d] = sum_g partA[d][g] (blocks [0, blocksA)),  T[t] = sum_g partT[t][g] (the rest): `lanes` lanes of a wave per output
 // (a few serial additions, then a shuffle tree).  The lane counts are chosen by the host so that the launch has at most one
 // wave per SIMD: these chains are latency-bound, and a second wave on a SIMD doubles the latency of both.
-__global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x_t* partA, const g1x_t* partT, ReduceGeom g, g1x_t* SA, g1x_t* T, uint32_t lanesA,
+__global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x29_t* partA, const g1x29_t* partT, ReduceGeom g, g1x29_t* SA, g1x29_t* T, uint32_t lanesA,
                                                          uint32_t lanesT, uint32_t blocksA) {
     const bool isA = blockIdx.x < blocksA;
     const uint32_t lanes = isA ? lanesA : lanesT, per = 64 / lanes;
     const uint32_t o = (isA ? blockIdx.x : blockIdx.x - blocksA) * per + threadIdx.x / lanes, j = threadIdx.x % lanes;
     const uint32_t nout = isA ? (1u << g.wA) : (1u << (g.wB + g.wC)), G = isA ? g.GA : g.GT;
-    g1x_t acc = g1x_identity();
+    g1x29_t acc = g1x29_identity();
     if (o < nout) {
-        const g1x_t* src = (isA ? partA : partT) + (size_t)o * G;
-        for (uint32_t i = j; i < G; i += lanes) acc = g1x_add(acc, ld_g1x(src + i));
+        const g1x29_t* src = (isA ? partA : partT) + (size_t)o * G;
+        for (uint32_t i = j; i < G; i += lanes) acc = g1x29_add(acc, ld_g1x29(src + i));
     }
-    acc = g1x_group_sum(acc, lanes);
-    if (j == 0 && o < nout) st_g1x((isA ? SA : T) + o, acc);
+    acc = g1x29_group_sum(acc, lanes);
+    if (j == 0 && o < nout) st_g1x29((isA ? SA : T) + o, acc);
 }
 // one workgroup per plane: planes[0] = TOTAL; planes[1 + ws + j] = sum of the field sums whose digit has bit j
-__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* SA, const g1x_t* T, ReduceGeom g, g1x_t* planes) {
-    __shared__ uint4 sh[8 * 4];
+__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes) {
+    __shared__ uint4 sh[9 * 4];
     uint32_t id = blockIdx.x, field = 0, j = 0;      // field 0: TOTAL, 1: A, 2: B, 3: C
     if (id > 0) {
         id -= 1;
@@ -448,22 +471,22 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x_t* SA, const 
         else { field = 3; j = id - g.wA - g.wB; }
     }
     const uint32_t nA = 1u << g.wA, nT = 1u << (g.wB + g.wC);
-    g1x_t acc = g1x_identity();
+    g1x29_t acc = g1x29_identity();
     // every thread walks indices that HAVE the bit (k-th such index: k with a 1 inserted at the bit position), so no
     // lane idles through the serial part
     auto with_bit = [](uint32_t k, uint32_t bit) { return ((k >> bit) << (bit + 1)) | (1u << bit) | (k & ((1u << bit) - 1u)); };
     if (field == 0) {
-        for (uint32_t d = threadIdx.x; d < nA; d += 256) acc = g1x_add(acc, ld_g1x(SA + d));
+        for (uint32_t d = threadIdx.x; d < nA; d += 256) acc = g1x29_add(acc, ld_g1x29(SA + d));
     } else if (field == 1) {
-        for (uint32_t k = threadIdx.x; k < nA / 2; k += 256) acc = g1x_add(acc, ld_g1x(SA + with_bit(k, j)));
+        for (uint32_t k = threadIdx.x; k < nA / 2; k += 256) acc = g1x29_add(acc, ld_g1x29(SA + with_bit(k, j)));
     } else {
         const uint32_t sh_bits = field == 2 ? j : g.wB + j;          // t = (dC << wB) | dB
-        for (uint32_t k = threadIdx.x; k < nT / 2; k += 256) acc = g1x_add(acc, ld_g1x(T + with_bit(k, sh_bits)));
+        for (uint32_t k = threadIdx.x; k < nT / 2; k += 256) acc = g1x29_add(acc, ld_g1x29(T + with_bit(k, sh_bits)));
     }
-    acc = g1x_block256_sum(acc, sh);
+    acc = g1x29_block256_sum(acc, sh);
     if (threadIdx.x == 0) {
         const uint32_t ws = field == 1 ? g.wsA : field == 2 ? g.wsB : g.wsC;
-        st_g1x(planes + (field == 0 ? 0u : 1u + ws + j), acc);
+        st_g1x29(planes + (field == 0 ? 0u : 1u + ws + j), acc);
     }
 }
 
@@ -479,6 +502,7 @@ static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
     for (uint32_t w = 1; w < t.wp.W; w++)
         hipLaunchKernelGGL(msm_precompute_kernel, dim3(cdiv(t.n, 256)), dim3(256), 0, st, t.tab + (size_t)(w - 1) * t.n,
                            t.tab + (size_t)w * t.n, t.n, t.wp.width(w - 1));
+    hipLaunchKernelGGL(msm_table_to_r261_kernel, dim3(cdiv((size_t)t.wp.W * t.n, 256)), dim3(256), 0, st, t.tab, (size_t)t.wp.W * t.n);
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipStreamSynchronize(st));
     g_tables[b] = t;
@@ -501,7 +525,7 @@ struct MsmSlot {
     hipStream_t st = nullptr;
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
-    h64::xyzz* pinned = nullptr;      // 1 + 22 planes
+    uint32_t* pinned = nullptr;       // 1 + 22 planes of 36 limbs (g1x29_t)
     hipEvent_t done = nullptr;
     uint32_t bits = 0;
     bool busy = false;
@@ -512,7 +536,7 @@ static int slot_prepare(MsmSlot& sl, size_t bytes) {
     if (!sl.st) {
         EZ_HIP(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
         EZ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        EZ_HIP(hipHostMalloc((void**)&sl.pinned, 32 * sizeof(h64::xyzz), hipHostMallocDefault));
+        EZ_HIP(hipHostMalloc((void**)&sl.pinned, 32 * sizeof(g1x29_t), hipHostMallocDefault));
     }
     if (bytes > sl.scratch_bytes) {
         if (sl.scratch) {
@@ -530,13 +554,13 @@ static int slot_prepare(MsmSlot& sl, size_t bytes) {
 // host tail: result = TOTAL + sum_k 2^k * plane[1+k] (Horner from the top bit), then canonical affine
 static int msm_finish(MsmSlot& sl, void* out_host) {
     EZ_HIP(hipEventSynchronize(sl.done));
-    const h64::xyzz* hp = sl.pinned;
+    const uint32_t* hp = sl.pinned;            // planes in the kernels' radix-2^29 form -> canonical 64-bit limbs
     h64::xyzz acc = h64::identity();
     for (int k = (int)sl.bits - 1; k >= 0; k--) {
         acc = h64::dbl(acc);
-        acc = h64::add(acc, hp[1 + k]);
+        acc = h64::add(acc, h64::from_limbs29_point(hp + 36 * (1 + k)));
     }
-    acc = h64::add(acc, hp[0]);
+    acc = h64::add(acc, h64::from_limbs29_point(hp));
     h64::aff r = h64::to_affine(acc);
     memcpy(out_host, &r, 64);
     sl.busy = false;
@@ -596,11 +620,11 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_wgh = carve((size_t)sgrid * NP * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256);
     size_t o_lfirst = carve((size_t)nlanes * 4);
-    size_t o_bkt = carve((size_t)nb * sizeof(g1x_t));
-    size_t o_head = carve((size_t)nlanes * sizeof(g1x_t)), o_tail = carve((size_t)nlanes * sizeof(g1x_t));
-    size_t o_partA = carve((size_t)n_partA * sizeof(g1x_t)), o_partT = carve((size_t)n_partT * sizeof(g1x_t));
-    size_t o_SA = carve((size_t)nA * sizeof(g1x_t)), o_T = carve((size_t)nT * sizeof(g1x_t));
-    size_t o_planes = carve((size_t)nplanes * sizeof(g1x_t));
+    size_t o_bkt = carve((size_t)nb * sizeof(g1x29_t));
+    size_t o_head = carve((size_t)nlanes * sizeof(g1x29_t)), o_tail = carve((size_t)nlanes * sizeof(g1x29_t));
+    size_t o_partA = carve((size_t)n_partA * sizeof(g1x29_t)), o_partT = carve((size_t)n_partT * sizeof(g1x29_t));
+    size_t o_SA = carve((size_t)nA * sizeof(g1x29_t)), o_T = carve((size_t)nT * sizeof(g1x29_t));
+    size_t o_planes = carve((size_t)nplanes * sizeof(g1x29_t));
     rc = slot_prepare(sl, off);
     if (rc) return rc;
     uint8_t* S = sl.scratch;
@@ -610,9 +634,9 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *wghist = (uint32_t*)(S + o_wgh);
     uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt);
     uint32_t* lfirst = (uint32_t*)(S + o_lfirst);
-    g1x_t *bkt = (g1x_t*)(S + o_bkt), *head = (g1x_t*)(S + o_head), *tail = (g1x_t*)(S + o_tail);
-    g1x_t *partA = (g1x_t*)(S + o_partA), *partT = (g1x_t*)(S + o_partT), *SA = (g1x_t*)(S + o_SA), *TT = (g1x_t*)(S + o_T);
-    g1x_t* planes = (g1x_t*)(S + o_planes);
+    g1x29_t *bkt = (g1x29_t*)(S + o_bkt), *head = (g1x29_t*)(S + o_head), *tail = (g1x29_t*)(S + o_tail);
+    g1x29_t *partA = (g1x29_t*)(S + o_partA), *partT = (g1x29_t*)(S + o_partT), *SA = (g1x29_t*)(S + o_SA), *TT = (g1x29_t*)(S + o_T);
+    g1x29_t* planes = (g1x29_t*)(S + o_planes);
 
     hipEvent_t m0 = nullptr, m1 = nullptr, a0 = nullptr, a1 = nullptr;
     if (timed) {
@@ -621,8 +645,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         EZ_HIP(hipEventRecord(m0, st));
     }
     EZ_HIP(hipMemsetAsync(hcnt, 0, 4, st));
-    EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x_t), st));          // empty buckets = identity (ZZ = 0)
-    EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x_t), st));
+    EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x29_t), st));          // empty buckets = identity (ZZ = 0)
+    EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
     // sort
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist);
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NP, 32)), dim3(1024), 0, st, wghist, sgrid, NP, pcnt);
@@ -665,7 +689,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         fprintf(stderr, "[msm] n=%zu W=%u bits=%u L=%u nlanes=%u heavy=%u\n", n, W, bits, L, nlanes, hc);
     }
     if (timed) EZ_HIP(hipEventRecord(m1, st));
-    EZ_HIP(hipMemcpyAsync(sl.pinned, planes, (size_t)nplanes * sizeof(g1x_t), hipMemcpyDeviceToHost, st));
+    EZ_HIP(hipMemcpyAsync(sl.pinned, planes, (size_t)nplanes * sizeof(g1x29_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipEventRecord(sl.done, st));
     sl.bits = bits;
     sl.busy = true;

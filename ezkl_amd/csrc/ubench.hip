@@ -2,6 +2,7 @@
 // Montgomery products/s (the real ceiling of MSM/NTT), v_mad_u64_u32 issue rate, and HBM copy GB/s.
 #include "common.hpp"
 #include "curve.hpp"
+#include "montmul29_gen.hpp"
 #include <string.h>
 #include <vector>
 #include <stdlib.h>
@@ -39,6 +40,17 @@ __global__ __launch_bounds__(256) void ub_mad64_kernel(uint64_t* io, int iters) 
     }
     io[i] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
+__global__ __launch_bounds__(256) void ub_mullo_kernel(uint64_t* io, int iters) {       // issue rate of v_mul_lo_u32
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = (uint32_t)io[i];
+    uint32_t a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7, m = x | 1u;
+    for (int k = 0; k < iters; k++) {
+        asm volatile("v_mul_lo_u32 %0, %0, %8\n\tv_mul_lo_u32 %1, %1, %8\n\tv_mul_lo_u32 %2, %2, %8\n\tv_mul_lo_u32 %3, %3, %8\n\t"
+                     "v_mul_lo_u32 %4, %4, %8\n\tv_mul_lo_u32 %5, %5, %8\n\tv_mul_lo_u32 %6, %6, %8\n\tv_mul_lo_u32 %7, %7, %8"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+    }
+    io[i] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
 __global__ __launch_bounds__(256) void ub_dfma_kernel(double* io, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double x = io[i];
@@ -68,6 +80,61 @@ __global__ __launch_bounds__(256) void ub_gather_kernel(const uint4* table, uint
         acc.x ^= a.x ^ b.y ^ c.z ^ d.w; acc.y += a.y + b.x; acc.z ^= c.x + d.y; acc.w += a.w ^ d.z;
     }
     out[tid] = acc;
+}
+
+// ---- radix-2^29 Montgomery product (tools/gen_montmul29.py): rate probe and self-check against a portable restatement ----
+__device__ __forceinline__ void mont_mul29_ref_fq(const uint32_t (&a)[9], const uint32_t (&b)[9], uint32_t (&r)[9]) {
+    const uint32_t MASK = (1u << 29) - 1;
+    uint32_t p[9];
+    {   // limbs of q in radix 2^29 from the 32-bit limb table
+        uint64_t acc = 0; int bits = 0, w = 0;
+        for (int i = 0; i < 9; i++) {
+            while (bits < 29 && w < 8) { acc |= (uint64_t)FqP::MOD[w++] << bits; bits += 32; }
+            p[i] = (uint32_t)acc & MASK; acc >>= 29; bits -= 29;
+        }
+    }
+    uint32_t pinv = 1;                                   // -p^-1 mod 2^29 by Newton iteration
+    for (int i = 0; i < 5; i++) pinv *= 2u - p[0] * pinv;
+    pinv = (0u - pinv) & MASK;
+    uint32_t m[9];
+    uint64_t acc = 0;
+    for (int k = 0; k < 17; k++) {
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) acc += (uint64_t)a[i] * b[k - i];
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++)
+            if (i < k || k >= 9) { if (i != k) acc += (uint64_t)m[i] * p[k - i]; }
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * pinv) & MASK;
+            acc += (uint64_t)m[k] * p[0];
+        } else r[k - 9] = (uint32_t)acc & MASK;
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+}
+__global__ __launch_bounds__(256) void ub_modmul29_kernel(uint32_t* io, int iters, uint32_t* mismatches) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t a[9], b[9], c[9], d[9], r[9];
+    for (int i = 0; i < 9; i++) {
+        uint32_t x = io[t * 8 + (i & 7)] * 2654435761u + i;
+        a[i] = x & 0x1fffffffu; b[i] = (x >> 3) & 0x1fffffffu; c[i] = (x * 7u) & 0x1fffffffu; d[i] = (x * 13u) & 0x1fffffffu;
+    }
+    a[8] &= 0x3fffu; b[8] &= 0x3fffu; c[8] &= 0x3fffu; d[8] &= 0x3fffu;          // < 2^246: far below p
+    if (mismatches) {
+        uint32_t want[9];
+        mont_mul29_fq(a, b, r);
+        mont_mul29_ref_fq(a, b, want);
+        bool bad = false;
+        for (int i = 0; i < 9; i++) bad |= r[i] != want[i];
+        if (bad) atomicAdd(mismatches, 1u);
+    }
+    for (int k = 0; k < iters; k++) {      // two independent chains, as in ub_modmul_kernel
+        mont_mul29_fq(a, b, r); for (int i = 0; i < 9; i++) a[i] = r[i];
+        mont_mul29_fq(c, d, r); for (int i = 0; i < 9; i++) c[i] = r[i];
+        mont_mul29_fq(b, a, r); for (int i = 0; i < 9; i++) b[i] = r[i];
+        mont_mul29_fq(d, c, r); for (int i = 0; i < 9; i++) d[i] = r[i];
+    }
+    uint32_t x = 0;
+    for (int i = 0; i < 9; i++) x ^= a[i] ^ b[i] ^ c[i] ^ d[i];
+    io[t * 8] = x;
 }
 
 // dependent chain of general XYZZ additions: launch latency / cold-instruction-fetch probe for the small tail kernels
@@ -110,18 +177,22 @@ int ubench(Ctx* c, const char* which, double* out) {
     const int blocks = c->num_cus * 16, threads = 256;
     const size_t nthreads = (size_t)blocks * threads;
     float ms = 0.f;
-    const bool is_mm = !strncmp(which, "modmul", 6);
-    if (is_mm || !strcmp(which, "mad64") || !strcmp(which, "dfma") || !strcmp(which, "addsub")) {
+    const bool is_mm = !strncmp(which, "modmul", 6) && strncmp(which, "modmul29", 8);
+    if (is_mm || !strcmp(which, "mad64") || !strcmp(which, "mullo") || !strcmp(which, "dfma") || !strcmp(which, "addsub")) {
         void* buf = nullptr;
         EZ_HIP(hipMalloc(&buf, nthreads * 32));
         EZ_HIP(hipMemsetAsync(buf, 0x11, nthreads * 32, st));
         const int iters = is_mm ? 256 : 4096;
+        int blocks = c->num_cus * 16;
+        if (const char* o = strstr(which, "_o")) blocks = c->num_cus * atoi(o + 2);
+        const size_t nthreads = (size_t)blocks * threads;
         for (int rep = 0; rep < 2; rep++) {     // rep 0 = warm-up
             EZ_HIP(hipEventRecord(e0, st));
-            if (!strcmp(which, "modmul")) hipLaunchKernelGGL(ub_modmul_kernel<0>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            if (!strncmp(which, "modmul_o", 8) || !strcmp(which, "modmul")) hipLaunchKernelGGL(ub_modmul_kernel<0>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
             else if (!strcmp(which, "modmul_c")) hipLaunchKernelGGL(ub_modmul_kernel<1>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
             else if (!strcmp(which, "modmul_inl")) hipLaunchKernelGGL(ub_modmul_kernel<2>, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
             else if (!strcmp(which, "addsub")) hipLaunchKernelGGL(ub_addsub_kernel, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            else if (!strcmp(which, "mullo")) hipLaunchKernelGGL(ub_mullo_kernel, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
             else if (!strcmp(which, "mad64")) hipLaunchKernelGGL(ub_mad64_kernel, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
             else hipLaunchKernelGGL(ub_dfma_kernel, dim3(blocks), dim3(threads), 0, st, (double*)buf, iters);
             EZ_HIP(hipEventRecord(e1, st));
@@ -131,6 +202,32 @@ int ubench(Ctx* c, const char* which, double* out) {
         EZ_HIP(hipFree(buf));
         const double per_thread = (is_mm || !strcmp(which, "addsub")) ? 4.0 * iters : 8.0 * iters;
         *out = per_thread * (double)nthreads / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strncmp(which, "modmul29", 8)) {       // "modmul29": products per second; "modmul29_check": mismatches vs the portable form
+        void* buf = nullptr;
+        uint32_t* mis = nullptr;
+        EZ_HIP(hipMalloc(&buf, nthreads * 32));
+        EZ_HIP(hipMalloc((void**)&mis, 4));
+        EZ_HIP(hipMemsetAsync(buf, 0x5b, nthreads * 32, st));
+        EZ_HIP(hipMemsetAsync(mis, 0, 4, st));
+        const bool chk = strstr(which, "check") != nullptr;
+        const int iters = chk ? 1 : 256;
+        int blocks = c->num_cus * 16;                              // "modmul29_oN": N waves per SIMD instead of as many as fit
+        if (const char* o = strstr(which, "_o")) blocks = c->num_cus * atoi(o + 2);
+        const size_t nthreads = (size_t)blocks * threads;
+        for (int rep = 0; rep < 2; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(ub_modmul29_kernel, dim3(blocks), dim3(threads), 0, st, (uint32_t*)buf, iters, chk ? mis : nullptr);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        uint32_t hm = 0;
+        EZ_HIP(hipMemcpy(&hm, mis, 4, hipMemcpyDeviceToHost));
+        EZ_HIP(hipFree(buf));
+        EZ_HIP(hipFree(mis));
+        *out = chk ? (double)hm : 4.0 * iters * (double)nthreads / (ms * 1e-3);
         return EZKL_OK;
     }
     if (!strncmp(which, "ecadd", 5)) {         // "ecadd<iters>[w|f]": microseconds of the 4th launch; w = one wave, f = full GPU
