@@ -234,7 +234,8 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
     if (t == NP - 1) part_base[NP] = sh[t];
 }
 // one pass: the slot of a pair is part_base[p] + (pairs of partition p in earlier workgroups) + its rank inside this
-// workgroup (LDS atomic) -- no global atomics, no second digit pass
+// workgroup (LDS atomic) -- no global atomics, no second digit pass.  Measured split of its ~150 us at 2^20 points: the
+// 13.6 M scattered 8-byte stores are ~100 us (one L2 request each, whatever the partition count), digits + LDS ranks ~55 us.
 __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                             uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
                                                             const uint32_t* part_base, const uint32_t* wg_hist, uint2* entries) {

@@ -26,7 +26,7 @@ class EzklHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libezkl_hip.so")
+    return os.environ.get("EZKL_HIP_LIB") or os.path.join(_HERE, "libezkl_hip.so")      # override: A/B builds of the kernels
 
 
 def load():

@@ -61,6 +61,15 @@ def test_edge_cases(hip):
     assert (B.msm_g1(bases, np.zeros((n, 4), np.uint64)) == 0).all()             # all-zero scalars -> identity
     same = np.tile(fe_from_int(3), (n, 1))                                        # every point in ONE bucket (heavy path)
     assert (B.msm_g1(bases, same) == ob.msm(same, pts)).all()
+    # ONE point repeated with ONE scalar: every lane partial of the bucket is the same multiple of P, so the fixup /
+    # reduce trees add EQUAL points (the doubling branch of the general addition) at every level
+    n2 = 4096
+    rep = np.tile(pts[3], (n2, 1))
+    breps = B.Bases(rep)
+    for val in (5, R - 5):
+        sc = np.tile(fe_from_int(val), (n2, 1))
+        assert (B.msm_g1(breps, sc) == ob.msm(sc, rep)).all()
+    breps.free()
     short = s[:100]                                                               # ragged: fewer scalars than bases
     assert (B.msm_g1(bases, short) == ob.msm(short, pts[:100])).all()
     bases.free()
