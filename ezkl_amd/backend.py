@@ -75,6 +75,23 @@ class DeviceBuffer:
             pass
 
 
+class PinnedArray:
+    """a numpy view of page-locked host memory (ezkl_hip_host_malloc): witness columns filled here upload at PCIe speed"""
+
+    def __init__(self, shape, dtype=np.uint64):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = _vp()
+        _l.check(_l.load().ezkl_hip_host_malloc(C.byref(self._p), C.c_size_t(self.nbytes)), "ezkl_hip_host_malloc")
+        buf = (C.c_uint8 * max(1, self.nbytes)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            _l.load().ezkl_hip_host_free(self._p)
+            self._p = None
+
+
 class _Bases:
     def __init__(self, pts):
         pts = _fe(pts, 8)

@@ -187,6 +187,20 @@ int ezkl_hip_free(void* dptr) {
     EZ_HIP(hipFree(dptr));
     return EZKL_OK;
 }
+int ezkl_hip_host_malloc(void** p, size_t bytes) {
+    if (!p) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return EZKL_ERR_NOMEM;
+    if (e != hipSuccess) return set_hip_error(e, "hipHostMalloc", __FILE__, __LINE__);
+    return EZKL_OK;
+}
+int ezkl_hip_host_free(void* p) {
+    if (!p) return EZKL_OK;
+    EZ_CTX(c);
+    EZ_HIP(hipHostFree(p));
+    return EZKL_OK;
+}
 int ezkl_hip_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     EZ_CTX(c);
     EZ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));

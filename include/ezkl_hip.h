@@ -48,6 +48,11 @@ const char* ezkl_hip_version(void);
 int ezkl_hip_malloc(void** dptr, size_t bytes);
 int ezkl_hip_free(void* dptr);
 int ezkl_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+/* page-locked host memory for columns that will be uploaded (the witness: A x 2^k x 32 B per proof).  Copies from it run
+ * without the runtime's pageable staging step; a fork would allocate the advice / instance vectors that synthesize() fills
+ * from here.  (On the measured box the blocking pageable path was already as fast: 14 x 32 MiB in ~10 ms either way.) */
+int ezkl_hip_host_malloc(void** host_ptr, size_t bytes);
+int ezkl_hip_host_free(void* host_ptr);
 int ezkl_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 
 /* ---- MSM: replaces ParamsKZG::commit / commit_lagrange -> halo2curves::msm (CPU) / icicle msm (GPU);

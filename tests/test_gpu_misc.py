@@ -308,3 +308,20 @@ def test_chacha20_field_sampler(hip, n, first):
     B.chacha20_fr(key, 0xabcdef0123 + n, out.ptr, n, first=first)
     got = out.to_numpy(shape=(n, 4))
     assert (got == ob.chacha20_fr(key, 0xabcdef0123 + n, n, first=first)).all()
+
+
+def test_radix29_montgomery_product_self_check(hip):
+    """the generated carry-free radix-2^29 product (montmul29_gen.hpp, the MSM's field multiplication) against its
+    portable restatement on 1M operand pairs, on the device"""
+    from ezkl_amd import backend as B
+    assert B.ubench("modmul29_check") == 0.0
+
+
+def test_pinned_host_memory(hip):
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(3)
+    pa = B.PinnedArray((1 << 12, 4))
+    pa.array[:] = rand_fr(rng, 1 << 12)
+    d = B.DeviceBuffer.from_numpy(pa.array)
+    assert (d.to_numpy(shape=(1 << 12, 4)) == pa.array).all()
+    pa.free()

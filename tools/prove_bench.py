@@ -143,6 +143,11 @@ out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLO
        "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
 if "--native" in sys.argv and world == 1:
     from ezkl_amd import native as NV
+    if "--pinned" in sys.argv:                     # witness in page-locked memory (ezkl_hip_host_malloc); measured: no gain over pageable here
+        pinned = [B.PinnedArray((n, 4)) for _ in adv]
+        for pa, a in zip(pinned, adv):
+            pa.array[:] = a
+        adv = [pa.array for pa in pinned]
     gb_, glb_ = B.Bases(g), B.Bases(gl)
     t0 = time.time(); npk = NV.NativeProvingKey(NV.NativeCircuit(cs), gb_, fixed, copies); t_nkeygen = time.time() - t0
     NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5))            # warm-up
