@@ -77,6 +77,13 @@ def consts(tag, mod):
         assert c[8] >= ((K - 1) * mod) >> 232
         rows.append("        %s,   // %d p" % (arr(c), K))
     o.append("    static constexpr uint32_t SUBC[5][9] = {\n" + "\n".join(rows) + "\n    };")
+    # conditional subtraction of K*p (K = 1, 2, 4, 8): x + (2^261 - K p) carries into bit 261 exactly when x >= K p
+    rows = []
+    for K in (1, 2, 4, 8):
+        d = limbs29((1 << 261) - K * mod)
+        assert all(x < (1 << 29) for x in d)
+        rows.append("        %s,   // 2^261 - %d p" % (arr(d), K))
+    o.append("    static constexpr uint32_t CSUB[4][9] = {\n" + "\n".join(rows) + "\n    };")
     k261 = (1 << 261) % mod
     o.append("    static constexpr uint32_t R261_32[8] = %s;    // 2^261 mod p as 8 x 32-bit limbs (table conversion R -> R')" %
              arr([(k261 >> (32 * i)) & 0xffffffff for i in range(8)]))
