@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Device time of one resident 2^22 NTT (HIP events)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, ezkl_amd
 from ezkl_amd import backend as B
 ezkl_amd.init(0)
