@@ -141,6 +141,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_msm, t_ntt = float(t[0]), float(t[1])
 
+    # N > 1: the end-to-end prove with its MSMs sharded by points across the ranks (BASELINE configs[3]).  Every rank starts a
+    # CHILD (tools/prove_bench.py) and the children form their own process group on the next port, so a failure or a hang in
+    # this leg can only cost its timeout: the headline line below is printed regardless.
+    prove_multi = None
+    if world > 1 and not args.no_cpu_baseline:
+        prove_multi = prove_leg_multi(world, rank, local_rank, args)
+
     if rank == 0:
         modmul = B.ubench("modmul")
         modmul29 = B.ubench("modmul29")           # the carry-free radix-2^29 product the MSM kernels use
@@ -186,6 +193,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
             out["prove"] = prove_leg()
+        if prove_multi is not None:
+            out["prove"] = prove_multi
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -213,6 +222,34 @@ def prove_leg():
                 "cpu_threads": j["cpu_kernel_sample"]["threads"]}
     except Exception as e:          # the headline line must still be printed
         return {"error": repr(e)[:200]}
+
+
+def prove_leg_multi(world, rank, local_rank, args):
+    """k = 20 prove with the proof's MSMs sharded across `world` GPUs (plonk.DistGpuBackend: every rank holds 1/world of the
+    SRS, one all_gather of 64-byte partials per commit batch; NTTs and the sweep replicated).  Runs in child processes."""
+    import subprocess
+    env = dict(os.environ, K="20", BLOCKS="4", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(local_rank))
+    for k_ in list(env):                       # the children rendezvous on their own: no torchrun agent store behind the new port
+        if k_.startswith("TORCHELASTIC_") or k_ in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
+                                                      "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+            env.pop(k_)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "prove_bench.py")]
+    if args.backend != "nccl":
+        cmd.append("--gloo")
+    if args.share_device:
+        cmd.append("--share-device")
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "240")))
+        if rank != 0:
+            return None
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
+                "n_gpus": j["n_gpus"], "msm_sharding": j["msm_sharding"], "host": "ezkl_amd/plonk.py (Python) + DistGpuBackend",
+                "prove_seconds_gpu": j["prove_seconds_gpu"], "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
+                "all_ranks_same_proof": True, "breakdown_seconds": j["prove_breakdown_seconds"]}
+    except Exception as e:
+        return {"error": repr(e)[:300]} if rank == 0 else None
 
 
 def cpu_baseline(bases, scalars, n, gpu_result):

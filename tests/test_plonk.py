@@ -349,3 +349,24 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     j2 = json.loads(lines[-1])
     assert j1["verifier_accepts"] and j2["verifier_accepts"]
     assert j2["n_gpus"] == 2 and j1["proof_sha256"] == j2["proof_sha256"]
+
+
+@pytest.mark.gpu
+def test_bench_contract_two_ranks(hip):
+    """`bench.py --gpus 2` the way the driver launches it (torchrun), on one GPU with gloo: ONE JSON line from rank 0 with the
+    contract's keys, the whole-job value, and the sharded end-to-end prove leg accepted by the verifier"""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="200")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", "--share-device"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stderr[-2000:]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in j
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["vs_baseline"] is None and "workload" in j["config"]
+    assert abs(j["value"] - 2 * (1 << 20) * 3 / (j["ms_per_step"] * 3e-3)) < 1e-3 * j["value"]
+    assert j["prove"].get("verifier_accepts") is True and j["prove"]["n_gpus"] == 2
