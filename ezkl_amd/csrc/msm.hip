@@ -29,6 +29,7 @@ namespace ezkl {
 
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
+static constexpr uint32_t MSM_HEAVY_CHUNK = 1024;    // lane partials folded by one workgroup in the first heavy pass
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
 
 // Window plan: W signed-digit windows covering 254 bits (253-bit magnitudes after the r - s fold + the last carry),
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
 // longer (a skewed witness) is queued for msm_fixup_heavy_kernel.
 __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, uint32_t nlanes,
                                                                  const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
-                                                                 uint32_t* heavy_list, uint32_t* heavy_count) {
+                                                                 uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
     if (t >= nlanes) return;
     const uint64_t k0 = (uint64_t)t * L;
@@ -393,24 +394,42 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
     const uint32_t beg = offsets[b], end = offsets[b + 1];
     if (beg >= k0) return;                                                 // the bucket starts exactly on the boundary: not cut
     const uint32_t t1 = beg / L, t2 = (end - 1) / L;
-    if (t != t1 + 1) return;                                               // a later boundary of a bucket cut several times
-    if (t2 - t1 > MSM_SPAN_HEAVY) {
-        heavy_list[atomicAdd(heavy_count, 1u)] = b;
+    if (t2 - t1 > MSM_SPAN_HEAVY) {                                        // skewed witness: queue the bucket once, and one work item
+        if (t == t1 + 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;       // per chunk of MSM_HEAVY_CHUNK lane partials
+        if ((t - t1 - 1) % MSM_HEAVY_CHUNK == 0) chunk_list[atomicAdd(heavy_count + 1, 1u)] = t;
         return;
     }
+    if (t != t1 + 1) return;                                               // a later boundary of a bucket cut several times
     g1x29_t acc = g1x29_add(ld_g1x29(tail + t1), ld_g1x29(head + t));
     for (uint32_t u = t + 1; u <= t2; u++) acc = g1x29_add(acc, ld_g1x29(head + u));
     st_g1x29(buckets + b, acc);
 }
-// heavily skewed buckets (e.g. thousands of equal witness values): one workgroup folds the lane partials
-__global__ __launch_bounds__(256) void msm_fixup_heavy_kernel(const uint32_t* offsets, uint32_t L, const g1x29_t* head, const g1x29_t* tail,
-                                                              const uint32_t* heavy_list, const uint32_t* heavy_count, g1x29_t* buckets) {
+// Heavily skewed buckets (thousands of equal witness values -- a constant column is ONE bucket cut by every lane boundary).
+// Pass 1: one workgroup per chunk of MSM_HEAVY_CHUNK lane partials folds head[start .. start + chunk) into head[start].
+// Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
+// (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
+__global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t L, const uint32_t* lane_first, g1x29_t* head,
+                                                               const uint32_t* chunk_list, const uint32_t* counts) {
     __shared__ uint4 sh[9 * 4];
-    for (uint32_t h = blockIdx.x; h < *heavy_count; h += gridDim.x) {
+    const uint32_t nchunks = counts[1];
+    for (uint32_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
+        const uint32_t start = chunk_list[ci], b = lane_first[start];
+        const uint32_t t2 = (offsets[b + 1] - 1) / L;
+        const uint32_t stop = start + MSM_HEAVY_CHUNK - 1 < t2 ? start + MSM_HEAVY_CHUNK - 1 : t2;
+        g1x29_t acc = g1x29_identity();
+        for (uint32_t t = start + threadIdx.x; t <= stop; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
+        acc = g1x29_block256_sum(acc, sh);                          // ends with a workgroup barrier: every read of head[start..stop] is done
+        if (threadIdx.x == 0) st_g1x29(head + start, acc);
+    }
+}
+__global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t L, const g1x29_t* head, const g1x29_t* tail,
+                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets) {
+    __shared__ uint4 sh[9 * 4];
+    for (uint32_t h = blockIdx.x; h < counts[0]; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
         g1x29_t acc = threadIdx.x == 0 ? ld_g1x29(tail + t1) : g1x29_identity();
-        for (uint32_t t = t1 + 1 + threadIdx.x; t <= t2; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
+        for (uint32_t t = t1 + 1 + threadIdx.x * MSM_HEAVY_CHUNK; t <= t2; t += 256 * MSM_HEAVY_CHUNK) acc = g1x29_add(acc, ld_g1x29(head + t));
         acc = g1x29_block256_sum(acc, sh);
         if (threadIdx.x == 0) st_g1x29(buckets + b, acc);
     }
@@ -619,7 +638,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     auto carve = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
     size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_wgh = carve((size_t)sgrid * NP * 4);
-    size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256);
+    size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256), o_chunks = carve(((size_t)nlanes + 1) * 4);
     size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x29_t));
     size_t o_head = carve((size_t)nlanes * sizeof(g1x29_t)), o_tail = carve((size_t)nlanes * sizeof(g1x29_t));
@@ -633,7 +652,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     uint32_t* vals = (uint32_t*)(S + o_vals);
     uint32_t* offs = (uint32_t*)(S + o_offs);
     uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *wghist = (uint32_t*)(S + o_wgh);
-    uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt);
+    uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt), *chunks = (uint32_t*)(S + o_chunks);   // hcnt[0] buckets, [1] chunks
     uint32_t* lfirst = (uint32_t*)(S + o_lfirst);
     g1x29_t *bkt = (g1x29_t*)(S + o_bkt), *head = (g1x29_t*)(S + o_head), *tail = (g1x29_t*)(S + o_tail);
     g1x29_t *partA = (g1x29_t*)(S + o_partA), *partT = (g1x29_t*)(S + o_partT), *SA = (g1x29_t*)(S + o_SA), *TT = (g1x29_t*)(S + o_T);
@@ -645,7 +664,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
         EZ_HIP(hipEventRecord(m0, st));
     }
-    EZ_HIP(hipMemsetAsync(hcnt, 0, 4, st));
+    EZ_HIP(hipMemsetAsync(hcnt, 0, 8, st));
     EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x29_t), st));          // empty buckets = identity (ZZ = 0)
     EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
     // sort
@@ -662,11 +681,14 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     if (timed) EZ_HIP(hipEventRecord(a1, st));
     if (nlanes > 1)
         hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256)), dim3(256), 0, st, offs, nb, L, nlanes, lfirst, head, tail, bkt,
-                           heavy, hcnt);
+                           heavy, hcnt, chunks);
     {
         size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_fixup_heavy_kernel, dim3(hb), dim3(256), 0, st, offs, L, head, tail, heavy, hcnt, bkt);
+        size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
+        unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
+        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb), dim3(256), 0, st, offs, L, lfirst, head, chunks, hcnt);
+        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb), dim3(256), 0, st, offs, L, head, tail, heavy, hcnt, bkt);
     }
     // reduce
     {

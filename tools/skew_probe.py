@@ -23,3 +23,10 @@ for name, s in cases.items():
         got = B.msm_g1_dev(bases, d.ptr, n)
     ok = (got == ob.msm(s, pts)).all()
     print("%-14s device %.3f ms (accumulate %.3f)  parity=%s" % (name, B.last_kernel_ms("msm"), B.last_kernel_ms("msm_accumulate"), ok), flush=True)
+# a prover phase: 14 witness-like columns committed as one pipelined batch
+cols = [B.DeviceBuffer.from_numpy(witness_like(rng, n)) for _ in range(14)]
+B.msm_g1_batch_dev(bases, [c.ptr for c in cols], n)
+t0 = time.perf_counter()
+for _ in range(3):
+    B.msm_g1_batch_dev(bases, [c.ptr for c in cols], n)
+print("batch of 14 witness-like columns: %.3f ms per column" % ((time.perf_counter() - t0) / 3 / 14 * 1e3))
