@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars,
 }
 // ---- sort pass 2: one workgroup per partition, counting sort on the low bucket bits in LDS ---------
 __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
-                                                          uint32_t* offsets, uint32_t* vals) {
+                                                          uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
     __shared__ uint32_t cnt[2048];
     __shared__ uint32_t tsum[512];
     const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
         if (j < nbins) {
             cnt[j] = run;
             offsets[(size_t)p * nbins + j] = beg + run;
-        }
+            if (loc[q] == 0) st_f29(&buckets[(size_t)p * nbins + j].zz, Fq29::zero());     // an empty bucket is the identity (ZZ = 0): no
+        }                                                                                   // 75 MB memset of the whole bucket array
         run += loc[q];
     }
     if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
@@ -665,7 +666,6 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         EZ_HIP(hipEventRecord(m0, st));
     }
     EZ_HIP(hipMemsetAsync(hcnt, 0, 8, st));
-    EZ_HIP(hipMemsetAsync(bkt, 0, (size_t)nb * sizeof(g1x29_t), st));          // empty buckets = identity (ZZ = 0)
     EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
     // sort
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist);
@@ -673,7 +673,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase);
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, base_offset, T->n,
                        pbase, wghist, entries);
-    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals);
+    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals, bkt);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail,
