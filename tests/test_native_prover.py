@@ -186,3 +186,30 @@ def test_native_prover_k12(hip):
     G2 = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
           (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
     assert V.verify(vk_g, (1, 2), G2, E.g2_mul(G2, s), proof)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,seed", [(7, 31), (8, 32), (9, 33), (10, 34)])
+def test_native_random_circuits_larger_domains(hip, k, seed):
+    """random gate sets / lookups / copies on generated SRSs of growing size: native C++ proof == Python-on-HIP proof,
+    pairing verifier accepts, a corrupted witness is rejected"""
+    from ezkl_amd import backend as B
+    from oracle import pairing as E, verifier as V
+    s = 0xabcdef12345 + seed
+    g, gl = B.gen_srs(k, s)
+    g_pts, gl_pts = g.download(), gl.download()
+    cs, adv, fixed, copies = random_circuit(seed, k=k)
+    pk = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    gpu = P.GpuBackend(g_pts, gl_pts, k)
+    pk_g, vk_g = P.keygen(cs, gpu, fixed, copies)
+    _, _, digest = pk.vk()
+    assert digest == vk_g.digest
+    proof = N.create_proof(pk, g, gl, adv, rng=det_rng(seed))
+    assert proof == P.create_proof(pk_g, gpu, adv, det_rng(seed))
+    G2 = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
+          (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
+    s_g2 = E.g2_mul(G2, s)
+    assert V.verify(vk_g, (1, 2), G2, s_g2, proof)
+    bad = [a.copy() for a in adv]
+    bad[cs.n_advice - 1][5] = P.to_mont((P.from_mont(bad[cs.n_advice - 1][5]) + 1) % P.R)
+    assert not V.verify(vk_g, (1, 2), G2, s_g2, N.create_proof(pk, g, gl, bad, seed=3))
