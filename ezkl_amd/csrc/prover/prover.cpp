@@ -586,6 +586,103 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     return pk;
 }
 
+// ------------------------------------------------------------------ key files (halo2 ProvingKey::{write, read}, SerdeFormat::RawBytes)
+// The layout of the reference's vk.key / pk.key (/root/reference/src/pfsys/mod.rs:593-683; verified on tests/assets in
+// SURVEY.md §8(c) item 3):  VK = [3, k, compress_selectors] | u32 LE #fixed | #fixed x G1 | #perm x G1 | selectors (none
+// here: selectors are plain fixed columns);  PK = VK | poly l0 | poly l_last | poly l_active_row | vec fixed_values |
+// vec fixed_polys | vec fixed_cosets | vec permutations | vec perm_polys | vec perm_cosets, with
+// poly = u32 BE len | len x 32 B and vec = u32 BE count | count x u32 BE len | count x poly.  Field and curve bytes are
+// the resident Montgomery bytes, copied unchanged in both directions.
+static void put_be32(std::vector<uint8_t>& o, uint32_t v) {
+    for (int i = 3; i >= 0; i--) o.push_back((uint8_t)(v >> (8 * i)));
+}
+static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
+    const ConstraintSystem& cs = *pk.cs;
+    Backend be(cs.k, cs.n, nullptr, nullptr);
+    std::vector<uint8_t> o = {3, (uint8_t)cs.k, 1};
+    const uint32_t nf = cs.n_fixed;
+    for (int i = 0; i < 4; i++) o.push_back((uint8_t)(nf >> (8 * i)));
+    auto put_points = [&](const std::vector<G1>& v) {
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(v.data());
+        o.insert(o.end(), b, b + 64 * v.size());
+    };
+    put_points(pk.fixed_commitments);
+    put_points(pk.sigma_commitments);
+    auto put_poly = [&](const Col& c, size_t m) {
+        std::vector<U256> v = be.download(c, m);
+        put_be32(o, (uint32_t)m);
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(v.data());
+        o.insert(o.end(), b, b + 32 * m);
+    };
+    auto put_vec = [&](const std::vector<Col>& cols, size_t m) {
+        put_be32(o, (uint32_t)cols.size());
+        for (size_t i = 0; i < cols.size(); i++) put_be32(o, (uint32_t)m);
+        for (auto& c : cols) put_poly(c, m);
+    };
+    const size_t n = cs.n, ne = (size_t)1 << cs.ext_k;
+    put_poly(pk.l0, ne); put_poly(pk.l_last, ne); put_poly(pk.l_active, ne);
+    put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_vec(pk.fixed_cosets, ne);
+    put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_vec(pk.sigma_cosets, ne);
+    return o;
+}
+static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* buf, size_t len) {
+    Backend be(cs.k, cs.n, nullptr, nullptr);
+    size_t off = 0;
+    auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
+    need(7);
+    invalid(buf[0] != 3, "unsupported key version");
+    invalid(buf[1] != cs.k, "key was made for another k");
+    uint32_t nf = 0;
+    for (int i = 0; i < 4; i++) nf |= (uint32_t)buf[3 + i] << (8 * i);
+    invalid(nf != cs.n_fixed, "key has another number of fixed columns");
+    off = 7;
+    auto pk = std::make_unique<ProvingKey>();
+    pk->cs = &cs;
+    auto get_points = [&](std::vector<G1>& v, size_t m) {
+        need(64 * m);
+        v.resize(m);
+        if (m) std::memcpy(v.data(), buf + off, 64 * m);
+        off += 64 * m;
+    };
+    get_points(pk->fixed_commitments, cs.n_fixed);
+    get_points(pk->sigma_commitments, cs.perm.size());
+    auto be32 = [&]() {
+        need(4);
+        uint32_t v = ((uint32_t)buf[off] << 24) | ((uint32_t)buf[off + 1] << 16) | ((uint32_t)buf[off + 2] << 8) | buf[off + 3];
+        off += 4;
+        return v;
+    };
+    auto get_poly = [&](size_t m) {
+        invalid(be32() != m, "polynomial of unexpected length in the key");
+        need(32 * m);
+        for (size_t i = 0; i < m; i++) {                               // every element must be a canonical residue
+            U256 e;
+            std::memcpy(e.data(), buf + off + 32 * i, 32);
+            invalid(cmp(e, FR.p) >= 0, "non-canonical field element in the key");
+        }
+        Col c = be.upload(buf + off, m);
+        off += 32 * m;
+        return c;
+    };
+    auto get_vec = [&](std::vector<Col>& cols, size_t count, size_t m) {
+        invalid(be32() != count, "vector of unexpected length in the key");
+        for (size_t i = 0; i < count; i++) invalid(be32() != m, "polynomial of unexpected length in the key");
+        for (size_t i = 0; i < count; i++) cols.push_back(get_poly(m));
+    };
+    const size_t n = cs.n, ne = (size_t)1 << cs.ext_k;
+    pk->l0 = get_poly(ne); pk->l_last = get_poly(ne); pk->l_active = get_poly(ne);
+    get_vec(pk->fixed_values, cs.n_fixed, n); get_vec(pk->fixed_polys, cs.n_fixed, n); get_vec(pk->fixed_cosets, cs.n_fixed, ne);
+    get_vec(pk->sigma_values, cs.perm.size(), n); get_vec(pk->sigma_polys, cs.perm.size(), n); get_vec(pk->sigma_cosets, cs.perm.size(), ne);
+    invalid(off != len, "trailing bytes in the proving key");
+    // derived columns that the file does not hold
+    pk->omega_col = be.omega_powers();
+    std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
+    xcoef[1] = FR.one;
+    pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
+    pk->digest = vk_digest(*pk);
+    return pk;
+}
+
 // ------------------------------------------------------------------ randomness
 // Blinding rows and the vanishing argument's random polynomial.  With a caller-supplied generator (ezkl_rng_fn) the
 // elements come from the callback.  Otherwise they are ChaCha20 output under a 256-bit key -- OS entropy, or derived
@@ -1219,6 +1316,19 @@ int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_va
         invalid(ezkl_hip_bases_len(g) < cs->cs->n, "SRS smaller than 2^k");
         *out = new ezkl_prover_pk{keygen(*cs->cs, g, fixed_values, copies, n_copies)};
     });
+}
+int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len) {
+    if (!pk || !len) return EZKL_ERR_INVALID;
+    return guarded([&] {
+        std::vector<uint8_t> b = pk_write(*pk->pk);
+        *len = b.size();
+        if (b.size() > cap || !out) throw Error(EZKL_ERR_NOMEM, "key buffer too small");
+        std::memcpy(out, b.data(), b.size());
+    });
+}
+int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out) {
+    if (!cs || !buf || !out) return EZKL_ERR_INVALID;
+    return guarded([&] { *out = new ezkl_prover_pk{pk_read(*cs->cs, (const uint8_t*)buf, len)}; });
 }
 int ezkl_prover_pk_free(ezkl_pk_t pk) {
     delete pk;

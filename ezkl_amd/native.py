@@ -13,7 +13,7 @@ from . import plonk as _pl
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_vk",
+SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -135,6 +135,24 @@ class NativeProvingKey:
         self.h = C.c_void_p()
         _check(load().ezkl_prover_keygen(circuit.h, g.h, _ptr_array(fixed), cp.ctypes.data_as(C.c_void_p), C.c_size_t(cp.shape[0]), C.byref(self.h)),
                "ezkl_prover_keygen")
+
+    @classmethod
+    def from_bytes(cls, circuit, data):
+        """load a key in halo2's raw-bytes pk.key layout (load_pk): columns go straight to HBM"""
+        self = cls.__new__(cls)
+        self.circuit = circuit
+        self.h = C.c_void_p()
+        data = bytes(data)
+        _check(load().ezkl_prover_pk_read(circuit.h, data, C.c_size_t(len(data)), C.byref(self.h)), "ezkl_prover_pk_read")
+        return self
+
+    def to_bytes(self):
+        """the key in halo2's raw-bytes pk.key layout (save_pk)"""
+        ln = C.c_size_t(0)
+        load().ezkl_prover_pk_write(self.h, None, C.c_size_t(0), C.byref(ln))          # first call: the size
+        buf = (C.c_uint8 * ln.value)()
+        _check(load().ezkl_prover_pk_write(self.h, buf, C.c_size_t(ln.value), C.byref(ln)), "ezkl_prover_pk_write")
+        return bytes(buf)
 
     def vk(self):
         """(fixed commitments (F,8) u64, permutation commitments (P,8) u64, digest as a canonical int)"""

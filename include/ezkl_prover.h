@@ -50,6 +50,13 @@ int ezkl_prover_cs_info(ezkl_cs_t cs, uint32_t out[8]);
  * borrowed and must outlive the pk. */
 int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies, ezkl_pk_t* out);
 int ezkl_prover_pk_free(ezkl_pk_t pk);
+/* the proving key in the raw-bytes layout of halo2's ProvingKey::{write, read} (the reference's pk.key, saved / loaded at
+ * /root/reference/src/pfsys/mod.rs:615-683; layout verified on its fixture): vk prefix, l0 / l_last /
+ * l_active_row, fixed values / polys / cosets, permutation values / polys / cosets.  write: EZKL_ERR_NOMEM with *len set if
+ * cap is too small (a k = 20 key is GiBs).  read: the cs supplies what the file does not hold (column counts, extended_k);
+ * every element is checked to be a canonical residue; columns go straight to HBM. */
+int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len);
+int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out);
 /* verifying key: n_fixed + n_perm affine commitments (64 B Montgomery each) and the 32-byte transcript digest
  * (Montgomery Fr).  Any output pointer may be NULL. */
 int ezkl_prover_vk(ezkl_pk_t pk, void* fixed_commitments, void* permutation_commitments, void* digest);
@@ -60,8 +67,9 @@ int ezkl_prover_vk(ezkl_pk_t pk, void* fixed_commitments, void* permutation_comm
  *   once per phase with the challenges squeezed so far and fills columns[c] (host, 2^k x 32 B) for every column c of
  *   that phase; a non-zero return aborts with EZKL_ERR_INVALID.
  * instances: n_instance host pointers with instance_lens[i] Montgomery Fr each (hashed, not committed).
- * rng: fills n_elems x 32 B with uniform Montgomery residues < r; NULL = the library's xoshiro256** seeded with `seed`
- *   (the reference's det-prove feature, pfsys/mod.rs:436-439) or, if seed == 0, from the OS.
+ * rng: fills n_elems x 32 B with uniform residues < r; NULL = the library's generator: ChaCha20 (the sampler of
+ *   ezkl_hip_chacha20_fr_dev, uniform on [0, r)) keyed from `seed` (the reference's det-prove feature,
+ *   pfsys/mod.rs:436-439) or, if seed == 0, from OS entropy; whole columns (the random polynomial) are expanded on the device.
  * proof_out / cap / proof_len: EvmTranscript bytes; EZKL_ERR_NOMEM with *proof_len set if cap is too small.
  * timings (may be NULL): 12 doubles, seconds per prover stage in the order advice_commit, lookup_m, permutation_z,
  *   lookup_phi, random_poly, intt_and_coset_ntt, quotient_sweep, h_split_commit, evaluations, shplonk, total, reserved. */

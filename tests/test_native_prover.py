@@ -213,3 +213,35 @@ def test_native_random_circuits_larger_domains(hip, k, seed):
     bad = [a.copy() for a in adv]
     bad[cs.n_advice - 1][5] = P.to_mont((P.from_mont(bad[cs.n_advice - 1][5]) + 1) % P.R)
     assert not V.verify(vk_g, (1, 2), G2, s_g2, N.create_proof(pk, g, gl, bad, seed=3))
+
+
+@pytest.mark.gpu
+def test_native_key_file_roundtrip(hip, golden_srs):
+    """save_pk / load_pk in halo2's raw-bytes layout: the native key serialises to the same bytes as the Python codecs (whose
+    layout is pinned on the reference's pk.key), loads back, and the loaded key proves byte-identically"""
+    from ezkl_amd import backend as B, codecs
+    cs = lookup_circuit(6)
+    adv, fixed, copies = lookup_witness(cs, 4)
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    gpu = P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6)
+    pk_py, _ = P.keygen(cs, gpu, fixed, copies)
+    vkb, pkb = P.export_keys(pk_py, gpu)
+    data = pk.to_bytes()
+    assert data == pkb and data.startswith(vkb)
+    back = codecs.read_pk(data, n_perm=len(cs.perm), n_selectors=0)
+    assert back["l0"].shape == (1 << cs.ext_k, 4) and len(back["perm_cosets"]) == len(cs.perm)
+    pk2 = N.NativeProvingKey.from_bytes(pk.circuit, data)
+    assert pk2.vk()[2] == pk.vk()[2]
+    assert N.create_proof(pk2, g, gl, adv, rng=det_rng(9)) == N.create_proof(pk, g, gl, adv, rng=det_rng(9))
+    for bad in (data[:-1], data + b"\0", b"\x02" + data[1:], data[:7] + bytes(64) + data[71:]):
+        if bad == data[:7] + bytes(64) + data[71:]:
+            k2 = N.NativeProvingKey.from_bytes(pk.circuit, bad)          # a different commitment parses, but changes the vk digest
+            assert k2.vk()[2] != pk.vk()[2]
+        else:
+            with pytest.raises(RuntimeError):
+                N.NativeProvingKey.from_bytes(pk.circuit, bad)
+    # a non-canonical field element is rejected
+    off = len(vkb) + 4
+    evil = bytearray(data); evil[off:off + 32] = b"\xff" * 32
+    with pytest.raises(RuntimeError):
+        N.NativeProvingKey.from_bytes(pk.circuit, bytes(evil))
