@@ -29,6 +29,7 @@ namespace ezkl {
 
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
+static constexpr uint32_t MSM_BINSORT_STAGE = 15360;  // payloads a sort workgroup stages in LDS (60 KiB): 2 workgroups per CU
 static constexpr uint32_t MSM_HEAVY_CHUNK = 1024;    // lane partials folded by one workgroup in the first heavy pass
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
 
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
                                                           uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
     __shared__ uint32_t cnt[2048];
     __shared__ uint32_t tsum[512];
+    extern __shared__ uint32_t stage[];                      // MSM_BINSORT_STAGE sorted payloads: written out as one contiguous run
     const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
     const uint32_t beg = part_base[p], end = part_base[p + 1];
     for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
@@ -301,17 +303,25 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
     }
     if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
     __syncthreads();
-    // four entries in flight per thread: the returning LDS atomics and the stores that depend on them overlap
+    // four entries in flight per thread: the returning LDS atomics and the stores that depend on them overlap.  A partition of
+    // ordinary size is ranked into LDS and leaves as one contiguous run (the scattered 4-byte stores cost one L2 request each,
+    // like the partition pass's); an oversized one (skew) is ranked straight into HBM.
+    const bool staged = (end - beg) <= MSM_BINSORT_STAGE;           // uniform over the workgroup
+    uint32_t* dst = staged ? stage : vals + beg;
     uint32_t e = beg + t;
     for (; e + 3 * 512 < end; e += 4 * 512) {
         uint2 v0 = entries[e], v1 = entries[e + 512], v2 = entries[e + 1024], v3 = entries[e + 1536];
         uint32_t p0 = atomicAdd(&cnt[v0.y], 1u), p1 = atomicAdd(&cnt[v1.y], 1u), p2 = atomicAdd(&cnt[v2.y], 1u), p3 = atomicAdd(&cnt[v3.y], 1u);
-        vals[beg + p0] = v0.x; vals[beg + p1] = v1.x; vals[beg + p2] = v2.x; vals[beg + p3] = v3.x;
+        dst[p0] = v0.x; dst[p1] = v1.x; dst[p2] = v2.x; dst[p3] = v3.x;
     }
     for (; e < end; e += 512) {
         uint2 v = entries[e];
         uint32_t pos = atomicAdd(&cnt[v.y], 1u);
-        vals[beg + pos] = v.x;
+        dst[pos] = v.x;
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = t; i < end - beg; i += 512) vals[beg + i] = stage[i];
     }
 }
 
@@ -598,6 +608,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     // ---- lane length for the accumulate kernel: fill the resident lanes an integer number of times ----
     static int acc_blocks_per_cu = 0;
     if (!acc_blocks_per_cu) {
+        EZ_HIP(hipFuncSetAttribute((const void*)msm_binsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         EZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&acc_blocks_per_cu, msm_accumulate_kernel, 256, 0));
         if (acc_blocks_per_cu < 1) acc_blocks_per_cu = 1;
     }
@@ -673,7 +684,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase);
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, base_offset, T->n,
                        pbase, wghist, entries);
-    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), 0, st, entries, pbase, LB, NP, offs, vals, bkt);
+    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, offs, vals, bkt);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail,
