@@ -206,8 +206,15 @@ EZ_D uint32_t ht_hash(const fe_t& v, uint32_t mask) {
 }
 __global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* table, uint32_t usable, uint32_t* slots, uint32_t mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= usable) return;
-    const fe_t key = ld_fe(table + i);
+    const bool live = i < usable;
+    const fe_t key = live ? ld_fe(table + i) : Fr::zero();
+    // Only the first row of a run of equal values goes to the table: a lookup table padded with one repeated tuple (ezkl pads
+    // every table to the column height) would otherwise send a million lanes to ONE slot -- measured 3.4 ms of atomics for a
+    // 2^15-row table in a 2^20-row column.  (The lane before me holds the previous row; lane 0 always proceeds.)
+    bool same_as_prev = true;
+#pragma unroll
+    for (int q = 0; q < 8; q++) same_as_prev &= (__shfl_up(key.v[q], 1) == key.v[q]);
+    if (!live || ((threadIdx.x & 63) != 0 && same_as_prev)) return;
     uint32_t h = ht_hash(key, mask);
     for (;;) {
         uint32_t cur = slots[h];
