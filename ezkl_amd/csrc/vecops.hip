@@ -107,8 +107,10 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(fe_t* a, fe_t* pre, s
 }
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n) {
     if (n == 0) return EZKL_OK;
-    size_t T = n / 64;                       // >= 64 elements per chain amortises the Fermat inversion
-    size_t cap = (size_t)c->num_cus * 256 * 4;
+    // every chain ends in one Fermat inversion (~380 dependent products, the latency floor of this kernel), so chains are
+    // made short and many -- but no more than one wave per SIMD, beyond which the inversions start to cost throughput
+    size_t T = n / 16;
+    size_t cap = (size_t)c->num_cus * 256;
     if (T > cap) T = cap;
     if (T < 1) T = 1;
     fe_t* pre = nullptr;
@@ -334,8 +336,48 @@ int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& 
     return arena_done(c->aux, st);
 }
 
-// m evaluations (polynomial j at point xs[j], all of length n) with ONE upload of the x-power tables, ONE download and
-// ONE stream synchronisation: create_proof step 10 issues dozens of these back to back
+// m evaluations (polynomial j at point xs[j], all of length n): ONE launch for all of them (blockIdx.y = j -- a single
+// 2^20-coefficient polynomial only fills 128 workgroups), one upload of the x-power tables, one download, one stream
+// synchronisation.  create_proof's step 10 issues ~50 of these.
+struct EvalItem {
+    const fe_t* coeffs;
+    fe_t x;
+};
+__global__ __launch_bounds__(256) void eval_poly_multi_kernel(const EvalItem* items, size_t n, const fe_t* pws, uint32_t pw_stride, uint32_t npow,
+                                                              fe_t* partial) {
+    __shared__ fe_t sh[256];
+    const EvalItem it = items[blockIdx.y];
+    const fe_t* xpow2 = pws + (size_t)blockIdx.y * pw_stride;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, base = t * EVP_SEG;
+    fe_t acc = Fr::zero();
+    if (base < n) {
+        const uint32_t m = n - base < EVP_SEG ? (uint32_t)(n - base) : EVP_SEG;
+        acc = ld_fe(it.coeffs + base + m - 1);
+        for (uint32_t j = m - 1; j-- > 0;) acc = Fr::add(Fr::mul(acc, it.x), ld_fe(it.coeffs + base + j));
+        for (uint32_t b = 0; b < npow; b++)
+            if ((t >> b) & 1) acc = Fr::mul(acc, ld_fe(xpow2 + b));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_fe(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, sh[0]);
+}
+__global__ __launch_bounds__(256) void sum_multi_kernel(const fe_t* in, size_t per, fe_t* out) {
+    __shared__ fe_t sh[256];
+    const fe_t* src = in + (size_t)blockIdx.x * per;
+    fe_t acc = Fr::zero();
+    for (size_t i = threadIdx.x; i < per; i += 256) acc = Fr::add(acc, ld_fe(src + i));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = Fr::add(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_fe(out + blockIdx.x, sh[0]);
+}
 int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_t* xs, uint32_t m, size_t n, void* out_host) {
     if (m == 0) return EZKL_OK;
     if (n == 0) { memset(out_host, 0, 32 * (size_t)m); return EZKL_OK; }
@@ -344,21 +386,28 @@ int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_
     uint32_t npow = 0;
     while (((size_t)1 << npow) < nseg) npow++;
     const size_t pws = npow ? npow : 1;
-    std::vector<fe_t> pw(pws * m);
+    // one staging buffer: [items | power tables], so a single upload
+    const size_t items_fe = ((size_t)m * sizeof(EvalItem) + sizeof(fe_t) - 1) / sizeof(fe_t);
+    std::vector<fe_t> host(items_fe + pws * m);
+    EvalItem* items = reinterpret_cast<EvalItem*>(host.data());
     for (uint32_t j = 0; j < m; j++) {
+        items[j].coeffs = coeffs[j];
+        items[j].x = xs[j];
         fe_t p = xs[j];
         for (int i = 0; i < 5; i++) p = Fr::sqr(p);          // x^32
-        for (uint32_t b = 0; b < npow; b++) { pw[j * pws + b] = p; p = Fr::sqr(p); }
+        for (uint32_t b = 0; b < npow; b++) { host[items_fe + j * pws + b] = p; p = Fr::sqr(p); }
     }
     fe_t* d = nullptr;
-    int rc = arena_reserve(c->aux, (pw.size() + (size_t)m * blocks + m) * sizeof(fe_t), st, (void**)&d);
+    int rc = arena_reserve(c->aux, (host.size() + (size_t)m * blocks + m) * sizeof(fe_t), st, (void**)&d);
     if (rc) return rc;
-    fe_t *d_pw = d, *d_part = d + pw.size(), *d_out = d_part + (size_t)m * blocks;
-    EZ_HIP(hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
-    for (uint32_t j = 0; j < m; j++) {
-        hipLaunchKernelGGL(eval_poly_kernel, dim3(blocks), dim3(256), 0, st, coeffs[j], n, xs[j], d_pw + j * pws, npow, d_part + (size_t)j * blocks);
-        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, d_part + (size_t)j * blocks, (size_t)blocks, d_out + j);
+    fe_t *d_pw = d + items_fe, *d_part = d + host.size(), *d_out = d_part + (size_t)m * blocks;
+    EZ_HIP(hipMemcpyAsync(d, host.data(), host.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    for (uint32_t j0 = 0; j0 < m; j0 += 65535) {             // gridDim.y limit
+        const uint32_t mj = m - j0 < 65535 ? m - j0 : 65535;
+        hipLaunchKernelGGL(eval_poly_multi_kernel, dim3(blocks, mj), dim3(256), 0, st, reinterpret_cast<const EvalItem*>(d) + j0, n, d_pw + (size_t)j0 * pws,
+                           (uint32_t)pws, npow, d_part + (size_t)j0 * blocks);
     }
+    hipLaunchKernelGGL(sum_multi_kernel, dim3(m), dim3(256), 0, st, d_part, (size_t)blocks, d_out);
     hipError_t e = hipMemcpyAsync(out_host, d_out, 32 * (size_t)m, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return set_hip_error(e, "eval_poly_batch", __FILE__, __LINE__);
