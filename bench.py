@@ -209,12 +209,12 @@ def prove_leg():
     import subprocess
     env = dict(os.environ, K="20", BLOCKS="4")
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py"), "--cpu-kernels", "--native"], env=env,
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py"), "--cpu-kernels", "--native", "--pinned"], env=env,
                            capture_output=True, text=True, timeout=600)
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         nv = j.get("native_prover", {})
         return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
-                "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "host": "libezkl_prover.so (C++), ChaCha20 randomness expanded on the device",
+                "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "host": "libezkl_prover.so (C++); witness columns in page-locked host memory, uploads overlapped with the commits; ChaCha20 randomness expanded on the device",
                 "prove_seconds_gpu_python_host": j["prove_seconds_gpu"], "native_proof_identical_to_python_host": nv.get("proof_identical_to_python_prover"),
                 "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
                 "breakdown_seconds": nv.get("breakdown_seconds_library_rng"),

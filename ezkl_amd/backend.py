@@ -172,6 +172,25 @@ class MsmBatch:
         return out[:self.count]
 
 
+def upload_commit_batch(bases, host_cols, tails=None, tail_start=0):
+    """one prover phase: upload the host columns ((n,4) u64 arrays, ideally PinnedArray views), overwrite rows
+    [tail_start, tail_start + t) of column j with tails[j] ((t,4) arrays), commit each.  Returns (device columns, (batch, 8) points)."""
+    cols = [np.ascontiguousarray(a, np.uint64) for a in host_cols]
+    n = cols[0].shape[0]
+    devs = [DeviceBuffer(32 * n) for _ in cols]
+    hp = (C.c_void_p * len(cols))(*[a.ctypes.data for a in cols])
+    dp = (C.c_void_p * len(cols))(*[d.ptr for d in devs])
+    tp, tcount, keep = None, 0, []
+    if tails is not None:
+        keep = [np.ascontiguousarray(t, np.uint64) for t in tails]
+        tcount = keep[0].shape[0]
+        tp = (C.c_void_p * len(cols))(*[t.ctypes.data for t in keep])
+    out = np.zeros((len(cols), 8), np.uint64)
+    _l.check(_l.load().ezkl_hip_upload_commit_batch(bases.h, hp, dp, C.c_size_t(len(cols)), C.c_size_t(n), tp, C.c_size_t(tail_start), C.c_size_t(tcount),
+                                                    _p(out)), "ezkl_hip_upload_commit_batch")
+    return devs, out
+
+
 def msm_g1(bases, scalars):
     """sum_i scalars[i]*bases[i]; scalars numpy (n,4) or a DeviceBuffer-resident vector via msm_dev."""
     s = _fe(scalars)

@@ -769,6 +769,69 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
     return EZKL_OK;
 }
 
+// One prover phase in one call: upload `batch` host columns into the caller's device columns, overwrite their tail rows
+// (blinding) and commit each.  All copies are queued up front on a dedicated copy stream (column j, then its tail rows, then
+// an event); the MSM of column j waits for that event on its slot stream, so PCIe traffic for column j+1.. runs under the
+// kernels of column j.  The host columns should be page-locked (ezkl_hip_host_malloc) for the copies to be truly asynchronous;
+// pageable memory still works (the runtime stages it).
+static hipStream_t g_copy_st = nullptr;
+static fe_t* g_tail_pinned = nullptr;
+static size_t g_tail_pinned_elems = 0;
+int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails,
+                      size_t tail_start, size_t tail_count, void* out_host) {
+    if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
+    if (batch == 0) return EZKL_OK;
+    if (n == 0 || tail_start + tail_count > n) return EZKL_ERR_INVALID;
+    MsmTable* T = nullptr;
+    int rc = table_get(c, c->stream, b, &T);
+    if (rc) return rc;
+    if (!g_copy_st) EZ_HIP(hipStreamCreateWithFlags(&g_copy_st, hipStreamNonBlocking));
+    if (tails && tail_count && batch * tail_count > g_tail_pinned_elems) {
+        if (g_tail_pinned) EZ_HIP(hipHostFree(g_tail_pinned));
+        g_tail_pinned = nullptr;
+        g_tail_pinned_elems = batch * tail_count * 2;
+        EZ_HIP(hipHostMalloc((void**)&g_tail_pinned, g_tail_pinned_elems * sizeof(fe_t), hipHostMallocDefault));
+    }
+    EZ_HIP(hipStreamSynchronize(c->stream));          // the destination columns may have been touched on the library stream
+    std::vector<hipEvent_t> ev(batch, nullptr);
+    auto cleanup = [&]() {
+        for (auto e : ev)
+            if (e) (void)hipEventDestroy(e);
+    };
+    for (size_t j = 0; j < batch; j++) {
+        hipError_t e = hipEventCreateWithFlags(&ev[j], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMemcpyAsync(dev_cols[j], host_cols[j], n * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);
+        if (e == hipSuccess && tails && tail_count) {
+            memcpy(g_tail_pinned + j * tail_count, tails[j], tail_count * sizeof(fe_t));
+            e = hipMemcpyAsync(dev_cols[j] + tail_start, g_tail_pinned + j * tail_count, tail_count * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev[j], g_copy_st);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(g_copy_st);
+            cleanup();
+            return set_hip_error(e, "msm_upload_commit", __FILE__, __LINE__);
+        }
+    }
+    for (size_t j = 0; j < batch + MSM_SLOTS && !rc; j++) {
+        if (j >= MSM_SLOTS) {
+            size_t done = j - MSM_SLOTS;
+            if (done < batch) rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done);
+        }
+        if (j < batch && !rc) {
+            MsmSlot& sl = g_slots[j % MSM_SLOTS];
+            rc = slot_prepare(sl, 0);
+            if (!rc && hipStreamWaitEvent(sl.st, ev[j], 0) != hipSuccess) rc = EZKL_ERR_HIP;
+            if (!rc) rc = msm_enqueue(c, sl, sl.st, T, 0, dev_cols[j], n, false);
+        }
+    }
+    (void)hipStreamSynchronize(g_copy_st);
+    if (rc)
+        for (auto& sl : g_slots)
+            if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
+    cleanup();
+    return rc;
+}
+
 // The same pipeline fed one column at a time: the caller uploads column j+1 (a blocking PCIe copy) while the slots
 // run the MSMs of the columns pushed so far.  One batch may be open per device; other MSM entry points refuse
 // (EZKL_ERR_INVALID) until it is finished.

@@ -1080,16 +1080,22 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             invalid(advice == nullptr, "no advice columns");
             for (uint32_t c : idxs) src[c] = advice[c];
         }
-        // (measured: pushing each column into an incremental batch right after its upload is SLOWER, 36 vs 22 ms at k = 20 --
-        // a blocking copy from pageable memory queues behind the MSM kernels already in flight -- so: all uploads, then one batch)
-        std::vector<Col> batch;
+        // upload, blind and commit the phase in ONE call: all copies go to a copy stream at once and the MSM of a column waits
+        // only for its own copy, so PCIe runs under the kernels (a blocking upload per column followed by the batch costs the sum)
+        std::vector<std::vector<U256>> tails;
+        std::vector<const void*> hostp, tailp;
+        std::vector<void*> devp;
         for (uint32_t c : idxs) {
             invalid(src[c] == nullptr, "missing advice column");
-            adv_cols[c] = be.upload(src[c], n);                 // witness column -> HBM, then blind rows [u, n) in place
-            be.set_rows(adv_cols[c], u, rng.vec(n - u));
-            batch.push_back(adv_cols[c]);
+            adv_cols[c] = be.alloc(n);
+            tails.push_back(rng.vec(n - u));                    // blinding rows [u, n)
+            hostp.push_back(src[c]);
+            devp.push_back(adv_cols[c]->ptr());
         }
-        for (auto& p : be.commit_lagrange(batch)) T.write_point(p);
+        for (auto& t : tails) tailp.push_back(t.data());
+        std::vector<G1> commits(idxs.size());
+        check(ezkl_hip_upload_commit_batch(gl, hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, commits.data()), "ezkl_hip_upload_commit_batch");
+        for (auto& p : commits) T.write_point(p);
         if (phase == 0)
             for (uint32_t i = 0; i < cs.n_challenges; i++) user_chal.push_back(T.squeeze_challenge());
     }

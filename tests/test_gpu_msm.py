@@ -260,3 +260,29 @@ def test_incremental_commit_batch(hip):
     assert (mb.finish()[0] == ob.msm(cols[0][: n // 2], pts[n // 4: n // 4 + n // 2])).all()
     assert B.MsmBatch(bases, n).finish().shape == (0, 8)
     bases.free()
+
+
+def test_upload_commit_batch(hip):
+    """the one-call prover phase (async uploads on a copy stream, blinding rows, pipelined commits) == upload + set rows + commit"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(91)
+    n, t0 = 1 << 12, (1 << 12) - 6
+    pts = ob.gen_bases(9, n)
+    bases = B.Bases(pts)
+    cols = [rand_fr(rng, n) for _ in range(8)]
+    pinned = [B.PinnedArray((n, 4)) for _ in range(4)]
+    for pa, c in zip(pinned, cols):
+        pa.array[:] = c
+    host = [pa.array for pa in pinned] + cols[4:]            # page-locked and pageable columns mixed
+    tails = [rand_fr(rng, 6) for _ in range(8)]
+    devs, commits = B.upload_commit_batch(bases, host, tails, t0)
+    for j in range(8):
+        want = cols[j].copy()
+        want[t0:] = tails[j]
+        assert (devs[j].to_numpy(shape=(n, 4)) == want).all()
+        assert (commits[j] == ob.msm(want, pts)).all()
+    devs2, commits2 = B.upload_commit_batch(bases, cols[:2])          # no blinding rows
+    assert (commits2[1] == ob.msm(cols[1], pts)).all() and (devs2[0].to_numpy(shape=(n, 4)) == cols[0]).all()
+    for pa in pinned:
+        pa.free()
+    bases.free()

@@ -143,7 +143,7 @@ out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLO
        "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
 if "--native" in sys.argv and world == 1:
     from ezkl_amd import native as NV
-    if "--pinned" in sys.argv:                     # witness in page-locked memory (ezkl_hip_host_malloc); measured: no gain over pageable here
+    if "--pinned" in sys.argv:                     # witness in page-locked memory (ezkl_hip_host_malloc): uploads run under the commits
         pinned = [B.PinnedArray((n, 4)) for _ in adv]
         for pa, a in zip(pinned, adv):
             pa.array[:] = a
