@@ -42,6 +42,16 @@ def test_constraint_system_analysis_matches_python(make):
                         n_advice_queries=len(cs.advice_queries), n_fixed_queries=len(cs.fixed_queries), n_instance_queries=len(cs.instance_queries))
 
 
+@pytest.mark.parametrize("seed", range(40, 60))
+def test_constraint_system_analysis_random_circuits(seed):
+    """degree / extended_k / permutation chunking / query sets of the C++ parser == the Python ConstraintSystem on random
+    gate sets (no GPU needed: the description is parsed and analysed on the host)"""
+    cs = random_circuit(seed, k=6 + seed % 5)[0]
+    info = N.NativeCircuit(cs).info()
+    assert info == dict(degree=cs.degree, ext_k=cs.ext_k, chunk=cs.chunk, n_chunks=cs.n_chunks, usable=cs.usable,
+                        n_advice_queries=len(cs.advice_queries), n_fixed_queries=len(cs.fixed_queries), n_instance_queries=len(cs.instance_queries))
+
+
 def test_malformed_circuit_descriptions_are_rejected():
     import ctypes as C
     good = N.serialize_cs(lookup_circuit(6))
