@@ -29,6 +29,7 @@ namespace ezkl {
 
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
+static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workgroup stages in LDS (104 KiB): 1024 scalars x 13 windows
 static constexpr uint32_t MSM_BINSORT_STAGE = 15360;  // payloads a sort workgroup stages in LDS (60 KiB): 2 workgroups per CU
 static constexpr uint32_t MSM_HEAVY_CHUNK = 1024;    // lane partials folded by one workgroup in the first heavy pass
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
@@ -160,7 +161,7 @@ __device__ __forceinline__ bool msm_digit_step(const fe_t& s, uint32_t neg, uint
 // No global atomics: every workgroup histograms its slice of scalars in LDS and stores the row; a column scan turns the
 // rows into per-(workgroup, partition) start slots; the partition pass ranks its pairs with LDS atomics.
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
-                                                       uint32_t LB, uint32_t NP, uint32_t* wg_hist) {
+                                                       uint32_t LB, uint32_t NP, uint32_t* wg_hist, uint32_t* wg_cnt) {
     __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
     for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
     __syncthreads();
@@ -186,7 +187,10 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
         }
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < NP; p += 256) wg_hist[(size_t)blockIdx.x * NP + p] = lh[p];   // row of this workgroup, coalesced
+    for (uint32_t p = threadIdx.x; p < NP; p += 256) {                 // row of this workgroup, coalesced; wg_hist is scanned in place later,
+        wg_hist[(size_t)blockIdx.x * NP + p] = lh[p];                   // wg_cnt keeps the raw counts for the partition pass's local ranking
+        wg_cnt[(size_t)blockIdx.x * NP + p] = lh[p];
+    }
 }
 // wg_hist[g][p] (G workgroups x NP partitions) -> in place, the exclusive prefix over g of column p; part_count[p] = column
 // total.  One workgroup per 32 columns: thread (c, j) sums the j-th chunk of G/32 rows of column c (a row segment of 32
@@ -235,24 +239,65 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
     if (t < NP) part_base[t] = sh[t] - v;
     if (t == NP - 1) part_base[NP] = sh[t];
 }
-// one pass: the slot of a pair is part_base[p] + (pairs of partition p in earlier workgroups) + its rank inside this
-// workgroup (LDS atomic) -- no global atomics, no second digit pass.  Measured split of its ~150 us at 2^20 points: the
-// 13.6 M scattered 8-byte stores are ~100 us (one L2 request each, whatever the partition count), digits + LDS ranks ~55 us.
-__global__ __launch_bounds__(256) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
-                                                            uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
-                                                            const uint32_t* part_base, const uint32_t* wg_hist, uint2* entries) {
-    __shared__ uint32_t lcur[1u << MSM_MAX_PART_BITS];
-    for (uint32_t p = threadIdx.x; p < NP; p += 256) lcur[p] = part_base[p] + wg_hist[(size_t)blockIdx.x * NP + p];
+// One pass, one scalar per thread.  A workgroup first ranks its (up to MSM_PART_STAGE) pairs into LDS grouped by partition
+// (start[p] = exclusive scan of its own histogram row, cursors advanced with LDS atomics), then writes them out in staged order:
+// consecutive lanes hold consecutive pairs of the same partition, i.e. consecutive global slots
+//     slot = part_base[p] + (pairs of partition p in earlier workgroups) + (index - start[p]).
+// The 13.6 M pairs of a 2^20-point MSM used to leave as 13.6 M scattered 8-byte stores, one L2 request each (~100 of the
+// kernel's 146 us); staged, a run of ~13 pairs of one partition is two cache lines.
+__global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
+                                                             uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
+                                                             const uint32_t* part_base, const uint32_t* wg_hist, const uint32_t* wg_cnt, uint2* entries) {
+    extern __shared__ uint32_t plds[];
+    __shared__ uint32_t tsum[1024];
+    uint32_t* start = plds;                    // NP: first staged index of partition p
+    uint32_t* cursor = plds + NP;              // NP: next free staged index
+    uint32_t* gbase = plds + 2 * NP;           // NP: global slot of the workgroup's first pair of partition p
+    uint2* stage = reinterpret_cast<uint2*>(plds + 3 * NP);
+    const uint32_t t = threadIdx.x, T = blockDim.x;
+    // exclusive scan of this workgroup's histogram row: K consecutive partitions per thread, then a scan over threads
+    const uint32_t K = (NP + T - 1) / T;
+    uint32_t loc = 0;
+    for (uint32_t q = 0; q < K; q++) {
+        const uint32_t p = t * K + q;
+        if (p < NP) loc += wg_cnt[(size_t)blockIdx.x * NP + p];
+    }
+    tsum[t] = loc;
     __syncthreads();
-    size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
-    const uint32_t PB = 31 - __clz(NP);
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+    for (uint32_t d = 1; d < T; d <<= 1) {
+        uint32_t x = t >= d ? tsum[t - d] : 0;
+        __syncthreads();
+        tsum[t] += x;
+        __syncthreads();
+    }
+    const uint32_t total = tsum[T - 1];
+    uint32_t run = tsum[t] - loc;
+    for (uint32_t q = 0; q < K; q++) {
+        const uint32_t p = t * K + q;
+        if (p < NP) {
+            start[p] = run;
+            cursor[p] = run;
+            gbase[p] = part_base[p] + wg_hist[(size_t)blockIdx.x * NP + p];
+            run += wg_cnt[(size_t)blockIdx.x * NP + p];
+        }
+    }
+    __syncthreads();
+    const size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+    const size_t i = lo + t;
+    if (i < hi) {
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
         msm_foreach_digit(s, neg, wp, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
-            uint32_t slot = atomicAdd(&lcur[bucket & (NP - 1)], 1u);
-            entries[slot] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket >> PB);
+            const uint32_t r = atomicAdd(&cursor[bucket & (NP - 1)], 1u);
+            stage[r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket);
         });
+    }
+    __syncthreads();
+    const uint32_t PB = 31 - __clz(NP);
+    for (uint32_t idx = t; idx < total; idx += T) {
+        const uint2 e = stage[idx];
+        const uint32_t p = e.y & (NP - 1);
+        entries[gbase[p] + (idx - start[p])] = make_uint2(e.x, e.y >> PB);
     }
 }
 // ---- sort pass 2: one workgroup per partition, counting sort on the low bucket bits in LDS ---------
@@ -609,6 +654,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     static int acc_blocks_per_cu = 0;
     if (!acc_blocks_per_cu) {
         EZ_HIP(hipFuncSetAttribute((const void*)msm_binsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         EZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&acc_blocks_per_cu, msm_accumulate_kernel, 256, 0));
         if (acc_blocks_per_cu < 1) acc_blocks_per_cu = 1;
     }
@@ -640,16 +686,17 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const uint32_t n_partA = nA * rg.GA, n_partT = nT * rg.GT;
     const uint32_t nplanes = 1 + bits;
     // ---- sort geometry: sgrid workgroups, each owning per_block consecutive scalars ----
-    unsigned sgrid = (unsigned)c->num_cus * 4;
-    if ((size_t)sgrid * 256 > n) sgrid = cdiv(n, 256);
-    const size_t per_block = ((n + sgrid - 1) / sgrid + 255) / 256 * 256;
-    sgrid = cdiv(n, per_block);
+    // (one scalar per thread of the partition pass; all of a workgroup's pairs must fit its LDS staging area)
+    size_t per_block = MSM_PART_STAGE / W / 64 * 64;
+    if (per_block > 1024) per_block = 1024;
+    if (per_block < 64) per_block = 64;
+    const unsigned sgrid = cdiv(n, per_block);
     // ---- carve scratch ----
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
-    size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_wgh = carve((size_t)sgrid * NP * 4);
+    size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_wgh = carve((size_t)sgrid * NP * 4), o_wgc = carve((size_t)sgrid * NP * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256), o_chunks = carve(((size_t)nlanes + 1) * 4);
     size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x29_t));
@@ -663,7 +710,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     uint2* entries = (uint2*)(S + o_ent);
     uint32_t* vals = (uint32_t*)(S + o_vals);
     uint32_t* offs = (uint32_t*)(S + o_offs);
-    uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *wghist = (uint32_t*)(S + o_wgh);
+    uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *wghist = (uint32_t*)(S + o_wgh), *wgcnt = (uint32_t*)(S + o_wgc);
     uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt), *chunks = (uint32_t*)(S + o_chunks);   // hcnt[0] buckets, [1] chunks
     uint32_t* lfirst = (uint32_t*)(S + o_lfirst);
     g1x29_t *bkt = (g1x29_t*)(S + o_bkt), *head = (g1x29_t*)(S + o_head), *tail = (g1x29_t*)(S + o_tail);
@@ -679,11 +726,11 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     EZ_HIP(hipMemsetAsync(hcnt, 0, 8, st));
     EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
     // sort
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt);
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NP, 32)), dim3(1024), 0, st, wghist, sgrid, NP, pcnt);
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase);
-    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, base_offset, T->n,
-                       pbase, wghist, entries);
+    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3((unsigned)per_block), (3 * (size_t)NP + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
+                       LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, offs, vals, bkt);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
