@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void msm_reduce1_kernel(const g1x29_t* buck
         const uint32_t nT = 1u << (g.wB + g.wC);
         if (idx >= nT * g.GT) return;
         const uint32_t grp = idx % g.GT, t = idx / g.GT;
-        for (uint32_t e = 0; e < g.ET; e++) acc = g1x29_add(acc, ld_g1x29(buckets + (((size_t)t << g.wA) | (grp * g.ET + e))));
+        for (uint32_t e = 0; e < g.ET; e++) acc = g1x29_add(acc, ld_g1x29(buckets + (((size_t)t << g.wA) | (e * g.GT + grp))));   // lanes = consecutive buckets
         st_g1x29(partT + (size_t)t * g.GT + grp, acc);
     }
 }
