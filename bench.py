@@ -234,7 +234,7 @@ def prove_leg_multi(world, rank, local_rank, args):
         if k_.startswith("TORCHELASTIC_") or k_ in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
                                                       "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
             env.pop(k_)
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "prove_bench.py")]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "prove_bench.py"), "--native", "--pinned"]
     if args.backend != "nccl":
         cmd.append("--gloo")
     if args.share_device:
@@ -244,10 +244,15 @@ def prove_leg_multi(world, rank, local_rank, args):
         if rank != 0:
             return None
         j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        nv = j.get("native_prover", {})
         return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
-                "n_gpus": j["n_gpus"], "msm_sharding": j["msm_sharding"], "host": "ezkl_amd/plonk.py (Python) + DistGpuBackend",
-                "prove_seconds_gpu": j["prove_seconds_gpu"], "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
-                "all_ranks_same_proof": True, "breakdown_seconds": j["prove_breakdown_seconds"]}
+                "n_gpus": j["n_gpus"], "msm_sharding": j["msm_sharding"],
+                "host": "libezkl_prover.so (C++), MSMs sharded by points (ezkl_prover_cs_set_shard): every rank holds 1/N of the SRS, one all_gather of 64-byte partials per commit batch",
+                "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "native_proof_identical_to_python_host": nv.get("proof_identical_to_python_prover"),
+                "all_ranks_same_proof": nv.get("all_ranks_same_proof"), "native_proof_verifies": nv.get("library_rng_proof_verifies"),
+                "breakdown_seconds": nv.get("breakdown_seconds_library_rng"),
+                "prove_seconds_gpu_python_host": j["prove_seconds_gpu"], "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
+                "breakdown_seconds_python_host": j["prove_breakdown_seconds"]}
     except Exception as e:
         return {"error": repr(e)[:300]} if rank == 0 else None
 

@@ -172,9 +172,10 @@ class MsmBatch:
         return out[:self.count]
 
 
-def upload_commit_batch(bases, host_cols, tails=None, tail_start=0):
+def upload_commit_batch(bases, host_cols, tails=None, tail_start=0, commit_range=None):
     """one prover phase: upload the host columns ((n,4) u64 arrays, ideally PinnedArray views), overwrite rows
-    [tail_start, tail_start + t) of column j with tails[j] ((t,4) arrays), commit each.  Returns (device columns, (batch, 8) points)."""
+    [tail_start, tail_start + t) of column j with tails[j] ((t,4) arrays), commit each (commit_range = (lo, hi): only rows [lo, hi)
+    against bases [0, hi - lo), a rank's slice of a sharded SRS).  Returns (device columns, (batch, 8) points)."""
     cols = [np.ascontiguousarray(a, np.uint64) for a in host_cols]
     n = cols[0].shape[0]
     devs = [DeviceBuffer(32 * n) for _ in cols]
@@ -186,8 +187,9 @@ def upload_commit_batch(bases, host_cols, tails=None, tail_start=0):
         tcount = keep[0].shape[0]
         tp = (C.c_void_p * len(cols))(*[t.ctypes.data for t in keep])
     out = np.zeros((len(cols), 8), np.uint64)
+    lo, hi = commit_range if commit_range is not None else (0, n)
     _l.check(_l.load().ezkl_hip_upload_commit_batch(bases.h, hp, dp, C.c_size_t(len(cols)), C.c_size_t(n), tp, C.c_size_t(tail_start), C.c_size_t(tcount),
-                                                    _p(out)), "ezkl_hip_upload_commit_batch")
+                                                    C.c_size_t(lo), C.c_size_t(hi - lo), _p(out)), "ezkl_hip_upload_commit_batch")
     return devs, out
 
 

@@ -319,15 +319,16 @@ int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t bat
     return rc;
 }
 int ezkl_hip_upload_commit_batch(ezkl_bases_t h, const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n,
-                                 const void* const* tail_rows, size_t tail_start, size_t tail_count, void* out) {
+                                 const void* const* tail_rows, size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count,
+                                 void* out) {
     if (!h || (batch && (!host_cols || !dev_cols || !out))) return EZKL_ERR_INVALID;
     Bases* b = reinterpret_cast<Bases*>(h);
-    if (n > b->n) return EZKL_ERR_INVALID;
+    if (commit_count > b->n || commit_first > n || commit_count > n - commit_first) return EZKL_ERR_INVALID;
     for (size_t j = 0; j < batch; j++)
         if (!host_cols[j] || !dev_cols[j] || (tail_rows && tail_count && !tail_rows[j])) return EZKL_ERR_INVALID;
     EZ_CTX(c);
     return msm_upload_commit(c, b, (const fe_t* const*)host_cols, (fe_t* const*)dev_cols, batch, n, (const fe_t* const*)tail_rows, tail_start,
-                             tail_count, out);
+                             tail_count, commit_first, commit_count, out);
 }
 int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_msm_batch_t* out) {
     if (!h || !out) return EZKL_ERR_INVALID;

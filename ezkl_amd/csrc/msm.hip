@@ -825,12 +825,12 @@ static hipStream_t g_copy_st = nullptr;
 static fe_t* g_tail_pinned = nullptr;
 static size_t g_tail_pinned_elems = 0;
 int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails,
-                      size_t tail_start, size_t tail_count, void* out_host) {
+                      size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count, void* out_host) {
     if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (batch == 0) return EZKL_OK;
-    if (n == 0 || tail_start + tail_count > n) return EZKL_ERR_INVALID;
+    if (n == 0 || tail_start + tail_count > n || commit_first + commit_count > n) return EZKL_ERR_INVALID;
     MsmTable* T = nullptr;
-    int rc = table_get(c, c->stream, b, &T);
+    int rc = commit_count ? table_get(c, c->stream, b, &T) : EZKL_OK;
     if (rc) return rc;
     if (!g_copy_st) EZ_HIP(hipStreamCreateWithFlags(&g_copy_st, hipStreamNonBlocking));
     if (tails && tail_count && batch * tail_count > g_tail_pinned_elems) {
@@ -859,7 +859,8 @@ int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t
             return set_hip_error(e, "msm_upload_commit", __FILE__, __LINE__);
         }
     }
-    for (size_t j = 0; j < batch + MSM_SLOTS && !rc; j++) {
+    if (commit_count == 0) memset(out_host, 0, 64 * batch);           // empty slice: the identity
+    for (size_t j = 0; commit_count && j < batch + MSM_SLOTS && !rc; j++) {
         if (j >= MSM_SLOTS) {
             size_t done = j - MSM_SLOTS;
             if (done < batch) rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done);
@@ -868,7 +869,7 @@ int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t
             MsmSlot& sl = g_slots[j % MSM_SLOTS];
             rc = slot_prepare(sl, 0);
             if (!rc && hipStreamWaitEvent(sl.st, ev[j], 0) != hipSuccess) rc = EZKL_ERR_HIP;
-            if (!rc) rc = msm_enqueue(c, sl, sl.st, T, 0, dev_cols[j], n, false);
+            if (!rc) rc = msm_enqueue(c, sl, sl.st, T, 0, dev_cols[j] + commit_first, commit_count, false);
         }
     }
     (void)hipStreamSynchronize(g_copy_st);

@@ -43,6 +43,13 @@ struct Lookup {
     std::vector<std::vector<uint32_t>> inputs;
     std::vector<uint32_t> table;
 };
+// MSMs sharded by points (ezkl_prover_cs_set_shard): this rank's SRS handles hold points [lo, hi) only
+struct Shard {
+    uint32_t lo = 0, hi = 0;          // hi == 0: not sharded
+    ezkl_fold_fn fold = nullptr;
+    void* user = nullptr;
+    bool on() const { return hi != 0; }
+};
 struct ConstraintSystem {
     uint32_t k = 0, n = 0, n_advice = 0, n_fixed = 0, n_instance = 0, n_challenges = 0;
     std::vector<uint32_t> advice_phase;
@@ -53,6 +60,7 @@ struct ConstraintSystem {
     uint32_t usable = 0, degree = 0, chunk = 0, ext_k = 0, n_chunks = 0;
     std::vector<Query> advice_queries, fixed_queries, instance_queries;
     std::vector<uint32_t> deg_memo;
+    Shard shard;
 
     uint32_t deg(uint32_t id) {
         if (deg_memo[id] != UINT32_MAX) return deg_memo[id];
@@ -301,9 +309,17 @@ struct Lowering {
 struct Backend {
     uint32_t k, n;
     ezkl_bases_t g, gl;
+    Shard shard;
     Fe one = Fe::one();
     std::map<U256, std::pair<Col, Col>> zpow;       // kate_div: z^j and z^-(j+1) columns per opening point
-    Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_) : k(k_), n(n_), g(g_), gl(gl_) {}
+    Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_, const Shard& sh = Shard()) : k(k_), n(n_), g(g_), gl(gl_), shard(sh) {}
+    size_t commit_first() const { return shard.on() ? shard.lo : 0; }
+    size_t commit_count() const { return shard.on() ? shard.hi - shard.lo : n; }
+    // sharded: the partial sums over this rank's slice become the sums over all ranks (one all_gather per batch on the caller's side)
+    void fold(std::vector<G1>& pts) const {
+        if (!shard.on() || pts.empty()) return;
+        if (shard.fold(shard.user, pts.data(), (uint32_t)pts.size()) != 0) throw Error(EZKL_ERR_INVALID, "fold callback failed");
+    }
 
     Col alloc(size_t m) const { return std::make_shared<DeviceColumn>(m); }
     Col upload(const void* host, size_t m) const {
@@ -337,8 +353,9 @@ struct Backend {
         std::vector<G1> out(hs.size());
         if (hs.empty()) return out;
         std::vector<const void*> ptrs;
-        for (auto& h : hs) ptrs.push_back(h->ptr());
-        check(ezkl_hip_msm_g1_batch_dev(b, 0, ptrs.data(), ptrs.size(), n, out.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+        for (auto& h : hs) ptrs.push_back(at(h, commit_first()));
+        check(ezkl_hip_msm_g1_batch_dev(b, 0, ptrs.data(), ptrs.size(), commit_count(), out.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+        fold(out);
         return out;
     }
     std::vector<G1> commit_lagrange(const std::vector<Col>& hs) const { return commit_with(gl, hs); }
@@ -517,7 +534,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     invalid(cs.n_advice > 255 || cs.n_fixed > 255 || cs.perm.size() > 255 || cs.n_instance > 255 || cs.n_challenges > 255 || cs.lookups.size() > 255 || cs.degree > 255,
             "column / argument counts above 255 are not supported by the vk digest");
     const uint32_t n = cs.n, k = cs.k;
-    Backend be(k, n, g, nullptr);
+    Backend be(k, n, g, nullptr, cs.shard);
     auto pk = std::make_unique<ProvingKey>();
     pk->cs = &cs;
     for (uint32_t c = 0; c < cs.n_fixed; c++) {
@@ -1039,7 +1056,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
                                          const void* const* instances, const uint32_t* instance_lens, Rng& rng, double* timings) {
     ConstraintSystem& cs = *pk.cs;
     const uint32_t n = cs.n, k = cs.k, u = cs.usable;
-    Backend be(k, n, g, gl);
+    Backend be(k, n, g, gl, cs.shard);
     Stopwatch sw(timings);
     EvmTranscript T;
     T.common_scalar(pk.digest);
@@ -1094,7 +1111,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
         for (auto& t : tails) tailp.push_back(t.data());
         std::vector<G1> commits(idxs.size());
-        check(ezkl_hip_upload_commit_batch(gl, hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, commits.data()), "ezkl_hip_upload_commit_batch");
+        check(ezkl_hip_upload_commit_batch(gl, hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, be.commit_first(), be.commit_count(),
+                                           commits.data()), "ezkl_hip_upload_commit_batch");
+        be.fold(commits);
         for (auto& p : commits) T.write_point(p);
         if (phase == 0)
             for (uint32_t i = 0; i < cs.n_challenges; i++) user_chal.push_back(T.squeeze_challenge());
@@ -1316,10 +1335,20 @@ int ezkl_prover_cs_info(ezkl_cs_t h, uint32_t out[8]) {
     std::memcpy(out, v, sizeof v);
     return EZKL_OK;
 }
+int ezkl_prover_cs_set_shard(ezkl_cs_t h, uint32_t lo, uint32_t hi, ezkl_fold_fn fold, void* user) {
+    if (!h) return EZKL_ERR_INVALID;
+    if (hi == 0 && lo == 0) {                  // back to one GPU
+        h->cs->shard = Shard();
+        return EZKL_OK;
+    }
+    if (!fold || lo >= hi || hi > h->cs->n) return EZKL_ERR_INVALID;
+    h->cs->shard = Shard{lo, hi, fold, user};
+    return EZKL_OK;
+}
 int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies, ezkl_pk_t* out) {
     if (!cs || !g || !out || (cs->cs->n_fixed && !fixed_values) || (n_copies && !copies)) return EZKL_ERR_INVALID;
     return guarded([&] {
-        invalid(ezkl_hip_bases_len(g) < cs->cs->n, "SRS smaller than 2^k");
+        invalid(ezkl_hip_bases_len(g) < (cs->cs->shard.on() ? cs->cs->shard.hi - cs->cs->shard.lo : cs->cs->n), "SRS smaller than 2^k (or than this rank's slice)");
         *out = new ezkl_prover_pk{keygen(*cs->cs, g, fixed_values, copies, n_copies)};
     });
 }
@@ -1354,7 +1383,10 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
     if (!pk || !g || !g_lagrange || !proof_len) return EZKL_ERR_INVALID;
     if (pk->pk->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
     return guarded([&] {
-        invalid(ezkl_hip_bases_len(g) < pk->pk->cs->n || ezkl_hip_bases_len(g_lagrange) != pk->pk->cs->n, "SRS size does not match 2^k");
+        const Shard& sh = pk->pk->cs->shard;
+        const size_t want = sh.on() ? sh.hi - sh.lo : pk->pk->cs->n;
+        invalid(sh.on() && !rng && seed == 0, "sharded proving needs the same randomness on every rank: pass a seed or an rng callback");
+        invalid(ezkl_hip_bases_len(g) < want || ezkl_hip_bases_len(g_lagrange) != want, "SRS size does not match 2^k (or this rank's slice)");
         Rng r(rng, rng_user, seed);
         std::vector<uint8_t> proof = create_proof(*pk->pk, g, g_lagrange, advice, advice_fn, advice_user, instances, instance_lens, r, timings);
         *proof_len = proof.size();

@@ -13,10 +13,11 @@ from . import plonk as _pl
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_vk",
+SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+FOLD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
 STAGES = ["advice_commit", "lookup_m", "permutation_z", "lookup_phi", "random_poly", "intt_and_coset_ntt", "quotient_sweep", "h_split_commit",
           "evaluations", "shplonk", "total"]
 
@@ -112,6 +113,32 @@ class NativeCircuit:
         out = (C.c_uint32 * 8)()
         _check(load().ezkl_prover_cs_info(self.h, out), "ezkl_prover_cs_info")
         return dict(zip(["degree", "ext_k", "chunk", "n_chunks", "usable", "n_advice_queries", "n_fixed_queries", "n_instance_queries"], list(out)))
+
+    def set_shard(self, dist, device):
+        """Shard the MSMs of keygen / create_proof by points over the ranks of `dist` (torch.distributed, nccl = RCCL on the
+        GPU box): afterwards the Bases handles passed to NativeProvingKey / create_proof must hold this rank's slice
+        `shard_slice()` of the SRS.  Each commit batch costs one all_gather of 64-byte partials."""
+        from . import dist as D
+        world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        lo, hi = D.shard_range(self.cs.n, rank, world)
+
+        def _fold(_user, pts, count):
+            try:
+                a = np.ctypeslib.as_array(C.cast(pts, C.POINTER(C.c_uint64)), shape=(count, 8))
+                a[:] = D.fold_columns(D.allgather_points(a.copy(), dist, device))
+                return 0
+            except Exception:                         # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._fold = FOLD_FN(_fold)                   # keep the thunk alive as long as the handle
+        self._slice = (lo, hi)
+        _check(load().ezkl_prover_cs_set_shard(self.h, C.c_uint32(lo), C.c_uint32(hi), self._fold, None), "ezkl_prover_cs_set_shard")
+        return lo, hi
+
+    def shard_slice(self):
+        return getattr(self, "_slice", (0, self.cs.n))
 
     def free(self):
         if self.h:

@@ -91,12 +91,14 @@ int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* co
  * time; the other MSM entry points return EZKL_ERR_INVALID while it is. */
 /* One prover phase in one call (create_proof: "assign advice, blind, commit"): host_cols[j] (n x 32 B) is copied into the
  * caller's device column dev_cols[j], rows [tail_start, tail_start + tail_count) are overwritten with tail_rows[j] (the blinding
- * values; tail_rows may be NULL) and the column is committed against the first n bases; out_affine gets `batch` points.
+ * values; tail_rows may be NULL) and rows [commit_first, commit_first + commit_count) of the column are committed against
+ * bases [0, commit_count) (the whole column: 0, n; a rank holding one slice of the SRS: its slice); out_affine gets `batch` points.
  * Every copy is queued at once on a dedicated copy stream and the MSM of column j only waits for ITS copy, so the PCIe
  * traffic of the later columns runs under the kernels of the earlier ones.  Page-locked host columns
  * (ezkl_hip_host_malloc) make the copies asynchronous; pageable ones work but are staged by the runtime. */
 int ezkl_hip_upload_commit_batch(ezkl_bases_t h, const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n,
-                                 const void* const* tail_rows, size_t tail_start, size_t tail_count, void* out_affine);
+                                 const void* const* tail_rows, size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count,
+                                 void* out_affine);
 typedef struct ezkl_msm_batch_s* ezkl_msm_batch_t;
 int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_msm_batch_t* out_batch);
 int ezkl_hip_msm_batch_push_dev(ezkl_msm_batch_t batch, const void* scalars_dev);

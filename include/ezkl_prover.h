@@ -44,6 +44,17 @@ int ezkl_prover_cs_free(ezkl_cs_t cs);
  * #fixed queries, #instance queries */
 int ezkl_prover_cs_info(ezkl_cs_t cs, uint32_t out[8]);
 
+/* ---- multi-GPU: the MSMs of keygen / create_proof sharded by points (BASELINE configs[3]) ----
+ * One process per GPU, every rank running the same deterministic prover on replicated columns.  After this call the `g` /
+ * `g_lagrange` handles given to keygen / create_proof hold only points [lo, hi) of the SRS (base-set memory and MSM work divide
+ * by the number of ranks); every commit batch is computed as partial sums over rows [lo, hi) and handed to `fold`, which must
+ * replace the `count` 64-byte affine Montgomery points IN PLACE by their sums over all ranks (one all_gather of the partials
+ * over RCCL + ezkl_hip_g1_add_affine: ezkl_amd/native.py) and return 0.  All ranks then derive the same transcript and emit the
+ * same proof bytes as the unsharded prover.  An empty slice is not allowed (lo < hi <= 2^k); lo = hi = 0 switches sharding off.
+ * The randomness must be the same on every rank (a shared `seed`, or an rng callback that is). */
+typedef int (*ezkl_fold_fn)(void* user, void* points, uint32_t count);
+int ezkl_prover_cs_set_shard(ezkl_cs_t cs, uint32_t lo, uint32_t hi, ezkl_fold_fn fold, void* user);
+
 /* ---- keygen (keygen_vk + keygen_pk): fixed columns and copy constraints -> resident proving key ----
  * fixed_values: n_fixed host pointers, 2^k x 32 B Montgomery Fr each.  copies: n_copies x {colpos_a, row_a, colpos_b, row_b}
  * with colpos indexing the permutation column list.  g = the SRS in coefficient basis (ParamsKZG::g).  The cs handle is

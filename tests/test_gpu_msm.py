@@ -283,6 +283,18 @@ def test_upload_commit_batch(hip):
         assert (commits[j] == ob.msm(want, pts)).all()
     devs2, commits2 = B.upload_commit_batch(bases, cols[:2])          # no blinding rows
     assert (commits2[1] == ob.msm(cols[1], pts)).all() and (devs2[0].to_numpy(shape=(n, 4)) == cols[0]).all()
+    # a rank's slice of a sharded SRS: the whole column is uploaded and blinded, rows [lo, hi) are committed against bases [0, hi - lo)
+    lo, hi = 1000, 3001
+    devs3, commits3 = B.upload_commit_batch(bases, cols[:3], tails[:3], t0, commit_range=(lo, hi))
+    for j in range(3):
+        want = cols[j].copy()
+        want[t0:] = tails[j]
+        assert (devs3[j].to_numpy(shape=(n, 4)) == want).all()
+        assert (commits3[j] == ob.msm(want[lo:hi], pts[: hi - lo])).all()
+    _, commits4 = B.upload_commit_batch(bases, cols[:2], commit_range=(5, 5))     # empty slice: the identity
+    assert not commits4.any()
+    with pytest.raises(RuntimeError):
+        B.upload_commit_batch(bases, cols[:1], commit_range=(n - 4, n + 4))
     for pa in pinned:
         pa.free()
     bases.free()

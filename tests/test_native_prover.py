@@ -78,6 +78,21 @@ def test_malformed_circuit_descriptions_are_rejected():
     assert parse(bad) == -3
 
 
+def test_shard_arguments_are_validated():
+    """ezkl_prover_cs_set_shard: empty / out-of-range slices and a missing fold callback are refused (no GPU needed)"""
+    import ctypes as C
+    circ = N.NativeCircuit(mul_add_circuit(6))
+    L = N.load()
+    fold = N.FOLD_FN(lambda user, pts, count: 0)
+    assert L.ezkl_prover_cs_set_shard(circ.h, C.c_uint32(0), C.c_uint32(32), fold, None) == 0
+    assert L.ezkl_prover_cs_set_shard(circ.h, C.c_uint32(32), C.c_uint32(64), fold, None) == 0
+    assert L.ezkl_prover_cs_set_shard(circ.h, C.c_uint32(0), C.c_uint32(0), C.cast(None, N.FOLD_FN), None) == 0       # off again
+    assert L.ezkl_prover_cs_set_shard(circ.h, C.c_uint32(8), C.c_uint32(8), fold, None) == -3                          # empty
+    assert L.ezkl_prover_cs_set_shard(circ.h, C.c_uint32(0), C.c_uint32(65), fold, None) == -3                         # beyond 2^k
+    assert L.ezkl_prover_cs_set_shard(circ.h, C.c_uint32(0), C.c_uint32(32), C.cast(None, N.FOLD_FN), None) == -3      # no callback
+    assert L.ezkl_prover_cs_set_shard(None, C.c_uint32(0), C.c_uint32(32), fold, None) == -3
+
+
 # ------------------------------------------------------------------ GPU
 def _native_setup(golden_srs, cs, fixed, copies):
     from ezkl_amd import backend as B
@@ -141,6 +156,40 @@ def test_native_proof_bit_identical_instances_and_second_phase(hip, golden_srs):
 def test_native_proof_bit_identical_random_circuits(hip, golden_srs, seed):
     cs, adv, fixed, copies = random_circuit(seed)
     _check_against_python(golden_srs, cs, adv, fixed, copies, seed)
+
+
+@pytest.mark.gpu
+def test_native_sharded_commit_path_single_rank(hip, golden_srs):
+    """ezkl_prover_cs_set_shard with one rank owning the whole range: every commitment goes through the slice MSM + fold
+    callback and the proof bytes do not change; a failing fold aborts the proof; sharding without shared randomness is refused.
+    (Two real ranks: tests/test_plonk.py::test_msm_sharded_prover_two_ranks_same_proof.)"""
+    import ctypes as C
+    from ezkl_amd import backend as B
+    cs = lookup_circuit(6)
+    adv, fixed, copies = lookup_witness(cs, 4)
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    want = N.create_proof(pk, g, gl, adv, rng=det_rng(3))
+    circ = N.NativeCircuit(cs)
+    assert circ.set_shard(None, None) == (0, cs.n) and circ.shard_slice() == (0, cs.n)
+    pk2 = N.NativeProvingKey(circ, g, fixed, copies)
+    assert pk2.vk()[2] == pk.vk()[2]
+    assert N.create_proof(pk2, g, gl, adv, rng=det_rng(3)) == want
+    assert N.create_proof(pk2, g, gl, adv, seed=9) == N.create_proof(pk, g, gl, adv, seed=9)
+    with pytest.raises(RuntimeError, match="randomness"):
+        N.create_proof(pk2, g, gl, adv)                               # seed 0 = OS entropy: ranks would diverge
+    calls = []
+    bad = N.FOLD_FN(lambda user, pts, count: calls.append(count) or 1)
+    assert N.load().ezkl_prover_cs_set_shard(circ.h, C.c_uint32(0), C.c_uint32(cs.n), bad, None) == 0
+    with pytest.raises(RuntimeError, match="fold"):
+        N.create_proof(pk2, g, gl, adv, rng=det_rng(3))
+    assert calls == [cs.n_advice]                                      # the first commit batch: all phase-0 advice columns
+    # a slice needs slice-sized SRS handles
+    half = N.FOLD_FN(lambda user, pts, count: 0)
+    assert N.load().ezkl_prover_cs_set_shard(circ.h, C.c_uint32(0), C.c_uint32(cs.n // 2), half, None) == 0
+    with pytest.raises(RuntimeError, match="slice"):
+        N.create_proof(pk2, g, gl, adv, rng=det_rng(3))
+    gh, glh = B.Bases(golden_srs["g"][: cs.n // 2]), B.Bases(golden_srs["g_lagrange"][: cs.n // 2])
+    assert len(N.create_proof(pk2, gh, glh, adv, rng=det_rng(3))) == len(want)       # runs; the bytes are one rank's partial view
 
 
 @pytest.mark.gpu

@@ -342,13 +342,16 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py")], env=env, capture_output=True, text=True, timeout=600)
     j1 = json.loads(one.stdout.strip().splitlines()[-1])
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29541", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo"],
+                          "--master-port", "29541", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo", "--native"],
                          env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
     assert lines, two.stderr[-2000:]
     j2 = json.loads(lines[-1])
     assert j1["verifier_accepts"] and j2["verifier_accepts"]
     assert j2["n_gpus"] == 2 and j1["proof_sha256"] == j2["proof_sha256"]
+    # the C++ host prover sharded the same way (ezkl_prover_cs_set_shard): same bytes as the Python host, same on both ranks
+    nv = j2["native_prover"]
+    assert nv["proof_identical_to_python_prover"] and nv["all_ranks_same_proof"] and nv["library_rng_proof_verifies"]
 
 
 @pytest.mark.gpu
@@ -370,3 +373,5 @@ def test_bench_contract_two_ranks(hip):
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["vs_baseline"] is None and "workload" in j["config"]
     assert abs(j["value"] - 2 * (1 << 20) * 3 / (j["ms_per_step"] * 3e-3)) < 1e-3 * j["value"]
     assert j["prove"].get("verifier_accepts") is True and j["prove"]["n_gpus"] == 2
+    assert j["prove"]["native_proof_identical_to_python_host"] is True and j["prove"]["all_ranks_same_proof"] is True and j["prove"]["native_proof_verifies"] is True
+    assert j["prove"]["prove_seconds_gpu"] > 0

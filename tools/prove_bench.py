@@ -124,6 +124,31 @@ def run(backend_name):
     return vk, proof, t_keygen, t_prove
 
 vk, proof, t_keygen, t_prove = run("hip")
+native_multi = None
+if world > 1 and "--native" in sys.argv:
+    # the C++ host prover with its MSMs sharded the same way (ezkl_prover_cs_set_shard): every rank holds its slice of the SRS
+    from ezkl_amd import native as NV
+    import hashlib, torch
+    if "--pinned" in sys.argv:
+        pinned = [B.PinnedArray((n, 4)) for _ in adv]
+        for pa, a in zip(pinned, adv):
+            pa.array[:] = a
+        adv = [pa.array for pa in pinned]
+    nc = NV.NativeCircuit(cs)
+    lo, hi = nc.set_shard(dist, ddev)
+    gb_, glb_ = B.Bases(np.ascontiguousarray(g[lo:hi])), B.Bases(np.ascontiguousarray(gl[lo:hi]))
+    npk = NV.NativeProvingKey(nc, gb_, fixed, copies)
+    nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5))   # warm-up; same randomness as the Python host above
+    ltm = {}
+    dist.barrier()
+    t0 = time.time(); lproof = NV.create_proof(npk, gb_, glb_, adv, seed=5, timings=ltm); t_native = time.time() - t0
+    hs_ = torch.tensor(list(hashlib.sha256(lproof).digest()), dtype=torch.uint8, device=ddev)
+    all_h = [torch.empty_like(hs_) for _ in range(world)]
+    dist.all_gather(all_h, hs_)
+    tt = torch.tensor([t_native], dtype=torch.float64, device=ddev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    native_multi = {"prove_seconds_library_rng": round(float(tt[0]), 4), "proof_identical_to_python_prover": nproof == proof,
+                    "all_ranks_same_proof": all(bool((h == all_h[0]).all()) for h in all_h), "library_rng_proof": lproof,
+                    "breakdown_seconds_library_rng": {a: round(b, 4) for a, b in ltm.items()}}
 if world > 1:
     import hashlib, torch
     hs_ = torch.tensor(list(hashlib.sha256(proof).digest()), dtype=torch.uint8, device=ddev)
@@ -141,6 +166,10 @@ out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLO
        "k": k, "advice_columns": cs.n_advice, "fixed_columns": cs.n_fixed, "degree": cs.degree, "ext_k": cs.ext_k, "copies": len(copies),
        "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "keygen_seconds_gpu": round(t_keygen, 3),
        "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
+if native_multi is not None:
+    lproof = native_multi.pop("library_rng_proof")
+    native_multi["library_rng_proof_verifies"] = bool(V.verify(vk, (1, 2), g2, s_g2, lproof))
+    out["native_prover"] = native_multi
 if "--native" in sys.argv and world == 1:
     from ezkl_amd import native as NV
     if "--pinned" in sys.argv:                     # witness in page-locked memory (ezkl_hip_host_malloc): uploads run under the commits
