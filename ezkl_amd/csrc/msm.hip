@@ -159,7 +159,8 @@ __device__ __forceinline__ bool msm_digit_step(const fe_t& s, uint32_t neg, uint
 // values in a small numeric range, so the partitions stay balanced).  Buckets are stored at position
 // pos = (bucket & (NP-1)) * 2^LB + (bucket >> PB); the reduce phase weights positions accordingly.
 // No global atomics: every workgroup histograms its slice of scalars in LDS and stores the row; a column scan turns the
-// rows into per-(workgroup, partition) start slots; the partition pass ranks its pairs with LDS atomics.
+// rows into per-(workgroup, partition) start slots; the partition pass ranks its pairs with LDS atomics into an LDS
+// staging area grouped by partition and writes them out in staged order (runs of one partition leave as whole cache lines).
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                        uint32_t LB, uint32_t NP, uint32_t* wg_hist, uint32_t* wg_cnt) {
     __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
 // Perfectly balanced segmented accumulation: lane t owns sorted pairs [t*L, (t+1)*L) regardless of bucket
 // boundaries.  A bucket that lies inside one lane's range is written directly; a bucket cut by a lane
 // boundary leaves partial sums in tail[t] (continues into lane t+1) / head[t] (started before lane t), which
-// msm_fixup_kernel folds.  Each pair costs one 64-byte gather from T and one mixed add (8M + 2S).
+// msm_fixup_boundary_kernel folds.  Each pair costs one 64-byte gather from T and one mixed add (8M + 2S).
 // a gathered table record: 64 bytes, canonical coordinates in R' = 2^261 Montgomery form (msm_table_to_r261_kernel); the
 // sign bit of the pair selects -P, applied inside the mixed addition
 struct MsmRec {
@@ -436,9 +437,9 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
     }
 }
 // A bucket cut by lane boundaries is tail[t1] + head[t1+1 .. t2].  One thread per LANE BOUNDARY (not per bucket: with
-// ~26 pairs per bucket and ~52 per lane nearly every boundary cuts a bucket, so the waves are full).  The common case,
+// ~26 pairs per bucket and ~69 per lane nearly every boundary cuts a bucket, so the waves are full).  The common case,
 // a bucket cut once, is one addition; a bucket cut a few times is folded serially by its first boundary; anything
-// longer (a skewed witness) is queued for msm_fixup_heavy_kernel.
+// longer (a skewed witness) is queued for msm_fixup_heavy{1,2}_kernel.
 __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, uint32_t nlanes,
                                                                  const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
                                                                  uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list) {
