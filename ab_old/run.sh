@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B: previous build (ab_old/) vs in-tree build, alternating, same box
+for i in 1 2 3; do
+  for v in old new; do
+    if [ $v = old ]; then export EZKL_HIP_LIB=$PWD/ab_old/libezkl_hip.so EZKL_PROVER_LIB=$PWD/ab_old/libezkl_prover.so; else unset EZKL_HIP_LIB EZKL_PROVER_LIB; fi
+    K=${K:-20} BLOCKS=4 python tools/prove_bench.py --native --pinned 2>/dev/null | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); nv=j['native_prover']
+print('$v', 'py', j['prove_seconds_gpu'], j['prove_breakdown_seconds'], 'native', nv['prove_seconds_library_rng'], nv['breakdown_seconds_library_rng'])"
+  done
+done

@@ -172,6 +172,59 @@ class MsmBatch:
         return out[:self.count]
 
 
+class Stream:
+    """a caller stream for the `stream=` arguments (pass `.ptr`): work queued on it is asynchronous until synchronize()"""
+
+    def __init__(self):
+        p = _vp()
+        _l.check(_l.load().ezkl_hip_stream_create(C.byref(p)), "ezkl_hip_stream_create")
+        self.ptr = p.value
+
+    def synchronize(self):
+        _l.check(_l.load().ezkl_hip_stream_synchronize(_vp(self.ptr)), "ezkl_hip_stream_synchronize")
+
+    def free(self):
+        if self.ptr:
+            _l.check(_l.load().ezkl_hip_stream_destroy(_vp(self.ptr)), "ezkl_hip_stream_destroy")
+            self.ptr = None
+
+
+class UploadPhase:
+    """upload_commit_batch in steps (ezkl_hip_upload_begin / _wait / _commit / _end): the copies are queued by the
+    constructor; wait(j, stream) orders a caller stream behind column j; commit(bases) returns the (batch, 8) points;
+    end() closes the phase.  The host columns are kept alive until end()."""
+
+    def __init__(self, host_cols, tails=None, tail_start=0):
+        self.cols = [np.ascontiguousarray(a, np.uint64) for a in host_cols]
+        self.n = self.cols[0].shape[0]
+        self.devs = [DeviceBuffer(32 * self.n) for _ in self.cols]
+        m = len(self.cols)
+        hp = (C.c_void_p * m)(*[a.ctypes.data for a in self.cols])
+        dp = (C.c_void_p * m)(*[d.ptr for d in self.devs])
+        tp, tcount, self._tails = None, 0, []
+        if tails is not None:
+            self._tails = [np.ascontiguousarray(t, np.uint64) for t in tails]
+            tcount = self._tails[0].shape[0]
+            tp = (C.c_void_p * m)(*[t.ctypes.data for t in self._tails])
+        self.h = _vp()
+        _l.check(_l.load().ezkl_hip_upload_begin(hp, dp, C.c_size_t(m), C.c_size_t(self.n), tp, C.c_size_t(tail_start), C.c_size_t(tcount), C.byref(self.h)),
+                 "ezkl_hip_upload_begin")
+
+    def wait(self, j, stream):
+        _l.check(_l.load().ezkl_hip_upload_wait(self.h, C.c_size_t(j), _vp(stream.ptr if isinstance(stream, Stream) else stream)), "ezkl_hip_upload_wait")
+
+    def commit(self, bases, commit_range=None):
+        lo, hi = commit_range if commit_range is not None else (0, self.n)
+        out = np.zeros((len(self.cols), 8), np.uint64)
+        _l.check(_l.load().ezkl_hip_upload_commit(self.h, bases.h, C.c_size_t(lo), C.c_size_t(hi - lo), _p(out)), "ezkl_hip_upload_commit")
+        return out
+
+    def end(self):
+        if self.h:
+            h, self.h = self.h, None
+            _l.check(_l.load().ezkl_hip_upload_end(h), "ezkl_hip_upload_end")
+
+
 def upload_commit_batch(bases, host_cols, tails=None, tail_start=0, commit_range=None):
     """one prover phase: upload the host columns ((n,4) u64 arrays, ideally PinnedArray views), overwrite rows
     [tail_start, tail_start + t) of column j with tails[j] ((t,4) arrays), commit each (commit_range = (lo, hi): only rows [lo, hi)

@@ -140,8 +140,11 @@ const char* ezkl_hip_version(void) { return "ezkl_hip 0.1 (gfx950)"; }
 
 // Column buffers are recycled: hipMalloc / hipFree cost ~0.2 ms each (hipFree synchronises the device) and a prover
 // allocates and drops hundreds of same-sized columns per proof.  Freed blocks are parked per exact size (up to
-// POOL_CAP bytes) and handed out again; work on a recycled block is ordered by the device-wide sync hipFree would have
-// implied only when the pool actually returns memory to the driver.
+// POOL_CAP bytes) and handed out again.  Ordering contract (the one of every caching allocator): calls on the library
+// stream are complete when they return, so a block the caller only ever used through stream = NULL calls is idle when it
+// is freed; a caller that used it on ITS OWN stream synchronises that stream before freeing it.  (hipFree's implicit
+// device-wide sync on every reuse was measured at 0.3 ms per allocation with the library's ten streams alive, and it turned
+// every allocation into a barrier for work in flight on other streams; EZKL_HIP_POOL_SYNC=1 brings it back for debugging.)
 namespace {
 std::map<size_t, std::vector<void*>> g_pool;          // guarded by the ctx mutex
 std::map<void*, size_t> g_sizes;
@@ -157,8 +160,8 @@ int ezkl_hip_malloc(void** dptr, size_t bytes) {
         *dptr = it->second.back();
         it->second.pop_back();
         g_pool_bytes -= bytes;
-        // the previous owner's kernels may still be running on another stream: order them before the new owner's
-        EZ_HIP(hipDeviceSynchronize());
+        static const bool pool_sync = getenv("EZKL_HIP_POOL_SYNC") != nullptr;
+        if (pool_sync) EZ_HIP(hipDeviceSynchronize());
         return EZKL_OK;
     }
     hipError_t e = hipMalloc(dptr, bytes);
@@ -318,17 +321,72 @@ int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t bat
     (void)hipFree(d);
     return rc;
 }
+static int upload_args_ok(const void* const* host_cols, void* const* dev_cols, size_t batch, const void* const* tail_rows, size_t tail_count) {
+    if (batch && (!host_cols || !dev_cols)) return 0;
+    for (size_t j = 0; j < batch; j++)
+        if (!host_cols[j] || !dev_cols[j] || (tail_rows && tail_count && !tail_rows[j])) return 0;
+    return 1;
+}
+int ezkl_hip_upload_begin(const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n, const void* const* tail_rows, size_t tail_start,
+                          size_t tail_count, ezkl_upload_t* out) {
+    if (!out || !upload_args_ok(host_cols, dev_cols, batch, tail_rows, tail_count)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    MsmUpload* u = nullptr;
+    int rc = msm_upload_begin(c, (const fe_t* const*)host_cols, (fe_t* const*)dev_cols, batch, n, (const fe_t* const*)tail_rows, tail_start, tail_count, &u);
+    if (!rc) *out = reinterpret_cast<ezkl_upload_t>(u);
+    return rc;
+}
+int ezkl_hip_upload_wait(ezkl_upload_t u, size_t column, void* stream) {
+    if (!u || !stream) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_upload_wait(reinterpret_cast<MsmUpload*>(u), column, (hipStream_t)stream);
+}
+int ezkl_hip_upload_commit(ezkl_upload_t u, ezkl_bases_t h, size_t commit_first, size_t commit_count, void* out) {
+    if (!u || !h || !out) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (commit_count > b->n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_upload_commit(c, reinterpret_cast<MsmUpload*>(u), b, commit_first, commit_count, out);
+}
+int ezkl_hip_upload_end(ezkl_upload_t u) {
+    if (!u) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_upload_end(reinterpret_cast<MsmUpload*>(u));
+}
 int ezkl_hip_upload_commit_batch(ezkl_bases_t h, const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n,
                                  const void* const* tail_rows, size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count,
                                  void* out) {
-    if (!h || (batch && (!host_cols || !dev_cols || !out))) return EZKL_ERR_INVALID;
+    if (!h || (batch && !out) || !upload_args_ok(host_cols, dev_cols, batch, tail_rows, tail_count)) return EZKL_ERR_INVALID;
     Bases* b = reinterpret_cast<Bases*>(h);
     if (commit_count > b->n || commit_first > n || commit_count > n - commit_first) return EZKL_ERR_INVALID;
-    for (size_t j = 0; j < batch; j++)
-        if (!host_cols[j] || !dev_cols[j] || (tail_rows && tail_count && !tail_rows[j])) return EZKL_ERR_INVALID;
+    if (batch == 0) return EZKL_OK;
     EZ_CTX(c);
-    return msm_upload_commit(c, b, (const fe_t* const*)host_cols, (fe_t* const*)dev_cols, batch, n, (const fe_t* const*)tail_rows, tail_start,
-                             tail_count, commit_first, commit_count, out);
+    MsmUpload* u = nullptr;
+    int rc = msm_upload_begin(c, (const fe_t* const*)host_cols, (fe_t* const*)dev_cols, batch, n, (const fe_t* const*)tail_rows, tail_start, tail_count, &u);
+    if (rc) return rc;
+    rc = msm_upload_commit(c, u, b, commit_first, commit_count, out);
+    int rc2 = msm_upload_end(u);
+    return rc ? rc : rc2;
+}
+int ezkl_hip_stream_create(void** out) {
+    if (!out) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st;
+    EZ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out = st;
+    return EZKL_OK;
+}
+int ezkl_hip_stream_synchronize(void* stream) {
+    if (!stream) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    EZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return EZKL_OK;
+}
+int ezkl_hip_stream_destroy(void* stream) {
+    if (!stream) return EZKL_OK;
+    EZ_CTX(c);
+    EZ_HIP(hipStreamDestroy((hipStream_t)stream));
+    return EZKL_OK;
 }
 int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_msm_batch_t* out) {
     if (!h || !out) return EZKL_ERR_INVALID;

@@ -68,8 +68,12 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
             void* out_affine_host);
 int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
                   void* out_host);
-int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails,
-                      size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count, void* out_host);
+struct MsmUpload;
+int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails, size_t tail_start,
+                     size_t tail_count, MsmUpload** out);
+int msm_upload_wait(MsmUpload* u, size_t j, hipStream_t st);
+int msm_upload_commit(Ctx* c, MsmUpload* u, const Bases* b, size_t commit_first, size_t commit_count, void* out_host);
+int msm_upload_end(MsmUpload* u);
 struct MsmBatch;
 int msm_batch_begin(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, size_t n, MsmBatch** out);
 int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev);

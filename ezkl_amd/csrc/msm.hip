@@ -33,6 +33,21 @@ static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workg
 static constexpr uint32_t MSM_BINSORT_STAGE = 15360;  // payloads a sort workgroup stages in LDS (60 KiB): 2 workgroups per CU
 static constexpr uint32_t MSM_HEAVY_CHUNK = 1024;    // lane partials folded by one workgroup in the first heavy pass
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
+static constexpr uint32_t MSM_LMIN = 8;             // shortest lane of the accumulate kernel
+
+// Partition of a bucket in the first sorting pass: its low bits -- except bucket 0, which gets a partition of its own
+// (index 0; ordinary partition p is index p + 1).  Bucket 0 holds the digits +-1: every carry of the signed recoding into an
+// otherwise empty window, every boolean, every one.  For a witness of 20-bit values that is 2^19 pairs in ONE bucket, and the
+// workgroup sorting its partition used to walk them alone (0.89 of that MSM's 1.87 ms).  A one-bucket partition needs no
+// sorting: the partition pass writes its payloads straight to their final place.
+__device__ __forceinline__ uint32_t msm_part_of(uint32_t bucket, uint32_t NP) { return bucket ? 1u + (bucket & (NP - 1u)) : 0u; }
+// Lane length of the accumulate kernel, decided ON THE DEVICE from the number of pairs that actually exist: the host sizes
+// the launch for n * W pairs, but small witness values have one or two non-zero digits, and with the host's lane length
+// such a column filled a third of the CUs with one wave each (0.45 ms for 1.5 M pairs; 1.1 ms for 13.6 M).
+__device__ __forceinline__ uint32_t msm_lane_len(const uint32_t* offsets, uint32_t nb, uint32_t nlanes) {
+    const uint32_t l = (uint32_t)(((uint64_t)offsets[nb] + nlanes - 1) / nlanes);
+    return l < MSM_LMIN ? MSM_LMIN : l;
+}
 
 // Window plan: W signed-digit windows covering 254 bits (253-bit magnitudes after the r - s fold + the last carry),
 // the first `rem` windows base+1 bits wide, the others base bits.  Balanced widths instead of "c, c, ..., short top
@@ -163,8 +178,9 @@ __device__ __forceinline__ bool msm_digit_step(const fe_t& s, uint32_t neg, uint
 // staging area grouped by partition and writes them out in staged order (runs of one partition leave as whole cache lines).
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                        uint32_t LB, uint32_t NP, uint32_t* wg_hist, uint32_t* wg_cnt) {
-    __shared__ uint32_t lh[1u << MSM_MAX_PART_BITS];
-    for (uint32_t p = threadIdx.x; p < NP; p += 256) lh[p] = 0;
+    __shared__ uint32_t lh[(1u << MSM_MAX_PART_BITS) + 1];
+    const uint32_t NQ = NP + 1;                                           // + the bucket-0 partition
+    for (uint32_t p = threadIdx.x; p < NQ; p += 256) lh[p] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
     for (size_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * 256) {          // four scalars in flight per thread
@@ -182,15 +198,15 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint32_t bucket, sign;
-                if (msm_digit_step(s[q], neg[q], off, c, carry[q], bucket, sign)) atomicAdd(&lh[bucket & (NP - 1)], 1u);
+                if (msm_digit_step(s[q], neg[q], off, c, carry[q], bucket, sign)) atomicAdd(&lh[msm_part_of(bucket, NP)], 1u);
             }
             off += c;
         }
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < NP; p += 256) {                 // row of this workgroup, coalesced; wg_hist is scanned in place later,
-        wg_hist[(size_t)blockIdx.x * NP + p] = lh[p];                   // wg_cnt keeps the raw counts for the partition pass's local ranking
-        wg_cnt[(size_t)blockIdx.x * NP + p] = lh[p];
+    for (uint32_t p = threadIdx.x; p < NQ; p += 256) {                 // row of this workgroup, coalesced; wg_hist is scanned in place later,
+        wg_hist[(size_t)blockIdx.x * NQ + p] = lh[p];                   // wg_cnt keeps the raw counts for the partition pass's local ranking
+        wg_cnt[(size_t)blockIdx.x * NQ + p] = lh[p];
     }
 }
 // wg_hist[g][p] (G workgroups x NP partitions) -> in place, the exclusive prefix over g of column p; part_count[p] = column
@@ -225,11 +241,12 @@ __global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, 
         }
     }
 }
-// exclusive scan of <= 1024 partition counts
-__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NP, uint32_t* part_base) {
+// exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base) {
     __shared__ uint32_t sh[1024];
-    uint32_t t = threadIdx.x, v = t < NP ? part_count[t] : 0;
-    sh[t] = v;
+    const uint32_t t = threadIdx.x;
+    const uint32_t v0 = 2 * t < NQ ? part_count[2 * t] : 0, v1 = 2 * t + 1 < NQ ? part_count[2 * t + 1] : 0;
+    sh[t] = v0 + v1;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         uint32_t x = t >= d ? sh[t - d] : 0;
@@ -237,8 +254,10 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
         sh[t] += x;
         __syncthreads();
     }
-    if (t < NP) part_base[t] = sh[t] - v;
-    if (t == NP - 1) part_base[NP] = sh[t];
+    const uint32_t excl = sh[t] - v0 - v1;
+    if (2 * t < NQ) part_base[2 * t] = excl;
+    if (2 * t + 1 < NQ) part_base[2 * t + 1] = excl + v0;
+    if (t == 1023) part_base[NQ] = sh[t];
 }
 // One pass, one scalar per thread.  A workgroup first ranks its (up to MSM_PART_STAGE) pairs into LDS grouped by partition
 // (start[p] = exclusive scan of its own histogram row, cursors advanced with LDS atomics), then writes them out in staged order:
@@ -248,20 +267,22 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
 // kernel's 146 us); staged, a run of ~13 pairs of one partition is two cache lines.
 __global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                              uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
-                                                             const uint32_t* part_base, const uint32_t* wg_hist, const uint32_t* wg_cnt, uint2* entries) {
+                                                             const uint32_t* part_base, const uint32_t* wg_hist, const uint32_t* wg_cnt, uint2* entries,
+                                                             uint32_t* vals) {
     extern __shared__ uint32_t plds[];
     __shared__ uint32_t tsum[1024];
-    uint32_t* start = plds;                    // NP: first staged index of partition p
-    uint32_t* cursor = plds + NP;              // NP: next free staged index
-    uint32_t* gbase = plds + 2 * NP;           // NP: global slot of the workgroup's first pair of partition p
-    uint2* stage = reinterpret_cast<uint2*>(plds + 3 * NP);
+    const uint32_t NQ = NP + 1;                // partitions incl. bucket 0's (msm_part_of); the arrays below are padded to NQ + 1 words
+    uint32_t* start = plds;                    // NQ: first staged index of partition p
+    uint32_t* cursor = plds + (NQ + 1);        // NQ: next free staged index
+    uint32_t* gbase = plds + 2 * (NQ + 1);     // NQ: global slot of the workgroup's first pair of partition p
+    uint2* stage = reinterpret_cast<uint2*>(plds + 3 * (NQ + 1));
     const uint32_t t = threadIdx.x, T = blockDim.x;
     // exclusive scan of this workgroup's histogram row: K consecutive partitions per thread, then a scan over threads
-    const uint32_t K = (NP + T - 1) / T;
+    const uint32_t K = (NQ + T - 1) / T;
     uint32_t loc = 0;
     for (uint32_t q = 0; q < K; q++) {
         const uint32_t p = t * K + q;
-        if (p < NP) loc += wg_cnt[(size_t)blockIdx.x * NP + p];
+        if (p < NQ) loc += wg_cnt[(size_t)blockIdx.x * NQ + p];
     }
     tsum[t] = loc;
     __syncthreads();
@@ -275,11 +296,11 @@ __global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars
     uint32_t run = tsum[t] - loc;
     for (uint32_t q = 0; q < K; q++) {
         const uint32_t p = t * K + q;
-        if (p < NP) {
+        if (p < NQ) {
             start[p] = run;
             cursor[p] = run;
-            gbase[p] = part_base[p] + wg_hist[(size_t)blockIdx.x * NP + p];
-            run += wg_cnt[(size_t)blockIdx.x * NP + p];
+            gbase[p] = part_base[p] + wg_hist[(size_t)blockIdx.x * NQ + p];
+            run += wg_cnt[(size_t)blockIdx.x * NQ + p];
         }
     }
     __syncthreads();
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars
         uint32_t neg;
         fe_t s = msm_canon(scalars, i, neg);
         msm_foreach_digit(s, neg, wp, [&](uint32_t w, uint32_t bucket, uint32_t sign) {
-            const uint32_t r = atomicAdd(&cursor[bucket & (NP - 1)], 1u);
+            const uint32_t r = atomicAdd(&cursor[msm_part_of(bucket, NP)], 1u);
             stage[r] = make_uint2((uint32_t)(w * tab_stride + base_offset + i) | (sign << 31), bucket);
         });
     }
@@ -297,9 +318,24 @@ __global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars
     const uint32_t PB = 31 - __clz(NP);
     for (uint32_t idx = t; idx < total; idx += T) {
         const uint2 e = stage[idx];
-        const uint32_t p = e.y & (NP - 1);
-        entries[gbase[p] + (idx - start[p])] = make_uint2(e.x, e.y >> PB);
+        const uint32_t p = msm_part_of(e.y, NP);
+        const uint32_t slot = gbase[p] + (idx - start[p]);
+        if (p) entries[slot] = make_uint2(e.x, e.y >> PB);
+        else vals[slot] = e.x;                              // bucket 0: already in its final place (its partition comes first)
     }
+}
+// atomicAdd(&cnt[key], 1) for every active lane, with ONE atomic when the whole wave holds the same key (a heavy bucket:
+// 2^19 increments of one LDS word serialise otherwise)
+__device__ __forceinline__ uint32_t msm_wave_rank(uint32_t* cnt, uint32_t key) {
+    const uint64_t active = __ballot(1);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(key);
+    if (__ballot(key == first) == active) {                          // wave-uniform branch
+        const uint32_t rank = (uint32_t)__popcll(active & ((1ull << (threadIdx.x & 63u)) - 1ull));
+        uint32_t base = 0;
+        if (rank == 0) base = atomicAdd(&cnt[first], (uint32_t)__popcll(active));
+        return (uint32_t)__builtin_amdgcn_readfirstlane(base) + rank;
+    }
+    return atomicAdd(&cnt[key], 1u);
 }
 // ---- sort pass 2: one workgroup per partition, counting sort on the low bucket bits in LDS ---------
 __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
@@ -308,16 +344,19 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
     __shared__ uint32_t tsum[512];
     extern __shared__ uint32_t stage[];                      // MSM_BINSORT_STAGE sorted payloads: written out as one contiguous run
     const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
-    const uint32_t beg = part_base[p], end = part_base[p + 1];
+    const uint32_t beg = part_base[p + 1], end = part_base[p + 2];       // index 0 is bucket 0's own partition (msm_part_of)
+    const bool staged = (end - beg) <= MSM_BINSORT_STAGE;                // uniform over the workgroup
     for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
     __syncthreads();
-    {
+    if (staged) {
         uint32_t e = beg + t;
         for (; e + 3 * 512 < end; e += 4 * 512) {
             uint32_t y0 = entries[e].y, y1 = entries[e + 512].y, y2 = entries[e + 1024].y, y3 = entries[e + 1536].y;
             atomicAdd(&cnt[y0], 1u); atomicAdd(&cnt[y1], 1u); atomicAdd(&cnt[y2], 1u); atomicAdd(&cnt[y3], 1u);
         }
         for (; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
+    } else {
+        for (uint32_t e = beg + t; e < end; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
     }
     __syncthreads();
     // exclusive scan of cnt[0..nbins): 4 consecutive bins per thread
@@ -342,8 +381,10 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
         uint32_t j = t * 4 + q;
         if (j < nbins) {
             cnt[j] = run;
-            offsets[(size_t)p * nbins + j] = beg + run;
-            if (loc[q] == 0) st_f29(&buckets[(size_t)p * nbins + j].zz, Fq29::zero());     // an empty bucket is the identity (ZZ = 0): no
+            const bool b0 = (p == 0 && j == 0);                                            // bucket 0 lives in partition index 0
+            offsets[(size_t)p * nbins + j] = b0 ? part_base[0] : beg + run;
+            if (b0 ? part_base[1] == part_base[0] : loc[q] == 0)
+                st_f29(&buckets[(size_t)p * nbins + j].zz, Fq29::zero());                  // an empty bucket is the identity (ZZ = 0): no
         }                                                                                   // 75 MB memset of the whole bucket array
         run += loc[q];
     }
@@ -351,23 +392,27 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
     __syncthreads();
     // four entries in flight per thread: the returning LDS atomics and the stores that depend on them overlap.  A partition of
     // ordinary size is ranked into LDS and leaves as one contiguous run (the scattered 4-byte stores cost one L2 request each,
-    // like the partition pass's); an oversized one (skew) is ranked straight into HBM.
-    const bool staged = (end - beg) <= MSM_BINSORT_STAGE;           // uniform over the workgroup
-    uint32_t* dst = staged ? stage : vals + beg;
-    uint32_t e = beg + t;
-    for (; e + 3 * 512 < end; e += 4 * 512) {
-        uint2 v0 = entries[e], v1 = entries[e + 512], v2 = entries[e + 1024], v3 = entries[e + 1536];
-        uint32_t p0 = atomicAdd(&cnt[v0.y], 1u), p1 = atomicAdd(&cnt[v1.y], 1u), p2 = atomicAdd(&cnt[v2.y], 1u), p3 = atomicAdd(&cnt[v3.y], 1u);
-        dst[p0] = v0.x; dst[p1] = v1.x; dst[p2] = v2.x; dst[p3] = v3.x;
-    }
-    for (; e < end; e += 512) {
-        uint2 v = entries[e];
-        uint32_t pos = atomicAdd(&cnt[v.y], 1u);
-        dst[pos] = v.x;
-    }
+    // like the partition pass's); an oversized one (skew: a constant column is ONE bucket per window) is ranked straight into
+    // HBM, a whole wave of equal keys with one LDS atomic (msm_wave_rank).
     if (staged) {
+        uint32_t e = beg + t;
+        for (; e + 3 * 512 < end; e += 4 * 512) {
+            uint2 v0 = entries[e], v1 = entries[e + 512], v2 = entries[e + 1024], v3 = entries[e + 1536];
+            uint32_t p0 = atomicAdd(&cnt[v0.y], 1u), p1 = atomicAdd(&cnt[v1.y], 1u), p2 = atomicAdd(&cnt[v2.y], 1u), p3 = atomicAdd(&cnt[v3.y], 1u);
+            stage[p0] = v0.x; stage[p1] = v1.x; stage[p2] = v2.x; stage[p3] = v3.x;
+        }
+        for (; e < end; e += 512) {
+            uint2 v = entries[e];
+            uint32_t pos = atomicAdd(&cnt[v.y], 1u);
+            stage[pos] = v.x;
+        }
         __syncthreads();
         for (uint32_t i = t; i < end - beg; i += 512) vals[beg + i] = stage[i];
+    } else {
+        for (uint32_t e = beg + t; e < end; e += 512) {
+            const uint2 v = entries[e];
+            vals[beg + msm_wave_rank(cnt, v.y)] = v.x;
+        }
     }
 }
 
@@ -389,10 +434,10 @@ __device__ __forceinline__ MsmRec msm_fetch(const g1a_t* tab, uint32_t v) {
     return r;
 }
 __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
-                                                             uint32_t nb, uint32_t L, g1x29_t* buckets, g1x29_t* head, g1x29_t* tail,
+                                                             uint32_t nb, uint32_t nlanes, g1x29_t* buckets, g1x29_t* head, g1x29_t* tail,
                                                              uint32_t* lane_first) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = offsets[nb];
+    const uint32_t total = offsets[nb], L = msm_lane_len(offsets, nb, nlanes);
     const uint64_t k0w = (uint64_t)t * L;
     if (k0w >= total) return;
     const uint32_t k0 = (uint32_t)k0w;
@@ -440,11 +485,12 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
 // ~26 pairs per bucket and ~69 per lane nearly every boundary cuts a bucket, so the waves are full).  The common case,
 // a bucket cut once, is one addition; a bucket cut a few times is folded serially by its first boundary; anything
 // longer (a skewed witness) is queued for msm_fixup_heavy{1,2}_kernel.
-__global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t L, uint32_t nlanes,
+__global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes,
                                                                  const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
                                                                  uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
     if (t >= nlanes) return;
+    const uint32_t L = msm_lane_len(offsets, nb, nlanes);
     const uint64_t k0 = (uint64_t)t * L;
     if (k0 >= offsets[nb]) return;
     const uint32_t b = lane_first[t];
@@ -465,10 +511,10 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
 // Pass 1: one workgroup per chunk of MSM_HEAVY_CHUNK lane partials folds head[start .. start + chunk) into head[start].
 // Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
 // (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
-__global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t L, const uint32_t* lane_first, g1x29_t* head,
+__global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const uint32_t* lane_first, g1x29_t* head,
                                                                const uint32_t* chunk_list, const uint32_t* counts) {
     __shared__ uint4 sh[9 * 4];
-    const uint32_t nchunks = counts[1];
+    const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes);
     for (uint32_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
         const uint32_t start = chunk_list[ci], b = lane_first[start];
         const uint32_t t2 = (offsets[b + 1] - 1) / L;
@@ -479,9 +525,10 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* o
         if (threadIdx.x == 0) st_g1x29(head + start, acc);
     }
 }
-__global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t L, const g1x29_t* head, const g1x29_t* tail,
+__global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
                                                                const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets) {
     __shared__ uint4 sh[9 * 4];
+    const uint32_t L = msm_lane_len(offsets, nb, nlanes);
     for (uint32_t h = blockIdx.x; h < counts[0]; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
@@ -697,7 +744,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
-    size_t o_pcnt = carve((NP + 1) * 4), o_pbase = carve((NP + 1) * 4), o_wgh = carve((size_t)sgrid * NP * 4), o_wgc = carve((size_t)sgrid * NP * 4);
+    const uint32_t NQ = NP + 1;                          // + bucket 0's own partition (msm_part_of)
+    size_t o_pcnt = carve((NQ + 1) * 4), o_pbase = carve((NQ + 1) * 4), o_wgh = carve((size_t)sgrid * NQ * 4), o_wgc = carve((size_t)sgrid * NQ * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256), o_chunks = carve(((size_t)nlanes + 1) * 4);
     size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x29_t));
@@ -728,26 +776,26 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
     // sort
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt);
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NP, 32)), dim3(1024), 0, st, wghist, sgrid, NP, pcnt);
-    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NP, pbase);
-    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3((unsigned)per_block), (3 * (size_t)NP + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
-                       LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32)), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt);
+    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NQ, pbase);
+    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
+                       LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, offs, vals, bkt);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, L, bkt, head, tail,
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, nlanes, bkt, head, tail,
                        lfirst);
     if (timed) EZ_HIP(hipEventRecord(a1, st));
     if (nlanes > 1)
-        hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256)), dim3(256), 0, st, offs, nb, L, nlanes, lfirst, head, tail, bkt,
+        hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256)), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
                            heavy, hcnt, chunks);
     {
         size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
         size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
         unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb), dim3(256), 0, st, offs, L, lfirst, head, chunks, hcnt);
-        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb), dim3(256), 0, st, offs, L, head, tail, heavy, hcnt, bkt);
+        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt);
+        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt);
     }
     // reduce
     {
@@ -825,14 +873,28 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
 static hipStream_t g_copy_st = nullptr;
 static fe_t* g_tail_pinned = nullptr;
 static size_t g_tail_pinned_elems = 0;
-int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails,
-                      size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count, void* out_host) {
-    if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
-    if (batch == 0) return EZKL_OK;
-    if (n == 0 || tail_start + tail_count > n || commit_first + commit_count > n) return EZKL_ERR_INVALID;
-    MsmTable* T = nullptr;
-    int rc = commit_count ? table_get(c, c->stream, b, &T) : EZKL_OK;
-    if (rc) return rc;
+// One upload phase in flight: the copies are queued by begin(), a caller stream can be made to wait for a column
+// (wait), the columns are committed (commit: each MSM waits for its own copy) and end() drains the copy stream.
+struct MsmUpload {
+    std::vector<hipEvent_t> ev;
+    std::vector<fe_t*> dev_cols;
+    size_t n = 0;
+};
+static MsmUpload* g_open_upload = nullptr;
+int msm_upload_end(MsmUpload* u) {
+    if (!u || u != g_open_upload) return EZKL_ERR_INVALID;
+    hipError_t e = g_copy_st ? hipStreamSynchronize(g_copy_st) : hipSuccess;
+    for (auto ev : u->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    g_open_upload = nullptr;
+    delete u;
+    if (e != hipSuccess) return set_hip_error(e, "msm_upload_end", __FILE__, __LINE__);
+    return EZKL_OK;
+}
+int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails, size_t tail_start,
+                     size_t tail_count, MsmUpload** out) {
+    if (g_open_upload || g_open_batch_fwd()) return EZKL_ERR_INVALID;
+    if (n == 0 || tail_start + tail_count > n) return EZKL_ERR_INVALID;
     if (!g_copy_st) EZ_HIP(hipStreamCreateWithFlags(&g_copy_st, hipStreamNonBlocking));
     if (tails && tail_count && batch * tail_count > g_tail_pinned_elems) {
         if (g_tail_pinned) EZ_HIP(hipHostFree(g_tail_pinned));
@@ -841,27 +903,44 @@ int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t
         EZ_HIP(hipHostMalloc((void**)&g_tail_pinned, g_tail_pinned_elems * sizeof(fe_t), hipHostMallocDefault));
     }
     EZ_HIP(hipStreamSynchronize(c->stream));          // the destination columns may have been touched on the library stream
-    std::vector<hipEvent_t> ev(batch, nullptr);
-    auto cleanup = [&]() {
-        for (auto e : ev)
-            if (e) (void)hipEventDestroy(e);
-    };
+    MsmUpload* u = new MsmUpload();
+    u->n = n;
+    u->ev.assign(batch, nullptr);
+    u->dev_cols.assign(dev_cols, dev_cols + batch);
+    g_open_upload = u;
     for (size_t j = 0; j < batch; j++) {
-        hipError_t e = hipEventCreateWithFlags(&ev[j], hipEventDisableTiming);
+        hipError_t e = hipEventCreateWithFlags(&u->ev[j], hipEventDisableTiming);
         if (e == hipSuccess) e = hipMemcpyAsync(dev_cols[j], host_cols[j], n * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);
         if (e == hipSuccess && tails && tail_count) {
             memcpy(g_tail_pinned + j * tail_count, tails[j], tail_count * sizeof(fe_t));
             e = hipMemcpyAsync(dev_cols[j] + tail_start, g_tail_pinned + j * tail_count, tail_count * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);
         }
-        if (e == hipSuccess) e = hipEventRecord(ev[j], g_copy_st);
+        if (e == hipSuccess) e = hipEventRecord(u->ev[j], g_copy_st);
         if (e != hipSuccess) {
-            (void)hipStreamSynchronize(g_copy_st);
-            cleanup();
-            return set_hip_error(e, "msm_upload_commit", __FILE__, __LINE__);
+            (void)msm_upload_end(u);
+            return set_hip_error(e, "msm_upload_begin", __FILE__, __LINE__);
         }
     }
-    if (commit_count == 0) memset(out_host, 0, 64 * batch);           // empty slice: the identity
-    for (size_t j = 0; commit_count && j < batch + MSM_SLOTS && !rc; j++) {
+    *out = u;
+    return EZKL_OK;
+}
+int msm_upload_wait(MsmUpload* u, size_t j, hipStream_t st) {
+    if (!u || u != g_open_upload || j >= u->ev.size() || !st) return EZKL_ERR_INVALID;
+    EZ_HIP(hipStreamWaitEvent(st, u->ev[j], 0));
+    return EZKL_OK;
+}
+int msm_upload_commit(Ctx* c, MsmUpload* u, const Bases* b, size_t commit_first, size_t commit_count, void* out_host) {
+    if (!u || u != g_open_upload) return EZKL_ERR_INVALID;
+    const size_t batch = u->ev.size();
+    if (commit_first + commit_count > u->n) return EZKL_ERR_INVALID;
+    if (batch == 0) return EZKL_OK;
+    if (commit_count == 0) {                               // empty slice: the identity
+        memset(out_host, 0, 64 * batch);
+        return EZKL_OK;
+    }
+    MsmTable* T = nullptr;
+    int rc = table_get(c, c->stream, b, &T);
+    for (size_t j = 0; j < batch + MSM_SLOTS && !rc; j++) {
         if (j >= MSM_SLOTS) {
             size_t done = j - MSM_SLOTS;
             if (done < batch) rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done);
@@ -869,17 +948,16 @@ int msm_upload_commit(Ctx* c, const Bases* b, const fe_t* const* host_cols, fe_t
         if (j < batch && !rc) {
             MsmSlot& sl = g_slots[j % MSM_SLOTS];
             rc = slot_prepare(sl, 0);
-            if (!rc && hipStreamWaitEvent(sl.st, ev[j], 0) != hipSuccess) rc = EZKL_ERR_HIP;
-            if (!rc) rc = msm_enqueue(c, sl, sl.st, T, 0, dev_cols[j] + commit_first, commit_count, false);
+            if (!rc && hipStreamWaitEvent(sl.st, u->ev[j], 0) != hipSuccess) rc = EZKL_ERR_HIP;
+            if (!rc) rc = msm_enqueue(c, sl, sl.st, T, 0, u->dev_cols[j] + commit_first, commit_count, false);
         }
     }
-    (void)hipStreamSynchronize(g_copy_st);
     if (rc)
         for (auto& sl : g_slots)
             if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
-    cleanup();
     return rc;
 }
+bool msm_upload_is_open() { return g_open_upload != nullptr; }
 
 // The same pipeline fed one column at a time: the caller uploads column j+1 (a blocking PCIe copy) while the slots
 // run the MSMs of the columns pushed so far.  One batch may be open per device; other MSM entry points refuse

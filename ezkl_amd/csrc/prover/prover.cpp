@@ -313,6 +313,41 @@ struct Backend {
     Fe one = Fe::one();
     std::map<U256, std::pair<Col, Col>> zpow;       // kate_div: z^j and z^-(j+1) columns per opening point
     Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_, const Shard& sh = Shard()) : k(k_), n(n_), g(g_), gl(gl_), shard(sh) {}
+    Backend(const Backend&) = delete;
+    ~Backend() {
+        if (aux) {                             // also on unwinding: nothing queued on the aux stream may outlive its columns
+            (void)ezkl_hip_stream_synchronize(aux);
+            (void)ezkl_hip_stream_destroy(aux);
+        }
+    }
+    std::vector<Col> aux_keep;                 // inputs / outputs of work queued on the aux stream, alive until the stream is drained
+    // A second stream for the NTTs of finished columns: a column's coefficient and extended-coset forms do not depend on any
+    // challenge, so they are queued the moment the column is final and run in the shadow of the commit phases (the advice phase
+    // is PCIe-bound, single MSMs leave the GPU half empty during their sort / reduce tails); step 7 only waits for the stream.
+    void* aux = nullptr;
+    void* aux_stream() {
+        if (!aux) check(ezkl_hip_stream_create(&aux), "ezkl_hip_stream_create");
+        return aux;
+    }
+    void aux_sync() {
+        if (aux) check(ezkl_hip_stream_synchronize(aux), "ezkl_hip_stream_synchronize");
+        aux_keep.clear();
+    }
+    struct Forms {
+        Col poly, coset;
+    };
+    // lagrange -> (coefficients, extended coset), stream-ordered on the aux stream; `lagrange` must stay untouched until aux_sync()
+    Forms forms_alloc(uint32_t ext_k) const { return Forms{alloc(n), alloc((size_t)1 << ext_k)}; }
+    Forms forms_async(const Col& lagrange, uint32_t ext_k, const Forms* pre = nullptr) {
+        Forms f = pre ? *pre : forms_alloc(ext_k);
+        aux_keep.insert(aux_keep.end(), {lagrange, f.poly, f.coset});
+        void* st = aux_stream();
+        const Fe winv = omega(k).inv();
+        check(ezkl_hip_vec_scale_dev(lagrange->ptr(), one.v.data(), f.poly->ptr(), n, st), "ezkl_hip_vec_scale_dev");
+        check(ezkl_hip_ntt_dev(f.poly->ptr(), k, winv.v.data(), 1, 1, n, st), "ezkl_hip_ntt_dev");
+        check(ezkl_hip_coset_ntt_dev(f.poly->ptr(), f.coset->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, 0, st), "ezkl_hip_coset_ntt_dev");
+        return f;
+    }
     size_t commit_first() const { return shard.on() ? shard.lo : 0; }
     size_t commit_count() const { return shard.on() ? shard.hi - shard.lo : n; }
     // sharded: the partial sums over this rank's slice become the sums over all ranks (one all_gather per batch on the caller's side)
@@ -1074,6 +1109,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     }
     // 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges
     std::vector<Col> adv_cols(cs.n_advice);
+    std::vector<Backend::Forms> adv_forms(cs.n_advice);
     std::vector<Fe> user_chal;
     for (uint32_t phase = 0; phase < 2; phase++) {
         std::vector<uint32_t> idxs;
@@ -1111,8 +1147,33 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
         for (auto& t : tails) tailp.push_back(t.data());
         std::vector<G1> commits(idxs.size());
-        check(ezkl_hip_upload_commit_batch(gl, hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, be.commit_first(), be.commit_count(),
-                                           commits.data()), "ezkl_hip_upload_commit_batch");
+        {
+            // the phase in steps (ezkl_hip_upload_commit_batch in one call): every copy is queued, the NTTs of column j are queued
+            // behind ITS copy on the aux stream, then the commits run -- PCIe, MSMs and NTTs overlap
+            ezkl_upload_t up = nullptr;
+            check(ezkl_hip_upload_begin(hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, &up), "ezkl_hip_upload_begin");
+            int rc = EZKL_OK;
+            auto t0 = std::chrono::steady_clock::now();
+            for (size_t j = 0; j < idxs.size(); j++) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);
+            auto tA = std::chrono::steady_clock::now();
+            if (getenv("EZKL_PROVER_DEBUG")) fprintf(stderr, "[advice] alloc %.2f ms\n", std::chrono::duration<double, std::milli>(tA - t0).count());
+            try {
+                for (size_t j = 0; j < idxs.size(); j++) {
+                    check(ezkl_hip_upload_wait(up, j, be.aux_stream()), "ezkl_hip_upload_wait");
+                    adv_forms[idxs[j]] = be.forms_async(adv_cols[idxs[j]], cs.ext_k, &adv_forms[idxs[j]]);
+                }
+                auto tB = std::chrono::steady_clock::now();
+                rc = ezkl_hip_upload_commit(up, gl, be.commit_first(), be.commit_count(), commits.data());
+                auto tC = std::chrono::steady_clock::now();
+                if (getenv("EZKL_PROVER_DEBUG")) fprintf(stderr, "[advice] schedule %.2f ms, commit %.2f ms\n", std::chrono::duration<double, std::milli>(tB - tA).count(), std::chrono::duration<double, std::milli>(tC - tB).count());
+            } catch (...) {
+                (void)ezkl_hip_upload_end(up);
+                throw;
+            }
+            const int rc2 = ezkl_hip_upload_end(up);
+            check(rc, "ezkl_hip_upload_commit");
+            check(rc2, "ezkl_hip_upload_end");
+        }
         be.fold(commits);
         for (auto& p : commits) T.write_point(p);
         if (phase == 0)
@@ -1125,6 +1186,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     struct LookupState {
         std::vector<Col> inputs;
         Col table, m, phi;
+        Backend::Forms m_forms, phi_forms;
     };
     std::vector<LookupState> lk;
     if (!cs.lookups.empty()) {
@@ -1139,6 +1201,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
         std::vector<Col> ms;
         for (auto& st : lk) ms.push_back(st.m);
+        for (auto& st : lk) st.m_forms = be.forms_async(st.m, cs.ext_k);
         for (auto& p : be.commit_lagrange(ms)) T.write_point(p);
     }
     sw.lap(1);
@@ -1146,6 +1209,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     const Fe beta = T.squeeze_challenge(), gamma = T.squeeze_challenge();
     // 4. permutation grand products, chained across chunks
     std::vector<Col> zs;
+    std::vector<Backend::Forms> z_forms;
     {
         bool have_last = false;
         Fe last;
@@ -1161,6 +1225,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             zs.push_back(z);
             pos += (uint32_t)chunk.size();
         }
+        for (auto& z : zs) z_forms.push_back(be.forms_async(z, cs.ext_k));
         for (auto& p : be.commit_lagrange(zs)) T.write_point(p);
     }
     sw.lap(2);
@@ -1172,6 +1237,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             be.set_rows(st.phi, u + 1, rng.vec(n - u - 1));
             phis.push_back(st.phi);
         }
+        for (auto& st : lk) st.phi_forms = be.forms_async(st.phi, cs.ext_k);
         for (auto& p : be.commit_lagrange(phis)) T.write_point(p);
     }
     sw.lap(3);
@@ -1182,15 +1248,12 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     sw.lap(4);
     // 7. quotient
     std::vector<Col> adv_polys, inst_cosets, z_polys, adv_cosets, z_cosets, m_polys, phi_polys, m_cosets, phi_cosets;
-    for (auto& h : adv_cols) adv_polys.push_back(be.lagrange_to_coeff(h));
     for (auto& h : inst_cols) inst_cosets.push_back(be.coeff_to_extended(be.lagrange_to_coeff(h), cs.ext_k));
-    for (auto& h : zs) z_polys.push_back(be.lagrange_to_coeff(h));
-    for (auto& h : adv_polys) adv_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
-    for (auto& h : z_polys) z_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
-    for (auto& st : lk) m_polys.push_back(be.lagrange_to_coeff(st.m));
-    for (auto& st : lk) phi_polys.push_back(be.lagrange_to_coeff(st.phi));
-    for (auto& h : m_polys) m_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
-    for (auto& h : phi_polys) phi_cosets.push_back(be.coeff_to_extended(h, cs.ext_k));
+    be.aux_sync();                                   // the forms queued behind each finished column (Backend::forms_async)
+    for (auto& f : adv_forms) { adv_polys.push_back(f.poly); adv_cosets.push_back(f.coset); }
+    for (auto& f : z_forms) { z_polys.push_back(f.poly); z_cosets.push_back(f.coset); }
+    for (auto& st : lk) { m_polys.push_back(st.m_forms.poly); m_cosets.push_back(st.m_forms.coset); }
+    for (auto& st : lk) { phi_polys.push_back(st.phi_forms.poly); phi_cosets.push_back(st.phi_forms.coset); }
     sw.lap(5);
     Col hnum = be.zeros((size_t)1 << cs.ext_k);
     {

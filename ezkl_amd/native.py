@@ -23,7 +23,7 @@ STAGES = ["advice_commit", "lookup_m", "permutation_z", "lookup_phi", "random_po
 
 
 def lib_path():
-    return os.path.join(_HERE, "libezkl_prover.so")
+    return os.environ.get("EZKL_PROVER_LIB") or os.path.join(_HERE, "libezkl_prover.so")      # override: A/B builds
 
 
 def load():

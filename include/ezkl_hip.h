@@ -40,11 +40,19 @@ int ezkl_hip_init(int device);                 /* idempotent, thread-safe; devic
 int ezkl_hip_warmup(void);
 int ezkl_hip_device_count(void);
 int ezkl_hip_synchronize(void);
+/* caller streams for the `stream` arguments below (a hipStream_t created by the caller works just as well; these exist so
+ * that a client of this header alone can use the stream-ordered mode): work queued on one is asynchronous */
+int ezkl_hip_stream_create(void** out_stream);
+int ezkl_hip_stream_synchronize(void* stream);
+int ezkl_hip_stream_destroy(void* stream);
 const char* ezkl_hip_strerror(int code);
 int ezkl_hip_last_hip_error(void);
 const char* ezkl_hip_version(void);
 
-/* ---- raw device memory for resident columns (library-owned until freed) ---- */
+/* ---- raw device memory for resident columns (library-owned until freed) ----
+ * Freed blocks are recycled by size without returning to the driver (no implicit device synchronisation, unlike hipFree):
+ * a block that was used on a CALLER stream must not be freed before that stream has been synchronised.  Blocks only
+ * touched through stream = NULL calls are always safe to free. */
 int ezkl_hip_malloc(void** dptr, size_t bytes);
 int ezkl_hip_free(void* dptr);
 int ezkl_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
@@ -99,6 +107,17 @@ int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* co
 int ezkl_hip_upload_commit_batch(ezkl_bases_t h, const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n,
                                  const void* const* tail_rows, size_t tail_start, size_t tail_count, size_t commit_first, size_t commit_count,
                                  void* out_affine);
+/* The same phase in steps, for callers that want other work to start as each column lands (the prover queues the iNTT and the
+ * coset NTT of an advice column on its own stream while later columns are still crossing PCIe and earlier ones are being
+ * committed): begin queues every copy and returns at once (the host columns must stay valid until end); wait makes `stream` (a
+ * caller stream, not NULL) wait for column j; commit runs the MSMs (each waits for its own column) and returns the `batch`
+ * points; end drains the copy stream and closes the phase, also after an error.  One phase may be open at a time. */
+typedef struct ezkl_upload_s* ezkl_upload_t;
+int ezkl_hip_upload_begin(const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n, const void* const* tail_rows,
+                          size_t tail_start, size_t tail_count, ezkl_upload_t* out_upload);
+int ezkl_hip_upload_wait(ezkl_upload_t upload, size_t column, void* stream);
+int ezkl_hip_upload_commit(ezkl_upload_t upload, ezkl_bases_t h, size_t commit_first, size_t commit_count, void* out_affine);
+int ezkl_hip_upload_end(ezkl_upload_t upload);
 typedef struct ezkl_msm_batch_s* ezkl_msm_batch_t;
 int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_msm_batch_t* out_batch);
 int ezkl_hip_msm_batch_push_dev(ezkl_msm_batch_t batch, const void* scalars_dev);

@@ -262,6 +262,53 @@ def test_incremental_commit_batch(hip):
     bases.free()
 
 
+def test_upload_phase_in_steps(hip):
+    """ezkl_hip_upload_begin / _wait / _commit / _end: work queued on a caller stream behind column j sees that column (with its
+    blinding rows); the commits equal the one-call form; a second open phase and calls on a closed handle are refused"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(92)
+    n, t0 = 1 << 13, (1 << 13) - 6
+    pts = ob.gen_bases(10, n)
+    bases = B.Bases(pts)
+    pinned = [B.PinnedArray((n, 4)) for _ in range(5)]
+    cols = [rand_fr(rng, n) for _ in range(5)]
+    for pa, c in zip(pinned, cols):
+        pa.array[:] = c
+    tails = [rand_fr(rng, 6) for _ in range(5)]
+    st = B.Stream()
+    up = B.UploadPhase([pa.array for pa in pinned], tails, t0)
+    with pytest.raises(RuntimeError):
+        B.UploadPhase(cols[:1])                                   # one phase at a time
+    k = 13
+    w_inv = ob.fr_inv(ob.omega(k))
+    outs = []
+    for j in range(5):                                            # per column, behind its copy: clone + iNTT on the caller stream
+        up.wait(j, st)
+        o = B.DeviceBuffer(32 * n)
+        B.vec_scale(up.devs[j].ptr, fe_from_int(1), o.ptr, n, stream=st.ptr)
+        B.ntt_dev(o.ptr, k, w_inv, inverse=True, stream=st.ptr)
+        outs.append(o)
+    commits = up.commit(bases)
+    half = up.commit(bases, commit_range=(100, 5000))            # a second commit of the same phase (a slice)
+    up.end()
+    st.synchronize()
+    for j in range(5):
+        want = cols[j].copy()
+        want[t0:] = tails[j]
+        assert (up.devs[j].to_numpy(shape=(n, 4)) == want).all()
+        assert (commits[j] == ob.msm(want, pts)).all()
+        assert (half[j] == ob.msm(want[100:5000], pts[:4900])).all()
+        assert (outs[j].to_numpy(shape=(n, 4)) == ob.lagrange_to_coeff(want, k)).all()
+    up.end()                                                      # idempotent on the Python side
+    up2 = B.UploadPhase(cols[:2])                                 # the slot is free again; pageable memory works too
+    assert (up2.commit(bases)[1] == ob.msm(cols[1], pts)).all()
+    up2.end()
+    st.free()
+    for pa in pinned:
+        pa.free()
+    bases.free()
+
+
 def test_upload_commit_batch(hip):
     """the one-call prover phase (async uploads on a copy stream, blinding rows, pipelined commits) == upload + set rows + commit"""
     from ezkl_amd import backend as B
