@@ -1153,19 +1153,13 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             ezkl_upload_t up = nullptr;
             check(ezkl_hip_upload_begin(hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, &up), "ezkl_hip_upload_begin");
             int rc = EZKL_OK;
-            auto t0 = std::chrono::steady_clock::now();
-            for (size_t j = 0; j < idxs.size(); j++) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);
-            auto tA = std::chrono::steady_clock::now();
-            if (getenv("EZKL_PROVER_DEBUG")) fprintf(stderr, "[advice] alloc %.2f ms\n", std::chrono::duration<double, std::milli>(tA - t0).count());
+            for (size_t j = 0; j < idxs.size(); j++) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);     // before the copies are in flight
             try {
                 for (size_t j = 0; j < idxs.size(); j++) {
                     check(ezkl_hip_upload_wait(up, j, be.aux_stream()), "ezkl_hip_upload_wait");
                     adv_forms[idxs[j]] = be.forms_async(adv_cols[idxs[j]], cs.ext_k, &adv_forms[idxs[j]]);
                 }
-                auto tB = std::chrono::steady_clock::now();
                 rc = ezkl_hip_upload_commit(up, gl, be.commit_first(), be.commit_count(), commits.data());
-                auto tC = std::chrono::steady_clock::now();
-                if (getenv("EZKL_PROVER_DEBUG")) fprintf(stderr, "[advice] schedule %.2f ms, commit %.2f ms\n", std::chrono::duration<double, std::milli>(tB - tA).count(), std::chrono::duration<double, std::milli>(tC - tB).count());
             } catch (...) {
                 (void)ezkl_hip_upload_end(up);
                 throw;

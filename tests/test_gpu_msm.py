@@ -202,6 +202,35 @@ def test_gen_srs_structure(hip):
     assert (B.msm_g1(gl, v) == B.msm_g1(g, ob.lagrange_to_coeff(v, k))).all()
 
 
+@pytest.mark.parametrize("n", [5, 300, 1 << 12, 1 << 16, 1 << 18])
+def test_small_values_and_bucket_zero(hip, n):
+    """Witness-shaped scalars: bucket 0 (digits +-1: ones, minus ones, booleans, the carries of values just above half a window)
+    has a sorting partition of its own, and the accumulate kernel sizes its lanes from the pairs that exist.  Parity for columns
+    that are all / mostly bucket 0, for values straddling the signed-digit carry of every window width in use, and for mixes."""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n)
+    pts = ob.gen_bases(SEED + 3, n)
+    bases = B.Bases(pts)
+    one, minus_one = fe_from_int(1), fe_from_int(R - 1)
+    cases = {
+        "ones": np.tile(one, (n, 1)),
+        "minus_ones": np.tile(minus_one, (n, 1)),
+        "booleans": np.stack([fe_from_int(int(v)) for v in rng.integers(0, 2, n)]),
+        "signs": np.stack([(one, minus_one, fe_from_int(0))[int(v)] for v in rng.integers(0, 3, n)]),
+    }
+    for bits in (8, 15, 19, 20, 21, 39, 40, 41):                      # around one and two windows of 19 / 20 / smaller-plan bits
+        cases["bits%d" % bits] = np.stack([fe_from_int(int(v)) for v in rng.integers(1, 1 << bits, n, dtype=np.uint64)])
+    half = [(1 << c) // 2 + d for c in (10, 13, 16, 19, 20) for d in (-1, 0, 1)]      # raw digit == half: the carry boundary itself
+    cases["carry_edges"] = np.stack([fe_from_int(half[int(v)]) for v in rng.integers(0, len(half), n)])
+    cases["neg_small"] = np.stack([fe_from_int(R - int(v)) for v in rng.integers(1, 1 << 20, n, dtype=np.uint64)])
+    mix = rand_fr(rng, n)
+    mix[rng.integers(0, n, max(1, n // 2))] = one                     # half ones, half uniform
+    cases["half_ones"] = mix
+    for name, s in cases.items():
+        assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all(), name
+    bases.free()
+
+
 def test_sparse_column_is_fast_and_correct(hip):
     """a column with a few thousand equal small values plus a handful of full-width blinding rows (the shape of the
     mv-lookup m(X) column): entries are scattered over ~2^19 mostly empty buckets"""
