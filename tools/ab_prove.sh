@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B: previous build (ab_old/) vs in-tree build, alternating, same box
+# A/B of the end-to-end prove on ONE box: a previous build (its two .so files copied into ab_old/, git-ignored but shipped by gpurun)
+# against the in-tree build, alternating; usage (on the GPU box): bash tools/ab_prove.sh
 for i in 1 2 3; do
   for v in old new; do
     if [ $v = old ]; then export EZKL_HIP_LIB=$PWD/ab_old/libezkl_hip.so EZKL_PROVER_LIB=$PWD/ab_old/libezkl_prover.so; else unset EZKL_HIP_LIB EZKL_PROVER_LIB; fi
