@@ -34,6 +34,8 @@ static constexpr uint32_t MSM_BINSORT_STAGE = 15360;  // payloads a sort workgro
 static constexpr uint32_t MSM_HEAVY_CHUNK = 1024;    // lane partials folded by one workgroup in the first heavy pass
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
 static constexpr uint32_t MSM_LMIN = 8;             // shortest lane of the accumulate kernel
+static constexpr uint32_t MSM_MAX_BIG = 64;         // oversized partitions sorted by several workgroups each (the rest: one workgroup)
+static constexpr uint32_t MSM_BIG_BLOCKS = 64;      // workgroups per oversized partition
 
 // Partition of a bucket in the first sorting pass: its low bits -- except bucket 0, which gets a partition of its own
 // (index 0; ordinary partition p is index p + 1).  Bucket 0 holds the digits +-1: every carry of the signed recoding into an
@@ -241,8 +243,10 @@ __global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, 
         }
     }
 }
-// exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs
-__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base) {
+// exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs.  Also lists the oversized
+// ordinary partitions (big_flag[p] = 1 + slot, big_list[slot] = p, big_count[0] = how many asked for a slot).
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
+                                                             uint32_t* big_list, uint32_t* big_count) {
     __shared__ uint32_t sh[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t v0 = 2 * t < NQ ? part_count[2 * t] : 0, v1 = 2 * t + 1 < NQ ? part_count[2 * t + 1] : 0;
@@ -258,6 +262,17 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
     if (2 * t < NQ) part_base[2 * t] = excl;
     if (2 * t + 1 < NQ) part_base[2 * t + 1] = excl + v0;
     if (t == 1023) part_base[NQ] = sh[t];
+#pragma unroll
+    for (uint32_t q = 2 * t; q < 2 * t + 2; q++) {
+        if (q == 0 || q >= NQ) continue;                                 // index 0 is bucket 0's partition: never sorted
+        uint32_t slot = 0;
+        if ((q == 2 * t ? v0 : v1) > MSM_BINSORT_STAGE) {
+            slot = atomicAdd(big_count, 1u);
+            if (slot < MSM_MAX_BIG) big_list[slot] = q - 1;
+            slot = slot < MSM_MAX_BIG ? slot + 1 : 0;
+        }
+        big_flag[q - 1] = slot;
+    }
 }
 // One pass, one scalar per thread.  A workgroup first ranks its (up to MSM_PART_STAGE) pairs into LDS grouped by partition
 // (start[p] = exclusive scan of its own histogram row, cursors advanced with LDS atomics), then writes them out in staged order:
@@ -338,31 +353,14 @@ __device__ __forceinline__ uint32_t msm_wave_rank(uint32_t* cnt, uint32_t key) {
     return atomicAdd(&cnt[key], 1u);
 }
 // ---- sort pass 2: one workgroup per partition, counting sort on the low bucket bits in LDS ---------
-__global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
-                                                          uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
-    __shared__ uint32_t cnt[2048];
-    __shared__ uint32_t tsum[512];
-    extern __shared__ uint32_t stage[];                      // MSM_BINSORT_STAGE sorted payloads: written out as one contiguous run
-    const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
-    const uint32_t beg = part_base[p + 1], end = part_base[p + 2];       // index 0 is bucket 0's own partition (msm_part_of)
-    const bool staged = (end - beg) <= MSM_BINSORT_STAGE;                // uniform over the workgroup
-    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
-    __syncthreads();
-    if (staged) {
-        uint32_t e = beg + t;
-        for (; e + 3 * 512 < end; e += 4 * 512) {
-            uint32_t y0 = entries[e].y, y1 = entries[e + 512].y, y2 = entries[e + 1024].y, y3 = entries[e + 1536].y;
-            atomicAdd(&cnt[y0], 1u); atomicAdd(&cnt[y1], 1u); atomicAdd(&cnt[y2], 1u); atomicAdd(&cnt[y3], 1u);
-        }
-        for (; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
-    } else {
-        for (uint32_t e = beg + t; e < end; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
-    }
-    __syncthreads();
-    // exclusive scan of cnt[0..nbins): 4 consecutive bins per thread
+// cnt[0..nbins) counts -> exclusive bases in place (512 threads, <= 2048 bins); with `emit` also the partition's bucket offsets
+// and the empty-bucket marks (an empty bucket is the identity, ZZ = 0: no 75 MB memset of the whole bucket array)
+__device__ __forceinline__ void msm_bins_scan(uint32_t* cnt, uint32_t* tsum, uint32_t nbins, uint32_t p, uint32_t beg, const uint32_t* part_base,
+                                              bool emit, uint32_t* offsets, g1x29_t* buckets) {
+    const uint32_t t = threadIdx.x;
     uint32_t loc[4], s = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 4; q++) {                        // 4 consecutive bins per thread
         uint32_t j = t * 4 + q;
         loc[q] = j < nbins ? cnt[j] : 0;
         s += loc[q];
@@ -381,19 +379,44 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
         uint32_t j = t * 4 + q;
         if (j < nbins) {
             cnt[j] = run;
-            const bool b0 = (p == 0 && j == 0);                                            // bucket 0 lives in partition index 0
-            offsets[(size_t)p * nbins + j] = b0 ? part_base[0] : beg + run;
-            if (b0 ? part_base[1] == part_base[0] : loc[q] == 0)
-                st_f29(&buckets[(size_t)p * nbins + j].zz, Fq29::zero());                  // an empty bucket is the identity (ZZ = 0): no
-        }                                                                                   // 75 MB memset of the whole bucket array
+            if (emit) {
+                const bool b0 = (p == 0 && j == 0);                                        // bucket 0 lives in partition index 0
+                offsets[(size_t)p * nbins + j] = b0 ? part_base[0] : beg + run;
+                if (b0 ? part_base[1] == part_base[0] : loc[q] == 0) st_f29(&buckets[(size_t)p * nbins + j].zz, Fq29::zero());
+            }
+        }
         run += loc[q];
     }
-    if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
     __syncthreads();
+}
+__global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
+                                                          const uint32_t* big_flag, uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
+    __shared__ uint32_t cnt[2048];
+    __shared__ uint32_t tsum[512];
+    extern __shared__ uint32_t stage[];                      // MSM_BINSORT_STAGE sorted payloads: written out as one contiguous run
+    const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
+    const uint32_t beg = part_base[p + 1], end = part_base[p + 2];       // index 0 is bucket 0's own partition (msm_part_of)
+    if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
+    if (big_flag[p]) return;                                             // oversized: msm_bigsort_{count,scatter}_kernel
+    const bool staged = (end - beg) <= MSM_BINSORT_STAGE;                // uniform over the workgroup
+    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
+    __syncthreads();
+    if (staged) {
+        uint32_t e = beg + t;
+        for (; e + 3 * 512 < end; e += 4 * 512) {
+            uint32_t y0 = entries[e].y, y1 = entries[e + 512].y, y2 = entries[e + 1024].y, y3 = entries[e + 1536].y;
+            atomicAdd(&cnt[y0], 1u); atomicAdd(&cnt[y1], 1u); atomicAdd(&cnt[y2], 1u); atomicAdd(&cnt[y3], 1u);
+        }
+        for (; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
+    } else {
+        for (uint32_t e = beg + t; e < end; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
+    }
+    __syncthreads();
+    msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, true, offsets, buckets);
     // four entries in flight per thread: the returning LDS atomics and the stores that depend on them overlap.  A partition of
     // ordinary size is ranked into LDS and leaves as one contiguous run (the scattered 4-byte stores cost one L2 request each,
-    // like the partition pass's); an oversized one (skew: a constant column is ONE bucket per window) is ranked straight into
-    // HBM, a whole wave of equal keys with one LDS atomic (msm_wave_rank).
+    // like the partition pass's).  An oversized one that did not get a slot in the multi-workgroup sort below (more than
+    // MSM_MAX_BIG of them) is ranked straight into HBM, a whole wave of equal keys with one LDS atomic (msm_wave_rank).
     if (staged) {
         uint32_t e = beg + t;
         for (; e + 3 * 512 < end; e += 4 * 512) {
@@ -413,6 +436,53 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
             const uint2 v = entries[e];
             vals[beg + msm_wave_rank(cnt, v.y)] = v.x;
         }
+    }
+}
+// Oversized partitions (skew: a column with long constant runs -- a permutation product over rows without copy constraints,
+// a padded column -- puts most of its pairs into one bucket per window, i.e. into one partition each; a single workgroup
+// walking 2^20 pairs took 1.3-1.5 ms).  They are sorted by MSM_BIG_BLOCKS workgroups each, in two kernels: every workgroup
+// histograms its slice and reserves, per bin, a range inside the bin with ONE global atomic (the order of pairs inside a bucket
+// is irrelevant); after the kernel boundary the bin totals are complete, every workgroup scans them and scatters its slice.
+__device__ __forceinline__ void msm_big_slice(uint32_t beg, uint32_t end, uint32_t& s0, uint32_t& s1) {
+    const uint32_t chunk = (end - beg + MSM_BIG_BLOCKS - 1) / MSM_BIG_BLOCKS;
+    s0 = beg + blockIdx.x * chunk;
+    s1 = s0 + chunk < end ? s0 + chunk : end;
+    if (s0 > end) s0 = end;
+}
+__global__ __launch_bounds__(512) void msm_bigsort_count_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
+                                                                const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off) {
+    __shared__ uint32_t cnt[2048];
+    const uint32_t y = blockIdx.y, t = threadIdx.x, nbins = 1u << LB;
+    if (y >= (big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG)) return;
+    const uint32_t p = big_list[y];
+    uint32_t s0, s1;
+    msm_big_slice(part_base[p + 1], part_base[p + 2], s0, s1);
+    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
+    __syncthreads();
+    for (uint32_t e = s0 + t; e < s1; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
+    __syncthreads();
+    for (uint32_t j = t; j < nbins; j += 512)                            // this workgroup's range inside bin j starts at the returned value
+        block_off[((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins + j] = cnt[j] ? atomicAdd(&bin_total[(size_t)y * nbins + j], cnt[j]) : 0u;
+}
+__global__ __launch_bounds__(512) void msm_bigsort_scatter_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
+                                                                  const uint32_t* big_count, const uint32_t* bin_total, const uint32_t* block_off,
+                                                                  uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
+    __shared__ uint32_t cnt[2048];
+    __shared__ uint32_t tsum[512];
+    const uint32_t y = blockIdx.y, t = threadIdx.x, nbins = 1u << LB;
+    if (y >= (big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG)) return;
+    const uint32_t p = big_list[y], beg = part_base[p + 1];
+    uint32_t s0, s1;
+    msm_big_slice(beg, part_base[p + 2], s0, s1);
+    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = bin_total[(size_t)y * nbins + j];
+    __syncthreads();
+    msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, blockIdx.x == 0, offsets, buckets);     // cnt[j] = start of bin j in the partition
+    const uint32_t* mine = block_off + ((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins;      // + this workgroup's range inside each bin
+    for (uint32_t j = t; j < nbins; j += 512) cnt[j] += mine[j];
+    __syncthreads();
+    for (uint32_t e = s0 + t; e < s1; e += 512) {
+        const uint2 v = entries[e];
+        vals[beg + msm_wave_rank(cnt, v.y)] = v.x;
     }
 }
 
@@ -747,6 +817,9 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const uint32_t NQ = NP + 1;                          // + bucket 0's own partition (msm_part_of)
     size_t o_pcnt = carve((NQ + 1) * 4), o_pbase = carve((NQ + 1) * 4), o_wgh = carve((size_t)sgrid * NQ * 4), o_wgc = carve((size_t)sgrid * NQ * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256), o_chunks = carve(((size_t)nlanes + 1) * 4);
+    const size_t nbins = (size_t)1 << LB;
+    size_t o_bflag = carve((size_t)NP * 4), o_blist = carve(MSM_MAX_BIG * 4), o_btot = carve(MSM_MAX_BIG * nbins * 4),
+           o_boff = carve((size_t)MSM_MAX_BIG * MSM_BIG_BLOCKS * nbins * 4);
     size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x29_t));
     size_t o_head = carve((size_t)nlanes * sizeof(g1x29_t)), o_tail = carve((size_t)nlanes * sizeof(g1x29_t));
@@ -762,6 +835,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     uint32_t *pcnt = (uint32_t*)(S + o_pcnt), *pbase = (uint32_t*)(S + o_pbase), *wghist = (uint32_t*)(S + o_wgh), *wgcnt = (uint32_t*)(S + o_wgc);
     uint32_t *heavy = (uint32_t*)(S + o_heavy), *hcnt = (uint32_t*)(S + o_hcnt), *chunks = (uint32_t*)(S + o_chunks);   // hcnt[0] buckets, [1] chunks
     uint32_t* lfirst = (uint32_t*)(S + o_lfirst);
+    uint32_t *bflag = (uint32_t*)(S + o_bflag), *blist = (uint32_t*)(S + o_blist), *btot = (uint32_t*)(S + o_btot), *boff = (uint32_t*)(S + o_boff);
+    uint32_t* bcnt = hcnt + 2;                                // hcnt[0] heavy buckets, [1] chunks, [2] oversized partitions
     g1x29_t *bkt = (g1x29_t*)(S + o_bkt), *head = (g1x29_t*)(S + o_head), *tail = (g1x29_t*)(S + o_tail);
     g1x29_t *partA = (g1x29_t*)(S + o_partA), *partT = (g1x29_t*)(S + o_partT), *SA = (g1x29_t*)(S + o_SA), *TT = (g1x29_t*)(S + o_T);
     g1x29_t* planes = (g1x29_t*)(S + o_planes);
@@ -772,15 +847,19 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
         EZ_HIP(hipEventRecord(m0, st));
     }
-    EZ_HIP(hipMemsetAsync(hcnt, 0, 8, st));
+    EZ_HIP(hipMemsetAsync(hcnt, 0, 12, st));
+    EZ_HIP(hipMemsetAsync(btot, 0, MSM_MAX_BIG * nbins * 4, st));
     EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
     // sort
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt);
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32)), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt);
-    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NQ, pbase);
+    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NQ, pbase, bflag, blist, bcnt);
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
                        LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals);
-    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, offs, vals, bkt);
+    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs, vals, bkt);
+    hipLaunchKernelGGL(msm_bigsort_count_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff);
+    hipLaunchKernelGGL(msm_bigsort_scatter_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, offs,
+                       vals, bkt);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, nlanes, bkt, head, tail,
