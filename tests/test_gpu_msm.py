@@ -231,6 +231,34 @@ def test_small_values_and_bucket_zero(hip, n):
     bases.free()
 
 
+@pytest.mark.parametrize("distinct", [1, 2, 7, 60, 400])
+def test_constant_runs_full_size(hip, distinct):
+    """2^20 scalars drawn from a handful of values, in long runs (a permutation product over rows without copy constraints, a
+    padded column): one heavy bucket per value and window.  1 .. 7 values: every oversized sort partition gets the multi-workgroup
+    sort; 60 values: ~780 oversized partitions, more than its 64 slots, so most take the single-workgroup path; 400: ordinary."""
+    from ezkl_amd import backend as B
+    n = 1 << 20
+    rng = np.random.default_rng(distinct)
+    pts, bases = _bases_2_20()
+    vals = rand_fr(rng, distinct)
+    runs = np.sort(rng.integers(0, distinct, n))                      # long runs of each value
+    if distinct == 7:
+        runs = rng.integers(0, distinct, n)                           # ... or the same values interleaved
+    s = vals[runs]
+    assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all()
+
+
+_B20 = []
+
+
+def _bases_2_20():
+    from ezkl_amd import backend as B
+    if not _B20:
+        bases = B.Bases.generate(SEED, 1 << 20)          # same deterministic function as the oracle's (test_gen_bases_matches_oracle)
+        _B20.append((bases.download(), bases))
+    return _B20[0]
+
+
 def test_sparse_column_is_fast_and_correct(hip):
     """a column with a few thousand equal small values plus a handful of full-width blinding rows (the shape of the
     mv-lookup m(X) column): entries are scattered over ~2^19 mostly empty buckets"""
