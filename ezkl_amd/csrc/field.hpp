@@ -158,6 +158,67 @@ struct Field {
         for (int i = 0; i < 8; i++) o[i] = r.v[i];
         return o;
     }
+    // ---- lazily reduced forms for the NTT butterflies (Harvey): values live in [0, 2p), which 4p < 2^256 leaves room for ----
+    // limb i of 2p
+    EZ_HD static constexpr uint32_t mod2(int i) { return (P::MOD[i] << 1) | (i ? (P::MOD[i - 1] >> 31) : 0u); }
+    // a in [0, 4p) -> [0, 2p)
+    EZ_HD static fe_t reduce_2p(const fe_t& a) {
+        fe_t d;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.v[i] = subb32(a.v[i], mod2(i), br);
+        fe_t r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : d.v[i];
+        return r;
+    }
+    // a, b in [0, 2p): a + b in [0, 2p)
+    EZ_HD static fe_t add_lazy(const fe_t& a, const fe_t& b) {
+        fe_t s;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s.v[i] = addc32(a.v[i], b.v[i], c);
+        return reduce_2p(s);
+    }
+    // a, b in [0, 2p): a - b + 2p in (0, 4p) -- no comparison; feed it to mul_lazy or reduce_2p
+    EZ_HD static fe_t sub_lazy(const fe_t& a, const fe_t& b) {
+        fe_t d;
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d.v[i] = subb32(a.v[i], b.v[i], br);      // mod 2^256; the true value a - b + 2p fits
+        uint32_t c = 0;
+        fe_t r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = addc32(d.v[i], mod2(i), c);
+        return r;
+    }
+    // a in [0, 4p), b in [0, p) (a twiddle): a b / R in [0, 2p) WITHOUT the final conditional subtraction
+    // ((4p p + R p) / R = p (4p/R + 1) < 2p because 4p < 0.76 R)
+    __host__ __device__ __attribute__((noinline)) static u32x8 mul_lazy_call(u32x8 a, u32x8 b) {
+        fe_t x, y;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { x.v[i] = a[i]; y.v[i] = b[i]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        fe_t r;
+        mont_mul_single<P>(x.v, y.v, r.v);
+#else
+        fe_t r = mul_portable(reduce_once(reduce_2p(x)), y);
+#endif
+        u32x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = r.v[i];
+        return o;
+    }
+    EZ_HD static fe_t mul_lazy(const fe_t& a, const fe_t& b) {
+        u32x8 x, y;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { x[i] = a.v[i]; y[i] = b.v[i]; }
+        u32x8 o = mul_lazy_call(x, y);
+        fe_t r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.v[i] = o[i];
+        return r;
+    }
     EZ_HD static fe_t mul(const fe_t& a, const fe_t& b) {
         u32x8 x, y;
 #pragma unroll

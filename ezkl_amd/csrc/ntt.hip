@@ -79,14 +79,15 @@ __device__ __forceinline__ void ntt_superstage(uint2* data, const fe_t* tloc, ui
 #pragma unroll
             for (uint32_t i = 0; i < M; i++) {
                 if (i & half) continue;
+                // lazily reduced butterfly: everything lives in [0, 2p); the difference u - v + 2p goes into the twiddle product
+                // unreduced and the product skips its final subtraction (Field::mul_lazy) -- 281 issue slots instead of 309
                 fe_t u = x[i], v = x[i + half];
-                x[i] = Fr::add(u, v);
-                fe_t d = Fr::sub(u, v);
+                x[i] = Fr::add_lazy(u, v);
+                fe_t d = Fr::sub_lazy(u, v);
                 // twiddle exponent (j + (i & (half-1))*hG) << (s+t); in the last group hG == 1 and j == 0, so the
                 // members with (i & (half-1)) == 0 multiply by w^0 = 1: skipped (wave-uniform condition)
                 const bool unit = (hG == 1) && ((i & (half - 1)) == 0);
-                if (need_tw && !unit) d = Fr::mul(d, tloc[(j + (i & (half - 1)) * hG) << (s + t)]);
-                x[i + half] = d;
+                x[i + half] = (need_tw && !unit) ? Fr::mul_lazy(d, tloc[(j + (i & (half - 1)) * hG) << (s + t)]) : Fr::reduce_2p(d);
             }
         }
 #pragma unroll
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
         if (!a.last) {
             uint32_t colid = tile * C + c;
             uint32_t pos = (k1 << log_s) + (colid & (S - 1));        // position inside the block
-            x = Fr::mul(x, twp ? *twp : ld_fe(a.tw_inter + pos));
+            x = Fr::mul_lazy(x, twp ? *twp : ld_fe(a.tw_inter + pos));                  // the work buffer holds values in [0, 2p)
             st_fe(out + (((size_t)(colid >> log_s) << a.log_m) + pos), x);
         } else {
             uint32_t blk = (uint32_t)(col_base(c) >> a.log_r);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
                 shift += a.log_radix[p];
             }
             oidx += (size_t)k1 << shift;
-            if (a.post) x = Fr::mul(x, a.post_c[oidx % 3]);
+            x = a.post ? Fr::mul(x, a.post_c[oidx % 3]) : Fr::reduce_once(x);          // [0, 2p) -> canonical
             st_fe(out + oidx, x);
         }
     };
