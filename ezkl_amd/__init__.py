@@ -5,6 +5,14 @@ mirror of the reference interface (ParamsKZG / EvaluationDomain / GraphEvaluator
 tests and bench; it never falls back to a CPU path: without the HIP library or a GPU every op raises."""
 from .lib import EzklHipError, load, lib_path  # noqa: F401
 from . import codecs  # noqa: F401
+
+
+def enabled(k):
+    """the runtime gate (ENABLE_HIP_GPU set and k > HIP_SMALL_K, default 8): the role of ENABLE_ICICLE_GPU / ICICLE_SMALL_K"""
+    import ctypes
+    return bool(load().ezkl_hip_enabled(ctypes.c_uint32(k)))
+
+
 from .backend import (  # noqa: F401
     ParamsKZG, EvaluationDomain, DeviceBuffer, GraphProgram, msm_g1, ntt, vec_op, device_count, init,
 )

@@ -137,6 +137,16 @@ const char* ezkl_hip_strerror(int code) {
 }
 int ezkl_hip_last_hip_error(void) { return g_last_hip_err.load(); }
 const char* ezkl_hip_version(void) { return "ezkl_hip 0.1 (gfx950)"; }
+int ezkl_hip_enabled(uint32_t k) {
+    if (!getenv("ENABLE_HIP_GPU")) return 0;
+    unsigned long small_k = 8;
+    if (const char* e = getenv("HIP_SMALL_K")) {
+        char* end = nullptr;
+        const unsigned long v = strtoul(e, &end, 10);
+        if (end != e && *end == 0) small_k = v;          // a malformed value keeps the default
+    }
+    return k > small_k ? 1 : 0;
+}
 
 // Column buffers are recycled: hipMalloc / hipFree cost ~0.2 ms each (hipFree synchronises the device) and a prover
 // allocates and drops hundreds of same-sized columns per proof.  Freed blocks are parked per exact size (up to

@@ -48,6 +48,10 @@ int ezkl_hip_stream_destroy(void* stream);
 const char* ezkl_hip_strerror(int code);
 int ezkl_hip_last_hip_error(void);
 const char* ezkl_hip_version(void);
+/* The runtime gate, in one place for every host language: 1 if the environment variable ENABLE_HIP_GPU is set (to anything:
+ * like ENABLE_ICICLE_GPU it is disabled by unsetting it, /root/reference/README.md:106-122) and k > HIP_SMALL_K (default 8, the
+ * role of ICICLE_SMALL_K: below the cutoff the caller keeps its CPU path), else 0.  Touches no device. */
+int ezkl_hip_enabled(uint32_t k);
 
 /* ---- raw device memory for resident columns (library-owned until freed) ----
  * Freed blocks are recycled by size without returning to the driver (no implicit device synchronisation, unlike hipFree):

@@ -37,6 +37,9 @@ inline void check(int rc, const char* what) {
 }
 
 // ---- minimal host Fr arithmetic (domain constants only: omega, its inverse, n^-1) ----
+// the runtime gate: ENABLE_HIP_GPU set and k > HIP_SMALL_K (default 8) -- what ENABLE_ICICLE_GPU / ICICLE_SMALL_K decide in the reference
+inline bool enabled(uint32_t k) { return ezkl_hip_enabled(k) != 0; }
+
 namespace fr {
 typedef unsigned __int128 u128;
 constexpr Fr MOD = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};

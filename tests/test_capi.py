@@ -27,6 +27,23 @@ def test_strerror_and_version():
     assert b"gfx950" in lib.ezkl_hip_version()
 
 
+def test_runtime_gate(monkeypatch):
+    """ENABLE_HIP_GPU / HIP_SMALL_K: the semantics of the reference's ENABLE_ICICLE_GPU / ICICLE_SMALL_K (README.md:106-122):
+    disabled by UNSETTING the variable (any value, even "false", enables); k above the cutoff (default 8) goes to the GPU"""
+    import ezkl_amd
+    monkeypatch.delenv("ENABLE_HIP_GPU", raising=False)
+    monkeypatch.delenv("HIP_SMALL_K", raising=False)
+    assert not ezkl_amd.enabled(20)
+    monkeypatch.setenv("ENABLE_HIP_GPU", "false")
+    assert ezkl_amd.enabled(20) and ezkl_amd.enabled(9) and not ezkl_amd.enabled(8) and not ezkl_amd.enabled(0)
+    monkeypatch.setenv("HIP_SMALL_K", "12")
+    assert ezkl_amd.enabled(13) and not ezkl_amd.enabled(12)
+    monkeypatch.setenv("HIP_SMALL_K", "0")
+    assert ezkl_amd.enabled(1) and not ezkl_amd.enabled(0)
+    monkeypatch.setenv("HIP_SMALL_K", "junk")
+    assert ezkl_amd.enabled(9) and not ezkl_amd.enabled(8)            # malformed: the default
+
+
 def test_product_path_does_not_import_oracle():
     """the product package must never reach into oracle/ (parity claims depend on it)"""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "ezkl_amd")):
