@@ -419,6 +419,11 @@ def lincomb(input_ptrs, coeffs, out_ptr, n, accumulate=False, stream=None):
              "ezkl_hip_lincomb_dev")
 
 
+def kate_division(a_ptr, z, out_ptr, n, stream=None):
+    """out = a(X) / (X - z) without the remainder (halo2's kate_division); out may alias a"""
+    _l.check(_l.load().ezkl_hip_kate_division_dev(_vp(a_ptr), _p(_fe(z)), _vp(out_ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_kate_division_dev")
+
+
 def chacha20_fr(key32, stream_id, out_ptr, n, first=0, stream=None):
     """n uniform Fr elements of ChaCha20 stream `stream_id` under the 32-byte key, starting at element `first`"""
     key = np.frombuffer(bytes(key32), np.uint8)

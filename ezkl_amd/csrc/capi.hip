@@ -576,6 +576,15 @@ int ezkl_hip_lincomb_dev(const void* const* inputs, const void* coeffs, uint32_t
     int rc = lincomb(c, st, (const fe_t* const*)inputs, (const fe_t*)coeffs, m, (fe_t*)out, n, accumulate);
     return rc ? rc : finish(c, st, stream);
 }
+int ezkl_hip_kate_division_dev(const void* a, const void* z, void* out, size_t n, void* stream) {
+    if (!z || ((!a || !out) && n)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    fe_t zz;
+    memcpy(&zz, z, 32);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = kate_division(c, st, (const fe_t*)a, zz, (fe_t*)out, n);
+    return rc ? rc : finish(c, st, stream);
+}
 int ezkl_hip_chacha20_fr_dev(const void* key32, uint64_t stream_id, size_t first, void* out, size_t n, void* stream) {
     if (!key32 || (!out && n)) return EZKL_ERR_INVALID;
     EZ_CTX(c);

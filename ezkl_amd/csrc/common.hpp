@@ -89,6 +89,7 @@ int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& 
 int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, fe_t* out, size_t n);
 int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_t* xs, uint32_t m, size_t n, void* out_host);
 int lincomb(Ctx* c, hipStream_t st, const fe_t* const* in, const fe_t* coeffs, uint32_t m, fe_t* out, size_t n, int accumulate);
+int kate_division(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& z, fe_t* out, size_t n);
 int chacha20_fr(Ctx* c, hipStream_t st, const uint32_t key[8], uint64_t stream, size_t first, fe_t* out, size_t n);
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
 int eval_jit_compile_only(const ezkl_program_t* p);

@@ -311,7 +311,6 @@ struct Backend {
     ezkl_bases_t g, gl;
     Shard shard;
     Fe one = Fe::one();
-    std::map<U256, std::pair<Col, Col>> zpow;       // kate_div: z^j and z^-(j+1) columns per opening point
     Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_, const Shard& sh = Shard()) : k(k_), n(n_), g(g_), gl(gl_), shard(sh) {}
     Backend(const Backend&) = delete;
     ~Backend() {
@@ -518,23 +517,9 @@ struct Backend {
         check(ezkl_hip_lookup_multiplicity_dev(ptrs.data(), (uint32_t)ptrs.size(), table->ptr(), n, usable, out->ptr(), &missing, nullptr), "ezkl_hip_lookup_multiplicity_dev");
         return out;
     }
-    // q(X) = p(X) / (X - z) for p(z) = 0, in place: q_i = z^-(i+1) * sum_{j>i} p_j z^j, via scans
-    void kate_div(const Col& h, const Fe& z, size_t m) {
-        const U256 key = z.canonical();
-        auto it = zpow.find(key);
-        if (it == zpow.end()) {
-            if (zpow.size() > 8) zpow.clear();
-            Col zp = alloc(m), zi = alloc(m);
-            fill(zp->ptr(), z, m);
-            scan(EZKL_VEC_MUL, true, zp->ptr(), zp->ptr(), m);
-            fill(zi->ptr(), z.inv(), m);
-            scan(EZKL_VEC_MUL, false, zi->ptr(), zi->ptr(), m);
-            it = zpow.emplace(key, std::make_pair(zp, zi)).first;
-        }
-        vec(EZKL_VEC_MUL, h->ptr(), it->second.first->ptr(), h->ptr(), m);         // w_j = p_j z^j
-        scan(EZKL_VEC_ADD, false, h->ptr(), h->ptr(), m);                          // P_i = sum_{j<=i} w_j ; P_{n-1} = p(z) = 0
-        scale(h, -Fe::one(), m);                                                   // -P_i = sum_{j>i} w_j
-        vec(EZKL_VEC_MUL, h->ptr(), it->second.second->ptr(), h->ptr(), m);
+    // q(X) = p(X) / (X - z) in place (halo2's kate_division)
+    void kate_div(const Col& h, const Fe& z, size_t m) const {
+        check(ezkl_hip_kate_division_dev(h->ptr(), z.v.data(), h->ptr(), m, nullptr), "ezkl_hip_kate_division_dev");
     }
 };
 

@@ -196,6 +196,93 @@ int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, f
     return arena_done(c->aux, st);
 }
 
+// ---- kate_division: q(X) = a(X) / (X - z) without the remainder (halo2_proofs::arithmetic::kate_division, the quotients of
+// the KZG / SHPLONK openings): q[n-1] = 0, q[i-1] = a[i] + z q[i], i.e. q[i] = sum_{j>i} a[j] z^(j-i-1) -----------------------
+// A descending first-order recurrence with a constant coefficient.  A workgroup owns KD_CHUNK consecutive coefficients, a
+// thread KD_E of them: Horner inside the thread, a doubling scan of the thread totals with ratio r = z^KD_E across the
+// workgroup, and the carry from the chunks above -- which is the SAME division applied to the chunk totals with Z = z^KD_CHUNK,
+// so the host recurses.  The coefficients are read twice and written once (96 B per element; the formulation with resident
+// columns of z^j and z^-(j+1) around a prefix sum moved ~400 B), ~4 products per element.
+static constexpr uint32_t KD_E = 8, KD_CHUNK = 256 * KD_E;
+struct KdPowers {
+    fe_t z;             // the point
+    fe_t lev[8];        // r^(2^l), r = z^KD_E
+};
+// I[t] = sum_{t' >= t} T_t' r^(t' - t) over the 256 thread totals (T_t = the thread's coefficients evaluated at z), with the
+// carry c from the chunks above folded into the last thread as T_255 + r c
+__device__ __forceinline__ void kd_load_and_scan(const fe_t* a, size_t n, size_t base, const KdPowers& pw, const fe_t& carry, fe_t (&x)[KD_E], fe_t* I) {
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (uint32_t e = 0; e < KD_E; e++) {
+        const size_t i = base + (size_t)t * KD_E + e;
+        x[e] = i < n ? ld_fe(a + i) : Fr::zero();
+    }
+    fe_t h = x[KD_E - 1];
+#pragma unroll
+    for (int e = (int)KD_E - 2; e >= 0; e--) h = Fr::add(x[e], Fr::mul(pw.z, h));
+    if (t == 255) h = Fr::add(h, Fr::mul(pw.lev[0], carry));
+    I[t] = h;
+    __syncthreads();
+    for (uint32_t l = 0, d = 1; d < 256; l++, d <<= 1) {
+        fe_t up = Fr::zero();
+        const bool have = t + d < 256;
+        if (have) up = I[t + d];
+        __syncthreads();
+        if (have) I[t] = Fr::add(I[t], Fr::mul(pw.lev[l], up));
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void kate_totals_kernel(const fe_t* a, size_t n, KdPowers pw, fe_t* totals) {
+    __shared__ fe_t I[256];
+    fe_t x[KD_E];
+    kd_load_and_scan(a, n, (size_t)blockIdx.x * KD_CHUNK, pw, Fr::zero(), x, I);
+    if (threadIdx.x == 0) st_fe(totals + blockIdx.x, I[0]);
+}
+// carries[b] = q at the last coefficient of chunk b (null: a single chunk, nothing above it)
+__global__ __launch_bounds__(256) void kate_apply_kernel(const fe_t* a, size_t n, KdPowers pw, const fe_t* carries, fe_t* out) {
+    __shared__ fe_t I[256];
+    fe_t x[KD_E];
+    const size_t base = (size_t)blockIdx.x * KD_CHUNK;
+    const fe_t carry = carries ? ld_fe(carries + blockIdx.x) : Fr::zero();
+    kd_load_and_scan(a, n, base, pw, carry, x, I);
+    const uint32_t t = threadIdx.x;
+    fe_t q = t < 255 ? I[t + 1] : carry;                     // q at the thread's last coefficient: everything above it
+#pragma unroll
+    for (int e = (int)KD_E - 1; e >= 0; e--) {
+        const size_t i = base + (size_t)t * KD_E + e;
+        if (i < n) st_fe(out + i, q);
+        q = Fr::add(x[e], Fr::mul(pw.z, q));                 // q[i-1] = a[i] + z q[i]
+    }
+}
+static int kate_rec(Ctx* c, hipStream_t st, const fe_t* a, fe_t* out, size_t n, const fe_t& z, fe_t* scratch) {
+    KdPowers pw;
+    pw.z = z;
+    fe_t r = z;
+    for (uint32_t e = 1; e < KD_E; e <<= 1) r = Fr::sqr(r);                  // z^KD_E (KD_E is a power of two)
+    for (int l = 0; l < 8; l++) { pw.lev[l] = r; r = Fr::sqr(r); }           // r ends as z^KD_CHUNK
+    const unsigned chunks = cdiv(n, KD_CHUNK);
+    fe_t* carries = nullptr;
+    if (chunks > 1) {
+        carries = scratch;
+        hipLaunchKernelGGL(kate_totals_kernel, dim3(chunks), dim3(256), 0, st, a, n, pw, carries);
+        int rc = kate_rec(c, st, carries, carries, chunks, r, scratch + (((size_t)chunks + 63) & ~(size_t)63));
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kate_apply_kernel, dim3(chunks), dim3(256), 0, st, a, n, pw, carries, out);
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+int kate_division(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& z, fe_t* out, size_t n) {
+    if (n == 0) return EZKL_OK;
+    size_t need = 0;
+    for (size_t m = n; m > KD_CHUNK;) { m = (m + KD_CHUNK - 1) / KD_CHUNK; need += (m + 63) & ~(size_t)63; }
+    fe_t* scratch = nullptr;
+    int rc = arena_reserve(c->aux, (need + 64) * sizeof(fe_t), st, (void**)&scratch);
+    if (rc) return rc;
+    if ((rc = kate_rec(c, st, a, out, n, z, scratch))) return rc;
+    return arena_done(c->aux, st);
+}
+
 // ---- mv-lookup multiplicities (A13: [UPSTREAM] mv_lookup::prover::prepare builds m(X) with a BTreeMap from table
 //      value to its FIRST row, then counts every input occurrence) ----
 // Open-addressing hash table over 256-bit keys in HBM: slot = first table row holding the key (atomicCAS to claim,

@@ -231,22 +231,8 @@ class GpuBackend:
         _b.memcpy_h2d(h.ptr + 32 * start, np.ascontiguousarray(mont_rows, np.uint64))
     def get_row(self, h, i): return from_mont(_b.memcpy_d2h(h.ptr + 32 * i, 32).view(np.uint64))
     def kate_div(self, h, z, n):
-        """q(X) = p(X) / (X - z) for p(z) = 0, in place: q_i = z^-(i+1) * sum_{j>i} p_j z^j, via scans"""
-        key = (z, n)
-        if key not in self._zpow:                                               # z^j and z^-(j+1), cached per opening point
-            zp, zi = _b.DeviceBuffer(32 * n), _b.DeviceBuffer(32 * n)
-            _b.vec_fill(zp.ptr, to_mont(z), n)
-            _b.prefix_scan("mul", zp.ptr, zp.ptr, n, exclusive=True)
-            _b.vec_fill(zi.ptr, to_mont(pow(z, -1, R)), n)
-            _b.prefix_scan("mul", zi.ptr, zi.ptr, n, exclusive=False)
-            if len(self._zpow) > 8:
-                self._zpow.clear()
-            self._zpow[key] = (zp, zi)
-        zp, zi = self._zpow[key]
-        _b.vec_op("mul", h.ptr, zp.ptr, h.ptr, n)                               # w_j = p_j z^j
-        _b.prefix_scan("add", h.ptr, h.ptr, n, exclusive=False)                # P_i = sum_{j<=i} w_j ; P_{n-1} = p(z) = 0
-        _b.vec_scale(h.ptr, to_mont(R - 1), h.ptr, n)                           # -P_i = sum_{j>i} w_j
-        _b.vec_op("mul", h.ptr, zi.ptr, h.ptr, n)
+        """q(X) = p(X) / (X - z) in place (halo2's kate_division)"""
+        _b.kate_division(h.ptr, to_mont(z), h.ptr, n)
         return h
 
 

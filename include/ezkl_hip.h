@@ -172,6 +172,9 @@ int ezkl_hip_eval_poly_batch_dev(const void* const* coeffs_dev, const void* xs_h
 /* out[i] = (accumulate ? out[i] : 0) + sum_j coeffs[j] * inputs[j][i]: the linear combinations of SHPLONK
  * (ProverSHPLONK::create_proof) and the x^n-Horner over the quotient pieces, each input read once.  inputs: m DEVICE
  * pointers in host memory; coeffs: m x 32 B host */
+/* q(X) = a(X) / (X - z), remainder dropped: out[n-1] = 0, out[i-1] = a[i] + z out[i] (halo2_proofs::arithmetic::kate_division,
+ * the quotients of the KZG / SHPLONK openings).  n coefficients resident, z host (32 B Montgomery); out may alias a. */
+int ezkl_hip_kate_division_dev(const void* a_dev, const void* z_host, void* out_dev, size_t n, void* stream);
 int ezkl_hip_lincomb_dev(const void* const* inputs_dev, const void* coeffs_host, uint32_t m, void* out_dev, size_t n, int accumulate,
                          void* stream);
 /* out[i] = uniform element of Fr, i < n, expanded from a 256-bit key with ChaCha20 (64-bit block counter, 64-bit stream

@@ -404,7 +404,8 @@ void oracle_batch_invert(fe *a, size_t n) {
     free(pre);
 }
 
-/* q(X) = p(X) / (X - z) for p(z) = 0 (synthetic division), in place; the top coefficient becomes 0 */
+/* q(X) = p(X) / (X - z), remainder dropped (synthetic division: halo2_proofs::arithmetic::kate_division, un-vendored; the
+ * quotients of the KZG / SHPLONK openings behind /root/reference/src/pfsys/mod.rs:456-463), in place; the top coefficient becomes 0 */
 void oracle_kate_div(fe *a, size_t n, const fe *z) {
     fe carry = {{0, 0, 0, 0}};
     for (size_t i = n; i-- > 0;) {

@@ -299,6 +299,31 @@ def test_lincomb(hip, n, m, acc):
     assert (out.to_numpy(shape=(n, 4)) == want).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 255, 2047, 2048, 2049, 5000, 1 << 16, (1 << 20) + 3, 1 << 22, (1 << 22) + 2049])
+def test_kate_division(hip, n):
+    """a(X) / (X - z) without the remainder (halo2's kate_division) == the oracle's synthetic division: sizes around the thread
+    (8), chunk (2048) and second-level (2048^2) boundaries, in place and out of place, special points; and the identity
+    q(X) (X - z) + a(z) = a(X) through independent evaluations"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(n)
+    a = rand_fr(rng, n)
+    d = B.DeviceBuffer.from_numpy(a)
+    o = B.DeviceBuffer(32 * n)
+    for z in (rand_fr(rng, 1)[0], fe_from_int(0), fe_from_int(1), fe_from_int(R - 1)):
+        B.kate_division(d.ptr, z, o.ptr, n)
+        want = ob.kate_div(a, z)
+        assert (o.to_numpy(shape=(n, 4)) == want).all()
+        assert (d.to_numpy(shape=(n, 4)) == a).all()                       # input untouched
+    z, x = rand_fr(rng, 1)[0], rand_fr(rng, 1)[0]
+    B.kate_division(d.ptr, z, d.ptr, n)                                    # in place
+    q = d.to_numpy(shape=(n, 4))
+    assert (q == ob.kate_div(a, z)).all()
+    one = lambda v: np.asarray(v, np.uint64).reshape(1, 4)
+    xz = ob.vec_op("sub", one(x), one(z))[0]
+    lhs = ob.vec_op("add", one(ob.fr_mul(ob.eval_poly(q, x), xz)), one(ob.eval_poly(a, z)))[0]
+    assert (lhs == ob.eval_poly(a, x)).all()
+
+
 @pytest.mark.parametrize("n,first", [(1, 0), (1000, 0), (5000, 123456), (1 << 18, 1 << 40)])
 def test_chacha20_field_sampler(hip, n, first):
     """device keystream expansion == the C restatement (itself pinned on the RFC 8439 vector), element for element"""
