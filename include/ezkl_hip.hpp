@@ -354,6 +354,18 @@ class GraphEvaluator {
     uint32_t num_intermediates_ = 0;
 };
 
+// ---- halo2_proofs::arithmetic helpers of the opening step, on resident columns ----
+// eval_polynomial(poly, point)
+inline Fr eval_polynomial(const DeviceColumn& poly, const Fr& point) {
+    Fr out;
+    check(ezkl_hip_eval_poly_dev(poly.ptr(), poly.len(), point.data(), out.data(), nullptr), "ezkl_hip_eval_poly_dev");
+    return out;
+}
+// kate_division(a, z): a(X) / (X - z), remainder dropped; in place (the top coefficient becomes 0)
+inline void kate_division(DeviceColumn& a, const Fr& z) {
+    check(ezkl_hip_kate_division_dev(a.ptr(), z.data(), a.ptr(), a.len(), nullptr), "ezkl_hip_kate_division_dev");
+}
+
 // ---- PolyCommitChip::commit (/root/reference/src/circuit/modules/polycommit.rs:46-81) ----
 inline std::vector<G1Affine> polycommit_commit(const std::vector<Fr>& message, uint32_t num_unusable_rows, const ParamsKZG& params) {
     const uint64_t rows = params.n(), n = rows - num_unusable_rows;

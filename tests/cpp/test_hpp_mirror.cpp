@@ -23,6 +23,8 @@ void oracle_lagrange_to_coeff(void* a, unsigned k);
 void oracle_coeff_to_extended(const void* in, unsigned k, unsigned ext_k, void* out);
 void oracle_extended_to_coeff(void* a, unsigned ext_k);
 void oracle_divide_by_vanishing(void* a, unsigned k, unsigned ext_k);
+void oracle_kate_div(void* a, size_t n, const void* z);
+void oracle_eval_poly(const void* c, size_t n, const void* x, void* out);
 struct oracle_program {
     const uint32_t* code; uint32_t n_instr; uint32_t n_intermediates;
     const void* constants; uint32_t n_constants;
@@ -215,6 +217,24 @@ int main(int argc, char** argv) {
         std::vector<Fr> hc = domain.extended_to_coeff(quotient);
         oracle_extended_to_coeff(want.data(), EXT_K);
         EXPECT(hc == want);
+    }
+
+    // ---- the opening step's arithmetic: eval_polynomial, kate_division; and the runtime gate ----
+    {
+        std::vector<Fr> a(5000);
+        for (auto& v : a) v = random_fr();
+        const Fr z = random_fr();
+        DeviceColumn col(a);
+        Fr want_eval;
+        oracle_eval_poly(a.data(), a.size(), z.data(), want_eval.data());
+        EXPECT(eval_polynomial(col, z) == want_eval);
+        kate_division(col, z);
+        oracle_kate_div(a.data(), a.size(), z.data());
+        EXPECT(col.to_host() == a);
+        unsetenv("ENABLE_HIP_GPU");
+        EXPECT(!enabled(20));
+        setenv("ENABLE_HIP_GPU", "1", 1);
+        EXPECT(enabled(20) && !enabled(8));
     }
 
     std::printf(failures ? "%d check(s) FAILED\n" : "all checks passed\n", failures);
