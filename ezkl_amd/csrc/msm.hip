@@ -797,8 +797,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     }
     {
         const uint32_t rows = 1u << (rg.wB + rg.wC), cols = 1u << rg.wA;
-        rg.EA = rows < MSM_DIGIT_E ? rows : MSM_DIGIT_E; rg.GA = rows / rg.EA;
-        rg.ET = cols < MSM_DIGIT_E ? cols : MSM_DIGIT_E; rg.GT = cols / rg.ET;
+        uint32_t E = MSM_DIGIT_E;
+        if (const char* e = getenv("EZKL_MSM_E")) E = (uint32_t)atoi(e);     // tuning knob: power of two
+        rg.EA = rows < E ? rows : E; rg.GA = rows / rg.EA;
+        rg.ET = cols < E ? cols : E; rg.GT = cols / rg.ET;
     }
     const uint32_t nA = 1u << rg.wA, nT = 1u << (rg.wB + rg.wC);
     const uint32_t n_partA = nA * rg.GA, n_partT = nT * rg.GT;
