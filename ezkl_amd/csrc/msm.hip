@@ -116,13 +116,6 @@ __device__ __forceinline__ bool gt_half_r(const fe_t& s) {      // s > (r-1)/2  
     for (int i = 0; i < 8; i++) (void)subb32(d[i], FrP::MOD[i], br);
     return c != 0 || br == 0;
 }
-__device__ __forceinline__ uint32_t get_bits(const fe_t& s, uint32_t lo, uint32_t c) {
-    if (lo >= 256) return 0;
-    uint32_t w = lo >> 5, sh = lo & 31;
-    uint64_t x = s.v[w];
-    if (w + 1 < 8) x |= (uint64_t)s.v[w + 1] << 32;
-    return (uint32_t)((x >> sh) & (((uint64_t)1 << c) - 1));
-}
 // canonical scalar, negated into [0, (r-1)/2] when that is shorter: s*P = (r-s)*(-P).  Small negative
 // witness values (src/fieldutils.rs:9-17) thereby become single-digit scalars.
 __device__ __forceinline__ fe_t msm_canon(const fe_t* scalars, size_t i, uint32_t& neg) {
@@ -136,14 +129,23 @@ __device__ __forceinline__ fe_t msm_canon(const fe_t* scalars, size_t i, uint32_
     }
     return s;
 }
+// the low c bits of s (c < 32), then s >>= c.  The windows are consumed by SHIFTING the scalar down: indexing its limbs with a
+// run-time window offset (s.v[off >> 5]) put every scalar of the sort passes into scratch memory (144 B per lane in the
+// histogram pass) and each digit cost two scratch loads.
+__device__ __forceinline__ uint32_t msm_take_bits(fe_t& s, uint32_t c) {
+    const uint32_t d = s.v[0] & ((1u << c) - 1u);
+#pragma unroll
+    for (int k = 0; k < 7; k++) s.v[k] = __builtin_amdgcn_alignbit(s.v[k + 1], s.v[k], c);
+    s.v[7] >>= c;
+    return d;
+}
 // calls f(w, bucket, sign) for every non-zero signed c-bit digit (bucket = |digit| - 1)
 template <class F>
-__device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, const WinPlan& wp, F&& f) {
-    uint32_t carry = 0, off = 0;
+__device__ __forceinline__ void msm_foreach_digit(fe_t s, uint32_t neg, const WinPlan& wp, F&& f) {
+    uint32_t carry = 0;
     for (uint32_t w = 0; w < wp.W; w++) {
         const uint32_t c = wp.width(w), half = 1u << (c - 1);
-        uint32_t raw = get_bits(s, off, c) + carry;
-        off += c;
+        uint32_t raw = msm_take_bits(s, c) + carry;
         if (raw > half) {                       // negative digit raw - 2^c, carry into the next window
             carry = 1;
             if (raw != (1u << c)) f(w, (1u << c) - raw - 1u, neg ^ 1u);   // raw == 2^c: digit 0 with a carry
@@ -154,11 +156,10 @@ __device__ __forceinline__ void msm_foreach_digit(const fe_t& s, uint32_t neg, c
     }
 }
 
-// one window of the recoding above, for loops that interleave several scalars: returns whether the digit is non-zero
-__device__ __forceinline__ bool msm_digit_step(const fe_t& s, uint32_t neg, uint32_t off, uint32_t c, uint32_t& carry, uint32_t& bucket,
-                                               uint32_t& sign) {
+// one window of the recoding above (consumed from s), for loops that interleave several scalars: returns whether the digit is non-zero
+__device__ __forceinline__ bool msm_digit_step(fe_t& s, uint32_t neg, uint32_t c, uint32_t& carry, uint32_t& bucket, uint32_t& sign) {
     const uint32_t half = 1u << (c - 1);
-    const uint32_t raw = get_bits(s, off, c) + carry;
+    const uint32_t raw = msm_take_bits(s, c) + carry;
     if (raw > half) {
         carry = 1;
         bucket = (1u << c) - raw - 1u;
@@ -194,15 +195,13 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
             if (i < hi) s[q] = msm_canon(scalars, i, neg[q]);
             else { s[q] = Fr::zero(); neg[q] = 0; }
         }
-        uint32_t off = 0;
         for (uint32_t w = 0; w < wp.W; w++) {
             const uint32_t c = wp.width(w);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint32_t bucket, sign;
-                if (msm_digit_step(s[q], neg[q], off, c, carry[q], bucket, sign)) atomicAdd(&lh[msm_part_of(bucket, NP)], 1u);
+                if (msm_digit_step(s[q], neg[q], c, carry[q], bucket, sign)) atomicAdd(&lh[msm_part_of(bucket, NP)], 1u);
             }
-            off += c;
         }
     }
     __syncthreads();
