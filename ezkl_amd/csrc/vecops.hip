@@ -223,7 +223,9 @@ __device__ __forceinline__ void kd_load_and_scan(const fe_t* a, size_t n, size_t
     if (t == 255) h = Fr::add(h, Fr::mul(pw.lev[0], carry));
     I[t] = h;
     __syncthreads();
-    for (uint32_t l = 0, d = 1; d < 256; l++, d <<= 1) {
+#pragma unroll
+    for (uint32_t l = 0; l < 8; l++) {                       // unrolled: pw.lev[l] with a run-time l goes through scratch
+        const uint32_t d = 1u << l;
         fe_t up = Fr::zero();
         const bool have = t + d < 256;
         if (have) up = I[t + d];
