@@ -780,7 +780,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     if (rounds < 1) rounds = 1;
     uint32_t L = (uint32_t)((npairs + resident * rounds - 1) / (resident * rounds));
     if (L < 8) L = 8;
-    if (const char* e = getenv("EZKL_MSM_L")) L = (uint32_t)atoi(e);   // tuning knob (tools/gpu_probe.py)
+    if (const char* e = getenv("EZKL_MSM_L")) {                        // tuning knob (tools/gpu_probe.py); nonsense keeps the default
+        const int v = atoi(e);
+        if (v > 0 && v < (1 << 20)) L = (uint32_t)v;
+    }
     const uint32_t nlanes = cdiv(npairs, L);
     // ---- field geometry of the reduce phase (positions: pos = (bucket & (NP-1)) << LB | bucket >> PB) ----
     ReduceGeom rg;
@@ -797,7 +800,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     {
         const uint32_t rows = 1u << (rg.wB + rg.wC), cols = 1u << rg.wA;
         uint32_t E = MSM_DIGIT_E;
-        if (const char* e = getenv("EZKL_MSM_E")) E = (uint32_t)atoi(e);     // tuning knob: power of two
+        if (const char* e = getenv("EZKL_MSM_E")) {                          // tuning knob: a power of two; nonsense keeps the default
+            const int v = atoi(e);
+            if (v > 0 && v <= 1024 && (v & (v - 1)) == 0) E = (uint32_t)v;
+        }
         rg.EA = rows < E ? rows : E; rg.GA = rows / rg.EA;
         rg.ET = cols < E ? cols : E; rg.GT = cols / rg.ET;
     }
