@@ -69,3 +69,51 @@ def fold_columns(gathered):
     for j in range(gathered.shape[1]):
         out[j] = fold_points(gathered[:, j])
     return out
+
+
+# ---- columns -> row windows: the one exchange of the row-sharded quotient sweep -------------------
+# After NTTs sharded by columns, rank r holds whole extended columns c with c % world == r.  The sweep sharded by ROWS
+# needs, on every rank, rows [lo, hi) of every (column, rotation) pair its gate program reads: one all_to_all in which
+# the owner of a column sends each destination the window that destination asked for.  Windows wrap around the domain,
+# so a large rotation (the permutation argument reads z at omega^usable) is just another window, not a halo.
+def row_windows(queries, n_ext, rank, world):
+    """queries: list of (column, row_shift).  Returns [(column, start, length)]: the rows of `column` this rank needs,
+    start taken modulo n_ext"""
+    lo, hi = shard_range(n_ext, rank, world)
+    return [(c, (lo + s) % n_ext, hi - lo) for c, s in queries]
+
+
+def _window(col, start, length):
+    """rows [start, start + length) of a column, wrapping around"""
+    n = col.shape[0]
+    if start + length <= n:
+        return col[start:start + length]
+    return np.concatenate([col[start:], col[: start + length - n]])
+
+
+def reshard_columns_to_rows(owned, queries, n_ext, dist, device):
+    """owned: {column: (n_ext, 4) u64 array} for the columns this rank owns (shard_columns).  queries: the (column,
+    row_shift) pairs of the gate program, the same list on every rank.  Returns {(column, row_shift): (rows, 4) array}
+    with this rank's row window of every queried pair.  One all_to_all (byte tensors; RCCL on the GPU box, gloo on CPU)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {(c, s): _window(owned[c], s % n_ext, n_ext) for c, s in queries}
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    send, send_sizes = [], []
+    for d in range(world):                                   # what destination d needs from the columns I own, in query order
+        parts = [_window(owned[c], start, ln) for (c, start, ln) in row_windows(queries, n_ext, d, world) if c % world == rank]
+        blob = np.concatenate(parts).view(np.uint8).reshape(-1) if parts else np.zeros(0, np.uint8)
+        send.append(blob)
+        send_sizes.append(blob.size)
+    mine = row_windows(queries, n_ext, rank, world)
+    recv_sizes = [sum(ln * 32 for (c, _, ln) in mine if c % world == s) for s in range(world)]
+    sbuf = torch.from_numpy(np.concatenate(send) if sum(send_sizes) else np.zeros(0, np.uint8)).to(device)
+    rbuf = torch.empty(sum(recv_sizes), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(rbuf, sbuf, output_split_sizes=recv_sizes, input_split_sizes=send_sizes)
+    flat = rbuf.cpu().numpy()
+    out, off = {}, [sum(recv_sizes[:s]) for s in range(world)]
+    for (c, s_), (_, _, ln) in zip(queries, mine):           # unpack in the same per-source query order the senders used
+        src = c % world
+        out[(c, s_)] = flat[off[src]:off[src] + ln * 32].view(np.uint64).reshape(ln, 4).copy()
+        off[src] += ln * 32
+    return out

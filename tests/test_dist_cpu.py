@@ -51,6 +51,55 @@ def test_sharded_msm_fold_world2():
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]
 
 
+def _reshard_check(world, rank, port, n_ext, ncols):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ezkl_amd import dist as D
+    rng = np.random.default_rng(9)
+    cols = [rand_fr(rng, n_ext) for _ in range(ncols)]                    # every rank can rebuild every column (the ground truth)
+    owned = {c: cols[c] for c in D.shard_columns(ncols, rank, world)}
+    queries = [(c, s) for c in range(ncols) for s in ((0,) if c % 2 else (0, 4, -4))] + [(0, n_ext - 24), (ncols - 1, 1000)]
+    got = D.reshard_columns_to_rows(owned, queries, n_ext, dist, torch.device("cpu"))
+    lo, hi = D.shard_range(n_ext, rank, world)
+    ok = set(got) == set(queries)
+    for (c, s) in queries:
+        want = np.stack([cols[c][(r + s) % n_ext] for r in range(lo, hi)])
+        ok = ok and got[(c, s)].shape == (hi - lo, 4) and bool((got[(c, s)] == want).all())
+    dist.barrier()
+    dist.destroy_process_group()
+    return ok
+
+
+def _reshard_worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ok = _reshard_check(3, rank, port, 250, 4)                            # ragged row counts: 84 / 83 / 83
+    if rank < 2:
+        ok = _reshard_check(2, rank, port + 1, 256, 5) and ok
+    q.put((rank, ok))
+
+
+def test_columns_to_row_windows_world3_and_2():
+    """the exchange of the row-sharded quotient sweep: columns owned round-robin -> every rank's row window of every
+    (column, rotation) pair, including windows that wrap around the domain; three ranks (ragged row counts), then two"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_reshard_worker, args=(r, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in res) == [0, 1, 2] and all(ok for _, ok in res)
+    # one rank: the identity (every window is the whole, rotated column)
+    from ezkl_amd import dist as D
+    col = rand_fr(np.random.default_rng(1), 64)
+    got = D.reshard_columns_to_rows({0: col}, [(0, 0), (0, 5)], 64, None, None)
+    assert (got[(0, 0)] == col).all() and (got[(0, 5)] == np.roll(col, -5, axis=0)).all()
+
+
 def test_shard_range_covers_everything():
     from ezkl_amd import dist as D
     for n in (0, 1, 7, 8, 1 << 20):
