@@ -583,6 +583,30 @@ class GraphProgram:
         rots = np.asarray(self.rotations, np.int32)
         return code, consts, rots
 
+    def row_sharded(self, log_world):
+        """The same program for ONE row shard of a sweep split over 2^log_world ranks.  Returns
+        (program, queries): every distinct (column, rotation) the code reads becomes a column of its own, read at rotation 0,
+        and queries[j] = (column, row_shift) says which window of the original extended column the j-th new column is: rows
+        [lo + row_shift, hi + row_shift) mod 2^ext_k for the shard [lo, hi) (dist.row_windows / reshard_columns_to_rows).
+        The shard is a domain of 2^(ext_k - log_world) rows, so the existing sweep entry point runs it unchanged."""
+        assert 0 <= log_world <= self.k
+        step = 1 << (self.ext_k - self.k)
+        sub = GraphProgram(self.k - log_world, self.ext_k - log_world)
+        sub.constants, sub.n_intermediates, sub.rotations = list(self.constants), self.n_intermediates, [0]
+        queries, index = [], {}
+
+        def remap(t, idx, rot):
+            if t != COLUMN:
+                return [t, idx, rot]
+            key = (idx, self.rotations[rot] * step)
+            if key not in index:
+                index[key] = len(queries)
+                queries.append(key)
+            return [COLUMN, index[key], 0]
+        for op, target, t0, i0, r0, t1, i1, r1 in self.code:
+            sub.code.append([op, target, *remap(t0, i0, r0), *remap(t1, i1, r1)])
+        return sub, queries
+
     def check_compiles(self, n_columns):
         """host-only: lower the program to HIP source and compile it for gfx950 with hiprtc (no GPU needed)"""
         code, consts, rots = self.arrays()
