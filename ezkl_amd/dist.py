@@ -117,3 +117,20 @@ def reshard_columns_to_rows(owned, queries, n_ext, dist, device):
         out[(c, s_)] = flat[off[src]:off[src] + ln * 32].view(np.uint64).reshape(ln, 4).copy()
         off[src] += ln * 32
     return out
+
+
+def allgather_rows(buf, lo, hi, n, dist, device):
+    """buf: a resident column (backend.DeviceBuffer) of n rows of which this rank computed [lo, hi); afterwards every rank
+    holds all rows.  Equal shards (n divisible by the world size): one all_gather.  Host-staged here; a GPU-direct version would
+    hand RCCL the device pointers."""
+    import torch
+    world = dist.get_world_size()
+    assert n % world == 0 and hi - lo == n // world
+    rows = hi - lo
+    mine = torch.from_numpy(_b.memcpy_d2h(buf.ptr + 32 * lo, 32 * rows)).to(device)
+    recv = torch.empty(world * mine.numel(), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, mine)
+    full = recv.cpu().numpy().view(np.uint64).reshape(n, 4)
+    for r in range(world):
+        if r * rows != lo:
+            _b.memcpy_h2d(buf.ptr + 32 * r * rows, np.ascontiguousarray(full[r * rows:(r + 1) * rows]))

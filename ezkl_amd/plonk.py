@@ -275,6 +275,34 @@ class DistGpuBackend(GpuBackend):
     def commit_lagrange(self, hs): return self._commit(self.gl, hs) if hs else []
     def commit(self, hs): return self._commit(self.g, hs) if hs else []
 
+    SWEEP_MIN_ROWS = 1 << 14
+
+    def eval_program(self, prog, cols, challenges, out):
+        """The quotient sweep sharded by ROWS: this rank evaluates rows [lo, hi) of the extended domain with the
+        program rewritten per shard (GraphProgram.row_sharded: every (column, rotation) read becomes a window of the resident
+        column -- an offset pointer, or a stitched copy when the window wraps around the domain) and the ranks all_gather their
+        rows of h.  The columns are replicated here (the NTTs are not sharded yet), so there is no column exchange."""
+        world = self.dist.get_world_size() if self.dist is not None and self.dist.is_initialized() else 1
+        ne, m = 1 << prog.ext_k, world.bit_length() - 1
+        if world == 1 or (1 << m) != world or m > prog.k or ne < self.SWEEP_MIN_ROWS:
+            return super().eval_program(prog, cols, challenges, out)
+        rank = self.dist.get_rank()
+        sub, queries = prog.row_sharded(m)
+        lo, hi = self.D.shard_range(ne, rank, world)
+        one, ptrs, keep = to_mont(1), [], []
+        for c, start, ln in self.D.row_windows(queries, ne, rank, world):
+            if start + ln <= ne:
+                ptrs.append(cols[c].ptr + 32 * start)
+            else:
+                w, first = _b.DeviceBuffer(32 * ln), ne - start
+                _b.vec_scale(cols[c].ptr + 32 * start, one, w.ptr, first)
+                _b.vec_scale(cols[c].ptr, one, w.ptr + 32 * first, ln - first)
+                keep.append(w)
+                ptrs.append(w.ptr)
+        sub.evaluate_h(ptrs, [to_mont(c) for c in challenges], out.ptr + 32 * lo)
+        self.D.allgather_rows(out, lo, hi, ne, self.dist, self.device)
+        self.sharded_sweeps = getattr(self, "sharded_sweeps", 0) + 1
+
 
 # ------------------------------------------------------------------ keygen
 class ProvingKey:

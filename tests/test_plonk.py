@@ -349,6 +349,7 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     j2 = json.loads(lines[-1])
     assert j1["verifier_accepts"] and j2["verifier_accepts"]
     assert j2["n_gpus"] == 2 and j1["proof_sha256"] == j2["proof_sha256"]
+    assert "2 sharded sweep(s)" in j2["sweep_sharding"] and "0 sharded" in j1["sweep_sharding"]      # warm-up + timed proof, rows split over the ranks
     # the C++ host prover sharded the same way (ezkl_prover_cs_set_shard): same bytes as the Python host, same on both ranks
     nv = j2["native_prover"]
     assert nv["proof_identical_to_python_prover"] and nv["all_ranks_same_proof"] and nv["library_rng_proof_verifies"]

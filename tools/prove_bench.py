@@ -121,6 +121,7 @@ def run(backend_name):
     tm = {}
     t0 = time.time(); proof = P.create_proof(pk, be, adv, P.Rng(5), timings=tm); t_prove = time.time() - t0
     run.timings = {a: round(b, 4) for a, b in tm.items()}
+    run.sharded_sweeps = getattr(be, "sharded_sweeps", 0)
     return vk, proof, t_keygen, t_prove
 
 vk, proof, t_keygen, t_prove = run("hip")
@@ -162,6 +163,7 @@ t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof); t_verify = time.ti
 out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLONK, Keccak EVM transcript): matmul-accumulation blocks + ReLU lookup",
        "lookups": len(lookups), "lookup_table_rows": (1 << tbits) if relu else 0,
        "n_gpus": world, "msm_sharding": "points across %d rank(s), all_gather of 64-B partials per commit batch" % world,
+       "sweep_sharding": "rows across %d rank(s) (Python host), all_gather of h: %d sharded sweep(s)" % (world, run.sharded_sweeps),
        "proof_sha256": __import__("hashlib").sha256(proof).hexdigest()[:16],
        "k": k, "advice_columns": cs.n_advice, "fixed_columns": cs.n_fixed, "degree": cs.degree, "ext_k": cs.ext_k, "copies": len(copies),
        "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "keygen_seconds_gpu": round(t_keygen, 3),
