@@ -48,7 +48,21 @@ struct Shard {
     uint32_t lo = 0, hi = 0;          // hi == 0: not sharded
     ezkl_fold_fn fold = nullptr;
     void* user = nullptr;
+    ezkl_gather_fn gather = nullptr;  // optional: the quotient sweep sharded by rows (ezkl_prover_cs_set_sweep_gather)
+    void* gather_user = nullptr;
+    mutable uint64_t sharded_sweeps = 0;
     bool on() const { return hi != 0; }
+    // equal power-of-two slices: rank / log2(world) of this one, or false
+    bool geometry(uint32_t n, uint32_t& rank, uint32_t& log_world) const {
+        const uint32_t len = hi - lo;
+        if (!on() || len == 0 || n % len || lo % len) return false;
+        const uint32_t world = n / len;
+        if (world & (world - 1)) return false;
+        rank = lo / len;
+        log_world = 0;
+        while ((1u << log_world) < world) log_world++;
+        return true;
+    }
 };
 struct ConstraintSystem {
     uint32_t k = 0, n = 0, n_advice = 0, n_fixed = 0, n_instance = 0, n_challenges = 0;
@@ -248,9 +262,39 @@ struct Program {
         for (auto& p : parts) calc(EZKL_OP_HORNER_STEP, p, factor, t.idx);
         return t;
     }
+    // The program of ONE row shard of a sweep split over 2^log_world ranks: every distinct (column, rotation) the code reads
+    // becomes a column of its own at rotation 0; windows[j] = (column, row shift) says which rows of the original extended
+    // column the j-th new column holds: [lo + shift, hi + shift) mod 2^ext_k for the shard [lo, hi).  The shard is a domain of
+    // 2^(ext_k - log_world) rows, so ezkl_hip_eval_h_dev runs it unchanged (GraphProgram.row_sharded is the Python twin).
+    Program row_sharded(uint32_t log_world, std::vector<std::pair<uint32_t, int64_t>>& windows) const {
+        Program sub(k - log_world, ext_k - log_world);
+        sub.constants = constants;
+        sub.n_int = n_int;
+        sub.rotations = {0};
+        sub.code = code;
+        const int64_t step = (int64_t)1 << (ext_k - k);
+        std::map<std::pair<uint32_t, int64_t>, uint32_t> index;
+        for (size_t i = 0; i < sub.code.size(); i += 8)
+            for (size_t s : {(size_t)2, (size_t)5}) {
+                if (sub.code[i + s] != EZKL_SRC_COLUMN) continue;
+                const std::pair<uint32_t, int64_t> key{sub.code[i + s + 1], rotations[sub.code[i + s + 2]] * step};
+                auto it = index.find(key);
+                if (it == index.end()) {
+                    it = index.emplace(key, (uint32_t)windows.size()).first;
+                    windows.push_back(key);
+                }
+                sub.code[i + s + 1] = it->second;
+                sub.code[i + s + 2] = 0;
+            }
+        return sub;
+    }
     void run(const std::vector<Col>& cols, const std::vector<Fe>& chal, void* out) const {
         std::vector<const void*> ptrs;
         for (auto& c : cols) ptrs.push_back(c->ptr());
+        run_ptrs(ptrs, chal, out);
+    }
+    void run_ptrs(std::vector<const void*> ptrs, const std::vector<Fe>& chal, void* out) const {
+        const uint32_t n_cols = (uint32_t)ptrs.size();
         if (ptrs.empty()) ptrs.push_back(nullptr);
         ezkl_program_t p{};
         p.code = code.data();
@@ -261,7 +305,7 @@ struct Program {
         p.rotations = rotations.data();
         p.n_rotations = (uint32_t)rotations.size();
         p.columns = ptrs.data();
-        p.n_columns = (uint32_t)cols.size();
+        p.n_columns = n_cols;
         p.challenges = chal.data();
         p.n_challenges = (uint32_t)chal.size();
         p.k = k;
@@ -1237,7 +1281,36 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     Col hnum = be.zeros((size_t)1 << cs.ext_k);
     {
         Quotient Q = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal);
-        Q.prog.run(Q.cols, Q.chal, hnum->ptr());
+        uint32_t rank = 0, log_world = 0;
+        if (cs.shard.gather && cs.shard.geometry(n, rank, log_world) && log_world > 0 && log_world <= cs.k) {
+            // the sweep sharded by ROWS: this rank evaluates its rows of the extended domain from windows of the
+            // (replicated) coset columns -- an offset pointer, or a stitched copy where the window wraps around -- and the ranks
+            // all_gather their rows of h through the caller's collective
+            std::vector<std::pair<uint32_t, int64_t>> windows;
+            const Program sub = Q.prog.row_sharded(log_world, windows);
+            const int64_t ne = (int64_t)1 << cs.ext_k, rows = ne >> log_world, rlo = (int64_t)rank * rows;
+            std::vector<const void*> ptrs;
+            std::vector<Col> stitched;
+            for (auto& w : windows) {
+                const int64_t start = (((rlo + w.second) % ne) + ne) % ne;
+                const Col& col = Q.cols[w.first];
+                if (start + rows <= ne) {
+                    ptrs.push_back(Backend::at(col, (size_t)start));
+                } else {
+                    Col t = be.alloc((size_t)rows);
+                    const size_t first = (size_t)(ne - start);
+                    be.scale_into(Backend::at(col, (size_t)start), be.one, t->ptr(), first);
+                    be.scale_into(col->ptr(), be.one, Backend::at(t, first), (size_t)rows - first);
+                    stitched.push_back(t);
+                    ptrs.push_back(t->ptr());
+                }
+            }
+            sub.run_ptrs(ptrs, Q.chal, Backend::at(hnum, (size_t)rlo));
+            invalid(cs.shard.gather(cs.shard.gather_user, hnum->ptr(), (size_t)ne * 32, (size_t)rlo * 32, (size_t)rows * 32) != 0, "gather callback failed");
+            cs.shard.sharded_sweeps++;
+        } else {
+            Q.prog.run(Q.cols, Q.chal, hnum->ptr());
+        }
     }
     sw.lap(6);
     adv_cosets.clear(); z_cosets.clear(); m_cosets.clear(); phi_cosets.clear(); inst_cosets.clear();
@@ -1384,7 +1457,20 @@ int ezkl_prover_cs_set_shard(ezkl_cs_t h, uint32_t lo, uint32_t hi, ezkl_fold_fn
         return EZKL_OK;
     }
     if (!fold || lo >= hi || hi > h->cs->n) return EZKL_ERR_INVALID;
-    h->cs->shard = Shard{lo, hi, fold, user};
+    Shard s = h->cs->shard;                    // keeps a sweep gather installed earlier
+    s.lo = lo; s.hi = hi; s.fold = fold; s.user = user;
+    h->cs->shard = s;
+    return EZKL_OK;
+}
+int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t h, ezkl_gather_fn gather, void* user) {
+    if (!h) return EZKL_ERR_INVALID;
+    h->cs->shard.gather = gather;
+    h->cs->shard.gather_user = user;
+    return EZKL_OK;
+}
+int ezkl_prover_cs_sharded_sweeps(ezkl_cs_t h, uint64_t* out) {
+    if (!h || !out) return EZKL_ERR_INVALID;
+    *out = h->cs->shard.sharded_sweeps;
     return EZKL_OK;
 }
 int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies, ezkl_pk_t* out) {

@@ -134,3 +134,40 @@ def allgather_rows(buf, lo, hi, n, dist, device):
     for r in range(world):
         if r * rows != lo:
             _b.memcpy_h2d(buf.ptr + 32 * r * rows, np.ascontiguousarray(full[r * rows:(r + 1) * rows]))
+
+
+class DeviceBytes:
+    """a library-owned device buffer seen through __cuda_array_interface__, so that torch (and through it RCCL) can work on it in
+    place: torch.as_tensor(DeviceBytes(ptr, n), device=...) aliases the memory, it does not copy"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+_direct_gather_ok = [True]
+
+
+def allgather_device_rows(ptr, total, off, nbytes, dist, device):
+    """In-place all_gather on a device buffer of `total` bytes of which this rank wrote [off, off + nbytes) (equal slices, rank
+    order).  On the GPU box RCCL works on the device pointers directly (in-place all_gather: the input is the rank's slice of the
+    output); with gloo -- or if torch refuses the pointer -- the slices are staged through the host."""
+    import os
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert total == world * nbytes and off == rank * nbytes
+    if getattr(device, "type", "cpu") == "cuda" and _direct_gather_ok[0] and not os.environ.get("EZKL_GATHER_HOST"):
+        try:
+            full = torch.as_tensor(DeviceBytes(ptr, total), device=device)
+        except Exception:                                    # decided before any collective is entered: the same on every rank
+            _direct_gather_ok[0] = False
+        else:
+            dist.all_gather_into_tensor(full, full[off:off + nbytes])
+            torch.cuda.synchronize(device)
+            return
+    mine = torch.from_numpy(_b.memcpy_d2h(ptr + off, nbytes)).to(device)
+    recv = torch.empty(total, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, mine)
+    full = recv.cpu().numpy()
+    for r in range(world):
+        if r != rank:
+            _b.memcpy_h2d(ptr + r * nbytes, np.ascontiguousarray(full[r * nbytes:(r + 1) * nbytes]))

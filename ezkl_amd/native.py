@@ -13,11 +13,13 @@ from . import plonk as _pl
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_vk",
+SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_sweep_gather",
+           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 FOLD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t)
 STAGES = ["advice_commit", "lookup_m", "permutation_z", "lookup_phi", "random_poly", "intt_and_coset_ntt", "quotient_sweep", "h_split_commit",
           "evaluations", "shplonk", "total"]
 
@@ -132,10 +134,26 @@ class NativeCircuit:
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._fold = FOLD_FN(_fold)                   # keep the thunk alive as long as the handle
+        def _gather(_user, buf, total, off, nbytes):
+            try:
+                D.allgather_device_rows(int(buf), int(total), int(off), int(nbytes), dist, device)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._fold = FOLD_FN(_fold)                   # keep the thunks alive as long as the handle
+        self._gather = GATHER_FN(_gather)
         self._slice = (lo, hi)
         _check(load().ezkl_prover_cs_set_shard(self.h, C.c_uint32(lo), C.c_uint32(hi), self._fold, None), "ezkl_prover_cs_set_shard")
+        if world > 1 and world & (world - 1) == 0 and self.cs.n % world == 0:      # the sweep by rows needs equal power-of-two slices
+            _check(load().ezkl_prover_cs_set_sweep_gather(self.h, self._gather, None), "ezkl_prover_cs_set_sweep_gather")
         return lo, hi
+
+    def sharded_sweeps(self):
+        out = C.c_uint64(0)
+        _check(load().ezkl_prover_cs_sharded_sweeps(self.h, C.byref(out)), "ezkl_prover_cs_sharded_sweeps")
+        return int(out.value)
 
     def shard_slice(self):
         return getattr(self, "_slice", (0, self.cs.n))

@@ -54,6 +54,14 @@ int ezkl_prover_cs_info(ezkl_cs_t cs, uint32_t out[8]);
  * The randomness must be the same on every rank (a shared `seed`, or an rng callback that is). */
 typedef int (*ezkl_fold_fn)(void* user, void* points, uint32_t count);
 int ezkl_prover_cs_set_shard(ezkl_cs_t cs, uint32_t lo, uint32_t hi, ezkl_fold_fn fold, void* user);
+/* Optional, on top of set_shard with equal power-of-two slices: the quotient sweep sharded by ROWS.  Each rank evaluates
+ * 2^ext_k / world rows of the quotient numerator (the gate program rewritten per shard: every (column, rotation) it reads is a
+ * window of the resident coset column) and calls `gather`, which must make the whole device buffer `buf` (total_bytes) identical
+ * on all ranks given that this rank wrote [offset, offset + bytes) -- an in-place all_gather (RCCL on device pointers;
+ * ezkl_amd/native.py) -- and return 0.  gather = NULL switches it off.  sharded_sweeps counts the sweeps done this way. */
+typedef int (*ezkl_gather_fn)(void* user, void* buf_dev, size_t total_bytes, size_t offset, size_t bytes);
+int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t cs, ezkl_gather_fn gather, void* user);
+int ezkl_prover_cs_sharded_sweeps(ezkl_cs_t cs, uint64_t* out);
 
 /* ---- keygen (keygen_vk + keygen_pk): fixed columns and copy constraints -> resident proving key ----
  * fixed_values: n_fixed host pointers, 2^k x 32 B Montgomery Fr each.  copies: n_copies x {colpos_a, row_a, colpos_b, row_b}

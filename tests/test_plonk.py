@@ -353,6 +353,7 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     # the C++ host prover sharded the same way (ezkl_prover_cs_set_shard): same bytes as the Python host, same on both ranks
     nv = j2["native_prover"]
     assert nv["proof_identical_to_python_prover"] and nv["all_ranks_same_proof"] and nv["library_rng_proof_verifies"]
+    assert nv["sharded_sweeps"] == 2                                   # warm-up + timed proof: the sweep split by rows, h all_gathered
 
 
 @pytest.mark.gpu

@@ -55,3 +55,37 @@ def test_row_sharded_program_on_the_device(hip, mode, monkeypatch):
         sub.evaluate_h([w.ptr for w in wins], chal, out.ptr)
         got[lo:hi] = out.to_numpy(shape=(hi - lo, 4))
     assert (got == want).all()
+
+
+_ALIAS_SCRIPT = r"""
+import sys, numpy as np, torch
+torch.cuda.set_device(0)                      # torch's HIP runtime first, as in every multi-rank entry point (bench.py, tools/prove_bench.py)
+sys.path.insert(0, sys.argv[1])
+import ezkl_amd
+from ezkl_amd import backend as B, dist as D
+ezkl_amd.init(0)
+rng = np.random.default_rng(3)
+a = rng.integers(0, 1 << 60, size=(1000, 4), dtype=np.uint64)
+d = B.DeviceBuffer.from_numpy(a)
+t = torch.as_tensor(D.DeviceBytes(d.ptr, d.nbytes), device=torch.device("cuda", 0))
+assert t.data_ptr() == d.ptr and t.numel() == 32000
+assert (t.cpu().numpy().view(np.uint64).reshape(1000, 4) == a).all()
+t[32:64] = 7                                                            # torch writes row 1 ...
+torch.cuda.synchronize()
+got = d.to_numpy(shape=(1000, 4))
+assert (got[1] == np.frombuffer(bytes([7]) * 32, np.uint64)).all() and (got[2:] == a[2:]).all() and (got[0] == a[0]).all()
+B.vec_fill(d.ptr, a[5], 10)                                             # ... and sees what the library writes
+assert (t[:320].cpu().numpy().view(np.uint64).reshape(10, 4) == a[5]).all()
+print("alias ok")
+"""
+
+
+@pytest.mark.gpu
+def test_torch_sees_library_memory_in_place(hip):
+    """the in-place RCCL all_gather of the sharded sweep hands torch the library's device pointer (dist.DeviceBytes through
+    __cuda_array_interface__): the tensor must ALIAS the buffer, both ways.  In a child process: torch's own HIP runtime has to
+    come up before the library's, as it does in the multi-rank entry points."""
+    import subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "-c", _ALIAS_SCRIPT, ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "alias ok" in r.stdout, r.stderr[-2000:]
