@@ -171,3 +171,29 @@ def allgather_device_rows(ptr, total, off, nbytes, dist, device):
     for r in range(world):
         if r != rank:
             _b.memcpy_h2d(ptr + r * nbytes, np.ascontiguousarray(full[r * nbytes:(r + 1) * nbytes]))
+
+
+def probe_direct_gather(dist, device):
+    """Called once by every rank before the first sharded sweep: an in-place all_gather on a small library-owned buffer through
+    DeviceBytes, checked on every rank, and the ranks agree (all_reduce MIN) on whether the direct path is usable; otherwise the
+    slices are staged through the host.  gloo / CPU: nothing to probe."""
+    import torch
+    if getattr(device, "type", "cpu") != "cuda":
+        _direct_gather_ok[0] = False
+        return False
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ok = 1
+    try:
+        buf = _b.DeviceBuffer(world * 256)
+        _b.memcpy_h2d(buf.ptr + 256 * rank, np.full(256, rank + 1, np.uint8))
+        full = torch.as_tensor(DeviceBytes(buf.ptr, world * 256), device=device)
+        dist.all_gather_into_tensor(full, full[256 * rank:256 * (rank + 1)])
+        torch.cuda.synchronize(device)
+        got = _b.memcpy_d2h(buf.ptr, world * 256).reshape(world, 256)
+        ok = int(all((got[r] == r + 1).all() for r in range(world)))
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    _direct_gather_ok[0] = bool(int(flag[0]))
+    return _direct_gather_ok[0]

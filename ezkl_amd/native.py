@@ -147,6 +147,7 @@ class NativeCircuit:
         self._slice = (lo, hi)
         _check(load().ezkl_prover_cs_set_shard(self.h, C.c_uint32(lo), C.c_uint32(hi), self._fold, None), "ezkl_prover_cs_set_shard")
         if world > 1 and world & (world - 1) == 0 and self.cs.n % world == 0:      # the sweep by rows needs equal power-of-two slices
+            self.direct_gather = D.probe_direct_gather(dist, device)               # RCCL on the library's pointers, verified once
             _check(load().ezkl_prover_cs_set_sweep_gather(self.h, self._gather, None), "ezkl_prover_cs_set_sweep_gather")
         return lo, hi
 

@@ -148,7 +148,7 @@ if world > 1 and "--native" in sys.argv:
     dist.all_gather(all_h, hs_)
     tt = torch.tensor([t_native], dtype=torch.float64, device=ddev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     native_multi = {"prove_seconds_library_rng": round(float(tt[0]), 4), "proof_identical_to_python_prover": nproof == proof,
-                    "sharded_sweeps": nc.sharded_sweeps(),
+                    "sharded_sweeps": nc.sharded_sweeps(), "gather_on_device_pointers": bool(getattr(nc, "direct_gather", False)),
                     "all_ranks_same_proof": all(bool((h == all_h[0]).all()) for h in all_h), "library_rng_proof": lproof,
                     "breakdown_seconds_library_rng": {a: round(b, 4) for a, b in ltm.items()}}
 if world > 1:
