@@ -25,7 +25,8 @@ using ezkl_hip::Error;
 using Col = std::shared_ptr<DeviceColumn>;
 
 static thread_local std::string g_last_error;
-constexpr uint32_t BLINDING = 5;      // as in ezkl (/root/reference/src/graph/mod.rs:100): the last BLINDING+1 rows are unusable
+// blinding factors: halo2's ConstraintSystem::blinding_factors() = max(3, most queries of one advice column) + 2, carried by the
+// blob or derived from the queries; ezkl's circuits give 5 (/root/reference/src/graph/mod.rs:100).  The last blinding+1 rows are unusable.
 
 // ------------------------------------------------------------------ constraint system
 enum NodeOp : uint32_t { N_CONST = 0, N_ADV, N_FIX, N_INST, N_CHAL, N_NEG, N_ADD, N_SUB, N_MUL };
@@ -72,6 +73,11 @@ struct ConstraintSystem {
     std::vector<std::pair<uint32_t, uint32_t>> perm;      // (kind = N_ADV | N_FIX | N_INST, col)
     std::vector<Lookup> lookups;
     uint32_t usable = 0, degree = 0, chunk = 0, ext_k = 0, n_chunks = 0;
+    uint32_t blinding = 0, minimum_degree = 0;           // 0 = derive / none (blob version 1)
+    uint32_t n_selectors = 0;                             // halo2 selectors behind the fixed columns: sizes the selector section of vk / pk files
+    bool queries_given = false;                           // halo2's order of first query (blob version 2)
+    std::vector<uint8_t> unblinded;                       // per advice column: unusable rows hold Blind::default() = 1
+    std::array<uint8_t, 32> blob_hash{};                  // keccak256 of the blob: binds gates / lookups / queries into the vk digest
     std::vector<Query> advice_queries, fixed_queries, instance_queries;
     std::vector<uint32_t> deg_memo;
     Shard shard;
@@ -104,7 +110,6 @@ struct ConstraintSystem {
     }
     void finalize() {
         n = 1u << k;
-        usable = n - BLINDING - 1;
         deg_memo.assign(nodes.size(), UINT32_MAX);
         uint32_t d = 3;
         for (uint32_t g : gates) d = std::max(d, deg(g));
@@ -118,7 +123,7 @@ struct ConstraintSystem {
             for (uint32_t e : l.table) tmax = std::max(tmax, deg(e));
             d = std::max(d, s + tmax);
         }
-        degree = d;
+        degree = d = std::max(d, minimum_degree);
         chunk = d - 2;
         ext_k = k;
         while ((1ull << ext_k) < (uint64_t)n * (d - 1)) ext_k++;
@@ -131,9 +136,27 @@ struct ConstraintSystem {
                 for (uint32_t e : t) collect(e, qs, seen);
             for (uint32_t e : l.table) collect(e, qs, seen);
         }
-        advice_queries.assign(qs[0].begin(), qs[0].end());
-        fixed_queries.assign(qs[1].begin(), qs[1].end());
-        instance_queries.assign(qs[2].begin(), qs[2].end());
+        if (queries_given) {                              // must cover what the expressions read, without duplicates
+            std::vector<Query>* given[3] = {&advice_queries, &fixed_queries, &instance_queries};
+            for (int t = 0; t < 3; t++) {
+                std::set<Query> have(given[t]->begin(), given[t]->end());
+                if (have.size() != given[t]->size()) throw Error(EZKL_ERR_INVALID, "duplicate query");
+                for (auto& q : qs[t])
+                    if (!have.count(q)) throw Error(EZKL_ERR_INVALID, "query lists do not cover the expressions");
+            }
+        } else {
+            advice_queries.assign(qs[0].begin(), qs[0].end());
+            fixed_queries.assign(qs[1].begin(), qs[1].end());
+            instance_queries.assign(qs[2].begin(), qs[2].end());
+        }
+        if (blinding == 0) {                              // halo2 ConstraintSystem::blinding_factors
+            std::map<uint32_t, uint32_t> per_col;
+            uint32_t most = 1;
+            for (auto& q : advice_queries) most = std::max(most, ++per_col[q.col]);
+            blinding = std::max(3u, most) + 2;
+        }
+        if (blinding + 2 > n) throw Error(EZKL_ERR_INVALID, "no usable rows");
+        usable = n - blinding - 1;
         n_chunks = perm.empty() ? 0 : (uint32_t)((perm.size() + chunk - 1) / chunk);
     }
 };
@@ -160,14 +183,31 @@ static void invalid(bool cond, const char* what) {
 static std::unique_ptr<ConstraintSystem> parse_cs(const void* blob, size_t len) {
     Reader r{(const uint8_t*)blob, len};
     invalid(r.u32() != 0x53435a45u, "bad magic");
-    invalid(r.u32() != 1, "unsupported version");
+    const uint32_t version = r.u32();
+    invalid(version != 1 && version != 2, "unsupported version");
     auto cs = std::make_unique<ConstraintSystem>();
+    cs->blob_hash = keccak256((const uint8_t*)blob, len);
     cs->k = r.u32(); cs->n_advice = r.u32(); cs->n_fixed = r.u32(); cs->n_instance = r.u32(); cs->n_challenges = r.u32();
     invalid(cs->k < 4 || cs->k > 28, "k out of range");
     invalid(cs->n_advice > (1u << 16) || cs->n_fixed > (1u << 16) || cs->n_instance > (1u << 16) || cs->n_challenges > (1u << 16), "column count out of range");
     for (uint32_t i = 0; i < cs->n_advice; i++) {
         cs->advice_phase.push_back(r.u32());
         invalid(cs->advice_phase.back() > 1, "advice phase must be 0 or 1");
+    }
+    cs->unblinded.assign(cs->n_advice, 0);
+    if (version >= 2) {
+        cs->blinding = r.u32();
+        cs->minimum_degree = r.u32();
+        invalid(cs->blinding > 64 || cs->minimum_degree > 64, "blinding / minimum degree out of range");
+        const uint32_t nu = r.u32();
+        invalid((size_t)nu * 4 > r.left, "unblinded list truncated");
+        for (uint32_t i = 0; i < nu; i++) {
+            const uint32_t c = r.u32();
+            invalid(c >= cs->n_advice, "unblinded column out of range");
+            cs->unblinded[c] = 1;
+        }
+        cs->n_selectors = r.u32();
+        invalid(cs->n_selectors > (1u << 20), "selector count out of range");
     }
     const uint32_t nn = r.u32();
     invalid((size_t)nn * 48 > r.left, "node table truncated");
@@ -216,6 +256,24 @@ static std::unique_ptr<ConstraintSystem> parse_cs(const void* blob, size_t len) 
         node_list(l.table);
         for (auto& t : l.inputs) invalid(t.size() != l.table.size(), "lookup arity mismatch");
         cs->lookups.push_back(std::move(l));
+    }
+    if (version >= 2) {
+        cs->queries_given = r.u32() != 0;
+        if (cs->queries_given) {
+            std::vector<Query>* lists[3] = {&cs->advice_queries, &cs->fixed_queries, &cs->instance_queries};
+            const uint32_t limits[3] = {cs->n_advice, cs->n_fixed, cs->n_instance};
+            for (int t = 0; t < 3; t++) {
+                const uint32_t m = r.u32();
+                invalid((size_t)m * 8 > r.left, "query list truncated");
+                for (uint32_t i = 0; i < m; i++) {
+                    Query q;
+                    q.col = r.u32();
+                    q.rot = (int32_t)r.u32();
+                    invalid(q.col >= limits[t], "query column out of range");
+                    lists[t]->push_back(q);
+                }
+            }
+        }
     }
     invalid(r.left != 0, "trailing bytes");
     cs->finalize();
@@ -559,6 +617,8 @@ struct Backend {
         for (auto& c : inputs) ptrs.push_back(c->ptr());
         uint32_t missing = 0;
         check(ezkl_hip_lookup_multiplicity_dev(ptrs.data(), (uint32_t)ptrs.size(), table->ptr(), n, usable, out->ptr(), &missing, nullptr), "ezkl_hip_lookup_multiplicity_dev");
+        // the reference's mv-lookup prover fails here too (a witness with an input outside the table has no valid proof)
+        if (missing != 0) throw Error(EZKL_ERR_INVALID, "lookup input not in table (" + std::to_string(missing) + " rows)");
         return out;
     }
     // q(X) = p(X) / (X - z) in place (halo2's kate_division)
@@ -573,13 +633,15 @@ struct ProvingKey {
     std::vector<Col> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
     Col omega_col, l0, l_last, l_active, x_coset;
     std::vector<G1> fixed_commitments, sigma_commitments;
+    std::vector<uint8_t> selector_bits;      // n_selectors x n/8 bytes, bit-packed rows as in halo2's vk files (zero if the key was made here)
     Fe digest;
 };
 static Fe vk_digest(const ProvingKey& pk) {
     const ConstraintSystem& cs = *pk.cs;
-    std::vector<uint8_t> t = {(uint8_t)cs.k, (uint8_t)cs.n_advice, (uint8_t)cs.n_fixed, (uint8_t)cs.degree, (uint8_t)cs.perm.size(),
-                              (uint8_t)cs.n_instance, (uint8_t)cs.n_challenges, (uint8_t)cs.lookups.size()};
-    for (uint32_t p : cs.advice_phase) t.push_back((uint8_t)p);
+    // keccak256(keccak256(constraint-system blob) || fixed commitments || permutation commitments): the whole description of
+    // the circuit -- columns, gates, lookups, permutation, query order -- is bound into the transcript, as halo2's
+    // vk.transcript_repr binds its pinned constraint system
+    std::vector<uint8_t> t(cs.blob_hash.begin(), cs.blob_hash.end());
     auto put = [&](const G1& p) {
         U256 x, y;
         p.canonical(x, y);
@@ -689,6 +751,11 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
     };
     put_points(pk.fixed_commitments);
     put_points(pk.sigma_commitments);
+    {
+        const size_t sel_bytes = (size_t)cs.n_selectors * ((cs.n + 7) / 8);
+        if (pk.selector_bits.size() == sel_bytes) o.insert(o.end(), pk.selector_bits.begin(), pk.selector_bits.end());
+        else o.insert(o.end(), sel_bytes, 0);
+    }
     auto put_poly = [&](const Col& c, size_t m) {
         std::vector<U256> v = be.download(c, m);
         put_be32(o, (uint32_t)m);
@@ -727,6 +794,13 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
     };
     get_points(pk->fixed_commitments, cs.n_fixed);
     get_points(pk->sigma_commitments, cs.perm.size());
+    {
+        // halo2 does not store the selector count: it re-runs configure (src/pfsys/mod.rs:627); here the constraint system carries it
+        const size_t sel_bytes = (size_t)cs.n_selectors * ((cs.n + 7) / 8);
+        need(sel_bytes);
+        pk->selector_bits.assign(buf + off, buf + off + sel_bytes);
+        off += sel_bytes;
+    }
     auto be32 = [&]() {
         need(4);
         uint32_t v = ((uint32_t)buf[off] << 24) | ((uint32_t)buf[off + 1] << 16) | ((uint32_t)buf[off + 2] << 8) | buf[off + 3];
@@ -762,6 +836,16 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
     pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
     pk->digest = vk_digest(*pk);
     return pk;
+}
+
+// commitments of the fixed / permutation polynomials under another SRS (a key file made with the public SRS, proved here under a
+// test SRS): the resident polynomials are committed again and the digest follows
+static void pk_recommit(ProvingKey& pk, ezkl_bases_t g) {
+    ConstraintSystem& cs = *pk.cs;
+    Backend be(cs.k, cs.n, g, nullptr, cs.shard);
+    pk.fixed_commitments = be.commit(pk.fixed_polys);
+    pk.sigma_commitments = be.commit(pk.sigma_polys);
+    pk.digest = vk_digest(pk);
 }
 
 // ------------------------------------------------------------------ randomness
@@ -1170,7 +1254,8 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         for (uint32_t c : idxs) {
             invalid(src[c] == nullptr, "missing advice column");
             adv_cols[c] = be.alloc(n);
-            tails.push_back(rng.vec(n - u));                    // blinding rows [u, n)
+            if (cs.unblinded[c]) tails.push_back(std::vector<U256>(n - u, Fe::one().v));   // Blind::default() (polycommit.rs:57-61), no randomness drawn
+            else tails.push_back(rng.vec(n - u));               // blinding rows [u, n)
             hostp.push_back(src[c]);
             devp.push_back(adv_cols[c]->ptr());
         }
@@ -1349,9 +1434,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         if (j + 1 < z_polys.size()) want(z_polys[j], x_last);
     }
     for (size_t i = 0; i < lk.size(); i++) {
-        want(m_polys[i], x);
-        want(phi_polys[i], x);
+        want(phi_polys[i], x);                     // mv_lookup::prover::Committed::evaluate: phi(x), phi(wx), m(x)
         want(phi_polys[i], x_next);
+        want(m_polys[i], x);
     }
     const size_t n_written = ev_polys.size();
     const size_t h_slot = want(hcomb, x);          // not part of the proof: the verifier derives it
@@ -1396,9 +1481,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         if (z_evals[j].has2) qs.push_back({{K_Z, j}, z_polys[j], rot_point((int32_t)u), z_evals[j].e2});
     }
     for (uint32_t i = 0; i < lk.size(); i++) {
-        qs.push_back({{K_M, i}, m_polys[i], x, lk_evals[i][0]});
-        qs.push_back({{K_PHI, i}, phi_polys[i], x, lk_evals[i][1]});
-        qs.push_back({{K_PHI, i}, phi_polys[i], rot_point(1), lk_evals[i][2]});
+        qs.push_back({{K_PHI, i}, phi_polys[i], x, lk_evals[i][0]});
+        qs.push_back({{K_PHI, i}, phi_polys[i], rot_point(1), lk_evals[i][1]});
+        qs.push_back({{K_M, i}, m_polys[i], x, lk_evals[i][2]});
     }
     shplonk_prove(be, T, qs, n);
     sw.lap(9);
@@ -1492,6 +1577,12 @@ int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len) {
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out) {
     if (!cs || !buf || !out) return EZKL_ERR_INVALID;
     return guarded([&] { *out = new ezkl_prover_pk{pk_read(*cs->cs, (const uint8_t*)buf, len)}; });
+}
+int ezkl_prover_pk_recommit(ezkl_pk_t pk, ezkl_bases_t g) {
+    return guarded([&] {
+        if (!pk || !g) throw Error(EZKL_ERR_INVALID, "null handle");
+        pk_recommit(*pk->pk, g);
+    });
 }
 int ezkl_prover_pk_free(ezkl_pk_t pk) {
     delete pk;

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_sweep_gather",
-           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_vk",
+           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_recommit", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -52,49 +52,7 @@ def keccak256(data):
     return bytes(out)
 
 
-_OPS = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "chal": 4, "neg": 5, "add": 6, "sub": 7, "mul": 8}
-_KINDS = {"adv": 1, "fix": 2, "inst": 3}
-
-
-def serialize_cs(cs):
-    """plonk.ConstraintSystem -> the blob of include/ezkl_prover.h (expression DAG with shared sub-expressions kept shared)"""
-    nodes, ids = [], {}
-
-    def visit(e):
-        if id(e) in ids:
-            return ids[id(e)]
-        op = e.node[0]
-        a = b = 0
-        const = bytes(32)
-        if op == "const":
-            const = _pl.to_mont(e.node[1]).tobytes()
-        elif op in ("adv", "fix", "inst"):
-            a, b = e.node[1], e.node[2] & 0xffffffff
-        elif op == "chal":
-            a = e.node[1]
-        elif op == "neg":
-            a = visit(e.node[1])
-        else:
-            a, b = visit(e.node[1]), visit(e.node[2])
-        nodes.append(struct.pack("<4I", _OPS[op], a, b, 0) + const)
-        ids[id(e)] = len(nodes) - 1
-        return ids[id(e)]
-
-    gates = [visit(g) for g in cs.gates]
-    lookups = [([[visit(e) for e in t] for t in ins], [visit(e) for e in tab]) for ins, tab in cs.lookups]
-    out = bytearray(struct.pack("<7I", 0x53435a45, 1, cs.k, cs.n_advice, cs.n_fixed, cs.n_instance, cs.n_challenges))
-    out += struct.pack("<%dI" % cs.n_advice, *cs.advice_phase)
-    out += struct.pack("<I", len(nodes)) + b"".join(nodes)
-    out += struct.pack("<I%dI" % len(gates), len(gates), *gates)
-    out += struct.pack("<I", len(cs.perm))
-    for kind, col in cs.perm:
-        out += struct.pack("<2I", _KINDS[kind], col)
-    out += struct.pack("<I", len(lookups))
-    for ins, tab in lookups:
-        out += struct.pack("<I", len(ins))
-        for t in ins + [tab]:
-            out += struct.pack("<I%dI" % len(t), len(t), *t)
-    return bytes(out)
+serialize_cs = _pl.serialize_cs
 
 
 def _ptr_array(arrays):
@@ -183,13 +141,16 @@ class NativeProvingKey:
                "ezkl_prover_keygen")
 
     @classmethod
-    def from_bytes(cls, circuit, data):
-        """load a key in halo2's raw-bytes pk.key layout (load_pk): columns go straight to HBM"""
+    def from_bytes(cls, circuit, data, recommit=None):
+        """load a key in halo2's raw-bytes pk.key layout (load_pk): columns go straight to HBM.  recommit = a Bases handle: commit
+        the fixed / permutation polynomials again under that SRS (a key file made under another SRS)"""
         self = cls.__new__(cls)
         self.circuit = circuit
         self.h = C.c_void_p()
         data = bytes(data)
         _check(load().ezkl_prover_pk_read(circuit.h, data, C.c_size_t(len(data)), C.byref(self.h)), "ezkl_prover_pk_read")
+        if recommit is not None:
+            _check(load().ezkl_prover_pk_recommit(self.h, recommit.h), "ezkl_prover_pk_recommit")
         return self
 
     def to_bytes(self):

@@ -115,10 +115,16 @@ def lower(e, prog, col_index, memo):
 
 
 class ConstraintSystem:
-    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns, lookups=(), n_instance=0, advice_phase=None, n_challenges=0):
+    def __init__(self, k, n_advice, n_fixed, gates, permutation_columns, lookups=(), n_instance=0, advice_phase=None, n_challenges=0,
+                 query_order=None, blinding=None, minimum_degree=None, unblinded=(), n_selectors=0):
         """lookups: [(input_tuples, table_tuple)]: every input tuple (list of Expr) of a lookup must appear as a row of
         the table tuple (list of Expr of the same arity) on the usable rows -- the mv-lookup (logUp) argument the
-        zkonduit halo2 fork uses (cargo feature `mv-lookup`, /root/reference/Cargo.toml:255)."""
+        zkonduit halo2 fork uses (cargo feature `mv-lookup`, /root/reference/Cargo.toml:255).
+        query_order: (advice, fixed, instance) lists of (column, rotation) in halo2's order of first query (halo2_cs.py); without
+        it the queries are collected from the expressions and sorted.  blinding: halo2's cs.blinding_factors() (computed from
+        the advice queries when omitted: max(3, most queries of one advice column) + 2; ezkl's circuits give 5,
+        src/graph/mod.rs:100).  minimum_degree: set by halo2's chunk_lookups.  unblinded: advice columns whose unusable rows
+        hold Blind::default() = 1 instead of randomness (src/circuit/modules/polycommit.rs:57-61, src/tensor/var.rs:73-108)."""
         self.k, self.n = k, 1 << k
         self.n_advice, self.n_fixed, self.n_instance = n_advice, n_fixed, n_instance
         # second-phase advice (ezkl's Freivalds einsum, src/circuit/ops/chip/einsum/mod.rs:67-76,716): columns with phase 1 are
@@ -128,14 +134,16 @@ class ConstraintSystem:
         self.gates = list(gates)
         self.perm = list(permutation_columns)             # [("adv"|"fix"|"inst", col)]
         self.lookups = [([list(t) for t in ins], list(tab)) for ins, tab in lookups]
-        self.usable = self.n - BLINDING - 1               # row index of l_last; rows [0, usable) carry the witness
+        self.unblinded = sorted(set(unblinded))
+        self.n_selectors = n_selectors                    # halo2 selectors behind the fixed columns (sizes the selector section of key files)
+        self.minimum_degree = minimum_degree
         d = max([degree(g) for g in self.gates] + [3])
         for ins, tab in self.lookups:                     # l_active * phi * prod(f_j + beta) * (t + beta)
             d = max(d, 2 + sum(max(degree(e) for e in t) for t in ins) + max(degree(e) for e in tab))
-        self.degree = d
-        self.chunk = d - 2
+        self.degree = max(d, minimum_degree or 1)
+        self.chunk = self.degree - 2
         self.ext_k = k
-        while (1 << self.ext_k) < self.n * (d - 1):
+        while (1 << self.ext_k) < self.n * (self.degree - 1):
             self.ext_k += 1
         qs = set()
         for g in self.gates:
@@ -146,9 +154,25 @@ class ConstraintSystem:
             for t in ins + [tab]:
                 for e in t:
                     queries(e, qs)
-        self.advice_queries = sorted((c, r) for kd, c, r in qs if kd == "adv")
-        self.fixed_queries = sorted((c, r) for kd, c, r in qs if kd == "fix")
-        self.instance_queries = sorted((c, r) for kd, c, r in qs if kd == "inst")
+        if query_order is not None:
+            self.advice_queries, self.fixed_queries, self.instance_queries = [[(int(c), int(r)) for c, r in q] for q in query_order]
+            have = {("adv", c, r) for c, r in self.advice_queries} | {("fix", c, r) for c, r in self.fixed_queries} | {("inst", c, r) for c, r in self.instance_queries}
+            assert qs <= have, "query lists do not cover the expressions: %s" % sorted(qs - have)[:4]
+            for q in (self.advice_queries, self.fixed_queries, self.instance_queries):
+                assert len(set(q)) == len(q), "duplicate query"
+        else:
+            self.advice_queries = sorted((c, r) for kd, c, r in qs if kd == "adv")
+            self.fixed_queries = sorted((c, r) for kd, c, r in qs if kd == "fix")
+            self.instance_queries = sorted((c, r) for kd, c, r in qs if kd == "inst")
+        self.queries_given = query_order is not None
+        if blinding is None:                              # halo2 ConstraintSystem::blinding_factors
+            per_col = {}
+            for c, _ in self.advice_queries:
+                per_col[c] = per_col.get(c, 0) + 1
+            blinding = max(3, max(per_col.values(), default=1)) + 2
+        self.blinding = blinding
+        self.usable = self.n - blinding - 1               # row index of l_last; rows [0, usable) carry the witness
+        assert self.usable > 0
         self.n_chunks = -(-len(self.perm) // self.chunk) if self.perm else 0
 
     def perm_chunks(self):
@@ -237,16 +261,35 @@ class GpuBackend:
 
 
 class Rng:
-    """prover randomness (blinding rows, the vanishing argument's random polynomial).  Seeded = the reference's
-    `det-prove` feature (src/pfsys/mod.rs:436-439); unseeded draws from the OS."""
+    """prover randomness (blinding rows, the vanishing argument's random polynomial), uniform on [0, r) by rejection
+    sampling.  Unseeded = OS entropy (the reference's OsRng, src/pfsys/mod.rs:436-439); seeded = its `det-prove` feature
+    (tests only: a deterministic stream, NOT cryptographic)."""
 
     def __init__(self, seed=None):
-        self.g = np.random.default_rng(seed)
+        self.g = None if seed is None else np.random.default_rng(seed)
+
+    def _raw(self, m):
+        if self.g is None:
+            import os
+            return np.frombuffer(os.urandom(32 * m), np.uint64).reshape(m, 4).copy()
+        return self.g.bit_generator.random_raw(4 * m).astype(np.uint64, copy=False).reshape(m, 4)
 
     def vec(self, m):
-        a = self.g.bit_generator.random_raw(4 * m).astype(np.uint64, copy=False).reshape(m, 4)
-        a[:, 3] &= np.uint64((1 << 61) - 1)          # 253 uniform bits < r, read as Montgomery residues
-        return a
+        out = np.empty((m, 4), np.uint64)
+        have = 0
+        top, rest = np.uint64(R >> 192), [np.uint64((R >> s) & 0xffffffffffffffff) for s in (128, 64, 0)]
+        while have < m:
+            a = self._raw(m - have + 8)
+            a[:, 3] &= np.uint64((1 << 62) - 1)      # 254 bits; accept a < r (limb-wise comparison, most significant first)
+            lt = a[:, 3] < top
+            eq = a[:, 3] == top
+            for limb, rv in zip((2, 1, 0), rest):
+                lt |= eq & (a[:, limb] < rv)
+                eq &= a[:, limb] == rv
+            a = a[lt][: m - have]
+            out[have:have + len(a)] = a
+            have += len(a)
+        return out
 
 
 class DistGpuBackend(GpuBackend):
@@ -390,7 +433,8 @@ class VerifyingKey:
 def export_keys(pk, backend):
     """the proving / verifying key in the raw-bytes layout of halo2's ProvingKey::write (the format of the reference's
     pk.key / vk.key, SURVEY.md §8(c) item 3, written by /root/reference/src/pfsys/mod.rs:638-683 save_pk / save_vk):
-    returns (vk_bytes, pk_bytes).  Selectors are plain fixed columns here, so the selector section is empty."""
+    returns (vk_bytes, pk_bytes).  The selector section holds cs.n_selectors bit-packed rows (pk.selectors, zero when the
+    circuit was described with plain fixed columns)."""
     from . import codecs
     cs = pk.cs
     def pt(p):
@@ -399,7 +443,7 @@ def export_keys(pk, backend):
     vk = dict(k=cs.k, compress_selectors=True,
               fixed_commitments=np.stack([pt(p) for p in pk.vk.fixed_commitments]) if pk.vk.fixed_commitments else np.zeros((0, 8), np.uint64),
               permutation_commitments=np.stack([pt(p) for p in pk.vk.sigma_commitments]) if pk.vk.sigma_commitments else np.zeros((0, 8), np.uint64),
-              selectors=np.zeros((0, cs.n), bool))
+              selectors=getattr(pk, "selectors", None) if getattr(pk, "selectors", None) is not None else np.zeros((cs.n_selectors, cs.n), bool))
     ne = 1 << cs.ext_k
     dl = lambda h, m: np.array(backend.download(h, m), np.uint64, copy=True)
     d = dict(vk=vk, l0=dl(pk.l0, ne), l_last=dl(pk.l_last, ne), l_active_row=dl(pk.l_active, ne),
@@ -409,9 +453,70 @@ def export_keys(pk, backend):
     return codecs.write_vk(vk), codecs.write_pk(d)
 
 
+_OPS = {"const": 0, "adv": 1, "fix": 2, "inst": 3, "chal": 4, "neg": 5, "add": 6, "sub": 7, "mul": 8}
+_KINDS = {"adv": 1, "fix": 2, "inst": 3}
+
+
+def serialize_cs(cs):
+    """ConstraintSystem -> the EZCS blob of include/ezkl_prover.h, version 2 (expression DAG with shared sub-expressions kept
+    shared; blinding factors, minimum degree, unblinded columns and halo2's query order carried explicitly).  The blob is the
+    canonical description of the circuit: its hash is what the vk digest binds."""
+    import struct
+    nodes, ids = [], {}
+
+    def visit(e):
+        stack = [e]
+        while stack:                                   # iterative: gate expressions of wide circuits are deep
+            cur = stack[-1]
+            if id(cur) in ids:
+                stack.pop(); continue
+            op = cur.node[0]
+            kids = [c for c in cur.node[1:] if isinstance(c, Expr)] if op in ("neg", "add", "sub", "mul") else []
+            pend = [c for c in kids if id(c) not in ids]
+            if pend:
+                stack.extend(pend); continue
+            a = b = 0
+            cst = bytes(32)
+            if op == "const": cst = to_mont(cur.node[1]).tobytes()
+            elif op in ("adv", "fix", "inst"): a, b = cur.node[1], cur.node[2] & 0xffffffff
+            elif op == "chal": a = cur.node[1]
+            elif op == "neg": a = ids[id(cur.node[1])]
+            else: a, b = ids[id(cur.node[1])], ids[id(cur.node[2])]
+            nodes.append(struct.pack("<4I", _OPS[op], a, b, 0) + cst)
+            ids[id(cur)] = len(nodes) - 1
+            stack.pop()
+        return ids[id(e)]
+
+    gates = [visit(g) for g in cs.gates]
+    lookups = [([[visit(e) for e in t] for t in ins], [visit(e) for e in tab]) for ins, tab in cs.lookups]
+    out = bytearray(struct.pack("<7I", 0x53435a45, 2, cs.k, cs.n_advice, cs.n_fixed, cs.n_instance, cs.n_challenges))
+    out += struct.pack("<%dI" % cs.n_advice, *cs.advice_phase)
+    out += struct.pack("<3I%dI" % len(cs.unblinded), cs.blinding, cs.minimum_degree or 0, len(cs.unblinded), *cs.unblinded)
+    out += struct.pack("<I", cs.n_selectors)
+    out += struct.pack("<I", len(nodes)) + b"".join(nodes)
+    out += struct.pack("<I%dI" % len(gates), len(gates), *gates)
+    out += struct.pack("<I", len(cs.perm))
+    for kind, col in cs.perm:
+        out += struct.pack("<2I", _KINDS[kind], col)
+    out += struct.pack("<I", len(lookups))
+    for ins, tab in lookups:
+        out += struct.pack("<I", len(ins))
+        for t in ins + [tab]:
+            out += struct.pack("<I%dI" % len(t), len(t), *t)
+    out += struct.pack("<I", 1 if cs.queries_given else 0)
+    if cs.queries_given:
+        for q in (cs.advice_queries, cs.fixed_queries, cs.instance_queries):
+            out += struct.pack("<I", len(q))
+            for c, r in q:
+                out += struct.pack("<2I", c, r & 0xffffffff)
+    return bytes(out)
+
+
 def vk_digest(vk):
-    t = bytearray([vk.cs.k, vk.cs.n_advice, vk.cs.n_fixed, vk.cs.degree, len(vk.cs.perm), vk.cs.n_instance, vk.cs.n_challenges,
-                   len(vk.cs.lookups)] + list(vk.cs.advice_phase))
+    """keccak256(keccak256(constraint-system blob) || fixed commitments || permutation commitments) mod r: the whole circuit
+    description (gates, lookups, permutation, query order) is bound into the transcript, the role of halo2's
+    vk.transcript_repr (a Blake2b hash of the pinned constraint system's Debug text, not reproducible without its source)."""
+    t = bytearray(keccak256(serialize_cs(vk.cs)))
     for p in list(vk.fixed_commitments) + list(vk.sigma_commitments):
         x, y = (0, 0) if p is None else p
         t += x.to_bytes(32, "big") + y.to_bytes(32, "big")
@@ -419,12 +524,13 @@ def vk_digest(vk):
 
 
 # ------------------------------------------------------------------ prover
-def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
+def create_proof(pk, backend, advice_values, rng, timings=None, instances=(), strict=True):
     """advice_values: list of (n,4) Montgomery arrays (rows >= usable are overwritten with blinding randomness), or a
     callable advice_values(phase, challenges) -> {column: array} for circuits with second-phase advice.
     instances: list (one per instance column) of lists of public field elements (ints); they are hashed into the
     transcript, not committed (halo2 KZG: QUERY_INSTANCE = false).
-    rng.vec(m) -> (m,4) uniformly random Montgomery residues.  Returns proof bytes (EvmTranscript layout)."""
+    rng.vec(m) -> (m,4) uniformly random Montgomery residues.  Returns proof bytes (EvmTranscript layout).
+    strict=False lets a witness with a lookup input outside its table through (soundness tests of the verifier only)."""
     import time as _time
     _t = [_time.perf_counter()]
     def lap(name):
@@ -454,7 +560,10 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
         vals = advice_values(phase, list(user_chal)) if callable(advice_values) else {c: advice_values[c] for c in idxs}
         for c in idxs:
             adv_cols[c] = backend.upload(vals[c])                    # witness column -> HBM, then blind rows [u, n) in place
-            backend.set_rows(adv_cols[c], u, rng.vec(n - u))
+            if c in cs.unblinded:                                    # Blind::default() = 1, no randomness drawn (polycommit.rs:57-61)
+                backend.set_rows(adv_cols[c], u, np.tile(to_mont(1), (n - u, 1)))
+            else:
+                backend.set_rows(adv_cols[c], u, rng.vec(n - u))
         for p in backend.commit_lagrange([adv_cols[c] for c in idxs]):
             T.write_point(p)
         if phase == 0:
@@ -467,7 +576,9 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
         theta = T.squeeze_challenge()
         for ins, tab in cs.lookups:
             comp = [compress_column(cs, backend, t, theta, col_handle, user_chal) for t in ins + [tab]]
-            m, _missing = backend.lookup_multiplicity(comp[:-1], comp[-1], u)
+            m, missing = backend.lookup_multiplicity(comp[:-1], comp[-1], u)
+            if missing and strict:                    # the reference's mv-lookup prover errors here: such a witness has no valid proof
+                raise ValueError("lookup input not in table (%d rows)" % missing)
             backend.set_rows(m, u, rng.vec(n - u))
             lk.append({"inputs": comp[:-1], "table": comp[-1], "m": m})
         for d_, p in zip(lk, backend.commit_lagrange([d_["m"] for d_ in lk])):
@@ -548,7 +659,8 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
         z_evals.append((e0, e1, e2))
     lk_evals = []
     for mp, pp in zip(m_polys, phi_polys):
-        e = (backend.eval_poly(mp, n, x), backend.eval_poly(pp, n, x), backend.eval_poly(pp, n, rot_point(1)))
+        # mv_lookup::prover::Committed::evaluate writes phi(x), phi(wx), m(x)
+        e = (backend.eval_poly(pp, n, x), backend.eval_poly(pp, n, rot_point(1)), backend.eval_poly(mp, n, x))
         for v_ in e: T.write_scalar(v_)
         lk_evals.append(e)
     lap("evaluations")
@@ -569,8 +681,8 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=()):
         qs.append((("z", j), zp, x, z_evals[j][0])); qs.append((("z", j), zp, rot_point(1), z_evals[j][1]))
         if z_evals[j][2] is not None: qs.append((("z", j), zp, rot_point(u), z_evals[j][2]))
     for i, (mp, pp) in enumerate(zip(m_polys, phi_polys)):
-        qs.append((("m", i), mp, x, lk_evals[i][0]))
-        qs.append((("phi", i), pp, x, lk_evals[i][1])); qs.append((("phi", i), pp, rot_point(1), lk_evals[i][2]))
+        qs.append((("phi", i), pp, x, lk_evals[i][0])); qs.append((("phi", i), pp, rot_point(1), lk_evals[i][1]))
+        qs.append((("m", i), mp, x, lk_evals[i][2]))
     shplonk_prove(backend, T, qs, n)
     lap("shplonk")
     return bytes(T.proof)

@@ -27,14 +27,23 @@ extern "C" {
 #endif
 
 /* ---- constraint system ----
- * blob (little-endian u32 words unless noted):
- *   magic 0x53435a45 ("EZCS"), version 1, k, n_advice, n_fixed, n_instance, n_challenges, advice_phase[n_advice],
+ * blob (little-endian u32 words unless noted), version 2 (version 1 = the same without the fields marked [2]):
+ *   magic 0x53435a45 ("EZCS"), version, k, n_advice, n_fixed, n_instance, n_challenges, advice_phase[n_advice],
+ *   [2] blinding (halo2's cs.blinding_factors(); 0 = derive max(3, most queries of one advice column) + 2),
+ *   [2] minimum_degree (set by halo2's chunk_lookups; 0 = none), [2] n_unblinded, unblinded advice columns[n_unblinded]
+ *       (unusable rows hold Blind::default() = 1, /root/reference/src/circuit/modules/polycommit.rs:57-61),
+ *   [2] n_selectors (halo2 selectors behind the fixed columns: the size of the selector section of vk.key / pk.key, which the
+ *       files do not record -- halo2 re-runs configure, src/pfsys/mod.rs:627),
  *   n_nodes, nodes[n_nodes] of 48 B: {u32 op, u32 a, u32 b, u32 0, u8 constant[32] (Montgomery Fr)}
  *       op 0 CONST | 1 ADVICE(col a, rotation (i32) b) | 2 FIXED | 3 INSTANCE | 4 CHALLENGE(index a)
  *          | 5 NEG(node a) | 6 ADD(node a, node b) | 7 SUB | 8 MUL        (children precede parents)
  *   n_gates, gate_node[n_gates]                              -- the polynomials of ConstraintSystem::gates
  *   n_perm, {u32 kind (1 advice, 2 fixed, 3 instance), u32 col}[n_perm]   -- permutation::Argument columns, in order
  *   n_lookups, per lookup: n_inputs, per input {arity, node[arity]}, table {arity, node[arity]}   -- mv-lookup arguments
+ *   [2] has_queries; if set: advice, fixed, instance query lists {count, {col, rotation (i32)}[count]} in halo2's order of first
+ *       query (cs.advice_queries ...): the order of the evaluations in the proof (pinned on the reference's proof.json,
+ *       tests/test_ezkl_circuit.py).  Without it the queries are collected from the expressions and sorted.
+ * The keccak256 of the blob is bound into the vk digest (the role of halo2's vk.transcript_repr).
  */
 typedef struct ezkl_prover_cs* ezkl_cs_t;
 typedef struct ezkl_prover_pk* ezkl_pk_t;
@@ -76,6 +85,9 @@ int ezkl_prover_pk_free(ezkl_pk_t pk);
  * every element is checked to be a canonical residue; columns go straight to HBM. */
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len);
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out);
+/* Commit the key's resident fixed / permutation polynomials again under the SRS `g` (coefficient basis) and recompute the digest:
+ * a key file written under one SRS (the reference's tests/assets/pk.key: the public powers of tau) proved under another. */
+int ezkl_prover_pk_recommit(ezkl_pk_t pk, ezkl_bases_t g);
 /* verifying key: n_fixed + n_perm affine commitments (64 B Montgomery each) and the 32-byte transcript digest
  * (Montgomery Fr).  Any output pointer may be NULL. */
 int ezkl_prover_vk(ezkl_pk_t pk, void* fixed_commitments, void* permutation_commitments, void* digest);

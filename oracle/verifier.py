@@ -101,7 +101,7 @@ def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
         for e in tup[1:]:
             acc = (acc * theta + P.evaluate(e, q)) % R
         return acc
-    for (ins, tab), (m_e, phi_e, phi_n) in zip(cs.lookups, lk_ev):
+    for (ins, tab), (phi_e, phi_n, m_e) in zip(cs.lookups, lk_ev):
         fb = [(compress(t) + beta) % R for t in ins]
         tb = (compress(tab) + beta) % R
         prodf = 1
@@ -133,9 +133,9 @@ def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
     for j in range(cs.n_chunks):
         qs.append((("z", j), z_c[j], x, z_ev[j][0])); qs.append((("z", j), z_c[j], rot_point(1), z_ev[j][1]))
         if z_ev[j][2] is not None: qs.append((("z", j), z_c[j], rot_point(u), z_ev[j][2]))
-    for i, (m_e, phi_e, phi_n) in enumerate(lk_ev):
-        qs.append((("m", i), m_c[i], x, m_e))
+    for i, (phi_e, phi_n, m_e) in enumerate(lk_ev):
         qs.append((("phi", i), phi_c[i], x, phi_e)); qs.append((("phi", i), phi_c[i], rot_point(1), phi_n))
+        qs.append((("m", i), m_c[i], x, m_e))
     # ---- SHPLONK
     groups = P.group_queries(qs)
     ys = T.squeeze_challenge()

@@ -3,7 +3,8 @@
 
 Run in the build container only (needs /root/reference, which does not exist on the GPU box):
     python tests/golden/make_golden.py
-Outputs (committed): tests/golden/kzg_k6.srs, kzg_k1_public.srs, vk_k6.key, pk_k6_subset.npz
+Outputs (committed): tests/golden/kzg_k6.srs, kzg_k1_public.srs, vk_k6.key, pk_k6_subset.npz, pk_k6.key, proof_k6.json,
+                     settings_k6.json, witness_k6.json
 
 Sources (read-only, data not code): /root/reference/tests/assets/{kzg,kzg1.srs,vk.key,pk.key}.
 What they pin:
@@ -11,7 +12,10 @@ What they pin:
   * kzg1.srs (public k=1 SRS) : vk permutation commitments of identity sigma columns == delta^j * sG
   * pk.key                    : fixed_polys==iNTT_64(fixed_values); fixed_cosets==coeff_to_extended(polys);
                                 l0/l_last/l_active_row extended forms; permutation polys/cosets likewise
-pk.key is 1.4 MB, so only a subset of columns is kept (every stored column is kept whole).
+pk_k6_subset.npz keeps a few columns for the kernel KATs; pk_k6.key is the whole key (1.4 MB): the fixture CIRCUIT tests
+(tests/test_ezkl_circuit.py) load it as `ezkl prove` would and need every fixed / permutation column.
+  * proof.json / settings.json / witness.json : the proof the reference made for this key (layout 114 G1 | 231 Fr | 2 G1;
+    its fixed / sigma evaluations equal pk.key's polynomials at the challenge x recovered from the identity sigma columns)
 """
 import os, shutil, sys
 import numpy as np
@@ -23,6 +27,13 @@ A = "/root/reference/tests/assets/"
 shutil.copyfile(A + "kzg", os.path.join(HERE, "kzg_k6.srs"))
 shutil.copyfile(A + "kzg1.srs", os.path.join(HERE, "kzg_k1_public.srs"))
 shutil.copyfile(A + "vk.key", os.path.join(HERE, "vk_k6.key"))
+shutil.copyfile(A + "pk.key", os.path.join(HERE, "pk_k6.key"))
+shutil.copyfile(A + "settings.json", os.path.join(HERE, "settings_k6.json"))
+shutil.copyfile(A + "witness.json", os.path.join(HERE, "witness_k6.json"))
+import json
+_p = json.load(open(A + "proof.json"))
+_p["proof"] = []          # the byte list duplicates hex_proof
+json.dump(_p, open(os.path.join(HERE, "proof_k6.json"), "w"))
 pk = parse_pk(open(A + "pk.key", "rb").read(), n_perm=32, n_sel=80)
 u8 = lambda b: np.frombuffer(b, dtype=np.uint8)
 FIXED = [0, 1, 5, 17, 37]
