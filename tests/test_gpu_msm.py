@@ -402,3 +402,16 @@ def test_upload_commit_batch(hip):
     for pa in pinned:
         pa.free()
     bases.free()
+
+
+def test_c5_size_2_22_full_oracle_compare(hip):
+    """2^22 points (BASELINE configs[4]'s SRS size) against the oracle's Pippenger over ALL points, uniform and witness-shaped"""
+    from ezkl_amd import backend as B
+    n = 1 << 22
+    bases = B.Bases.generate(SEED + 2, n)
+    pts = bases.download()
+    s = rand_fr(np.random.default_rng(2222), n)
+    assert (B.msm_g1(bases, s) == ob.msm(s, pts)).all()
+    wl = witness_like(np.random.default_rng(6), n)
+    assert (B.msm_g1(bases, wl) == ob.msm(wl, pts)).all()
+    bases.free()

@@ -159,3 +159,33 @@ def test_extended_domain_size_2_25(hip):
         assert fe_to_int(f[j]) == want
     B.ntt_dev(ds.ptr, ek, d.omega_inv, inverse=True)
     assert (ds.to_numpy(shape=(ne, 4)) == sparse).all()
+
+
+def test_benchmark_size_2_22_full_oracle_compare(hip):
+    """BASELINE configs[1] size, byte-compared with the C oracle over the WHOLE output (about a second of OpenMP CPU work per
+    transform): forward 2^22, scaled inverse 2^22, coeff_to_extended 2^20 -> 2^22 and extended_to_coeff back"""
+    k = 22
+    n = 1 << k
+    rng = np.random.default_rng(2222)
+    a = rand_fr(rng, n)
+    d = hip.EvaluationDomain(2, k)
+    assert (hip.ntt(a, k, d.omega) == ob.fft(a, k, ob.omega(k))).all()
+    assert (d.lagrange_to_coeff(a) == ob.lagrange_to_coeff(a, k)).all()
+    d4 = hip.EvaluationDomain(5, 20)                       # degree 5 -> 4 n rows: ext_k = 22
+    assert d4.ext_k == 22
+    p = a[: 1 << 20]
+    ext = d4.coeff_to_extended(p)
+    assert (ext == ob.coeff_to_extended(p, 20, 22)).all()
+    assert (d4.extended_to_coeff(ext) == ob.extended_to_coeff(ext, 22)).all()
+
+
+def test_extended_2_24_full_oracle_compare(hip):
+    """the extended domain of a k = 22 circuit of degree 5 (2^22 -> 2^24), whole-output byte compare with the oracle"""
+    rng = np.random.default_rng(2424)
+    p = rand_fr(rng, 1 << 22)
+    d = hip.EvaluationDomain(5, 22)
+    assert d.ext_k == 24
+    ext = d.coeff_to_extended(p)
+    assert (ext == ob.coeff_to_extended(p, 22, 24)).all()
+    back = d.extended_to_coeff(ext)
+    assert (back[: 1 << 22] == p).all() and (back[1 << 22:] == 0).all()
