@@ -1578,6 +1578,14 @@ int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* ou
     if (!cs || !buf || !out) return EZKL_ERR_INVALID;
     return guarded([&] { *out = new ezkl_prover_pk{pk_read(*cs->cs, (const uint8_t*)buf, len)}; });
 }
+int ezkl_prover_pk_set_selectors(ezkl_pk_t pk, const void* bits, size_t len) {
+    return guarded([&] {
+        if (!pk || (!bits && len)) throw Error(EZKL_ERR_INVALID, "null handle");
+        const ConstraintSystem& cs = *pk->pk->cs;
+        if (len != (size_t)cs.n_selectors * ((cs.n + 7) / 8)) throw Error(EZKL_ERR_INVALID, "selector section of unexpected length");
+        pk->pk->selector_bits.assign((const uint8_t*)bits, (const uint8_t*)bits + len);
+    });
+}
 int ezkl_prover_pk_recommit(ezkl_pk_t pk, ezkl_bases_t g) {
     return guarded([&] {
         if (!pk || !g) throw Error(EZKL_ERR_INVALID, "null handle");

@@ -222,3 +222,256 @@ def ints_to_mont(colv):
     """list of n canonical ints -> (n, 4) u64 Montgomery array"""
     M = 1 << 256
     return np.frombuffer(b"".join((v * M % R).to_bytes(32, "little") for v in colv), np.uint64).reshape(len(colv), 4).copy()
+
+
+# =====================================================================================================================
+# Base-op layouts (src/circuit/ops/layouts.rs) over the three model VarTensors, with RegionCtx's single linear coordinate
+# =====================================================================================================================
+class BaseRegion(Region):
+    """RegionCtx (src/circuit/ops/region.rs) for BaseConfig's columns: `assign` writes a tensor at the linear coordinate of a
+    VarTensor (block, inner column, row = VarTensor::cartesian_coord), `increment` advances it; constants are assigned with a copy
+    constraint to ONE cell of the constant column per distinct value (first use) and to that first advice cell afterwards
+    (assigned_constants, src/tensor/var.rs assign_value); previously assigned values are copy-constrained to their cell."""
+
+    def __init__(self, gc, witness=True):
+        super().__init__(gc.cs, gc.settings.logrows)
+        self.gc, self.base, self.w = gc, gc.base, gc.settings.num_inner_cols
+        self.inputs, self.output = [gc.advices[0], gc.advices[1]], gc.advices[2]
+        self.linear = 0
+        self.witness = witness
+        self.first_const = {}                          # value -> first advice cell holding it
+        self.const_order = []                          # (value, advice cell) in order of first use: the floor planner's fixed cells
+
+    def cell_of(self, var, linear):
+        x, y, z = var.cartesian_coord(linear)
+        assert x < var.num_blocks(), "circuit does not fit: raise total_assignments"
+        return var.inner[x][y], z
+
+    def put(self, var, linear, val):
+        col, row = self.cell_of(var, linear)
+        cell = ("adv", col.index, row)
+        if self.witness:
+            self.column(col)[row] = val.v
+        if val.const:
+            first = self.first_const.get(val.v)
+            if first is None:
+                self.first_const[val.v] = cell
+                self.const_order.append((val.v, cell))
+            else:
+                self.copy(cell, first)
+        elif val.cell is not None:
+            self.copy(cell, val.cell)
+        return Val(val.v, cell)
+
+    def assign(self, var, vals, offset=None):
+        base = self.linear if offset is None else offset
+        return [self.put(var, base + t, v) for t, v in enumerate(vals)]
+
+    def increment(self, m): self.linear += m
+
+    def flush(self):
+        rem = self.linear % self.w
+        if rem:
+            self.linear += self.w - rem
+
+    def finish(self, const_cols):
+        """the floor planner's constants: one fixed cell per distinct constant, in order of first use, copied to its first advice cell"""
+        u = self.usable
+        for i, (v, cell) in enumerate(self.const_order):
+            col = const_cols[i // u]
+            self.column(col)[i % u] = v
+            self.copy(("fix", col.index, i % u), cell)
+
+    # ---- layouts.rs ------------------------------------------------------------------------------------------------
+    def pairwise(self, a, b, op):
+        """layouts.rs:2917-2990 (both operands already broadcast to one length)"""
+        assert len(a) == len(b)
+        ia, ib = self.assign(self.inputs[0], a), self.assign(self.inputs[1], b)
+        f = {EC.ADD: lambda x, y: x + y, EC.SUB: lambda x, y: x - y, EC.MULT: lambda x, y: x * y}[op]
+        out = self.assign(self.output, [Val(f(x.v, y.v)) for x, y in zip(ia, ib)])
+        for t in range(len(out)):
+            x, y, z = self.inputs[0].cartesian_coord(self.linear + t)
+            self.enable(self.base.selectors[(op, x, y)], z)
+        self.increment(len(out))
+        return out
+
+    def enforce_equality(self, a, b):
+        """layouts.rs:4959-4981"""
+        ia = self.assign(self.inputs[1], a)
+        ob = self.assign(self.output, b)
+        for x, y in zip(ia, ob):
+            self.copy(x.cell, y.cell)
+        self.increment(len(ob))
+        return ob
+
+    def range_check(self, vals, rng):
+        """layouts.rs:5024-5105: value into the first input VarTensor, its table-column index beside it in the second"""
+        rc = self.base.range_checks[tuple(rng)]
+        w = self.assign(self.inputs[0], vals)
+        def col_index(v):
+            s = v if v < R // 2 else v - R
+            return abs(s - rc.range[0]) // rc.col_size
+        self.assign(self.inputs[1], [Val(col_index(v.v)) for v in w])
+        for t in range(len(w)):
+            x, y, z = self.inputs[0].cartesian_coord(self.linear + t)
+            self.enable(self.base.range_selectors[(tuple(rng), x, y)], z)
+        self.increment(len(w))
+        return w
+
+    def _dup_inputs(self, var, vals):
+        """assign_with_duplication_unconstrained: at a block boundary one row of filler (copies of the last value) is inserted"""
+        bs, out, pos, used = var.block_size(), [], self.linear, 0
+        for v in vals:
+            out.append(self.put(var, pos, v))
+            pos += 1; used += 1
+            if pos % bs == 0:
+                for _ in range(self.w):
+                    self.put(var, pos, Val(v.v))
+                    pos += 1; used += 1
+        return out, used
+
+    def dot(self, a, b):
+        """layouts.rs:532-610: accumulated dot product, one row (w products) per step, DOTINIT then DOT with rotation -1"""
+        assert len(a) == len(b)
+        self.flush()
+        w = self.w
+        pad = (-len(a)) % w
+        a, b = list(a) + [Val(0, const=True)] * pad, list(b) + [Val(0, const=True)] * pad
+        ia, used = self._dup_inputs(self.inputs[0], a)
+        ib, _ = self._dup_inputs(self.inputs[1], b)
+        acc, pos, first, last = 0, self.linear, True, None
+        for s in range(0, len(ia), w):
+            acc = (acc + sum(x.v * y.v for x, y in zip(ia[s:s + w], ib[s:s + w]))) % R
+            x, _, z = self.output.cartesian_coord(pos)
+            if z == 0 and not first:                   # duplicate of the running sum at the top of a new column: no selector
+                dup = self.put(self.output, pos, Val(last.v))
+                self.copy(dup.cell, last.cell)
+                pos += w
+                x, _, z = self.output.cartesian_coord(pos)
+            last = self.put(self.output, pos, Val(acc))
+            self.enable(self.base.selectors[(EC.DOTINIT if first else EC.DOT, x, 0)], z)
+            first = False
+            pos += w
+        self.increment(used)
+        return last
+
+    def decompose(self, vals, base, legs):
+        """layouts.rs:6321-6423 (zero_sign_matters = false): hints [sign, digits..] on the output VarTensor, range checks, recomposition
+        by dot products with the base powers, multiplication by the sign, equality with the input"""
+        if any(v.cell is None and not v.const for v in vals):
+            vals = self.assign(self.inputs[0], vals)   # not yet assigned (model input / instance): placed without advancing
+        hints = []
+        for v in vals:
+            s = v.v if v.v < R // 2 else v.v - R
+            sg, mag = (s > 0) - (s < 0), abs(s)
+            digs = [(mag // base ** (legs - 1 - t)) % base for t in range(legs)]
+            assert mag < base ** legs, "value exceeds the decomposition range"
+            hints += [Val(sg)] + [Val(d) for d in digs]
+        claimed = self.assign(self.output, hints)
+        self.increment(len(claimed))
+        signs = [claimed[t] for t in range(0, len(claimed), legs + 1)]
+        rest = [claimed[t] for t in range(len(claimed)) if t % (legs + 1)]
+        signs = self.range_check(signs, (-1, 1))
+        rest = self.range_check(rest, (0, base - 1))
+        bases = [Val(base ** (legs - 1 - t), const=True) for t in range(legs)]
+        recomposed = [self.dot(rest[i * legs:(i + 1) * legs], bases) for i in range(len(vals))]
+        signed = self.pairwise(recomposed, signs, EC.MULT)
+        self.enforce_equality(vals, signed)
+        return claimed, vals
+
+    def equals_zero(self, vals):
+        """layouts.rs:3549-3580"""
+        inv = [Val(pow(v.v, -1, R) if v.v else 0) for v in vals]
+        prod = self.pairwise(vals, inv, EC.MULT)
+        out = self.pairwise([Val(1, const=True)] * len(vals), prod, EC.SUB)
+        check = self.pairwise(vals, out, EC.MULT)
+        self.enforce_equality(check, [Val(0, const=True)] * len(check))
+        return out
+
+    def relu(self, vals, base, legs):
+        """leaky_relu with alpha = 0 (layouts.rs:6457-6474): sign by decomposition, mask = (sign == 1), x * mask"""
+        claimed, vals = self.decompose(vals, base, legs)
+        sign = [claimed[t] for t in range(0, len(claimed), legs + 1)]
+        diff = self.pairwise(sign, [Val(1, const=True)] * len(sign), EC.SUB)
+        mask = self.equals_zero(diff)
+        return self.pairwise(vals, mask, EC.MULT)
+
+    def output_equals_instance(self, vals, inst_col, inst_offset, base, legs, decomp=True):
+        """layouts.rs:6740-6779 `output`: range check (decompose) the outputs and the instance cells, then equality"""
+        if decomp:
+            _, vals = self.decompose(vals, base, legs)
+        inst = []
+        for t, v in enumerate(vals):                   # assign_advice_from_instance: the advice copy is tied to the instance cell
+            inst.append(Val(v.v, ("inst", inst_col.index, inst_offset + t)))
+        if decomp:
+            inst = self.assign(self.inputs[0], inst)    # `!all_prev_assigned()`: an advice copy of the instance cells, placed without advancing
+            _, inst = self.decompose(inst, base, legs)
+        return self.enforce_equality(vals, inst)
+
+
+class MlpCircuit:
+    """`layers` x (Gemm + bias + ReLU) on one input vector, the op sequence of the reference's fixture model
+    (tests/assets/network.onnx: Gemm 3 -> 4 + ReLU) and of examples/onnx/large_mlp/gen.py:6-43 (9 x Linear(100, 100) + ReLU; with
+    batch 1 the einsum "mk,nk->mn" has one non-common index and is laid out with base ops, einsum/analysis.rs:165-184), private
+    input and parameters, public output, inputs / outputs range-checked by decomposition (src/graph/model.rs:1132-1258)."""
+
+    def __init__(self, logrows, num_inner_cols, weights, biases, decomp_base, decomp_legs, total_assignments=None, relu_last=True):
+        self.k, self.w = logrows, num_inner_cols
+        self.weights = [[[int(v) for v in row] for row in W] for W in weights]
+        self.biases = [[int(v) for v in b] for b in biases]
+        self.base, self.legs, self.relu_last = decomp_base, decomp_legs, relu_last
+        if total_assignments is None:                  # the dummy layout pass of gen-settings: count the cells
+            total_assignments = self._count_cells()
+        n_out = len(self.weights[-1])
+        # max_rows uses blinding factors = 5 (no gate queries 3+ rotations of a column)
+        self.settings = EC.GraphSettings(logrows, num_inner_cols, total_assignments, total_const_size=4,
+                                         required_range_checks=[(-1, 1), (0, decomp_base - 1)], model_instance_shapes=[[1, n_out]])
+        self.gc = EC.GraphConfig(self.settings)
+
+    def _count_cells(self):
+        w, lg = self.w, self.legs
+        def dec(m): return m * (lg + 1) + m + m * lg + m * (-(-lg // w) * w) + 2 * m
+        def al(c): return -(-c // w) * w
+        c = dec(len(self.weights[0][0]))
+        for i, W in enumerate(self.weights):
+            m, kk = len(W), len(W[0])
+            c = al(c) + m * al(kk) + m
+            if i + 1 < len(self.weights) or self.relu_last:
+                c += dec(m) + 6 * m
+        m = len(self.weights[-1])
+        return c + 2 * dec(m) + m + 64
+
+    def synthesize(self, x, witness=True):
+        reg = BaseRegion(self.gc, witness)
+        vals = [Val(int(v)) for v in x]
+        _, vals = reg.decompose(vals, self.base, self.legs)                     # input range check
+        for i, (W, b) in enumerate(zip(self.weights, self.biases)):
+            outs = [reg.dot(vals, [Val(wv) for wv in row]) for row in W]           # einsum_with_base_ops: one dot per output
+            vals = reg.pairwise(outs, [Val(bv) for bv in b], EC.ADD)
+            if i + 1 < len(self.weights) or self.relu_last:
+                vals = reg.relu(vals, self.base, self.legs)
+        reg.output_equals_instance(vals, self.gc.instance, 0, self.base, self.legs)
+        reg.finish(self.gc.const_cols)
+        self.outputs = [v.v for v in vals]
+        return reg
+
+    def keygen_inputs(self, x):
+        """-> (plonk.ConstraintSystem, fixed columns (lists of ints), copies over cs.perm positions, region)"""
+        reg = self.synthesize(x, witness=False)
+        n = 1 << self.k
+        cs0 = self.gc.cs
+        sel_cols = cs0.compress_selectors(reg.selector_rows())
+        cs = cs0.to_plonk(self.k)
+        tabs = self.gc.table_columns()
+        n_pre = cs.n_fixed - len(sel_cols)
+        fixed = [tabs.get(c) or reg.fixed.get(c) or [0] * n for c in range(n_pre)] + sel_cols
+        pos = {kc: i for i, kc in enumerate(cs.perm)}
+        copies = [((pos[(a[0], a[1])], a[2]), (pos[(b[0], b[1])], b[2])) for a, b in reg.copies]
+        return cs, fixed, copies, reg
+
+    def witness(self, x):
+        """advice columns (lists of ints) and the instance column"""
+        reg = self.synthesize(x, witness=True)
+        n = 1 << self.k
+        adv = [reg.advice.get(c.index) or [0] * n for c in self.gc.cs.advice]
+        return adv, [self.outputs]

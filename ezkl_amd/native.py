@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_sweep_gather",
-           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_recommit", "ezkl_prover_vk",
+           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -152,6 +152,11 @@ class NativeProvingKey:
         if recommit is not None:
             _check(load().ezkl_prover_pk_recommit(self.h, recommit.h), "ezkl_prover_pk_recommit")
         return self
+
+    def set_selectors(self, activations):
+        """activations: (n_selectors, n) booleans -> the selector section of the key file"""
+        bits = np.packbits(np.asarray(activations, bool), axis=1, bitorder="little").tobytes()
+        _check(load().ezkl_prover_pk_set_selectors(self.h, bits, C.c_size_t(len(bits))), "ezkl_prover_pk_set_selectors")
 
     def to_bytes(self):
         """the key in halo2's raw-bytes pk.key layout (save_pk)"""

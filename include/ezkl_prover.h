@@ -85,6 +85,9 @@ int ezkl_prover_pk_free(ezkl_pk_t pk);
  * every element is checked to be a canonical residue; columns go straight to HBM. */
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len);
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out);
+/* The selector activations of the circuit (n_selectors rows of 2^k bits, bit-packed little-endian as in halo2's vk files): what
+ * keygen's caller learned from synthesis; only carried into ezkl_prover_pk_write so that the key file is complete. */
+int ezkl_prover_pk_set_selectors(ezkl_pk_t pk, const void* bits, size_t len);
 /* Commit the key's resident fixed / permutation polynomials again under the SRS `g` (coefficient basis) and recompute the digest:
  * a key file written under one SRS (the reference's tests/assets/pk.key: the public powers of tau) proved under another. */
 int ezkl_prover_pk_recommit(ezkl_pk_t pk, ezkl_bases_t g);

@@ -188,3 +188,57 @@ def test_gpu_native_prover_on_the_reference_pk_file(hip, fx):
     proof_c = P.create_proof(pk_c, cpu, FX.mont_cols(adv), rng_a, instances=inst)
     proof_n = NV.create_proof(pk2, bg, bgl, FX.mont_cols(adv), rng=rng_b, instances=inst)
     assert proof_n == proof_c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `ezkl setup` parity: the layout engine (ezkl_amd/ezkl_layout.py), run on the fixture MODEL, reproduces the reference's key
+# ---------------------------------------------------------------------------------------------------------------------
+FIXTURE_W = [[0, -1, 0], [0, -1, 0], [0, 0, -1], [0, 0, 0]]       # round(dense.weight) of tests/assets/network.onnx at scale 0
+FIXTURE_B = [0, 1, 0, 0]
+
+
+def fixture_mlp():
+    from ezkl_amd import ezkl_layout as EL
+    st = json.load(open(os.path.join(FX.G, "settings_k6.json")))
+    ra = st["run_args"]
+    return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], [FIXTURE_W], [FIXTURE_B], ra["decomp_base"], ra["decomp_legs"],
+                         total_assignments=st["total_assignments"])
+
+
+def test_layout_engine_reproduces_the_reference_key(fx, golden_srs):
+    """selector activations == vk.key's 80 x 64 bits; all 38 fixed columns (constants, tables, compressed selectors) and all 32
+    permutation columns == pk.key's `fixed_values` / `permutations`, bit for bit; the witness == the one read off the key"""
+    from oracle.cpu_backend import OracleBackend
+    c = fixture_mlp()
+    cs, fixed, copies, reg = c.keygen_inputs([2, 1, 1])
+    assert (np.array(reg.selector_rows()) == fx["pk"]["vk"]["selectors"]).all()
+    assert reg.linear == 198
+    assert fixed == fx["fixed"]
+    be = OracleBackend(golden_srs["g"], golden_srs["g_lagrange"], FX.K)
+    pk, vk = P.keygen(cs, be, FX.mont_cols(fixed), copies)
+    for j in range(32):
+        assert (np.asarray(be.download(pk.sigma_values[j], cs.n)) == fx["pk"]["permutations"][j]).all(), "sigma column %d" % j
+    adv, inst = c.witness([2, 1, 1])
+    adv_ref, inst_ref, _ = FX.witness(fx)
+    assert adv == adv_ref and inst == inst_ref
+    assert MP.check(cs, adv, fixed, inst, copies) == []
+    # the serialised constraint system is the fixture's, byte for byte (same gates, lookups, query order)
+    assert P.serialize_cs(cs) == P.serialize_cs(fx["cs"])
+
+
+@pytest.mark.gpu
+def test_gpu_setup_reproduces_reference_pk_file(hip, fx, golden_srs):
+    """keygen on the GPU from the MODEL (layout engine -> fixed columns + copy constraints), written in halo2's pk.key layout:
+    equal to the reference's tests/assets/pk.key byte for byte outside the 70 SRS-dependent commitments (the reference used the
+    public powers of tau, which are not in the tree)."""
+    from ezkl_amd import backend as B, native as NV
+    c = fixture_mlp()
+    cs, fixed, copies, reg = c.keygen_inputs([2, 1, 1])
+    bg = B.Bases(golden_srs["g"])
+    pk = NV.NativeProvingKey(NV.NativeCircuit(cs), bg, FX.mont_cols(fixed), copies)
+    pk.set_selectors(reg.selector_rows())
+    mine = pk.to_bytes()
+    ref = open(os.path.join(FX.G, "pk_k6.key"), "rb").read()
+    assert len(mine) == len(ref) == 1489595
+    lo, hi = 7, 7 + 64 * (38 + 32)
+    assert mine[:lo] == ref[:lo] and mine[hi:] == ref[hi:]
