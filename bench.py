@@ -202,26 +202,44 @@ def main():
 
 
 def prove_leg():
-    """End-to-end `prove` of a k = 20 matmul + ReLU-lookup circuit (tools/prove_bench.py) in a CHILD process, so that
-    the per-kernel averages rocprofv3 reports for this process stay those of the timed MSM / NTT regions.  Part of the
-    checker leg: the child verifies the proof with the oracle's pairing verifier and times the C oracle's MSM / NTT
-    kernels at the proof's call counts."""
+    """End-to-end `prove` of ezkl circuits (tools/prove_bench.py, tools/bench_circuits.py) in CHILD processes, so that the per-kernel
+    averages rocprofv3 reports for this process stay those of the timed MSM / NTT regions.  Part of the checker leg: each child
+    verifies its proof with the oracle's pairing verifier.
+      * `einsum`: the reference's own criterion bench circuit benches/accum_einsum_matmul.rs raised to k = 20 (BASELINE configs[3]):
+        warm prove, the COLD one-shot prove (fresh process, SRS + pk files -> HBM -> proof.json), and the same create_proof on the host
+        cores (C oracle kernels, OpenMP) with identical proof bytes;
+      * `mlp`: an MLP over the ezkl gate set (range-check lookups, permutation over ~20 columns) at k = 17 (BASELINE configs[2]'s size),
+        GPU and CPU."""
     import subprocess
-    env = dict(os.environ, K="20", BLOCKS="4")
+    tool = os.path.join(ROOT, "tools", "prove_bench.py")
+    def child(env_extra, flags, timeout):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, tool] + flags, env=env, capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            raise RuntimeError(r.stderr[-300:])
+        return json.loads(lines[-1])
+    out = {}
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py"), "--cpu-kernels", "--native", "--pinned"], env=env,
-                           capture_output=True, text=True, timeout=600)
-        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        nv = j.get("native_prover", {})
-        return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
-                "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "host": "libezkl_prover.so (C++); witness columns in page-locked host memory, uploads overlapped with the commits; ChaCha20 randomness expanded on the device",
-                "prove_seconds_gpu_python_host": j["prove_seconds_gpu"], "native_proof_identical_to_python_host": nv.get("proof_identical_to_python_prover"),
-                "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
-                "breakdown_seconds": nv.get("breakdown_seconds_library_rng"),
-                "cpu_msm_plus_ntt_seconds_at_call_counts": j["cpu_kernel_sample"]["msm_plus_ntt_seconds_at_call_counts"],
-                "cpu_threads": j["cpu_kernel_sample"]["threads"]}
+        k_e = os.environ.get("EZKL_BENCH_EINSUM_K", "20")
+        j = child({"CIRCUIT": "einsum", "K": k_e}, ["--cold", "--cpu"], 900)
+        out = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
+               "cold_seconds": (j.get("cold") or {}).get("cold_seconds"), "cold": j.get("cold"),
+               "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "cpu_prover": j.get("cpu_prover"),
+               "proofs_identical_gpu_cpu": j.get("proofs_identical"), "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds"),
+               "host": "libezkl_prover.so (C++) over the C ABI; ChaCha20 randomness expanded on the device", "verifier_accepts": j["verifier_accepts"],
+               "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"]}
     except Exception as e:          # the headline line must still be printed
-        return {"error": repr(e)[:200]}
+        out = {"error": repr(e)[:300]}
+    try:
+        k_m = os.environ.get("EZKL_BENCH_MLP_K", "17")
+        j = child({"CIRCUIT": "mlp", "K": k_m}, ["--cpu", "--pinned"], 900)
+        out["mlp"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
+                      "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
+                      "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "breakdown_seconds": j["prove_breakdown_seconds"]}
+    except Exception as e:
+        out["mlp"] = {"error": repr(e)[:300]}
+    return out
 
 
 def prove_leg_multi(world, rank, local_rank, args):

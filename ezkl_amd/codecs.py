@@ -169,3 +169,32 @@ def split_evm_proof(proof, n_commitments, n_evals):
     tail = [(int.from_bytes(proof[off + 64 * i: off + 64 * i + 32], "big"), int.from_bytes(proof[off + 64 * i + 32: off + 64 * i + 64], "big"))
             for i in range((len(proof) - off) // 64)]
     return pts, ev, tail
+
+
+def write_proof_json(proof, instances, pretty_public_inputs=None, timestamp_ms=None, version="ezkl_amd"):
+    """`Snark::save` (src/pfsys/mod.rs:198-230, 291-298): serde_json of the Snark struct, compact, fields in declaration order --
+    protocol (None for a plain proof), instances as 32-byte little-endian hex felts, the proof as a byte list AND as "0x.." hex
+    (create_hex_proof, :285-289), split, pretty_public_inputs, timestamp (ms), version."""
+    import time
+    j = {"protocol": None,
+         "instances": [[felt_to_hex_le(v) for v in col] for col in instances],
+         "proof": list(proof),
+         "hex_proof": "0x" + bytes(proof).hex(),
+         "split": None,
+         "pretty_public_inputs": pretty_public_inputs,
+         "timestamp": int(time.time() * 1000) if timestamp_ms is None else timestamp_ms,
+         "version": version}
+    return json.dumps(j, separators=(",", ":"))
+
+
+def read_witness_json(text):
+    """GraphWitness (src/graph/mod.rs:120-141, loaded by `prove` at src/execute.rs:1584): inputs / outputs as 32-byte little-endian
+    hex felts, the optional processed_* module results, and the lookup statistics -> ints"""
+    j = json.loads(text)
+    def felts(t): return [[felt_from_hex_le(h) for h in col] for col in (t or [])]
+    out = dict(inputs=felts(j.get("inputs")), outputs=felts(j.get("outputs")), raw=j)
+    for key in ("processed_inputs", "processed_params", "processed_outputs"):
+        out[key] = j.get(key)
+    for key in ("max_lookup_inputs", "min_lookup_inputs", "max_range_size"):
+        out[key] = j.get(key)
+    return out

@@ -32,7 +32,7 @@ class Region:
         self.usable = self.n - cs.blinding_factors() - 1
         self.advice = {}                               # advice column index -> list of n ints
         self.fixed = {}
-        self.activations = [set() for _ in cs.selectors]
+        self.activations = [None] * len(cs.selectors)   # per selector: numpy bool rows, allocated on first use
         self.copies = []                               # ((kind, col, row), (kind, col, row))
         self.coord = 0                                 # einsum_col_coord
         self.const_cells = {}                          # value -> (fixed col, row)
@@ -46,7 +46,10 @@ class Region:
 
     def enable(self, selector, row):
         assert row < self.usable
-        self.activations[selector.index].add(row)
+        a = self.activations[selector.index]
+        if a is None:
+            a = self.activations[selector.index] = np.zeros(self.n, bool)
+        a[row] = True
 
     def copy(self, a, b):
         if a != b:
@@ -63,14 +66,9 @@ class Region:
             self.const_cells[value] = ("fix", col.index, row)
         return self.const_cells[value]
 
-    def selector_rows(self):
-        out = []
-        for rows in self.activations:
-            a = [False] * self.n
-            for r in rows:
-                a[r] = True
-            out.append(a)
-        return out
+    def selector_rows(self, dense=True):
+        """one boolean row-vector per selector (None for a selector that is never on, unless dense)"""
+        return [np.zeros(self.n, bool) if (a is None and dense) else a for a in self.activations]
 
 
 class Val:
@@ -200,10 +198,12 @@ class EinsumMatmulCircuit:
         """-> (plonk.ConstraintSystem, fixed columns (ints), copies over cs.perm positions, rows used)"""
         region = self.synthesize(a, b)
         n = 1 << self.k
-        sel_cols = self.cs.compress_selectors(region.selector_rows())
+        sel_cols = self.cs.compress_selectors(region.selector_rows(dense=False))
+        if n <= 1 << 12:                               # small circuits: plain ints (MockProver); large: numpy (ints_to_limbs is vectorised)
+            sel_cols = [c.tolist() for c in sel_cols]
         cs = self.cs.to_plonk(self.k)
         n_pre = cs.n_fixed - len(sel_cols)
-        fixed = [region.fixed.get(c, [0] * n) for c in range(n_pre)] + sel_cols
+        fixed = [region.fixed.get(c, [0] * n) for c in range(n_pre)] + list(sel_cols)
         pos = {kc: i for i, kc in enumerate(cs.perm)}
         copies = [((pos[(x[0], x[1])], x[2]), (pos[(y[0], y[1])], y[2])) for x, y in region.copies]
         return cs, fixed, copies, region.coord
@@ -219,9 +219,58 @@ class EinsumMatmulCircuit:
 
 
 def ints_to_mont(colv):
-    """list of n canonical ints -> (n, 4) u64 Montgomery array"""
+    """list of n canonical ints -> (n, 4) u64 Montgomery array (plain Python: small columns / tests)"""
+    if isinstance(colv, np.ndarray):
+        colv = colv.tolist()
     M = 1 << 256
-    return np.frombuffer(b"".join((v * M % R).to_bytes(32, "little") for v in colv), np.uint64).reshape(len(colv), 4).copy()
+    return np.frombuffer(b"".join((int(v) % R * M % R).to_bytes(32, "little") for v in colv), np.uint64).reshape(len(colv), 4).copy()
+
+
+_R_LIMBS = np.array([(R >> (64 * i)) & 0xffffffffffffffff for i in range(4)], np.uint64)
+
+
+def ints_to_limbs(colv):
+    """n field elements (ints mod r, or a numpy array of small signed ints) -> (n, 4) u64 CANONICAL limbs, vectorised for what
+    witness columns mostly hold: small values and negated small values (integer_rep_to_felt, src/fieldutils.rs:9-17)"""
+    n = len(colv)
+    out = np.zeros((n, 4), np.uint64)
+    if isinstance(colv, np.ndarray) and colv.dtype != object:
+        v = colv.astype(np.int64)
+        small, mag = v >= 0, np.abs(v).astype(np.uint64)
+        out[small, 0] = mag[small]
+        neg = ~small
+    else:
+        arr = np.asarray(colv, dtype=object)
+        small = arr < (1 << 62)
+        out[small, 0] = arr[small].astype(np.uint64)
+        rest = np.nonzero(~small)[0]
+        negv = R - arr[rest]                               # object arithmetic: negated small values become small again
+        isneg = negv < (1 << 62)
+        full = rest[~isneg]
+        if len(full):
+            out[full] = np.frombuffer(b"".join(int(arr[i]).to_bytes(32, "little") for i in full), np.uint64).reshape(len(full), 4)
+        neg = np.zeros(n, bool)
+        neg[rest[isneg]] = True
+        mag = np.zeros(n, np.uint64)
+        mag[rest[isneg]] = negv[isneg].astype(np.uint64)
+    if neg.any():                                          # r - m with m < 2^62 < r's lowest limb: no borrow leaves limb 0
+        out[neg] = _R_LIMBS
+        out[neg, 0] = _R_LIMBS[0] - mag[neg]
+    return out
+
+
+def cols_to_mont(cols, gpu=None):
+    """columns of field elements -> (n, 4) u64 Montgomery arrays.  With gpu = ezkl_amd.backend the canonical limbs are multiplied
+    by R^2 on the device (one Montgomery product per element); without, element by element in Python."""
+    if gpu is None:
+        return [ints_to_mont(c) for c in cols]
+    r2 = P.to_mont((1 << 256) % R)
+    out = []
+    for c in cols:
+        buf = gpu.DeviceBuffer.from_numpy(ints_to_limbs(c))
+        gpu.vec_scale(buf.ptr, r2, buf.ptr, len(c))
+        out.append(buf.to_numpy(shape=(len(c), 4)).copy())
+    return out
 
 
 # =====================================================================================================================
@@ -460,11 +509,13 @@ class MlpCircuit:
         reg = self.synthesize(x, witness=False)
         n = 1 << self.k
         cs0 = self.gc.cs
-        sel_cols = cs0.compress_selectors(reg.selector_rows())
+        sel_cols = cs0.compress_selectors(reg.selector_rows(dense=False))
+        if n <= 1 << 12:
+            sel_cols = [c.tolist() for c in sel_cols]
         cs = cs0.to_plonk(self.k)
         tabs = self.gc.table_columns()
         n_pre = cs.n_fixed - len(sel_cols)
-        fixed = [tabs.get(c) or reg.fixed.get(c) or [0] * n for c in range(n_pre)] + sel_cols
+        fixed = [tabs.get(c) or reg.fixed.get(c) or [0] * n for c in range(n_pre)] + list(sel_cols)
         pos = {kc: i for i, kc in enumerate(cs.perm)}
         copies = [((pos[(a[0], a[1])], a[2]), (pos[(b[0], b[1])], b[2])) for a, b in reg.copies]
         return cs, fixed, copies, reg

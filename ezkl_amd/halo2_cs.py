@@ -281,10 +281,14 @@ class ConstraintSystem:
 
     # ---- selectors -> fixed columns (keygen)
     def compress_selectors(self, activations):
-        """activations: one boolean row-vector per selector.  Returns the fixed-column assignments (lists of small ints, one
-        per NEW fixed column, in allocation order); gates and lookups are rewritten in place."""
+        """activations: one boolean row-vector per selector (list / numpy array; None = never enabled).  Returns the fixed-column
+        assignments (numpy int64 arrays of small integers, one per NEW fixed column, in allocation order); gates and lookups are
+        rewritten in place."""
+        import numpy as np
         assert len(activations) == len(self.selectors)
         nsel = len(self.selectors)
+        n = next((len(a) for a in activations if a is not None), 0)
+        act = [None if a is None else np.asarray(a, dtype=bool) for a in activations]
         degrees = [0] * nsel
         for g in self.gates:
             for p in g.polys:
@@ -293,7 +297,6 @@ class ConstraintSystem:
                 for s in ss:
                     degrees[s] = max(degrees[s], degree(p))
         max_degree = self.degree()
-        n = len(activations[0]) if nsel else 0
         meta = VirtualCells(self)
         new_cols, repl, smap = [], [None] * nsel, [None] * nsel
 
@@ -305,11 +308,10 @@ class ConstraintSystem:
         for i in range(nsel):                          # complex selectors and selectors of no gate: a column of their own
             if degrees[i] == 0:
                 col, q = alloc()
-                new_cols.append([1 if b else 0 for b in activations[i]])
+                new_cols.append(np.zeros(n, np.int64) if act[i] is None else act[i].astype(np.int64))
                 repl[i], smap[i] = q, col.index
             else:
                 rest.append(i)
-        act = {i: frozenset(r for r in range(n) if activations[i][r]) for i in rest}
         added = set()
         for pos, i in enumerate(rest):
             if i in added:
@@ -318,10 +320,13 @@ class ConstraintSystem:
             assert degrees[i] <= max_degree
             d = degrees[i] - 1
             combo = [i]
+            union = None if act[i] is None else act[i].copy()     # rows where some selector of the combination is on
             for j in rest[pos + 1:]:
                 if d + len(combo) == max_degree:
                     break
-                if j in added or any(act[j] & act[c] for c in combo):
+                if j in added:
+                    continue
+                if union is not None and act[j] is not None and (union & act[j]).any():
                     continue
                 nd = max(d, degrees[j] - 1)
                 if nd + len(combo) + 1 > max_degree:
@@ -329,16 +334,18 @@ class ConstraintSystem:
                 d = nd
                 combo.append(j)
                 added.add(j)
+                if act[j] is not None:
+                    union = act[j].copy() if union is None else (union | act[j])
             col, q = alloc()
-            assign = [0] * n
+            assign = np.zeros(n, np.int64)
             for root, s in enumerate(combo, start=1):
                 e = q
                 for other in range(1, len(combo) + 1):
                     if other != root:
                         e = e * (P.const(other) - q)
                 repl[s], smap[s] = e, col.index
-                for r in act[s]:
-                    assign[r] = root
+                if act[s] is not None:
+                    assign[act[s]] = root
             new_cols.append(assign)
         self.selector_map = smap
         self._replace_selectors(repl)
@@ -351,7 +358,7 @@ class ConstraintSystem:
             col = self.fixed_column()
             repl.append(meta.query_fixed(col, CUR))
             smap.append(col.index)
-            cols.append([1 if b else 0 for b in activations[i]])
+            cols.append([0] * 0 if activations[i] is None else [1 if b else 0 for b in activations[i]])
         self.selector_map = smap
         self._replace_selectors(repl)
         return cols

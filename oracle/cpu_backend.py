@@ -40,38 +40,46 @@ class OracleBackend:
         h[:m] = ob.vec_op("sub", h[:m], np.stack([to_mont(c) for c in coeffs]))
     def scale(self, h, s, n): h[:n] = ob.vec_scale(h[:n], to_mont(s))
     def omega_powers(self): return None
+    def _omega_col(self):
+        if getattr(self, "_wcol", None) is None:
+            w = pow(ROOT, 1 << (28 - self.k), R)
+            self._wcol = ob.prefix_scan(np.tile(to_mont(w), (self.n, 1)), "mul", exclusive=True)       # omega^i
+        return self._wcol
+
     def permutation_product(self, value_cols, sigma_cols, beta, gamma, first_index, z0, omega_col):
-        n, w = self.n, pow(ROOT, 1 << (28 - self.k), R)
-        V = [[from_mont(x) for x in c] for c in value_cols]
-        S = [[from_mont(x) for x in c] for c in sigma_cols]
-        num, den = np.empty((n, 4), np.uint64), np.empty((n, 4), np.uint64)
-        wi = 1
-        for i in range(n):
-            a = b = 1
-            for j in range(len(V)):
-                a = a * (V[j][i] + beta * pow(DELTA, first_index + j, R) % R * wi + gamma) % R
-                b = b * (V[j][i] + beta * S[j][i] + gamma) % R
-            num[i], den[i] = to_mont(a), to_mont(b)
-            wi = wi * w % R
+        """z[i] = prod_{r<i} prod_j (v_j + beta delta^j omega^r + gamma) / (v_j + beta sigma_j + gamma), all O(n) steps in the C oracle"""
+        n = self.n
+        wcol, gcol = self._omega_col(), np.tile(to_mont(gamma), (n, 1))
+        num = den = None
+        for j in range(len(value_cols)):
+            v = ob.vec_op("add", value_cols[j][:n], gcol)
+            a = ob.vec_op("add", v, ob.vec_scale(wcol, to_mont(beta * pow(DELTA, first_index + j, R) % R)))
+            b = ob.vec_op("add", v, ob.vec_scale(sigma_cols[j][:n], to_mont(beta)))
+            num = a if num is None else ob.vec_op("mul", num, a)
+            den = b if den is None else ob.vec_op("mul", den, b)
         ratio = ob.vec_op("mul", num, ob.batch_invert(den))
         z = ob.prefix_scan(ratio, "mul", exclusive=True)
         if z0 is not None:
             z = ob.vec_scale(z, to_mont(z0))
         return z
     def lookup_multiplicity(self, inputs, table, usable):
-        first = {}
-        for i in range(usable):
-            first.setdefault(table[i].tobytes(), i)
-        m = np.zeros((self.n, 4), np.uint64)
-        cnt, missing = {}, 0
+        """m[first row holding t] = number of input cells equal to t (rows compared as 32-byte strings, numpy sort / search)"""
+        tv = np.ascontiguousarray(table[:usable]).view("V32").reshape(-1)
+        uniq, first = np.unique(tv, return_index=True)
+        m = np.zeros(self.n, np.int64)
+        missing = 0
         for x in inputs:
-            for r in range(usable):
-                idx = first.get(x[r].tobytes())
-                if idx is None: missing += 1
-                else: cnt[idx] = cnt.get(idx, 0) + 1
-        for idx, c in cnt.items():
-            m[idx] = to_mont(c)
-        return m, missing
+            xv = np.ascontiguousarray(x[:usable]).view("V32").reshape(-1)
+            pos = np.searchsorted(uniq, xv)
+            pos[pos >= len(uniq)] = 0
+            hit = uniq[pos] == xv
+            missing += int((~hit).sum())
+            np.add.at(m, first[pos[hit]], 1)
+        out = np.zeros((self.n, 4), np.uint64)
+        nz = np.nonzero(m)[0]
+        for i in nz:
+            out[i] = to_mont(int(m[i]))
+        return out, missing
     def lookup_grand_sum(self, inputs, table, m, beta):
         n = self.n
         b = to_mont(beta)

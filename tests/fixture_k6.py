@@ -32,7 +32,7 @@ def load():
     gc = EC.GraphConfig(st)
     pk = codecs.read_pk(open(os.path.join(G, "pk_k6.key"), "rb").read(), N_PERM, N_SEL)
     pre = dict(n_fixed=len(gc.cs.fixed), n_selectors=len(gc.cs.selectors), n_lookups=len(gc.cs.lookups), degree=gc.cs.degree())
-    sel_cols = gc.cs.compress_selectors([list(map(bool, a)) for a in pk["vk"]["selectors"]])
+    sel_cols = [c.tolist() for c in gc.cs.compress_selectors(list(pk["vk"]["selectors"]))]
     cs = gc.cs.to_plonk(K)
     return dict(gc=gc, cs=cs, pk=pk, pre=pre, selector_columns=sel_cols, table_columns=gc.table_columns(),
                 fixed=[col_ints(p) for p in pk["fixed_values"]])

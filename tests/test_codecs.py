@@ -67,3 +67,20 @@ def test_reference_pk_and_proof_files():
 def test_felt_hex():
     assert codecs.felt_from_hex_le("02" + "00" * 31) == 2
     assert codecs.felt_to_hex_le(2) == "02" + "00" * 31
+
+
+def test_snark_json_round_trip_and_witness_reader():
+    """Snark JSON writer against the reference's proof.json (same instances encoding, hex_proof == 0x + hex(proof)); witness.json reader"""
+    import json, os
+    from ezkl_amd import codecs
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = codecs.read_proof_json(open(os.path.join(G, "proof_k6.json")).read())
+    text = codecs.write_proof_json(ref["proof"], ref["instances"], pretty_public_inputs=ref["raw"]["pretty_public_inputs"], timestamp_ms=ref["raw"]["timestamp"])
+    j = json.loads(text)
+    assert list(j) == ["protocol", "instances", "proof", "hex_proof", "split", "pretty_public_inputs", "timestamp", "version"]   # Snark's field order
+    assert j["hex_proof"] == ref["raw"]["hex_proof"] and j["instances"] == ref["raw"]["instances"] and j["protocol"] is None
+    assert bytes(j["proof"]) == ref["proof"] and ", " not in text
+    back = codecs.read_proof_json(text)
+    assert back["proof"] == ref["proof"] and back["instances"] == ref["instances"]
+    w = codecs.read_witness_json(open(os.path.join(G, "witness_k6.json")).read())
+    assert w["inputs"] == [[2, 1, 1]] and w["outputs"] == [[0, 0, 0, 0]] and w["max_range_size"] == 127

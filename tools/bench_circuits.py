@@ -1,0 +1,68 @@
+"""The ezkl circuits the end-to-end prove benchmarks run (built by ezkl_amd/ezkl_circuit.py + ezkl_layout.py):
+
+  einsum : the reference's own criterion bench circuit /root/reference/benches/accum_einsum_matmul.rs ("ij,jk->ik" through
+           configure_einsums: Freivalds' argument, 3 first-phase + 3 second-phase advice columns, 2 challenges), raised from its
+           k = 16 / len 128 to k = 20 / len 512 (BASELINE configs[3]: reduction_length 787 456 of the 1 048 570 usable rows)
+  mlp    : `layers` x (Gemm N x N + bias + ReLU) on one input vector, the op family of the reference's fixture model and of
+           examples/onnx/large_mlp (gen.py:6-43), private input / parameters, public output, decomposition range checks
+           (base 16384, 2 legs = ezkl's defaults, src/lib.rs:257-260): BaseConfig gates + range-check lookups + permutation
+"""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from ezkl_amd import ezkl_layout as EL, plonk as P      # noqa: E402
+
+
+def sparse_weights(rng, n_out, n_in, nnz=4):
+    """mostly-zero +-1 weights: activations stay far inside the 2-leg decomposition range through many layers (ezkl would rescale
+    between layers; the zero weights are still private advice cells, so the circuit is as large as with dense weights)"""
+    W = np.zeros((n_out, n_in), np.int64)
+    for i in range(n_out):
+        idx = rng.choice(n_in, min(nnz, n_in), replace=False)
+        W[i, idx] = rng.choice([-1, 1], len(idx))
+    return W.tolist()
+
+
+def build(kind, k, gpu=None, seed=1, **kw):
+    """-> dict(cs, fixed (Montgomery arrays), copies, advice (list of arrays, or callable(phase, challenges)), instances, info)"""
+    rng = np.random.default_rng(seed)
+    if kind == "einsum":
+        L = kw.get("length") or {20: 512, 19: 360, 18: 256, 17: 180, 16: 128, 15: 90, 14: 64, 12: 30, 10: 14, 8: 6, 6: 3}[k]
+        c = EL.EinsumMatmulCircuit(k, L)
+        a, b = rng.integers(-128, 128, (L, L)), rng.integers(-128, 128, (L, L))
+        cs, fixed, copies, rows = c.keygen_inputs(a, b)
+        fn = c.advice_fn(a, b, cs.n_advice)
+        cache = {}
+        def advice(phase, chal):
+            key = (phase, tuple(chal))
+            if key not in cache:
+                cols = fn(phase, chal)
+                idx = sorted(cols)
+                cache[key] = dict(zip(idx, EL.cols_to_mont([cols[i] for i in idx], gpu)))
+            return cache[key]
+        info = dict(circuit="accum_einsum_matmul (benches/accum_einsum_matmul.rs) ij,jk->ik len %d, Freivalds, k=%d" % (L, k), rows_used=rows)
+        return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=advice, instances=[], info=info)
+    if kind == "mlp":
+        layers, N = kw.get("layers", 9), kw.get("width")
+        if N is None:                                  # fill about 1.9 blocks of 2 x (2^k - 6) cells
+            N = int(((1.9 * 2 * ((1 << k) - 6)) / layers) ** 0.5)
+        Ws = [sparse_weights(rng, N, N) for _ in range(layers)]
+        bs = [rng.integers(-20, 20, N).tolist() for _ in range(layers)]
+        x = rng.integers(-60, 60, N).tolist()
+        c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2)
+        cs, fixed, copies, reg = c.keygen_inputs(x)
+        adv, inst = c.witness(x)
+        info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),
+                    cells_used=reg.linear, blocks=c.gc.advices[0].num_blocks(), range_checks=[list(r) for r in c.settings.required_range_checks])
+        return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
+    raise ValueError(kind)
+
+
+def describe(cs):
+    return dict(k=cs.k, advice_columns=cs.n_advice, fixed_columns=cs.n_fixed, instance_columns=cs.n_instance, selectors=cs.n_selectors,
+                gates=len(cs.gates), lookups=len(cs.lookups), permutation_columns=len(cs.perm), degree=cs.degree, ext_k=cs.ext_k,
+                second_phase_advice=sum(cs.advice_phase), challenges=cs.n_challenges, advice_queries=len(cs.advice_queries),
+                fixed_queries=len(cs.fixed_queries))

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""End-to-end `prove` wall-seconds on a matmul-accumulation circuit (the shape of benches/accum_einsum_matmul.rs:
-DOT-style gates  s_init*(acc - a*b) = 0,  s_acc*(acc - acc[-1] - a*b) = 0  over B column blocks, plus a permutation
-argument tying repeated operands), proved by ezkl_amd.plonk on the GPU and checked by the independent pairing verifier.
+"""End-to-end `prove` wall-seconds, proved on the GPU and checked by the independent pairing verifier.
 
-    K=16 BLOCKS=2 python tools/prove_bench.py [--cpu] [--native]
+    CIRCUIT=einsum K=20 python tools/prove_bench.py [--cpu] [--native] [--pinned]     the reference's accum_einsum_matmul bench circuit
+    CIRCUIT=mlp K=17 [LAYERS=9 WIDTH=..] python tools/prove_bench.py ...               MLP over the ezkl gate set (tools/bench_circuits.py)
+    K=16 BLOCKS=2 python tools/prove_bench.py ...     (CIRCUIT unset) the round-1 hand-written matmul-accumulation + lookup circuit,
+                                                      kept for the two-rank sharding tests
 (--cpu also times the CPU oracle backend; --native also times the C++ host prover libezkl_prover.so on the same witness /
 randomness and requires its proof to be byte-identical)
 The SRS is generated here with a known secret (no public SRS without network, src/pfsys/srs.rs:10-11)."""
@@ -46,21 +47,37 @@ s_g2 = E.g2_mul(g2, s)
 t_srs = time.time() - t0
 
 # ---- circuit
+CIRCUIT = os.environ.get("CIRCUIT", "synthetic")
+instances, circuit_info = [], {}
+if CIRCUIT != "synthetic":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_circuits as BC
+    t0 = time.time()
+    kw = {}
+    if os.environ.get("LAYERS"): kw["layers"] = int(os.environ["LAYERS"])
+    if os.environ.get("WIDTH"): kw["width"] = int(os.environ["WIDTH"])
+    built = BC.build(CIRCUIT, k, gpu=B, **kw)
+    cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
+    circuit_info = dict(built["info"], **BC.describe(cs), layout_seconds_python=round(time.time() - t0, 1))
+    lookups, relu, tbits = cs.lookups, False, 0
+SYNTH = CIRCUIT == "synthetic"
 gates, perm = [], []
-for b in range(blocks):
+for b in range(blocks if SYNTH else 0):
     a_, b_, acc_ = P.adv(3 * b), P.adv(3 * b + 1), P.adv(3 * b + 2)
     gates.append(P.fix(2 * b) * (acc_ - a_ * b_))
     gates.append(P.fix(2 * b + 1) * (acc_ - P.adv(3 * b + 2, -1) - a_ * b_))
     perm += [("adv", 3 * b), ("adv", 3 * b + 1)]
 # one ReLU-style nonlinearity as a two-column mv-lookup: (sel*pre, sel*post) in {(x, relu(x))}, x in [-2^(T-1), 2^(T-1))
-relu = os.environ.get("RELU", "1") == "1"
+relu = SYNTH and os.environ.get("RELU", "1") == "1"
 tbits = min(15, k - 2)
-lookups = []
+if SYNTH:
+    lookups = []
 if relu:
     pre_c, post_c, sel_c, tin_c, tout_c = 3 * blocks, 3 * blocks + 1, 2 * blocks, 2 * blocks + 1, 2 * blocks + 2
     lookups = [([[P.fix(sel_c) * P.adv(pre_c), P.fix(sel_c) * P.adv(post_c)]], [P.fix(tin_c), P.fix(tout_c)])]
     perm += [("adv", post_c)]
-cs = P.ConstraintSystem(k, 3 * blocks + (2 if relu else 0), 2 * blocks + (3 if relu else 0), gates, perm, lookups)
+if SYNTH:
+    cs = P.ConstraintSystem(k, 3 * blocks + (2 if relu else 0), 2 * blocks + (3 if relu else 0), gates, perm, lookups)
 u = cs.usable
 rng = np.random.default_rng(1)
 def canon_col(v64):
@@ -70,9 +87,10 @@ def to_mont_dev(v64):
     d = B.DeviceBuffer.from_numpy(canon_col(v64))
     B.vec_scale(d.ptr, R2, d.ptr, n)          # mont_mul(x, R^2) = x*R
     return d.to_numpy(shape=(n, 4))
-adv, fixed, copies = [], [], []
+if SYNTH:
+    adv, fixed, copies = [], [], []
 rows = np.arange(n)
-for b in range(blocks):
+for b in range(blocks if SYNTH else 0):
     av = rng.integers(1, 1 << 20, size=n).astype(np.uint64); bv = rng.integers(1, 1 << 20, size=n).astype(np.uint64)
     av[u // 2:u] = av[:u - u // 2]                       # second half re-uses the first half's operands (copy constraints)
     bv[u // 2:u] = bv[:u - u // 2]
@@ -117,12 +135,81 @@ if relu:
 def run(backend_name):
     be = (P.DistGpuBackend(g, gl, k, dist, ddev) if world > 1 else P.GpuBackend(g, gl, k)) if backend_name == "hip" else __import__("oracle.cpu_backend", fromlist=["OracleBackend"]).OracleBackend(g, gl, k)
     t0 = time.time(); pk, vk = P.keygen(cs, be, fixed, copies); t_keygen = time.time() - t0
-    P.create_proof(pk, be, adv, P.Rng(5))      # warm-up (window tables, twiddles, JIT)
+    P.create_proof(pk, be, adv, P.Rng(5), instances=instances)      # warm-up (window tables, twiddles, JIT)
     tm = {}
-    t0 = time.time(); proof = P.create_proof(pk, be, adv, P.Rng(5), timings=tm); t_prove = time.time() - t0
+    t0 = time.time(); proof = P.create_proof(pk, be, adv, P.Rng(5), timings=tm, instances=instances); t_prove = time.time() - t0
     run.timings = {a: round(b, 4) for a, b in tm.items()}
     run.sharded_sweeps = getattr(be, "sharded_sweeps", 0)
     return vk, proof, t_keygen, t_prove
+
+if not SYNTH:
+    # ---- ezkl circuits: the C++ host prover (libezkl_prover.so) on the GPU; the Python host only as the CPU baseline's driver
+    from ezkl_amd import native as NV
+    assert world == 1, "the ezkl bench circuits run on one rank here (multi-rank: CIRCUIT unset)"
+    gb_, glb_ = B.Bases(g), B.Bases(gl)
+    nc = NV.NativeCircuit(cs)
+    t0 = time.time(); npk = NV.NativeProvingKey(nc, gb_, fixed, copies); t_keygen = time.time() - t0
+    fc, pc, digest = npk.vk()
+    vk = P.VerifyingKey(); vk.cs = cs
+    vk.fixed_commitments = [P.point_to_ints(p) for p in fc]; vk.sigma_commitments = [P.point_to_ints(p) for p in pc]
+    vk.digest = P.vk_digest(vk)
+    assert vk.digest == digest
+    if "--pinned" in sys.argv and not callable(adv):
+        pinned = [B.PinnedArray((n, 4)) for _ in adv]
+        for pa, a in zip(pinned, adv):
+            pa.array[:] = a
+        adv = [pa.array for pa in pinned]
+    t0 = time.time(); NV.create_proof(npk, gb_, glb_, adv, seed=5, instances=instances); t_first = time.time() - t0   # first proof of the process: tables, plans, JIT
+    tm = {}
+    t0 = time.time(); proof = NV.create_proof(npk, gb_, glb_, adv, seed=5, instances=instances, timings=tm); t_prove = time.time() - t0
+    t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof, instances=instances); t_verify = time.time() - t0
+    out = {"what": "create_proof (KZG / SHPLONK, Keccak EVM transcript) of an ezkl circuit by libezkl_prover.so over the C ABI", "circuit": circuit_info,
+           "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "first_prove_seconds_gpu": round(t_first, 4), "keygen_seconds_gpu": round(t_keygen, 3),
+           "prove_breakdown_seconds": {a: round(b, 4) for a, b in tm.items()}, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2),
+           "srs_setup_seconds": round(t_srs, 1), "n_gpus": 1}
+    if "--cold" in sys.argv:
+        # the one-shot `ezkl prove`: artefact files on disk, a FRESH process (tools/prove_cold.py) reads SRS + pk into HBM and proves once
+        import subprocess, tempfile, shutil
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import prove_cold
+        d = tempfile.mkdtemp(prefix="ezkl_cold_", dir=os.environ.get("EZKL_COLD_DIR", "/tmp"))
+        try:
+            if callable(adv):
+                seen = {}
+                def recording(phase, chal):
+                    seen[phase] = adv(phase, chal)
+                    return seen[phase]
+                NV.create_proof(npk, gb_, glb_, recording, seed=5, instances=instances)
+                by_phase = {ph: {c: np.ascontiguousarray(a) for c, a in cols.items()} for ph, cols in seen.items()}
+            else:
+                by_phase = {0: {c: np.ascontiguousarray(a) for c, a in enumerate(adv)}}
+            t0 = time.time()
+            prove_cold.write(d, k, g, gl, g2, s_g2, cs, npk.to_bytes(), by_phase, instances, 5)
+            t_write = time.time() - t0
+            size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "prove_cold.py"), "run", d],
+                               capture_output=True, text=True, timeout=900)
+            cj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
+            if "proof_sha256" in cj:
+                cj["same_proof_as_warm"] = cj["proof_sha256"] == __import__("hashlib").sha256(proof).hexdigest()[:16]
+            cj["artifact_bytes"] = size; cj["artifact_write_seconds"] = round(t_write, 2)
+            out["cold"] = cj
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "--cpu" in sys.argv:
+        # the SAME create_proof on the host cores: Python host + the C oracle's OpenMP kernels (oracle/cpu_backend.py), same witness and
+        # randomness as a GPU proof made through the rng callback, bytes compared
+        from oracle.cpu_backend import OracleBackend
+        proof_g = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), instances=instances)
+        cpu = OracleBackend(g, gl, k)
+        t0 = time.time(); pk_c, _ = P.keygen(cs, cpu, fixed, copies); t_ck = time.time() - t0
+        ctm = {}
+        t0 = time.time(); proof_c = P.create_proof(pk_c, cpu, adv, P.Rng(5), timings=ctm, instances=instances); t_cpu = time.time() - t0
+        out.update({"prove_seconds_cpu": round(t_cpu, 3), "cpu_threads": ob.num_threads(), "cpu_keygen_seconds": round(t_ck, 2),
+                    "cpu_prover": "the same create_proof, Python host + C oracle kernels (OpenMP): a CPU restatement, not halo2",
+                    "cpu_breakdown_seconds": {a: round(b, 3) for a, b in ctm.items()}, "proofs_identical": proof_c == proof_g})
+    print(json.dumps(out))
+    sys.exit(0)
 
 vk, proof, t_keygen, t_prove = run("hip")
 native_multi = None
@@ -130,7 +217,7 @@ if world > 1 and "--native" in sys.argv:
     # the C++ host prover with its MSMs sharded the same way (ezkl_prover_cs_set_shard): every rank holds its slice of the SRS
     from ezkl_amd import native as NV
     import hashlib, torch
-    if "--pinned" in sys.argv:
+    if "--pinned" in sys.argv and not callable(adv):
         pinned = [B.PinnedArray((n, 4)) for _ in adv]
         for pa, a in zip(pinned, adv):
             pa.array[:] = a
@@ -139,10 +226,10 @@ if world > 1 and "--native" in sys.argv:
     lo, hi = nc.set_shard(dist, ddev)
     gb_, glb_ = B.Bases(np.ascontiguousarray(g[lo:hi])), B.Bases(np.ascontiguousarray(gl[lo:hi]))
     npk = NV.NativeProvingKey(nc, gb_, fixed, copies)
-    nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5))   # warm-up; same randomness as the Python host above
+    nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), instances=instances)   # warm-up; same randomness as the Python host above
     ltm = {}
     dist.barrier()
-    t0 = time.time(); lproof = NV.create_proof(npk, gb_, glb_, adv, seed=5, timings=ltm); t_native = time.time() - t0
+    t0 = time.time(); lproof = NV.create_proof(npk, gb_, glb_, adv, seed=5, timings=ltm, instances=instances); t_native = time.time() - t0
     hs_ = torch.tensor(list(hashlib.sha256(lproof).digest()), dtype=torch.uint8, device=ddev)
     all_h = [torch.empty_like(hs_) for _ in range(world)]
     dist.all_gather(all_h, hs_)
@@ -160,8 +247,9 @@ if world > 1:
     tt = torch.tensor([t_prove], dtype=torch.float64, device=ddev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); t_prove = float(tt[0])
     if rank != 0:
         dist.barrier(); dist.destroy_process_group(); sys.exit(0)
-t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof); t_verify = time.time() - t0
-out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLONK, Keccak EVM transcript): matmul-accumulation blocks + ReLU lookup",
+t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof, instances=instances); t_verify = time.time() - t0
+out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLONK, Keccak EVM transcript): " +
+               (circuit_info.get("circuit") or "matmul-accumulation blocks + ReLU lookup"), "circuit": circuit_info,
        "lookups": len(lookups), "lookup_table_rows": (1 << tbits) if relu else 0,
        "n_gpus": world, "msm_sharding": "points across %d rank(s), all_gather of 64-B partials per commit batch" % world,
        "sweep_sharding": "rows across %d rank(s) (Python host), all_gather of h: %d sharded sweep(s)" % (world, run.sharded_sweeps),
@@ -171,24 +259,24 @@ out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLO
        "prove_breakdown_seconds": run.timings, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2), "srs_setup_seconds": round(t_srs, 1)}
 if native_multi is not None:
     lproof = native_multi.pop("library_rng_proof")
-    native_multi["library_rng_proof_verifies"] = bool(V.verify(vk, (1, 2), g2, s_g2, lproof))
+    native_multi["library_rng_proof_verifies"] = bool(V.verify(vk, (1, 2), g2, s_g2, lproof, instances=instances))
     out["native_prover"] = native_multi
 if "--native" in sys.argv and world == 1:
     from ezkl_amd import native as NV
-    if "--pinned" in sys.argv:                     # witness in page-locked memory (ezkl_hip_host_malloc): uploads run under the commits
+    if "--pinned" in sys.argv and not callable(adv):     # witness in page-locked memory (ezkl_hip_host_malloc): uploads run under the commits
         pinned = [B.PinnedArray((n, 4)) for _ in adv]
         for pa, a in zip(pinned, adv):
             pa.array[:] = a
         adv = [pa.array for pa in pinned]
     gb_, glb_ = B.Bases(g), B.Bases(gl)
     t0 = time.time(); npk = NV.NativeProvingKey(NV.NativeCircuit(cs), gb_, fixed, copies); t_nkeygen = time.time() - t0
-    NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5))            # warm-up
+    NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), instances=instances)            # warm-up
     ntm = {}
-    t0 = time.time(); nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), timings=ntm); t_native = time.time() - t0
+    t0 = time.time(); nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), timings=ntm, instances=instances); t_native = time.time() - t0
     ltm = {}
-    t0 = time.time(); lproof = NV.create_proof(npk, gb_, glb_, adv, seed=5, timings=ltm); t_native_librng = time.time() - t0
+    t0 = time.time(); lproof = NV.create_proof(npk, gb_, glb_, adv, seed=5, timings=ltm, instances=instances); t_native_librng = time.time() - t0
     out["native_prover"] = {"prove_seconds": round(t_native, 4), "prove_seconds_library_rng": round(t_native_librng, 4), "keygen_seconds": round(t_nkeygen, 3),
-                            "proof_identical_to_python_prover": nproof == proof, "library_rng_proof_verifies": bool(V.verify(vk, (1, 2), g2, s_g2, lproof)),
+                            "proof_identical_to_python_prover": nproof == proof, "library_rng_proof_verifies": bool(V.verify(vk, (1, 2), g2, s_g2, lproof, instances=instances)),
                             "breakdown_seconds": {a: round(b, 4) for a, b in ntm.items()},
                             "breakdown_seconds_library_rng": {a: round(b, 4) for a, b in ltm.items()}}
 if "--cpu-kernels" in sys.argv:
