@@ -340,7 +340,7 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     MSM of the proof by points, all_gather the partials; the proof equals the single-rank proof and verifies"""
     import json, os, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, K="12", BLOCKS="1")
+    env = dict(os.environ, K="12", BLOCKS="1", CIRCUIT="synthetic")
     one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py")], env=env, capture_output=True, text=True, timeout=600)
     j1 = json.loads(one.stdout.strip().splitlines()[-1])
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
