@@ -17,6 +17,7 @@
 #include "ezkl_prover.h"
 #include "hostfield.hpp"
 #include "transcript.hpp"
+#include "pairing.hpp"
 
 namespace ezkl_prover {
 using ezkl_hip::check;
@@ -1491,6 +1492,289 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     return T.proof();
 }
 
+
+// ------------------------------------------------------------------ verify_proof (the SAFE self-check, verify_proof_circuit)
+// halo2's verifier for the proofs create_proof above emits (/root/reference/src/pfsys/mod.rs:557-590 verify_proof_circuit, and the
+// CheckMode::SAFE branch of create_proof_circuit :470-480): replay the transcript, recompute the quotient identity at x from the
+// claimed evaluations, and check the SHPLONK opening with one pairing product against the SRS's g2 / s_g2.  O(#columns) field and
+// group operations on the host (pairing.hpp); no device work.
+struct ProofReader {
+    const uint8_t* p;
+    size_t len, off = 0;
+    std::vector<uint8_t> buf;
+    void need(size_t m) {
+        if (off + m > len) throw Error(EZKL_ERR_INVALID, "proof truncated");
+    }
+    void common_scalar(const Fe& s) {
+        uint8_t b[32];
+        to_be32(s.canonical(), b);
+        buf.insert(buf.end(), b, b + 32);
+    }
+    bn::P1 read_point() {
+        need(64);
+        const U256 x = from_be32(p + off), y = from_be32(p + off + 32);
+        if (cmp(x, FQ.p) >= 0 || cmp(y, FQ.p) >= 0) throw Error(EZKL_ERR_INVALID, "non-canonical point in the proof");
+        buf.insert(buf.end(), p + off, p + off + 64);
+        off += 64;
+        bn::P1 r;
+        r.x = bn::Fq{mont_mul(x, FQ.r2, FQ)};
+        r.y = bn::Fq{mont_mul(y, FQ.r2, FQ)};
+        r.inf = r.x.is_zero() && r.y.is_zero();
+        if (!r.inf && !(r.y * r.y == r.x * r.x * r.x + bn::Fq::from_u64(3))) throw Error(EZKL_ERR_INVALID, "point not on the curve");
+        return r;
+    }
+    Fe read_scalar() {
+        need(32);
+        const U256 c = from_be32(p + off);
+        if (cmp(c, FR.p) >= 0) throw Error(EZKL_ERR_INVALID, "non-canonical scalar in the proof");
+        buf.insert(buf.end(), p + off, p + off + 32);
+        off += 32;
+        return Fe::from_canonical(c);
+    }
+    Fe squeeze_challenge() {
+        if (buf.size() == 32) buf.push_back(0x01);
+        auto h = keccak256(buf.data(), buf.size());
+        buf.assign(h.begin(), h.end());
+        return Fe::from_canonical(reduce_fr(from_be32(h.data())));
+    }
+};
+
+static bool verify_proof(ConstraintSystem& cs, const std::vector<G1>& fixed_commitments, const std::vector<G1>& sigma_commitments, const Fe& digest,
+                         const bn::G2& g2, const bn::G2& s_g2, const uint8_t* proof, size_t proof_len, const void* const* instances,
+                         const uint32_t* instance_lens) {
+    using bn::P1;
+    const uint32_t n = cs.n, k = cs.k, u = cs.usable;
+    ProofReader T{proof, proof_len};
+    T.common_scalar(digest);
+    std::vector<std::vector<Fe>> inst(cs.n_instance);
+    for (uint32_t i = 0; i < cs.n_instance; i++) {
+        if (instance_lens[i] > u) return false;
+        for (uint32_t j = 0; j < instance_lens[i]; j++) {
+            U256 v;
+            std::memcpy(v.data(), (const uint8_t*)instances[i] + 32 * j, 32);
+            if (cmp(v, FR.p) >= 0) return false;
+            inst[i].push_back(Fe{v});
+            T.common_scalar(Fe{v});
+        }
+    }
+    std::vector<P1> adv_c(cs.n_advice);
+    std::vector<Fe> user_chal;
+    for (uint32_t phase = 0; phase < 2; phase++) {
+        bool any = false;
+        for (uint32_t c = 0; c < cs.n_advice; c++)
+            if (cs.advice_phase[c] == phase) { adv_c[c] = T.read_point(); any = true; }
+        if (phase == 0 && any)
+            for (uint32_t i = 0; i < cs.n_challenges; i++) user_chal.push_back(T.squeeze_challenge());
+    }
+    const size_t nl = cs.lookups.size();
+    Fe theta = Fe::zero();
+    std::vector<P1> m_c, phi_c, z_c, h_c;
+    if (nl) {
+        theta = T.squeeze_challenge();
+        for (size_t i = 0; i < nl; i++) m_c.push_back(T.read_point());
+    }
+    const Fe beta = T.squeeze_challenge(), gamma = T.squeeze_challenge();
+    for (uint32_t j = 0; j < cs.n_chunks; j++) z_c.push_back(T.read_point());
+    for (size_t i = 0; i < nl; i++) phi_c.push_back(T.read_point());
+    const P1 rnd_c = T.read_point();
+    const Fe y = T.squeeze_challenge();
+    for (uint32_t i = 0; i + 1 < cs.degree; i++) h_c.push_back(T.read_point());
+    const Fe x = T.squeeze_challenge();
+    std::map<std::pair<uint32_t, int32_t>, Fe> ev[3];        // advice, fixed, instance evaluations by (column, rotation)
+    for (auto& q : cs.advice_queries) ev[0][{q.col, q.rot}] = T.read_scalar();
+    for (auto& q : cs.fixed_queries) ev[1][{q.col, q.rot}] = T.read_scalar();
+    const Fe random_eval = T.read_scalar();
+    std::vector<Fe> sigma_ev;
+    for (size_t i = 0; i < cs.perm.size(); i++) sigma_ev.push_back(T.read_scalar());
+    struct ZE { Fe e0, e1, e2; bool has2; };
+    std::vector<ZE> z_ev;
+    for (uint32_t j = 0; j < cs.n_chunks; j++) {
+        ZE z{T.read_scalar(), T.read_scalar(), Fe::zero(), j + 1 < cs.n_chunks};
+        if (z.has2) z.e2 = T.read_scalar();
+        z_ev.push_back(z);
+    }
+    struct LE { Fe phi, phi_next, m; };
+    std::vector<LE> lk_ev;
+    for (size_t i = 0; i < nl; i++) lk_ev.push_back(LE{T.read_scalar(), T.read_scalar(), T.read_scalar()});
+    const Fe w = omega(k);
+    auto rot_point = [&](int32_t r) { return x * w.pow((uint64_t)(r >= 0 ? (uint32_t)r % n : n - ((uint32_t)(-r) % n))); };
+    const Fe xn = x.pow((uint64_t)n), zx = xn - Fe::one(), ninv = Fe::from_u64(n).inv();
+    auto lagrange = [&](const Fe& at, const Fe& at_n_minus_1, uint32_t i) {   // l_i(at) = omega^i (at^n - 1) / (n (at - omega^i))
+        const Fe wi = w.pow((uint64_t)i);
+        return wi * at_n_minus_1 * ninv * (at - wi).inv();
+    };
+    for (auto& q : cs.instance_queries) {                     // instance columns are evaluated by the verifier from the public values
+        const Fe z = rot_point(q.rot), zn1 = z.pow((uint64_t)n) - Fe::one();
+        Fe acc = Fe::zero();
+        for (size_t i = 0; i < inst[q.col].size(); i++) acc = acc + inst[q.col][i] * lagrange(z, zn1, (uint32_t)i);
+        ev[2][{q.col, q.rot}] = acc;
+    }
+    const Fe l0 = lagrange(x, zx, 0), llast = lagrange(x, zx, u);
+    Fe lblind = Fe::zero();
+    for (uint32_t i = u; i < n; i++) lblind = lblind + lagrange(x, zx, i);
+    const Fe lact = Fe::one() - lblind;
+    std::vector<Fe> memo(cs.nodes.size());
+    std::vector<uint8_t> have(cs.nodes.size(), 0);
+    std::function<Fe(uint32_t)> evalx = [&](uint32_t id) -> Fe {
+        if (have[id]) return memo[id];
+        const Node& nd = cs.nodes[id];
+        Fe r;
+        switch (nd.op) {
+        case N_CONST: r = nd.c; break;
+        case N_ADV: case N_FIX: case N_INST: {
+            auto it = ev[nd.op - N_ADV].find({nd.a, (int32_t)nd.b});
+            if (it == ev[nd.op - N_ADV].end()) throw Error(EZKL_ERR_INVALID, "expression reads an unqueried cell");
+            r = it->second;
+            break;
+        }
+        case N_CHAL: r = user_chal.at(nd.a); break;
+        case N_NEG: r = -evalx(nd.a); break;
+        case N_ADD: r = evalx(nd.a) + evalx(nd.b); break;
+        case N_SUB: r = evalx(nd.a) - evalx(nd.b); break;
+        default: r = evalx(nd.a) * evalx(nd.b); break;
+        }
+        have[id] = 1;
+        return memo[id] = r;
+    };
+    std::vector<Fe> terms;
+    for (uint32_t g : cs.gates) terms.push_back(evalx(g));
+    if (!cs.perm.empty()) {
+        terms.push_back(l0 * (Fe::one() - z_ev[0].e0));
+        const Fe zl = z_ev.back().e0;
+        terms.push_back(llast * (zl * zl - zl));
+        for (uint32_t j = 1; j < cs.n_chunks; j++) terms.push_back(l0 * (z_ev[j].e0 - z_ev[j - 1].e2));
+        uint32_t pos = 0;
+        const Fe delta{FR_DELTA};
+        Fe dpow = Fe::one();
+        uint32_t j = 0;
+        for (auto& chunk : cs.perm_chunks()) {
+            Fe left = z_ev[j].e1, right = z_ev[j].e0;
+            for (size_t i = 0; i < chunk.size(); i++) {
+                const Fe v = ev[chunk[i].first - N_ADV].at({chunk[i].second, 0});
+                left = left * (v + beta * sigma_ev[pos + i] + gamma);
+                right = right * (v + beta * dpow * x + gamma);
+                dpow = dpow * delta;
+            }
+            terms.push_back(lact * (left - right));
+            pos += (uint32_t)chunk.size();
+            j++;
+        }
+    }
+    auto compress = [&](const std::vector<uint32_t>& tup) {
+        Fe acc = evalx(tup[0]);
+        for (size_t i = 1; i < tup.size(); i++) acc = acc * theta + evalx(tup[i]);
+        return acc;
+    };
+    for (size_t li = 0; li < nl; li++) {
+        const Lookup& l = cs.lookups[li];
+        std::vector<Fe> fb;
+        for (auto& t : l.inputs) fb.push_back(compress(t) + beta);
+        const Fe tb = compress(l.table) + beta;
+        Fe prodf = Fe::one(), ssum = Fe::zero();
+        for (auto& f : fb) prodf = prodf * f;
+        for (size_t jj = 0; jj < fb.size(); jj++) {
+            Fe pj = Fe::one();
+            for (size_t i2 = 0; i2 < fb.size(); i2++)
+                if (i2 != jj) pj = pj * fb[i2];
+            ssum = ssum + pj;
+        }
+        const Fe lhs = (lk_ev[li].phi_next - lk_ev[li].phi) * prodf * tb, rhs = ssum * tb - lk_ev[li].m * prodf;
+        terms.push_back(l0 * lk_ev[li].phi);
+        terms.push_back(llast * lk_ev[li].phi);
+        terms.push_back(lact * (lhs - rhs));
+    }
+    Fe num = Fe::zero();
+    for (auto& t : terms) num = num * y + t;
+    const Fe h_eval = num * zx.inv();
+    // ---- the opening queries, in the prover's order: (commitment, point, evaluation) grouped like shplonk_prove
+    P1 hc{};
+    for (size_t i = h_c.size(); i-- > 0;) hc = bn::p1_add(bn::p1_mul(hc, xn), h_c[i]);
+    struct VQ { std::vector<uint32_t> key; P1 com; Fe point, eval; };
+    enum : uint32_t { K_ADV = 1, K_FIX, K_H, K_RND, K_SIGMA, K_Z, K_M, K_PHI };
+    std::vector<VQ> qs;
+    for (auto& q : cs.advice_queries) qs.push_back({{K_ADV, q.col}, adv_c[q.col], rot_point(q.rot), ev[0][{q.col, q.rot}]});
+    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, bn::p1_from(fixed_commitments[q.col]), rot_point(q.rot), ev[1][{q.col, q.rot}]});
+    qs.push_back({{K_H}, hc, x, h_eval});
+    qs.push_back({{K_RND}, rnd_c, x, random_eval});
+    for (uint32_t i = 0; i < sigma_ev.size(); i++) qs.push_back({{K_SIGMA, i}, bn::p1_from(sigma_commitments[i]), x, sigma_ev[i]});
+    for (uint32_t j = 0; j < z_ev.size(); j++) {
+        qs.push_back({{K_Z, j}, z_c[j], x, z_ev[j].e0});
+        qs.push_back({{K_Z, j}, z_c[j], rot_point(1), z_ev[j].e1});
+        if (z_ev[j].has2) qs.push_back({{K_Z, j}, z_c[j], rot_point((int32_t)u), z_ev[j].e2});
+    }
+    for (uint32_t i = 0; i < nl; i++) {
+        qs.push_back({{K_PHI, i}, phi_c[i], x, lk_ev[i].phi});
+        qs.push_back({{K_PHI, i}, phi_c[i], rot_point(1), lk_ev[i].phi_next});
+        qs.push_back({{K_M, i}, m_c[i], x, lk_ev[i].m});
+    }
+    struct VPoly { P1 com; std::map<U256, std::pair<Fe, Fe>> ev; };
+    std::vector<VPoly> polys;
+    std::map<std::vector<uint32_t>, size_t> by_key;
+    for (auto& q : qs) {
+        auto it = by_key.find(q.key);
+        if (it == by_key.end()) {
+            it = by_key.emplace(q.key, polys.size()).first;
+            polys.push_back(VPoly{q.com, {}});
+        }
+        polys[it->second].ev[q.point.canonical()] = {q.point, q.eval};
+    }
+    struct VGroup { std::vector<U256> pts; std::vector<Fe> pts_fe; std::vector<size_t> members; };
+    std::vector<VGroup> groups;
+    for (size_t i = 0; i < polys.size(); i++) {
+        std::vector<U256> pts;
+        for (auto& e : polys[i].ev) pts.push_back(e.first);
+        std::sort(pts.begin(), pts.end(), u256_less);
+        size_t gi = 0;
+        for (; gi < groups.size(); gi++)
+            if (groups[gi].pts == pts) break;
+        if (gi == groups.size()) {
+            VGroup gn;
+            gn.pts = pts;
+            for (auto& p : pts) gn.pts_fe.push_back(polys[i].ev[p].first);
+            groups.push_back(gn);
+        }
+        groups[gi].members.push_back(i);
+    }
+    const Fe ys = T.squeeze_challenge();
+    std::vector<U256> all_pts;
+    std::map<U256, Fe> pt_fe;
+    for (auto& gr : groups)
+        for (size_t i = 0; i < gr.pts.size(); i++) { all_pts.push_back(gr.pts[i]); pt_fe[gr.pts[i]] = gr.pts_fe[i]; }
+    std::sort(all_pts.begin(), all_pts.end(), u256_less);
+    all_pts.erase(std::unique(all_pts.begin(), all_pts.end()), all_pts.end());
+    const Fe v = T.squeeze_challenge();
+    const P1 pi1 = T.read_point();
+    const Fe uu = T.squeeze_challenge();
+    const P1 pi2 = T.read_point();
+    if (T.off != proof_len) return false;
+    Fe zt_u = Fe::one();
+    for (auto& p : all_pts) zt_u = zt_u * (uu - pt_fe[p]);
+    P1 gen;
+    gen.inf = false; gen.x = bn::Fq::one(); gen.y = bn::Fq::from_u64(2);
+    P1 L{};
+    Fe pw = Fe::one();
+    for (auto& gr : groups) {
+        P1 qc{};
+        std::vector<Fe> evs(gr.pts.size(), Fe::zero());
+        Fe yp = Fe::one();
+        for (size_t mi : gr.members) {
+            qc = bn::p1_add(qc, bn::p1_mul(polys[mi].com, yp));
+            for (size_t i = 0; i < gr.pts.size(); i++) evs[i] = evs[i] + yp * polys[mi].ev[gr.pts[i]].second;
+            yp = yp * ys;
+        }
+        const std::vector<Fe> r = interpolate(gr.pts_fe, evs);
+        Fe zdiff = Fe::one();
+        for (auto& p : all_pts)
+            if (!std::binary_search(gr.pts.begin(), gr.pts.end(), p, u256_less)) zdiff = zdiff * (uu - pt_fe[p]);
+        const P1 term = bn::p1_add(qc, bn::p1_neg(bn::p1_mul(gen, eval_small(r, uu))));
+        L = bn::p1_add(L, bn::p1_mul(term, pw * zdiff));
+        pw = pw * v;
+    }
+    L = bn::p1_add(L, bn::p1_neg(bn::p1_mul(pi1, zt_u)));
+    const P1 lhs = bn::p1_add(L, bn::p1_mul(pi2, uu));
+    return bn::pairing_check({{pi2, s_g2}, {bn::p1_neg(lhs), g2}});
+}
+
 }  // namespace ezkl_prover
 
 // ------------------------------------------------------------------ C ABI
@@ -1619,6 +1903,33 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
         *proof_len = proof.size();
         if (proof.size() > cap || !proof_out) throw Error(EZKL_ERR_NOMEM, "proof buffer too small");
         std::memcpy(proof_out, proof.data(), proof.size());
+    });
+}
+int ezkl_prover_verify_proof(ezkl_pk_t pk, const void* g2, const void* s_g2, const void* proof, size_t proof_len, const void* const* instances,
+                             const uint32_t* instance_lens, int* accepted) {
+    if (!pk || !g2 || !s_g2 || !proof || !accepted) return EZKL_ERR_INVALID;
+    *accepted = 0;
+    return guarded([&] {
+        const ProvingKey& k = *pk->pk;
+        const bn::G2 a = bn::g2_from_bytes((const uint8_t*)g2), b = bn::g2_from_bytes((const uint8_t*)s_g2);
+        if (!bn::g2_on_curve(a) || !bn::g2_on_curve(b) || a.inf || b.inf) throw Error(EZKL_ERR_INVALID, "g2 / s_g2 not on the twist");
+        bool ok = false;
+        try {
+            ok = verify_proof(*k.cs, k.fixed_commitments, k.sigma_commitments, k.digest, a, b, (const uint8_t*)proof, proof_len, instances, instance_lens);
+        } catch (const Error& e) {             // a malformed proof is a rejection, not a failure of the call
+            if (e.code != EZKL_ERR_INVALID) throw;
+            g_last_error = e.what();
+        }
+        *accepted = ok ? 1 : 0;
+    });
+}
+int ezkl_prover_g2_mul_generator(const void* scalar, void* out128) {
+    if (!scalar || !out128) return EZKL_ERR_INVALID;
+    return guarded([&] {
+        U256 sv;
+        std::memcpy(sv.data(), scalar, 32);
+        if (cmp(sv, FR.p) >= 0) throw Error(EZKL_ERR_INVALID, "non-canonical scalar");
+        bn::g2_to_bytes(bn::g2_mul(bn::g2_generator(), Fe{sv}.canonical()), (uint8_t*)out128);
     });
 }
 int ezkl_prover_keccak256(const void* data, size_t len, void* out32) {

@@ -1,0 +1,104 @@
+"""The command bodies around the prove hot path, with the reference's names and argument meaning
+(/root/reference/src/execute.rs): artefact FILES in, artefact files out, everything O(n) on the GPU through libezkl_prover.so.
+
+    setup(compiled_circuit, srs_path, vk_path, pk_path)                         execute.rs:1543-1572 -> pfsys::create_keys (mod.rs:376-400)
+    prove(witness, compiled_circuit, pk_path, proof_path, srs_path, check_mode)  execute.rs:1575-1627 -> create_proof_circuit (mod.rs:404-489)
+    verify(proof_path, compiled_circuit, pk_path, srs_path)                      execute.rs:1651-1722 -> verify_proof_circuit (mod.rs:557-590)
+
+File formats are the reference's: kzg*.srs / pk.key / vk.key in halo2 raw bytes, witness.json (GraphWitness), proof.json (Snark)
+(ezkl_amd/codecs.py).  The one artefact that is NOT the reference's is the compiled circuit: ezkl's `model.compiled` is a bincode of its
+ONNX graph IR and its layout lives in 6.8k lines of Rust (out of scope); here it is a JSON description of the
+model family ezkl_layout.MlpCircuit lays out ({"model": "mlp", "run_args": {...}, "weights": [...], "biases": [...]}) -- on the
+reference's own fixture model that layout reproduces the reference's pk.key bit for bit (tests/test_ezkl_circuit.py).
+Errors surface as exceptions with the reference's wording where it has one."""
+import json
+
+import numpy as np
+
+from . import backend as B
+from . import codecs, ezkl_layout as EL, native as NV
+
+
+class CheckMode:
+    SAFE, UNSAFE = "SAFE", "UNSAFE"
+
+
+def _load_circuit(path):
+    j = json.load(open(path))
+    if j.get("model") != "mlp":
+        raise ValueError("unsupported compiled circuit: %r" % j.get("model"))
+    ra = j["run_args"]
+    return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], j["weights"], j["biases"], ra["decomp_base"], ra["decomp_legs"],
+                         total_assignments=j.get("total_assignments"), relu_last=j.get("relu_last", True)), j
+
+
+def load_params_prover(srs_path, logrows):
+    """execute.rs:1739-1750: read the SRS, downsize if the file is larger (coefficient basis only: see codecs.downsize_srs)"""
+    srs = codecs.read_srs(open(srs_path, "rb").read())
+    if srs["k"] < logrows:
+        raise ValueError("SRS too small: k=%d < logrows=%d" % (srs["k"], logrows))
+    if srs["k"] > logrows:
+        raise ValueError("downsizing g_lagrange needs an inverse FFT over G1 (halo2 ParamsKZG::downsize): supply an SRS of k=%d" % logrows)
+    return srs
+
+
+def setup(compiled_circuit, srs_path, vk_path, pk_path, sample_input=None):
+    """keygen_vk + keygen_pk on the GPU, keys written in halo2's raw-bytes layout"""
+    circuit, j = _load_circuit(compiled_circuit)
+    srs = load_params_prover(srs_path, circuit.k)
+    x = sample_input if sample_input is not None else [0] * len(circuit.weights[0][0])
+    cs, fixed, copies, reg = circuit.keygen_inputs(x)          # synthesis without witness values: selectors + copy constraints
+    bg = B.Bases(srs["g"])
+    try:
+        pk = NV.NativeProvingKey(NV.NativeCircuit(cs), bg, EL.cols_to_mont(fixed, B), copies)
+        pk.set_selectors(reg.selector_rows())
+        data = pk.to_bytes()
+    finally:
+        bg.free()
+    open(pk_path, "wb").write(data)
+    vk_len = 7 + 64 * (cs.n_fixed + len(cs.perm)) + cs.n_selectors * ((cs.n + 7) // 8)
+    open(vk_path, "wb").write(data[:vk_len])                   # vk.key is the prefix of pk.key
+    return dict(n_advice=cs.n_advice, n_fixed=cs.n_fixed, n_lookups=len(cs.lookups), degree=cs.degree, pk_bytes=len(data))
+
+
+def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_mode=CheckMode.UNSAFE, seed=0):
+    """GraphWitness + compiled circuit + pk + SRS files -> proof.json (Snark).  seed = 0: OS entropy (OsRng); otherwise the
+    reference's det-prove.  CheckMode.SAFE verifies the proof before returning it, as create_proof_circuit does."""
+    w = codecs.read_witness_json(open(witness_path).read())
+    circuit, j = _load_circuit(compiled_circuit)
+    if len(w["inputs"]) != 1 or len(w["inputs"][0]) != len(circuit.weights[0][0]):
+        raise ValueError("witness does not match the circuit's input shape")
+    signed = lambda v: v if v < EL.R // 2 else v - EL.R
+    cs = circuit.gc.cs
+    adv, inst = circuit.witness([signed(v) for v in w["inputs"][0]])            # GraphCircuit::synthesize
+    if w["outputs"] and inst != w["outputs"]:
+        raise ValueError("the witness file's outputs do not match the circuit's outputs")
+    ncs = _plonk_cs(circuit)
+    srs_bytes = open(srs_path, "rb").read()
+    srs = codecs.read_srs(srs_bytes)
+    bg, bgl = B.Bases(srs["g"]), B.Bases(srs["g_lagrange"])
+    try:
+        pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(ncs), open(pk_path, "rb").read())
+        proof = NV.create_proof(pk, bg, bgl, EL.cols_to_mont(adv, B), seed=seed, instances=inst, check_mode=check_mode,
+                                g2=srs["g2"], s_g2=srs["s_g2"])
+    finally:
+        bg.free(); bgl.free()
+    open(proof_path, "w").write(codecs.write_proof_json(proof, inst))
+    return proof
+
+
+def verify(proof_path, compiled_circuit, pk_path, srs_path):
+    """-> True / False.  The key file supplies the verifying key (vk.key is its prefix)."""
+    circuit, j = _load_circuit(compiled_circuit)
+    pr = codecs.read_proof_json(open(proof_path).read())
+    srs = codecs.read_srs(open(srs_path, "rb").read())
+    pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(_plonk_cs(circuit)), open(pk_path, "rb").read())
+    return NV.verify_proof(pk, srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])
+
+
+def _plonk_cs(circuit):
+    """the constraint system as keygen saw it: re-running `configure` + selector compression (halo2 does the same on load_pk,
+    src/pfsys/mod.rs:627) -- a fresh synthesis pass without witness values gives the selector activations"""
+    fresh = EL.MlpCircuit(circuit.k, circuit.w, circuit.weights, circuit.biases, circuit.base, circuit.legs,
+                          total_assignments=circuit.settings.total_assignments, relu_last=circuit.relu_last)
+    return fresh.keygen_inputs([0] * len(circuit.weights[0][0]))[0]

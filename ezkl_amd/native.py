@@ -15,7 +15,7 @@ _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_vk",
-           "ezkl_prover_create_proof", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
+           "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 FOLD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
@@ -185,7 +185,25 @@ class NativeProvingKey:
             pass
 
 
-def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(), timings=None):
+def g2_mul_generator(s):
+    """[s] G2 as the 128 raw bytes of an SRS file (s = 1: the generator)"""
+    out = (C.c_uint8 * 128)()
+    _check(load().ezkl_prover_g2_mul_generator(_pl.to_mont(s).ctypes.data_as(C.c_void_p), out), "ezkl_prover_g2_mul_generator")
+    return bytes(out)
+
+
+def verify_proof(pk, g2, s_g2, proof, instances=()):
+    """verify_proof_circuit (src/pfsys/mod.rs:557-590) on the host side of the library: g2 / s_g2 = the 128-byte tail elements of the SRS"""
+    inst = [np.stack([_pl.to_mont(v) for v in vals]) if len(vals) else np.zeros((0, 4), np.uint64) for vals in instances]
+    lens = (C.c_uint32 * max(1, len(inst)))(*[a.shape[0] for a in inst])
+    ok = C.c_int(0)
+    proof = bytes(proof)
+    _check(load().ezkl_prover_verify_proof(pk.h, bytes(g2), bytes(s_g2), proof, C.c_size_t(len(proof)), _ptr_array(inst), lens, C.byref(ok)),
+           "ezkl_prover_verify_proof")
+    return bool(ok.value)
+
+
+def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(), timings=None, check_mode="UNSAFE", g2=None, s_g2=None):
     """advice_values: list of (n,4) Montgomery arrays, or a callable advice_values(phase, challenges) -> {column: array}
     (second-phase advice); rng: object with .vec(m) -> (m,4) u64 Montgomery residues (None = the library's own
     generator, seeded with `seed`, 0 = OS entropy); instances: list of lists of ints.  Returns the proof bytes."""
@@ -227,4 +245,10 @@ def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(
                                            buf, C.c_size_t(cap), C.byref(plen), tm), "ezkl_prover_create_proof")
     if timings is not None:
         timings.update(dict(zip(STAGES, list(tm))))
-    return bytes(buf[:plen.value])
+    proof = bytes(buf[:plen.value])
+    if check_mode == "SAFE":                          # create_proof_circuit's CheckMode::SAFE (src/pfsys/mod.rs:470-480): verify what was just proved
+        if g2 is None or s_g2 is None:
+            raise ValueError("check_mode SAFE needs the SRS's g2 / s_g2")
+        if not verify_proof(pk, g2, s_g2, proof, instances):
+            raise RuntimeError("SAFE check failed: the proof just made does not verify")
+    return proof

@@ -113,6 +113,16 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
                              void* advice_user, const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng, void* rng_user,
                              uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings);
 
+/* ---- verify_proof: the verifier of these proofs, on the host (pairing in csrc/prover/pairing.hpp) ----
+ * /root/reference/src/pfsys/mod.rs:557-590 verify_proof_circuit, and the CheckMode::SAFE self-check of create_proof_circuit (:470-480:
+ * every proof is verified before it is returned).  pk supplies the constraint system and the verifying key (commitments + digest);
+ * g2 / s_g2 are the 128-byte G2 elements that end the SRS file (halo2curves raw bytes: x.c0 | x.c1 | y.c0 | y.c1, Montgomery LE;
+ * /root/reference/src/pfsys/srs.rs:14-16).  *accepted = 1 iff the transcript replays, the quotient identity holds at x and the SHPLONK
+ * pairing check passes; a malformed proof is a rejection (0), not an error. */
+int ezkl_prover_verify_proof(ezkl_pk_t pk, const void* g2, const void* s_g2, const void* proof, size_t proof_len, const void* const* instances,
+                             const uint32_t* instance_lens, int* accepted);
+/* [s] G2 for a Montgomery Fr scalar s: the `s_g2` of a test SRS (gen_srs, src/pfsys/srs.rs:13-16); s = 1 gives the generator g2. */
+int ezkl_prover_g2_mul_generator(const void* scalar, void* out128);
 /* keccak256 of a byte string (exposed so the transcript can be tested against the Python restatement without a GPU) */
 int ezkl_prover_keccak256(const void* data, size_t len, void* out32);
 /* last error text of the calling thread ("" if none) */

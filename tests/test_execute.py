@@ -1,0 +1,47 @@
+"""`setup` / `prove` / `verify` on artefact FILES with the reference's names (ezkl_amd/execute.py mirrors src/execute.rs:1543-1722), run
+on the reference's own fixture: its model (tests/assets/network.onnx at scale 0), its settings.json, its witness.json, its k = 6 test
+SRS file -- the key written by `setup` equals the reference's pk.key outside the SRS-dependent commitments, `prove` with CheckMode SAFE
+writes a proof.json with the reference proof's layout, `verify` accepts it and rejects a tampered one."""
+import json
+import os
+
+import pytest
+
+import fixture_k6 as FX
+from test_ezkl_circuit import FIXTURE_B, FIXTURE_W
+
+pytestmark = pytest.mark.gpu
+
+
+def test_setup_prove_verify_on_files(hip, tmp_path):
+    from ezkl_amd import codecs, execute as X
+    st = json.load(open(os.path.join(FX.G, "settings_k6.json")))
+    compiled = tmp_path / "model.compiled.json"
+    compiled.write_text(json.dumps({"model": "mlp", "run_args": st["run_args"], "weights": [FIXTURE_W], "biases": [FIXTURE_B],
+                                    "total_assignments": st["total_assignments"]}))
+    srs, wit = os.path.join(FX.G, "kzg_k6.srs"), os.path.join(FX.G, "witness_k6.json")
+    vk_path, pk_path, proof_path = tmp_path / "vk.key", tmp_path / "pk.key", tmp_path / "proof.json"
+    info = X.setup(str(compiled), srs, str(vk_path), str(pk_path))
+    assert info["n_advice"] == 30 and info["n_fixed"] == 38 and info["n_lookups"] == 35 and info["degree"] == 7
+    mine, ref = pk_path.read_bytes(), open(os.path.join(FX.G, "pk_k6.key"), "rb").read()
+    lo, hi = 7, 7 + 64 * 70
+    assert len(mine) == len(ref) and mine[:lo] == ref[:lo] and mine[hi:] == ref[hi:]
+    assert vk_path.read_bytes() == mine[:5127] and len(open(os.path.join(FX.G, "vk_k6.key"), "rb").read()) == 5127
+    proof = X.prove(wit, str(compiled), str(pk_path), str(proof_path), srs, X.CheckMode.SAFE)
+    assert len(proof) == 14816
+    pj = codecs.read_proof_json(proof_path.read_text())
+    assert pj["proof"] == proof and pj["instances"] == [[0, 0, 0, 0]]
+    ref_pj = json.load(open(os.path.join(FX.G, "proof_k6.json")))
+    assert pj["raw"]["instances"] == ref_pj["instances"] and len(pj["raw"]["hex_proof"]) == len(ref_pj["hex_proof"])
+    assert X.verify(str(proof_path), str(compiled), str(pk_path), srs)
+    j = json.loads(proof_path.read_text())
+    j["proof"][4000] ^= 1
+    j["hex_proof"] = "0x" + bytes(j["proof"]).hex()
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(j))
+    assert not X.verify(str(bad), str(compiled), str(pk_path), srs)
+    # a witness file whose outputs disagree with the circuit is refused before proving
+    w = json.load(open(wit)); w["outputs"][0][0] = "01" + "00" * 31
+    wb = tmp_path / "w.json"; wb.write_text(json.dumps(w))
+    with pytest.raises(ValueError, match="outputs"):
+        X.prove(str(wb), str(compiled), str(pk_path), str(proof_path), srs)

@@ -304,3 +304,41 @@ def test_native_key_file_roundtrip(hip, golden_srs):
     evil = bytearray(data); evil[off:off + 32] = b"\xff" * 32
     with pytest.raises(RuntimeError):
         N.NativeProvingKey.from_bytes(pk.circuit, bytes(evil))
+
+
+@pytest.mark.gpu
+def test_native_verifier_agrees_with_the_oracle_verifier(hip, golden_srs):
+    """ezkl_prover_verify_proof (C++ host, ate pairing in csrc/prover/pairing.hpp) = verify_proof_circuit / the SAFE self-check: accepts
+    what the oracle's verifier (optimal-ate pairing, Python) accepts and rejects what it rejects -- lookups, instances, second phase"""
+    import os
+    from oracle import verifier as V, pyref as pr, pairing as E
+    import test_plonk as TP
+    from ezkl_amd import backend as B
+    srs_bytes = open(os.path.join(os.path.dirname(__file__), "golden", "kzg_k6.srs"), "rb").read()
+    g2b, sg2b = srs_bytes[-256:-128], srs_bytes[-128:]
+    assert N.g2_mul_generator(1) == g2b                                     # the SRS's g2 is the generator halo2curves uses
+    g1, g2, s_g2 = TP.setup(golden_srs)
+    bg, bgl = B.Bases(golden_srs["g"]), B.Bases(golden_srs["g_lagrange"])
+    # lookups + permutation
+    cs = TP.lookup_circuit(6)
+    adv, fixed, copies = TP.lookup_witness(cs, 4)
+    pk = N.NativeProvingKey(N.NativeCircuit(cs), bg, fixed, copies)
+    proof = N.create_proof(pk, bg, bgl, adv, seed=3, check_mode="SAFE", g2=g2b, s_g2=sg2b)
+    _, vk = P.keygen(cs, P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6), fixed, copies)
+    assert V.verify(vk, g1, g2, s_g2, proof) and N.verify_proof(pk, g2b, sg2b, proof)
+    for pos in (5, 64 * 3 + 40, len(proof) - 200, len(proof) - 10):
+        bad = bytearray(proof); bad[pos] ^= 4
+        assert N.verify_proof(pk, g2b, sg2b, bytes(bad)) == V.verify(vk, g1, g2, s_g2, bytes(bad)) == False
+    assert not N.verify_proof(pk, g2b, sg2b, proof[:-64]) and not N.verify_proof(pk, g2b, sg2b, proof + b"\0" * 32)
+    assert not N.verify_proof(pk, sg2b, g2b, proof)                          # the pairing check really uses s: swapped G2 elements fail
+    # instances + second-phase advice with a challenge
+    cs2 = TP.instance_phase_circuit(6)
+    fn, fixed2, copies2, inst = TP.instance_phase_witness(cs2, 5)
+    pk2 = N.NativeProvingKey(N.NativeCircuit(cs2), bg, fixed2, copies2)
+    p2 = N.create_proof(pk2, bg, bgl, fn, seed=8, instances=inst, check_mode="SAFE", g2=g2b, s_g2=sg2b)
+    assert N.verify_proof(pk2, g2b, sg2b, p2, instances=inst)
+    assert not N.verify_proof(pk2, g2b, sg2b, p2, instances=[[(inst[0][0] + 1) % P.R]])
+    # a witness that violates a gate: the prover still emits bytes, SAFE refuses to return them
+    bad_adv = [a.copy() for a in adv]; bad_adv[0][3] = P.to_mont(12345)
+    with pytest.raises(RuntimeError, match="SAFE"):
+        N.create_proof(pk, bg, bgl, bad_adv, seed=3, check_mode="SAFE", g2=g2b, s_g2=sg2b)
