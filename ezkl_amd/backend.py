@@ -126,6 +126,11 @@ class _Bases:
         _l.check(_l.load().ezkl_hip_bases_download(self.h, _p(out)), "ezkl_hip_bases_download")
         return out
 
+    def prepare(self):
+        """start the window-table precompute now, without waiting (ezkl_hip_bases_prepare)"""
+        _l.check(_l.load().ezkl_hip_bases_prepare(self.h), "ezkl_hip_bases_prepare")
+        return self
+
     def free(self):
         if self.h:
             _l.load().ezkl_hip_bases_free(self.h)

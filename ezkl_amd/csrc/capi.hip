@@ -244,6 +244,11 @@ int ezkl_hip_bases_upload(const void* pts, size_t n, ezkl_bases_t* out) {
     *out = reinterpret_cast<ezkl_bases_t>(b);
     return EZKL_OK;
 }
+int ezkl_hip_bases_prepare(ezkl_bases_t h) {
+    if (!h) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_table_prepare(c, reinterpret_cast<Bases*>(h));
+}
 int ezkl_hip_bases_free(ezkl_bases_t h) {
     if (!h) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include "../../include/ezkl_hip.h"
 #include "field.hpp"
 
@@ -47,7 +48,15 @@ int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1);
         if (_e != hipSuccess) return ::ezkl::set_hip_error(_e, #call, __FILE__, __LINE__); \
     } while (0)
 
+// a roctx range per C-ABI call: `rocprofv3 --marker-trace` shows ezkl_hip_msm_g1_dev, ezkl_hip_ntt_dev ... as named
+// host ranges above the kernels they launch; a push / pop pair costs nanoseconds when no tool is attached
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctxRangePushA(name); }
+    ~RoctxRange() { roctxRangePop(); }
+};
+
 #define EZ_CTX(c)                                   \
+    ::ezkl::RoctxRange _roctx(__func__);            \
     ::ezkl::Ctx* c = ::ezkl::ctx();                 \
     if (!c) return EZKL_ERR_NO_DEVICE;              \
     std::lock_guard<std::recursive_mutex> _lk(c->mu); \
@@ -95,6 +104,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
 int eval_jit_compile_only(const ezkl_program_t* p);
 int ubench(Ctx* c, const char* which, double* out);
 void msm_table_drop(const Bases* b);
+int msm_table_prepare(Ctx* c, const Bases* b);
 int g1_mul_fixed(Ctx* c, hipStream_t st, const void* base_host, const fe_t* scalars, size_t n, void* out_dev);
 int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, void* out_dev);
 void g1_add_affine_host(const void* a, const void* b, void* out);

@@ -13,6 +13,8 @@
 #include <hip/hiprtc.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <functional>
 
@@ -172,8 +174,10 @@ static uint32_t allocate_slots(const ezkl_program_t* p, std::vector<uint32_t>& c
 struct JitKernel {
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
+    std::string key;          // the bytes the hash was taken of (code words + rotations): compared on a hit, a hash collision is a miss
+    bool failed = false;      // negative cache: a program that did not compile is not compiled again on every sweep
 };
-static std::map<uint64_t, JitKernel> g_jit;    // guarded by the ctx mutex
+static std::multimap<uint64_t, JitKernel> g_jit;    // guarded by the ctx mutex
 
 static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
     const uint8_t* p = (const uint8_t*)data;
@@ -233,36 +237,114 @@ static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_
     s += "    st_fe(out + r, v" + std::to_string(last) + ");\n  }\n}\n";
     return s;
 }
-static int jit_get(const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
-    uint64_t h = fnv1a(p->code, (size_t)p->n_instr * 32, 1469598103934665603ull);
-    h = fnv1a(rot.data(), rot.size() * 4, h);
-    auto it = g_jit.find(h);
-    if (it != g_jit.end()) { *fn = it->second.fn; return EZKL_OK; }
-    std::string src = jit_source(p, rot);
-    const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
-    const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 3, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
-    if (r != HIPRTC_SUCCESS) {
-        size_t ls = 0;
-        hiprtcGetProgramLogSize(prog, &ls);
-        std::string log(ls, 0);
-        if (ls) hiprtcGetProgramLog(prog, &log[0]);
-        fprintf(stderr, "[ezkl_hip] eval_h JIT compile failed (%d):\n%.2000s\n", (int)r, log.c_str());
+// Compiled code objects are also kept on disk, keyed by a hash of (program, rotations, architecture, library build): the gate program
+// of a circuit is the same in every `ezkl prove` process, and a one-shot prover (src/execute.rs:1575-1627) should not pay hiprtc
+// (0.2-1 s per program) each time.  Directory: $EZKL_HIP_CACHE_DIR, else $XDG_CACHE_HOME/ezkl_hip, else ~/.cache/ezkl_hip;
+// EZKL_HIP_CACHE_DIR=off disables it.  Files are written to a temporary name and renamed (concurrent provers).
+static std::string jit_cache_dir() {
+    const char* e = getenv("EZKL_HIP_CACHE_DIR");
+    if (e && (!strcmp(e, "off") || !*e)) return "";
+    std::string d;
+    if (e) d = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/ezkl_hip";
+    else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/ezkl_hip";
+    else return "";
+    std::string cur;
+    for (size_t i = 0; i <= d.size(); i++) {       // mkdir -p
+        if (i == d.size() || (d[i] == '/' && i)) {
+            cur = d.substr(0, i);
+            if (!cur.empty()) (void)mkdir(cur.c_str(), 0700);
+        }
+    }
+    return d;
+}
+static std::string jit_arch(Ctx* c) {
+    hipDeviceProp_t prop;
+    if (c && hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.gcnArchName[0]) {
+        std::string a = prop.gcnArchName;          // "gfx950:sramecc+:xnack-" -> "gfx950"
+        return a.substr(0, a.find(':'));
+    }
+    return "gfx950";
+}
+static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
+    std::string key((const char*)p->code, (size_t)p->n_instr * 32);
+    key.append((const char*)rot.data(), rot.size() * 4);
+    const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
+    auto range = g_jit.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+        if (it->second.key != key) continue;       // a 64-bit collision: not this program
+        if (it->second.failed) return EZKL_ERR_HIP;
+        *fn = it->second.fn;
+        return EZKL_OK;
+    }
+    JitKernel k;
+    k.key = key;
+    const std::string arch = jit_arch(c), dir = jit_cache_dir();
+    char name[160];
+    // second, independent hash in the file name + the key length: a stale or colliding file is caught by the embedded key check below
+    snprintf(name, sizeof name, "/evalh_%s_%016llx_%016llx_%zu.co", arch.c_str(), (unsigned long long)h,
+             (unsigned long long)fnv1a(key.data(), key.size(), 0x9e3779b97f4a7c15ull ^ fnv1a(ezkl_hip_version(), strlen(ezkl_hip_version()), 7)), key.size());
+    std::vector<char> bin;
+    bool from_disk = false;
+    if (!dir.empty()) {
+        if (FILE* f = fopen((dir + name).c_str(), "rb")) {
+            fseek(f, 0, SEEK_END);
+            long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (sz > (long)key.size() + 8) {
+                std::vector<char> all((size_t)sz);
+                if (fread(all.data(), 1, (size_t)sz, f) == (size_t)sz && !memcmp(all.data(), key.data(), key.size())) {
+                    bin.assign(all.begin() + key.size(), all.end());
+                    from_disk = true;
+                }
+            }
+            fclose(f);
+        }
+    }
+    if (!from_disk) {
+        std::string src = jit_source(p, rot);
+        const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
+        const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 3, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
+        const std::string archopt = "--offload-arch=" + arch;
+        const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
+        hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t ls = 0;
+            hiprtcGetProgramLogSize(prog, &ls);
+            std::string log(ls, 0);
+            if (ls) hiprtcGetProgramLog(prog, &log[0]);
+            fprintf(stderr, "[ezkl_hip] eval_h JIT compile failed (%d):\n%.2000s\n", (int)r, log.c_str());
+            hiprtcDestroyProgram(&prog);
+            k.failed = true;
+            g_jit.emplace(h, k);
+            return EZKL_ERR_HIP;
+        }
+        size_t cs = 0;
+        hiprtcGetCodeSize(prog, &cs);
+        bin.resize(cs);
+        hiprtcGetCode(prog, bin.data());
         hiprtcDestroyProgram(&prog);
+        if (!dir.empty()) {
+            char tmp[64];
+            snprintf(tmp, sizeof tmp, ".tmp.%d.%llx", (int)getpid(), (unsigned long long)h);
+            const std::string tpath = dir + name + tmp;
+            if (FILE* f = fopen(tpath.c_str(), "wb")) {
+                const bool ok = fwrite(key.data(), 1, key.size(), f) == key.size() && fwrite(bin.data(), 1, bin.size(), f) == bin.size();
+                fclose(f);
+                if (!ok || rename(tpath.c_str(), (dir + name).c_str()) != 0) (void)remove(tpath.c_str());
+            }
+        }
+    }
+    if (hipModuleLoadData(&k.mod, bin.data()) != hipSuccess || hipModuleGetFunction(&k.fn, k.mod, "evalh_jit") != hipSuccess) {
+        (void)hipGetLastError();
+        if (from_disk) (void)remove((dir + name).c_str());     // a damaged cache entry: drop it, the next call compiles
+        k.failed = !from_disk;
+        if (k.failed) g_jit.emplace(h, k);
         return EZKL_ERR_HIP;
     }
-    size_t cs = 0;
-    hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> bin(cs);
-    hiprtcGetCode(prog, bin.data());
-    hiprtcDestroyProgram(&prog);
-    JitKernel k;
-    EZ_HIP(hipModuleLoadData(&k.mod, bin.data()));
-    EZ_HIP(hipModuleGetFunction(&k.fn, k.mod, "evalh_jit"));
-    g_jit[h] = k;
+    g_jit.emplace(h, k);
     *fn = k.fn;
     return EZKL_OK;
 }
@@ -343,7 +425,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     if ((rc = ev_pair(c, "eval_h", &e0, &e1))) return rc;
     const char* mode = getenv("EZKL_EVALH_MODE");                 // "interp" forces the interpreter
     hipFunction_t jfn = nullptr;
-    const bool use_jit = !(mode && !strcmp(mode, "interp")) && jit_get(p, rot, &jfn) == EZKL_OK;
+    const bool use_jit = !(mode && !strcmp(mode, "interp")) && jit_get(c, p, rot, &jfn) == EZKL_OK;
     EZ_HIP(hipEventRecord(e0, st));
     if (use_jit) {
         const fe_t* const* d_cols = a.columns;

@@ -8,16 +8,26 @@
 //   * At first use of a base set we precompute T[w][i] = 2^(c*w) * P_i in HBM (W = ceil(255/c) tables).
 //     Every (point, window) digit then lands in ONE shared bucket set of 2^(c-1) buckets: no per-window
 //     bucket reduction, no final window Horner, and c can be large (few adds per point).
-//   * digits kernel : scalar -> canonical -> (s > r/2 ? r - s, negated) -> signed c-bit digits; one
-//                     (bucket, table index | sign) pair per non-zero digit; bucket histogram by atomics.
-//                     The r - s trick turns witness-like small negative values (src/fieldutils.rs:9-17)
-//                     into single-digit scalars.
-//   * counting sort  : exclusive scan of the histogram (hipCUB), scatter of the pair payloads.
-//   * accumulate     : one lane per bucket walks its run, gathering 64-byte affine points from T and
-//                     mixed-adding into an XYZZ accumulator held in VGPRs (the dominant kernel).
-//                     Buckets longer than HEAVY are handed to a workgroup-per-bucket kernel with an LDS tree.
-//   * reduce         : sum_b (b+1)*B_b via 8-bucket running sums + small scalar multiples, then a
-//                     workgroup tree sum staged through LDS; final to-affine on the device.
+//   * window plan    : W signed-digit windows of BALANCED widths covering 254 bits (2^20 points: 13 windows of 20 / 19 bits),
+//                      chosen by the cost model n*W + 4*#buckets.
+//   * hist / scans / partition : scalar -> canonical -> (s > r/2 ? r - s, negated) -> signed digits (the r - s trick turns
+//                      witness-like small negative values, src/fieldutils.rs:9-17, into one-digit scalars).  No global atomics:
+//                      every workgroup histograms its slice in LDS, a column scan gives (workgroup, partition) start slots, the
+//                      partition pass ranks its (bucket, table index | sign) pairs in 104 KiB of LDS by the LOW bucket bits and
+//                      writes them out in staged order; bucket 0 (+-1 digits, carries) is a partition of its own.
+//   * binsort        : one workgroup per partition, counting sort on the remaining bucket bits in LDS, contiguous output, bucket
+//                      offsets + empty-bucket marks; oversized partitions (skewed witnesses) go through bigsort_{count,scatter}.
+//   * accumulate     : balanced SEGMENTED lanes -- lane t owns sorted pairs [t*L, (t+1)*L) whatever the bucket boundaries, L
+//                      chosen on the device from the number of pairs that exist; 64-byte table records gathered (next record
+//                      prefetched under the current add) and mixed-added (8M + 2S, radix-2^29 lazy limbs, curve29.hpp) into an
+//                      XYZZ accumulator in VGPRs: the dominant kernel.  fixup_boundary folds buckets cut by lane boundaries
+//                      (one thread per boundary), fixup_heavy1/2 the buckets cut more than 16 times.
+//   * reduce         : sum_b weight(b) * B_b with the position split into three bit-fields: reduce1 (column sums), reduce2 (row
+//                      sums, <= 1 wave per SIMD), planes (per-bit plane sums, one workgroup per plane); the last ~40 dependent
+//                      point operations (plane Horner + to-affine) run on the host (host64.hpp): 0.5 us per link there, ~9 us on
+//                      one GPU wave.
+//   * batches        : msm_run_batch pipelines independent MSMs over stream slots so the latency-bound sort / reduce tails of
+//                      one overlap the accumulation of the next.
 // Order of additions differs from the CPU Pippenger, the group element (and its canonical affine bytes) does not.
 #include "common.hpp"
 #include "curve.hpp"
@@ -65,6 +75,8 @@ struct MsmTable {
     g1a_t* tab = nullptr;    // W x n affine: T[w][i] = 2^offset(w) * P_i
     WinPlan wp{0, 0, 0};
     size_t n = 0;
+    hipEvent_t ready = nullptr;   // recorded after the build
+    bool synced = false;          // a host wait on `ready` has happened
 };
 static std::map<const Bases*, MsmTable> g_tables;   // guarded by the ctx mutex
 
@@ -683,9 +695,10 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, cons
     }
 }
 
-static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
-    auto it = g_tables.find(b);
-    if (it != g_tables.end()) { *out = &it->second; return EZKL_OK; }
+// The table is built once per base set: on first use (blocking), or ahead of time by msm_table_prepare (ezkl_hip_bases_prepare) on the
+// library's table stream WITHOUT waiting -- a one-shot prover uploads the SRS, starts the build and goes on reading the proving key;
+// the first MSM only waits for the `ready` event if the build is still running.
+static int table_build(Ctx* c, hipStream_t st, const Bases* b, bool wait) {
     MsmTable t;
     t.n = b->n;
     t.wp = pick_plan(b->n);
@@ -697,14 +710,39 @@ static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
                            t.tab + (size_t)w * t.n, t.n, t.wp.width(w - 1));
     hipLaunchKernelGGL(msm_table_to_r261_kernel, dim3(cdiv((size_t)t.wp.W * t.n, 256)), dim3(256), 0, st, t.tab, (size_t)t.wp.W * t.n);
     EZ_HIP(hipGetLastError());
-    EZ_HIP(hipStreamSynchronize(st));
+    EZ_HIP(hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+    EZ_HIP(hipEventRecord(t.ready, st));
+    if (wait) {
+        EZ_HIP(hipStreamSynchronize(st));
+        t.synced = true;
+    }
     g_tables[b] = t;
-    *out = &g_tables[b];
     return EZKL_OK;
+}
+static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
+    auto it = g_tables.find(b);
+    if (it == g_tables.end()) {
+        int rc = table_build(c, st, b, true);
+        if (rc) return rc;
+        it = g_tables.find(b);
+    }
+    if (!it->second.synced) {                     // prepared ahead of time: make sure the build has finished
+        EZ_HIP(hipEventSynchronize(it->second.ready));
+        it->second.synced = true;
+    }
+    *out = &it->second;
+    return EZKL_OK;
+}
+static hipStream_t g_table_stream = nullptr;
+int msm_table_prepare(Ctx* c, const Bases* b) {
+    if (g_tables.count(b)) return EZKL_OK;
+    if (!g_table_stream) EZ_HIP(hipStreamCreateWithFlags(&g_table_stream, hipStreamNonBlocking));
+    return table_build(c, g_table_stream, b, false);
 }
 void msm_table_drop(const Bases* b) {
     auto it = g_tables.find(b);
     if (it != g_tables.end()) {
+        if (it->second.ready) { (void)hipEventSynchronize(it->second.ready); (void)hipEventDestroy(it->second.ready); }
         (void)hipFree(it->second.tab);
         g_tables.erase(it);
     }

@@ -13,6 +13,10 @@
 #include <random>
 #include <set>
 #include <unordered_map>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "ezkl_hip.hpp"
 #include "ezkl_prover.h"
 #include "hostfield.hpp"
@@ -657,9 +661,6 @@ static Fe vk_digest(const ProvingKey& pk) {
     return Fe::from_canonical(reduce_fr(from_be32(h.data())));
 }
 static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies) {
-    // the vk digest packs these counts into single bytes (as the Python restatement does)
-    invalid(cs.n_advice > 255 || cs.n_fixed > 255 || cs.perm.size() > 255 || cs.n_instance > 255 || cs.n_challenges > 255 || cs.lookups.size() > 255 || cs.degree > 255,
-            "column / argument counts above 255 are not supported by the vk digest");
     const uint32_t n = cs.n, k = cs.k;
     Backend be(k, n, g, nullptr, cs.shard);
     auto pk = std::make_unique<ProvingKey>();
@@ -831,6 +832,114 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
     get_vec(pk->sigma_values, cs.perm.size(), n); get_vec(pk->sigma_polys, cs.perm.size(), n); get_vec(pk->sigma_cosets, cs.perm.size(), ne);
     invalid(off != len, "trailing bytes in the proving key");
     // derived columns that the file does not hold
+    pk->omega_col = be.omega_powers();
+    std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
+    xcoef[1] = FR.one;
+    pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
+    pk->digest = vk_digest(*pk);
+    return pk;
+}
+
+// `load_pk` for a one-shot prover (/root/reference/src/pfsys/mod.rs:615-636, called from execute::prove): the key file is mapped, only
+// what cannot be recomputed faster than it can be read goes over PCIe -- the n-row `fixed_values` and `permutations` sections
+// (32 B x n per column); the coefficient forms, the extended cosets (the bulk of the file: 2^(ext_k - k) x larger) and l0 / l_last /
+// l_active are recomputed on the device with the kernels keygen uses (an iNTT + a coset NTT per column: milliseconds, against a read
+// of GiBs at k = 20).  The section headers are still checked against the constraint system; the commitments come from the file.
+static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char* path) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) throw Error(EZKL_ERR_INVALID, std::string("cannot open proving key ") + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); throw Error(EZKL_ERR_INVALID, "cannot stat proving key"); }
+    const size_t len = (size_t)sb.st_size;
+    void* map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) throw Error(EZKL_ERR_INVALID, "cannot map proving key");
+    struct Unmap { void* p; size_t l; ~Unmap() { munmap(p, l); } } unmap{map, len};
+    (void)madvise(map, len, MADV_SEQUENTIAL);
+    const uint8_t* buf = (const uint8_t*)map;
+    Backend be(cs.k, cs.n, nullptr, nullptr);
+    size_t off = 0;
+    auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
+    need(7);
+    invalid(buf[0] != 3, "unsupported key version");
+    invalid(buf[1] != cs.k, "key was made for another k");
+    uint32_t nf = 0;
+    for (int i = 0; i < 4; i++) nf |= (uint32_t)buf[3 + i] << (8 * i);
+    invalid(nf != cs.n_fixed, "key has another number of fixed columns");
+    off = 7;
+    auto pk = std::make_unique<ProvingKey>();
+    pk->cs = &cs;
+    const size_t n = cs.n, ne = (size_t)1 << cs.ext_k, np = cs.perm.size();
+    need(64 * (nf + np));
+    pk->fixed_commitments.resize(nf);
+    pk->sigma_commitments.resize(np);
+    if (nf) std::memcpy(pk->fixed_commitments.data(), buf + off, 64 * (size_t)nf);
+    off += 64 * (size_t)nf;
+    if (np) std::memcpy(pk->sigma_commitments.data(), buf + off, 64 * np);
+    off += 64 * np;
+    const size_t sel_bytes = (size_t)cs.n_selectors * ((cs.n + 7) / 8);
+    need(sel_bytes);
+    pk->selector_bits.assign(buf + off, buf + off + sel_bytes);
+    off += sel_bytes;
+    auto be32 = [&]() {
+        need(4);
+        uint32_t v = ((uint32_t)buf[off] << 24) | ((uint32_t)buf[off + 1] << 16) | ((uint32_t)buf[off + 2] << 8) | buf[off + 3];
+        off += 4;
+        return v;
+    };
+    auto skip_poly = [&](size_t m) {
+        invalid(be32() != m, "polynomial of unexpected length in the key");
+        need(32 * m);
+        off += 32 * m;
+    };
+    auto vec_header = [&](size_t count, size_t m) {
+        invalid(be32() != count, "vector of unexpected length in the key");
+        for (size_t i = 0; i < count; i++) invalid(be32() != m, "polynomial of unexpected length in the key");
+    };
+    auto load_values = [&](std::vector<Col>& cols, size_t count) {
+        vec_header(count, n);
+        for (size_t i = 0; i < count; i++) {
+            invalid(be32() != n, "polynomial of unexpected length in the key");
+            need(32 * n);
+            const uint64_t* e = (const uint64_t*)(buf + off);       // canonical residues: the top limb decides all but 2^-60 of the cases
+            for (size_t r = 0; r < n; r++) {
+                const uint64_t top = e[4 * r + 3];
+                if (top >= FR.p[3]) {
+                    U256 v;
+                    std::memcpy(v.data(), e + 4 * r, 32);
+                    invalid(cmp(v, FR.p) >= 0, "non-canonical field element in the key");
+                }
+            }
+            cols.push_back(be.upload(buf + off, n));
+            off += 32 * n;
+        }
+    };
+    auto skip_vec = [&](size_t count, size_t m) {
+        vec_header(count, m);
+        for (size_t i = 0; i < count; i++) skip_poly(m);
+    };
+    skip_poly(ne); skip_poly(ne); skip_poly(ne);                    // l0, l_last, l_active_row: recomputed
+    load_values(pk->fixed_values, nf);
+    skip_vec(nf, n); skip_vec(nf, ne);
+    load_values(pk->sigma_values, np);
+    skip_vec(np, n); skip_vec(np, ne);
+    invalid(off != len, "trailing bytes in the proving key");
+    for (auto& v : pk->fixed_values) {
+        pk->fixed_polys.push_back(be.lagrange_to_coeff(v));
+        pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
+    }
+    for (auto& v : pk->sigma_values) {
+        pk->sigma_polys.push_back(be.lagrange_to_coeff(v));
+        pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+    }
+    auto lag = [&](uint32_t lo, uint32_t hi) {
+        std::vector<U256> v(n, U256{0, 0, 0, 0});
+        for (uint32_t r = lo; r < hi; r++) v[r] = FR.one;
+        return be.coeff_to_extended(be.lagrange_to_coeff(be.upload(v)), cs.ext_k);
+    };
+    pk->l0 = lag(0, 1);
+    pk->l_last = lag(cs.usable, cs.usable + 1);
+    pk->l_active = lag(0, cs.usable);
     pk->omega_col = be.omega_powers();
     std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
     xcoef[1] = FR.one;
@@ -1861,6 +1970,10 @@ int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len) {
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out) {
     if (!cs || !buf || !out) return EZKL_ERR_INVALID;
     return guarded([&] { *out = new ezkl_prover_pk{pk_read(*cs->cs, (const uint8_t*)buf, len)}; });
+}
+int ezkl_prover_pk_read_file(ezkl_cs_t cs, const char* path, ezkl_pk_t* out) {
+    if (!cs || !path || !out) return EZKL_ERR_INVALID;
+    return guarded([&] { *out = new ezkl_prover_pk{pk_read_file(*cs->cs, path)}; });
 }
 int ezkl_prover_pk_set_selectors(ezkl_pk_t pk, const void* bits, size_t len) {
     return guarded([&] {

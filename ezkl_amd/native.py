@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_sweep_gather",
-           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_vk",
+           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -149,6 +149,17 @@ class NativeProvingKey:
         self.h = C.c_void_p()
         data = bytes(data)
         _check(load().ezkl_prover_pk_read(circuit.h, data, C.c_size_t(len(data)), C.byref(self.h)), "ezkl_prover_pk_read")
+        if recommit is not None:
+            _check(load().ezkl_prover_pk_recommit(self.h, recommit.h), "ezkl_prover_pk_recommit")
+        return self
+
+    @classmethod
+    def from_file(cls, circuit, path, recommit=None):
+        """load_pk of a one-shot prover: the file is mapped and only its n-row sections are uploaded (ezkl_prover_pk_read_file)"""
+        self = cls.__new__(cls)
+        self.circuit = circuit
+        self.h = C.c_void_p()
+        _check(load().ezkl_prover_pk_read_file(circuit.h, os.fsencode(path), C.byref(self.h)), "ezkl_prover_pk_read_file")
         if recommit is not None:
             _check(load().ezkl_prover_pk_recommit(self.h, recommit.h), "ezkl_prover_pk_recommit")
         return self

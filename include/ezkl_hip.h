@@ -71,6 +71,11 @@ int ezkl_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
  *      in-tree call site /root/reference/src/circuit/modules/polycommit.rs:71 ---- */
 /* bases: n affine points, host pointer, copied to HBM once (SRS load time, src/pfsys/srs.rs:40-47) */
 int ezkl_hip_bases_upload(const void* affine_pts, size_t n, ezkl_bases_t* out_handle);
+/* start the per-base-set precompute (the window tables of msm.hip, ~55 ms for 2^20 points) on a library stream WITHOUT waiting: a
+ * one-shot `prove` (src/execute.rs:1575-1627) uploads the SRS, calls this, and reads the proving key while the tables are built.
+ * Optional: the first MSM on a base set builds them itself (blocking) when this was not called.  The icicle build does the analogous
+ * work at ParamsKZG::read time. */
+int ezkl_hip_bases_prepare(ezkl_bases_t h);
 int ezkl_hip_bases_free(ezkl_bases_t h);
 size_t ezkl_hip_bases_len(ezkl_bases_t h);
 /* synthetic base set for benchmarks/tests (no public SRS without network, src/pfsys/srs.rs:10-11):

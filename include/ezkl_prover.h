@@ -85,6 +85,10 @@ int ezkl_prover_pk_free(ezkl_pk_t pk);
  * every element is checked to be a canonical residue; columns go straight to HBM. */
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len);
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out);
+/* load_pk for a one-shot `prove`: maps the key file and uploads only its n-row sections (fixed values, permutations); coefficient forms,
+ * extended cosets and l0 / l_last / l_active are recomputed on the device instead of being read (the cosets are most of the file:
+ * 4 GB of a 4.03 GB key at k = 20, ext_k = 21).  Same checks of the section headers as ezkl_prover_pk_read. */
+int ezkl_prover_pk_read_file(ezkl_cs_t cs, const char* path, ezkl_pk_t* out);
 /* The selector activations of the circuit (n_selectors rows of 2^k bits, bit-packed little-endian as in halo2's vk files): what
  * keygen's caller learned from synthesis; only carried into ezkl_prover_pk_write so that the key file is complete. */
 int ezkl_prover_pk_set_selectors(ezkl_pk_t pk, const void* bits, size_t len);

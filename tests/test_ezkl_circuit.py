@@ -169,6 +169,10 @@ def test_gpu_native_prover_on_the_reference_pk_file(hip, fx):
     adv, inst, _ = FX.witness(fx)
     proof = NV.create_proof(pk, bg, bgl, FX.mont_cols(adv), seed=11, instances=inst)
     assert len(proof) == 14816
+    # the one-shot loader (mapped file, n-row sections only, cosets recomputed on the device) yields the same key: same proof bytes
+    pk_f = NV.NativeProvingKey.from_file(circ, os.path.join(FX.G, "pk_k6.key"), recommit=bg)
+    assert pk_f.to_bytes() == pk.to_bytes()
+    assert NV.create_proof(pk_f, bg, bgl, FX.mont_cols(adv), seed=11, instances=inst) == proof
     fc, pc, digest = pk.vk()
     vk = P.VerifyingKey()
     vk.cs = cs

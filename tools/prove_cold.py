@@ -7,7 +7,7 @@ warm: library init, base-set upload, window-table precompute, NTT plans and the 
     python tools/prove_cold.py run DIR       -> one JSON line with the stage split
 
 Artefacts in DIR: kzg.srs, pk.key, circuit.ezcs (the constraint-system blob = what re-running `configure` yields in ezkl),
-witness.npz (advice columns per phase as the prover's synthesis would produce them + instances), meta.json."""
+adv_<phase>_<column>.npy (advice columns as the prover's synthesis would produce them), meta.json (instances, seed)."""
 import json
 import os
 import sys
@@ -30,7 +30,7 @@ def run(d):
     t0 = time.time()
     srs = codecs.read_srs(open(os.path.join(d, "kzg.srs"), "rb").read())
     t["srs_read"] = time.time() - t0
-    t0 = time.time(); bg, bgl = B.Bases(srs["g"]), B.Bases(srs["g_lagrange"]); t["srs_to_hbm"] = time.time() - t0
+    t0 = time.time(); bg, bgl = B.Bases(srs["g"]).prepare(), B.Bases(srs["g_lagrange"]).prepare(); t["srs_to_hbm"] = time.time() - t0   # tables build in the background
     t0 = time.time()
     blob = open(os.path.join(d, "circuit.ezcs"), "rb").read()
     h = C.c_void_p()
@@ -39,11 +39,16 @@ def run(d):
     circ.h = h
     circ.cs = type("CS", (), dict(n=1 << meta["k"], n_fixed=meta["n_fixed"], perm=[None] * meta["n_perm"], advice_phase=meta["advice_phase"]))()
     t["circuit_parse"] = time.time() - t0
-    t0 = time.time(); pk = NV.NativeProvingKey.from_bytes(circ, open(os.path.join(d, "pk.key"), "rb").read()); t["pk_read_to_hbm"] = time.time() - t0
     t0 = time.time()
-    w = np.load(os.path.join(d, "witness.npz"))
-    phases = sorted({int(kk.split("_")[1]) for kk in w.files if kk.startswith("adv_")})
-    cols = {ph: {int(kk.split("_")[2]): w[kk] for kk in w.files if kk.startswith("adv_%d_" % ph)} for ph in phases}
+    if os.environ.get("EZKL_COLD_FULL_PK_READ"):     # every section of the file, as halo2's ProvingKey::read does
+        pk = NV.NativeProvingKey.from_bytes(circ, open(os.path.join(d, "pk.key"), "rb").read())
+    else:
+        pk = NV.NativeProvingKey.from_file(circ, os.path.join(d, "pk.key"))
+    t["pk_read_to_hbm"] = time.time() - t0
+    t0 = time.time()
+    files = sorted(f for f in os.listdir(d) if f.startswith("adv_") and f.endswith(".npy"))
+    phases = sorted({int(f.split("_")[1]) for f in files})
+    cols = {ph: {int(f.split("_")[2][:-4]): np.load(os.path.join(d, f), mmap_mode="r") for f in files if f.startswith("adv_%d_" % ph)} for ph in phases}
     inst = [[int(x) for x in col] for col in meta["instances"]]
     t["witness_read"] = time.time() - t0
     if len(phases) > 1:
@@ -73,7 +78,9 @@ def write(d, k, g, gl, g2_ints, s_g2_ints, cs, pk_bytes, advice_cols_by_phase, i
     open(os.path.join(d, "kzg.srs"), "wb").write(codecs.write_srs(dict(k=k, g=g, g_lagrange=gl, g2=g2b(g2_ints), s_g2=g2b(s_g2_ints))))
     open(os.path.join(d, "pk.key"), "wb").write(pk_bytes)
     open(os.path.join(d, "circuit.ezcs"), "wb").write(P.serialize_cs(cs))
-    np.savez(os.path.join(d, "witness.npz"), **{"adv_%d_%d" % (ph, c): a for ph, cols in advice_cols_by_phase.items() for c, a in cols.items()})
+    for ph, cols in advice_cols_by_phase.items():           # the witness columns synthesis hands to create_proof, one mappable file each
+        for c, a in cols.items():
+            np.save(os.path.join(d, "adv_%d_%d.npy" % (ph, c)), np.ascontiguousarray(a, np.uint64))
     json.dump(dict(k=k, n_fixed=cs.n_fixed, n_perm=len(cs.perm), advice_phase=cs.advice_phase, instances=[[int(v) for v in col] for col in instances], seed=seed),
               open(os.path.join(d, "meta.json"), "w"))
 
