@@ -81,6 +81,7 @@ struct ConstraintSystem {
     uint32_t blinding = 0, minimum_degree = 0;           // 0 = derive / none (blob version 1)
     uint32_t n_selectors = 0;                             // halo2 selectors behind the fixed columns: sizes the selector section of vk / pk files
     bool queries_given = false;                           // halo2's order of first query (blob version 2)
+    bool advice_by_pointer = false;                       // ezkl_prover_cs_set_advice_by_pointer
     std::vector<uint8_t> unblinded;                       // per advice column: unusable rows hold Blind::default() = 1
     std::array<uint8_t, 32> blob_hash{};                  // keccak256 of the blob: binds gates / lookups / queries into the vk digest
     std::vector<Query> advice_queries, fixed_queries, instance_queries;
@@ -1342,16 +1343,21 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         std::vector<std::vector<U256>> host;
         std::vector<const void*> src(cs.n_advice, nullptr);
         if (advice_fn) {
-            host.resize(cs.n_advice);
             std::vector<void*> dst(cs.n_advice, nullptr);
-            for (uint32_t c : idxs) {
-                host[c].assign(n, U256{0, 0, 0, 0});
-                dst[c] = host[c].data();
+            if (!cs.advice_by_pointer) {
+                host.resize(cs.n_advice);
+                for (uint32_t c : idxs) {
+                    host[c].assign(n, U256{0, 0, 0, 0});
+                    dst[c] = host[c].data();
+                }
             }
             std::vector<U256> ch;
             for (auto& f : user_chal) ch.push_back(f.v);
             invalid(advice_fn(advice_user, phase, ch.data(), (uint32_t)ch.size(), dst.data()) != 0, "advice callback failed");
-            for (uint32_t c : idxs) src[c] = host[c].data();
+            for (uint32_t c : idxs) {
+                invalid(dst[c] == nullptr, "advice callback left a column of this phase unset");
+                src[c] = dst[c];                              // by pointer: the callee's own buffers, valid until create_proof returns
+            }
         } else {
             invalid(advice == nullptr, "no advice columns");
             for (uint32_t c : idxs) src[c] = advice[c];
@@ -1944,6 +1950,11 @@ int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t h, ezkl_gather_fn gather, void* us
     if (!h) return EZKL_ERR_INVALID;
     h->cs->shard.gather = gather;
     h->cs->shard.gather_user = user;
+    return EZKL_OK;
+}
+int ezkl_prover_cs_set_advice_by_pointer(ezkl_cs_t h, int on) {
+    if (!h) return EZKL_ERR_INVALID;
+    h->cs->advice_by_pointer = on != 0;
     return EZKL_OK;
 }
 int ezkl_prover_cs_sharded_sweeps(ezkl_cs_t h, uint64_t* out) {

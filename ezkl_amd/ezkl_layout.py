@@ -259,9 +259,13 @@ def ints_to_limbs(colv):
     return out
 
 
-def cols_to_mont(cols, gpu=None):
+_PINNED = []                                               # page-locked buffers handed out by cols_to_mont(pinned=True): kept alive here
+
+
+def cols_to_mont(cols, gpu=None, pinned=False):
     """columns of field elements -> (n, 4) u64 Montgomery arrays.  With gpu = ezkl_amd.backend the canonical limbs are multiplied
-    by R^2 on the device (one Montgomery product per element); without, element by element in Python."""
+    by R^2 on the device (one Montgomery product per element); without, element by element in Python.  pinned: the arrays live in
+    page-locked host memory (ezkl_hip_host_malloc), what a prover's synthesis should fill so that uploads run at PCIe speed."""
     if gpu is None:
         return [ints_to_mont(c) for c in cols]
     r2 = P.to_mont((1 << 256) % R)
@@ -269,7 +273,15 @@ def cols_to_mont(cols, gpu=None):
     for c in cols:
         buf = gpu.DeviceBuffer.from_numpy(ints_to_limbs(c))
         gpu.vec_scale(buf.ptr, r2, buf.ptr, len(c))
-        out.append(buf.to_numpy(shape=(len(c), 4)).copy())
+        a = buf.to_numpy(shape=(len(c), 4))
+        if pinned:
+            pa = gpu.PinnedArray((len(c), 4))
+            pa.array[:] = a
+            _PINNED.append(pa)
+            a = pa.array
+        else:
+            a = a.copy()
+        out.append(a)
     return out
 
 

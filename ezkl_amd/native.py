@@ -13,7 +13,7 @@ from . import plonk as _pl
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_sweep_gather",
+SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
@@ -223,6 +223,7 @@ def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(
     keep = []
     adv_arr, adv_cb = None, C.cast(None, ADVICE_FN)
     if callable(advice_values):
+        _check(load().ezkl_prover_cs_set_advice_by_pointer(pk.circuit.h, 1), "ezkl_prover_cs_set_advice_by_pointer")
         def _cb(_user, phase, chal_ptr, n_chal, cols_ptr):
             try:
                 ch = np.ctypeslib.as_array(C.cast(chal_ptr, C.POINTER(C.c_uint64)), shape=(n_chal, 4)) if n_chal else np.zeros((0, 4), np.uint64)
@@ -230,7 +231,10 @@ def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(
                 for c, a in vals.items():
                     if cs.advice_phase[c] != phase:
                         continue
-                    C.memmove(cols_ptr[c], np.ascontiguousarray(a, np.uint64).ctypes.data, 32 * n)
+                    a = np.ascontiguousarray(a, np.uint64)
+                    assert a.size == 4 * n
+                    keep.append(a)                    # by pointer: the array must outlive the call
+                    cols_ptr[c] = a.ctypes.data
                 return 0
             except Exception:                         # never unwind through the C frames
                 import traceback

@@ -72,6 +72,12 @@ typedef int (*ezkl_gather_fn)(void* user, void* buf_dev, size_t total_bytes, siz
 int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t cs, ezkl_gather_fn gather, void* user);
 int ezkl_prover_cs_sharded_sweeps(ezkl_cs_t cs, uint64_t* out);
 
+/* How advice_fn hands over its columns.  Off (default): `columns[c]` points at a zeroed host buffer of 2^k x 32 B the callback fills.
+ * On: `columns` arrives as an array of NULL pointers and the callback STORES, for every column c of the phase, a pointer to its own
+ * host column (it may be page-locked, ezkl_hip_host_malloc) that stays valid until create_proof returns: no allocation, no copy --
+ * what a fork does with the advice vectors synthesize() has just filled. */
+int ezkl_prover_cs_set_advice_by_pointer(ezkl_cs_t cs, int on);
+
 /* ---- keygen (keygen_vk + keygen_pk): fixed columns and copy constraints -> resident proving key ----
  * fixed_values: n_fixed host pointers, 2^k x 32 B Montgomery Fr each.  copies: n_copies x {colpos_a, row_a, colpos_b, row_b}
  * with colpos indexing the permutation column list.  g = the SRS in coefficient basis (ParamsKZG::g).  The cs handle is

@@ -41,7 +41,7 @@ def build(kind, k, gpu=None, seed=1, **kw):
             if key not in cache:
                 cols = fn(phase, chal)
                 idx = sorted(cols)
-                cache[key] = dict(zip(idx, EL.cols_to_mont([cols[i] for i in idx], gpu)))
+                cache[key] = dict(zip(idx, EL.cols_to_mont([cols[i] for i in idx], gpu, pinned=gpu is not None)))
             return cache[key]
         info = dict(circuit="accum_einsum_matmul (benches/accum_einsum_matmul.rs) ij,jk->ik len %d, Freivalds, k=%d" % (L, k), rows_used=rows)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=advice, instances=[], info=info)
