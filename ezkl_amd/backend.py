@@ -716,3 +716,52 @@ def lookup_grand_sum(k, input_cols, table_col, m_col, beta):
 
 def _from_mont_int(a):
     return int.from_bytes(np.ascontiguousarray(a, np.uint64).tobytes(), "little") * pow(_MONT, -1, _R) % _R
+
+
+# ---- multi-GPU: the library's RCCL communicator (csrc/comm.hip) --------------------------------------------------------------
+def comm_unique_id():
+    out = (C.c_uint8 * 128)()
+    _l.check(_l.load().ezkl_hip_comm_unique_id(out), "ezkl_hip_comm_unique_id")
+    return bytes(out)
+
+
+def comm_init(unique_id, world, rank):
+    _l.check(_l.load().ezkl_hip_comm_init(bytes(unique_id), C.c_int(world), C.c_int(rank)), "ezkl_hip_comm_init")
+
+
+def comm_init_from_torch(dist, device):
+    """rank 0 creates the id, torch.distributed (any backend) broadcasts its 128 bytes, every rank joins"""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        t = torch.tensor(list(comm_unique_id()), dtype=torch.uint8, device=device)
+    dist.broadcast(t, 0)
+    comm_init(bytes(t.cpu().numpy().tobytes()), world, rank)
+
+
+def comm_info():
+    w, r = C.c_int(0), C.c_int(0)
+    _l.check(_l.load().ezkl_hip_comm_info(C.byref(w), C.byref(r)), "ezkl_hip_comm_info")
+    return w.value, r.value
+
+
+def comm_destroy():
+    _l.check(_l.load().ezkl_hip_comm_destroy(), "ezkl_hip_comm_destroy")
+
+
+def comm_allgather_dev(ptr, total_bytes):
+    _l.check(_l.load().ezkl_hip_comm_allgather_dev(_vp(ptr), C.c_size_t(total_bytes)), "ezkl_hip_comm_allgather_dev")
+
+
+def comm_fold_points(points):
+    """(count, 8) u64 partial sums -> sums over all ranks (in a copy)"""
+    a = np.ascontiguousarray(points, np.uint64).copy()
+    _l.check(_l.load().ezkl_hip_comm_fold_points(_p(a), C.c_uint32(a.shape[0])), "ezkl_hip_comm_fold_points")
+    return a
+
+
+def comm_alltoall_dev(send_ptr, send_off, send_len, recv_ptr, recv_off, recv_len):
+    arr = lambda v: (C.c_size_t * len(v))(*[int(x) for x in v])
+    _l.check(_l.load().ezkl_hip_comm_alltoall_dev(_vp(send_ptr), arr(send_off), arr(send_len), _vp(recv_ptr), arr(recv_off), arr(recv_len)),
+             "ezkl_hip_comm_alltoall_dev")

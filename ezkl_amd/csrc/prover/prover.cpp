@@ -1946,6 +1946,23 @@ int ezkl_prover_cs_set_shard(ezkl_cs_t h, uint32_t lo, uint32_t hi, ezkl_fold_fn
     h->cs->shard = s;
     return EZKL_OK;
 }
+// the same sharding with the library's own RCCL communicator (include/ezkl_hip.h ezkl_hip_comm_*): no caller callbacks, no torch
+static int comm_fold(void*, void* points, uint32_t count) { return ezkl_hip_comm_fold_points(points, count); }
+static int comm_gather(void*, void* buf, size_t total, size_t, size_t) { return ezkl_hip_comm_allgather_dev(buf, total); }
+int ezkl_prover_cs_set_shard_comm(ezkl_cs_t h) {
+    if (!h) return EZKL_ERR_INVALID;
+    int world = 0, rank = 0;
+    int rc = ezkl_hip_comm_info(&world, &rank);
+    if (rc) return rc;
+    if (world < 1) return EZKL_ERR_INVALID;               // ezkl_hip_comm_init first
+    const uint32_t n = h->cs->n;
+    const uint32_t base = n / (uint32_t)world, rem = n % (uint32_t)world;
+    const uint32_t lo = (uint32_t)rank * base + std::min((uint32_t)rank, rem), hi = lo + base + ((uint32_t)rank < rem ? 1 : 0);
+    rc = ezkl_prover_cs_set_shard(h, lo, hi, comm_fold, nullptr);
+    if (rc) return rc;
+    if (world > 1 && (world & (world - 1)) == 0 && n % (uint32_t)world == 0) return ezkl_prover_cs_set_sweep_gather(h, comm_gather, nullptr);
+    return EZKL_OK;
+}
 int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t h, ezkl_gather_fn gather, void* user) {
     if (!h) return EZKL_ERR_INVALID;
     h->cs->shard.gather = gather;

@@ -212,6 +212,23 @@ int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out_dev, void* stream)
  * checks that a program lowers and compiles (column pointers are not dereferenced; no GPU needed) */
 int ezkl_hip_eval_h_check(const ezkl_program_t* prog);
 
+/* ---- multi-GPU: the collectives of the sharded prove path, RCCL over xGMI on the library's device pointers (csrc/comm.hip) ----
+ * One process per GPU (ezkl_hip_init picks the device).  The reference has no multi-GPU path (icicle is single-GPU), so
+ * these replace nothing: a launcher creates the id on rank 0 (ezkl_hip_comm_unique_id), hands the 128 bytes to every rank by whatever
+ * means it has (env, file, MPI, torch.distributed), and every rank calls ezkl_hip_comm_init.  librccl is dlopen'ed on first use.
+ * EZKL_ERR_UNSUPPORTED: RCCL cannot be loaded.  MSM partials: gather-then-add (RCCL has no elliptic-curve reduce op). */
+int ezkl_hip_comm_unique_id(void* out128);
+int ezkl_hip_comm_init(const void* id128, int world, int rank);
+int ezkl_hip_comm_info(int* world, int* rank);            /* world = 0: no communicator */
+int ezkl_hip_comm_destroy(void);
+/* in-place all_gather of a device buffer made of `world` equal slices (rank r wrote slice r): the row-sharded quotient sweep's h */
+int ezkl_hip_comm_allgather_dev(void* buf_dev, size_t total_bytes);
+/* one commit batch: `count` 64-byte affine Montgomery partial sums (host) -> their sums over all ranks, in place, on every rank */
+int ezkl_hip_comm_fold_points(void* points_host, uint32_t count);
+/* all-to-all on device pointers (per-peer byte offsets / lengths): columns transformed by their owner -> the row shards of the sweep */
+int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, const size_t* send_len, void* recv_dev, const size_t* recv_off,
+                               const size_t* recv_len);
+
 /* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
 /* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */
 int ezkl_hip_last_kernel_ms(const char* which, float* out_ms);

@@ -63,6 +63,11 @@ int ezkl_prover_cs_info(ezkl_cs_t cs, uint32_t out[8]);
  * The randomness must be the same on every rank (a shared `seed`, or an rng callback that is). */
 typedef int (*ezkl_fold_fn)(void* user, void* points, uint32_t count);
 int ezkl_prover_cs_set_shard(ezkl_cs_t cs, uint32_t lo, uint32_t hi, ezkl_fold_fn fold, void* user);
+/* The same, over the library's own RCCL communicator (ezkl_hip_comm_init, include/ezkl_hip.h): the slice is this rank's share of the
+ * 2^k points, commit batches are folded by ezkl_hip_comm_fold_points (all_gather of the 64-byte partials + group law), and with a
+ * power-of-two world the quotient sweep is sharded by rows with h all_gathered in place on the device (ezkl_hip_comm_allgather_dev).
+ * No callbacks, no torch: what a fork's worker process (one per GPU) calls after exchanging the unique id. */
+int ezkl_prover_cs_set_shard_comm(ezkl_cs_t cs);
 /* Optional, on top of set_shard with equal power-of-two slices: the quotient sweep sharded by ROWS.  Each rank evaluates
  * 2^ext_k / world rows of the quotient numerator (the gate program rewritten per shard: every (column, rotation) it reads is a
  * window of the resident coset column) and calls `gather`, which must make the whole device buffer `buf` (total_bytes) identical

@@ -1,0 +1,39 @@
+"""The library's RCCL communicator (csrc/comm.hip) on the hardware available to the tests: ONE GPU, so world = 1 -- every entry point
+runs through librccl (unique id, ncclCommInitRank, ncclAllGather, grouped send / recv with only the self slice), and the C++ host
+prover sharded over it emits the unsharded proof.  World > 1 needs one GPU per rank (RCCL refuses two ranks on a device); the same
+sharding logic is covered with gloo on CPU (tests/test_dist_cpu.py) and with two gloo ranks sharing the GPU (tests/test_plonk.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
+    from ezkl_amd import backend as B, native as NV, plonk as P
+    import test_plonk as TP
+    assert B.comm_info() == (0, 0)
+    B.comm_init(B.comm_unique_id(), 1, 0)
+    try:
+        assert B.comm_info() == (1, 0)
+        pts = np.ascontiguousarray(golden_srs["g"][:5])
+        assert (B.comm_fold_points(pts) == pts).all()                      # one rank: the fold is the identity
+        buf = B.DeviceBuffer.from_numpy(np.arange(1024, dtype=np.uint64))
+        B.comm_allgather_dev(buf.ptr, buf.nbytes)
+        assert (buf.to_numpy() == np.arange(1024, dtype=np.uint64)).all()
+        dst = B.DeviceBuffer(buf.nbytes)
+        B.comm_alltoall_dev(buf.ptr, [256], [4096], dst.ptr, [512], [4096])
+        got = dst.to_numpy()
+        assert (got[64:64 + 512] == np.arange(32, 32 + 512, dtype=np.uint64)).all()
+        # the C++ host prover over the library communicator: same bytes as the unsharded prover
+        cs = TP.lookup_circuit(6)
+        adv, fixed, copies = TP.lookup_witness(cs, 4)
+        bg, bgl = B.Bases(golden_srs["g"]), B.Bases(golden_srs["g_lagrange"])
+        plain = NV.NativeProvingKey(NV.NativeCircuit(cs), bg, fixed, copies)
+        want = NV.create_proof(plain, bg, bgl, adv, seed=9)
+        nc = NV.NativeCircuit(cs)
+        assert nc.set_shard_comm() == (0, cs.n)
+        pk = NV.NativeProvingKey(nc, bg, fixed, copies)
+        assert NV.create_proof(pk, bg, bgl, adv, seed=9) == want
+    finally:
+        B.comm_destroy()
+    assert B.comm_info() == (0, 0)

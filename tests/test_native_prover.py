@@ -339,6 +339,14 @@ def test_native_verifier_agrees_with_the_oracle_verifier(hip, golden_srs):
     assert N.verify_proof(pk2, g2b, sg2b, p2, instances=inst)
     assert not N.verify_proof(pk2, g2b, sg2b, p2, instances=[[(inst[0][0] + 1) % P.R]])
     # a witness that violates a gate: the prover still emits bytes, SAFE refuses to return them
-    bad_adv = [a.copy() for a in adv]; bad_adv[0][3] = P.to_mont(12345)
+    cs3 = TP.mul_add_circuit(6)
+    adv3, fixed3, copies3 = TP.witness(cs3, 2)
+    pk3 = N.NativeProvingKey(N.NativeCircuit(cs3), bg, fixed3, copies3)
+    assert N.verify_proof(pk3, g2b, sg2b, N.create_proof(pk3, bg, bgl, adv3, seed=3, check_mode="SAFE", g2=g2b, s_g2=sg2b))
+    bad_adv = [a.copy() for a in adv3]; bad_adv[2][3] = P.to_mont(12345)
     with pytest.raises(RuntimeError, match="SAFE"):
-        N.create_proof(pk, bg, bgl, bad_adv, seed=3, check_mode="SAFE", g2=g2b, s_g2=sg2b)
+        N.create_proof(pk3, bg, bgl, bad_adv, seed=3, check_mode="SAFE", g2=g2b, s_g2=sg2b)
+    # and a lookup input outside its table is refused by the prover itself, as the reference's mv-lookup prover does
+    bad_lk = [a.copy() for a in adv]; bad_lk[0][3] = P.to_mont(12345)
+    with pytest.raises(RuntimeError, match="not in table"):
+        N.create_proof(pk, bg, bgl, bad_lk, seed=3)

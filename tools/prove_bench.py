@@ -187,9 +187,14 @@ if not SYNTH:
             prove_cold.write(d, k, g, gl, g2, s_g2, cs, npk.to_bytes(), by_phase, instances, 5)
             t_write = time.time() - t0
             size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
-            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "prove_cold.py"), "run", d],
-                               capture_output=True, text=True, timeout=900)
-            cj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
+            def cold_child(extra_env):
+                r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "prove_cold.py"), "run", d],
+                                   capture_output=True, text=True, timeout=900, env=dict(os.environ, **extra_env))
+                return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
+            first_ever = cold_child({"EZKL_HIP_CACHE_DIR": "off"})       # no code-object cache: the very first prove of this circuit on a machine
+            cj = cold_child({})                                          # every later one: the gate programs' code objects come from disk
+            cj["first_ever_cold_seconds"] = first_ever.get("cold_seconds")
+            cj["first_ever_create_proof_seconds"] = (first_ever.get("stages") or {}).get("create_proof")
             if "proof_sha256" in cj:
                 cj["same_proof_as_warm"] = cj["proof_sha256"] == __import__("hashlib").sha256(proof).hexdigest()[:16]
             cj["artifact_bytes"] = size; cj["artifact_write_seconds"] = round(t_write, 2)
