@@ -141,6 +141,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_msm, t_ntt = float(t[0]), float(t[1])
 
+    # N > 1: STRONG scaling of one MSM (BASELINE configs[3]: "MSM sharded across 8"): ONE 2^20-point and ONE 2^22-point MSM whose points
+    # are split over the ranks, partials folded after an all_gather of 64 bytes per rank -- next to the weak-scaling headline above.
+    strong = None
+    if world > 1:
+        try:
+            strong = strong_scaling(world, rank, dist, dev, B, D, torch, args, barrier_sync)
+        except Exception as e:                      # never lose the headline line to this leg
+            strong = {"error": repr(e)[:200]}
+
     # N > 1: the end-to-end prove with its MSMs sharded by points across the ranks (BASELINE configs[3]).  Every rank starts a
     # CHILD (tools/prove_bench.py) and the children form their own process group on the next port, so a failure or a hang in
     # this leg can only cost its timeout: the headline line below is printed regardless.
@@ -154,11 +163,14 @@ def main():
         copy_bps = B.ubench("copy")
         acc_avg_ms = float(np.mean(acc_ms))
         achieved = MSM_BYTES_PER_POINT * n_msm / (acc_avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (the guide: never together with the
+        # kernel trace), so bench.py cannot measure them itself; it reports the tracked reduction of those passes WITH its source label
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("msm_accumulate_kernel_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, traffic_source = tj.get("msm_accumulate_kernel_bytes_per_launch"), "profiles/pmc_traffic.json: " + str(tj.get("source"))
             except Exception:
                 traffic = None
         out = {
@@ -178,7 +190,7 @@ def main():
                                    "+ 2^22 scalar-field NTT per GPU", "msm_points_per_gpu": n_msm, "ntt_elems_per_gpu": n_ntt,
                        "parallelism": "points sharded across %d rank(s); all_gather of 64-B partials + host fold" % world},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": acc_avg_ms,
                          "note": "integer-VALU bound, not HBM bound: see extra.modmul29_per_s (DESIGN.md §roofline)"},
             "extra": {"msm_device_ms": float(np.mean(msm_ms)), "ntt_elems_per_s": world * n_ntt * args.steps / t_ntt,
@@ -195,10 +207,38 @@ def main():
             out["prove"] = prove_leg()
         if prove_multi is not None:
             out["prove"] = prove_multi
+        if strong is not None:
+            out["extra"]["msm_strong_scaling"] = strong
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def strong_scaling(world, rank, dist, dev, B, D, torch, args, barrier_sync):
+    """one MSM of 2^20 (and 2^22) points split over the ranks: rank r commits points [r n/N, (r+1) n/N), the 64-byte partials are
+    all_gathered and folded.  Returns whole-MSM milliseconds and points/s (max over ranks), per size."""
+    out = {}
+    for logn in (20, 22):
+        n = 1 << logn
+        lo, hi = D.shard_range(n, rank, world)
+        bases = B.Bases.generate(SEED + 7, hi - lo, first=lo)                 # this rank's slice of ONE global base set
+        rng = np.random.default_rng(SEED + 100 + logn)                       # the same scalar vector on every rank; each uses its slice
+        sc = B.DeviceBuffer.from_numpy(np.ascontiguousarray(rand_fr(rng, n)[lo:hi]))
+        step = lambda: D.fold_partials(B.msm_g1_dev(bases, sc.ptr, hi - lo), dist, dev)
+        for _ in range(max(1, args.warmup)):
+            res = step()
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        barrier_sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t[0]) / args.steps * 1e3
+        out["2^%d" % logn] = {"ms_per_msm": ms, "pts_per_s": n / (ms * 1e-3), "points_per_rank": hi - lo, "result_x_limb0": int(res[0])}
+        bases.free()
+    return out
 
 
 def prove_leg():
@@ -246,7 +286,7 @@ def prove_leg_multi(world, rank, local_rank, args):
     """k = 20 prove with the proof's MSMs sharded across `world` GPUs (plonk.DistGpuBackend: every rank holds 1/world of the
     SRS, one all_gather of 64-byte partials per commit batch; NTTs and the sweep replicated).  Runs in child processes."""
     import subprocess
-    env = dict(os.environ, K="20", BLOCKS="4", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+    env = dict(os.environ, K="20", BLOCKS="4", CIRCUIT="synthetic", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(local_rank))
     for k_ in list(env):                       # the children rendezvous on their own: no torchrun agent store behind the new port
         if k_.startswith("TORCHELASTIC_") or k_ in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",

@@ -75,6 +75,13 @@ class DeviceBuffer:
             pass
 
 
+class DeviceView:
+    """a window of another resident buffer (no ownership): .ptr / .nbytes like DeviceBuffer, keeps its parent alive"""
+
+    def __init__(self, ptr, nbytes, parent):
+        self.ptr, self.nbytes, self._parent = ptr, nbytes, parent
+
+
 class PinnedArray:
     """a numpy view of page-locked host memory (ezkl_hip_host_malloc): witness columns filled here upload at PCIe speed"""
 

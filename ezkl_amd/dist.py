@@ -91,7 +91,7 @@ def _window(col, start, length):
     return np.concatenate([col[start:], col[: start + length - n]])
 
 
-def reshard_columns_to_rows(owned, queries, n_ext, dist, device):
+def reshard_columns_to_rows(owned, queries, n_ext, dist, device, owner=None):
     """owned: {column: (n_ext, 4) u64 array} for the columns this rank owns (shard_columns).  queries: the (column,
     row_shift) pairs of the gate program, the same list on every rank.  Returns {(column, row_shift): (rows, 4) array}
     with this rank's row window of every queried pair.  One all_to_all (byte tensors; RCCL on the GPU box, gloo on CPU)."""
@@ -99,24 +99,45 @@ def reshard_columns_to_rows(owned, queries, n_ext, dist, device):
         return {(c, s): _window(owned[c], s % n_ext, n_ext) for c, s in queries}
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
+    if owner is None:
+        owner = lambda c: c % world                          # round-robin column ownership (shard_columns)
     send, send_sizes = [], []
     for d in range(world):                                   # what destination d needs from the columns I own, in query order
-        parts = [_window(owned[c], start, ln) for (c, start, ln) in row_windows(queries, n_ext, d, world) if c % world == rank]
+        parts = [_window(owned[c], start, ln) for (c, start, ln) in row_windows(queries, n_ext, d, world) if owner(c) == rank]
         blob = np.concatenate(parts).view(np.uint8).reshape(-1) if parts else np.zeros(0, np.uint8)
         send.append(blob)
         send_sizes.append(blob.size)
     mine = row_windows(queries, n_ext, rank, world)
-    recv_sizes = [sum(ln * 32 for (c, _, ln) in mine if c % world == s) for s in range(world)]
+    recv_sizes = [sum(ln * 32 for (c, _, ln) in mine if owner(c) == s) for s in range(world)]
     sbuf = torch.from_numpy(np.concatenate(send) if sum(send_sizes) else np.zeros(0, np.uint8)).to(device)
     rbuf = torch.empty(sum(recv_sizes), dtype=torch.uint8, device=device)
     dist.all_to_all_single(rbuf, sbuf, output_split_sizes=recv_sizes, input_split_sizes=send_sizes)
     flat = rbuf.cpu().numpy()
     out, off = {}, [sum(recv_sizes[:s]) for s in range(world)]
     for (c, s_), (_, _, ln) in zip(queries, mine):           # unpack in the same per-source query order the senders used
-        src = c % world
+        src = owner(c)
         out[(c, s_)] = flat[off[src]:off[src] + ln * 32].view(np.uint64).reshape(ln, 4).copy()
         off[src] += ln * 32
     return out
+
+
+def allgather_array(a, dist, device):
+    """all_gather a numpy array of the same shape on every rank -> list of world arrays"""
+    import torch
+    world = dist.get_world_size()
+    a = np.ascontiguousarray(a)
+    send = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(device)
+    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    flat = recv.cpu().numpy()
+    return [flat[r * a.nbytes:(r + 1) * a.nbytes].view(a.dtype).reshape(a.shape).copy() for r in range(world)]
+
+
+def allgather_ints(vals, dist, device):
+    """all_gather a list of field elements (ints < 2^256) -> [world][len(vals)]"""
+    a = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), np.uint8).copy() if vals else np.zeros(0, np.uint8)
+    parts = allgather_array(a, dist, device)
+    return [[int.from_bytes(p[32 * i:32 * i + 32].tobytes(), "little") for i in range(len(vals))] for p in parts]
 
 
 def allgather_rows(buf, lo, hi, n, dist, device):

@@ -292,18 +292,84 @@ class Rng:
         return out
 
 
-class DistGpuBackend(GpuBackend):
+class _SharedEval:
+    """marks an owned polynomial whose evaluations are taken from the all_gathered list (same consumption order on every rank)"""
+    _shared_eval = True
+
+    def __init__(self, h):
+        self.h = h
+
+
+class ColumnShardMixin:
+    """NTTs sharded by COLUMNS over the ranks of a torch.distributed group, on top of a backend whose MSMs are
+    sharded by points and whose sweep is sharded by rows.  Requires of the backend: download / upload / window / eval_rows /
+    gather_rows (the row-shard primitives) and eval_poly / zeros / axpy.  Replicated data (the key's fixed / sigma columns, the
+    witness VALUES every rank receives) are owned by everyone: in SHPLONK's partial sums they count on rank (index % world)."""
+
+    def _dist_init(self, dist, device):
+        self.dist, self.device = dist, device
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.sharded_ntt_columns = 0
+
+    def owner_of(self, index):
+        return index % self.world
+
+    def lagrange_to_coeff(self, h):
+        self.sharded_ntt_columns += 1
+        return super().lagrange_to_coeff(h)
+
+    def eval_program_sharded(self, prog, cols, owners, challenges, out):
+        """cols[i] is None where another rank owns slot i; owners[i] = owning rank, -1 = resident on every rank"""
+        from . import dist as D
+        world, rank = self.world, self.rank
+        ne, m = 1 << prog.ext_k, world.bit_length() - 1
+        assert (1 << m) == world and m <= prog.k, "the row-sharded sweep needs a power-of-two world"
+        sub, queries = prog.row_sharded(m)
+        lo, hi = D.shard_range(ne, rank, world)
+        exq = [(c, s) for c, s in queries if owners[c] >= 0]
+        owned = {c: np.asarray(self.download(cols[c], ne)) for c in {c for c, _ in exq} if owners[c] == rank}
+        got = D.reshard_columns_to_rows(owned, exq, ne, self.dist, self.device, owner=lambda c: owners[c])
+        handles = []
+        for c, s in queries:
+            if owners[c] >= 0:
+                handles.append(self.upload(got[(c, s)]))
+            else:
+                handles.append(self.window(cols[c], (lo + s) % ne, hi - lo, ne))
+        self.eval_rows(sub, handles, challenges, out, lo, hi)
+        self.gather_rows(out, lo, hi, ne)
+        self.sharded_sweeps = getattr(self, "sharded_sweeps", 0) + 1
+
+    def eval_by_owner(self, wanted, n):
+        """wanted: [(poly handle or None, owner, point)] in the same order on every rank -> the evaluations, on every rank"""
+        from . import dist as D
+        mine = [self.eval_poly(h, n, pt) if o == self.rank else 0 for h, o, pt in wanted]
+        allv = D.allgather_ints(mine, self.dist, self.device)
+        return [allv[o][i] for i, (_, o, _) in enumerate(wanted)]
+
+    def sum_over_ranks(self, h, n):
+        from . import dist as D
+        parts = D.allgather_array(np.asarray(self.download(h, n)), self.dist, self.device)
+        acc = self.upload(parts[0])
+        for p_ in parts[1:]:
+            self.axpy(acc, 1, self.upload(p_), n)
+        return acc
+
+
+class DistGpuBackend(ColumnShardMixin, GpuBackend):
     """BASELINE configs[3]: the MSMs of a proof sharded across the GPUs of a node.  Every rank runs
     the same deterministic prover on replicated columns but holds only its contiguous slice of the SRS (base-set memory
     and MSM work divide by the world size); each commit batch ends with ONE all_gather of the 64-byte partials (RCCL
     over xGMI) and a host fold, so all ranks derive identical transcripts.  NTTs / the sweep stay replicated here."""
     name = "hip-dist"
 
-    def __init__(self, params_g, params_g_lagrange, k, dist, device):
+    def __init__(self, params_g, params_g_lagrange, k, dist, device, shard_columns=False):
         from . import dist as D
-        self.D, self.dist, self.device = D, dist, device
-        world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-        rank = dist.get_rank() if world > 1 else 0
+        self.D = D
+        self._dist_init(dist, device)
+        world, rank = self.world, self.rank
+        if not (shard_columns and world > 1 and world & (world - 1) == 0):
+            self.owner_of = None                     # NTTs replicated (MSMs by points + sweep by rows only)
         self.lo, self.hi = D.shard_range(1 << k, rank, world)
         self.k, self.n = k, 1 << k
         self.g = _b.Bases(np.ascontiguousarray(params_g[self.lo:self.hi]))
@@ -319,6 +385,20 @@ class DistGpuBackend(GpuBackend):
     def commit(self, hs): return self._commit(self.g, hs) if hs else []
 
     SWEEP_MIN_ROWS = 1 << 14
+
+    # the row-shard primitives of ColumnShardMixin on resident buffers
+    def window(self, h, start, length, total):
+        if start + length <= total:
+            return _b.DeviceView(h.ptr + 32 * start, 32 * length, h)
+        w, first = _b.DeviceBuffer(32 * length), total - start
+        one = to_mont(1)
+        _b.vec_scale(h.ptr + 32 * start, one, w.ptr, first)
+        _b.vec_scale(h.ptr, one, w.ptr + 32 * first, length - first)
+        return w
+    def eval_rows(self, sub, handles, challenges, out, lo, hi):
+        sub.evaluate_h([h.ptr for h in handles], [to_mont(c) for c in challenges], out.ptr + 32 * lo)
+    def gather_rows(self, out, lo, hi, total):
+        self.D.allgather_rows(out, lo, hi, total, self.dist, self.device)
 
     def eval_program(self, prog, cols, challenges, out):
         """The quotient sweep sharded by ROWS: this rank evaluates rows [lo, hi) of the extended domain with the
@@ -615,19 +695,39 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=(), st
     y = T.squeeze_challenge()
     lap("random_poly")
     # 7. quotient
-    adv_polys = [backend.lagrange_to_coeff(h) for h in adv_cols]
-    inst_cosets = [backend.coeff_to_extended(backend.lagrange_to_coeff(h), cs.ext_k) for h in inst_cols]
-    z_polys = [backend.lagrange_to_coeff(h) for h in zs]
-    adv_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in adv_polys]
-    z_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in z_polys]
-    m_polys = [backend.lagrange_to_coeff(d_["m"]) for d_ in lk]
-    phi_polys = [backend.lagrange_to_coeff(d_["phi"]) for d_ in lk]
-    m_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in m_polys]
-    phi_cosets = [backend.coeff_to_extended(h, cs.ext_k) for h in phi_polys]
+    # Column-sharded backends ("per-column NTT batches shard"): every witness-dependent column has an OWNER rank
+    # (round-robin over one global numbering) which alone computes its coefficient and extended forms, evaluates it at x and adds
+    # it into the SHPLONK combinations; the row-sharded sweep gets its windows of every coset through one all-to-all.
+    owner_of = getattr(backend, "owner_of", None)
+    gidx = {"n": 0}
+    def forms(handles, with_coset=True):
+        polys, cosets, owners = [], [], []
+        for h in handles:
+            o = -1 if owner_of is None else owner_of(gidx["n"])
+            gidx["n"] += 1
+            mine = owner_of is None or o == backend.rank
+            p_ = backend.lagrange_to_coeff(h) if mine else None
+            polys.append(p_); owners.append(o)
+            cosets.append(backend.coeff_to_extended(p_, cs.ext_k) if (mine and with_coset) else None)
+        return polys, cosets, owners
+    adv_polys, adv_cosets, adv_own = forms(adv_cols)
+    _, inst_cosets, inst_own = forms(inst_cols)
+    z_polys, z_cosets, z_own = forms(zs)
+    m_polys, m_cosets, m_own = forms([d_["m"] for d_ in lk])
+    phi_polys, phi_cosets, phi_own = forms([d_["phi"] for d_ in lk])
     lap("intt_and_coset_ntt")
-    prog, cols, chal = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal)
+    prog, cols, chal, names = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal, names=True)
     hnum = backend.zeros(1 << cs.ext_k)
-    backend.eval_program(prog, cols, chal, hnum)
+    if owner_of is None:
+        backend.eval_program(prog, cols, chal, hnum)
+    else:
+        own_by_name = {}
+        for c, o in enumerate(adv_own): own_by_name[("adv", c)] = o
+        for c, o in enumerate(inst_own): own_by_name[("inst", c)] = o
+        for j, o in enumerate(z_own): own_by_name[("z", j)] = o
+        for i, o in enumerate(m_own): own_by_name[("m", i)] = o
+        for i, o in enumerate(phi_own): own_by_name[("phi", i)] = o
+        backend.eval_program_sharded(prog, cols, [own_by_name.get(nm, -1) for nm in names], chal, hnum)
     lap("quotient_sweep")
     backend.divide_by_vanishing(hnum, cs.ext_k)
     hcoef = backend.extended_to_coeff(hnum, cs.ext_k)
@@ -641,9 +741,27 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=(), st
     w = omega(k)
     def rot_point(r): return x * pow(w, r % n if r >= 0 else n + r, R) % R
     # 9. evaluations
+    if owner_of is not None:
+        # owner-evaluated: every (polynomial, point) of the witness-dependent columns is evaluated by the column's owner and the scalars
+        # are all_gathered once; key-side polynomials (fixed, sigma) are resident everywhere
+        wanted = [(adv_polys[c], adv_own[c], rot_point(r)) for c, r in cs.advice_queries]
+        for j, zp in enumerate(z_polys):
+            wanted += [(zp, z_own[j], x), (zp, z_own[j], rot_point(1))] + ([(zp, z_own[j], rot_point(u))] if j + 1 < len(z_polys) else [])
+        for i in range(len(lk)):
+            wanted += [(phi_polys[i], phi_own[i], x), (phi_polys[i], phi_own[i], rot_point(1)), (m_polys[i], m_own[i], x)]
+        shared = iter(backend.eval_by_owner(wanted, n))
+        real_eval = backend.eval_poly
+        def eval_poly(h, n_, pt, offset=0):
+            return next(shared) if h is None or getattr(h, "_shared_eval", False) else real_eval(h, n_, pt, offset)
+        for lst in (adv_polys, z_polys, m_polys, phi_polys):      # owned columns also take the gathered value: same order on all ranks
+            for i_, h in enumerate(lst):
+                if h is not None:
+                    lst[i_] = _SharedEval(h)
+    else:
+        eval_poly = backend.eval_poly
     evals = {}
     for c, r in cs.advice_queries:
-        evals[("adv", c, r)] = backend.eval_poly(adv_polys[c], n, rot_point(r)); T.write_scalar(evals[("adv", c, r)])
+        evals[("adv", c, r)] = eval_poly(adv_polys[c], n, rot_point(r)); T.write_scalar(evals[("adv", c, r)])
     for c, r in cs.fixed_queries:
         evals[("fix", c, r)] = backend.eval_poly(pk.fixed_polys[c], n, rot_point(r)); T.write_scalar(evals[("fix", c, r)])
     random_eval = backend.eval_poly(rnd, n, x); T.write_scalar(random_eval)
@@ -651,18 +769,23 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=(), st
     for e in sigma_evals: T.write_scalar(e)
     z_evals = []
     for j, zp in enumerate(z_polys):
-        e0, e1 = backend.eval_poly(zp, n, x), backend.eval_poly(zp, n, rot_point(1))
+        e0, e1 = eval_poly(zp, n, x), eval_poly(zp, n, rot_point(1))
         T.write_scalar(e0); T.write_scalar(e1)
         e2 = None
         if j + 1 < len(z_polys):
-            e2 = backend.eval_poly(zp, n, rot_point(u)); T.write_scalar(e2)
+            e2 = eval_poly(zp, n, rot_point(u)); T.write_scalar(e2)
         z_evals.append((e0, e1, e2))
     lk_evals = []
     for mp, pp in zip(m_polys, phi_polys):
         # mv_lookup::prover::Committed::evaluate writes phi(x), phi(wx), m(x)
-        e = (backend.eval_poly(pp, n, x), backend.eval_poly(pp, n, rot_point(1)), backend.eval_poly(mp, n, x))
+        e = (eval_poly(pp, n, x), eval_poly(pp, n, rot_point(1)), eval_poly(mp, n, x))
         for v_ in e: T.write_scalar(v_)
         lk_evals.append(e)
+    if owner_of is not None:                          # back to plain handles (None where this rank does not own the column)
+        for lst in (adv_polys, z_polys, m_polys, phi_polys):
+            for i_, h in enumerate(lst):
+                if isinstance(h, _SharedEval):
+                    lst[i_] = h.h
     lap("evaluations")
     # 10. multiopen (SHPLONK)
     xn = pow(x, n, R)
@@ -671,12 +794,14 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=(), st
         backend.scale(hcomb, xn, n)
         backend.axpy(hcomb, 1, pieces[i], n)
     h_eval = backend.eval_poly(hcomb, n, x)
+    def rep(h, i):    # a polynomial resident on every rank counts on ONE rank in the column-sharded SHPLONK partial sums
+        return h if owner_of is None or i % backend.world == backend.rank else None
     qs = []   # (key, poly handle, point, eval) -- the verifier rebuilds the same list with commitments for handles
     for c, r in cs.advice_queries: qs.append((("adv", c), adv_polys[c], rot_point(r), evals[("adv", c, r)]))
-    for c, r in cs.fixed_queries: qs.append((("fix", c), pk.fixed_polys[c], rot_point(r), evals[("fix", c, r)]))
-    qs.append((("h",), hcomb, x, h_eval))
-    qs.append((("rnd",), rnd, x, random_eval))
-    for i, (h, e) in enumerate(zip(pk.sigma_polys, sigma_evals)): qs.append((("sigma", i), h, x, e))
+    for c, r in cs.fixed_queries: qs.append((("fix", c), rep(pk.fixed_polys[c], c), rot_point(r), evals[("fix", c, r)]))
+    qs.append((("h",), rep(hcomb, 0), x, h_eval))
+    qs.append((("rnd",), rep(rnd, 1), x, random_eval))
+    for i, (h, e) in enumerate(zip(pk.sigma_polys, sigma_evals)): qs.append((("sigma", i), rep(h, i), x, e))
     for j, zp in enumerate(z_polys):
         qs.append((("z", j), zp, x, z_evals[j][0])); qs.append((("z", j), zp, rot_point(1), z_evals[j][1]))
         if z_evals[j][2] is not None: qs.append((("z", j), zp, rot_point(u), z_evals[j][2]))
@@ -714,14 +839,14 @@ def compress_column(cs, backend, tuple_exprs, theta, col_handle, user_chal=()):
     return out
 
 
-def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m_cosets=(), phi_cosets=(), inst_cosets=(), user_chal=()):
+def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m_cosets=(), phi_cosets=(), inst_cosets=(), user_chal=(), names=False):
     """the numerator of h(X) as ONE straight-line program over the extended-coset columns: custom gates, then the
     permutation constraints, folded with y (value = value*y + constraint), as evaluate_h does"""
     prog = _b.GraphProgram(cs.k, cs.ext_k)
-    cols, index = [], {}
+    cols, index, slot_names = [], {}, []
     def slot(name, handle):
         if name not in index:
-            index[name] = len(cols); cols.append(handle)
+            index[name] = len(cols); cols.append(handle); slot_names.append(name)
         return index[name]
     chal = [y, beta, gamma] + list(user_chal)
     def col_index(kind, c):
@@ -781,6 +906,8 @@ def quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta=None, m
             terms.append(prog.calc("mul", llast, phi))
             terms.append(prog.calc("mul", lact, prog.calc("sub", lhs, rhs)))
     prog.horner(prog.previous(), terms, Y)
+    if names:
+        return prog, cols, chal, slot_names
     return prog, cols, chal
 
 
@@ -836,10 +963,13 @@ def shplonk_prove(backend, T, qs, n):
         evs = {z: 0 for z in pts}
         pw = 1
         for p, ev in polys:
-            backend.axpy(q, pw, p, n)
+            if p is not None:                          # column-sharded: only the owner adds its polynomial ...
+                backend.axpy(q, pw, p, n)
             for z in pts:
                 evs[z] = (evs[z] + pw * ev[z]) % R
             pw = pw * ys % R
+        if getattr(backend, "owner_of", None) is not None:
+            q = backend.sum_over_ranks(q, n)           # ... and the partial combinations are summed over the ranks
         r = interpolate(list(pts), [evs[z] for z in pts])
         combos.append((pts, q, r))
     v = T.squeeze_challenge()

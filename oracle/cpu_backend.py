@@ -96,3 +96,37 @@ class OracleBackend:
     def kate_div(self, h, z, n):
         h[:n] = ob.kate_div(h[:n], to_mont(z))
         return h
+
+
+class DistOracleBackend(__import__("ezkl_amd.plonk", fromlist=["ColumnShardMixin"]).ColumnShardMixin, OracleBackend):
+    """The multi-rank decomposition on CPU (TEST INFRASTRUCTURE: gloo, world 2 / 4): MSMs sharded by points, NTTs by columns, the
+    sweep by rows with the all-to-all of ezkl_amd/dist.py -- the oracle does the arithmetic of every shard, so what is tested is the
+    sharding, the exchanges and the bookkeeping: the ranks must emit the single-rank proof."""
+    name = "oracle-dist"
+
+    def __init__(self, params_g, params_g_lagrange, k, dist, device):
+        from ezkl_amd import dist as D
+        OracleBackend.__init__(self, params_g, params_g_lagrange, k)
+        self.D = D
+        self._dist_init(dist, device)
+        self.lo, self.hi = D.shard_range(self.n, self.rank, self.world)
+
+    def _commit(self, bases, hs):
+        part = np.stack([ob.msm(h[self.lo:self.hi], bases[self.lo:self.hi]) for h in hs])
+        full = self.D.fold_columns(self.D.allgather_points(part, self.dist, self.device))
+        return [point_to_ints(p) for p in full]
+    def commit_lagrange(self, hs): return self._commit(self.gl, hs) if hs else []
+    def commit(self, hs): return self._commit(self.g, hs) if hs else []
+    # row-shard primitives
+    def window(self, h, start, length, total):
+        return h[start:start + length] if start + length <= total else np.concatenate([h[start:total], h[: start + length - total]])
+    def eval_rows(self, sub, handles, challenges, out, lo, hi):
+        code, consts, rots = sub.arrays()
+        ch = np.stack([to_mont(c) for c in challenges]) if challenges else np.zeros((1, 4), np.uint64)
+        out[lo:hi] = ob.eval_program(code, sub.n_intermediates, consts, rots, [np.ascontiguousarray(h) for h in handles], ch, sub.k, sub.ext_k,
+                                     previous=np.ascontiguousarray(out[lo:hi]))
+    def gather_rows(self, out, lo, hi, total):
+        parts = self.D.allgather_array(np.ascontiguousarray(out[lo:hi]), self.dist, self.device)
+        rows = hi - lo
+        for r, p_ in enumerate(parts):
+            out[r * rows:(r + 1) * rows] = p_

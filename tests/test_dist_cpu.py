@@ -107,3 +107,63 @@ def test_shard_range_covers_everything():
             spans = [D.shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _prove_worker(rank, world, port, q):
+    """the column-sharded prover on CPU: MSMs by points, NTTs by columns (owner-computed forms, evaluations, SHPLONK partial sums), the
+    sweep by rows fed by the all-to-all -- on the reference's fixture circuit (lookups, 32 permutation columns, instance)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import fixture_k6 as FX
+    from ezkl_amd import plonk as P
+    from oracle.cpu_backend import DistOracleBackend
+    from oracle import pyref as pr
+    srs = pr.parse_srs(open(os.path.join(FX.G, "kzg_k6.srs"), "rb").read())
+    g = np.stack([np.frombuffer(b, np.uint64) for b in srs["g"]])
+    gl = np.stack([np.frombuffer(b, np.uint64) for b in srs["g_lagrange"]])
+    fx = FX.load()
+    be = DistOracleBackend(g, gl, FX.K, dist, torch.device("cpu"))
+    adv, inst, _ = FX.witness(fx)
+    copies = FX.copies_of(FX.copy_cycles(fx["pk"]))
+    pk, vk = P.keygen(fx["cs"], be, FX.mont_cols(fx["fixed"]), copies)
+    proof = P.create_proof(pk, be, FX.mont_cols(adv), P.Rng(7), instances=inst)
+    q.put((rank, proof, be.sharded_ntt_columns, getattr(be, "sharded_sweeps", 0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_rank_fixture_proof():
+    import fixture_k6 as FX
+    from ezkl_amd import plonk as P
+    from oracle.cpu_backend import OracleBackend
+    from oracle import pyref as pr
+    srs = pr.parse_srs(open(os.path.join(FX.G, "kzg_k6.srs"), "rb").read())
+    g = np.stack([np.frombuffer(b, np.uint64) for b in srs["g"]])
+    gl = np.stack([np.frombuffer(b, np.uint64) for b in srs["g_lagrange"]])
+    fx = FX.load()
+    be = OracleBackend(g, gl, FX.K)
+    adv, inst, _ = FX.witness(fx)
+    pk, vk = P.keygen(fx["cs"], be, FX.mont_cols(fx["fixed"]), FX.copies_of(FX.copy_cycles(fx["pk"])))
+    return P.create_proof(pk, be, FX.mont_cols(adv), P.Rng(7), instances=inst), fx["cs"]
+
+
+def test_column_sharded_prover_world2_and_4_emit_the_single_rank_proof():
+    want, cs = _single_rank_fixture_proof()
+    n_cols = cs.n_advice + cs.n_instance + cs.n_chunks + 2 * len(cs.lookups)     # advice, instance, z, m, phi: 30 + 1 + 7 + 70
+    for world in (2, 4):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 33500 + world * 17 + (os.getpid() % 1500)
+        procs = [ctx.Process(target=_prove_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert all(r[1] == want for r in res), "world %d: sharded proof differs from the single-rank proof" % world
+        assert sum(r[2] for r in res) == n_cols + (70 + 3) * world       # every witness column transformed by exactly ONE rank (+ keygen's columns on all)
+        assert all(r[3] == 1 for r in res)

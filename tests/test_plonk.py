@@ -359,6 +359,26 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
 
 
 @pytest.mark.gpu
+def test_column_sharded_ntt_prover_two_ranks_same_proof(hip):
+    """SURVEY.md §8(e) in full on the device: MSMs by points, NTTs by COLUMNS (each rank transforms only the columns it owns), the sweep
+    by rows fed by the all-to-all of coset windows, evaluations and SHPLONK partial sums by owner -- two ranks (gloo, sharing the one
+    GPU of the test box) emit the single-rank proof"""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, K="12", BLOCKS="2", CIRCUIT="synthetic")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_bench.py")], env=env, capture_output=True, text=True, timeout=600)
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo", "--shard-columns"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert lines, two.stderr[-2000:]
+    j2 = json.loads(lines[-1])
+    assert j1["verifier_accepts"] and j2["verifier_accepts"] and j1["proof_sha256"] == j2["proof_sha256"]
+    assert j2["ntt_sharding"].startswith("columns round-robin across 2 ranks") and j1["ntt_sharding"] == "replicated"
+
+
+@pytest.mark.gpu
 def test_bench_contract_two_ranks(hip):
     """`bench.py --gpus 2` the way the driver launches it (torchrun), on one GPU with gloo: ONE JSON line from rank 0 with the
     contract's keys, the whole-job value, and the sharded end-to-end prove leg accepted by the verifier"""

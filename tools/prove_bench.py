@@ -133,13 +133,14 @@ if relu:
     fixed += [to_mont_dev_limbs(signed_to_canon_limbs(sel)), to_mont_dev_limbs(signed_to_canon_limbs(tin)), to_mont_dev_limbs(signed_to_canon_limbs(tout))]
 
 def run(backend_name):
-    be = (P.DistGpuBackend(g, gl, k, dist, ddev) if world > 1 else P.GpuBackend(g, gl, k)) if backend_name == "hip" else __import__("oracle.cpu_backend", fromlist=["OracleBackend"]).OracleBackend(g, gl, k)
+    be = (P.DistGpuBackend(g, gl, k, dist, ddev, shard_columns="--shard-columns" in sys.argv) if world > 1 else P.GpuBackend(g, gl, k)) if backend_name == "hip" else __import__("oracle.cpu_backend", fromlist=["OracleBackend"]).OracleBackend(g, gl, k)
     t0 = time.time(); pk, vk = P.keygen(cs, be, fixed, copies); t_keygen = time.time() - t0
     P.create_proof(pk, be, adv, P.Rng(5), instances=instances)      # warm-up (window tables, twiddles, JIT)
     tm = {}
     t0 = time.time(); proof = P.create_proof(pk, be, adv, P.Rng(5), timings=tm, instances=instances); t_prove = time.time() - t0
     run.timings = {a: round(b, 4) for a, b in tm.items()}
     run.sharded_sweeps = getattr(be, "sharded_sweeps", 0)
+    run.sharded_ntt_columns = getattr(be, "sharded_ntt_columns", None) if getattr(be, "owner_of", None) else None
     return vk, proof, t_keygen, t_prove
 
 if not SYNTH:
@@ -258,6 +259,7 @@ out = {"what": "ezkl_amd.plonk prove (gates + permutation + mv-lookup, KZG/SHPLO
        "lookups": len(lookups), "lookup_table_rows": (1 << tbits) if relu else 0,
        "n_gpus": world, "msm_sharding": "points across %d rank(s), all_gather of 64-B partials per commit batch" % world,
        "sweep_sharding": "rows across %d rank(s) (Python host), all_gather of h: %d sharded sweep(s)" % (world, run.sharded_sweeps),
+       "ntt_sharding": ("columns round-robin across %d ranks: this rank transformed %s columns; sweep windows by all-to-all" % (world, run.sharded_ntt_columns)) if run.sharded_ntt_columns else "replicated",
        "proof_sha256": __import__("hashlib").sha256(proof).hexdigest()[:16],
        "k": k, "advice_columns": cs.n_advice, "fixed_columns": cs.n_fixed, "degree": cs.degree, "ext_k": cs.ext_k, "copies": len(copies),
        "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "keygen_seconds_gpu": round(t_keygen, 3),
