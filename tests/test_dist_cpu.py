@@ -10,6 +10,14 @@ import torch.multiprocessing as mp
 from conftest import ROOT, SEED, rand_fr
 
 
+def free_port():
+    """a TCP port nobody listens on right now (bind to 0, read it back): fixed port formulas collide with leftovers of earlier runs"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _worker(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -35,7 +43,7 @@ def test_sharded_msm_fold_world2():
     n, world = 1001, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -71,12 +79,12 @@ def _reshard_check(world, rank, port, n_ext, ncols):
     return ok
 
 
-def _reshard_worker(rank, port, q):
+def _reshard_worker(rank, port, port2, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     ok = _reshard_check(3, rank, port, 250, 4)                            # ragged row counts: 84 / 83 / 83
     if rank < 2:
-        ok = _reshard_check(2, rank, port + 1, 256, 5) and ok
+        ok = _reshard_check(2, rank, port2, 256, 5) and ok
     q.put((rank, ok))
 
 
@@ -85,8 +93,9 @@ def test_columns_to_row_windows_world3_and_2():
     (column, rotation) pair, including windows that wrap around the domain; three ranks (ragged row counts), then two"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_reshard_worker, args=(r, port, q)) for r in range(3)]
+    port = free_port()
+    port2 = free_port()
+    procs = [ctx.Process(target=_reshard_worker, args=(r, port, port2, q)) for r in range(3)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(3)]
@@ -156,7 +165,7 @@ def test_column_sharded_prover_world2_and_4_emit_the_single_rank_proof():
     for world in (2, 4):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        port = 33500 + world * 17 + (os.getpid() % 1500)
+        port = free_port()
         procs = [ctx.Process(target=_prove_worker, args=(r, world, port, q)) for r in range(world)]
         for p in procs:
             p.start()
