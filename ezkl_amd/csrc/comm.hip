@@ -98,6 +98,8 @@ int ezkl_hip_comm_init(const void* id128, int world, int rank) {
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     EZ_HIP(hipStreamCreateWithFlags(&g_comm.st, hipStreamNonBlocking));
+    EZ_HIP(hipDeviceSynchronize());
+    (void)hipGetLastError();                            // RCCL reads the thread's last HIP error during init: an earlier, already reported one must not fail it
     EZ_RCCL(g_rccl.CommInitRank(&g_comm.comm, world, id, rank));
     g_comm.world = world;
     g_comm.rank = rank;
