@@ -617,6 +617,36 @@ struct Backend {
         scan(EZKL_VEC_ADD, true, acc->ptr(), acc->ptr(), n);
         return acc;
     }
+    // the running sums of ALL lookup arguments at once: the (input + beta) / (table + beta) columns of every argument are laid out in
+    // ONE buffer and inverted by ONE batch inversion -- each call ends in a ~380-product dependent Fermat chain (its latency floor,
+    // ~0.25 ms whatever the size), so one call for the whole proof instead of one per column (31 calls in a 12-lookup proof: 9 ms)
+    std::vector<Col> lookup_grand_sums(const std::vector<std::vector<Col>>& inputs, const std::vector<Col>& tables, const std::vector<Col>& ms,
+                                       const Fe& beta) const {
+        size_t total = 0;
+        for (size_t i = 0; i < tables.size(); i++) total += inputs[i].size() + 1;
+        std::vector<Col> out;
+        if (!total) return out;
+        Col big = alloc(total * n);
+        Program shift(k, k);
+        shift.add(shift.column(0), shift.challenge(0));
+        size_t slot = 0;
+        for (size_t i = 0; i < tables.size(); i++) {
+            for (auto& in : inputs[i]) shift.run({in}, {beta}, at(big, (slot++) * n));
+            shift.run({tables[i]}, {beta}, at(big, (slot++) * n));
+        }
+        invert(big->ptr(), total * n);
+        slot = 0;
+        for (size_t i = 0; i < tables.size(); i++) {
+            Col acc = zeros(n);
+            for (size_t j = 0; j < inputs[i].size(); j++) vec(EZKL_VEC_ADD, acc->ptr(), at(big, (slot++) * n), acc->ptr(), n);
+            void* t = at(big, (slot++) * n);
+            vec(EZKL_VEC_MUL, t, ms[i]->ptr(), t, n);
+            vec(EZKL_VEC_SUB, acc->ptr(), t, acc->ptr(), n);
+            scan(EZKL_VEC_ADD, true, acc->ptr(), acc->ptr(), n);
+            out.push_back(acc);
+        }
+        return out;
+    }
     Col lookup_multiplicity(const std::vector<Col>& inputs, const Col& table, uint32_t usable) const {
         Col out = alloc(n);
         std::vector<const void*> ptrs;
@@ -1456,10 +1486,16 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     // 4b. mv-lookup running sums phi(X)
     {
         std::vector<Col> phis;
-        for (auto& st : lk) {
-            st.phi = be.lookup_grand_sum(st.inputs, st.table, st.m, beta);
-            be.set_rows(st.phi, u + 1, rng.vec(n - u - 1));
-            phis.push_back(st.phi);
+        {
+            std::vector<std::vector<Col>> ins;
+            std::vector<Col> tabs, ms_;
+            for (auto& st : lk) { ins.push_back(st.inputs); tabs.push_back(st.table); ms_.push_back(st.m); }
+            std::vector<Col> sums = be.lookup_grand_sums(ins, tabs, ms_, beta);
+            for (size_t i = 0; i < lk.size(); i++) {
+                lk[i].phi = sums[i];
+                be.set_rows(lk[i].phi, u + 1, rng.vec(n - u - 1));       // same draw order as one lookup after the other
+                phis.push_back(lk[i].phi);
+            }
         }
         for (auto& st : lk) st.phi_forms = be.forms_async(st.phi, cs.ext_k);
         for (auto& p : be.commit_lagrange(phis)) T.write_point(p);

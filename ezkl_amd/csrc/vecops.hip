@@ -323,15 +323,33 @@ __global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* table, uint32
 __global__ __launch_bounds__(256) void ht_count_kernel(const fe_t* input, uint32_t rows, const fe_t* table, const uint32_t* slots,
                                                        uint32_t mask, uint32_t* counts, uint32_t* missing) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    const fe_t key = ld_fe(input + i);
-    uint32_t h = ht_hash(key, mask);
-    for (;;) {
-        uint32_t cur = slots[h];
-        if (cur == HT_EMPTY) { atomicAdd(missing, 1u); return; }
-        if (Fr::eq(ld_fe(table + cur), key)) { atomicAdd(&counts[cur], 1u); return; }
-        h = (h + 1) & mask;
+    // target: the table row this lane's input equals (HT_EMPTY = not in the table), HT_EMPTY - 1 = lane past the end
+    uint32_t target = HT_EMPTY - 1;
+    if (i < rows) {
+        const fe_t key = ld_fe(input + i);
+        uint32_t h = ht_hash(key, mask);
+        for (;;) {
+            const uint32_t cur = slots[h];
+            if (cur == HT_EMPTY) { target = HT_EMPTY; break; }
+            if (Fr::eq(ld_fe(table + cur), key)) { target = cur; break; }
+            h = (h + 1) & mask;
+        }
     }
+    // A witness column is mostly ONE value on the rows where its lookup is switched off (the table's first element, chip.rs:560-575)
+    // and small digits elsewhere: a million lanes adding 1 to the same counter serialise (1.5 ms per 2^17-row column measured).  The
+    // lanes of a wave that hit the same row add once: three leader rounds take out the common values, the rest go one by one.
+    const uint32_t lane = threadIdx.x & 63;
+    bool pending = target != HT_EMPTY - 1;
+    for (int round = 0; round < 3; round++) {
+        const uint64_t act = __ballot(pending);
+        if (!act) break;
+        const int leader = __ffsll((unsigned long long)act) - 1;
+        const uint32_t lt = __shfl(target, leader);
+        const uint64_t same = __ballot(pending && target == lt);
+        if ((int)lane == leader) atomicAdd(lt == HT_EMPTY ? missing : &counts[lt], (uint32_t)__popcll(same));
+        if (pending && target == lt) pending = false;
+    }
+    if (pending) atomicAdd(target == HT_EMPTY ? missing : &counts[target], 1u);
 }
 __global__ __launch_bounds__(256) void counts_to_fr_kernel(const uint32_t* counts, uint32_t n, fe_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
