@@ -600,6 +600,48 @@ struct Backend {
         if (z0) scale(d_num, *z0, n);
         return d_num;
     }
+    // all chunks of the permutation argument at once: the denominators of every chunk share ONE batch inversion (see
+    // lookup_grand_sums); chunk j starts from the value chunk j-1 reaches on row `usable` (the chaining of permutation::prover::commit)
+    std::vector<Col> permutation_products(const std::vector<std::vector<Col>>& values, const std::vector<std::vector<Col>>& sigmas, const Fe& beta,
+                                          const Fe& gamma, const Col& omega_col, uint32_t usable) const {
+        const size_t nch = values.size();
+        std::vector<Col> zs;
+        if (!nch) return zs;
+        Col dens = alloc(nch * n);
+        const Fe delta{FR_DELTA};
+        uint32_t first = 0;
+        for (size_t c = 0; c < nch; c++) {
+            const uint32_t m = (uint32_t)values[c].size();
+            std::vector<Col> cols(values[c]);
+            cols.insert(cols.end(), sigmas[c].begin(), sigmas[c].end());
+            cols.push_back(omega_col);
+            std::vector<Fe> chal = {beta, gamma};
+            Fe dp = delta.pow(first);
+            for (uint32_t j = 0; j < m; j++) { chal.push_back(beta * dp); dp = dp * delta; }
+            Program den(k, k), num(k, k);
+            Src acc{}, accn{};
+            for (uint32_t j = 0; j < m; j++) {
+                Src t = den.add(den.add(den.mul(den.challenge(0), den.column(m + j)), den.challenge(1)), den.column(j));
+                acc = j == 0 ? t : den.mul(acc, t);
+                Src tn = num.add(num.add(num.mul(num.challenge(2 + j), num.column(2 * m)), num.challenge(1)), num.column(j));
+                accn = j == 0 ? tn : num.mul(accn, tn);
+            }
+            Col d_num = alloc(n);
+            den.run(cols, chal, at(dens, c * n));
+            num.run(cols, chal, d_num->ptr());
+            zs.push_back(d_num);
+            first += m;
+        }
+        invert(dens->ptr(), nch * n);
+        Fe last = Fe::one();
+        for (size_t c = 0; c < nch; c++) {
+            vec(EZKL_VEC_MUL, zs[c]->ptr(), at(dens, c * n), zs[c]->ptr(), n);
+            scan(EZKL_VEC_MUL, true, zs[c]->ptr(), zs[c]->ptr(), n);
+            if (c) scale(zs[c], last, n);
+            if (c + 1 < nch) last = get_row(zs[c], usable);
+        }
+        return zs;
+    }
     // phi[0] = 0, phi[i+1] = phi[i] + sum_j 1/(f_j[i] + beta) - m[i]/(t[i] + beta)   (mv_lookup::prover::commit_grand_sum)
     Col lookup_grand_sum(const std::vector<Col>& inputs, const Col& table, const Col& m, const Fe& beta) const {
         Col acc = zeros(n), tmp = alloc(n);
@@ -1465,20 +1507,18 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     std::vector<Col> zs;
     std::vector<Backend::Forms> z_forms;
     {
-        bool have_last = false;
-        Fe last;
         uint32_t pos = 0;
+        std::vector<std::vector<Col>> vals_all, sigs_all;
         for (auto& chunk : cs.perm_chunks()) {
             std::vector<Col> vals, sigs;
             for (auto& pc : chunk) vals.push_back(col_handle(pc.first, pc.second));
             for (size_t i = 0; i < chunk.size(); i++) sigs.push_back(pk.sigma_values[pos + i]);
-            Col z = be.permutation_product(vals, sigs, beta, gamma, pos, have_last ? &last : nullptr, pk.omega_col);
-            last = be.get_row(z, u);
-            have_last = true;
-            be.set_rows(z, u + 1, rng.vec(n - u - 1));
-            zs.push_back(z);
+            vals_all.push_back(vals);
+            sigs_all.push_back(sigs);
             pos += (uint32_t)chunk.size();
         }
+        zs = be.permutation_products(vals_all, sigs_all, beta, gamma, pk.omega_col, u);
+        for (auto& z : zs) be.set_rows(z, u + 1, rng.vec(n - u - 1));
         for (auto& z : zs) z_forms.push_back(be.forms_async(z, cs.ext_k));
         for (auto& p : be.commit_lagrange(zs)) T.write_point(p);
     }
