@@ -239,8 +239,13 @@ int ezkl_hip_bases_upload(const void* pts, size_t n, ezkl_bases_t* out) {
     EZ_CTX(c);
     Bases* b = new Bases();
     b->n = n;
-    EZ_HIP(hipMalloc(&b->pts, n * 64));
-    EZ_HIP(copy_sync(c, b->pts, pts, n * 64, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc(&b->pts, n * 64);
+    if (e == hipSuccess) e = copy_sync(c, b->pts, pts, n * 64, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {                     // nothing leaks on failure
+        if (b->pts) (void)hipFree(b->pts);
+        delete b;
+        return set_hip_error(e, "ezkl_hip_bases_upload", __FILE__, __LINE__);
+    }
     *out = reinterpret_cast<ezkl_bases_t>(b);
     return EZKL_OK;
 }

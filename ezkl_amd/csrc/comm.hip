@@ -164,6 +164,26 @@ int ezkl_hip_comm_fold_points(void* points_host, uint32_t count) {
     return EZKL_OK;
 }
 
+// broadcast of a small host buffer from `root` (an all_gather of everyone's copy, root's slice kept): the 256-bit ChaCha key of a sharded
+// proof drawn from OS entropy on rank 0 (every rank must blind with the same randomness to emit the same proof)
+int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root) {
+    if (!buf_host || bytes == 0 || bytes > 4096) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (!g_comm.comm || root < 0 || root >= g_comm.world) return EZKL_ERR_INVALID;
+    const size_t total = bytes * (size_t)g_comm.world;
+    if (g_comm.stage_bytes < total) {
+        if (g_comm.stage) EZ_HIP(hipFree(g_comm.stage));
+        EZ_HIP(hipMalloc(&g_comm.stage, total));
+        g_comm.stage_bytes = total;
+    }
+    char* st = (char*)g_comm.stage;
+    EZ_HIP(hipMemcpyAsync(st + bytes * (size_t)g_comm.rank, buf_host, bytes, hipMemcpyHostToDevice, g_comm.st));
+    EZ_RCCL(g_rccl.AllGather(st + bytes * (size_t)g_comm.rank, st, bytes, ncclUint8, g_comm.comm, g_comm.st));
+    EZ_HIP(hipMemcpyAsync(buf_host, st + bytes * (size_t)root, bytes, hipMemcpyDeviceToHost, g_comm.st));
+    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    return EZKL_OK;
+}
+
 // all-to-all on device pointers: for every peer p, send_len[p] bytes at send_dev + send_off[p] go to p, recv_len[p] bytes from p land
 // at recv_dev + recv_off[p].  All peers at once (grouped ncclSend / ncclRecv); the slice to self is a device-to-device copy.
 int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, const size_t* send_len, void* recv_dev, const size_t* recv_off,

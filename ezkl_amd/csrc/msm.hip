@@ -975,18 +975,20 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
     int rc = table_get(c, st, b, &T);
     if (rc) return rc;
     EZ_HIP(hipStreamSynchronize(st));          // inputs produced on the caller's stream are complete
-    for (size_t j = 0; j < batch + MSM_SLOTS; j++) {
+    for (size_t j = 0; j < batch + MSM_SLOTS && !rc; j++) {
         if (j >= MSM_SLOTS) {                  // retire the MSM that used this slot MSM_SLOTS iterations ago
             size_t done = j - MSM_SLOTS;
-            if (done < batch && (rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done))) return rc;
+            if (done < batch) rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done);
         }
-        if (j < batch) {
+        if (j < batch && !rc) {
             MsmSlot& sl = g_slots[j % MSM_SLOTS];
-            if ((rc = slot_prepare(sl, 0))) return rc;
-            if ((rc = msm_enqueue(c, sl, sl.st, T, base_offset, scalars[j], n, false))) return rc;
+            if (!(rc = slot_prepare(sl, 0))) rc = msm_enqueue(c, sl, sl.st, T, base_offset, scalars[j], n, false);
         }
     }
-    return EZKL_OK;
+    if (rc)                                    // a failed batch (e.g. out of memory mid-way) leaves no slot busy: later calls must not see EZKL_ERR_INVALID forever
+        for (auto& sl : g_slots)
+            if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
+    return rc;
 }
 
 // One prover phase in one call: upload `batch` host columns into the caller's device columns, overwrite their tail rows

@@ -2113,9 +2113,17 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
     return guarded([&] {
         const Shard& sh = pk->pk->cs->shard;
         const size_t want = sh.on() ? sh.hi - sh.lo : pk->pk->cs->n;
-        invalid(sh.on() && !rng && seed == 0, "sharded proving needs the same randomness on every rank: pass a seed or an rng callback");
         invalid(ezkl_hip_bases_len(g) < want || ezkl_hip_bases_len(g_lagrange) != want, "SRS size does not match 2^k (or this rank's slice)");
         Rng r(rng, rng_user, seed);
+        if (sh.on() && !rng && seed == 0) {
+            // every rank must blind with the SAME randomness to emit the same proof: rank 0's 256-bit OS-entropy key goes to everyone over
+            // the library communicator (full entropy, fresh per proof -- not a 64-bit seed).  Callback-sharded provers without the
+            // communicator must pass an rng callback that is identical on every rank, or a det-prove seed.
+            int world = 0, rank = 0;
+            check(ezkl_hip_comm_info(&world, &rank), "ezkl_hip_comm_info");
+            invalid(world < 1, "sharded proving needs the same randomness on every rank: pass a seed or an rng callback, or shard over ezkl_hip_comm_init");
+            check(ezkl_hip_comm_broadcast_host(r.key, sizeof r.key, 0), "ezkl_hip_comm_broadcast_host");
+        }
         std::vector<uint8_t> proof = create_proof(*pk->pk, g, g_lagrange, advice, advice_fn, advice_user, instances, instance_lens, r, timings);
         *proof_len = proof.size();
         if (proof.size() > cap || !proof_out) throw Error(EZKL_ERR_NOMEM, "proof buffer too small");

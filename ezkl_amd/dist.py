@@ -203,18 +203,27 @@ def probe_direct_gather(dist, device):
         _direct_gather_ok[0] = False
         return False
     world, rank = dist.get_world_size(), dist.get_rank()
-    ok = 1
+    def agree(ok):                                           # every rank takes part in the same collectives whatever happened locally
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag[0]))
+    buf, full = None, None
     try:
         buf = _b.DeviceBuffer(world * 256)
         _b.memcpy_h2d(buf.ptr + 256 * rank, np.full(256, rank + 1, np.uint8))
         full = torch.as_tensor(DeviceBytes(buf.ptr, world * 256), device=device)
+    except Exception:
+        full = None
+    if not agree(full is not None):                          # a rank that cannot alias the pointer must not leave the others in the all_gather
+        _direct_gather_ok[0] = False
+        return False
+    ok = True
+    try:
         dist.all_gather_into_tensor(full, full[256 * rank:256 * (rank + 1)])
         torch.cuda.synchronize(device)
         got = _b.memcpy_d2h(buf.ptr, world * 256).reshape(world, 256)
-        ok = int(all((got[r] == r + 1).all() for r in range(world)))
+        ok = all((got[r] == r + 1).all() for r in range(world))
     except Exception:
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    _direct_gather_ok[0] = bool(int(flag[0]))
+        ok = False
+    _direct_gather_ok[0] = agree(ok)
     return _direct_gather_ok[0]

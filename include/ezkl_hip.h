@@ -225,6 +225,8 @@ int ezkl_hip_comm_destroy(void);
 int ezkl_hip_comm_allgather_dev(void* buf_dev, size_t total_bytes);
 /* one commit batch: `count` 64-byte affine Montgomery partial sums (host) -> their sums over all ranks, in place, on every rank */
 int ezkl_hip_comm_fold_points(void* points_host, uint32_t count);
+/* broadcast of a small host buffer (<= 4096 B) from rank `root`: the OS-entropy ChaCha key of a sharded proof */
+int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root);
 /* all-to-all on device pointers (per-peer byte offsets / lengths): columns transformed by their owner -> the row shards of the sweep */
 int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, const size_t* send_len, void* recv_dev, const size_t* recv_off,
                                const size_t* recv_len);

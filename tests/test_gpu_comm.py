@@ -34,6 +34,13 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
         assert nc.set_shard_comm() == (0, cs.n)
         pk = NV.NativeProvingKey(nc, bg, fixed, copies)
         assert NV.create_proof(pk, bg, bgl, adv, seed=9) == want
+        # seed 0 on a sharded prover: rank 0's 256-bit OS-entropy key is broadcast over the communicator (not a 64-bit seed)
+        from oracle import verifier as V
+        p0, p1 = NV.create_proof(pk, bg, bgl, adv, seed=0), NV.create_proof(pk, bg, bgl, adv, seed=0)
+        assert p0 != p1 and len(p0) == len(want)
+        _, vk = P.keygen(cs, P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], 6), fixed, copies)
+        g1, g2, s_g2 = TP.setup(golden_srs)
+        assert V.verify(vk, g1, g2, s_g2, p0)
     finally:
         B.comm_destroy()
     assert B.comm_info() == (0, 0)
