@@ -30,7 +30,7 @@ def build(kind, k, gpu=None, seed=1, **kw):
     """-> dict(cs, fixed (Montgomery arrays), copies, advice (list of arrays, or callable(phase, challenges)), instances, info)"""
     rng = np.random.default_rng(seed)
     if kind == "einsum":
-        L = kw.get("length") or {20: 512, 19: 360, 18: 256, 17: 180, 16: 128, 15: 90, 14: 64, 12: 30, 10: 14, 8: 6, 6: 3}[k]
+        L = kw.get("length") or {22: 1024, 21: 720, 20: 512, 19: 360, 18: 256, 17: 180, 16: 128, 15: 90, 14: 64, 12: 30, 10: 14, 8: 6, 6: 3}[k]
         c = EL.EinsumMatmulCircuit(k, L)
         a, b = rng.integers(-128, 128, (L, L)), rng.integers(-128, 128, (L, L))
         cs, fixed, copies, rows = c.keygen_inputs(a, b)

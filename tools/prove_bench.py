@@ -56,6 +56,7 @@ if CIRCUIT != "synthetic":
     kw = {}
     if os.environ.get("LAYERS"): kw["layers"] = int(os.environ["LAYERS"])
     if os.environ.get("WIDTH"): kw["width"] = int(os.environ["WIDTH"])
+    if os.environ.get("LENGTH"): kw["length"] = int(os.environ["LENGTH"])
     built = BC.build(CIRCUIT, k, gpu=B, **kw)
     cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
     circuit_info = dict(built["info"], **BC.describe(cs), layout_seconds_python=round(time.time() - t0, 1))
