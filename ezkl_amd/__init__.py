@@ -3,6 +3,8 @@
 The product is `libezkl_hip.so` (C ABI in include/ezkl_hip.h).  This package is the thin Python host
 mirror of the reference interface (ParamsKZG / EvaluationDomain / GraphEvaluator semantics) used by the
 tests and bench; it never falls back to a CPU path: without the HIP library or a GPU every op raises."""
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before any HIP runtime initialises (torch included): see ctx_init in csrc/capi.hip
 from .lib import EzklHipError, load, lib_path  # noqa: F401
 from . import codecs  # noqa: F401
 

@@ -751,7 +751,17 @@ void msm_table_drop(const Bases* b) {
 // One in-flight MSM: its own scratch arena, a pinned landing buffer for the plane sums and a completion event.
 // A batch (one commit phase of the prover) is pipelined over MSM_SLOTS of these on separate streams so that the
 // latency-bound sort / reduce tails of one MSM and the host Horner overlap the accumulate kernel of the next.
-static constexpr int MSM_SLOTS = 6;
+static constexpr int MSM_MAX_SLOTS = 16;
+// how many MSMs of a batch are in flight: EZKL_MSM_SLOTS (1..16) overrides the default
+static int msm_slots_init() {
+    int v = 6;
+    if (const char* e = getenv("EZKL_MSM_SLOTS")) {
+        const int x = atoi(e);
+        if (x >= 1 && x <= MSM_MAX_SLOTS) v = x;
+    }
+    return v;
+}
+static const int MSM_SLOTS = msm_slots_init();
 struct MsmSlot {
     hipStream_t st = nullptr;
     uint8_t* scratch = nullptr;
@@ -761,7 +771,7 @@ struct MsmSlot {
     uint32_t bits = 0;
     bool busy = false;
 };
-static MsmSlot g_slots[MSM_SLOTS];
+static MsmSlot g_slots[MSM_MAX_SLOTS];
 
 static int slot_prepare(MsmSlot& sl, size_t bytes) {
     if (!sl.st) {

@@ -10,6 +10,7 @@ randomness and requires its proof to be byte-identical)
 The SRS is generated here with a known secret (no public SRS without network, src/pfsys/srs.rs:10-11)."""
 import json, os, sys, time
 import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch / HIP initialise (the library's default, csrc/capi.hip ctx_init)
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 import ezkl_amd
