@@ -65,6 +65,14 @@ __device__ __forceinline__ uint32_t msm_lane_len(const uint32_t* offsets, uint32
 // the first `rem` windows base+1 bits wide, the others base bits.  Balanced widths instead of "c, c, ..., short top
 // window": a 14-bit top window under c = 20 pours 128 extra pairs into each of 2^13 buckets, which then get cut by
 // several lane boundaries of the accumulate kernel; with 7 x 20 + 6 x 19 bits no bucket outgrows a lane.
+// Batched launches: one launch serves `gridDim.z` MSMs of the same size whose scratch slabs have the same layout `bstride` bytes
+// apart; a kernel shifts every scratch pointer it is given by blockIdx.z * bstride (bstride = 0 / gridDim.z = 1: a single MSM).
+template <class T> __device__ __forceinline__ T* bshift(T* p, size_t bytes) {
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes);
+}
+#define BSH(p) p = bshift(p, _bo)
+#define BOFF() const size_t _bo = (size_t)blockIdx.z * bstride
+
 struct WinPlan {
     uint32_t W, base, rem;
     __host__ __device__ uint32_t width(uint32_t w) const { return base + (w < rem ? 1u : 0u); }
@@ -192,7 +200,10 @@ __device__ __forceinline__ bool msm_digit_step(fe_t& s, uint32_t neg, uint32_t c
 // rows into per-(workgroup, partition) start slots; the partition pass ranks its pairs with LDS atomics into an LDS
 // staging area grouped by partition and writes them out in staged order (runs of one partition leave as whole cache lines).
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
-                                                       uint32_t LB, uint32_t NP, uint32_t* wg_hist, uint32_t* wg_cnt) {
+                                                       uint32_t LB, uint32_t NP, uint32_t* wg_hist, uint32_t* wg_cnt,
+                                                       const fe_t* const* scal_list, size_t bstride) {
+    BOFF(); BSH(wg_hist); BSH(wg_cnt);
+    if (scal_list) scalars = scal_list[blockIdx.z];
     __shared__ uint32_t lh[(1u << MSM_MAX_PART_BITS) + 1];
     const uint32_t NQ = NP + 1;                                           // + the bucket-0 partition
     for (uint32_t p = threadIdx.x; p < NQ; p += 256) lh[p] = 0;
@@ -225,7 +236,8 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
 // wg_hist[g][p] (G workgroups x NP partitions) -> in place, the exclusive prefix over g of column p; part_count[p] = column
 // total.  One workgroup per 32 columns: thread (c, j) sums the j-th chunk of G/32 rows of column c (a row segment of 32
 // columns is one 128-byte line), the 32 chunk sums of a column are scanned in LDS, then the rows are rewritten.
-__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count) {
+__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count, size_t bstride) {
+    BOFF(); BSH(wg_hist); BSH(part_count);
     __shared__ uint32_t sums[32][33];
     const uint32_t c = threadIdx.x & 31, j = threadIdx.x >> 5;
     const uint32_t p = blockIdx.x * 32 + c;
@@ -257,7 +269,8 @@ __global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, 
 // exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs.  Also lists the oversized
 // ordinary partitions (big_flag[p] = 1 + slot, big_list[slot] = p, big_count[0] = how many asked for a slot).
 __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
-                                                             uint32_t* big_list, uint32_t* big_count) {
+                                                             uint32_t* big_list, uint32_t* big_count, size_t bstride) {
+    BOFF(); BSH(part_count); BSH(part_base); BSH(big_flag); BSH(big_list); BSH(big_count);
     __shared__ uint32_t sh[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t v0 = 2 * t < NQ ? part_count[2 * t] : 0, v1 = 2 * t + 1 < NQ ? part_count[2 * t + 1] : 0;
@@ -294,7 +307,9 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
 __global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                              uint32_t LB, uint32_t NP, size_t base_offset, size_t tab_stride,
                                                              const uint32_t* part_base, const uint32_t* wg_hist, const uint32_t* wg_cnt, uint2* entries,
-                                                             uint32_t* vals) {
+                                                             uint32_t* vals, const fe_t* const* scal_list, size_t bstride) {
+    BOFF(); BSH(part_base); BSH(wg_hist); BSH(wg_cnt); BSH(entries); BSH(vals);
+    if (scal_list) scalars = scal_list[blockIdx.z];
     extern __shared__ uint32_t plds[];
     __shared__ uint32_t tsum[1024];
     const uint32_t NQ = NP + 1;                // partitions incl. bucket 0's (msm_part_of); the arrays below are padded to NQ + 1 words
@@ -401,7 +416,8 @@ __device__ __forceinline__ void msm_bins_scan(uint32_t* cnt, uint32_t* tsum, uin
     __syncthreads();
 }
 __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
-                                                          const uint32_t* big_flag, uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
+                                                          const uint32_t* big_flag, uint32_t* offsets, uint32_t* vals, g1x29_t* buckets, size_t bstride) {
+    BOFF(); BSH(entries); BSH(part_base); BSH(big_flag); BSH(offsets); BSH(vals); BSH(buckets);
     __shared__ uint32_t cnt[2048];
     __shared__ uint32_t tsum[512];
     extern __shared__ uint32_t stage[];                      // MSM_BINSORT_STAGE sorted payloads: written out as one contiguous run
@@ -461,7 +477,8 @@ __device__ __forceinline__ void msm_big_slice(uint32_t beg, uint32_t end, uint32
     if (s0 > end) s0 = end;
 }
 __global__ __launch_bounds__(512) void msm_bigsort_count_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
-                                                                const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off) {
+                                                                const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off, size_t bstride) {
+    BOFF(); BSH(entries); BSH(part_base); BSH(big_list); BSH(big_count); BSH(bin_total); BSH(block_off);
     __shared__ uint32_t cnt[2048];
     const uint32_t y = blockIdx.y, t = threadIdx.x, nbins = 1u << LB;
     if (y >= (big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG)) return;
@@ -477,7 +494,8 @@ __global__ __launch_bounds__(512) void msm_bigsort_count_kernel(const uint2* ent
 }
 __global__ __launch_bounds__(512) void msm_bigsort_scatter_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
                                                                   const uint32_t* big_count, const uint32_t* bin_total, const uint32_t* block_off,
-                                                                  uint32_t* offsets, uint32_t* vals, g1x29_t* buckets) {
+                                                                  uint32_t* offsets, uint32_t* vals, g1x29_t* buckets, size_t bstride) {
+    BOFF(); BSH(entries); BSH(part_base); BSH(big_list); BSH(big_count); BSH(bin_total); BSH(block_off); BSH(offsets); BSH(vals); BSH(buckets);
     __shared__ uint32_t cnt[2048];
     __shared__ uint32_t tsum[512];
     const uint32_t y = blockIdx.y, t = threadIdx.x, nbins = 1u << LB;
@@ -516,7 +534,8 @@ __device__ __forceinline__ MsmRec msm_fetch(const g1a_t* tab, uint32_t v) {
 }
 __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
                                                              uint32_t nb, uint32_t nlanes, g1x29_t* buckets, g1x29_t* head, g1x29_t* tail,
-                                                             uint32_t* lane_first) {
+                                                             uint32_t* lane_first, size_t bstride) {
+    BOFF(); BSH(offsets); BSH(vals); BSH(buckets); BSH(head); BSH(tail); BSH(lane_first);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offsets[nb], L = msm_lane_len(offsets, nb, nlanes);
     const uint64_t k0w = (uint64_t)t * L;
@@ -568,7 +587,8 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
 // longer (a skewed witness) is queued for msm_fixup_heavy{1,2}_kernel.
 __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes,
                                                                  const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
-                                                                 uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list) {
+                                                                 uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list, size_t bstride) {
+    BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(tail); BSH(buckets); BSH(heavy_list); BSH(heavy_count); BSH(chunk_list);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
     if (t >= nlanes) return;
     const uint32_t L = msm_lane_len(offsets, nb, nlanes);
@@ -593,7 +613,8 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
 // Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
 // (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
 __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const uint32_t* lane_first, g1x29_t* head,
-                                                               const uint32_t* chunk_list, const uint32_t* counts) {
+                                                               const uint32_t* chunk_list, const uint32_t* counts, size_t bstride) {
+    BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(chunk_list); BSH(counts);
     __shared__ uint4 sh[9 * 4];
     const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes);
     for (uint32_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
@@ -607,7 +628,8 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* o
     }
 }
 __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
-                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets) {
+                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets, size_t bstride) {
+    BOFF(); BSH(offsets); BSH(head); BSH(tail); BSH(heavy_list); BSH(counts); BSH(buckets);
     __shared__ uint4 sh[9 * 4];
     const uint32_t L = msm_lane_len(offsets, nb, nlanes);
     for (uint32_t h = blockIdx.x; h < counts[0]; h += gridDim.x) {
@@ -632,7 +654,8 @@ struct ReduceGeom {
     uint32_t wsA, wsB, wsC;       // weight shifts of the fields
     uint32_t EA, GA, ET, GT;      // serial elements per lane / groups for column sums (A) and row sums (T)
 };
-__global__ __launch_bounds__(256, 2) void msm_reduce1_kernel(const g1x29_t* buckets, ReduceGeom g, g1x29_t* partA, g1x29_t* partT) {
+__global__ __launch_bounds__(256, 2) void msm_reduce1_kernel(const g1x29_t* buckets, ReduceGeom g, g1x29_t* partA, g1x29_t* partT, size_t bstride) {
+    BOFF(); BSH(buckets); BSH(partA); BSH(partT);
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     g1x29_t acc = g1x29_identity();
     if (blockIdx.y == 0) {            // column sums: S_A[dA] partials
@@ -652,7 +675,8 @@ __global__ __launch_bounds__(256, 2) void msm_reduce1_kernel(const g1x29_t* buck
 // (a few serial additions, then a shuffle tree).  The lane counts are chosen by the host so that the launch has at most one
 // wave per SIMD: these chains are latency-bound, and a second wave on a SIMD doubles the latency of both.
 __global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x29_t* partA, const g1x29_t* partT, ReduceGeom g, g1x29_t* SA, g1x29_t* T, uint32_t lanesA,
-                                                         uint32_t lanesT, uint32_t blocksA) {
+                                                         uint32_t lanesT, uint32_t blocksA, size_t bstride) {
+    BOFF(); BSH(partA); BSH(partT); BSH(SA); BSH(T);
     const bool isA = blockIdx.x < blocksA;
     const uint32_t lanes = isA ? lanesA : lanesT, per = 64 / lanes;
     const uint32_t o = (isA ? blockIdx.x : blockIdx.x - blocksA) * per + threadIdx.x / lanes, j = threadIdx.x % lanes;
@@ -666,7 +690,8 @@ __global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x29_t* partA, c
     if (j == 0 && o < nout) st_g1x29((isA ? SA : T) + o, acc);
 }
 // one workgroup per plane: planes[0] = TOTAL; planes[1 + ws + j] = sum of the field sums whose digit has bit j
-__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes) {
+__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes, size_t bstride) {
+    BOFF(); BSH(SA); BSH(T); BSH(planes);
     __shared__ uint4 sh[9 * 4];
     uint32_t id = blockIdx.x, field = 0, j = 0;      // field 0: TOTAL, 1: A, 2: B, 3: C
     if (id > 0) {
@@ -766,18 +791,32 @@ struct MsmSlot {
     hipStream_t st = nullptr;
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
-    uint32_t* pinned = nullptr;       // 1 + 22 planes of 36 limbs (g1x29_t)
+    uint32_t* pinned = nullptr;       // per MSM of the group: 1 + 22 planes of 36 limbs (g1x29_t), 32 records apart
+    size_t pinned_msms = 0;
+    const fe_t** list_pinned = nullptr;   // the group's scalar-column pointers, staged for the device
     hipEvent_t done = nullptr;
     uint32_t bits = 0;
+    uint32_t count = 0;               // MSMs in flight in this slot (one fused group)
+    void* out = nullptr;              // where msm_finish puts the group's `count` affine results (64 B each)
     bool busy = false;
 };
 static MsmSlot g_slots[MSM_MAX_SLOTS];
 
-static int slot_prepare(MsmSlot& sl, size_t bytes) {
+static constexpr size_t MSM_MAX_GROUP = 16;       // MSMs fused into one sequence of launches (gridDim.z)
+static int slot_prepare(MsmSlot& sl, size_t bytes, size_t msms = 1) {
     if (!sl.st) {
         EZ_HIP(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
         EZ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        EZ_HIP(hipHostMalloc((void**)&sl.pinned, 32 * sizeof(g1x29_t), hipHostMallocDefault));
+        EZ_HIP(hipHostMalloc((void**)&sl.list_pinned, MSM_MAX_GROUP * sizeof(void*), hipHostMallocDefault));
+    }
+    if (msms > sl.pinned_msms) {
+        if (sl.pinned) {
+            EZ_HIP(hipStreamSynchronize(sl.st));
+            EZ_HIP(hipHostFree(sl.pinned));
+            sl.pinned = nullptr;
+        }
+        EZ_HIP(hipHostMalloc((void**)&sl.pinned, msms * 32 * sizeof(g1x29_t), hipHostMallocDefault));
+        sl.pinned_msms = msms;
     }
     if (bytes > sl.scratch_bytes) {
         if (sl.scratch) {
@@ -793,23 +832,42 @@ static int slot_prepare(MsmSlot& sl, size_t bytes) {
     return EZKL_OK;
 }
 // host tail: result = TOTAL + sum_k 2^k * plane[1+k] (Horner from the top bit), then canonical affine
-static int msm_finish(MsmSlot& sl, void* out_host) {
+static int msm_finish(MsmSlot& sl, void* out_host = nullptr) {
+    if (!out_host) out_host = sl.out;
     EZ_HIP(hipEventSynchronize(sl.done));
-    const uint32_t* hp = sl.pinned;            // planes in the kernels' radix-2^29 form -> canonical 64-bit limbs
-    h64::xyzz acc = h64::identity();
-    for (int k = (int)sl.bits - 1; k >= 0; k--) {
-        acc = h64::dbl(acc);
-        acc = h64::add(acc, h64::from_limbs29_point(hp + 36 * (1 + k)));
+    for (uint32_t j = 0; j < sl.count; j++) {
+        const uint32_t* hp = sl.pinned + (size_t)j * 32 * 36;   // planes in the kernels' radix-2^29 form -> canonical 64-bit limbs
+        h64::xyzz acc = h64::identity();
+        for (int k = (int)sl.bits - 1; k >= 0; k--) {
+            acc = h64::dbl(acc);
+            acc = h64::add(acc, h64::from_limbs29_point(hp + 36 * (1 + k)));
+        }
+        acc = h64::add(acc, h64::from_limbs29_point(hp));
+        h64::aff r = h64::to_affine(acc);
+        memcpy((uint8_t*)out_host + 64 * (size_t)j, &r, 64);
     }
-    acc = h64::add(acc, h64::from_limbs29_point(hp));
-    h64::aff r = h64::to_affine(acc);
-    memcpy(out_host, &r, 64);
     sl.busy = false;
     return EZKL_OK;
 }
 
-static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t base_offset, const fe_t* scalars, size_t n, bool timed) {
+// how many MSMs of this size are fused into one group: enough to amortise the ~14 launches and the latency-bound sort / fixup / reduce
+// tails (at 2^17 points a lone MSM is 0.12 ms of accumulation inside a 0.6 ms chain), bounded by scratch (about 64 M pairs per group)
+static size_t msm_group_size(const MsmTable* T, size_t n) {
+    if (const char* e = getenv("EZKL_MSM_GROUP")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= (int)MSM_MAX_GROUP) return (size_t)v;
+    }
+    size_t g = ((size_t)64 << 20) / (n * T->wp.W + 1);
+    if (g < 1) g = 1;
+    if (g > MSM_MAX_GROUP) g = MSM_MAX_GROUP;
+    return g;
+}
+// `count` MSMs of n points each (scalar columns cols[0..count)) as ONE sequence of launches with gridDim.z = count
+static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t base_offset, const fe_t* const* cols, size_t count, size_t n, bool timed) {
     int rc = EZKL_OK;
+    if (count < 1 || count > MSM_MAX_GROUP) return EZKL_ERR_INVALID;
+    const unsigned Z = (unsigned)count;
+    const fe_t* scalars = cols[0];
     const WinPlan wp = T->wp;
     const uint32_t W = wp.W, bits = wp.cmax() - 1;
     const uint32_t nb = 1u << bits;
@@ -868,6 +926,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    size_t o_list = carve(MSM_MAX_GROUP * sizeof(void*));   // (first slab only) the group's scalar-column pointers
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
     const uint32_t NQ = NP + 1;                          // + bucket 0's own partition (msm_part_of)
     size_t o_pcnt = carve((NQ + 1) * 4), o_pbase = carve((NQ + 1) * 4), o_wgh = carve((size_t)sgrid * NQ * 4), o_wgc = carve((size_t)sgrid * NQ * 4);
@@ -881,9 +940,16 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     size_t o_partA = carve((size_t)n_partA * sizeof(g1x29_t)), o_partT = carve((size_t)n_partT * sizeof(g1x29_t));
     size_t o_SA = carve((size_t)nA * sizeof(g1x29_t)), o_T = carve((size_t)nT * sizeof(g1x29_t));
     size_t o_planes = carve((size_t)nplanes * sizeof(g1x29_t));
-    rc = slot_prepare(sl, off);
+    const size_t bstride = count > 1 ? off : 0;           // every MSM of the group owns one slab of this layout
+    rc = slot_prepare(sl, off * count, count);
     if (rc) return rc;
     uint8_t* S = sl.scratch;
+    const fe_t* const* scal_list = nullptr;
+    if (count > 1) {
+        for (size_t j = 0; j < count; j++) sl.list_pinned[j] = cols[j];
+        EZ_HIP(hipMemcpyAsync(S + o_list, sl.list_pinned, count * sizeof(void*), hipMemcpyHostToDevice, st));
+        scal_list = (const fe_t* const*)(S + o_list);
+    }
     uint2* entries = (uint2*)(S + o_ent);
     uint32_t* vals = (uint32_t*)(S + o_vals);
     uint32_t* offs = (uint32_t*)(S + o_offs);
@@ -902,39 +968,41 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
         EZ_HIP(hipEventRecord(m0, st));
     }
-    EZ_HIP(hipMemsetAsync(hcnt, 0, 12, st));
-    EZ_HIP(hipMemsetAsync(btot, 0, MSM_MAX_BIG * nbins * 4, st));
-    EZ_HIP(hipMemsetAsync(planes, 0, (size_t)nplanes * sizeof(g1x29_t), st));
+    for (size_t j = 0; j < count; j++) {
+        EZ_HIP(hipMemsetAsync((uint8_t*)hcnt + j * bstride, 0, 12, st));
+        EZ_HIP(hipMemsetAsync((uint8_t*)btot + j * bstride, 0, MSM_MAX_BIG * nbins * 4, st));
+        EZ_HIP(hipMemsetAsync((uint8_t*)planes + j * bstride, 0, (size_t)nplanes * sizeof(g1x29_t), st));
+    }
     // sort
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt);
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32)), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt);
-    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1), dim3(1024), 0, st, pcnt, NQ, pbase, bflag, blist, bcnt);
-    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
-                       LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals);
-    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs, vals, bkt);
-    hipLaunchKernelGGL(msm_bigsort_count_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff);
-    hipLaunchKernelGGL(msm_bigsort_scatter_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, offs,
-                       vals, bkt);
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, bstride);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, bstride);
+    hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1, 1, Z), dim3(1024), 0, st, pcnt, NQ, pbase, bflag, blist, bcnt, bstride);
+    hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid, 1, Z), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
+                       LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals, scal_list, bstride);
+    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP, 1, Z), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs, vals, bkt, bstride);
+    hipLaunchKernelGGL(msm_bigsort_count_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, bstride);
+    hipLaunchKernelGGL(msm_bigsort_scatter_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, offs,
+                       vals, bkt, bstride);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256)), dim3(256), 0, st, T->tab, offs, vals, nb, nlanes, bkt, head, tail,
-                       lfirst);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256), 1, Z), dim3(256), 0, st, T->tab, offs, vals, nb, nlanes, bkt, head, tail,
+                       lfirst, bstride);
     if (timed) EZ_HIP(hipEventRecord(a1, st));
     if (nlanes > 1)
-        hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256)), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
-                           heavy, hcnt, chunks);
+        hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
+                           heavy, hcnt, chunks, bstride);
     {
         size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
         size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
         unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt);
-        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt);
+        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt, bstride);
+        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, bstride);
     }
     // reduce
     {
         const uint32_t th = n_partA > n_partT ? n_partA : n_partT;
-        hipLaunchKernelGGL(msm_reduce1_kernel, dim3(cdiv(th, 256), 2), dim3(256), 0, st, bkt, rg, partA, partT);
+        hipLaunchKernelGGL(msm_reduce1_kernel, dim3(cdiv(th, 256), 2, Z), dim3(256), 0, st, bkt, rg, partA, partT, bstride);
         auto pow2_le = [](uint32_t x) { uint32_t p = 1; while (p * 2 <= x) p *= 2; return p; };
         uint32_t lanesA = pow2_le(rg.GA < 64 ? rg.GA : 64), lanesT = pow2_le(rg.GT < 64 ? rg.GT : 64);
         auto waves = [&](uint32_t nout, uint32_t lanes) { return cdiv(nout, 64 / lanes); };
@@ -942,8 +1010,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
             if (lanesT > 1 && waves(nT, lanesT) >= waves(nA, lanesA)) lanesT >>= 1; else if (lanesA > 1) lanesA >>= 1; else lanesT >>= 1;
         }
         const uint32_t blocksA = waves(nA, lanesA);
-        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT)), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA);
-        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes), dim3(256), 0, st, SA, TT, rg, planes);
+        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT), 1, Z), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA, bstride);
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, bstride);
     }
     EZ_HIP(hipGetLastError());
     if (getenv("EZKL_MSM_DEBUG")) {
@@ -953,11 +1021,41 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         fprintf(stderr, "[msm] n=%zu W=%u bits=%u L=%u nlanes=%u heavy=%u\n", n, W, bits, L, nlanes, hc);
     }
     if (timed) EZ_HIP(hipEventRecord(m1, st));
-    EZ_HIP(hipMemcpyAsync(sl.pinned, planes, (size_t)nplanes * sizeof(g1x29_t), hipMemcpyDeviceToHost, st));
+    for (size_t j = 0; j < count; j++)
+        EZ_HIP(hipMemcpyAsync(sl.pinned + j * 32 * 36, (uint8_t*)planes + j * bstride, (size_t)nplanes * sizeof(g1x29_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipEventRecord(sl.done, st));
     sl.bits = bits;
+    sl.count = (uint32_t)count;
     sl.busy = true;
     return EZKL_OK;
+}
+// A batch of `batch` MSMs as fused groups pipelined over the slot streams: group g runs on slot g % MSM_SLOTS; a slot is retired
+// (host Horner, results written to their place in out_host) before it is reused.  wait_ev (optional): column j may only be read
+// after wait_ev[j] (the upload phase's copy events).
+static int msm_run_groups(Ctx* c, MsmTable* T, size_t base_offset, const fe_t* const* cols, size_t batch, size_t n, void* out_host,
+                          const hipEvent_t* wait_ev) {
+    const size_t G = msm_group_size(T, n);
+    int rc = EZKL_OK;
+    size_t gi = 0;
+    for (size_t j0 = 0; j0 < batch && !rc; j0 += G, gi++) {
+        const size_t cnt = batch - j0 < G ? batch - j0 : G;
+        MsmSlot& sl = g_slots[gi % MSM_SLOTS];
+        if (sl.busy) rc = msm_finish(sl);
+        if (!rc) rc = slot_prepare(sl, 0);
+        for (size_t j = 0; wait_ev && j < cnt && !rc; j++)
+            if (hipStreamWaitEvent(sl.st, wait_ev[j0 + j], 0) != hipSuccess) rc = EZKL_ERR_HIP;
+        if (!rc) {
+            sl.out = (uint8_t*)out_host + 64 * j0;
+            rc = msm_enqueue(c, sl, sl.st, T, base_offset, cols + j0, cnt, n, false);
+        }
+    }
+    for (size_t k = 0; k < (size_t)MSM_SLOTS; k++) {     // drain in launch order
+        MsmSlot& sl = g_slots[(gi + k) % MSM_SLOTS];
+        if (!sl.busy) continue;
+        if (!rc) rc = msm_finish(sl);
+        else { (void)hipStreamSynchronize(sl.st); sl.busy = false; }   // a failed batch leaves no slot busy
+    }
+    return rc;
 }
 
 struct MsmBatch;
@@ -970,7 +1068,7 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     if (rc) return rc;
     MsmSlot& sl = g_slots[0];
     if (sl.busy) return EZKL_ERR_INVALID;
-    if ((rc = msm_enqueue(c, sl, st, T, base_offset, scalars, n, true))) return rc;
+    if ((rc = msm_enqueue(c, sl, st, T, base_offset, &scalars, 1, n, true))) return rc;
     return msm_finish(sl, out_host);
 }
 
@@ -985,20 +1083,7 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
     int rc = table_get(c, st, b, &T);
     if (rc) return rc;
     EZ_HIP(hipStreamSynchronize(st));          // inputs produced on the caller's stream are complete
-    for (size_t j = 0; j < batch + MSM_SLOTS && !rc; j++) {
-        if (j >= MSM_SLOTS) {                  // retire the MSM that used this slot MSM_SLOTS iterations ago
-            size_t done = j - MSM_SLOTS;
-            if (done < batch) rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done);
-        }
-        if (j < batch && !rc) {
-            MsmSlot& sl = g_slots[j % MSM_SLOTS];
-            if (!(rc = slot_prepare(sl, 0))) rc = msm_enqueue(c, sl, sl.st, T, base_offset, scalars[j], n, false);
-        }
-    }
-    if (rc)                                    // a failed batch (e.g. out of memory mid-way) leaves no slot busy: later calls must not see EZKL_ERR_INVALID forever
-        for (auto& sl : g_slots)
-            if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
-    return rc;
+    return msm_run_groups(c, T, base_offset, scalars, batch, n, out_host, nullptr);
 }
 
 // One prover phase in one call: upload `batch` host columns into the caller's device columns, overwrite their tail rows
@@ -1076,22 +1161,10 @@ int msm_upload_commit(Ctx* c, MsmUpload* u, const Bases* b, size_t commit_first,
     }
     MsmTable* T = nullptr;
     int rc = table_get(c, c->stream, b, &T);
-    for (size_t j = 0; j < batch + MSM_SLOTS && !rc; j++) {
-        if (j >= MSM_SLOTS) {
-            size_t done = j - MSM_SLOTS;
-            if (done < batch) rc = msm_finish(g_slots[done % MSM_SLOTS], (uint8_t*)out_host + 64 * done);
-        }
-        if (j < batch && !rc) {
-            MsmSlot& sl = g_slots[j % MSM_SLOTS];
-            rc = slot_prepare(sl, 0);
-            if (!rc && hipStreamWaitEvent(sl.st, u->ev[j], 0) != hipSuccess) rc = EZKL_ERR_HIP;
-            if (!rc) rc = msm_enqueue(c, sl, sl.st, T, 0, u->dev_cols[j] + commit_first, commit_count, false);
-        }
-    }
-    if (rc)
-        for (auto& sl : g_slots)
-            if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
-    return rc;
+    if (rc) return rc;
+    std::vector<const fe_t*> cols(batch);
+    for (size_t j = 0; j < batch; j++) cols[j] = u->dev_cols[j] + commit_first;
+    return msm_run_groups(c, T, 0, cols.data(), batch, commit_count, out_host, u->ev.data());
 }
 bool msm_upload_is_open() { return g_open_upload != nullptr; }
 
@@ -1135,7 +1208,7 @@ int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev) {
     if (mb->pushed - mb->retired >= (size_t)MSM_SLOTS && (rc = msm_batch_retire_one(mb))) return rc;
     MsmSlot& sl = g_slots[mb->pushed % MSM_SLOTS];
     if ((rc = slot_prepare(sl, 0))) return rc;
-    if ((rc = msm_enqueue(c, sl, sl.st, mb->T, mb->base_offset, scalars_dev, mb->n, false))) return rc;
+    if ((rc = msm_enqueue(c, sl, sl.st, mb->T, mb->base_offset, &scalars_dev, 1, mb->n, false))) return rc;
     mb->pushed++;
     return EZKL_OK;
 }
