@@ -850,17 +850,17 @@ static int msm_finish(MsmSlot& sl, void* out_host = nullptr) {
     return EZKL_OK;
 }
 
-// how many MSMs of this size are fused into one group: enough to amortise the ~14 launches and the latency-bound sort / fixup / reduce
-// tails (at 2^17 points a lone MSM is 0.12 ms of accumulation inside a 0.6 ms chain), bounded by scratch (about 64 M pairs per group)
+// how many MSMs of this size are fused into one group (gridDim.z): small MSMs are launch- and latency-bound (at 2^17 points a lone MSM
+// is 0.12 ms of accumulation inside a 0.6 ms chain of ~17 launches)
 static size_t msm_group_size(const MsmTable* T, size_t n) {
     if (const char* e = getenv("EZKL_MSM_GROUP")) {
         const int v = atoi(e);
         if (v >= 1 && v <= (int)MSM_MAX_GROUP) return (size_t)v;
     }
-    size_t g = ((size_t)64 << 20) / (n * T->wp.W + 1);
-    if (g < 1) g = 1;
-    if (g > MSM_MAX_GROUP) g = MSM_MAX_GROUP;
-    return g;
+    // measured (k = 17 MLP proof, 56 MSMs, 7 proofs per setting): groups of 4 on the six slot streams 40.4-41.9 ms, no fusing 43.0-46.3,
+    // groups of 16 41.2-45.7 (one group per phase leaves nothing for the other slots to overlap); at 2^20 points the sort / fixup /
+    // reduce kernels are throughput-bound, a fused group serialises what separate streams overlap (1.50 vs 1.35 ms per MSM): no fusing
+    return n * T->wp.W <= ((size_t)4 << 20) ? 4 : 1;
 }
 // `count` MSMs of n points each (scalar columns cols[0..count)) as ONE sequence of launches with gridDim.z = count
 static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t base_offset, const fe_t* const* cols, size_t count, size_t n, bool timed) {

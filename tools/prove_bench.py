@@ -163,11 +163,15 @@ if not SYNTH:
             pa.array[:] = a
         adv = [pa.array for pa in pinned]
     t0 = time.time(); NV.create_proof(npk, gb_, glb_, adv, seed=5, instances=instances); t_first = time.time() - t0   # first proof of the process: tables, plans, JIT
-    tm = {}
-    t0 = time.time(); proof = NV.create_proof(npk, gb_, glb_, adv, seed=5, instances=instances, timings=tm); t_prove = time.time() - t0
+    reps = int(os.environ.get("REPS", "3"))
+    runs = []
+    for _ in range(max(1, reps)):                  # the proof is deterministic (seed): the fastest of a few runs is reported, all are listed
+        tm_ = {}
+        t0 = time.time(); proof = NV.create_proof(npk, gb_, glb_, adv, seed=5, instances=instances, timings=tm_); runs.append((time.time() - t0, tm_))
+    t_prove, tm = min(runs, key=lambda r: r[0])
     t0 = time.time(); ok = V.verify(vk, (1, 2), g2, s_g2, proof, instances=instances); t_verify = time.time() - t0
     out = {"what": "create_proof (KZG / SHPLONK, Keccak EVM transcript) of an ezkl circuit by libezkl_prover.so over the C ABI", "circuit": circuit_info,
-           "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "first_prove_seconds_gpu": round(t_first, 4), "keygen_seconds_gpu": round(t_keygen, 3),
+           "proof_bytes": len(proof), "prove_seconds_gpu": round(t_prove, 4), "prove_seconds_gpu_runs": [round(r[0], 4) for r in runs], "first_prove_seconds_gpu": round(t_first, 4), "keygen_seconds_gpu": round(t_keygen, 3),
            "prove_breakdown_seconds": {a: round(b, 4) for a, b in tm.items()}, "verifier_accepts": bool(ok), "verify_seconds_python": round(t_verify, 2),
            "srs_setup_seconds": round(t_srs, 1), "n_gpus": 1}
     if "--cold" in sys.argv:
