@@ -308,7 +308,7 @@ def prove_leg_multi(world, rank, local_rank, args):
         return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
                 "n_gpus": j["n_gpus"], "msm_sharding": j["msm_sharding"],
                 "host": "libezkl_prover.so (C++), MSMs sharded by points (ezkl_prover_cs_set_shard): every rank holds 1/N of the SRS, one all_gather of 64-byte partials per commit batch; quotient sweep sharded by rows, h all_gathered in place",
-                "sharded_sweeps": nv.get("sharded_sweeps"), "gather_on_device_pointers": nv.get("gather_on_device_pointers"),
+                "sharded_sweeps": nv.get("sharded_sweeps"), "gather_on_device_pointers": nv.get("gather_on_device_pointers"), "collectives": nv.get("collectives"),
                 "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "native_proof_identical_to_python_host": nv.get("proof_identical_to_python_prover"),
                 "all_ranks_same_proof": nv.get("all_ranks_same_proof"), "native_proof_verifies": nv.get("library_rng_proof_verifies"),
                 "breakdown_seconds": nv.get("breakdown_seconds_library_rng"),

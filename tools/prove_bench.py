@@ -235,7 +235,23 @@ if world > 1 and "--native" in sys.argv:
             pa.array[:] = a
         adv = [pa.array for pa in pinned]
     nc = NV.NativeCircuit(cs)
-    lo, hi = nc.set_shard(dist, ddev)
+    # one GPU per rank over RCCL: shard through the library's OWN communicator (csrc/comm.hip: partial points folded and h all_gathered
+    # on device pointers, no Python in the data path); the ranks agree on whether it came up, otherwise the torch.distributed callbacks
+    comm_used = False
+    if "--gloo" not in sys.argv and "--share-device" not in sys.argv and not os.environ.get("EZKL_NO_LIB_COMM"):
+        import torch
+        ok = 1
+        try:
+            B.comm_init_from_torch(dist, ddev)
+        except Exception as e:
+            print("library communicator unavailable on rank %d: %r" % (rank, e), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=ddev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        comm_used = bool(int(flag[0]))
+        if ok and not comm_used:
+            B.comm_destroy()
+    lo, hi = nc.set_shard_comm() if comm_used else nc.set_shard(dist, ddev)
     gb_, glb_ = B.Bases(np.ascontiguousarray(g[lo:hi])), B.Bases(np.ascontiguousarray(gl[lo:hi]))
     npk = NV.NativeProvingKey(nc, gb_, fixed, copies)
     nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), instances=instances)   # warm-up; same randomness as the Python host above
@@ -247,7 +263,8 @@ if world > 1 and "--native" in sys.argv:
     dist.all_gather(all_h, hs_)
     tt = torch.tensor([t_native], dtype=torch.float64, device=ddev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     native_multi = {"prove_seconds_library_rng": round(float(tt[0]), 4), "proof_identical_to_python_prover": nproof == proof,
-                    "sharded_sweeps": nc.sharded_sweeps(), "gather_on_device_pointers": bool(getattr(nc, "direct_gather", False)),
+                    "sharded_sweeps": nc.sharded_sweeps(), "gather_on_device_pointers": bool(getattr(nc, "direct_gather", False)) or comm_used,
+                    "collectives": "libezkl_hip.so RCCL communicator (comm.hip)" if comm_used else "torch.distributed callbacks",
                     "all_ranks_same_proof": all(bool((h == all_h[0]).all()) for h in all_h), "library_rng_proof": lproof,
                     "breakdown_seconds_library_rng": {a: round(b, 4) for a, b in ltm.items()}}
 if world > 1:
