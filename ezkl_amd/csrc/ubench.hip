@@ -21,6 +21,47 @@ __global__ __launch_bounds__(256) void ub_modmul_kernel(fe_t* io, int iters) {
     }
     st_fe(io + i, Fr::add(Fr::add(a, b), Fr::add(c, d)));
 }
+// One step of a batched-affine bucket accumulation as a wave would have to do it: every lane holds the denominator of ITS addition;
+// the 64 values are inverted together by Montgomery's trick ACROSS the wave -- inclusive prefix products by 6 shuffle levels, ONE Fermat
+// inversion (all lanes run it: divergence-free), then each lane's inverse = prefix[l-1] * inv_total * suffix-corrected by a second
+// scan.  Returns nothing useful; the time per (lane, step) against the time of one product is the inversion overhead per addition.
+__global__ __launch_bounds__(256) void ub_waveinv_kernel(fe_t* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    fe_t x = Fr::reduce_once(ld_fe(io + i));
+    if (Fr::is_zero(x)) x = Fr::one();
+    for (int k = 0; k < iters; k++) {
+        fe_t pre = x;                                   // inclusive prefix product over the wave
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            fe_t up;
+#pragma unroll
+            for (int q = 0; q < 8; q++) up.v[q] = __shfl_up(pre.v[q], d);
+            if (lane >= d) pre = Fr::mul(pre, up);
+        }
+        fe_t tot;
+#pragma unroll
+        for (int q = 0; q < 8; q++) tot.v[q] = __shfl(pre.v[q], 63);
+        fe_t inv = Fr::inv(tot);                        // 1 / (x_0 ... x_63), computed by every lane
+        fe_t suf = x;                                   // inclusive suffix product
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            fe_t dn;
+#pragma unroll
+            for (int q = 0; q < 8; q++) dn.v[q] = __shfl_down(suf.v[q], d);
+            if (lane + d < 64) suf = Fr::mul(suf, dn);
+        }
+        fe_t before, after;                             // x_l^-1 = inv * prefix[l-1] * suffix[l+1]
+#pragma unroll
+        for (int q = 0; q < 8; q++) { before.v[q] = __shfl_up(pre.v[q], 1); after.v[q] = __shfl_down(suf.v[q], 1); }
+        fe_t r = inv;
+        if (lane > 0) r = Fr::mul(r, before);
+        if (lane < 63) r = Fr::mul(r, after);
+        x = Fr::add(r, x);                              // feed the next step
+        if (Fr::is_zero(x)) x = Fr::one();
+    }
+    st_fe(io + i, x);
+}
 __global__ __launch_bounds__(256) void ub_addsub_kernel(fe_t* io, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     fe_t a = ld_fe(io + i), b = Fr::reduce_once(a), c = Fr::add(b, b), d = c;
@@ -202,6 +243,29 @@ int ubench(Ctx* c, const char* which, double* out) {
         EZ_HIP(hipFree(buf));
         const double per_thread = (is_mm || !strcmp(which, "addsub")) ? 4.0 * iters : 8.0 * iters;
         *out = per_thread * (double)nthreads / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strcmp(which, "waveinv")) {            // wave-batched inversions per second (one per lane and step), full occupancy
+        const int threads = 256, blocks = c->num_cus * 16, iters = 16;
+        const size_t nthreads = (size_t)threads * blocks;
+        void* buf = nullptr;
+        EZ_HIP(hipMalloc(&buf, nthreads * sizeof(fe_t)));
+        std::vector<fe_t> init(nthreads);
+        for (size_t t = 0; t < nthreads; t++) { init[t] = Fr::one(); init[t].v[0] = (uint32_t)(t * 2654435761u) | 1u; init[t].v[7] = 0; }
+        EZ_HIP(hipMemcpy(buf, init.data(), nthreads * sizeof(fe_t), hipMemcpyHostToDevice));
+        hipEvent_t e0, e1;
+        EZ_HIP(hipEventCreate(&e0)); EZ_HIP(hipEventCreate(&e1));
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(ub_waveinv_kernel, dim3(blocks), dim3(threads), 0, st, (fe_t*)buf, iters);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipEventSynchronize(e1));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        (void)hipFree(buf);
+        *out = (double)nthreads * iters / (ms * 1e-3);
         return EZKL_OK;
     }
     if (!strncmp(which, "modmul29", 8)) {       // "modmul29": products per second; "modmul29_check": mismatches vs the portable form
