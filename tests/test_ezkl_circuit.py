@@ -246,3 +246,33 @@ def test_gpu_setup_reproduces_reference_pk_file(hip, fx, golden_srs):
     assert len(mine) == len(ref) == 1489595
     lo, hi = 7, 7 + 64 * (38 + 32)
     assert mine[:lo] == ref[:lo] and mine[hi:] == ref[hi:]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_layout_engine_random_mlps_satisfy_their_circuits(seed):
+    """MlpCircuit over random shapes -- layers, widths, inner columns, logrows chosen so that the VarTensors overflow into 1..4 blocks
+    (dot products and decompositions straddling column boundaries, with the duplicated accumulator rows of
+    assign_with_duplication) -- every layout satisfies every gate, lookup and copy constraint of its own constraint system"""
+    from ezkl_amd import ezkl_layout as EL
+    rng = np.random.default_rng(100 + seed)
+    layers = int(rng.integers(1, 4))
+    width = int(rng.integers(3, 11))
+    inner = int(rng.choice([1, 2, 3]))
+    Ws = [rng.integers(-4, 5, (width, width)).tolist() for _ in range(layers)]
+    bs = [rng.integers(-9, 10, width).tolist() for _ in range(layers)]
+    x = rng.integers(-20, 21, width).tolist()
+    probe = EL.MlpCircuit(12, inner, Ws, bs, 128, 2)
+    cells = probe.settings.total_assignments
+    k = 6
+    while ((1 << k) - 6) * inner * 4 < cells:                 # the smallest logrows that needs at most ~4 blocks
+        k += 1
+    c = EL.MlpCircuit(k, inner, Ws, bs, 128, 2)
+    cs, fixed, copies, reg = c.keygen_inputs(x)
+    adv, inst = c.witness(x)
+    assert MP.check(cs, adv, fixed, inst, copies) == []
+    assert c.gc.advices[0].num_blocks() >= 1 and reg.linear <= c.settings.total_assignments
+    # the model the circuit computes
+    v = np.array(x)
+    for W, b in zip(Ws, bs):
+        v = np.maximum(np.array(W) @ v + np.array(b), 0)
+    assert inst == [[int(t) % R for t in v]]
