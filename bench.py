@@ -251,7 +251,8 @@ def prove_leg():
         warm prove, the COLD one-shot prove (fresh process, SRS + pk files -> HBM -> proof.json), and the same create_proof on the host
         cores (C oracle kernels, OpenMP) with identical proof bytes;
       * `mlp`: an MLP over the ezkl gate set (range-check lookups, permutation over ~20 columns) at k = 17 (BASELINE configs[2]'s size),
-        GPU and CPU."""
+        GPU and CPU;
+      * `conv2d_mnist`: BASELINE configs[2] itself, examples/conv2d_mnist/main.rs's Config and layout at k = 17, GPU and CPU."""
     import subprocess
     tool = os.path.join(ROOT, "tools", "prove_bench.py")
     def child(env_extra, flags, timeout):
@@ -281,6 +282,13 @@ def prove_leg():
                       "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "breakdown_seconds": j["prove_breakdown_seconds"]}
     except Exception as e:
         out["mlp"] = {"error": repr(e)[:300]}
+    try:                                               # BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17
+        j = child({"CIRCUIT": "conv", "K": "17"}, ["--cpu", "--pinned"], 900)
+        out["conv2d_mnist"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
+                               "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
+                               "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "breakdown_seconds": j["prove_breakdown_seconds"]}
+    except Exception as e:
+        out["conv2d_mnist"] = {"error": repr(e)[:300]}
     return out
 
 

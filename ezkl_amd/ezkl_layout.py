@@ -457,6 +457,27 @@ class BaseRegion(Region):
         mask = self.equals_zero(diff)
         return self.pairwise(vals, mask, EC.MULT)
 
+    def nonlinearity(self, vals, name):
+        """layouts.rs:5143-5222: x into the lookup input VarTensor, f(x) into the output VarTensor, the table-column index of x into
+        the index VarTensor, the (op, block, inner column) selector on every row"""
+        table = self.base.static_tables[name]
+        w = self.assign(self.inputs[0], vals)
+        signed = lambda v: v if v < R // 2 else v - R
+        for v in w:
+            assert table.range[0] <= signed(v.v) <= table.range[1], "lookup input %d outside the table range" % signed(v.v)
+        out = self.assign(self.output, [Val(table.f(signed(v.v)) % R) for v in w])
+        self.assign(self.inputs[1], [Val((signed(v.v) - table.range[0]) // table.col_size) for v in w])
+        for t in range(len(w)):
+            x, y, z = self.inputs[0].cartesian_coord(self.linear + t)
+            self.enable(self.base.static_selectors[(name, x, y)], z)
+        self.increment(len(w))
+        return out
+
+    def constrain_instance(self, vals, inst_col, inst_offset=0):
+        """Layouter::constrain_instance: the cells are tied to the instance column directly (what a hand-written halo2 circuit does)"""
+        for t, v in enumerate(vals):
+            self.copy(v.cell, ("inst", inst_col.index, inst_offset + t))
+
     def output_equals_instance(self, vals, inst_col, inst_offset, base, legs, decomp=True):
         """layouts.rs:6740-6779 `output`: range check (decompose) the outputs and the instance cells, then equality"""
         if decomp:
@@ -470,7 +491,35 @@ class BaseRegion(Region):
         return self.enforce_equality(vals, inst)
 
 
-class MlpCircuit:
+class LayoutCircuit:
+    """what every circuit built on BaseRegion shares: the keygen pass (selector activations, fixed columns, copy constraints)
+    and the witness pass; subclasses give `synthesize(x, witness) -> region` and set self.outputs"""
+
+    def keygen_inputs(self, x):
+        """-> (plonk.ConstraintSystem, fixed columns (lists of ints), copies over cs.perm positions, region)"""
+        reg = self.synthesize(x, witness=False)
+        n = 1 << self.k
+        cs0 = self.gc.cs
+        sel_cols = cs0.compress_selectors(reg.selector_rows(dense=False))
+        if n <= 1 << 12:
+            sel_cols = [c.tolist() for c in sel_cols]
+        cs = cs0.to_plonk(self.k)
+        tabs = self.gc.table_columns()
+        n_pre = cs.n_fixed - len(sel_cols)
+        fixed = [tabs.get(c) or reg.fixed.get(c) or [0] * n for c in range(n_pre)] + list(sel_cols)
+        pos = {kc: i for i, kc in enumerate(cs.perm)}
+        copies = [((pos[(a[0], a[1])], a[2]), (pos[(b[0], b[1])], b[2])) for a, b in reg.copies]
+        return cs, fixed, copies, reg
+
+    def witness(self, x):
+        """advice columns (lists of ints) and the instance column"""
+        reg = self.synthesize(x, witness=True)
+        n = 1 << self.k
+        adv = [reg.advice.get(c.index) or [0] * n for c in self.gc.cs.advice]
+        return adv, [self.outputs]
+
+
+class MlpCircuit(LayoutCircuit):
     """`layers` x (Gemm + bias + ReLU) on one input vector, the op sequence of the reference's fixture model
     (tests/assets/network.onnx: Gemm 3 -> 4 + ReLU) and of examples/onnx/large_mlp/gen.py:6-43 (9 x Linear(100, 100) + ReLU; with
     batch 1 the einsum "mk,nk->mn" has one non-common index and is laid out with base ops, einsum/analysis.rs:165-184), private
@@ -516,25 +565,85 @@ class MlpCircuit:
         self.outputs = [v.v for v in vals]
         return reg
 
-    def keygen_inputs(self, x):
-        """-> (plonk.ConstraintSystem, fixed columns (lists of ints), copies over cs.perm positions, region)"""
-        reg = self.synthesize(x, witness=False)
-        n = 1 << self.k
-        cs0 = self.gc.cs
-        sel_cols = cs0.compress_selectors(reg.selector_rows(dense=False))
-        if n <= 1 << 12:
-            sel_cols = [c.tolist() for c in sel_cols]
-        cs = cs0.to_plonk(self.k)
-        tabs = self.gc.table_columns()
-        n_pre = cs.n_fixed - len(sel_cols)
-        fixed = [tabs.get(c) or reg.fixed.get(c) or [0] * n for c in range(n_pre)] + list(sel_cols)
-        pos = {kc: i for i, kc in enumerate(cs.perm)}
-        copies = [((pos[(a[0], a[1])], a[2]), (pos[(b[0], b[1])], b[2])) for a, b in reg.copies]
-        return cs, fixed, copies, reg
 
-    def witness(self, x):
-        """advice columns (lists of ints) and the instance column"""
-        reg = self.synthesize(x, witness=True)
-        n = 1 << self.k
-        adv = [reg.advice.get(c.index) or [0] * n for c in self.gc.cs.advice]
-        return adv, [self.outputs]
+class ConvMnistConfig(EC.GraphConfig):
+    """the Config of /root/reference/examples/conv2d_mnist/main.rs:148-186, in its order: three one-column advice VarTensors (input,
+    params, output), the constant columns, BaseConfig over them, range checks (-1, 1) and (0, base - 1) (RegionCtx's decomposition:
+    base 1024, 2 legs), the Div{denom} static lookup over (lookup_min, lookup_max), then the public-output instance column"""
+
+    def __init__(self, logrows, length, lookup_range, denom, decomp_base=1024, num_inner_cols=1, capacity=None):
+        cs = self.cs = EC.ConstraintSystem()
+        length = capacity or length                    # the example sizes its VarTensors by LEN (one column each); tests may ask for more blocks
+        self.settings = EC.GraphSettings(logrows, num_inner_cols, length, total_const_size=length,
+                                         required_range_checks=[(-1, 1), (0, decomp_base - 1)], model_instance_shapes=[[1, 10]])
+        self.advices = [EC.VarTensor.new_advice(cs, logrows, num_inner_cols, length) for _ in range(3)]
+        self.const_cols = EC.VarTensor.constant_cols(cs, logrows, length)
+        inp, params, out = self.advices
+        base = self.base = EC.BaseConfig(cs, [inp, params], out)
+        base.configure_range_check(inp, params, (-1, 1), logrows)
+        base.configure_range_check(inp, params, (0, decomp_base - 1), logrows)
+        half = denom // 2
+        self.div = lambda x: (abs(x) + half) // denom * (1 if x >= 0 else -1)           # f64::round of x / denom (tensor/ops.rs:2326-2331)
+        base.configure_lookup(inp, out, params, tuple(lookup_range), logrows, "div_%d" % denom, self.div)
+        self.instance = cs.instance_column()
+        cs.enable_equality(self.instance)
+        cs.chunk_lookups()
+
+
+class ConvMnistCircuit(LayoutCircuit):
+    """examples/conv2d_mnist (BASELINE configs[2]): Conv 1 -> 4 channels, 5 x 5, stride 2 over a 28 x 28 image (one dot product of
+    25 + a bias addition per output, layouts.rs:4499-4661), LeakyReLU slope 0 (sign by decomposition), Div{32} through a static
+    lookup table over (-32768, 32768) -- 65 537 rows: this is what makes the circuit k = 17 --, a 576 -> 10 linear layer
+    ("ij,j->ik" = 10 dot products of 576, layouts.rs:887-1098) and its bias; the 10 outputs are tied to the instance column.
+    The example reads MNIST and trained parameters from files that are not in the repository; shapes and value ranges are what
+    matter to the prover, the data is synthetic."""
+
+    def __init__(self, logrows=17, image=28, kernel=5, out_channels=4, stride=2, classes=10, lookup_range=(-32768, 32768), denom=32,
+                 decomp_base=1024, decomp_legs=2, seed=0, num_inner_cols=1, capacity=None):
+        self.k, self.w = logrows, num_inner_cols
+        self.image, self.kernel, self.oc, self.stride, self.classes = image, kernel, out_channels, stride, classes
+        self.slides = (image - kernel) // stride + 1
+        self.length = out_channels * self.slides * self.slides
+        self.base, self.legs, self.denom = decomp_base, decomp_legs, denom
+        rng = np.random.default_rng(seed)
+        self.kernels = rng.integers(-20, 21, (out_channels, kernel, kernel))               # round(32 * trained float), main.rs:346-358
+        self.conv_bias = np.zeros(out_channels, np.int64)                                 # main.rs:366-367
+        self.fc_w = rng.integers(-12, 13, (classes, self.length))
+        self.fc_b = rng.integers(-40, 41, classes)
+        self.gc = ConvMnistConfig(logrows, self.length, lookup_range, denom, decomp_base, num_inner_cols, capacity)
+
+    def model(self, img):
+        """the integer forward pass the circuit proves"""
+        img = np.asarray(img, np.int64).reshape(self.image, self.image)
+        s, K = self.slides, self.kernel
+        conv = np.array([[[int((img[i * self.stride:i * self.stride + K, j * self.stride:j * self.stride + K] * self.kernels[o]).sum()) + int(self.conv_bias[o])
+                           for j in range(s)] for i in range(s)] for o in range(self.oc)]).reshape(-1)
+        act = np.array([self.gc.div(max(int(v), 0)) for v in conv])
+        return [int(v) for v in self.fc_w @ act + self.fc_b]
+
+    def synthesize(self, img, witness=True):
+        reg = BaseRegion(self.gc, witness)
+        img = np.asarray(img, np.int64).reshape(self.image, self.image)
+        s, K, st = self.slides, self.kernel, self.stride
+        # conv: kernel and image are assigned once, side by side; every patch / filter slice below is a copy of those cells
+        ker = reg.assign(reg.inputs[0], [Val(int(v) % R) for v in self.kernels.reshape(-1)])
+        im = reg.assign(reg.inputs[1], [Val(int(v) % R) for v in img.reshape(-1)])
+        reg.increment(max(len(ker), len(im)))
+        ker = [ker[o * K * K:(o + 1) * K * K] for o in range(self.oc)]
+        vals = []
+        for o in range(self.oc):
+            for i in range(s):
+                for j in range(s):
+                    patch = [im[(i * st + a) * self.image + j * st + b] for a in range(K) for b in range(K)]
+                    res = reg.dot(patch, ker[o])
+                    res = reg.pairwise([res], [Val(int(self.conv_bias[o]) % R)], EC.ADD)
+                    reg.flush()
+                    vals.append(res[0])
+        vals = reg.relu(vals, self.base, self.legs)
+        vals = reg.nonlinearity(vals, "div_%d" % self.denom)
+        outs = [reg.dot([Val(int(v) % R) for v in row], vals) for row in self.fc_w]
+        outs = reg.pairwise(outs, [Val(int(v) % R) for v in self.fc_b], EC.ADD)
+        reg.constrain_instance(outs, self.gc.instance)
+        reg.finish(self.gc.const_cols)
+        self.outputs = [v.v for v in outs]
+        return reg

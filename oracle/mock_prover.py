@@ -35,7 +35,7 @@ def check(cs, advice, fixed, instance=(), copies=(), challenges=(), max_failures
         def q(kind, c, rot):
             if kind == "chal":
                 return challenges[c]
-            return cols[kind][c][(row + rot) % n]
+            return int(cols[kind][c][(row + rot) % n])
         return q
     for row in range(u):
         memo, q = {}, at(row)

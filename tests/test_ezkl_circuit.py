@@ -276,3 +276,92 @@ def test_layout_engine_random_mlps_satisfy_their_circuits(seed):
     for W, b in zip(Ws, bs):
         v = np.maximum(np.array(W) @ v + np.array(b), 0)
     assert inst == [[int(t) % R for t in v]]
+
+
+def _conv_small():
+    from ezkl_amd import ezkl_layout as EL
+    c = EL.ConvMnistCircuit(logrows=10, image=8, kernel=3, out_channels=2, stride=2, classes=3, lookup_range=(-700, 700), denom=4,
+                            decomp_base=32, decomp_legs=2)
+    rng = np.random.default_rng(1)
+    c.kernels = rng.integers(-3, 4, c.kernels.shape)
+    return c, rng.integers(0, 4, (8, 8))
+
+
+def test_conv2d_mnist_layout_small():
+    """the conv2d_mnist Config and layout (examples/conv2d_mnist/main.rs) on a small shape whose Div table spans two table columns
+    (the index column and the column-selector polynomial are live): satisfied; a wrong public output or a tampered lookup output is not"""
+    c, img = _conv_small()
+    cs, fixed, copies, reg = c.keygen_inputs(img)
+    adv, inst = c.witness(img)
+    assert (cs.n_advice, cs.n_instance) == (3, 1) and len(c.gc.base.static_tables["div_4"].table_inputs) == 2
+    assert MP.check(cs, adv, fixed, inst, copies) == []
+    assert [v if v < R // 2 else v - R for v in inst[0]] == c.model(img)
+    bad = [list(inst[0])]
+    bad[0][0] = (bad[0][0] + 1) % R
+    assert MP.check(cs, adv, fixed, bad, copies)
+    # a Div output that is not f(x): find a row with the lookup selector on and bump the output cell
+    sel = next(s for key, s in c.gc.base.static_selectors.items())
+    row = int(np.flatnonzero(reg.activations[sel.index])[0])
+    adv2 = [list(a) for a in adv]
+    adv2[2][row] = (adv2[2][row] + 1) % R
+    assert any("lookup" in f for f in MP.check(cs, adv2, fixed, inst, copies, max_failures=64))
+
+
+def test_conv2d_mnist_k17():
+    """BASELINE configs[2] at the reference's shapes (28 x 28, 4 x 5 x 5 stride 2, 576 -> 10, Div{32} over (-32768, 32768)): fits k = 17,
+    every constraint satisfied, the instance column is the integer model's output"""
+    from ezkl_amd import ezkl_layout as EL
+    c = EL.ConvMnistCircuit()
+    img = np.random.default_rng(3).integers(0, 16, (28, 28))
+    cs, fixed, copies, reg = c.keygen_inputs(img)
+    adv, inst = c.witness(img)
+    assert (cs.k, cs.n_advice, c.length) == (17, 3, 576) and reg.linear < (1 << 17)
+    assert MP.check(cs, adv, fixed, inst, copies) == []
+    assert [v if v < R // 2 else v - R for v in inst[0]] == c.model(img)
+
+
+def test_conv2d_mnist_tiny_proof_oracle_backend(golden_srs):
+    """a k = 6 instance of the same Config / layout (VarTensors overflowing into several blocks, Div table over four table columns):
+    MockProver, then keygen + create_proof on the CPU-oracle backend, accepted by the pairing verifier; a wrong public output is rejected"""
+    from ezkl_amd import ezkl_layout as EL
+    from test_ezkl_gateset import _prove_and_verify
+    from oracle import verifier as V
+    from test_plonk import setup
+    c = EL.ConvMnistCircuit(logrows=6, image=6, kernel=3, out_channels=1, stride=3, classes=2, lookup_range=(-100, 100), denom=4,
+                            decomp_base=16, decomp_legs=2, capacity=220)
+    rng = np.random.default_rng(2)
+    c.kernels = rng.integers(-3, 4, c.kernels.shape)
+    c.fc_w, c.fc_b = rng.integers(-5, 6, c.fc_w.shape), rng.integers(-9, 10, c.fc_b.shape)
+    img = rng.integers(0, 4, (6, 6))
+    cs, fixed, copies, reg = c.keygen_inputs(img)
+    adv, inst = c.witness(img)
+    assert c.gc.advices[0].num_blocks() >= 3 and len(c.gc.base.static_tables["div_4"].table_inputs) == 4
+    assert MP.check(cs, adv, fixed, inst, copies) == []
+    ok, vk, proof = _prove_and_verify(cs, fixed, adv, copies, golden_srs, inst)
+    assert ok
+    g1, g2, s_g2 = setup(golden_srs)
+    assert not V.verify(vk, g1, g2, s_g2, proof, instances=[[(inst[0][0] + 1) % R, inst[0][1]]])
+
+
+@pytest.mark.gpu
+def test_gpu_conv2d_mnist_small_native_prove_and_verify(hip):
+    """the conv2d_mnist Config / layout at k = 10 through the product: keygen on the GPU, ezkl_prover_create_proof with CheckMode SAFE
+    (the library verifies its own proof with the C++ pairing check), ezkl_prover_verify_proof accepts it and rejects a wrong instance;
+    byte-identical to the Python host on the CPU-oracle backend with the same randomness"""
+    from ezkl_amd import backend as B, native as NV, ezkl_layout as EL
+    from oracle.cpu_backend import OracleBackend
+    c, img = _conv_small()
+    cs, fixed, copies, reg = c.keygen_inputs(img)
+    adv, inst = c.witness(img)
+    s = 0x1d5c0ffee1234567
+    bg, bgl = B.gen_srs(cs.k, s)
+    g2, s_g2 = NV.g2_mul_generator(1), NV.g2_mul_generator(s)
+    pk = NV.NativeProvingKey(NV.NativeCircuit(cs), bg, EL.cols_to_mont(fixed, B), copies)
+    mont = EL.cols_to_mont(adv, B)
+    proof = NV.create_proof(pk, bg, bgl, mont, seed=9, instances=inst, check_mode="SAFE", g2=g2, s_g2=s_g2)
+    assert NV.verify_proof(pk, g2, s_g2, proof, inst)
+    assert not NV.verify_proof(pk, g2, s_g2, proof, [[(inst[0][0] + 1) % R] + list(inst[0][1:])])
+    cpu = OracleBackend(bg.download(), bgl.download(), cs.k)
+    pk_c, _ = P.keygen(cs, cpu, [EL.ints_to_mont(f) for f in fixed], copies)
+    assert P.create_proof(pk_c, cpu, [EL.ints_to_mont(a) for a in adv], P.Rng(5), instances=inst) == \
+        NV.create_proof(pk, bg, bgl, mont, rng=P.Rng(5), instances=inst)

@@ -6,6 +6,9 @@
   mlp    : `layers` x (Gemm N x N + bias + ReLU) on one input vector, the op family of the reference's fixture model and of
            examples/onnx/large_mlp (gen.py:6-43), private input / parameters, public output, decomposition range checks
            (base 16384, 2 legs = ezkl's defaults, src/lib.rs:257-260): BaseConfig gates + range-check lookups + permutation
+  conv   : BASELINE configs[2], /root/reference/examples/conv2d_mnist/main.rs: its Config (3 one-column advice VarTensors, range checks,
+           the Div{32} static lookup over (-32768, 32768) that forces k = 17) and its layout (conv as dot products, ReLU by
+           decomposition, table lookup, linear layer, outputs on the instance column); synthetic image / parameters
 """
 import os
 import sys
@@ -57,6 +60,14 @@ def build(kind, k, gpu=None, seed=1, **kw):
         adv, inst = c.witness(x)
         info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),
                     cells_used=reg.linear, blocks=c.gc.advices[0].num_blocks(), range_checks=[list(r) for r in c.settings.required_range_checks])
+        return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
+    if kind == "conv":
+        c = EL.ConvMnistCircuit(logrows=k, seed=seed)
+        img = rng.integers(0, 16, (28, 28))                     # MNIST pixels / 16 (examples/conv2d_mnist/main.rs:326-329)
+        cs, fixed, copies, reg = c.keygen_inputs(img)
+        adv, inst = c.witness(img)
+        info = dict(circuit="examples/conv2d_mnist: Conv 1->4 5x5 stride 2 on 28x28 + ReLU + Div{32} lookup (65 537-row table) + Linear 576->10, "
+                            "3 advice columns, k=%d (synthetic image and parameters of the example's shapes)" % k, cells_used=reg.linear)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
     raise ValueError(kind)
 

@@ -3,6 +3,7 @@
 
     CIRCUIT=einsum K=20 python tools/prove_bench.py [--cpu] [--native] [--pinned]     the reference's accum_einsum_matmul bench circuit
     CIRCUIT=mlp K=17 [LAYERS=9 WIDTH=..] python tools/prove_bench.py ...               MLP over the ezkl gate set (tools/bench_circuits.py)
+    CIRCUIT=conv K=17 python tools/prove_bench.py ...                                 examples/conv2d_mnist (BASELINE configs[2])
     K=16 BLOCKS=2 python tools/prove_bench.py ...     (CIRCUIT unset) the round-1 hand-written matmul-accumulation + lookup circuit,
                                                       kept for the two-rank sharding tests
 (--cpu also times the CPU oracle backend; --native also times the C++ host prover libezkl_prover.so on the same witness /
