@@ -1229,17 +1229,20 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
     {
         std::vector<Col> terms;
         std::vector<Fe> cf;
+        Fe norm = Fe::one();                               // halo2 normalises by the first set's coefficient: 1 / Z_{T \ S_0}(u)
         for (size_t gi = 0; gi < groups.size(); gi++) {
             Fe zdiff = Fe::one();
             for (auto& z : all_pts)
                 if (!std::binary_search(groups[gi].pts.begin(), groups[gi].pts.end(), z, u256_less)) zdiff = zdiff * (u - pt_fe[z]);
+            if (gi == 0) norm = zdiff.inv();
+            const Fe c = pw * zdiff * norm;
             terms.push_back(combos[gi].q);
-            cf.push_back(pw * zdiff);
-            const_term = const_term + pw * zdiff * eval_small(combos[gi].r, u);
+            cf.push_back(c);
+            const_term = const_term + c * eval_small(combos[gi].r, u);
             pw = pw * v;
         }
         terms.push_back(h);
-        cf.push_back(-zt_u);
+        cf.push_back(-(zt_u * norm));                     // Z_T(u) / Z_{T \ S_0}(u) = Z_{S_0}(u)
         be.lincomb(L, terms, cf, n, false);
     }
     be.sub_low(L, {const_term});
@@ -1661,12 +1664,11 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     sw.lap(8);
     // 10. multiopen (SHPLONK)
     enum : uint32_t { K_ADV = 1, K_FIX, K_H, K_RND, K_SIGMA, K_Z, K_M, K_PHI };
-    std::vector<OpenQuery> qs;     // the verifier rebuilds the same list with commitments for polynomials
+    // halo2's query order -- advice, permutation products, lookups, fixed, sigma, h, random -- fixes the order of SHPLONK's rotation
+    // sets (first appearance) and of the commitments inside each; pinned on the reference's generated EVM verifier
+    // (tests/test_evm_verifier.py).  The verifier rebuilds the same list with commitments for polynomials.
+    std::vector<OpenQuery> qs;
     for (auto& q : cs.advice_queries) qs.push_back({{K_ADV, q.col}, adv_polys[q.col], rot_point(q.rot), adv_evals[{q.col, q.rot}]});
-    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, pk.fixed_polys[q.col], rot_point(q.rot), fix_evals[{q.col, q.rot}]});
-    qs.push_back({{K_H}, hcomb, x, h_eval});
-    qs.push_back({{K_RND}, rnd, x, random_eval});
-    for (uint32_t i = 0; i < pk.sigma_polys.size(); i++) qs.push_back({{K_SIGMA, i}, pk.sigma_polys[i], x, sigma_evals[i]});
     for (uint32_t j = 0; j < z_polys.size(); j++) {
         qs.push_back({{K_Z, j}, z_polys[j], x, z_evals[j].e0});
         qs.push_back({{K_Z, j}, z_polys[j], rot_point(1), z_evals[j].e1});
@@ -1677,6 +1679,10 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         qs.push_back({{K_PHI, i}, phi_polys[i], rot_point(1), lk_evals[i][1]});
         qs.push_back({{K_M, i}, m_polys[i], x, lk_evals[i][2]});
     }
+    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, pk.fixed_polys[q.col], rot_point(q.rot), fix_evals[{q.col, q.rot}]});
+    for (uint32_t i = 0; i < pk.sigma_polys.size(); i++) qs.push_back({{K_SIGMA, i}, pk.sigma_polys[i], x, sigma_evals[i]});
+    qs.push_back({{K_H}, hcomb, x, h_eval});
+    qs.push_back({{K_RND}, rnd, x, random_eval});
     shplonk_prove(be, T, qs, n);
     sw.lap(9);
     sw.total();
@@ -1884,10 +1890,6 @@ static bool verify_proof(ConstraintSystem& cs, const std::vector<G1>& fixed_comm
     enum : uint32_t { K_ADV = 1, K_FIX, K_H, K_RND, K_SIGMA, K_Z, K_M, K_PHI };
     std::vector<VQ> qs;
     for (auto& q : cs.advice_queries) qs.push_back({{K_ADV, q.col}, adv_c[q.col], rot_point(q.rot), ev[0][{q.col, q.rot}]});
-    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, bn::p1_from(fixed_commitments[q.col]), rot_point(q.rot), ev[1][{q.col, q.rot}]});
-    qs.push_back({{K_H}, hc, x, h_eval});
-    qs.push_back({{K_RND}, rnd_c, x, random_eval});
-    for (uint32_t i = 0; i < sigma_ev.size(); i++) qs.push_back({{K_SIGMA, i}, bn::p1_from(sigma_commitments[i]), x, sigma_ev[i]});
     for (uint32_t j = 0; j < z_ev.size(); j++) {
         qs.push_back({{K_Z, j}, z_c[j], x, z_ev[j].e0});
         qs.push_back({{K_Z, j}, z_c[j], rot_point(1), z_ev[j].e1});
@@ -1898,6 +1900,10 @@ static bool verify_proof(ConstraintSystem& cs, const std::vector<G1>& fixed_comm
         qs.push_back({{K_PHI, i}, phi_c[i], rot_point(1), lk_ev[i].phi_next});
         qs.push_back({{K_M, i}, m_c[i], x, lk_ev[i].m});
     }
+    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, bn::p1_from(fixed_commitments[q.col]), rot_point(q.rot), ev[1][{q.col, q.rot}]});
+    for (uint32_t i = 0; i < sigma_ev.size(); i++) qs.push_back({{K_SIGMA, i}, bn::p1_from(sigma_commitments[i]), x, sigma_ev[i]});
+    qs.push_back({{K_H}, hc, x, h_eval});
+    qs.push_back({{K_RND}, rnd_c, x, random_eval});
     struct VPoly { P1 com; std::map<U256, std::pair<Fe, Fe>> ev; };
     std::vector<VPoly> polys;
     std::map<std::vector<uint32_t>, size_t> by_key;
@@ -1943,7 +1949,8 @@ static bool verify_proof(ConstraintSystem& cs, const std::vector<G1>& fixed_comm
     P1 gen;
     gen.inf = false; gen.x = bn::Fq::one(); gen.y = bn::Fq::from_u64(2);
     P1 L{};
-    Fe pw = Fe::one();
+    Fe pw = Fe::one(), norm = Fe::one();
+    bool first = true;
     for (auto& gr : groups) {
         P1 qc{};
         std::vector<Fe> evs(gr.pts.size(), Fe::zero());
@@ -1957,11 +1964,12 @@ static bool verify_proof(ConstraintSystem& cs, const std::vector<G1>& fixed_comm
         Fe zdiff = Fe::one();
         for (auto& p : all_pts)
             if (!std::binary_search(gr.pts.begin(), gr.pts.end(), p, u256_less)) zdiff = zdiff * (uu - pt_fe[p]);
+        if (first) { norm = zdiff.inv(); first = false; }    // halo2: coefficients normalised by the first set's
         const P1 term = bn::p1_add(qc, bn::p1_neg(bn::p1_mul(gen, eval_small(r, uu))));
-        L = bn::p1_add(L, bn::p1_mul(term, pw * zdiff));
+        L = bn::p1_add(L, bn::p1_mul(term, pw * zdiff * norm));
         pw = pw * v;
     }
-    L = bn::p1_add(L, bn::p1_neg(bn::p1_mul(pi1, zt_u)));
+    L = bn::p1_add(L, bn::p1_neg(bn::p1_mul(pi1, zt_u * norm)));
     const P1 lhs = bn::p1_add(L, bn::p1_mul(pi2, uu));
     return bn::pairing_check({{pi2, s_g2}, {bn::p1_neg(lhs), g2}});
 }

@@ -280,10 +280,12 @@ class ConstraintSystem:
         return self
 
     # ---- selectors -> fixed columns (keygen)
-    def compress_selectors(self, activations):
+    def compress_selectors(self, activations, grouping=None):
         """activations: one boolean row-vector per selector (list / numpy array; None = never enabled).  Returns the fixed-column
         assignments (numpy int64 arrays of small integers, one per NEW fixed column, in allocation order); gates and lookups are
-        rewritten in place."""
+        rewritten in place.  grouping: optional {first selector of a combination: [selectors]} that overrides the greedy choice
+        (must be a valid one: disjoint activations, degree bound) -- used to rebuild the constraint system of a key whose selector
+        activations are not known but whose combinations are (tests/test_evm_verifier.py)."""
         import numpy as np
         assert len(activations) == len(self.selectors)
         nsel = len(self.selectors)
@@ -321,7 +323,15 @@ class ConstraintSystem:
             d = degrees[i] - 1
             combo = [i]
             union = None if act[i] is None else act[i].copy()     # rows where some selector of the combination is on
-            for j in rest[pos + 1:]:
+            if grouping is not None:
+                combo = list(grouping[i])
+                assert combo[0] == i and max(degrees[t] - 1 for t in combo) + len(combo) <= max_degree
+                for t in combo[1:]:
+                    assert t not in added and (union is None or act[t] is None or not (union & act[t]).any()), "invalid selector grouping"
+                    added.add(t)
+                    if act[t] is not None:
+                        union = act[t].copy() if union is None else (union | act[t])
+            for j in (rest[pos + 1:] if grouping is None else ()):
                 if d + len(combo) == max_degree:
                     break
                 if j in added:

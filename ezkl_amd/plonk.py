@@ -796,18 +796,22 @@ def create_proof(pk, backend, advice_values, rng, timings=None, instances=(), st
     h_eval = backend.eval_poly(hcomb, n, x)
     def rep(h, i):    # a polynomial resident on every rank counts on ONE rank in the column-sharded SHPLONK partial sums
         return h if owner_of is None or i % backend.world == backend.rank else None
-    qs = []   # (key, poly handle, point, eval) -- the verifier rebuilds the same list with commitments for handles
+    # (key, poly handle, point, eval) in halo2's query order -- advice, permutation products, lookups, fixed, sigma, h, random
+    # (plonk/prover.rs step "queries"; plonk/verifier.rs builds the same chain) -- which fixes the order of SHPLONK's rotation sets
+    # (first appearance) and of the commitments inside each set.  Pinned on the reference's generated EVM verifier
+    # (tests/test_evm_verifier.py): set {x} = advice, m, fixed, sigma, h, random.
+    qs = []
     for c, r in cs.advice_queries: qs.append((("adv", c), adv_polys[c], rot_point(r), evals[("adv", c, r)]))
-    for c, r in cs.fixed_queries: qs.append((("fix", c), rep(pk.fixed_polys[c], c), rot_point(r), evals[("fix", c, r)]))
-    qs.append((("h",), rep(hcomb, 0), x, h_eval))
-    qs.append((("rnd",), rep(rnd, 1), x, random_eval))
-    for i, (h, e) in enumerate(zip(pk.sigma_polys, sigma_evals)): qs.append((("sigma", i), rep(h, i), x, e))
     for j, zp in enumerate(z_polys):
         qs.append((("z", j), zp, x, z_evals[j][0])); qs.append((("z", j), zp, rot_point(1), z_evals[j][1]))
         if z_evals[j][2] is not None: qs.append((("z", j), zp, rot_point(u), z_evals[j][2]))
     for i, (mp, pp) in enumerate(zip(m_polys, phi_polys)):
         qs.append((("phi", i), pp, x, lk_evals[i][0])); qs.append((("phi", i), pp, rot_point(1), lk_evals[i][1]))
         qs.append((("m", i), mp, x, lk_evals[i][2]))
+    for c, r in cs.fixed_queries: qs.append((("fix", c), rep(pk.fixed_polys[c], c), rot_point(r), evals[("fix", c, r)]))
+    for i, (h, e) in enumerate(zip(pk.sigma_polys, sigma_evals)): qs.append((("sigma", i), rep(h, i), x, e))
+    qs.append((("h",), rep(hcomb, 0), x, h_eval))
+    qs.append((("rnd",), rep(rnd, 1), x, random_eval))
     shplonk_prove(backend, T, qs, n)
     lap("shplonk")
     return bytes(T.proof)
@@ -992,15 +996,19 @@ def shplonk_prove(backend, T, qs, n):
     L = backend.zeros(n)
     pw = 1
     const_term = 0
+    norm = None                                        # halo2 normalises by the first set's coefficient: 1 / Z_{T \ S_0}(u)
     for pts, q, r in combos:
         zdiff = 1
         for z in all_pts:
             if z not in pts:
                 zdiff = zdiff * (u - z) % R
-        backend.axpy(L, pw * zdiff % R, q, n)
-        const_term = (const_term + pw * zdiff % R * eval_small(r, u)) % R
+        if norm is None:
+            norm = pow(zdiff, -1, R)
+        cf = pw * zdiff % R * norm % R
+        backend.axpy(L, cf, q, n)
+        const_term = (const_term + cf * eval_small(r, u)) % R
         pw = pw * v % R
     backend.sub_low(L, [const_term])
-    backend.axpy(L, (-zt_u) % R, h, n)
+    backend.axpy(L, (-zt_u * norm) % R, h, n)           # Z_T(u) / Z_{T \ S_0}(u) = Z_{S_0}(u)
     backend.kate_div(L, u, n)
     T.write_point(backend.commit([L])[0])

@@ -17,7 +17,8 @@ def _lagrange_evals(k, x, rows):
     return {i: pow(w, i, R) * zx % R * ninv % R * pow((x - pow(w, i, R)) % R, -1, R) % R for i in rows}
 
 
-def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
+def verify(vk, g1_gen, g2, s_g2, proof, instances=(), dbg=None):
+    """dbg: a dict that receives the intermediate values (challenges, Lagrange evaluations, quotient numerator, pairing inputs)"""
     cs = vk.cs
     n, k, u = cs.n, cs.k, cs.usable
     try:
@@ -120,22 +121,24 @@ def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
         num = (num * y + t) % R
     xn = pow(x, n, R)
     h_eval = num * pow((xn - 1) % R, -1, R) % R
+    if dbg is not None:
+        dbg.update(theta=theta, beta=beta, gamma=gamma, y=y, x=x, l0=l0, llast=llast, lact=lact, terms=list(terms), num=num, h_eval=h_eval, xn=xn)
     # ---- queries, in the prover's order
     hc = None
     for c in reversed(h_c):
         hc = E.g1_add(E.g1_mul(hc, xn), c)
     qs = []
     for c, r in cs.advice_queries: qs.append((("adv", c), adv_c[c], rot_point(r), ev[("adv", c, r)]))
-    for c, r in cs.fixed_queries: qs.append((("fix", c), vk.fixed_commitments[c], rot_point(r), ev[("fix", c, r)]))
-    qs.append((("h",), hc, x, h_eval))
-    qs.append((("rnd",), rnd_c, x, random_eval))
-    for i, e in enumerate(sigma_ev): qs.append((("sigma", i), vk.sigma_commitments[i], x, e))
     for j in range(cs.n_chunks):
         qs.append((("z", j), z_c[j], x, z_ev[j][0])); qs.append((("z", j), z_c[j], rot_point(1), z_ev[j][1]))
         if z_ev[j][2] is not None: qs.append((("z", j), z_c[j], rot_point(u), z_ev[j][2]))
     for i, (phi_e, phi_n, m_e) in enumerate(lk_ev):
         qs.append((("phi", i), phi_c[i], x, phi_e)); qs.append((("phi", i), phi_c[i], rot_point(1), phi_n))
         qs.append((("m", i), m_c[i], x, m_e))
+    for c, r in cs.fixed_queries: qs.append((("fix", c), vk.fixed_commitments[c], rot_point(r), ev[("fix", c, r)]))
+    for i, e in enumerate(sigma_ev): qs.append((("sigma", i), vk.sigma_commitments[i], x, e))
+    qs.append((("h",), hc, x, h_eval))
+    qs.append((("rnd",), rnd_c, x, random_eval))
     # ---- SHPLONK
     groups = P.group_queries(qs)
     ys = T.squeeze_challenge()
@@ -149,10 +152,8 @@ def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
         return False
     if T._rd != len(proof):
         return False
-    zt_u = 1
-    for z in all_pts: zt_u = zt_u * (uu - z) % R
-    L, pw = None, 1
-    for pts, polys in groups:
+    L, pw, norm, z0 = None, 1, None, 1
+    for gi, (pts, polys) in enumerate(groups):
         qc, evs, yp = None, {z: 0 for z in pts}, 1
         for c, e in polys:
             qc = E.g1_add(qc, E.g1_mul(c, yp))
@@ -162,9 +163,14 @@ def verify(vk, g1_gen, g2, s_g2, proof, instances=()):
         zdiff = 1
         for z in all_pts:
             if z not in pts: zdiff = zdiff * (uu - z) % R
+        if gi == 0:                                     # halo2: coefficients normalised by the first set's; -Z_{S_0}(u) on the first opening point
+            norm = pow(zdiff, -1, R)
+            for z in pts: z0 = z0 * (uu - z) % R
         term = E.g1_add(qc, E.g1_neg(E.g1_mul(g1_gen, P.eval_small(r, uu))))
-        L = E.g1_add(L, E.g1_mul(term, pw * zdiff % R))
+        L = E.g1_add(L, E.g1_mul(term, pw * zdiff % R * norm % R))
         pw = pw * v % R
-    L = E.g1_add(L, E.g1_neg(E.g1_mul(pi1, zt_u)))
+    L = E.g1_add(L, E.g1_neg(E.g1_mul(pi1, z0)))
     lhs = E.g1_add(L, E.g1_mul(pi2, uu))
+    if dbg is not None:
+        dbg.update(shplonk_y=ys, shplonk_v=v, shplonk_u=uu, pairing_lhs=lhs, pairing_rhs=pi2)
     return E.pairing_check([(pi2, s_g2), (E.g1_neg(lhs), g2)])

@@ -4,7 +4,7 @@
 Run in the build container only (needs /root/reference, which does not exist on the GPU box):
     python tests/golden/make_golden.py
 Outputs (committed): tests/golden/kzg_k6.srs, kzg_k1_public.srs, vk_k6.key, pk_k6_subset.npz, pk_k6.key, proof_k6.json,
-                     settings_k6.json, witness_k6.json
+                     settings_k6.json, witness_k6.json, verifier_k6.code
 
 Sources (read-only, data not code): /root/reference/tests/assets/{kzg,kzg1.srs,vk.key,pk.key}.
 What they pin:
@@ -16,6 +16,10 @@ pk_k6_subset.npz keeps a few columns for the kernel KATs; pk_k6.key is the whole
 (tests/test_ezkl_circuit.py) load it as `ezkl prove` would and need every fixed / permutation column.
   * proof.json / settings.json / witness.json : the proof the reference made for this key (layout 114 G1 | 231 Fr | 2 G1;
     its fixed / sigma evaluations equal pk.key's polynomials at the challenge x recovered from the identity sigma columns)
+  * wasm.code -> verifier_k6.code : the deployment bytecode (solc 0.8.20, hex text) of the Solidity verifier the reference's tooling
+    generated for a k = 6 key of the SAME constraint system (proof length 14 816, 4 instances; other selector combinations, other
+    commitments): compiled DATA, executed by oracle/mini_evm.py -- the reference's verifier for the EVM transcript, the only
+    executable piece of the zkonduit halo2 protocol in the tree (tests/test_evm_verifier.py)
 """
 import os, shutil, sys
 import numpy as np
@@ -30,6 +34,7 @@ shutil.copyfile(A + "vk.key", os.path.join(HERE, "vk_k6.key"))
 shutil.copyfile(A + "pk.key", os.path.join(HERE, "pk_k6.key"))
 shutil.copyfile(A + "settings.json", os.path.join(HERE, "settings_k6.json"))
 shutil.copyfile(A + "witness.json", os.path.join(HERE, "witness_k6.json"))
+shutil.copyfile(A + "wasm.code", os.path.join(HERE, "verifier_k6.code"))
 import json
 _p = json.load(open(A + "proof.json"))
 _p["proof"] = []          # the byte list duplicates hex_proof
