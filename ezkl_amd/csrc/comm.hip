@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include <dlfcn.h>
 #include <string.h>
+#include <string>
 #include <rccl/rccl.h>
 
 namespace ezkl {
@@ -39,7 +40,23 @@ static Comm g_comm;
 
 static int rccl_load() {
     if (g_rccl.lib) return EZKL_OK;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // RCCL must run on the SAME HIP runtime as this library.  A process can hold two (PyTorch wheels bundle libamdhip64 / librccl with
+    // the system sonames; whichever is loaded first satisfies later NEEDED entries), and a second runtime finds "no ROCm-capable
+    // device": take librccl from the directory of the libamdhip64 this library is bound to, by path, before falling back to the soname.
+    void* h = nullptr;
+    Dl_info di;
+    if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+        }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) {
         fprintf(stderr, "[ezkl_hip] RCCL not available: %s\n", dlerror());

@@ -1741,7 +1741,7 @@ static bool verify_proof(ConstraintSystem& cs, const std::vector<G1>& fixed_comm
                          const uint32_t* instance_lens) {
     using bn::P1;
     const uint32_t n = cs.n, k = cs.k, u = cs.usable;
-    ProofReader T{proof, proof_len};
+    ProofReader T{proof, proof_len, 0, {}};
     T.common_scalar(digest);
     std::vector<std::vector<Fe>> inst(cs.n_instance);
     for (uint32_t i = 0; i < cs.n_instance; i++) {
