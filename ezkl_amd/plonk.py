@@ -7,10 +7,12 @@ quotients) runs in the kernels of libezkl_hip.so on resident columns; the host o
 scalar glue, exactly the split the north-star describes.  Round order follows SURVEY.md §3.1: advice commits ->
 beta, gamma -> permutation products -> random poly -> y -> quotient pieces -> x -> evaluations -> SHPLONK.
 
-What it is NOT: a byte-compatible re-implementation of the zkonduit halo2 fork (its source is not on disk, so the
-exact query order / vk digest cannot be pinned).  The proof format is the EvmTranscript layout of the reference's
-proofs (points 64 B BE, scalars 32 B BE); acceptance is decided by an independent pairing verifier
-(oracle/verifier.py), which is how the reference itself validates proofs.
+Compatibility with the zkonduit halo2 fork (its source is not on disk): the proof format is the EvmTranscript layout of the
+reference's proofs (points 64 B BE, scalars 32 B BE), and the protocol is pinned on the one executable piece of halo2 the reference
+ships -- the compiled Solidity verifier tests/assets/wasm.code: with its verifying-key constants replaced by this key's, the
+reference's bytecode derives the same eight challenges, evaluates the same 200 quotient terms and ACCEPTS the proofs written here
+(tests/test_evm_verifier.py).  What stays unpinned is the 32-byte vk digest (halo2 hashes the Debug text of its
+constraint system); this module binds keccak256 of the serialised constraint system + the commitments in its place.
 
 Covered: custom gates, the permutation argument (chunked), mv-lookup (logUp) arguments with theta-compressed tuples,
 instance columns (hashed, not committed; evaluated by the verifier), second-phase advice with post-commitment challenges.

@@ -12,10 +12,13 @@
  * GPU every call that touches columns returns EZKL_ERR_NO_DEVICE.  Status codes are those of ezkl_hip.h; nothing
  * unwinds across the ABI.
  *
- * Not byte-compatible with the zkonduit halo2 fork's proofs (its source is not on disk, so query order / vk digest
- * cannot be pinned): the proof LAYOUT is the reference's (points 64 B BE, scalars 32 B BE), acceptance
- * is decided by the independent pairing verifier in oracle/verifier.py, and the bytes are identical to those of the
- * Python restatement ezkl_amd/plonk.py under the same randomness (tests/test_native_prover.py).
+ * Compatibility with the zkonduit halo2 fork: the proof LAYOUT is the reference's (points 64 B BE, scalars 32 B BE) and the protocol
+ * is the one the reference's own generated EVM verifier checks: tests/test_evm_verifier.py runs that bytecode
+ * (/root/reference/tests/assets/wasm.code) with its verifying-key constants replaced by this library's key and it accepts the proofs
+ * ezkl_prover_create_proof writes on the GPU -- same challenges, same quotient terms, same SHPLONK (halo2's query order, first-set
+ * normalisation), real pairing.  Not pinnable: halo2's vk digest (a hash of Debug text); the 32-byte digest here
+ * binds the serialised constraint system + the commitments.  The bytes are identical to those of the Python restatement
+ * ezkl_amd/plonk.py under the same randomness (tests/test_native_prover.py).
  */
 #ifndef EZKL_PROVER_H
 #define EZKL_PROVER_H
