@@ -2113,6 +2113,14 @@ int ezkl_prover_vk(ezkl_pk_t h, void* fixed_commitments, void* permutation_commi
     if (digest) std::memcpy(digest, pk.digest.v.data(), 32);
     return EZKL_OK;
 }
+int ezkl_prover_pk_set_transcript_repr(ezkl_pk_t h, const void* repr) {
+    if (!h || !repr) return EZKL_ERR_INVALID;
+    U256 v;
+    std::memcpy(v.data(), repr, 32);
+    if (cmp(v, FR.p) >= 0) return EZKL_ERR_INVALID;              // a canonical scalar, as halo2 transcript_repr is
+    h->pk->digest = Fe::from_canonical(v);
+    return EZKL_OK;
+}
 int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, ezkl_advice_fn advice_fn, void* advice_user,
                              const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng, void* rng_user, uint64_t seed, void* proof_out,
                              size_t cap, size_t* proof_len, double* timings) {

@@ -112,6 +112,11 @@ int ezkl_prover_pk_recommit(ezkl_pk_t pk, ezkl_bases_t g);
 /* verifying key: n_fixed + n_perm affine commitments (64 B Montgomery each) and the 32-byte transcript digest
  * (Montgomery Fr).  Any output pointer may be NULL. */
 int ezkl_prover_vk(ezkl_pk_t pk, void* fixed_commitments, void* permutation_commitments, void* digest);
+/* Replace the digest that heads every transcript of this key by the caller's 32-byte little-endian CANONICAL scalar: a halo2 fork
+ * passes vk.transcript_repr (halo2_proofs VerifyingKey::hash_into -- Blake2b of the Debug text of its pinned constraint system, which
+ * only the fork can compute) so that its own verifier reads the same transcript; everything after that scalar is already the
+ * reference's protocol (tests/test_evm_verifier.py).  Lost on pk_recommit / re-read (they recompute the default digest). */
+int ezkl_prover_pk_set_transcript_repr(ezkl_pk_t pk, const void* repr);
 
 /* ---- create_proof ----
  * advice: n_advice host pointers (2^k x 32 B Montgomery; rows >= usable are overwritten with blinding randomness on the

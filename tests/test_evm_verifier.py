@@ -185,3 +185,15 @@ def test_gpu_native_prover_proof_accepted_by_the_reference_verifier(hip, setup):
     assert EV.run(s["vk"], s["g2"], s["s_g2"], proof, s["inst"])[0]
     assert NV.verify_proof(pk, s["srs"]["g2"], s["srs"]["s_g2"], proof, s["inst"])
     assert NV.create_proof(pk, bg, bgl, mont, rng=P.Rng(7), instances=s["inst"]) == s["proof"]
+    # a fork's own digest through ezkl_prover_pk_set_transcript_repr: with the CONTRACT's digest constant the transcript is the one
+    # the untouched digest path of the bytecode reads (only the commitments are still replaced)
+    contract_digest = int.from_bytes(EV.CONTRACT_DIGEST, "big")
+    pk.set_transcript_repr(contract_digest)
+    assert pk.vk()[2] == contract_digest
+    proof_d = NV.create_proof(pk, bg, bgl, mont, seed=22, instances=s["inst"])
+    vk_d = P.VerifyingKey()
+    vk_d.cs, vk_d.fixed_commitments, vk_d.sigma_commitments, vk_d.digest = s["cs"], s["vk"].fixed_commitments, s["vk"].sigma_commitments, contract_digest
+    ok, tr, _ = EV.run(vk_d, s["g2"], s["s_g2"], proof_d, s["inst"])
+    assert ok and tr["keccak"][0][:32] == EV.CONTRACT_DIGEST
+    assert NV.verify_proof(pk, s["srs"]["g2"], s["srs"]["s_g2"], proof_d, s["inst"])
+    assert not EV.run(s["vk"], s["g2"], s["s_g2"], proof_d, s["inst"])[0]          # the default digest no longer matches it
