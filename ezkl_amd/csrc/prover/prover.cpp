@@ -57,6 +57,11 @@ struct Shard {
     ezkl_gather_fn gather = nullptr;  // optional: the quotient sweep sharded by rows (ezkl_prover_cs_set_sweep_gather)
     void* gather_user = nullptr;
     mutable uint64_t sharded_sweeps = 0;
+    // the SRS handles hold ALL 2^k points on every rank (ezkl_prover_cs_set_shard_full_bases; 288 GB of HBM per GPU: a 2^22 base set
+    // with its window tables is 3.5 GB): a commit batch is then divided by COLUMNS -- whole MSMs, which keep the per-call tail of a
+    // 2^k-point MSM off the critical path instead of paying it on every 2^k / world slice -- and by point ranges inside a column
+    // only when the batch has fewer columns than there are ranks
+    bool full_bases = false;
     bool on() const { return hi != 0; }
     // equal power-of-two slices: rank / log2(world) of this one, or false
     bool geometry(uint32_t n, uint32_t& rank, uint32_t& log_world) const {
@@ -492,11 +497,35 @@ struct Backend {
         return o;
     }
     std::vector<G1> commit_with(ezkl_bases_t b, const std::vector<Col>& hs) const {
-        std::vector<G1> out(hs.size());
+        std::vector<G1> out(hs.size());                      // zero bytes = the identity: what a rank contributes for work it does not do
         if (hs.empty()) return out;
+        uint32_t rank = 0, log_world = 0;
+        if (shard.on() && shard.full_bases && shard.geometry(n, rank, log_world)) {
+            const uint32_t world = 1u << log_world, m = (uint32_t)hs.size();
+            if (m >= world) {                                // by columns: column i on rank i mod world, whole MSMs
+                std::vector<const void*> ptrs;
+                std::vector<uint32_t> mine;
+                for (uint32_t i = rank; i < m; i += world) { ptrs.push_back(hs[i]->ptr()); mine.push_back(i); }
+                std::vector<G1> part(ptrs.size());
+                check(ezkl_hip_msm_g1_batch_dev(b, 0, ptrs.data(), ptrs.size(), n, part.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+                for (size_t j = 0; j < mine.size(); j++) out[mine[j]] = part[j];
+            } else {                                         // fewer columns than ranks: 2^t ranks per column, each a point range
+                uint32_t pieces = 1;
+                while (pieces * 2 * m <= world) pieces *= 2;
+                if (rank < m * pieces) {
+                    const uint32_t col = rank / pieces, q = rank % pieces;
+                    const size_t len = n / pieces, first = (size_t)q * len;
+                    const void* ptr = at(hs[col], first);
+                    check(ezkl_hip_msm_g1_batch_dev(b, first, &ptr, 1, len, &out[col], nullptr), "ezkl_hip_msm_g1_batch_dev");
+                }
+            }
+            fold(out);
+            return out;
+        }
         std::vector<const void*> ptrs;
         for (auto& h : hs) ptrs.push_back(at(h, commit_first()));
-        check(ezkl_hip_msm_g1_batch_dev(b, 0, ptrs.data(), ptrs.size(), commit_count(), out.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+        check(ezkl_hip_msm_g1_batch_dev(b, shard.on() && shard.full_bases ? commit_first() : 0, ptrs.data(), ptrs.size(), commit_count(), out.data(), nullptr),
+              "ezkl_hip_msm_g1_batch_dev");
         fold(out);
         return out;
     }
@@ -1464,7 +1493,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
                     check(ezkl_hip_upload_wait(up, j, be.aux_stream()), "ezkl_hip_upload_wait");
                     adv_forms[idxs[j]] = be.forms_async(adv_cols[idxs[j]], cs.ext_k, &adv_forms[idxs[j]]);
                 }
-                rc = ezkl_hip_upload_commit(up, gl, be.commit_first(), be.commit_count(), commits.data());
+                if (!(cs.shard.on() && cs.shard.full_bases)) rc = ezkl_hip_upload_commit(up, gl, be.commit_first(), be.commit_count(), commits.data());
             } catch (...) {
                 (void)ezkl_hip_upload_end(up);
                 throw;
@@ -1473,7 +1502,12 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             check(rc, "ezkl_hip_upload_commit");
             check(rc2, "ezkl_hip_upload_end");
         }
-        be.fold(commits);
+        if (cs.shard.on() && cs.shard.full_bases) {         // divided by columns: the copies have landed (upload_end drains them)
+            std::vector<Col> cols_;
+            for (uint32_t c : idxs) cols_.push_back(adv_cols[c]);
+            commits = be.commit_lagrange(cols_);
+        } else
+            be.fold(commits);
         for (auto& p : commits) T.write_point(p);
         if (phase == 0)
             for (uint32_t i = 0; i < cs.n_challenges; i++) user_chal.push_back(T.squeeze_challenge());
@@ -2045,6 +2079,11 @@ int ezkl_prover_cs_set_shard_comm(ezkl_cs_t h) {
     rc = ezkl_prover_cs_set_shard(h, lo, hi, comm_fold, nullptr);
     if (rc) return rc;
     if (world > 1 && (world & (world - 1)) == 0 && n % (uint32_t)world == 0) return ezkl_prover_cs_set_sweep_gather(h, comm_gather, nullptr);
+    return EZKL_OK;
+}
+int ezkl_prover_cs_set_shard_full_bases(ezkl_cs_t h, int on) {
+    if (!h) return EZKL_ERR_INVALID;
+    h->cs->shard.full_bases = on != 0;
     return EZKL_OK;
 }
 int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t h, ezkl_gather_fn gather, void* user) {

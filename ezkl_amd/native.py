@@ -13,7 +13,7 @@ from . import plonk as _pl
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
-SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
+SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
@@ -116,6 +116,10 @@ class NativeCircuit:
         _check(load().ezkl_prover_cs_set_shard_comm(self.h), "ezkl_prover_cs_set_shard_comm")
         self._slice = D.shard_range(self.cs.n, rank, world)
         return self._slice
+
+    def set_shard_full_bases(self, on=True):
+        """every rank passes COMPLETE base sets: commit batches are divided by columns (point ranges only when columns < ranks)"""
+        _check(load().ezkl_prover_cs_set_shard_full_bases(self.h, 1 if on else 0), "ezkl_prover_cs_set_shard_full_bases")
 
     def sharded_sweeps(self):
         out = C.c_uint64(0)

@@ -71,6 +71,12 @@ int ezkl_prover_cs_set_shard(ezkl_cs_t cs, uint32_t lo, uint32_t hi, ezkl_fold_f
  * power-of-two world the quotient sweep is sharded by rows with h all_gathered in place on the device (ezkl_hip_comm_allgather_dev).
  * No callbacks, no torch: what a fork's worker process (one per GPU) calls after exchanging the unique id. */
 int ezkl_prover_cs_set_shard_comm(ezkl_cs_t cs);
+/* Sharding with COMPLETE base sets: tell the prover that the SRS handles passed to keygen / create_proof on this rank hold all 2^k
+ * points (not the slice [lo, hi) of ezkl_prover_cs_set_shard).  A commit batch of m columns on `world` ranks is then divided by
+ * columns (column i on rank i mod world: whole MSMs, no per-slice tails) and, when m < world, by 2^t point ranges inside each
+ * column; a rank contributes the identity for work it does not do and the same fold callback / communicator sums the partials.
+ * The advice phase then commits after its copies have landed (no PCIe / MSM overlap on that path).  Call after set_shard*. */
+int ezkl_prover_cs_set_shard_full_bases(ezkl_cs_t cs, int on);
 /* Optional, on top of set_shard with equal power-of-two slices: the quotient sweep sharded by ROWS.  Each rank evaluates
  * 2^ext_k / world rows of the quotient numerator (the gate program rewritten per shard: every (column, rotation) it reads is a
  * window of the resident coset column) and calls `gather`, which must make the whole device buffer `buf` (total_bytes) identical

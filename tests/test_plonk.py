@@ -356,6 +356,16 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     nv = j2["native_prover"]
     assert nv["proof_identical_to_python_prover"] and nv["all_ranks_same_proof"] and nv["library_rng_proof_verifies"]
     assert nv["sharded_sweeps"] == 2                                   # warm-up + timed proof: the sweep split by rows, h all_gathered
+    assert nv["commit_sharding"].startswith("by columns")              # default: complete base sets, commit batches divided by columns
+    # the same with 1/world of the SRS per rank (every MSM divided by points): same proof again
+    two_s = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29543", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo", "--native", "--slice-bases"],
+                           env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in two_s.stdout.strip().splitlines() if l.startswith("{")]
+    assert lines, two_s.stderr[-2000:]
+    j3 = json.loads(lines[-1])
+    assert j3["native_prover"]["commit_sharding"].startswith("by points") and j3["native_prover"]["proof_identical_to_python_prover"]
+    assert j3["native_prover"]["all_ranks_same_proof"] and j3["native_prover"]["library_rng_proof_verifies"]
 
 
 @pytest.mark.gpu

@@ -253,7 +253,12 @@ if world > 1 and "--native" in sys.argv:
         if ok and not comm_used:
             B.comm_destroy()
     lo, hi = nc.set_shard_comm() if comm_used else nc.set_shard(dist, ddev)
-    gb_, glb_ = B.Bases(np.ascontiguousarray(g[lo:hi])), B.Bases(np.ascontiguousarray(gl[lo:hi]))
+    full_bases = "--slice-bases" not in sys.argv
+    if full_bases:       # every rank holds the whole SRS (and its window tables): commit batches divide by columns, see ezkl_prover.h
+        nc.set_shard_full_bases(True)
+        gb_, glb_ = B.Bases(np.ascontiguousarray(g)), B.Bases(np.ascontiguousarray(gl))
+    else:
+        gb_, glb_ = B.Bases(np.ascontiguousarray(g[lo:hi])), B.Bases(np.ascontiguousarray(gl[lo:hi]))
     npk = NV.NativeProvingKey(nc, gb_, fixed, copies)
     nproof = NV.create_proof(npk, gb_, glb_, adv, rng=P.Rng(5), instances=instances)   # warm-up; same randomness as the Python host above
     ltm = {}
@@ -263,7 +268,9 @@ if world > 1 and "--native" in sys.argv:
     all_h = [torch.empty_like(hs_) for _ in range(world)]
     dist.all_gather(all_h, hs_)
     tt = torch.tensor([t_native], dtype=torch.float64, device=ddev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    native_multi = {"prove_seconds_library_rng": round(float(tt[0]), 4), "proof_identical_to_python_prover": nproof == proof,
+    native_multi = {"prove_seconds_library_rng": round(float(tt[0]), 4),
+                    "commit_sharding": ("by columns (whole MSMs; point ranges when a batch has fewer columns than ranks), complete base sets on every rank"
+                                        if full_bases else "by points, 1/%d of the SRS per rank" % world), "proof_identical_to_python_prover": nproof == proof,
                     "sharded_sweeps": nc.sharded_sweeps(), "gather_on_device_pointers": bool(getattr(nc, "direct_gather", False)) or comm_used,
                     "collectives": "libezkl_hip.so RCCL communicator (comm.hip)" if comm_used else "torch.distributed callbacks",
                     "all_ranks_same_proof": all(bool((h == all_h[0]).all()) for h in all_h), "library_rng_proof": lproof,
