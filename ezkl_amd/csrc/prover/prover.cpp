@@ -2167,7 +2167,7 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
     if (pk->pk->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
     return guarded([&] {
         const Shard& sh = pk->pk->cs->shard;
-        const size_t want = sh.on() ? sh.hi - sh.lo : pk->pk->cs->n;
+        const size_t want = sh.on() && !sh.full_bases ? sh.hi - sh.lo : pk->pk->cs->n;
         invalid(ezkl_hip_bases_len(g) < want || ezkl_hip_bases_len(g_lagrange) != want, "SRS size does not match 2^k (or this rank's slice)");
         Rng r(rng, rng_user, seed);
         if (sh.on() && !rng && seed == 0) {
