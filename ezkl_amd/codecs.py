@@ -12,6 +12,11 @@
         poly = u32 BE len | len x 32 B ;  vec = u32 BE count | count x u32 BE len | count x poly
   proof.json  (src/pfsys/mod.rs:198-315 Snark): "hex_proof" = 0x + hex(proof bytes); instances = 32-byte LE hex felts
 
+  model.compiled  (src/graph/mod.rs:1250-1268 GraphCircuit::save / load: bincode, fixed-width little-endian integers, u64 lengths, u32
+        enum tags) -- read_compiled_circuit: the Model (nodes of src/graph/node.rs:522-536 with SupportedOp / PolyOp / Input / Constant,
+        field elements as 32 canonical LE bytes) and the GraphSettings 19-tuple (src/graph/mod.rs:545-568), checked against the
+        reference's fixture (its settings.json says the same, its weights are the fixture model's)
+
 All field / curve bytes stay in their on-disk Montgomery form: they are handed to the GPU unchanged.
 The number of permutation columns and selectors is not stored in the file (halo2 re-derives it by re-running
 `configure`, src/pfsys/mod.rs:627); callers pass them."""
@@ -198,3 +203,181 @@ def read_witness_json(text):
     for key in ("max_lookup_inputs", "min_lookup_inputs", "max_range_size"):
         out[key] = j.get(key)
     return out
+
+
+# ------------------------------------------------------------------ model.compiled (bincode of ezkl's GraphCircuit)
+_FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+_INPUT_TYPES = ["Bool", "F16", "F32", "F64", "Int", "TDim", "Unknown"]                       # src/circuit/ops/mod.rs:88-103
+# src/circuit/ops/lookup.rs:16-38: (name, number of f32 fields)
+_LOOKUP_OPS = [("Div", 1), ("IsOdd", 0), ("PowersOfTwo", 1), ("Ln", 1), ("Sigmoid", 1), ("Exp", 2), ("Cos", 1), ("ACos", 1), ("Cosh", 1), ("ACosh", 1),
+               ("Sin", 1), ("ASin", 1), ("Sinh", 1), ("ASinh", 1), ("Tan", 1), ("ATan", 1), ("Tanh", 1), ("ATanh", 1), ("Erf", 1), ("Pow", 2), ("HardSwish", 1)]
+
+
+class _Bincode:
+    """bincode 1.x default options: little-endian fixed-width integers, u64 sequence lengths, u32 enum variant tags, u8 Option tags"""
+
+    def __init__(self, buf):
+        self.b, self.o = bytes(buf), 0
+
+    def take(self, n):
+        v = self.b[self.o:self.o + n]
+        if len(v) != n:
+            raise ValueError("compiled circuit truncated at byte %d" % self.o)
+        self.o += n
+        return v
+
+    def u8(self): return self.take(1)[0]
+    def u32(self): return struct.unpack("<I", self.take(4))[0]
+    def i32(self): return struct.unpack("<i", self.take(4))[0]
+    def u64(self): return struct.unpack("<Q", self.take(8))[0]
+    def f32(self): return struct.unpack("<f", self.take(4))[0]
+    def f64(self): return struct.unpack("<d", self.take(8))[0]
+    def i128(self): return int.from_bytes(self.take(16), "little", signed=True)
+    def u128(self): return int.from_bytes(self.take(16), "little")
+
+    def boolean(self):
+        v = self.u8()
+        if v > 1:
+            raise ValueError("bad bool %d at byte %d" % (v, self.o - 1))
+        return bool(v)
+
+    def vec(self, f):
+        n = self.u64()
+        if n > len(self.b):
+            raise ValueError("bad sequence length %d at byte %d" % (n, self.o - 8))
+        return [f() for _ in range(n)]
+
+    def opt(self, f):
+        t = self.u8()
+        if t > 1:
+            raise ValueError("bad Option tag %d at byte %d" % (t, self.o - 1))
+        return f() if t else None
+
+    def string(self): return bytes(self.take(self.u64())).decode()
+
+    def char(self):
+        b0 = self.u8()
+        n = 1 if b0 < 0x80 else 2 if b0 < 0xe0 else 3 if b0 < 0xf0 else 4
+        return (bytes([b0]) + bytes(self.take(n - 1))).decode()
+
+    def felt(self):
+        v = int.from_bytes(self.take(32), "little")
+        if v >= _FR:
+            raise ValueError("non-canonical field element at byte %d" % (self.o - 32))
+        return v
+
+
+def _visibility(r):
+    """src/graph/vars.rs:22-41"""
+    t = r.u32()
+    if t == 2:
+        return {"Hashed": {"hash_is_public": r.boolean(), "outlets": r.vec(r.u64)}}
+    if t > 4:
+        raise ValueError("bad Visibility tag %d" % t)
+    return ["Private", "Public", None, "KZGCommit", "Fixed"][t]
+
+
+def _tensor(r, elem):
+    """src/tensor/mod.rs:176-182"""
+    return dict(inner=r.vec(elem), dims=r.vec(r.u64), scale=r.opt(r.i32), visibility=r.opt(lambda: _visibility(r)))
+
+
+def _poly_op(r):
+    """src/circuit/ops/poly.rs:15-108 (the variants an MLP-family graph holds; the others are refused by name)"""
+    names = ["Abs", "Sign", "LeakyReLU", "GatherElements", "GatherND", "ScatterElements", "ScatterND", "MultiBroadcastTo", "Einsum", "Conv", "Downsample",
+             "DeConv", "Add", "Sub", "Neg", "Mult", "Identity", "Reshape", "MoveAxis", "Flatten", "Pad", "Sum", "MeanOfSquares", "Prod", "Pow", "Concat",
+             "Slice", "Iff", "Resize", "Not", "And", "Or", "Xor", "Trilu"]
+    t = r.u32()
+    if t >= len(names):
+        raise ValueError("bad PolyOp tag %d" % t)
+    name = names[t]
+    if name in ("Abs", "Sign", "Add", "Sub", "Neg", "Mult", "Iff", "Not", "And", "Or", "Xor"): return {"op": name}
+    if name == "LeakyReLU": return {"op": name, "slope": r.f32(), "scale": r.i32()}
+    if name == "MultiBroadcastTo": return {"op": name, "shape": r.vec(r.u64)}
+    if name == "Einsum": return {"op": name, "equation": r.string()}
+    if name == "Identity": return {"op": name, "out_scale": r.opt(r.i32)}
+    if name in ("Reshape", "Flatten"): return {"op": name, "shape": r.vec(r.u64)}
+    if name in ("Sum", "MeanOfSquares"): return {"op": name, "axes": r.vec(r.u64)}
+    if name == "Pow": return {"op": name, "power": r.u32()}
+    if name == "Concat": return {"op": name, "axis": r.u64()}
+    if name == "Slice": return {"op": name, "axis": r.u64(), "start": r.u64(), "end": r.u64()}
+    if name == "MoveAxis": return {"op": name, "source": r.u64(), "destination": r.u64()}
+    if name == "Pad": return {"op": name, "padding": r.vec(lambda: (r.u64(), r.u64()))}
+    raise ValueError("PolyOp::%s in a compiled circuit is not supported by this reader" % name)
+
+
+def _supported_op(r):
+    """src/graph/node.rs:295-312"""
+    t = r.u32()
+    if t == 0: return {"kind": "Linear", **_poly_op(r)}
+    if t == 1:
+        name, nf = _LOOKUP_OPS[r.u32()]
+        return {"kind": "Nonlinear", "op": name, "params": [r.f32() for _ in range(nf)]}
+    if t == 3: return {"kind": "Input", "scale": r.i32(), "datum_type": _INPUT_TYPES[r.u32()], "decomp": r.boolean()}     # ops/mod.rs:186-193
+    if t == 4:                                                                                                           # ops/mod.rs:295-305
+        return {"kind": "Constant", "quantized_values": _tensor(r, r.felt), "raw_values": _tensor(r, r.f32), "decomp": r.boolean()}
+    if t == 5: return {"kind": "Unknown"}
+    if t == 6: return {"kind": "Rescaled", "inner": _supported_op(r), "scale": r.vec(lambda: (r.u64(), r.u128()))}     # node.rs:87-92
+    raise ValueError("SupportedOp tag %d (Hybrid / RebaseScale) is not supported by this reader" % t)
+
+
+def _run_args(r):
+    """src/lib.rs:198-285.  The reference's fixture was written by a build whose RunArgs still had `commitment: Option<Commitments>`
+    after check_mode (its settings.json shows the key); both layouts are accepted and the caller
+    checks the result (run_args.check_mode must equal the settings' own check_mode, the version string must be text)."""
+    a = dict(input_scale=r.i32(), param_scale=r.i32(), rebase_scale=r.opt(r.i32), scale_rebase_multiplier=r.u32(), lookup_range=(r.i128(), r.i128()),
+             logrows=r.u32(), num_inner_cols=r.u64(), variables=r.vec(lambda: (r.string(), r.u64())), input_visibility=_visibility(r),
+             output_visibility=_visibility(r), param_visibility=_visibility(r), rebase_frac_zero_constants=r.boolean())
+    t = r.u32()
+    if t > 1:
+        raise ValueError("bad CheckMode tag %d" % t)
+    a["check_mode"] = ["SAFE", "UNSAFE"][t]
+    return a
+
+
+def _settings(r, legacy):
+    a = _run_args(r)
+    if legacy:
+        a["commitment"] = r.opt(lambda: ["KZG", "IPA"][r.u32()])
+    a["decomp_base"], a["decomp_legs"] = r.u64(), r.u64()
+    a.update(bounded_log_lookup=r.boolean(), ignore_range_check_inputs_outputs=r.boolean(), epsilon=r.opt(r.f64), disable_freivalds=r.boolean())
+    s = dict(run_args=a, num_rows=r.u64(), total_assignments=r.u64(), total_const_size=r.u64())                          # graph/mod.rs:545-568
+    s.update(total_dynamic_col_size=r.u64(), max_dynamic_input_len=r.u64(), num_dynamic_lookups=r.u64(), num_shuffles=r.u64(), total_shuffle_col_size=r.u64())
+    s["einsum_params"] = dict(equations=r.vec(lambda: (r.string(), dict(r.vec(lambda: (r.char(), r.u64()))))), total_einsum_col_size=r.u64())
+    s.update(model_instance_shapes=r.vec(lambda: r.vec(r.u64)), model_output_scales=r.vec(r.i32), model_input_scales=r.vec(r.i32))
+    s["module_sizes"] = dict(polycommit=r.vec(r.u64), poseidon=[r.u64(), r.vec(r.u64)])
+    def lookup():
+        name, nf = _LOOKUP_OPS[r.u32()]
+        return {"op": name, "params": [r.f32() for _ in range(nf)]}
+    s.update(required_lookups=r.vec(lookup), required_range_checks=r.vec(lambda: (r.i128(), r.i128())))
+    t = r.u32()
+    if t > 1:
+        raise ValueError("bad CheckMode tag %d" % t)
+    s.update(check_mode=["SAFE", "UNSAFE"][t], version=r.string(), num_blinding_factors=r.opt(r.u64), timestamp=r.opt(r.u128),
+             input_types=r.opt(lambda: r.vec(lambda: _INPUT_TYPES[r.u32()])), output_types=r.opt(lambda: r.vec(lambda: _INPUT_TYPES[r.u32()])))
+    if s["check_mode"] != a["check_mode"] or not s["version"].isprintable() or not (1 <= a["logrows"] <= 28) or a["decomp_base"] < 2:
+        raise ValueError("settings do not parse under this layout")
+    return s
+
+
+def read_compiled_circuit(buf):
+    """bincode of GraphCircuit { core: CoreCircuit { model, settings }, graph_witness } -> {"model": {...}, "settings": {...}}; the witness
+    that trails the settings is not read (prove takes it from witness.json).  Nodes keep the reference's names."""
+    r = _Bincode(buf)
+    nodes = {}
+    for _ in range(r.u64()):                                   # ParsedNodes.nodes: BTreeMap<usize, NodeType> (graph/model.rs:378-384)
+        key = r.u64()
+        if r.u32() != 0:
+            raise ValueError("NodeType::SubGraph is not supported by this reader")
+        nodes[key] = dict(opkind=_supported_op(r), out_scale=r.i32(), inputs=r.vec(lambda: (r.u64(), r.u64())), out_dims=r.vec(r.u64), idx=r.u64(),
+                          num_uses=r.u64())
+    model = dict(nodes=nodes, inputs=r.vec(r.u64), outputs=r.vec(lambda: (r.u64(), r.u64())), output_types=r.vec(lambda: _INPUT_TYPES[r.u32()]),
+                 visibility=dict(input=_visibility(r), params=_visibility(r), output=_visibility(r)))
+    start, err = r.o, None
+    for legacy in (False, True):
+        r.o = start
+        try:
+            return dict(model=model, settings=_settings(r, legacy), settings_layout="legacy (commitment field)" if legacy else "current")
+        except (ValueError, IndexError, UnicodeDecodeError) as e:
+            err = e
+    raise ValueError("the GraphSettings of this compiled circuit do not parse: %s" % err)

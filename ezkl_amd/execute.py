@@ -24,12 +24,65 @@ class CheckMode:
 
 
 def _load_circuit(path):
-    j = json.load(open(path))
-    if j.get("model") != "mlp":
-        raise ValueError("unsupported compiled circuit: %r" % j.get("model"))
-    ra = j["run_args"]
-    return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], j["weights"], j["biases"], ra["decomp_base"], ra["decomp_legs"],
-                         total_assignments=j.get("total_assignments"), relu_last=j.get("relu_last", True)), j
+    """the reference's own `model.compiled` (bincode of GraphCircuit, codecs.read_compiled_circuit) or this package's JSON description"""
+    raw = open(path, "rb").read()
+    if raw[:1] == b"{":
+        j = json.loads(raw)
+        if j.get("model") != "mlp":
+            raise ValueError("unsupported compiled circuit: %r" % j.get("model"))
+        ra = j["run_args"]
+        return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], j["weights"], j["biases"], ra["decomp_base"], ra["decomp_legs"],
+                             total_assignments=j.get("total_assignments"), relu_last=j.get("relu_last", True)), j
+    c = codecs.read_compiled_circuit(raw)
+    weights, biases, relu_last = _mlp_of_graph(c["model"])
+    st, ra = c["settings"], c["settings"]["run_args"]
+    want = [(-1, 1), (0, ra["decomp_base"] - 1)]
+    if [tuple(x) for x in st["required_range_checks"]] != want or st["required_lookups"] or st["num_dynamic_lookups"] or st["num_shuffles"] \
+            or st["einsum_params"]["equations"]:
+        raise ValueError("unsupported compiled circuit: its settings ask for arguments outside the MLP family")
+    return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], weights, biases, ra["decomp_base"], ra["decomp_legs"],
+                         total_assignments=st["total_assignments"], relu_last=relu_last), c
+
+
+def _mlp_of_graph(model):
+    """the op family ezkl_layout.MlpCircuit lays out, read off ezkl's node graph: Input -> (Einsum "mk,nk->mn" with a constant [n, k]
+    -> Add of a constant [1, n] -> LeakyReLU slope 0)*, private input and parameters at scale 0, public output"""
+    nodes, vis = model["nodes"], model["visibility"]
+    if (vis["input"], vis["params"], vis["output"]) != ("Private", "Private", "Public") or len(model["inputs"]) != 1 or len(model["outputs"]) != 1:
+        raise ValueError("unsupported compiled circuit: visibility / arity")
+    signed = lambda v: v if v < EL.R // 2 else v - EL.R
+    def const(idx, dims_ok):
+        op = nodes[idx]["opkind"]
+        if op["kind"] != "Constant" or not dims_ok(op["quantized_values"]["dims"]):
+            raise ValueError("unsupported compiled circuit: node %d is not the expected constant" % idx)
+        q = op["quantized_values"]
+        return [signed(v) for v in q["inner"]], q["dims"]
+    cur = model["inputs"][0]
+    if nodes[cur]["opkind"]["kind"] != "Input" or any(n["out_scale"] != 0 for n in nodes.values()):
+        raise ValueError("unsupported compiled circuit: input node / non-zero scales")
+    order = sorted(k for k in nodes if nodes[k]["opkind"]["kind"] == "Linear")
+    weights, biases, relu_last, i = [], [], False, 0
+    while i < len(order):
+        n = nodes[order[i]]
+        if n["opkind"]["op"] != "Einsum" or n["opkind"]["equation"] != "mk,nk->mn" or n["inputs"][0] != (cur, 0):
+            raise ValueError("unsupported compiled circuit: node %d" % order[i])
+        w, dims = const(n["inputs"][1][0], lambda d: len(d) == 2)
+        weights.append([w[r * dims[1]:(r + 1) * dims[1]] for r in range(dims[0])])
+        cur, i = order[i], i + 1
+        n = nodes[order[i]] if i < len(order) else None
+        if n is None or n["opkind"]["op"] != "Add" or n["inputs"][0] != (cur, 0):
+            raise ValueError("unsupported compiled circuit: a Gemm without its bias")
+        biases.append(const(n["inputs"][1][0], lambda d: d[-1] == dims[0])[0])
+        cur, i = order[i], i + 1
+        relu_last = False
+        if i < len(order) and nodes[order[i]]["opkind"]["op"] == "LeakyReLU":
+            n = nodes[order[i]]
+            if n["opkind"]["slope"] != 0.0 or n["inputs"] != [(cur, 0)]:
+                raise ValueError("unsupported compiled circuit: LeakyReLU with a slope")
+            cur, i, relu_last = order[i], i + 1, True
+    if model["outputs"][0] != (cur, 0) or not weights:
+        raise ValueError("unsupported compiled circuit: output node")
+    return weights, biases, relu_last
 
 
 def load_params_prover(srs_path, logrows):
@@ -61,7 +114,7 @@ def setup(compiled_circuit, srs_path, vk_path, pk_path, sample_input=None):
     return dict(n_advice=cs.n_advice, n_fixed=cs.n_fixed, n_lookups=len(cs.lookups), degree=cs.degree, pk_bytes=len(data))
 
 
-def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_mode=CheckMode.UNSAFE, seed=0):
+def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_mode=CheckMode.UNSAFE, seed=0, recommit=False):
     """GraphWitness + compiled circuit + pk + SRS files -> proof.json (Snark).  seed = 0: OS entropy (OsRng); otherwise the
     reference's det-prove.  CheckMode.SAFE verifies the proof before returning it, as create_proof_circuit does."""
     w = codecs.read_witness_json(open(witness_path).read())
@@ -78,7 +131,8 @@ def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_m
     srs = codecs.read_srs(srs_bytes)
     bg, bgl = B.Bases(srs["g"]), B.Bases(srs["g_lagrange"])
     try:
-        pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(ncs), open(pk_path, "rb").read())
+        # recommit: the key file's commitments were made under ANOTHER SRS (the reference's fixture key: the public powers of tau)
+        pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(ncs), open(pk_path, "rb").read(), recommit=bg if recommit else None)
         proof = NV.create_proof(pk, bg, bgl, EL.cols_to_mont(adv, B), seed=seed, instances=inst, check_mode=check_mode,
                                 g2=srs["g2"], s_g2=srs["s_g2"])
     finally:
@@ -87,13 +141,18 @@ def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_m
     return proof
 
 
-def verify(proof_path, compiled_circuit, pk_path, srs_path):
+def verify(proof_path, compiled_circuit, pk_path, srs_path, recommit=False):
     """-> True / False.  The key file supplies the verifying key (vk.key is its prefix)."""
     circuit, j = _load_circuit(compiled_circuit)
     pr = codecs.read_proof_json(open(proof_path).read())
     srs = codecs.read_srs(open(srs_path, "rb").read())
-    pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(_plonk_cs(circuit)), open(pk_path, "rb").read())
-    return NV.verify_proof(pk, srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])
+    bg = B.Bases(srs["g"]) if recommit else None
+    try:
+        pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(_plonk_cs(circuit)), open(pk_path, "rb").read(), recommit=bg)
+        return NV.verify_proof(pk, srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])
+    finally:
+        if bg is not None:
+            bg.free()
 
 
 def _plonk_cs(circuit):

@@ -84,3 +84,28 @@ def test_snark_json_round_trip_and_witness_reader():
     assert back["proof"] == ref["proof"] and back["instances"] == ref["instances"]
     w = codecs.read_witness_json(open(os.path.join(G, "witness_k6.json")).read())
     assert w["inputs"] == [[2, 1, 1]] and w["outputs"] == [[0, 0, 0, 0]] and w["max_range_size"] == 127
+
+
+def test_compiled_circuit_reader_on_the_reference_model():
+    """tests/assets/model.compiled (bincode of GraphCircuit): the node graph is the fixture model (Gemm 3 -> 4 as Einsum "mk,nk->mn" + Add +
+    LeakyReLU slope 0, weights / bias of network.onnx at scale 0) and the GraphSettings inside equal the reference's settings.json"""
+    import json
+    from ezkl_amd import codecs, execute as X
+    from test_ezkl_circuit import FIXTURE_B, FIXTURE_W
+    c = codecs.read_compiled_circuit(open(os.path.join(GOLDEN, "model_k6.compiled"), "rb").read())
+    ref = json.load(open(os.path.join(GOLDEN, "settings_k6.json")))
+    st = json.loads(json.dumps(c["settings"]))
+    for key, val in st.items():
+        if key == "run_args":
+            for k2, v2 in val.items():
+                if k2 in ref["run_args"]:
+                    assert v2 == ref["run_args"][k2], k2
+        elif key in ref:
+            assert val == ref[key], key
+    assert st["total_assignments"] == 472 and st["required_range_checks"] == [[-1, 1], [0, 127]] and st["timestamp"] == ref["timestamp"]
+    kinds = {k: (n["opkind"]["kind"], n["opkind"].get("op")) for k, n in c["model"]["nodes"].items()}
+    assert kinds == {0: ("Input", None), 1: ("Constant", None), 2: ("Linear", "Einsum"), 3: ("Constant", None), 4: ("Linear", "Add"), 6: ("Linear", "LeakyReLU")}
+    assert c["model"]["nodes"][2]["opkind"]["equation"] == "mk,nk->mn" and c["model"]["outputs"] == [(6, 0)]
+    assert X._mlp_of_graph(c["model"]) == ([FIXTURE_W], [FIXTURE_B], True)
+    with pytest.raises(ValueError):
+        codecs.read_compiled_circuit(open(os.path.join(GOLDEN, "model_k6.compiled"), "rb").read()[:700])

@@ -45,3 +45,22 @@ def test_setup_prove_verify_on_files(hip, tmp_path):
     wb = tmp_path / "w.json"; wb.write_text(json.dumps(w))
     with pytest.raises(ValueError, match="outputs"):
         X.prove(str(wb), str(compiled), str(pk_path), str(proof_path), srs)
+
+
+def test_prove_from_the_reference_artefact_files_only(hip, tmp_path):
+    """`ezkl prove` with nothing but the reference's own files: witness.json, model.compiled (bincode of its GraphCircuit), pk.key, the k = 6
+    SRS file -> proof.json.  The key's commitments were made under the public SRS, so it is re-committed under the test SRS on load."""
+    from ezkl_amd import codecs, execute as X
+    g = lambda name: os.path.join(FX.G, name)
+    proof_path = tmp_path / "proof.json"
+    proof = X.prove(g("witness_k6.json"), g("model_k6.compiled"), g("pk_k6.key"), str(proof_path), g("kzg_k6.srs"), X.CheckMode.SAFE, recommit=True)
+    assert len(proof) == 14816
+    pj = codecs.read_proof_json(proof_path.read_text())
+    ref_pj = json.load(open(g("proof_k6.json")))
+    assert pj["instances"] == [[0, 0, 0, 0]] and pj["raw"]["instances"] == ref_pj["instances"]
+    assert X.verify(str(proof_path), g("model_k6.compiled"), g("pk_k6.key"), g("kzg_k6.srs"), recommit=True)
+    # and `setup` from the reference's compiled model reproduces the reference's key file outside its commitments
+    vk_path, pk_path = tmp_path / "vk.key", tmp_path / "pk.key"
+    X.setup(g("model_k6.compiled"), g("kzg_k6.srs"), str(vk_path), str(pk_path))
+    mine, ref = pk_path.read_bytes(), open(g("pk_k6.key"), "rb").read()
+    assert len(mine) == len(ref) and mine[:7] == ref[:7] and mine[7 + 64 * 70:] == ref[7 + 64 * 70:]
