@@ -5,11 +5,13 @@
     prove(witness, compiled_circuit, pk_path, proof_path, srs_path, check_mode)  execute.rs:1575-1627 -> create_proof_circuit (mod.rs:404-489)
     verify(proof_path, compiled_circuit, pk_path, srs_path)                      execute.rs:1651-1722 -> verify_proof_circuit (mod.rs:557-590)
 
-File formats are the reference's: kzg*.srs / pk.key / vk.key in halo2 raw bytes, witness.json (GraphWitness), proof.json (Snark)
-(ezkl_amd/codecs.py).  The one artefact that is NOT the reference's is the compiled circuit: ezkl's `model.compiled` is a bincode of its
-ONNX graph IR and its layout lives in 6.8k lines of Rust (out of scope); here it is a JSON description of the
-model family ezkl_layout.MlpCircuit lays out ({"model": "mlp", "run_args": {...}, "weights": [...], "biases": [...]}) -- on the
-reference's own fixture model that layout reproduces the reference's pk.key bit for bit (tests/test_ezkl_circuit.py).
+File formats are the reference's: kzg*.srs / pk.key / vk.key in halo2 raw bytes, witness.json (GraphWitness), proof.json (Snark) and
+`model.compiled` -- the bincode of ezkl's GraphCircuit (node graph + GraphSettings), read by codecs.read_compiled_circuit: on the
+reference's fixture `prove` runs from the reference's artefact files alone (tests/test_execute.py).  What a compiled circuit may
+CONTAIN here is the op family ezkl_layout.MlpCircuit lays out (Input -> Gemm as Einsum "mk,nk->mn" + bias + LeakyReLU slope 0, private
+parameters, public output): ezkl's general layout lives in 6.8k lines of Rust (out of scope) and any other graph
+is refused by name.  On the fixture model that layout reproduces the reference's pk.key bit for bit (tests/test_ezkl_circuit.py).  A JSON
+description of the same family ({"model": "mlp", "run_args": {...}, "weights": [...], "biases": [...]}) is accepted as well.
 Errors surface as exceptions with the reference's wording where it has one."""
 import json
 
