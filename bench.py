@@ -293,10 +293,14 @@ def prove_leg():
 
 
 def prove_leg_multi(world, rank, local_rank, args):
-    """k = 20 prove with the proof's MSMs sharded across `world` GPUs (plonk.DistGpuBackend: every rank holds 1/world of the
-    SRS, one all_gather of 64-byte partials per commit batch; NTTs and the sweep replicated).  Runs in child processes."""
+    """BASELINE configs[3]: the reference's accum_einsum_matmul bench circuit at k = 20 proved by libezkl_prover.so across `world` GPUs --
+    every rank holds the complete SRS (288 GB of HBM: base sets + window tables are < 2 GB), each commit batch is divided by columns
+    (point ranges when it has fewer columns than ranks) and folded with one all_gather of 64-byte partials, the quotient sweep is divided
+    by rows and h all_gathered in place, through the library's own RCCL communicator (csrc/comm.hip).  Every rank emits the same proof
+    bytes; rank 0 verifies them.  Runs in child processes (EZKL_BENCH_MULTI_CIRCUIT=mlp / synthetic selects another circuit)."""
     import subprocess
-    env = dict(os.environ, K="20", BLOCKS="4", CIRCUIT="synthetic", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+    circuit = os.environ.get("EZKL_BENCH_MULTI_CIRCUIT", "einsum")
+    env = dict(os.environ, K=os.environ.get("EZKL_BENCH_MULTI_K", "20"), BLOCKS="4", CIRCUIT=circuit, REPS="3", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(local_rank))
     for k_ in list(env):                       # the children rendezvous on their own: no torchrun agent store behind the new port
         if k_.startswith("TORCHELASTIC_") or k_ in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
@@ -308,20 +312,25 @@ def prove_leg_multi(world, rank, local_rank, args):
     if args.share_device:
         cmd.append("--share-device")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "240")))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300")))
         if rank != 0:
             return None
-        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        nv = j.get("native_prover", {})
-        return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5",
-                "n_gpus": j["n_gpus"], "msm_sharding": j["msm_sharding"],
-                "host": "libezkl_prover.so (C++), MSMs sharded by points (ezkl_prover_cs_set_shard): every rank holds 1/N of the SRS, one all_gather of 64-byte partials per commit batch; quotient sweep sharded by rows, h all_gathered in place",
-                "sharded_sweeps": nv.get("sharded_sweeps"), "gather_on_device_pointers": nv.get("gather_on_device_pointers"), "collectives": nv.get("collectives"),
-                "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "native_proof_identical_to_python_host": nv.get("proof_identical_to_python_prover"),
-                "all_ranks_same_proof": nv.get("all_ranks_same_proof"), "native_proof_verifies": nv.get("library_rng_proof_verifies"),
-                "breakdown_seconds": nv.get("breakdown_seconds_library_rng"),
-                "prove_seconds_gpu_python_host": j["prove_seconds_gpu"], "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"],
-                "breakdown_seconds_python_host": j["prove_breakdown_seconds"]}
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            raise RuntimeError(r.stderr[-300:])
+        j = json.loads(lines[-1])
+        if circuit == "synthetic":
+            nv = j.get("native_prover", {})
+            return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5", "n_gpus": j["n_gpus"],
+                    "commit_sharding": nv.get("commit_sharding"), "collectives": nv.get("collectives"), "sharded_sweeps": nv.get("sharded_sweeps"),
+                    "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "all_ranks_same_proof": nv.get("all_ranks_same_proof"),
+                    "verifier_accepts": nv.get("library_rng_proof_verifies"), "breakdown_seconds": nv.get("breakdown_seconds_library_rng"), "proof_bytes": j["proof_bytes"]}
+        m = j.get("multi_gpu", {})
+        return {"circuit": j["circuit"], "n_gpus": j["n_gpus"], "host": "libezkl_prover.so (C++) over the C ABI", "commit_sharding": m.get("commit_sharding"),
+                "sweep_sharding": m.get("sweep_sharding"), "collectives": m.get("collectives"), "sharded_sweeps": m.get("sharded_sweeps"),
+                "prove_seconds_gpu": j["prove_seconds_gpu"], "prove_seconds_gpu_runs": j.get("prove_seconds_gpu_runs"), "all_ranks_same_proof": m.get("all_ranks_same_proof"),
+                "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "proof_sha256": j.get("proof_sha256"),
+                "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"]}
     except Exception as e:
         return {"error": repr(e)[:300]} if rank == 0 else None
 
