@@ -55,6 +55,34 @@ def test_contract_is_a_verifier_for_the_fixture_constraint_system():
         V.Evm(EV.runtime(), V.verify_proof_calldata(pj["proof"][:-64], [0, 0, 0, 0]), {}).run()
 
 
+def test_contract_key_is_a_reference_key_of_this_setup():
+    """the verifying key inside the bytecode belongs to the reference's own setup: k = 6 (n^-1, omega of the 2^6 domain), G2 and -s*G2 of the
+    PUBLIC SRS whose k = 1 file ships in tests/assets (kzg1.srs), and 4 fixed + 17 permutation commitments that are the fixture vk.key's
+    (identity-sigma and constant columns do not depend on the layout); the others differ: another layout of the model"""
+    import os
+    from oracle import mini_evm as V, pairing as E, pyref as pr
+    class Rec(V.Evm):
+        def mstore(self, off, data):
+            if len(data) == 32 and len(self.trace["keccak"]) >= 8:
+                self.trace.setdefault("vk", {})[off] = int.from_bytes(data, "big")
+            super().mstore(off, data)
+    pj = codecs.read_proof_json(open(FX.G + "/proof_k6.json").read())
+    tr = {}
+    with pytest.raises(V.Revert):
+        Rec(EV.runtime(), V.verify_proof_calldata(pj["proof"], [0, 0, 0, 0]), tr).run()
+    vkb = tr["vk"]
+    assert vkb[EV.VK_MPTR] == int.from_bytes(EV.CONTRACT_DIGEST, "big") and vkb[EV.VK_MPTR + 0x20] == 4 and vkb[EV.VK_MPTR + 0x40] == 6
+    assert vkb[EV.VK_MPTR + 0x60] == pow(64, -1, R) and vkb[EV.VK_MPTR + 0x80] == P.omega(6)
+    srs = pr.parse_srs(open(os.path.join(FX.G, "kzg_k1_public.srs"), "rb").read())
+    g2, s_g2 = E.g2_from_bytes(srs["g2"]), E.g2_from_bytes(srs["s_g2"])
+    ns = (s_g2[0], E.f2_neg(s_g2[1]))
+    assert [vkb[EV.G2_MPTR + 32 * i] for i in range(8)] == [g2[0][1], g2[0][0], g2[1][1], g2[1][0], ns[0][1], ns[0][0], ns[1][1], ns[1][0]]
+    vk = codecs.read_vk(open(os.path.join(FX.G, "vk_k6.key"), "rb").read(), 32)
+    pts = [P.point_to_ints(p) or (0, 0) for p in list(vk["fixed_commitments"]) + list(vk["permutation_commitments"])]
+    same = [vkb[EV.COMMS_MPTR + 64 * i] == x and vkb[EV.COMMS_MPTR + 64 * i + 32] == y for i, (x, y) in enumerate(pts)]
+    assert sum(same[:38]) >= 4 and sum(same[38:]) >= 17 and not all(same)
+
+
 def test_challenges_and_lagrange_evaluations(setup):
     s = setup
     dbg = {}
