@@ -97,6 +97,65 @@ __global__ __launch_bounds__(256) void eval_program_kernel(EvalArgs a) {
     }
 }
 
+// ---- instruction scheduling for short live ranges ----
+// A host builds the numerator of h(X) the way halo2's GraphEvaluator does: every constraint term first, then ONE Horner chain over all
+// of them (value = value * y + term).  In that order every term is live until the chain starts -- 99 terms x 8 VGPRs for a 48-gate /
+// 12-lookup ezkl circuit: hiprtc's kernel came out with 256 VGPRs, 1984 bytes of scratch per lane and ONE wave per SIMD.  The order
+// is not part of the program's meaning, so the library re-orders it: demand-driven from the consumers (each Horner step, then the
+// final instruction), an instruction is emitted right before its first consumer.  Dependencies are tracked per intermediate INDEX
+// (read-after-write, write-after-read, write-after-write), so any program a caller hands over keeps its value.
+static std::vector<uint32_t> schedule_program(const ezkl_program_t* p) {
+    const uint32_t n = p->n_instr, ni = p->n_intermediates;
+    auto n_src = [](uint32_t op) { return (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE) ? 1 : 2; };
+    std::vector<std::vector<uint32_t>> deps(n);
+    std::vector<int64_t> last_writer(ni, -1);
+    std::vector<std::vector<uint32_t>> readers(ni);          // readers of the current value of an intermediate
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* I = p->code + 8 * (size_t)i;
+        auto read = [&](uint32_t x) {
+            if (last_writer[x] >= 0) deps[i].push_back((uint32_t)last_writer[x]);
+            readers[x].push_back(i);
+        };
+        for (int q = 0; q < n_src(I[0]); q++)
+            if (I[2 + 3 * q] == EZKL_SRC_INTERMEDIATE && I[3 + 3 * q] < ni) read(I[3 + 3 * q]);
+        const uint32_t t = I[1];
+        if (t >= ni) continue;                                // rejected later by the validation in eval_program
+        if (I[0] == EZKL_OP_HORNER_STEP) read(t);             // updates its target in place
+        for (uint32_t r : readers[t])
+            if (r != i) deps[i].push_back(r);                 // write after read
+        if (last_writer[t] >= 0) deps[i].push_back((uint32_t)last_writer[t]);   // write after write
+        readers[t].clear();
+        last_writer[t] = i;
+    }
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::vector<uint8_t> state(n, 0);                         // 0 new, 1 on the stack, 2 emitted
+    std::vector<std::pair<uint32_t, size_t>> stack;
+    auto visit = [&](uint32_t root) {
+        if (state[root]) return;
+        stack.push_back({root, 0});
+        state[root] = 1;
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            if (top.second < deps[top.first].size()) {
+                const uint32_t d = deps[top.first][top.second++];
+                if (!state[d]) { state[d] = 1; stack.push_back({d, 0}); }
+            } else {
+                order.push_back(top.first);
+                state[top.first] = 2;
+                stack.pop_back();
+            }
+        }
+    };
+    for (uint32_t i = 0; i + 1 < n; i++)
+        if (p->code[8 * (size_t)i] == EZKL_OP_HORNER_STEP) visit(i);
+    for (uint32_t i = 0; i + 1 < n; i++) visit(i);            // whatever no consumer asked for (dead code keeps its place before the result)
+    if (n) visit(n - 1);                                      // the result is the last instruction's target: it stays last
+    std::vector<uint32_t> code(8 * (size_t)n);
+    for (uint32_t j = 0; j < n; j++) memcpy(&code[8 * (size_t)j], p->code + 8 * (size_t)order[j], 32);
+    return code;
+}
+
 // Host-side register allocation: intermediates -> slots by linear scan over the straight-line program.
 // A slot is released after the last read of its value; the EV_NREG lowest slots live in VGPRs, the rest spill
 // to the HBM scratch.  Returns the rewritten code and the number of slots.
@@ -184,11 +243,18 @@ static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
     for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
     return h;
 }
+static int jit_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
 static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_t>& rot) {
     std::string s;
     s.reserve(256 + (size_t)p->n_instr * 96);
     s += "#include \"field.hpp\"\nusing namespace ezkl;\n";
-    s += "extern \"C\" __global__ __launch_bounds__(256) void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
+    const int waves = jit_knob("EZKL_EVALH_WAVES", 3), barrier = jit_knob("EZKL_EVALH_BARRIER", 0);
+    s += "extern \"C\" __global__ __launch_bounds__(256) ";
+    if (waves > 0) s += "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "," + std::to_string(waves) + "))) ";
+    s += "void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
          "    const fe_t* __restrict__ chal, fe_t* __restrict__ out, uint32_t ne_mask, uint32_t T) {\n"
          "  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;\n"
          "  for (uint32_t r = tid; r <= ne_mask; r += T) {\n"
@@ -216,6 +282,7 @@ static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_
             snprintf(lhs, sizeof lhs, "    v%lld = ", (long long)cur_ver[I[1]]);
             s += lhs;
             s += "Fr::add(Fr::mul(v" + std::to_string(cur_ver[I[1]]) + ", " + b + "), " + a + ");\n";
+            if (barrier) s += "    __builtin_amdgcn_sched_barrier(0);\n";
             last = cur_ver[I[1]];
             continue;
         }
@@ -269,6 +336,8 @@ static std::string jit_arch(Ctx* c) {
 static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
     std::string key((const char*)p->code, (size_t)p->n_instr * 32);
     key.append((const char*)rot.data(), rot.size() * 4);
+    const int knobs[2] = {jit_knob("EZKL_EVALH_WAVES", 3), jit_knob("EZKL_EVALH_BARRIER", 0)};      // code-generation options are part of the identity
+    key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
     auto range = g_jit.equal_range(h);
     for (auto it = range.first; it != range.second; ++it) {
@@ -349,9 +418,16 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     return EZKL_OK;
 }
 // offline self-check used by build(): does the JIT source for a program compile for gfx950? (no GPU needed)
-int eval_jit_compile_only(const ezkl_program_t* p) {
+int eval_jit_compile_only(const ezkl_program_t* p0) {
+    ezkl_program_t scheduled = *p0;
+    const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p0->code, p0->code + 8 * (size_t)p0->n_instr) : schedule_program(p0);
+    scheduled.code = sched_code.data();
+    const ezkl_program_t* p = &scheduled;
     std::vector<uint32_t> rot(p->n_rotations ? p->n_rotations : 1, 0);
     std::string src = jit_source(p, rot);
+    if (const char* dump = getenv("EZKL_HIP_JIT_DUMP")) {     // developer aid: the generated source, to look at its register use offline
+        if (FILE* f = fopen(dump, "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
+    }
     const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
     const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
     hiprtcProgram prog;
@@ -380,6 +456,10 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
             if (kind == EZKL_SRC_CHALLENGE && idx >= p->n_challenges) return EZKL_ERR_INVALID;
         }
     }
+    ezkl_program_t scheduled = *p;
+    const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p->code, p->code + 8 * (size_t)p->n_instr) : schedule_program(p);
+    scheduled.code = sched_code.data();
+    p = &scheduled;                                           // from here on: the same program in an order with short live ranges
     std::vector<uint32_t> code;
     const uint32_t n_slots = allocate_slots(p, code);
     if (n_slots == 0xffffffffu) return EZKL_ERR_INVALID;
