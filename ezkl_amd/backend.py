@@ -638,6 +638,13 @@ class GraphProgram:
         _l.check(_l.load().ezkl_hip_eval_h_dev(C.byref(pr), _vp(out_ptr), _stream_ptr(stream)), "ezkl_hip_eval_h_dev")
 
 
+def jit_stats():
+    """(compiled by hiprtc, loaded from the disk cache, found in memory) sweep kernels of this process"""
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _l.check(_l.load().ezkl_hip_eval_h_jit_stats(C.byref(a), C.byref(b), C.byref(c)), "ezkl_hip_eval_h_jit_stats")
+    return int(a.value), int(b.value), int(c.value)
+
+
 def last_kernel_ms(which):
     ms = C.c_float(0)
     _l.check(_l.load().ezkl_hip_last_kernel_ms(which.encode(), C.byref(ms)), "ezkl_hip_last_kernel_ms")

@@ -629,6 +629,19 @@ int ezkl_hip_eval_h_check(const ezkl_program_t* prog) {
     return eval_jit_compile_only(prog);        // host-only: hiprtc cross-compiles for gfx950 without a GPU
 }
 
+int ezkl_hip_eval_h_prepare(const ezkl_program_t* prog) {
+    if (!prog || !prog->code || prog->n_instr == 0) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return eval_prepare(c, prog);
+}
+
+int ezkl_hip_eval_h_jit_stats(uint64_t* compiled, uint64_t* from_disk, uint64_t* memory_hits) {
+    if (!compiled || !from_disk || !memory_hits) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    eval_jit_stats(compiled, from_disk, memory_hits);
+    return EZKL_OK;
+}
+
 int ezkl_hip_last_kernel_ms(const char* which, float* out_ms) {
     if (!which || !out_ms) return EZKL_ERR_INVALID;
     EZ_CTX(c);

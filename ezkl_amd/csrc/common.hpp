@@ -102,6 +102,8 @@ int kate_division(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& z, fe_t* ou
 int chacha20_fr(Ctx* c, hipStream_t st, const uint32_t key[8], uint64_t stream, size_t first, fe_t* out, size_t n);
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
 int eval_jit_compile_only(const ezkl_program_t* p);
+int eval_prepare(Ctx* c, const ezkl_program_t* p);
+void eval_jit_stats(uint64_t* compiled, uint64_t* from_disk, uint64_t* hits);
 int ubench(Ctx* c, const char* which, double* out);
 void msm_table_drop(const Bases* b);
 int msm_table_prepare(Ctx* c, const Bases* b);

@@ -237,6 +237,8 @@ struct JitKernel {
     bool failed = false;      // negative cache: a program that did not compile is not compiled again on every sweep
 };
 static std::multimap<uint64_t, JitKernel> g_jit;    // guarded by the ctx mutex
+static uint64_t g_jit_compiled = 0, g_jit_from_disk = 0, g_jit_hits = 0;
+void eval_jit_stats(uint64_t* compiled, uint64_t* from_disk, uint64_t* hits) { *compiled = g_jit_compiled; *from_disk = g_jit_from_disk; *hits = g_jit_hits; }
 
 static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
     const uint8_t* p = (const uint8_t*)data;
@@ -344,6 +346,7 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
         if (it->second.key != key) continue;       // a 64-bit collision: not this program
         if (it->second.failed) return EZKL_ERR_HIP;
         *fn = it->second.fn;
+        g_jit_hits++;
         return EZKL_OK;
     }
     JitKernel k;
@@ -415,6 +418,7 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     }
     g_jit.emplace(h, k);
     *fn = k.fn;
+    if (from_disk) g_jit_from_disk++; else g_jit_compiled++;
     return EZKL_OK;
 }
 // offline self-check used by build(): does the JIT source for a program compile for gfx950? (no GPU needed)
@@ -436,6 +440,29 @@ int eval_jit_compile_only(const ezkl_program_t* p0) {
     hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
     hiprtcDestroyProgram(&prog);
     return r == HIPRTC_SUCCESS ? EZKL_OK : EZKL_ERR_HIP;
+}
+
+// Compile (or load from the on-disk cache) the kernel of a program WITHOUT running it: a key generator calls this for the circuit's
+// quotient program, so that the first `prove` of a new circuit does not wait for hiprtc (9 s for a 786-instruction ezkl program).
+int eval_prepare(Ctx* c, const ezkl_program_t* p0) {
+    if (p0->ext_k > 28 || p0->k > p0->ext_k || p0->n_instr == 0) return EZKL_ERR_INVALID;
+    for (uint32_t i = 0; i < p0->n_instr; i++) {
+        const uint32_t* I = p0->code + 8 * (size_t)i;
+        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p0->n_intermediates) return EZKL_ERR_INVALID;
+    }
+    ezkl_program_t scheduled = *p0;
+    const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p0->code, p0->code + 8 * (size_t)p0->n_instr) : schedule_program(p0);
+    scheduled.code = sched_code.data();
+    const size_t ne = (size_t)1 << p0->ext_k;
+    std::vector<uint32_t> rot(p0->n_rotations ? p0->n_rotations : 1, 0);
+    const int64_t scale = (int64_t)1 << (p0->ext_k - p0->k);
+    for (uint32_t i = 0; i < p0->n_rotations; i++) {
+        int64_t v = ((int64_t)p0->rotations[i] * scale) % (int64_t)ne;
+        if (v < 0) v += (int64_t)ne;
+        rot[i] = (uint32_t)v;
+    }
+    hipFunction_t fn = nullptr;
+    return jit_get(c, &scheduled, rot, &fn);
 }
 
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {

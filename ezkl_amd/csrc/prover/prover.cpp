@@ -362,6 +362,26 @@ struct Program {
         for (auto& c : cols) ptrs.push_back(c->ptr());
         run_ptrs(ptrs, chal, out);
     }
+    // compile / load the kernel without running it (ezkl_hip_eval_h_prepare): nothing is read through the column pointers
+    void prepare(size_t n_cols, size_t n_chal) const {
+        std::vector<const void*> ptrs(n_cols ? n_cols : 1, nullptr);
+        std::vector<Fe> chal(n_chal ? n_chal : 1, Fe::zero());
+        ezkl_program_t p{};
+        p.code = code.data();
+        p.n_instr = (uint32_t)(code.size() / 8);
+        p.n_intermediates = n_int;
+        p.constants = constants.data();
+        p.n_constants = (uint32_t)constants.size();
+        p.rotations = rotations.data();
+        p.n_rotations = (uint32_t)rotations.size();
+        p.columns = ptrs.data();
+        p.n_columns = (uint32_t)n_cols;
+        p.challenges = chal.data();
+        p.n_challenges = (uint32_t)n_chal;
+        p.k = k;
+        p.ext_k = ext_k;
+        check(ezkl_hip_eval_h_prepare(&p), "ezkl_hip_eval_h_prepare");
+    }
     void run_ptrs(std::vector<const void*> ptrs, const std::vector<Fe>& chal, void* out) const {
         const uint32_t n_cols = (uint32_t)ptrs.size();
         if (ptrs.empty()) ptrs.push_back(nullptr);
@@ -1373,6 +1393,20 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
     prog.horner(prog.previous(), terms, Y);
     return Q;
 }
+// keygen / key loading: have the sweep kernel of this circuit compiled (and on disk) before the first proof asks for it.  The program
+// is a function of the constraint system alone (challenges and columns are run-time operands), so what is built here with placeholder
+// columns has the code bytes create_proof will build.  Best effort: a failure only means the first proof compiles it itself.
+static void prepare_quotient(const ProvingKey& pk) {
+    const ConstraintSystem& cs = *pk.cs;
+    if (cs.shard.on() && cs.shard.gather) return;       // a row-sharded sweep runs per-shard programs
+    try {
+        std::vector<Col> adv(cs.n_advice), zc(cs.n_chunks), mc(cs.lookups.size()), pc(cs.lookups.size()), ic(cs.n_instance);
+        std::vector<Fe> uc(cs.n_challenges, Fe::zero());
+        Quotient Q = quotient_program(cs, pk, adv, zc, Fe::one(), Fe::one(), Fe::one(), Fe::one(), mc, pc, ic, uc);
+        Q.prog.prepare(Q.cols.size(), Q.chal.size());
+    } catch (const Error&) {
+    }
+}
 // the theta-compressed lookup column over the n rows of the Lagrange domain (a gate program with ext_k = k)
 static Col compress_column(const ConstraintSystem& cs, const Backend& be, const std::vector<uint32_t>& tuple, const Fe& theta,
                            const std::function<Col(uint32_t, uint32_t)>& col_handle, const std::vector<Fe>& user_chal) {
@@ -2107,6 +2141,7 @@ int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_va
     return guarded([&] {
         invalid(ezkl_hip_bases_len(g) < (cs->cs->shard.on() ? cs->cs->shard.hi - cs->cs->shard.lo : cs->cs->n), "SRS smaller than 2^k (or than this rank's slice)");
         *out = new ezkl_prover_pk{keygen(*cs->cs, g, fixed_values, copies, n_copies)};
+        prepare_quotient(*(*out)->pk);      // `setup` pays hiprtc for the circuit's sweep kernel (cached on disk): the first `prove` does not
     });
 }
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len) {

@@ -211,6 +211,12 @@ int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out_dev, void* stream)
 /* the sweep is JIT-compiled (hiprtc) into straight-line gfx950 code, once per program; this host-only call
  * checks that a program lowers and compiles (column pointers are not dereferenced; no GPU needed) */
 int ezkl_hip_eval_h_check(const ezkl_program_t* prog);
+/* Compile the program's kernel now (or load it from the on-disk cache: $EZKL_HIP_CACHE_DIR, ~/.cache/ezkl_hip) without running it:
+ * columns / constants / challenges are not read.  A key generator calls it for the circuit's quotient program, so that the first
+ * prove of a new circuit -- in this or a later process -- does not wait for hiprtc (seconds for an ezkl-sized program). */
+int ezkl_hip_eval_h_prepare(const ezkl_program_t* prog);
+/* how this process obtained its sweep kernels so far: compiled by hiprtc, loaded from the on-disk cache, found in memory */
+int ezkl_hip_eval_h_jit_stats(uint64_t* compiled, uint64_t* from_disk, uint64_t* memory_hits);
 
 /* ---- multi-GPU: the collectives of the sharded prove path, RCCL over xGMI on the library's device pointers (csrc/comm.hip) ----
  * One process per GPU (ezkl_hip_init picks the device).  The reference has no multi-GPU path (icicle is single-GPU), so

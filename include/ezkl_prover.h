@@ -124,6 +124,9 @@ int ezkl_prover_vk(ezkl_pk_t pk, void* fixed_commitments, void* permutation_comm
  * reference's protocol (tests/test_evm_verifier.py).  Lost on pk_recommit / re-read (they recompute the default digest). */
 int ezkl_prover_pk_set_transcript_repr(ezkl_pk_t pk, const void* repr);
 
+/* ezkl_prover_keygen also has the sweep kernel of the circuit compiled (ezkl_hip_eval_h_prepare) and stored in the on-disk code-object cache:
+ * `setup` pays hiprtc, the first `prove` -- usually another process -- loads the code object. */
+
 /* ---- create_proof ----
  * advice: n_advice host pointers (2^k x 32 B Montgomery; rows >= usable are overwritten with blinding randomness on the
  *   device copy).  For circuits with second-phase advice pass advice_fn instead (advice may then be NULL): it is called

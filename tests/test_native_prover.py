@@ -350,3 +350,38 @@ def test_native_verifier_agrees_with_the_oracle_verifier(hip, golden_srs):
     bad_lk = [a.copy() for a in adv]; bad_lk[0][3] = P.to_mont(12345)
     with pytest.raises(RuntimeError, match="not in table"):
         N.create_proof(pk, bg, bgl, bad_lk, seed=3)
+
+
+@pytest.mark.gpu
+def test_keygen_prepares_the_sweep_kernel(hip, golden_srs, tmp_path, monkeypatch):
+    """`setup` pays hiprtc: ezkl_prover_keygen compiles the circuit's quotient-sweep kernel and stores the code object in the on-disk cache;
+    create_proof then finds it in memory, and a fresh process (the one-shot `prove`) loads it from disk instead of compiling"""
+    import subprocess, sys, json
+    from ezkl_amd import backend as B
+    monkeypatch.setenv("EZKL_HIP_CACHE_DIR", str(tmp_path))
+    from conftest import GOLDEN
+    NV = N
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 5)
+    c0, d0, h0 = B.jit_stats()
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    c1, d1, h1 = B.jit_stats()
+    assert (c1 - c0) + (d1 - d0) + (h1 - h0) == 1                      # keygen asked for exactly one kernel: the circuit's sweep
+    files = [f for f in os.listdir(tmp_path) if f.startswith("evalh_") and f.endswith(".co")]
+    assert files or (h1 - h0) == 1                                      # on disk now (unless this process already held it in memory)
+    NV.create_proof(pk, g, gl, adv, seed=3)
+    c2, d2, h2 = B.jit_stats()
+    assert c2 == c1 and d2 == d1 and h2 > h1                            # the proof compiled nothing: memory hits only
+    # a fresh process with the same cache directory: nothing compiled there either
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import ezkl_amd; ezkl_amd.init(0)\n"
+            "from ezkl_amd import backend as B, native as NV\nfrom test_plonk import mul_add_circuit, witness\n"
+            "import numpy as np, os\nbuf = open(os.path.join(%r, 'kzg_k6.srs'), 'rb').read()\n"
+            "g = np.frombuffer(buf, np.uint64, count=8 * 64, offset=4).reshape(64, 8).copy()\n"
+            "cs = mul_add_circuit(6); adv, fixed, copies = witness(cs, 5)\n"
+            "pk = NV.NativeProvingKey(NV.NativeCircuit(cs), B.Bases(g), fixed, copies)\nprint(json.dumps(B.jit_stats()))\n"
+            % (ROOT, os.path.join(ROOT, "tests"), GOLDEN))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, EZKL_HIP_CACHE_DIR=str(tmp_path)))
+    assert r.returncode == 0, r.stderr[-1500:]
+    compiled, from_disk, hits = json.loads(r.stdout.strip().splitlines()[-1])
+    if files:
+        assert compiled == 0 and from_disk == 1
