@@ -341,6 +341,7 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     const int knobs[2] = {jit_knob("EZKL_EVALH_WAVES", 3), jit_knob("EZKL_EVALH_BARRIER", 0)};      // code-generation options are part of the identity
     key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
+    if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_hip] sweep kernel %016llx: %u instructions, %u columns, ext_k %u\n", (unsigned long long)h, p->n_instr, p->n_columns, p->ext_k);
     auto range = g_jit.equal_range(h);
     for (auto it = range.first; it != range.second; ++it) {
         if (it->second.key != key) continue;       // a 64-bit collision: not this program

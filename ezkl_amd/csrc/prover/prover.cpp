@@ -1404,7 +1404,8 @@ static void prepare_quotient(const ProvingKey& pk) {
         std::vector<Fe> uc(cs.n_challenges, Fe::zero());
         Quotient Q = quotient_program(cs, pk, adv, zc, Fe::one(), Fe::one(), Fe::one(), Fe::one(), mc, pc, ic, uc);
         Q.prog.prepare(Q.cols.size(), Q.chal.size());
-    } catch (const Error&) {
+    } catch (const Error& e) {
+        if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_prover] sweep kernel not prepared at keygen: %s\n", e.what());
     }
 }
 // the theta-compressed lookup column over the n rows of the Lagrange domain (a gate program with ext_k = k)
