@@ -307,6 +307,15 @@ int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_
     if (!h || !out || (!scalars_dev && n)) return EZKL_ERR_INVALID;
     Bases* b = reinterpret_cast<Bases*>(h);
     if (base_offset + n > b->n) return EZKL_ERR_INVALID;
+    if (!stream && !getenv("EZKL_MSM_SERIAL_CALLS")) {     // on the library stream: concurrent callers overlap (msm_run_concurrent)
+        ::ezkl::RoctxRange _roctx(__func__);
+        Ctx* c = ctx();
+        if (!c) return EZKL_ERR_NO_DEVICE;
+        std::unique_lock<std::recursive_mutex> lk(c->mu);
+        EZ_HIP(hipSetDevice(c->device));
+        if (!msm_upload_is_open()) return msm_run_concurrent(c, lk, b, base_offset, (const fe_t*)scalars_dev, n, out);
+        return msm_run(c, c->stream, b, base_offset, (const fe_t*)scalars_dev, n, out);
+    }
     EZ_CTX(c);
     return msm_run(c, pick_stream(c, stream), b, base_offset, (const fe_t*)scalars_dev, n, out);
 }

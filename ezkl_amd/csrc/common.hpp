@@ -100,6 +100,8 @@ int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_
 int lincomb(Ctx* c, hipStream_t st, const fe_t* const* in, const fe_t* coeffs, uint32_t m, fe_t* out, size_t n, int accumulate);
 int kate_division(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& z, fe_t* out, size_t n);
 int chacha20_fr(Ctx* c, hipStream_t st, const uint32_t key[8], uint64_t stream, size_t first, fe_t* out, size_t n);
+bool msm_upload_is_open();
+int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host);
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
 int eval_jit_compile_only(const ezkl_program_t* p);
 int eval_prepare(Ctx* c, const ezkl_program_t* p);
