@@ -253,7 +253,7 @@ static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_
     std::string s;
     s.reserve(256 + (size_t)p->n_instr * 96);
     s += "#include \"field.hpp\"\nusing namespace ezkl;\n";
-    const int waves = jit_knob("EZKL_EVALH_WAVES", 3), barrier = jit_knob("EZKL_EVALH_BARRIER", 0);
+    const int waves = jit_knob("EZKL_EVALH_WAVES", 4), barrier = jit_knob("EZKL_EVALH_BARRIER", 1);
     s += "extern \"C\" __global__ __launch_bounds__(256) ";
     if (waves > 0) s += "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "," + std::to_string(waves) + "))) ";
     s += "void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
@@ -284,7 +284,8 @@ static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_
             snprintf(lhs, sizeof lhs, "    v%lld = ", (long long)cur_ver[I[1]]);
             s += lhs;
             s += "Fr::add(Fr::mul(v" + std::to_string(cur_ver[I[1]]) + ", " + b + "), " + a + ");\n";
-            if (barrier) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+            if (barrier == 1) s += "    asm volatile(\"\" ::: \"memory\");\n";
+            else if (barrier == 2) s += "    __builtin_amdgcn_sched_barrier(0);\n";
             last = cur_ver[I[1]];
             continue;
         }
@@ -304,6 +305,184 @@ static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_
         }
     }
     s += "    st_fe(out + r, v" + std::to_string(last) + ");\n  }\n}\n";
+    return s;
+}
+// ---- the same program in radix 2^29 (field29.hpp): the product costs 186 issue slots instead of 261 ----
+// Values live in the lazily reduced Montgomery form R' = 2^261 of the MSM kernels.  A column element x*R (canonical, < p) becomes a
+// representative of x*R' by a 5-bit shift while it is unpacked (32 * x*R < 32 p: a valid lazy value, no multiplication), every
+// intermediate carries, at CODE-GENERATION time, a bound alpha (value < alpha * p) and a limb looseness L (limbs < L * 2^29), and the
+// generator inserts a carry propagation or a multiplication by one only where the rules of field29.hpp need it:
+//   add: limb-wise, alpha and L add up (kept <= 160 and <= 6);  sub: a + (K p - b) with the smallest K in {2 .. 128} above b's bound,
+//   b normalized;  mul: L_a * L_b <= 6, alpha_a * alpha_b <= 5000, result < (alpha_a alpha_b / 169 + 1) p, normalized.
+// The result is multiplied by 2^256 (R' -> R), reduced to [0, p) and packed: the bytes written are those of the radix-2^32 kernel.
+struct V29 {
+    std::string expr;      // a variable name, or a load expression
+    int alpha = 32, L = 1;
+    long long var = -1;    // version id when `expr` is a variable (its state lives in the table), -1 for a load
+};
+static std::string jit_source_r29(const ezkl_program_t* p, const std::vector<uint32_t>& rot) {
+    std::string s;
+    s.reserve(1024 + (size_t)p->n_instr * 160);
+    const int waves = jit_knob("EZKL_EVALH_WAVES", 4), barrier = jit_knob("EZKL_EVALH_BARRIER", 1);
+    const std::string MUL = jit_knob("EZKL_EVALH_R29", 2) == 2 ? "Fr29::mul_cold(" : "Fr29::mul(";      // 2: the product as a call (small code)
+    s += "#include \"field29.hpp\"\nusing namespace ezkl;\n"
+         "__device__ __forceinline__ f29_t ld29(const fe_t* q) {\n"
+         "  const fe_t w = ld_fe(q);\n  f29_t r;\n  r.v[0] = (w.v[0] << 5) & M29;\n"
+         "#pragma unroll\n  for (int i = 1; i < 8; i++) {\n"
+         "    const int bit = 29 * i - 5, word = bit >> 5, sh = bit & 31;\n"
+         "    const uint32_t lo = w.v[word], hi = word + 1 < 8 ? w.v[word + 1] : 0u;\n"
+         "    r.v[i] = (sh ? __builtin_amdgcn_alignbit(hi, lo, sh) : lo) & M29;\n  }\n"
+         "  r.v[8] = w.v[7] >> 3;\n  return r;\n}\n";
+    s += "extern \"C\" __global__ __launch_bounds__(256) ";
+    if (waves > 0) s += "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "," + std::to_string(waves) + "))) ";
+    s += "void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
+         "    const fe_t* __restrict__ chal, fe_t* __restrict__ out, uint32_t ne_mask, uint32_t T) {\n"
+         "  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;\n"
+         "  const f29_t c_one = Fr29::one();\n"
+         "  const f29_t c_r256 = Fr29::unpack(Fr::one());\n"        // 2^256 mod p, normalized: R' -> R
+         "  for (uint32_t r = tid; r <= ne_mask; r += T) {\n";
+    auto n_src = [](uint32_t op) { return (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE) ? 1 : 2; };
+    std::vector<int64_t> cur_ver(p->n_intermediates, -1);
+    std::vector<int> A(p->n_instr, 0), Ls(p->n_instr, 0);                 // state of version i (defined by instruction i)
+    auto operand = [&](const uint32_t* I, int q) -> V29 {
+        const uint32_t kind = I[2 + 3 * q], idx = I[3 + 3 * q], ro = I[4 + 3 * q];
+        char b[112];
+        V29 v;
+        switch (kind) {
+        case EZKL_SRC_CONST: snprintf(b, sizeof b, "ld29(consts + %u)", idx); break;
+        case EZKL_SRC_INTERMEDIATE: {
+            const long long ver = cur_ver[idx];
+            snprintf(b, sizeof b, "v%lld", ver);
+            v.var = ver;
+            v.alpha = A[ver];
+            v.L = Ls[ver];
+            break;
+        }
+        case EZKL_SRC_COLUMN: snprintf(b, sizeof b, "ld29(cols[%u] + ((r + %uu) & ne_mask))", idx, rot[ro]); break;
+        case EZKL_SRC_CHALLENGE: snprintf(b, sizeof b, "ld29(chal + %u)", idx); break;
+        default: snprintf(b, sizeof b, "ld29(out + r)"); break;
+        }
+        v.expr = b;
+        return v;
+    };
+    auto normalize = [&](V29& v) {                     // carry propagation: limbs back below 2^29
+        if (v.L == 1) return;
+        s += "    " + v.expr + " = Fr29::normalize(" + v.expr + ");\n";
+        v.L = 1;
+        Ls[v.var] = 1;
+    };
+    auto reduce = [&](V29& v) {                        // a multiplication by one: the bound falls to alpha / 169 + 2
+        if (v.var < 0) return;                         // loads are < 32 p by construction
+        if (v.L > 6) normalize(v);
+        s += "    " + v.expr + " = " + MUL + v.expr + ", c_one);\n";
+        v.alpha = v.alpha / 169 + 2;
+        v.L = 1;
+        A[v.var] = v.alpha;
+        Ls[v.var] = 1;
+    };
+    auto prep_mul = [&](V29& a, V29& b) {
+        while (a.L * b.L > 6) normalize(a.L >= b.L && a.var >= 0 ? a : b);
+        while ((long long)a.alpha * b.alpha > 5000) reduce(a.alpha >= b.alpha && a.var >= 0 ? a : b);
+        return ((long long)a.alpha * b.alpha + 168) / 169 + 1;
+    };
+    auto prep_add = [&](V29& a, V29& b) {
+        while (a.L + b.L > 6) normalize(a.L >= b.L && a.var >= 0 ? a : b);
+        while (a.alpha + b.alpha > 160) reduce(a.alpha >= b.alpha && a.var >= 0 ? a : b);
+    };
+    auto sub_k = [&](V29& a, V29& b, int& ki) {        // a - b + K p
+        normalize(b);
+        if (b.alpha > 127) reduce(b);
+        int K = 2;
+        ki = 0;
+        while (K - 1 < b.alpha) { K <<= 1; ki++; }
+        while (a.L + 2 > 6) normalize(a);
+        while (a.alpha + K > 160 && a.var >= 0 && a.alpha > 3) reduce(a);
+        return K;
+    };
+    long long last = -1;
+    for (uint32_t i = 0; i < p->n_instr; i++) {
+        const uint32_t* I = p->code + 8 * (size_t)i;
+        V29 a = operand(I, 0), b = n_src(I[0]) == 2 ? operand(I, 1) : V29();
+        if (I[0] == EZKL_OP_HORNER_STEP && cur_ver[I[1]] >= 0) {
+            const long long tv = cur_ver[I[1]];
+            V29 t;
+            t.expr = "v" + std::to_string(tv);
+            t.var = tv; t.alpha = A[tv]; t.L = Ls[tv];
+            const long long am = prep_mul(t, b);
+            // the sum acc * factor + term: the product is normalized (L = 1) and below am * p
+            while (1 + a.L > 6) normalize(a);
+            while (am + a.alpha > 160 && a.var >= 0) reduce(a);
+            s += "    " + t.expr + " = Fr29::add(" + MUL + t.expr + ", " + b.expr + "), " + a.expr + ");\n";
+            if (barrier == 1) s += "    asm volatile(\"\" ::: \"memory\");\n";
+            else if (barrier == 2) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+            A[tv] = (int)(am + a.alpha);
+            Ls[tv] = 1 + a.L;
+            last = tv;
+            continue;
+        }
+        cur_ver[I[1]] = i;
+        last = i;
+        const std::string lhs = "    f29_t v" + std::to_string(i) + " = ";
+        switch (I[0]) {
+        case EZKL_OP_ADD:
+            prep_add(a, b);
+            s += lhs + "Fr29::add(" + a.expr + ", " + b.expr + ");\n";
+            A[i] = a.alpha + b.alpha; Ls[i] = a.L + b.L;
+            break;
+        case EZKL_OP_DOUBLE:
+            while (2 * a.L > 6) normalize(a);
+            while (2 * a.alpha > 160) reduce(a);
+            s += lhs + "Fr29::add(" + a.expr + ", " + a.expr + ");\n";
+            A[i] = 2 * a.alpha; Ls[i] = 2 * a.L;
+            break;
+        case EZKL_OP_SUB: {
+            int ki = 0;
+            const int K = sub_k(a, b, ki);
+            s += lhs + "Fr29::sub<" + std::to_string(ki) + ">(" + a.expr + ", " + b.expr + ");\n";
+            A[i] = a.alpha + K; Ls[i] = a.L + 2;
+            break;
+        }
+        case EZKL_OP_NEGATE: {
+            normalize(a);
+            if (a.alpha > 127) reduce(a);
+            int K = 2, ki = 0;
+            while (K - 1 < a.alpha) { K <<= 1; ki++; }
+            s += lhs + "Fr29::neg<" + std::to_string(ki) + ">(" + a.expr + ");\n";
+            A[i] = K; Ls[i] = 2;
+            break;
+        }
+        case EZKL_OP_MUL: {
+            const long long am = prep_mul(a, b);
+            s += lhs + MUL + a.expr + ", " + b.expr + ");\n";
+            A[i] = (int)am; Ls[i] = 1;
+            break;
+        }
+        case EZKL_OP_SQUARE: {
+            while (a.L > 2) normalize(a);
+            while ((long long)a.alpha * a.alpha > 5000) reduce(a);
+            s += lhs + MUL + a.expr + ", " + a.expr + ");\n";
+            A[i] = (int)(((long long)a.alpha * a.alpha + 168) / 169 + 1); Ls[i] = 1;
+            break;
+        }
+        case EZKL_OP_STORE:
+            s += lhs + a.expr + ";\n";
+            A[i] = a.alpha; Ls[i] = a.L;
+            break;
+        default:                                       // Horner on an unwritten target: 0 * factor + term
+            s += lhs + a.expr + ";\n";
+            A[i] = a.alpha; Ls[i] = a.L;
+            break;
+        }
+    }
+    // R' -> R and canonical form: v * 2^256 / 2^261 < (alpha / 169 + 1) p <= 2 p, one conditional subtraction, pack
+    {
+        V29 v;
+        v.expr = "v" + std::to_string(last);
+        v.var = last; v.alpha = A[last]; v.L = Ls[last];
+        while (v.L > 6) normalize(v);
+        while (v.alpha > 169) reduce(v);
+        s += "    st_fe(out + r, Fr29::pack(Fr29::cond_sub<0>(" + MUL + v.expr + ", c_r256))));\n  }\n}\n";
+    }
     return s;
 }
 // Compiled code objects are also kept on disk, keyed by a hash of (program, rotations, architecture, library build): the gate program
@@ -338,7 +517,7 @@ static std::string jit_arch(Ctx* c) {
 static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
     std::string key((const char*)p->code, (size_t)p->n_instr * 32);
     key.append((const char*)rot.data(), rot.size() * 4);
-    const int knobs[2] = {jit_knob("EZKL_EVALH_WAVES", 3), jit_knob("EZKL_EVALH_BARRIER", 0)};      // code-generation options are part of the identity
+    const int knobs[3] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2)};      // code-generation options are part of the identity
     key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
     if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_hip] sweep kernel %016llx: %u instructions, %u columns, ext_k %u\n", (unsigned long long)h, p->n_instr, p->n_columns, p->ext_k);
@@ -375,11 +554,11 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
         }
     }
     if (!from_disk) {
-        std::string src = jit_source(p, rot);
-        const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
-        const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
+        std::string src = jit_knob("EZKL_EVALH_R29", 2) ? jit_source_r29(p, rot) : jit_source(p, rot);
+        const char* hn[5] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp", "field29.hpp", "montmul29_gen.hpp"};
+        const char* hs[5] = {k_src_field, k_src_constants, k_src_montmul, k_src_field29, k_src_montmul29};
         hiprtcProgram prog;
-        if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 3, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
+        if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 5, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
         const std::string archopt = "--offload-arch=" + arch;
         const char* opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
         hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
@@ -429,14 +608,14 @@ int eval_jit_compile_only(const ezkl_program_t* p0) {
     scheduled.code = sched_code.data();
     const ezkl_program_t* p = &scheduled;
     std::vector<uint32_t> rot(p->n_rotations ? p->n_rotations : 1, 0);
-    std::string src = jit_source(p, rot);
+    std::string src = jit_knob("EZKL_EVALH_R29", 2) ? jit_source_r29(p, rot) : jit_source(p, rot);
     if (const char* dump = getenv("EZKL_HIP_JIT_DUMP")) {     // developer aid: the generated source, to look at its register use offline
         if (FILE* f = fopen(dump, "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
     }
-    const char* hn[3] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp"};
-    const char* hs[3] = {k_src_field, k_src_constants, k_src_montmul};
+    const char* hn[5] = {"field.hpp", "bn254_constants.h", "montmul_gen.hpp", "field29.hpp", "montmul29_gen.hpp"};
+    const char* hs[5] = {k_src_field, k_src_constants, k_src_montmul, k_src_field29, k_src_montmul29};
     hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 3, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "evalh_jit.hip", 5, hs, hn) != HIPRTC_SUCCESS) return EZKL_ERR_HIP;
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
     hiprtcDestroyProgram(&prog);
@@ -492,7 +671,9 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     const uint32_t n_slots = allocate_slots(p, code);
     if (n_slots == 0xffffffffu) return EZKL_ERR_INVALID;
     const uint32_t n_spill = n_slots > EV_NREG ? n_slots - EV_NREG : 0;
-    size_t T = (size_t)c->num_cus * 256 * 4;
+    // resident lanes: one workgroup of 4 waves per SIMD-wave the kernel is compiled for (EZKL_EVALH_WAVES), so that the grid can
+    // actually fill the occupancy the code generator asked for; rows beyond that are walked by the kernel's loop
+    size_t T = (size_t)c->num_cus * 256 * (size_t)jit_knob("EZKL_EVALH_TMUL", 16);
     if (T > ne) T = ne;
     std::vector<uint32_t> rot(p->n_rotations ? p->n_rotations : 1, 0);
     const int64_t scale = (int64_t)1 << (p->ext_k - p->k);

@@ -85,13 +85,13 @@ def consts(tag, mod):
     # subtraction constants: K*p with 2^29 lent from every limb to the one below, so that C[i] - b[i] >= 0 limb-wise for any
     # normalized b < (K-1)*p
     rows = []
-    for K in (2, 4, 8, 16, 32):
+    for K in (2, 4, 8, 16, 32, 64, 128):
         k = limbs29(K * mod)
         c = [k[0] + (1 << 29)] + [k[i] + (1 << 29) - 1 for i in range(1, 8)] + [k[8] - 1]
         assert sum(ci << (29 * i) for i, ci in enumerate(c)) == K * mod and all(0 < ci < (1 << 31) for ci in c)
         assert c[8] >= ((K - 1) * mod) >> 232
         rows.append("        %s,   // %d p" % (arr(c), K))
-    o.append("    static constexpr uint32_t SUBC[5][9] = {\n" + "\n".join(rows) + "\n    };")
+    o.append("    static constexpr uint32_t SUBC[7][9] = {\n" + "\n".join(rows) + "\n    };")
     # conditional subtraction of K*p (K = 1, 2, 4, 8): x + (2^261 - K p) carries into bit 261 exactly when x >= K p
     rows = []
     for K in (1, 2, 4, 8):
@@ -106,7 +106,7 @@ def consts(tag, mod):
     return "\n".join(o) + "\n"
 
 
-hdr = "// GENERATED by tools/gen_montmul29.py -- do not edit\n#pragma once\n#include <stdint.h>\nnamespace ezkl {\n"
+hdr = "// GENERATED by tools/gen_montmul29.py -- do not edit\n#pragma once\n#ifndef __HIPCC_RTC__            // hiprtc (the eval_h JIT) supplies the fixed-width types itself\n#include <stdint.h>\n#endif\nnamespace ezkl {\n"
 text = hdr + consts("Fq", FQ) + consts("Fr", FR) + gen("mont_mul29_fq", FQ) + gen("mont_mul29_fr", FR) + gen("mont_sqr29_fq", FQ, True) + gen("mont_sqr29_fr", FR, True) + "}  // namespace ezkl\n"
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ezkl_amd", "csrc", "montmul29_gen.hpp")
 open(path, "w").write(text)
