@@ -495,9 +495,11 @@ class LayoutCircuit:
     """what every circuit built on BaseRegion shares: the keygen pass (selector activations, fixed columns, copy constraints)
     and the witness pass; subclasses give `synthesize(x, witness) -> region` and set self.outputs"""
 
-    def keygen_inputs(self, x):
-        """-> (plonk.ConstraintSystem, fixed columns (lists of ints), copies over cs.perm positions, region)"""
-        reg = self.synthesize(x, witness=False)
+    def keygen_inputs(self, x, with_witness=False):
+        """-> (plonk.ConstraintSystem, fixed columns (lists of ints), copies over cs.perm positions, region); with_witness: ONE synthesis
+        pass that also fills the advice columns (region.advice; `witness_of(region)` returns them) -- halo2 runs keygen and proving as
+        separate passes, a benchmark that needs both can share one"""
+        reg = self.synthesize(x, witness=with_witness)
         n = 1 << self.k
         cs0 = self.gc.cs
         sel_cols = cs0.compress_selectors(reg.selector_rows(dense=False))
@@ -513,7 +515,9 @@ class LayoutCircuit:
 
     def witness(self, x):
         """advice columns (lists of ints) and the instance column"""
-        reg = self.synthesize(x, witness=True)
+        return self.witness_of(self.synthesize(x, witness=True))
+
+    def witness_of(self, reg):
         n = 1 << self.k
         adv = [reg.advice.get(c.index) or [0] * n for c in self.gc.cs.advice]
         return adv, [self.outputs]

@@ -56,16 +56,16 @@ def build(kind, k, gpu=None, seed=1, **kw):
         bs = [rng.integers(-20, 20, N).tolist() for _ in range(layers)]
         x = rng.integers(-60, 60, N).tolist()
         c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2)
-        cs, fixed, copies, reg = c.keygen_inputs(x)
-        adv, inst = c.witness(x)
+        cs, fixed, copies, reg = c.keygen_inputs(x, with_witness=True)      # one synthesis pass for the key and the witness
+        adv, inst = c.witness_of(reg)
         info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),
                     cells_used=reg.linear, blocks=c.gc.advices[0].num_blocks(), range_checks=[list(r) for r in c.settings.required_range_checks])
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
     if kind == "conv":
         c = EL.ConvMnistCircuit(logrows=k, seed=seed)
         img = rng.integers(0, 16, (28, 28))                     # MNIST pixels / 16 (examples/conv2d_mnist/main.rs:326-329)
-        cs, fixed, copies, reg = c.keygen_inputs(img)
-        adv, inst = c.witness(img)
+        cs, fixed, copies, reg = c.keygen_inputs(img, with_witness=True)
+        adv, inst = c.witness_of(reg)
         info = dict(circuit="examples/conv2d_mnist: Conv 1->4 5x5 stride 2 on 28x28 + ReLU + Div{32} lookup (65 537-row table) + Linear 576->10, "
                             "3 advice columns, k=%d (synthetic image and parameters of the example's shapes)" % k, cells_used=reg.linear)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
