@@ -23,6 +23,7 @@ import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # the library's default (csrc/capi.hip ctx_init); torch initialises HIP first in this process
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+T_PROCESS_START = time.time()
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -252,6 +253,7 @@ def prove_leg():
         cores (C oracle kernels, OpenMP) with identical proof bytes;
       * `mlp`: an MLP over the ezkl gate set (range-check lookups, permutation over ~20 columns) at k = 17 (BASELINE configs[2]'s size),
         GPU and CPU;
+      * `mlp_k20`: the north star's "k = 20 MLP circuit" (9 x Gemm 665 x 665 + bias + ReLU over the ezkl gate set), GPU and CPU;
       * `conv2d_mnist`: BASELINE configs[2] itself, examples/conv2d_mnist/main.rs's Config and layout at k = 17, GPU and CPU."""
     import subprocess
     tool = os.path.join(ROOT, "tools", "prove_bench.py")
@@ -282,6 +284,19 @@ def prove_leg():
                       "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "breakdown_seconds": j["prove_breakdown_seconds"]}
     except Exception as e:
         out["mlp"] = {"error": repr(e)[:300]}
+    try:
+        # the north star's own end-to-end configuration: a k = 20 MLP circuit, the CPU prover timed beside it in the same run.  The Python
+        # layout of its 4.1 M cells takes ~40 s and the CPU prover ~55 s (keygen + proof): EZKL_BENCH_MLP20=0 skips the leg,
+        # EZKL_BENCH_MLP20_CPU=0 (or a bench that has already run for three minutes) leaves the CPU side out
+        if os.environ.get("EZKL_BENCH_MLP20", "1") != "0":
+            with_cpu = os.environ.get("EZKL_BENCH_MLP20_CPU", "1") != "0" and time.time() - T_PROCESS_START < 180
+            j = child({"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned"] + (["--cpu"] if with_cpu else []), 900)
+            out["mlp_k20"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
+                              "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
+                              "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"],
+                              "breakdown_seconds": j["prove_breakdown_seconds"], "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds")}
+    except Exception as e:
+        out["mlp_k20"] = {"error": repr(e)[:300]}
     try:                                               # BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17
         j = child({"CIRCUIT": "conv", "K": "17"}, ["--cpu", "--pinned"], 900)
         out["conv2d_mnist"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
