@@ -313,10 +313,20 @@ def prove_leg_multi(world, rank, local_rank, args):
     (point ranges when it has fewer columns than ranks) and folded with one all_gather of 64-byte partials, the quotient sweep is divided
     by rows and h all_gathered in place, through the library's own RCCL communicator (csrc/comm.hip).  Every rank emits the same proof
     bytes; rank 0 verifies them.  Runs in child processes (EZKL_BENCH_MULTI_CIRCUIT=mlp / synthetic selects another circuit)."""
-    import subprocess
     circuit = os.environ.get("EZKL_BENCH_MULTI_CIRCUIT", "einsum")
-    env = dict(os.environ, K=os.environ.get("EZKL_BENCH_MULTI_K", "20"), BLOCKS="4", CIRCUIT=circuit, REPS="3", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 1), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(local_rank))
+    out = _prove_multi_one(world, rank, local_rank, args, circuit, os.environ.get("EZKL_BENCH_MULTI_K", "20"), 1)
+    # ... and the north star's k = 20 MLP circuit the same way (every rank lays the circuit out itself: ~40 s of Python)
+    if circuit == "einsum" and os.environ.get("EZKL_BENCH_MULTI_MLP20", "1") != "0":
+        m = _prove_multi_one(world, rank, local_rank, args, "mlp", "20", 2)
+        if rank == 0 and out is not None:
+            out["mlp_k20"] = m
+    return out
+
+
+def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
+    import subprocess
+    env = dict(os.environ, K=k, BLOCKS="4", CIRCUIT=circuit, REPS="3", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(local_rank))
     for k_ in list(env):                       # the children rendezvous on their own: no torchrun agent store behind the new port
         if k_.startswith("TORCHELASTIC_") or k_ in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
                                                       "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
@@ -327,7 +337,7 @@ def prove_leg_multi(world, rank, local_rank, args):
     if args.share_device:
         cmd.append("--share-device")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300")))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300" if circuit != "mlp" else "600")))
         if rank != 0:
             return None
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -394,7 +394,7 @@ def test_bench_contract_two_ranks(hip):
     contract's keys, the whole-job value, and the sharded end-to-end prove leg accepted by the verifier"""
     import json, os, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="200")
+    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="200", EZKL_BENCH_MULTI_MLP20="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--backend", "gloo", "--share-device"], env=env, capture_output=True, text=True, timeout=900)
