@@ -253,12 +253,13 @@ static std::string jit_source(const ezkl_program_t* p, const std::vector<uint32_
     std::string s;
     s.reserve(256 + (size_t)p->n_instr * 96);
     s += "#include \"field.hpp\"\nusing namespace ezkl;\n";
+    s += std::string("#define XCD_MAP ") + (jit_knob("EZKL_EVALH_XCD", 0) ? "1" : "0") + "\n";     // workgroups of one XCD walk adjacent rows
     const int waves = jit_knob("EZKL_EVALH_WAVES", 4), barrier = jit_knob("EZKL_EVALH_BARRIER", 1);
     s += "extern \"C\" __global__ __launch_bounds__(256) ";
     if (waves > 0) s += "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "," + std::to_string(waves) + "))) ";
     s += "void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
          "    const fe_t* __restrict__ chal, fe_t* __restrict__ out, uint32_t ne_mask, uint32_t T) {\n"
-         "  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;\n"
+         "  const uint32_t tid = (XCD_MAP && gridDim.x % 8 == 0 ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x) * blockDim.x + threadIdx.x;\n"
          "  for (uint32_t r = tid; r <= ne_mask; r += T) {\n"
          "    const fe_t prev = ld_fe(out + r);\n";
     auto n_src = [](uint32_t op) { return (op == EZKL_OP_SQUARE || op == EZKL_OP_DOUBLE || op == EZKL_OP_NEGATE || op == EZKL_OP_STORE) ? 1 : 2; };
@@ -325,6 +326,7 @@ static std::string jit_source_r29(const ezkl_program_t* p, const std::vector<uin
     s.reserve(1024 + (size_t)p->n_instr * 160);
     const int waves = jit_knob("EZKL_EVALH_WAVES", 4), barrier = jit_knob("EZKL_EVALH_BARRIER", 1);
     const std::string MUL = jit_knob("EZKL_EVALH_R29", 2) == 2 ? "Fr29::mul_cold(" : "Fr29::mul(";      // 2: the product as a call (small code)
+    s += std::string("#define XCD_MAP ") + (jit_knob("EZKL_EVALH_XCD", 0) ? "1" : "0") + "\n";
     s += "#include \"field29.hpp\"\nusing namespace ezkl;\n"
          "__device__ __forceinline__ f29_t ld29(const fe_t* q) {\n"
          "  const fe_t w = ld_fe(q);\n  f29_t r;\n  r.v[0] = (w.v[0] << 5) & M29;\n"
@@ -337,7 +339,7 @@ static std::string jit_source_r29(const ezkl_program_t* p, const std::vector<uin
     if (waves > 0) s += "__attribute__((amdgpu_waves_per_eu(" + std::to_string(waves) + "," + std::to_string(waves) + "))) ";
     s += "void evalh_jit(const fe_t* const* __restrict__ cols, const fe_t* __restrict__ consts,\n"
          "    const fe_t* __restrict__ chal, fe_t* __restrict__ out, uint32_t ne_mask, uint32_t T) {\n"
-         "  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;\n"
+         "  const uint32_t tid = (XCD_MAP && gridDim.x % 8 == 0 ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x) * blockDim.x + threadIdx.x;\n"
          "  const f29_t c_one = Fr29::one();\n"
          "  const f29_t c_r256 = Fr29::unpack(Fr::one());\n"        // 2^256 mod p, normalized: R' -> R
          "  for (uint32_t r = tid; r <= ne_mask; r += T) {\n";
@@ -517,7 +519,7 @@ static std::string jit_arch(Ctx* c) {
 static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
     std::string key((const char*)p->code, (size_t)p->n_instr * 32);
     key.append((const char*)rot.data(), rot.size() * 4);
-    const int knobs[3] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2)};      // code-generation options are part of the identity
+    const int knobs[4] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2), jit_knob("EZKL_EVALH_XCD", 0)};      // code-generation options are part of the identity
     key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
     if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_hip] sweep kernel %016llx: %u instructions, %u columns, ext_k %u\n", (unsigned long long)h, p->n_instr, p->n_columns, p->ext_k);
