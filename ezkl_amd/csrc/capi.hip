@@ -92,9 +92,11 @@ int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1) {
     return EZKL_OK;
 }
 
-// calls made on the library stream are synchronous; calls on a caller stream are stream-ordered
+// calls made on the library stream are synchronous (unless ezkl_hip_set_async(1): then they are ordered on that one stream and the
+// caller synchronises where it needs to -- every entry point that returns host data or borrows host memory still does by itself);
+// calls on a caller stream are stream-ordered
 static int finish(Ctx* c, hipStream_t st, void* user_stream) {
-    if (!user_stream) EZ_HIP(hipStreamSynchronize(st));
+    if (!user_stream && !c->async_library_stream) EZ_HIP(hipStreamSynchronize(st));
     return EZKL_OK;
 }
 
@@ -118,6 +120,21 @@ int ezkl_hip_synchronize(void) {
     return EZKL_OK;
 }
 
+int ezkl_hip_set_async(int on, int* previous) {
+    EZ_CTX(c);
+    if (previous) *previous = c->async_library_stream ? 1 : 0;
+    if (!on && c->async_library_stream) EZ_HIP(hipStreamSynchronize(c->stream));     // leaving the mode: everything queued has run
+    c->async_library_stream = on != 0;
+    return EZKL_OK;
+}
+int ezkl_hip_stream_wait_library(void* stream) {
+    if (!stream) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (!c->order_event) EZ_HIP(hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming));
+    EZ_HIP(hipEventRecord(c->order_event, c->stream));
+    EZ_HIP(hipStreamWaitEvent((hipStream_t)stream, c->order_event, 0));
+    return EZKL_OK;
+}
 int ezkl_hip_warmup(void) {
     EZ_CTX(c);
     // touch the stream + allocator once, as icicle's warmup(stream) does (src/execute.rs:89)

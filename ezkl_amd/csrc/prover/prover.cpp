@@ -474,6 +474,10 @@ struct Backend {
         Forms f = pre ? *pre : forms_alloc(ext_k);
         aux_keep.insert(aux_keep.end(), {lagrange, f.poly, f.coset});
         void* st = aux_stream();
+        // the column was finished by calls on the library stream, which create_proof runs asynchronously (ezkl_hip_set_async): the
+        // auxiliary stream starts behind everything queued there so far -- which also covers any earlier reader of the recycled
+        // blocks the forms were just allocated from
+        check(ezkl_hip_stream_wait_library(st), "ezkl_hip_stream_wait_library");
         const Fe winv = omega(k).inv();
         check(ezkl_hip_vec_scale_dev(lagrange->ptr(), one.v.data(), f.poly->ptr(), n, st), "ezkl_hip_vec_scale_dev");
         check(ezkl_hip_ntt_dev(f.poly->ptr(), k, winv.v.data(), 1, 1, n, st), "ezkl_hip_ntt_dev");
@@ -1454,6 +1458,19 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
                                          const void* const* instances, const uint32_t* instance_lens, Rng& rng, double* timings) {
     ConstraintSystem& cs = *pk.cs;
     const uint32_t n = cs.n, k = cs.k, u = cs.usable;
+    // the helper chains of a proof are hundreds of small device-only calls: queued on the library stream without a host round trip
+    // each (ezkl_hip_set_async); every call that returns host data still synchronises by itself.  EZKL_PROVER_SYNC_CALLS=1: off.
+    struct AsyncCalls {
+        int prev = 0;
+        bool on = false;
+        AsyncCalls() {
+            if (getenv("EZKL_PROVER_SYNC_CALLS")) return;
+            on = ezkl_hip_set_async(1, &prev) == EZKL_OK;
+        }
+        ~AsyncCalls() {
+            if (on) (void)ezkl_hip_set_async(prev, nullptr);
+        }
+    } async_calls;
     Backend be(k, n, g, gl, cs.shard);
     Stopwatch sw(timings);
     EvmTranscript T;

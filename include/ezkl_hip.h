@@ -45,6 +45,15 @@ int ezkl_hip_synchronize(void);
 int ezkl_hip_stream_create(void** out_stream);
 int ezkl_hip_stream_synchronize(void* stream);
 int ezkl_hip_stream_destroy(void* stream);
+/* Asynchronous library stream.  By default a call with stream == NULL returns when its work is done.  A host that issues hundreds of
+ * small device-only calls per proof (vec ops, scans, NTTs, inversions: the lookup / permutation helper chains) pays a host round trip
+ * for each; ezkl_hip_set_async(1, &prev) makes those calls return as soon as they are queued on the library stream -- still in order
+ * with each other.  Entry points that return host data (MSMs, eval_poly*, lookup_multiplicity, memcpy_d2h) or borrow host memory
+ * (memcpy_h2d, eval_h_dev, divide_by_vanishing) keep synchronising by themselves.  ezkl_hip_set_async(0, ..) drains the stream.
+ * ezkl_hip_stream_wait_library(s): work queued on the caller stream s from now on waits for everything queued on the library
+ * stream so far (a column produced by library-stream calls, consumed on s). */
+int ezkl_hip_set_async(int on, int* previous);
+int ezkl_hip_stream_wait_library(void* stream);
 const char* ezkl_hip_strerror(int code);
 int ezkl_hip_last_hip_error(void);
 const char* ezkl_hip_version(void);
