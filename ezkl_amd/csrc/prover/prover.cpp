@@ -722,12 +722,12 @@ struct Backend {
         std::vector<Col> out;
         if (!total) return out;
         Col big = alloc(total * n);
-        Program shift(k, k);
-        shift.add(shift.column(0), shift.challenge(0));
-        size_t slot = 0;
+        fill(big->ptr(), beta, total * n);                 // (column + beta) for every column: one fill, one addition each -- no program,
+        size_t slot = 0;                                   // no host round trip per column
         for (size_t i = 0; i < tables.size(); i++) {
-            for (auto& in : inputs[i]) shift.run({in}, {beta}, at(big, (slot++) * n));
-            shift.run({tables[i]}, {beta}, at(big, (slot++) * n));
+            for (auto& in : inputs[i]) { void* d = at(big, (slot++) * n); vec(EZKL_VEC_ADD, in->ptr(), d, d, n); }
+            void* d = at(big, (slot++) * n);
+            vec(EZKL_VEC_ADD, tables[i]->ptr(), d, d, n);
         }
         invert(big->ptr(), total * n);
         slot = 0;
@@ -1430,7 +1430,8 @@ static Col compress_column(const ConstraintSystem& cs, const Backend& be, const 
                  [&](uint32_t idx) { return prog.challenge(1 + idx); },
                  {}};
     Src r = low.compress(tuple, prog.challenge(0));
-    if (r.kind != EZKL_SRC_INTERMEDIATE) prog.calc(EZKL_OP_STORE, r);        // a bare column / constant: materialise it
+    if (r.kind == EZKL_SRC_COLUMN && prog.rotations[r.rot] == 0) return cols[r.idx];   // a bare column (a lookup table): it IS its compression, read-only below
+    if (r.kind != EZKL_SRC_INTERMEDIATE) prog.calc(EZKL_OP_STORE, r);        // a rotated column / constant: materialise it
     Col out = be.zeros(cs.n);
     std::vector<Fe> chal = {theta};
     chal.insert(chal.end(), user_chal.begin(), user_chal.end());
