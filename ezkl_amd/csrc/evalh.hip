@@ -605,10 +605,18 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
 }
 // offline self-check used by build(): does the JIT source for a program compile for gfx950? (no GPU needed)
 int eval_jit_compile_only(const ezkl_program_t* p0) {
+    for (uint32_t i = 0; i < p0->n_instr; i++) {
+        const uint32_t* I = p0->code + 8 * (size_t)i;
+        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p0->n_intermediates) return EZKL_ERR_INVALID;
+    }
     ezkl_program_t scheduled = *p0;
     const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p0->code, p0->code + 8 * (size_t)p0->n_instr) : schedule_program(p0);
     scheduled.code = sched_code.data();
     const ezkl_program_t* p = &scheduled;
+    {
+        std::vector<uint32_t> tmp;
+        if (allocate_slots(p, tmp) == 0xffffffffu) return EZKL_ERR_INVALID;
+    }
     std::vector<uint32_t> rot(p->n_rotations ? p->n_rotations : 1, 0);
     std::string src = jit_knob("EZKL_EVALH_R29", 2) ? jit_source_r29(p, rot) : jit_source(p, rot);
     if (const char* dump = getenv("EZKL_HIP_JIT_DUMP")) {     // developer aid: the generated source, to look at its register use offline
@@ -635,6 +643,10 @@ int eval_prepare(Ctx* c, const ezkl_program_t* p0) {
     ezkl_program_t scheduled = *p0;
     const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p0->code, p0->code + 8 * (size_t)p0->n_instr) : schedule_program(p0);
     scheduled.code = sched_code.data();
+    {
+        std::vector<uint32_t> tmp;                      // rejects reads of intermediates no instruction has written (the generators index by version)
+        if (allocate_slots(&scheduled, tmp) == 0xffffffffu) return EZKL_ERR_INVALID;
+    }
     const size_t ne = (size_t)1 << p0->ext_k;
     std::vector<uint32_t> rot(p0->n_rotations ? p0->n_rotations : 1, 0);
     const int64_t scale = (int64_t)1 << (p0->ext_k - p0->k);

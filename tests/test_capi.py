@@ -90,3 +90,22 @@ def test_eval_h_program_jit_compiles_offline():
     h = prog.calc("negate", prog.calc("double", prog.calc("square", prog.calc("add", g, prog.constant(fe_from_int(5))))))
     prog.horner(prog.previous(), [g, h], prog.challenge(0))
     prog.check_compiles(4)
+
+
+def test_eval_h_check_refuses_malformed_programs():
+    """host-only: a program that reads an intermediate no instruction has written, or names an unknown opcode, is refused by the
+    code generators' front door (the radix-2^29 generator indexes its bound table by value version)"""
+    import numpy as np
+    from ezkl_amd import backend as B, lib as L
+    prog = B.GraphProgram(4, 6)
+    prog.constant(np.zeros(4, np.uint64))
+    prog.code.append([B.OPS["add"], 0, B.INTERMEDIATE, 3, 0, B.CONST, 0, 0])
+    prog.n_intermediates = 4
+    with pytest.raises(L.EzklHipError):
+        prog.check_compiles(1)
+    bad = B.GraphProgram(4, 6)
+    bad.constant(np.zeros(4, np.uint64))
+    bad.code.append([99, 0, B.CONST, 0, 0, B.CONST, 0, 0])
+    bad.n_intermediates = 1
+    with pytest.raises(L.EzklHipError):
+        bad.check_compiles(1)
