@@ -628,6 +628,17 @@ class GraphProgram:
                    C.cast(cols, _vp), n_columns, _p(ch), 1, self.k, self.ext_k)
         _l.check(_l.load().ezkl_hip_eval_h_check(C.byref(pr)), "ezkl_hip_eval_h_check")
 
+    def scheduled_code(self, n_columns):
+        """host-only: the instruction order the library executes this program in (ezkl_hip_eval_h_schedule)"""
+        code, consts, rots = self.arrays()
+        cols = (C.c_void_p * max(1, n_columns))()
+        ch = np.zeros((1, 4), np.uint64)
+        pr = _Prog(_p(code), code.shape[0], self.n_intermediates, _p(consts), consts.shape[0], _p(rots), rots.shape[0],
+                   C.cast(cols, _vp), n_columns, _p(ch), 1, self.k, self.ext_k)
+        out = np.zeros_like(code)
+        _l.check(_l.load().ezkl_hip_eval_h_schedule(C.byref(pr), out.ctypes.data_as(C.c_void_p)), "ezkl_hip_eval_h_schedule")
+        return out
+
     def evaluate_h(self, column_ptrs, challenges, out_ptr, stream=None):
         """Run on device-resident columns (list of device pointers); out_ptr holds PreviousValue on entry."""
         code, consts, rots = self.arrays()

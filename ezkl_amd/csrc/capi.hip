@@ -655,6 +655,10 @@ int ezkl_hip_eval_h_check(const ezkl_program_t* prog) {
     return eval_jit_compile_only(prog);        // host-only: hiprtc cross-compiles for gfx950 without a GPU
 }
 
+int ezkl_hip_eval_h_schedule(const ezkl_program_t* prog, uint32_t* out_code) {
+    if (!prog || !prog->code || !out_code || prog->n_instr == 0) return EZKL_ERR_INVALID;
+    return eval_schedule_only(prog, out_code);       // host-only: no device needed
+}
 int ezkl_hip_eval_h_prepare(const ezkl_program_t* prog) {
     if (!prog || !prog->code || prog->n_instr == 0) return EZKL_ERR_INVALID;
     EZ_CTX(c);

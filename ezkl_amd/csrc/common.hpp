@@ -107,6 +107,7 @@ int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
 int eval_jit_compile_only(const ezkl_program_t* p);
 int eval_prepare(Ctx* c, const ezkl_program_t* p);
+int eval_schedule_only(const ezkl_program_t* p, uint32_t* out_code);
 void eval_jit_stats(uint64_t* compiled, uint64_t* from_disk, uint64_t* hits);
 int ubench(Ctx* c, const char* which, double* out);
 void msm_table_drop(const Bases* b);

@@ -632,6 +632,17 @@ int eval_jit_compile_only(const ezkl_program_t* p0) {
     return r == HIPRTC_SUCCESS ? EZKL_OK : EZKL_ERR_HIP;
 }
 
+// host-only: the order the library will execute a program in (schedule_program), for callers and tests that want to look at it
+int eval_schedule_only(const ezkl_program_t* p, uint32_t* out_code) {
+    for (uint32_t i = 0; i < p->n_instr; i++) {
+        const uint32_t* I = p->code + 8 * (size_t)i;
+        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p->n_intermediates) return EZKL_ERR_INVALID;
+    }
+    const std::vector<uint32_t> code = schedule_program(p);
+    memcpy(out_code, code.data(), code.size() * 4);
+    return EZKL_OK;
+}
+
 // Compile (or load from the on-disk cache) the kernel of a program WITHOUT running it: a key generator calls this for the circuit's
 // quotient program, so that the first `prove` of a new circuit does not wait for hiprtc (9 s for a 786-instruction ezkl program).
 int eval_prepare(Ctx* c, const ezkl_program_t* p0) {

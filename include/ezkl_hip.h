@@ -220,6 +220,10 @@ int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out_dev, void* stream)
 /* the sweep is JIT-compiled (hiprtc) into straight-line gfx950 code, once per program; this host-only call
  * checks that a program lowers and compiles (column pointers are not dereferenced; no GPU needed) */
 int ezkl_hip_eval_h_check(const ezkl_program_t* prog);
+/* host-only: the instruction order the sweep will execute (the library re-orders a program for short live ranges: every term is
+ * computed right before the Horner step that consumes it; dependencies per intermediate are kept, so the value is the program's);
+ * out_code receives n_instr x 8 words in the layout of prog->code */
+int ezkl_hip_eval_h_schedule(const ezkl_program_t* prog, uint32_t* out_code);
 /* Compile the program's kernel now (or load it from the on-disk cache: $EZKL_HIP_CACHE_DIR, ~/.cache/ezkl_hip) without running it:
  * columns / constants / challenges are not read.  A key generator calls it for the circuit's quotient program, so that the first
  * prove of a new circuit -- in this or a later process -- does not wait for hiprtc (seconds for an ezkl-sized program). */

@@ -182,3 +182,51 @@ def test_chacha20_rfc8439_vector_and_sampler():
 
 def fe_to_int_raw(a):
     return int.from_bytes(np.ascontiguousarray(a, np.uint64).tobytes(), "little")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_sweep_schedule_keeps_the_value(seed):
+    """the library re-orders a gate program before it runs it (every term right before the Horner step that consumes it: short live
+    ranges).  Host-only check of that pass: the re-ordered program is a permutation of the original one, its result is unchanged
+    (C oracle on random columns), and the number of values alive at once falls"""
+    from ezkl_amd import backend as B
+    from test_gpu_misc import _random_program
+    rng = np.random.default_rng(seed)
+    k, ek, ncols = 6, 8, 10
+    ne = 1 << ek
+    prog = _random_program(B, rng, k, ek, ncols, 240)
+    # a halo2-style tail: many terms first, ONE Horner chain over all of them at the end
+    code, consts, rots = prog.arrays()
+    sched = prog.scheduled_code(ncols)
+    assert sched.shape == code.shape and sorted(map(tuple, sched.tolist())) == sorted(map(tuple, code.tolist()))
+    assert (sched[-1] == code[-1]).all()
+    cols = [rand_fr(rng, ne) for _ in range(ncols)]
+    chal, prev = rand_fr(rng, 3), rand_fr(rng, ne)
+    want = ob.eval_program(code, prog.n_intermediates, consts, rots, cols, chal, k, ek, previous=prev)
+    got = ob.eval_program(sched, prog.n_intermediates, consts, rots, cols, chal, k, ek, previous=prev)
+    assert (got == want).all()
+    def max_live(c):
+        last = {}
+        for i, ins in enumerate(c.tolist()):
+            for q in (0, 1):
+                if ins[2 + 3 * q] == B.INTERMEDIATE:
+                    last[ins[3 + 3 * q]] = i
+            last.setdefault(ins[1], i)
+        first = {}
+        for i, ins in enumerate(c.tolist()):
+            first.setdefault(ins[1], i)
+        return max(sum(1 for t in first if first[t] <= i <= last[t]) for i in range(len(c)))
+    # on a halo2-shaped program -- 60 independent gate terms, then one Horner chain over all of them -- the live set collapses
+    gp = B.GraphProgram(k, ek)
+    terms = []
+    for t in range(60):
+        a, b_, c_, s_ = (gp.column(int(rng.integers(0, ncols)), int(rng.integers(-1, 2))) for _ in range(4))
+        terms.append(gp.calc("mul", s_, gp.calc("sub", c_, gp.calc("mul", a, b_))))
+    gp.horner(gp.previous(), terms, gp.challenge(0))
+    gcode, gconsts, grots = gp.arrays()
+    gsched = gp.scheduled_code(ncols)
+    assert max_live(gcode) >= 60 and max_live(gsched) <= 4
+    if gconsts.shape[0] == 0:
+        gconsts = np.zeros((1, 4), np.uint64)
+    assert (ob.eval_program(gsched, gp.n_intermediates, gconsts, grots, cols, chal, k, ek, previous=prev) ==
+            ob.eval_program(gcode, gp.n_intermediates, gconsts, grots, cols, chal, k, ek, previous=prev)).all()
