@@ -80,8 +80,11 @@ def test_host_side_point_add_matches_oracle():
     assert (g1_add_affine(np.zeros(8, np.uint64), b[4]) == b[4]).all()
 
 
-def test_eval_h_program_jit_compiles_offline():
-    """the quotient-sweep JIT: a gate program lowers to HIP source and hiprtc compiles it for gfx950 here"""
+@pytest.mark.parametrize("radix29", ["2", "1", "0"])
+def test_eval_h_program_jit_compiles_offline(radix29, monkeypatch):
+    """the quotient-sweep JIT: a gate program lowers to HIP source and hiprtc compiles it for gfx950 here -- the radix-2^29 generator
+    (product as a call / inline) and the radix-2^32 one"""
+    monkeypatch.setenv("EZKL_EVALH_R29", radix29)
     from ezkl_amd import backend as B
     from conftest import fe_from_int
     prog = B.GraphProgram(4, 6)
