@@ -416,6 +416,42 @@ class BaseRegion(Region):
         self.increment(used)
         return last
 
+    def _accumulate(self, vals, init_op, op, unit, fold):
+        """layouts.rs:2472-2621 `sum` / `prod`: the tensor goes into the SECOND input VarTensor (padded to a whole row with the
+        operation's unit), the running value into the output VarTensor one row per step, SUMINIT / CUMPRODINIT on the first row and
+        SUM / CUMPROD (rotation -1) on the others, with the same duplicated rows at column boundaries as `dot`"""
+        self.flush()
+        w = self.w
+        vals = list(vals) + [Val(unit, const=True)] * ((-len(vals)) % w)
+        ib, used = self._dup_inputs(self.inputs[1], vals)
+        acc, pos, first, last = unit, self.linear, True, None
+        for s in range(0, len(ib), w):
+            acc = fold(acc, [x.v for x in ib[s:s + w]])
+            x, _, z = self.output.cartesian_coord(pos)
+            if z == 0 and not first:                   # duplicate of the running value at the top of a new column: no selector
+                dup = self.put(self.output, pos, Val(last.v))
+                self.copy(dup.cell, last.cell)
+                pos += w
+                x, _, z = self.output.cartesian_coord(pos)
+            last = self.put(self.output, pos, Val(acc))
+            self.enable(self.base.selectors[(init_op if first else op, x, 0)], z)
+            first = False
+            pos += w
+        self.increment(used)
+        return last
+
+    def sum(self, vals):
+        if len(vals) == 1:
+            return vals[0]
+        return self._accumulate(vals, EC.SUMINIT, EC.SUM, 0, lambda acc, chunk: (acc + sum(chunk)) % R)
+
+    def prod(self, vals):
+        def fold(acc, chunk):
+            for v in chunk:
+                acc = acc * v % R
+            return acc
+        return self._accumulate(vals, EC.CUMPRODINIT, EC.CUMPROD, 1, fold)
+
     def decompose(self, vals, base, legs):
         """layouts.rs:6321-6423 (zero_sign_matters = false): hints [sign, digits..] on the output VarTensor, range checks, recomposition
         by dot products with the base powers, multiplication by the sign, equality with the input"""
@@ -647,6 +683,30 @@ class ConvMnistCircuit(LayoutCircuit):
         vals = reg.nonlinearity(vals, "div_%d" % self.denom)
         outs = [reg.dot([Val(int(v) % R) for v in row], vals) for row in self.fc_w]
         outs = reg.pairwise(outs, [Val(int(v) % R) for v in self.fc_b], EC.ADD)
+        reg.constrain_instance(outs, self.gc.instance)
+        reg.finish(self.gc.const_cols)
+        self.outputs = [v.v for v in outs]
+        return reg
+
+
+class SumProdCircuit(LayoutCircuit):
+    """the accumulated SUM / CUMPROD gates of BaseConfig (chip.rs:343-359, base.rs) on a private vector: instance = [sum(x), prod(x),
+    sum of the pairwise products x_i * x_{i+1}] -- used by the tests that drive the gates the MLP / conv circuits never switch on"""
+
+    def __init__(self, logrows, num_inner_cols, capacity):
+        self.k, self.w = logrows, num_inner_cols
+        self.settings = EC.GraphSettings(logrows, num_inner_cols, capacity, total_const_size=4, required_range_checks=[], model_instance_shapes=[[1, 3]])
+        self.gc = EC.GraphConfig(self.settings)
+
+    def synthesize(self, x, witness=True):
+        reg = BaseRegion(self.gc, witness)
+        vals = reg.assign(reg.inputs[0], [Val(int(v) % R) for v in x])
+        reg.increment(len(vals))
+        s = reg.sum(vals)
+        p = reg.prod(vals)
+        pw = reg.pairwise(vals[:-1], vals[1:], EC.MULT)
+        sp = reg.sum(pw)
+        outs = [s, p, sp]
         reg.constrain_instance(outs, self.gc.instance)
         reg.finish(self.gc.const_cols)
         self.outputs = [v.v for v in outs]

@@ -86,3 +86,38 @@ def test_dynamic_lookup_and_shuffle_arguments(golden_srs, kind):
     assert any("lookup" in f for f in MP.check(cs, bad, fixed))
     ok, _, _ = _prove_and_verify(cs, fixed, adv, [], golden_srs)
     assert ok
+
+
+@pytest.mark.parametrize("w,length", [(1, 9), (2, 7), (2, 40), (3, 23), (1, 70), (2, 130)])
+def test_accumulated_sum_and_cumprod_gates(golden_srs, w, length):
+    """SUMINIT / SUM and CUMPRODINIT / CUMPROD (layouts.rs `sum`, `prod`): the running value over rows of `w` inner columns, across
+    column boundaries when the vector is longer than a block; MockProver, a wrong running value caught by the gate, then a real proof"""
+    from ezkl_amd import ezkl_layout as ELy
+    rng = np.random.default_rng(w * 100 + length)
+    x = rng.integers(-9, 10, length).tolist()
+    c = ELy.SumProdCircuit(6, w, 7 * length + 32)
+    cs, fixed, copies, reg = c.keygen_inputs(x)
+    adv, inst = c.witness(x)
+    want_p = 1
+    for v in x:
+        want_p = want_p * v % R
+    assert inst == [[sum(x) % R, want_p, sum(a * b for a, b in zip(x[:-1], x[1:])) % R]]
+    assert MP.check(cs, adv, fixed, inst, copies) == []
+    used = {OPN for OPN in (EC.SUMINIT, EC.SUM, EC.CUMPRODINIT, EC.CUMPROD) if any(reg.activations[s.index] is not None and reg.activations[s.index].any()
+                                                                                  for (op, blk, col), s in c.gc.base.selectors.items() if op == OPN)}
+    assert used == {EC.SUMINIT, EC.SUM, EC.CUMPRODINIT, EC.CUMPROD}
+    # tamper with one running value of the output VarTensor: the accumulation gate of that row (or the next) fails
+    out_cols = [col.index for blk in c.gc.advices[2].inner for col in blk]
+    sel = next(s for (op, blk, col), s in c.gc.base.selectors.items() if op == EC.SUM and reg.activations[s.index] is not None and reg.activations[s.index].any())
+    row = int(np.flatnonzero(reg.activations[sel.index])[0])
+    bad = [list(a) for a in adv]
+    tampered = False
+    for ci in out_cols:
+        if bad[ci][row]:
+            bad[ci][row] = (bad[ci][row] + 1) % R
+            tampered = True
+            break
+    if tampered:
+        assert any("gate" in f for f in MP.check(cs, bad, fixed, inst, copies, max_failures=32))
+    ok, vk, proof = _prove_and_verify(cs, fixed, adv, copies, golden_srs, inst)
+    assert ok
