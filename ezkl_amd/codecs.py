@@ -260,6 +260,13 @@ class _Bincode:
         n = 1 if b0 < 0x80 else 2 if b0 < 0xe0 else 3 if b0 < 0xf0 else 4
         return (bytes([b0]) + bytes(self.take(n - 1))).decode()
 
+    def tag(self, names, what):
+        """a u32 enum variant tag, checked against the enum's variant list"""
+        t = self.u32()
+        if t >= len(names):
+            raise ValueError("bad %s tag %d at byte %d" % (what, t, self.o - 4))
+        return names[t]
+
     def felt(self):
         v = int.from_bytes(self.take(32), "little")
         if v >= _FR:
@@ -311,9 +318,9 @@ def _supported_op(r):
     t = r.u32()
     if t == 0: return {"kind": "Linear", **_poly_op(r)}
     if t == 1:
-        name, nf = _LOOKUP_OPS[r.u32()]
+        name, nf = r.tag(_LOOKUP_OPS, "LookupOp")
         return {"kind": "Nonlinear", "op": name, "params": [r.f32() for _ in range(nf)]}
-    if t == 3: return {"kind": "Input", "scale": r.i32(), "datum_type": _INPUT_TYPES[r.u32()], "decomp": r.boolean()}     # ops/mod.rs:186-193
+    if t == 3: return {"kind": "Input", "scale": r.i32(), "datum_type": r.tag(_INPUT_TYPES, "InputType"), "decomp": r.boolean()}     # ops/mod.rs:186-193
     if t == 4:                                                                                                           # ops/mod.rs:295-305
         return {"kind": "Constant", "quantized_values": _tensor(r, r.felt), "raw_values": _tensor(r, r.f32), "decomp": r.boolean()}
     if t == 5: return {"kind": "Unknown"}
@@ -338,7 +345,7 @@ def _run_args(r):
 def _settings(r, legacy):
     a = _run_args(r)
     if legacy:
-        a["commitment"] = r.opt(lambda: ["KZG", "IPA"][r.u32()])
+        a["commitment"] = r.opt(lambda: r.tag(["KZG", "IPA"], "Commitments"))
     a["decomp_base"], a["decomp_legs"] = r.u64(), r.u64()
     a.update(bounded_log_lookup=r.boolean(), ignore_range_check_inputs_outputs=r.boolean(), epsilon=r.opt(r.f64), disable_freivalds=r.boolean())
     s = dict(run_args=a, num_rows=r.u64(), total_assignments=r.u64(), total_const_size=r.u64())                          # graph/mod.rs:545-568
@@ -347,14 +354,14 @@ def _settings(r, legacy):
     s.update(model_instance_shapes=r.vec(lambda: r.vec(r.u64)), model_output_scales=r.vec(r.i32), model_input_scales=r.vec(r.i32))
     s["module_sizes"] = dict(polycommit=r.vec(r.u64), poseidon=[r.u64(), r.vec(r.u64)])
     def lookup():
-        name, nf = _LOOKUP_OPS[r.u32()]
+        name, nf = r.tag(_LOOKUP_OPS, "LookupOp")
         return {"op": name, "params": [r.f32() for _ in range(nf)]}
     s.update(required_lookups=r.vec(lookup), required_range_checks=r.vec(lambda: (r.i128(), r.i128())))
     t = r.u32()
     if t > 1:
         raise ValueError("bad CheckMode tag %d" % t)
     s.update(check_mode=["SAFE", "UNSAFE"][t], version=r.string(), num_blinding_factors=r.opt(r.u64), timestamp=r.opt(r.u128),
-             input_types=r.opt(lambda: r.vec(lambda: _INPUT_TYPES[r.u32()])), output_types=r.opt(lambda: r.vec(lambda: _INPUT_TYPES[r.u32()])))
+             input_types=r.opt(lambda: r.vec(lambda: r.tag(_INPUT_TYPES, "InputType"))), output_types=r.opt(lambda: r.vec(lambda: r.tag(_INPUT_TYPES, "InputType"))))
     if s["check_mode"] != a["check_mode"] or not s["version"].isprintable() or not (1 <= a["logrows"] <= 28) or a["decomp_base"] < 2:
         raise ValueError("settings do not parse under this layout")
     return s
@@ -371,7 +378,7 @@ def read_compiled_circuit(buf):
             raise ValueError("NodeType::SubGraph is not supported by this reader")
         nodes[key] = dict(opkind=_supported_op(r), out_scale=r.i32(), inputs=r.vec(lambda: (r.u64(), r.u64())), out_dims=r.vec(r.u64), idx=r.u64(),
                           num_uses=r.u64())
-    model = dict(nodes=nodes, inputs=r.vec(r.u64), outputs=r.vec(lambda: (r.u64(), r.u64())), output_types=r.vec(lambda: _INPUT_TYPES[r.u32()]),
+    model = dict(nodes=nodes, inputs=r.vec(r.u64), outputs=r.vec(lambda: (r.u64(), r.u64())), output_types=r.vec(lambda: r.tag(_INPUT_TYPES, "InputType")),
                  visibility=dict(input=_visibility(r), params=_visibility(r), output=_visibility(r)))
     start, err = r.o, None
     for legacy in (False, True):

@@ -109,3 +109,22 @@ def test_compiled_circuit_reader_on_the_reference_model():
     assert X._mlp_of_graph(c["model"]) == ([FIXTURE_W], [FIXTURE_B], True)
     with pytest.raises(ValueError):
         codecs.read_compiled_circuit(open(os.path.join(GOLDEN, "model_k6.compiled"), "rb").read()[:700])
+
+
+def test_compiled_circuit_reader_refuses_damaged_files():
+    """truncated or corrupted model.compiled files end in ValueError (never an index / decode error from inside the reader)"""
+    from ezkl_amd import codecs
+    b = open(os.path.join(GOLDEN, "model_k6.compiled"), "rb").read()
+    rng = np.random.default_rng(1)
+    for t in range(300):
+        if t % 2 == 0:
+            data = b[:int(rng.integers(0, len(b)))]
+        else:
+            data = bytearray(b)
+            for _ in range(3):
+                data[int(rng.integers(0, 1300))] = int(rng.integers(0, 256))
+            data = bytes(data)
+        try:
+            codecs.read_compiled_circuit(data)
+        except ValueError:
+            pass
