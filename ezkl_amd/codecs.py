@@ -313,8 +313,10 @@ def _poly_op(r):
     raise ValueError("PolyOp::%s in a compiled circuit is not supported by this reader" % name)
 
 
-def _supported_op(r):
+def _supported_op(r, depth=0):
     """src/graph/node.rs:295-312"""
+    if depth > 4:                                     # the reference never nests Rescaled; a damaged file must not become a RecursionError
+        raise ValueError("SupportedOp::Rescaled nested too deeply")
     t = r.u32()
     if t == 0: return {"kind": "Linear", **_poly_op(r)}
     if t == 1:
@@ -324,7 +326,7 @@ def _supported_op(r):
     if t == 4:                                                                                                           # ops/mod.rs:295-305
         return {"kind": "Constant", "quantized_values": _tensor(r, r.felt), "raw_values": _tensor(r, r.f32), "decomp": r.boolean()}
     if t == 5: return {"kind": "Unknown"}
-    if t == 6: return {"kind": "Rescaled", "inner": _supported_op(r), "scale": r.vec(lambda: (r.u64(), r.u128()))}     # node.rs:87-92
+    if t == 6: return {"kind": "Rescaled", "inner": _supported_op(r, depth + 1), "scale": r.vec(lambda: (r.u64(), r.u128()))}     # node.rs:87-92
     raise ValueError("SupportedOp tag %d (Hybrid / RebaseScale) is not supported by this reader" % t)
 
 

@@ -95,8 +95,12 @@ int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1) {
 // calls made on the library stream are synchronous (unless ezkl_hip_set_async(1): then they are ordered on that one stream and the
 // caller synchronises where it needs to -- every entry point that returns host data or borrows host memory still does by itself);
 // calls on a caller stream are stream-ordered
+// The mode belongs to the CALLING THREAD (a process-wide flag saved / restored by overlapping create_proof calls on
+// different threads could stay on, and unrelated threads lost the synchronous semantics while any proof ran).
+static thread_local bool t_async_library_stream = false;
 static int finish(Ctx* c, hipStream_t st, void* user_stream) {
-    if (!user_stream && !c->async_library_stream) EZ_HIP(hipStreamSynchronize(st));
+    (void)c;
+    if (!user_stream && !t_async_library_stream) EZ_HIP(hipStreamSynchronize(st));
     return EZKL_OK;
 }
 
@@ -122,9 +126,9 @@ int ezkl_hip_synchronize(void) {
 
 int ezkl_hip_set_async(int on, int* previous) {
     EZ_CTX(c);
-    if (previous) *previous = c->async_library_stream ? 1 : 0;
-    if (!on && c->async_library_stream) EZ_HIP(hipStreamSynchronize(c->stream));     // leaving the mode: everything queued has run
-    c->async_library_stream = on != 0;
+    if (previous) *previous = t_async_library_stream ? 1 : 0;
+    if (!on && t_async_library_stream) EZ_HIP(hipStreamSynchronize(c->stream));     // leaving the mode: everything queued has run
+    t_async_library_stream = on != 0;
     return EZKL_OK;
 }
 int ezkl_hip_stream_wait_library(void* stream) {

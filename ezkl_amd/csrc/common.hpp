@@ -16,7 +16,6 @@ namespace ezkl {
 struct Ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // library stream (used when the caller passes NULL)
-    bool async_library_stream = false; // ezkl_hip_set_async: device-only calls on the library stream do not end with a synchronisation
     hipEvent_t order_event = nullptr;  // ezkl_hip_stream_wait_library
     int num_cus = 256;
     std::recursive_mutex mu;          // serialises calls on this device (halo2 calls from rayon workers)

@@ -516,9 +516,23 @@ static std::string jit_arch(Ctx* c) {
     }
     return "gfx950";
 }
+// What the generated code depends on besides the program: the headers hiprtc compiles it against (embedded at build time) and the code
+// generators in this file.  Their digest is part of the cache identity, so a code object written by another build of the library -- other
+// field arithmetic, other generator -- is never loaded for the same program (the version string alone did not change).
+static constexpr uint32_t JIT_CODEGEN_REVISION = 3;     // bump when jit_source / jit_source_r29 / schedule_program change what they emit
+static uint64_t jit_build_digest() {
+    static const uint64_t d = [] {
+        uint64_t h = 1469598103934665603ull ^ JIT_CODEGEN_REVISION;
+        for (const char* src : {k_src_field, k_src_constants, k_src_montmul, k_src_field29, k_src_montmul29}) h = fnv1a(src, strlen(src), h * 31 + 7);
+        return fnv1a(ezkl_hip_version(), strlen(ezkl_hip_version()), h);
+    }();
+    return d;
+}
 static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>& rot, hipFunction_t* fn) {
     std::string key((const char*)p->code, (size_t)p->n_instr * 32);
     key.append((const char*)rot.data(), rot.size() * 4);
+    const uint64_t build = jit_build_digest();
+    key.append((const char*)&build, sizeof build);
     const int knobs[4] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2), jit_knob("EZKL_EVALH_XCD", 0)};      // code-generation options are part of the identity
     key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
@@ -537,7 +551,7 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     char name[160];
     // second, independent hash in the file name + the key length: a stale or colliding file is caught by the embedded key check below
     snprintf(name, sizeof name, "/evalh_%s_%016llx_%016llx_%zu.co", arch.c_str(), (unsigned long long)h,
-             (unsigned long long)fnv1a(key.data(), key.size(), 0x9e3779b97f4a7c15ull ^ fnv1a(ezkl_hip_version(), strlen(ezkl_hip_version()), 7)), key.size());
+             (unsigned long long)fnv1a(key.data(), key.size(), 0x9e3779b97f4a7c15ull ^ build), key.size());
     std::vector<char> bin;
     bool from_disk = false;
     if (!dir.empty()) {
@@ -603,12 +617,29 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     if (from_disk) g_jit_from_disk++; else g_jit_compiled++;
     return EZKL_OK;
 }
+// every entry point validates the WHOLE program -- opcodes, targets and every source operand -- before anything indexes with it
+// (schedule_program / allocate_slots index by operand, the generators index constants and columns)
+static int validate_program(const ezkl_program_t* p) {
+    if (p->ext_k > 28 || p->k > p->ext_k) return EZKL_ERR_INVALID;
+    if (p->n_instr && !p->code) return EZKL_ERR_INVALID;
+    for (uint32_t i = 0; i < p->n_instr; i++) {
+        const uint32_t* I = p->code + 8 * (size_t)i;
+        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p->n_intermediates) return EZKL_ERR_INVALID;
+        const bool unary = (I[0] == EZKL_OP_SQUARE || I[0] == EZKL_OP_DOUBLE || I[0] == EZKL_OP_NEGATE || I[0] == EZKL_OP_STORE);
+        for (int q = 0; q < (unary ? 1 : 2); q++) {
+            uint32_t kind = I[2 + 3 * q], idx = I[3 + 3 * q], rot = I[4 + 3 * q];
+            if (kind > EZKL_SRC_PREVIOUS) return EZKL_ERR_INVALID;
+            if (kind == EZKL_SRC_CONST && idx >= p->n_constants) return EZKL_ERR_INVALID;
+            if (kind == EZKL_SRC_INTERMEDIATE && idx >= p->n_intermediates) return EZKL_ERR_INVALID;
+            if (kind == EZKL_SRC_COLUMN && (idx >= p->n_columns || rot >= p->n_rotations)) return EZKL_ERR_INVALID;
+            if (kind == EZKL_SRC_CHALLENGE && idx >= p->n_challenges) return EZKL_ERR_INVALID;
+        }
+    }
+    return EZKL_OK;
+}
 // offline self-check used by build(): does the JIT source for a program compile for gfx950? (no GPU needed)
 int eval_jit_compile_only(const ezkl_program_t* p0) {
-    for (uint32_t i = 0; i < p0->n_instr; i++) {
-        const uint32_t* I = p0->code + 8 * (size_t)i;
-        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p0->n_intermediates) return EZKL_ERR_INVALID;
-    }
+    if (int rc = validate_program(p0)) return rc;
     ezkl_program_t scheduled = *p0;
     const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p0->code, p0->code + 8 * (size_t)p0->n_instr) : schedule_program(p0);
     scheduled.code = sched_code.data();
@@ -634,10 +665,7 @@ int eval_jit_compile_only(const ezkl_program_t* p0) {
 
 // host-only: the order the library will execute a program in (schedule_program), for callers and tests that want to look at it
 int eval_schedule_only(const ezkl_program_t* p, uint32_t* out_code) {
-    for (uint32_t i = 0; i < p->n_instr; i++) {
-        const uint32_t* I = p->code + 8 * (size_t)i;
-        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p->n_intermediates) return EZKL_ERR_INVALID;
-    }
+    if (int rc = validate_program(p)) return rc;
     const std::vector<uint32_t> code = schedule_program(p);
     memcpy(out_code, code.data(), code.size() * 4);
     return EZKL_OK;
@@ -646,11 +674,8 @@ int eval_schedule_only(const ezkl_program_t* p, uint32_t* out_code) {
 // Compile (or load from the on-disk cache) the kernel of a program WITHOUT running it: a key generator calls this for the circuit's
 // quotient program, so that the first `prove` of a new circuit does not wait for hiprtc (9 s for a 786-instruction ezkl program).
 int eval_prepare(Ctx* c, const ezkl_program_t* p0) {
-    if (p0->ext_k > 28 || p0->k > p0->ext_k || p0->n_instr == 0) return EZKL_ERR_INVALID;
-    for (uint32_t i = 0; i < p0->n_instr; i++) {
-        const uint32_t* I = p0->code + 8 * (size_t)i;
-        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p0->n_intermediates) return EZKL_ERR_INVALID;
-    }
+    if (p0->n_instr == 0) return EZKL_ERR_INVALID;
+    if (int rc = validate_program(p0)) return rc;
     ezkl_program_t scheduled = *p0;
     const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p0->code, p0->code + 8 * (size_t)p0->n_instr) : schedule_program(p0);
     scheduled.code = sched_code.data();
@@ -671,23 +696,9 @@ int eval_prepare(Ctx* c, const ezkl_program_t* p0) {
 }
 
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
-    if (p->ext_k > 28 || p->k > p->ext_k) return EZKL_ERR_INVALID;
+    if (int vrc = validate_program(p)) return vrc;          // before it touches the device
     if (p->n_instr == 0) return EZKL_OK;
     const size_t ne = (size_t)1 << p->ext_k;
-    // validate the program before it touches the device
-    for (uint32_t i = 0; i < p->n_instr; i++) {
-        const uint32_t* I = p->code + 8 * (size_t)i;
-        if (I[0] > EZKL_OP_HORNER_STEP || I[1] >= p->n_intermediates) return EZKL_ERR_INVALID;
-        const bool unary = (I[0] == EZKL_OP_SQUARE || I[0] == EZKL_OP_DOUBLE || I[0] == EZKL_OP_NEGATE || I[0] == EZKL_OP_STORE);
-        for (int q = 0; q < (unary ? 1 : 2); q++) {
-            uint32_t kind = I[2 + 3 * q], idx = I[3 + 3 * q], rot = I[4 + 3 * q];
-            if (kind > EZKL_SRC_PREVIOUS) return EZKL_ERR_INVALID;
-            if (kind == EZKL_SRC_CONST && idx >= p->n_constants) return EZKL_ERR_INVALID;
-            if (kind == EZKL_SRC_INTERMEDIATE && idx >= p->n_intermediates) return EZKL_ERR_INVALID;
-            if (kind == EZKL_SRC_COLUMN && (idx >= p->n_columns || rot >= p->n_rotations)) return EZKL_ERR_INVALID;
-            if (kind == EZKL_SRC_CHALLENGE && idx >= p->n_challenges) return EZKL_ERR_INVALID;
-        }
-    }
     ezkl_program_t scheduled = *p;
     const std::vector<uint32_t> sched_code = getenv("EZKL_EVALH_NO_SCHEDULE") ? std::vector<uint32_t>(p->code, p->code + 8 * (size_t)p->n_instr) : schedule_program(p);
     scheduled.code = sched_code.data();

@@ -2243,6 +2243,7 @@ int ezkl_prover_verify_proof(ezkl_pk_t pk, const void* g2, const void* s_g2, con
                              const uint32_t* instance_lens, int* accepted) {
     if (!pk || !g2 || !s_g2 || !proof || !accepted) return EZKL_ERR_INVALID;
     *accepted = 0;
+    if (pk->pk->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
     return guarded([&] {
         const ProvingKey& k = *pk->pk;
         const bn::G2 a = bn::g2_from_bytes((const uint8_t*)g2), b = bn::g2_from_bytes((const uint8_t*)s_g2);

@@ -50,6 +50,7 @@ int ezkl_hip_stream_destroy(void* stream);
  * for each; ezkl_hip_set_async(1, &prev) makes those calls return as soon as they are queued on the library stream -- still in order
  * with each other.  Entry points that return host data (MSMs, eval_poly*, lookup_multiplicity, memcpy_d2h) or borrow host memory
  * (memcpy_h2d, eval_h_dev, divide_by_vanishing) keep synchronising by themselves.  ezkl_hip_set_async(0, ..) drains the stream.
+ * The mode is a property of the CALLING THREAD: concurrent provers on other threads, and unrelated callers, keep their own setting.
  * ezkl_hip_stream_wait_library(s): work queued on the caller stream s from now on waits for everything queued on the library
  * stream so far (a column produced by library-stream calls, consumed on s). */
 int ezkl_hip_set_async(int on, int* previous);

@@ -29,8 +29,115 @@ def sparse_weights(rng, n_out, n_in, nnz=4):
     return W.tolist()
 
 
+# ---- on-disk cache of laid-out circuits -----------------------------------------------------------------------------
+# The Python layout engine is test / bench scaffolding (witness synthesis is ezkl's Rust `Model::layout` in a fork) and takes 35-75 s
+# for the k = 20 MLP.  A laid-out circuit is therefore written ONCE -- constraint system, copy constraints, instances and every fixed /
+# advice column as canonical values in the narrowest integer type that holds them -- and read back by every later process: the CPU
+# prover child of bench.py, the N ranks of `bench.py --gpus N` (rank 0 of a node lays out, the others wait for the file), the
+# profiling tools.  EZKL_BENCH_CACHE=<dir> (default <repo>/bench_cache, which travels to the GPU box with the snapshot), `off` disables.
+def _cache_dir():
+    d = os.environ.get("EZKL_BENCH_CACHE", os.path.join(ROOT, "bench_cache"))
+    return None if d in ("off", "0", "") else d
+
+
+def _pack_col(col):
+    """canonical field elements (ints mod r / small signed numpy ints) -> int32 / int64 signed values, or (n, 4) u64 limbs"""
+    if isinstance(col, np.ndarray) and col.dtype != object:
+        v = col.astype(np.int64)
+    else:
+        arr = np.asarray(col, dtype=object)
+        half = P.R >> 1
+        big = arr > half
+        if big.any():
+            arr = arr.copy()
+            arr[big] = arr[big] - P.R
+        if len(arr) and (max(arr) >= (1 << 62) or min(arr) <= -(1 << 62)):
+            return EL.ints_to_limbs(col)
+        v = arr.astype(np.int64)
+    if len(v) and np.abs(v).max() < (1 << 31):
+        return v.astype(np.int32)
+    return v
+
+
+def _unpack_cols(cols, gpu, pinned=False):
+    """packed columns -> (n, 4) u64 Montgomery arrays (the conversion runs on the device when a backend is given)"""
+    out = []
+    for c in cols:
+        if c.ndim == 2:                              # canonical limbs
+            if gpu is None:
+                out.append(EL.ints_to_mont([int.from_bytes(r.tobytes(), "little") for r in c]))
+                continue
+            limbs = c
+        else:
+            limbs = EL.ints_to_limbs(c.astype(np.int64))
+            if gpu is None:
+                out.append(EL.ints_to_mont([int(v) for v in c]))
+                continue
+        r2 = P.to_mont((1 << 256) % P.R)
+        buf = gpu.DeviceBuffer.from_numpy(np.ascontiguousarray(limbs))
+        gpu.vec_scale(buf.ptr, r2, buf.ptr, len(c))
+        a = buf.to_numpy(shape=(len(c), 4))
+        if pinned:
+            pa = gpu.PinnedArray((len(c), 4))
+            pa.array[:] = a
+            EL._PINNED.append(pa)
+            a = pa.array
+        else:
+            a = a.copy()
+        out.append(a)
+    return out
+
+
+def _cache_load(path, gpu):
+    import pickle
+    with np.load(path, allow_pickle=False) as z:
+        meta = pickle.loads(z["meta"].tobytes())
+        fixed = _unpack_cols([z["f%d" % i] for i in range(meta["n_fixed"])], gpu)
+        advice = _unpack_cols([z["a%d" % i] for i in range(meta["n_advice"])], gpu)
+        copies = [((int(a), int(b)), (int(c), int(d))) for a, b, c, d in z["copies"]]
+    return dict(cs=meta["cs"], fixed=fixed, copies=copies, advice=advice, instances=meta["instances"], info=dict(meta["info"], layout="read from " + os.path.basename(path)))
+
+
+def _cache_store(path, cs, fixed_raw, copies, adv_raw, instances, info):
+    import pickle
+    arrs = {"meta": np.frombuffer(pickle.dumps(dict(cs=cs, instances=instances, info=info, n_fixed=len(fixed_raw), n_advice=len(adv_raw))), np.uint8),
+            "copies": np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4)}
+    for i, c in enumerate(fixed_raw):
+        arrs["f%d" % i] = _pack_col(c)
+    for i, c in enumerate(adv_raw):
+        arrs["a%d" % i] = _pack_col(c)
+    tmp = path + ".tmp%d.npz" % os.getpid()
+    np.savez_compressed(tmp, **arrs)
+    os.replace(tmp, path)
+
+
 def build(kind, k, gpu=None, seed=1, **kw):
     """-> dict(cs, fixed (Montgomery arrays), copies, advice (list of arrays, or callable(phase, challenges)), instances, info)"""
+    d = _cache_dir()
+    if d is None or kind == "einsum":                # the einsum witness depends on the proof's challenges: laid out per proof
+        return _build(kind, k, gpu, seed, None, **kw)
+    os.makedirs(d, exist_ok=True)
+    tag = "_".join([kind, "k%d" % k, "s%d" % seed] + ["%s%s" % (a, kw[a]) for a in sorted(kw) if kw[a] is not None])
+    path = os.path.join(d, tag + ".npz")
+    lock = path + ".lock"
+    import time
+    while not os.path.exists(path):
+        try:
+            fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        except FileExistsError:                      # another process (rank) is laying the circuit out: wait for its file
+            if time.time() - os.path.getmtime(lock) > 1800:
+                os.unlink(lock)
+            time.sleep(0.5)
+            continue
+        try:
+            os.close(fd)
+            return _build(kind, k, gpu, seed, path, **kw)
+        finally:
+            os.unlink(lock)
+    return _cache_load(path, gpu)
+
+
+def _build(kind, k, gpu, seed, store, **kw):
     rng = np.random.default_rng(seed)
     if kind == "einsum":
         L = kw.get("length") or {22: 1024, 21: 720, 20: 512, 19: 360, 18: 256, 17: 180, 16: 128, 15: 90, 14: 64, 12: 30, 10: 14, 8: 6, 6: 3}[k]
@@ -60,6 +167,8 @@ def build(kind, k, gpu=None, seed=1, **kw):
         adv, inst = c.witness_of(reg)
         info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),
                     cells_used=reg.linear, blocks=c.gc.advices[0].num_blocks(), range_checks=[list(r) for r in c.settings.required_range_checks])
+        if store:
+            _cache_store(store, cs, fixed, copies, adv, inst, info)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
     if kind == "conv":
         c = EL.ConvMnistCircuit(logrows=k, seed=seed)
@@ -68,6 +177,8 @@ def build(kind, k, gpu=None, seed=1, **kw):
         adv, inst = c.witness_of(reg)
         info = dict(circuit="examples/conv2d_mnist: Conv 1->4 5x5 stride 2 on 28x28 + ReLU + Div{32} lookup (65 537-row table) + Linear 576->10, "
                             "3 advice columns, k=%d (synthetic image and parameters of the example's shapes)" % k, cells_used=reg.linear)
+        if store:
+            _cache_store(store, cs, fixed, copies, adv, inst, info)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=EL.cols_to_mont(adv, gpu), instances=inst, info=info)
     raise ValueError(kind)
 
