@@ -369,6 +369,18 @@ def coset_ntt_dev(in_ptr, out_ptr, k, ext_k, inverse=False, in_len=None, batch=1
              "ezkl_hip_coset_ntt_dev")
 
 
+def coeff_to_cosets_dev(in_ptr, out_ptr, k, ext_k, batch=1, stream=None):
+    """coeff_to_extended with the 2^(ext_k - k) cosets of the extended domain stored one after the other (coset-major): out[b 2^k + j]
+    = p(zeta w_ext^b omega^j) = natural-order element E j + b"""
+    _l.check(_l.load().ezkl_hip_coeff_to_cosets_dev(_vp(in_ptr), _vp(out_ptr), C.c_size_t(batch), C.c_size_t(1 << k), C.c_size_t(1 << ext_k),
+                                                     C.c_uint32(k), C.c_uint32(ext_k), _stream_ptr(stream)), "ezkl_hip_coeff_to_cosets_dev")
+
+
+def cosets_transpose_dev(in_ptr, out_ptr, k, ext_k, to_natural=True, stream=None):
+    _l.check(_l.load().ezkl_hip_cosets_transpose_dev(_vp(in_ptr), _vp(out_ptr), C.c_uint32(k), C.c_uint32(ext_k), C.c_int(1 if to_natural else 0),
+                                                      _stream_ptr(stream)), "ezkl_hip_cosets_transpose_dev")
+
+
 def divide_by_vanishing_dev(ptr, k, ext_k, stream=None):
     _l.check(_l.load().ezkl_hip_divide_by_vanishing_dev(_vp(ptr), C.c_uint32(k), C.c_uint32(ext_k), _stream_ptr(stream)),
              "ezkl_hip_divide_by_vanishing_dev")

@@ -363,6 +363,16 @@ int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* co
     EZ_CTX(c);
     return msm_run_batch(c, pick_stream(c, stream), b, base_offset, (const fe_t* const*)scalars_dev, batch, n, out);
 }
+int ezkl_hip_msm_g1_batch_small_dev(ezkl_bases_t h, size_t base_offset, const void* const* scalars_dev, size_t batch, size_t n,
+                                    void* out, void* stream) {
+    if (!h || !scalars_dev || !out) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (base_offset + n > b->n) return EZKL_ERR_INVALID;
+    for (size_t i = 0; i < batch; i++)
+        if (!scalars_dev[i] && n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_run_batch(c, pick_stream(c, stream), b, base_offset, (const fe_t* const*)scalars_dev, batch, n, out, true);
+}
 int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t batch, size_t n, void* out) {
     if (!h || !scalars || !out) return EZKL_ERR_INVALID;
     Bases* b = reinterpret_cast<Bases*>(h);
@@ -524,6 +534,22 @@ int ezkl_hip_coset_ntt_dev(const void* in, void* out, size_t batch, size_t in_st
         rc = ntt_run(c, st, (const fe_t*)in, (fe_t*)out, log_n_ext, w, false, batch, in_stride, out_stride, log_n, 1);
     else
         rc = ntt_run(c, st, (const fe_t*)in, (fe_t*)out, log_n_ext, w, true, batch, in_stride, out_stride, log_n_ext, 2);
+    if (rc) return rc;
+    return finish(c, st, stream);
+}
+int ezkl_hip_coeff_to_cosets_dev(const void* in, void* out, size_t batch, size_t in_stride, size_t out_stride, uint32_t log_n, uint32_t log_n_ext, void* stream) {
+    if (!in || !out || in == out || batch == 0 || log_n > log_n_ext || log_n_ext > 28 || log_n_ext - log_n > 6) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = coset_cm_run(c, st, (const fe_t*)in, (fe_t*)out, log_n, log_n_ext, domain_omega(log_n, false), domain_omega(log_n_ext, false), batch, in_stride, out_stride);
+    if (rc) return rc;
+    return finish(c, st, stream);
+}
+int ezkl_hip_cosets_transpose_dev(const void* in, void* out, uint32_t log_n, uint32_t log_n_ext, int to_natural, void* stream) {
+    if (!in || !out || in == out || log_n > log_n_ext || log_n_ext > 28) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = cm_transpose(c, st, (const fe_t*)in, (fe_t*)out, log_n, log_n_ext - log_n, to_natural != 0);
     if (rc) return rc;
     return finish(c, st, stream);
 }

@@ -74,10 +74,13 @@ struct Bases {
 
 int ntt_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
             size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode);
+int coset_cm_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_ext, const fe_t& w_n, const fe_t& w_ext, size_t batch,
+                 size_t in_stride, size_t out_stride);
+int cm_transpose(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_e, bool to_natural);
 int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* scalars_dev, size_t n,
             void* out_affine_host);
 int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
-                  void* out_host);
+                  void* out_host, bool small_scalars = false);
 struct MsmUpload;
 int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails, size_t tail_start,
                      size_t tail_count, MsmUpload** out);

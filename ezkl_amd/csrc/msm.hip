@@ -57,9 +57,9 @@ __device__ __forceinline__ uint32_t msm_part_of(uint32_t bucket, uint32_t NP) { 
 // Lane length of the accumulate kernel, decided ON THE DEVICE from the number of pairs that actually exist: the host sizes
 // the launch for n * W pairs, but small witness values have one or two non-zero digits, and with the host's lane length
 // such a column filled a third of the CUs with one wave each (0.45 ms for 1.5 M pairs; 1.1 ms for 13.6 M).
-__device__ __forceinline__ uint32_t msm_lane_len(const uint32_t* offsets, uint32_t nb, uint32_t nlanes) {
+__device__ __forceinline__ uint32_t msm_lane_len(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, uint32_t lmin) {
     const uint32_t l = (uint32_t)(((uint64_t)offsets[nb] + nlanes - 1) / nlanes);
-    return l < MSM_LMIN ? MSM_LMIN : l;
+    return l < lmin ? lmin : l;
 }
 
 // Window plan: W signed-digit windows covering 254 bits (253-bit magnitudes after the r - s fold + the last carry),
@@ -535,10 +535,10 @@ __device__ __forceinline__ MsmRec msm_fetch(const g1a_t* tab, uint32_t v) {
 }
 __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab, const uint32_t* offsets, const uint32_t* vals,
                                                              uint32_t nb, uint32_t nlanes, g1x29_t* buckets, g1x29_t* head, g1x29_t* tail,
-                                                             uint32_t* lane_first, size_t bstride) {
+                                                             uint32_t* lane_first, uint32_t lmin, size_t bstride) {
     BOFF(); BSH(offsets); BSH(vals); BSH(buckets); BSH(head); BSH(tail); BSH(lane_first);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = offsets[nb], L = msm_lane_len(offsets, nb, nlanes);
+    const uint32_t total = offsets[nb], L = msm_lane_len(offsets, nb, nlanes, lmin);
     const uint64_t k0w = (uint64_t)t * L;
     if (k0w >= total) return;
     const uint32_t k0 = (uint32_t)k0w;
@@ -588,18 +588,19 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
 // longer (a skewed witness) is queued for msm_fixup_heavy{1,2}_kernel.
 __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes,
                                                                  const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
-                                                                 uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list, size_t bstride) {
+                                                                 uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list, uint32_t lmin,
+                                                                 uint32_t span_heavy, size_t bstride) {
     BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(tail); BSH(buckets); BSH(heavy_list); BSH(heavy_count); BSH(chunk_list);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
     if (t >= nlanes) return;
-    const uint32_t L = msm_lane_len(offsets, nb, nlanes);
+    const uint32_t L = msm_lane_len(offsets, nb, nlanes, lmin);
     const uint64_t k0 = (uint64_t)t * L;
     if (k0 >= offsets[nb]) return;
     const uint32_t b = lane_first[t];
     const uint32_t beg = offsets[b], end = offsets[b + 1];
     if (beg >= k0) return;                                                 // the bucket starts exactly on the boundary: not cut
     const uint32_t t1 = beg / L, t2 = (end - 1) / L;
-    if (t2 - t1 > MSM_SPAN_HEAVY) {                                        // skewed witness: queue the bucket once, and one work item
+    if (t2 - t1 > span_heavy) {                                        // skewed witness: queue the bucket once, and one work item
         if (t == t1 + 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;       // per chunk of MSM_HEAVY_CHUNK lane partials
         if ((t - t1 - 1) % MSM_HEAVY_CHUNK == 0) chunk_list[atomicAdd(heavy_count + 1, 1u)] = t;
         return;
@@ -614,10 +615,10 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
 // Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
 // (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
 __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const uint32_t* lane_first, g1x29_t* head,
-                                                               const uint32_t* chunk_list, const uint32_t* counts, size_t bstride) {
+                                                               const uint32_t* chunk_list, const uint32_t* counts, uint32_t lmin, size_t bstride) {
     BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(chunk_list); BSH(counts);
     __shared__ uint4 sh[9 * 4];
-    const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes);
+    const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes, lmin);
     for (uint32_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
         const uint32_t start = chunk_list[ci], b = lane_first[start];
         const uint32_t t2 = (offsets[b + 1] - 1) / L;
@@ -629,10 +630,10 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* o
     }
 }
 __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
-                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets, size_t bstride) {
+                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets, uint32_t lmin, size_t bstride) {
     BOFF(); BSH(offsets); BSH(head); BSH(tail); BSH(heavy_list); BSH(counts); BSH(buckets);
     __shared__ uint4 sh[9 * 4];
-    const uint32_t L = msm_lane_len(offsets, nb, nlanes);
+    const uint32_t L = msm_lane_len(offsets, nb, nlanes, lmin);
     for (uint32_t h = blockIdx.x; h < counts[0]; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
@@ -853,7 +854,7 @@ static int msm_finish(MsmSlot& sl, void* out_host = nullptr, bool release = true
 
 // how many MSMs of this size are fused into one group (gridDim.z): small MSMs are launch- and latency-bound (at 2^17 points a lone MSM
 // is 0.12 ms of accumulation inside a 0.6 ms chain of ~17 launches)
-static size_t msm_group_size(const MsmTable* T, size_t n) {
+static size_t msm_group_size(const MsmTable* T, size_t n, bool small_scalars) {
     if (const char* e = getenv("EZKL_MSM_GROUP")) {
         const int v = atoi(e);
         if (v >= 1 && v <= (int)MSM_MAX_GROUP) return (size_t)v;
@@ -861,6 +862,10 @@ static size_t msm_group_size(const MsmTable* T, size_t n) {
     // measured (k = 17 MLP proof, 56 MSMs, 7 proofs per setting): groups of 4 on the six slot streams 40.4-41.9 ms, no fusing 43.0-46.3,
     // groups of 16 41.2-45.7 (one group per phase leaves nothing for the other slots to overlap); at 2^20 points the sort / fixup /
     // reduce kernels are throughput-bound, a fused group serialises what separate streams overlap (1.50 vs 1.35 ms per MSM): no fusing
+    // witness-shaped columns (the caller's hint: advice columns, multiplicities -- one or two non-zero digits per scalar) leave every
+    // kernel of the chain latency-bound whatever n is (serial profile of the k = 20 MLP's advice columns: accumulate 0.09-0.11 ms inside
+    // 0.55-0.93 ms of device time): four of them share one chain (k = 20 MLP proof: advice phase 17.3 -> 11.3 ms)
+    if (small_scalars) return 4;
     return n * T->wp.W <= ((size_t)4 << 20) ? 4 : 1;
 }
 // `count` MSMs of n points each (scalar columns cols[0..count)) as ONE sequence of launches with gridDim.z = count
@@ -892,6 +897,9 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if (v > 0 && v < (1 << 20)) L = (uint32_t)v;
     }
     const uint32_t nlanes = cdiv(npairs, L);
+    // device-side floor of the lane length (columns with few non-zero digits) and the cut count above which a bucket takes the heavy path
+    static const uint32_t lmin = [] { const char* e = getenv("EZKL_MSM_LMIN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_LMIN); }();
+    static const uint32_t span_heavy = [] { const char* e = getenv("EZKL_MSM_SPAN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_SPAN_HEAVY); }();
     // ---- field geometry of the reduce phase (positions: pos = (bucket & (NP-1)) << LB | bucket >> PB) ----
     ReduceGeom rg;
     memset(&rg, 0, sizeof rg);
@@ -987,18 +995,18 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3(cdiv(nlanes, 256), 1, Z), dim3(256), 0, st, T->tab, offs, vals, nb, nlanes, bkt, head, tail,
-                       lfirst, bstride);
+                       lfirst, lmin, bstride);
     if (timed) EZ_HIP(hipEventRecord(a1, st));
     if (nlanes > 1)
         hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
-                           heavy, hcnt, chunks, bstride);
+                           heavy, hcnt, chunks, lmin, span_heavy, bstride);
     {
-        size_t max_heavy = nlanes / MSM_SPAN_HEAVY + 1;
+        size_t max_heavy = nlanes / span_heavy + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
         size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
         unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt, bstride);
-        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, bstride);
+        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt, lmin, bstride);
+        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, lmin, bstride);
     }
     // reduce
     {
@@ -1034,8 +1042,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
 // (host Horner, results written to their place in out_host) before it is reused.  wait_ev (optional): column j may only be read
 // after wait_ev[j] (the upload phase's copy events).
 static int msm_run_groups(Ctx* c, MsmTable* T, size_t base_offset, const fe_t* const* cols, size_t batch, size_t n, void* out_host,
-                          const hipEvent_t* wait_ev) {
-    const size_t G = msm_group_size(T, n);
+                          const hipEvent_t* wait_ev, bool small_scalars) {
+    const size_t G = msm_group_size(T, n, small_scalars);
     int rc = EZKL_OK;
     size_t gi = 0;
     for (size_t j0 = 0; j0 < batch && !rc; j0 += G, gi++) {
@@ -1120,7 +1128,7 @@ int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const
 // `batch` independent MSMs against the same bases (the advice-column commits of one prover phase), pipelined
 // over MSM_SLOTS streams.  `st` orders the batch after prior work on the caller's stream.
 int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* const* scalars, size_t batch, size_t n,
-                  void* out_host) {
+                  void* out_host, bool small_scalars) {
     if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (batch == 0) return EZKL_OK;
     if (n == 0) { memset(out_host, 0, 64 * batch); return EZKL_OK; }
@@ -1128,7 +1136,7 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
     int rc = table_get(c, st, b, &T);
     if (rc) return rc;
     EZ_HIP(hipStreamSynchronize(st));          // inputs produced on the caller's stream are complete
-    return msm_run_groups(c, T, base_offset, scalars, batch, n, out_host, nullptr);
+    return msm_run_groups(c, T, base_offset, scalars, batch, n, out_host, nullptr, small_scalars);
 }
 
 // One prover phase in one call: upload `batch` host columns into the caller's device columns, overwrite their tail rows
@@ -1209,7 +1217,7 @@ int msm_upload_commit(Ctx* c, MsmUpload* u, const Bases* b, size_t commit_first,
     if (rc) return rc;
     std::vector<const fe_t*> cols(batch);
     for (size_t j = 0; j < batch; j++) cols[j] = u->dev_cols[j] + commit_first;
-    return msm_run_groups(c, T, 0, cols.data(), batch, commit_count, out_host, u->ev.data());
+    return msm_run_groups(c, T, 0, cols.data(), batch, commit_count, out_host, u->ev.data(), true);     // an upload phase commits witness columns
 }
 bool msm_upload_is_open() { return g_open_upload != nullptr; }
 

@@ -38,6 +38,10 @@ struct PassArgs {
     uint32_t k1_major;      // last pass: tile owns C blocks with consecutive leading digit
     fe_t zeta[2];           // zeta, zeta^2
     fe_t post_c[3];
+    // coset-major extended evaluation (coset_cm_run): blockIdx.y = column * E + coset; the first pass multiplies row i1 by
+    // tw_pre[coset][i1] = c_b^(S * i1) and its inter-pass table is per coset (tw_inter + coset * 2^log_n holds w^(i2 k1) * c_b^i2)
+    uint32_t cm, cm_log_e;
+    const fe_t* tw_pre;
 };
 
 EZ_D void lds_put(uint2* d, uint32_t tile, uint32_t e, const fe_t& x) {
@@ -103,8 +107,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     uint2* data = reinterpret_cast<uint2*>(smem);
     fe_t* tloc = reinterpret_cast<fe_t*>(smem + 32u * TILE);
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
-    const fe_t* in = a.in + (size_t)blockIdx.y * a.in_stride;
-    fe_t* out = a.out + (size_t)blockIdx.y * a.out_stride;
+    const uint32_t cm_b = a.cm ? (blockIdx.y & ((1u << a.cm_log_e) - 1u)) : 0u, cm_col = a.cm ? (blockIdx.y >> a.cm_log_e) : blockIdx.y;
+    // coset-major: the first pass reads column cm_col (one copy of the coefficients serves all E cosets), the last pass writes coset
+    // cm_b of that column's extended form; the work buffer in between holds one 2^log_n block per (column, coset)
+    const fe_t* in = a.in + (size_t)((a.cm && a.first) ? cm_col : blockIdx.y) * a.in_stride;
+    fe_t* out = (a.cm && a.last) ? a.out + (size_t)cm_col * a.out_stride + ((size_t)cm_b << a.log_n) : a.out + (size_t)blockIdx.y * a.out_stride;
+    const fe_t* tw_inter = a.tw_inter ? a.tw_inter + ((a.cm && a.first) ? ((size_t)cm_b << a.log_n) : 0) : nullptr;
+    const fe_t* tw_pre = (a.cm && a.first) ? a.tw_pre + ((size_t)cm_b << a.log_r) : nullptr;
 
     for (uint32_t j = tid; j < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(a.tw_local + j);
 
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
             uint32_t m3 = (uint32_t)(addr % 3);
             if (m3) x = Fr::mul(x, a.zeta[m3 - 1]);
         }
+        if (tw_pre) x = Fr::mul(x, ld_fe(tw_pre + (e >> logC)));      // coset-major: row i1 of the column FFT times c_b^(S i1)
         lds_put(data, TILE, e, x);     // LDS index = i1*C + c
     };
     if (TILE == 4 * NTT_THREADS) {
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
         if (!a.last) {
             uint32_t colid = tile * C + c;
             uint32_t pos = (k1 << log_s) + (colid & (S - 1));        // position inside the block
-            x = Fr::mul_lazy(x, twp ? *twp : ld_fe(a.tw_inter + pos));                  // the work buffer holds values in [0, 2p)
+            x = Fr::mul_lazy(x, twp ? *twp : ld_fe(tw_inter + pos));                  // the work buffer holds values in [0, 2p)
             st_fe(out + (((size_t)(colid >> log_s) << a.log_m) + pos), x);
         } else {
             uint32_t blk = (uint32_t)(col_base(c) >> a.log_r);
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             uint32_t e = tid + i * NTT_THREADS, c = e & (C - 1), k1 = e >> logC;
-            tw[i] = ld_fe(a.tw_inter + ((k1 << log_s) + ((tile * C + c) & (S - 1))));
+            tw[i] = ld_fe(tw_inter + ((k1 << log_s) + ((tile * C + c) & (S - 1))));
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) store_one(tid + i * NTT_THREADS, &tw[i]);
@@ -227,6 +237,44 @@ __global__ void ntt_twiddle_kernel(fe_t* out, uint32_t count, uint64_t mult, uin
     st_fe(out + idx, acc);
 }
 
+
+// coset-major tables: out[b * cnt + m] = w_ext^(e mod 2^log_ext) * zeta^(z mod 3) with
+//   mode 0 (first-pass row factors, cnt = R1):   j = m * S,            e = b * j,              z = j          -> c_b^(S m)
+//   mode 1 (first-pass inter-pass table, cnt = n): m = k1 * S + i2,     e = E * i2 * k1 + b * i2, z = i2        -> w_n^(i2 k1) * c_b^i2
+// for the coset generators c_b = zeta * w_ext^b, b < E = 2^log_e
+__global__ void ntt_coset_table_kernel(fe_t* out, uint32_t cnt, uint32_t log_e, uint32_t log_ext, uint32_t log_s, int mode, const fe_t* pow2tab,
+                                       fe_t zeta, fe_t zeta2) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ((size_t)cnt << log_e)) return;
+    const uint64_t b = idx / cnt, m = idx % cnt;
+    uint64_t e, z;
+    if (mode == 0) {
+        const uint64_t j = m << log_s;
+        e = b * j;
+        z = j % 3;
+    } else {
+        const uint64_t i2 = m & (((uint64_t)1 << log_s) - 1), k1 = m >> log_s;
+        e = ((i2 * k1) << log_e) + b * i2;
+        z = i2 % 3;
+    }
+    e &= ((uint64_t)1 << log_ext) - 1;
+    fe_t acc = z == 0 ? Fr::one() : (z == 1 ? zeta : zeta2);
+    for (uint32_t q = 0; q < log_ext; q++)
+        if ((e >> q) & 1) acc = Fr::mul(acc, ld_fe(pow2tab + q));
+    st_fe(out + idx, acc);
+}
+// natural <-> coset-major order of an extended column: nat[E j + b] = cm[b n + j].  One thread per j moves E elements: the coset-major
+// side is coalesced across the wave, the natural side is E * 32 contiguous bytes per thread.
+__global__ __launch_bounds__(256) void ntt_cm_transpose_kernel(const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_e, int to_natural) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >> log_n) return;
+    const uint32_t E = 1u << log_e;
+    for (uint32_t b = 0; b < E; b++) {
+        const size_t cm = ((size_t)b << log_n) + j, nat = (j << log_e) + b;
+        if (to_natural) st_fe(out + nat, ld_fe(in + cm));
+        else st_fe(out + cm, ld_fe(in + nat));
+    }
+}
 
 struct NttPlan {
     uint32_t log_n = 0;
@@ -376,6 +424,130 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
     if (work) return arena_done(c->scratch, st);
+    return EZKL_OK;
+}
+
+
+// ---- coset-major extended evaluation: EvaluationDomain::coeff_to_extended as E = 2^(ext_k - k) transforms of n points -------------
+// The extended domain {zeta w_ext^i} is the union of the E cosets c_b H, c_b = zeta w_ext^b, H = <w_n>, w_n = w_ext^E; natural index
+// i = E j + b.  Evaluating p (degree < n) on coset b is an n-point NTT of (a_j c_b^j): the 2^(ext_k - k) zero-padding stages of the
+// 4n-point transform never run, and a rotation by r rows is a shift by r INSIDE a coset, so the quotient sweep of coset b touches
+// nothing but coset b of every column.  Output layout: out[b n + j] = p(c_b w_n^j).  The scaling c_b^j with j = i1 S + i2 is split:
+// c_b^(S i1) multiplies the rows at the first pass's load, c_b^i2 is folded into that pass's (per-coset) inter-pass twiddle table.
+struct CosetTables {
+    fe_t* pre = nullptr;      // E x R1
+    fe_t* inter = nullptr;    // E x n (nullptr for single-pass transforms)
+};
+static std::map<uint64_t, CosetTables> g_coset_tables;   // key log_n | log_ext << 8; guarded by the ctx mutex
+
+static int coset_tables_get(Ctx* c, hipStream_t st, NttPlan* p, uint32_t log_n, uint32_t log_ext, const fe_t& w_ext, CosetTables* out) {
+    const uint64_t key = (uint64_t)log_n | ((uint64_t)log_ext << 8);
+    auto it = g_coset_tables.find(key);
+    if (it != g_coset_tables.end()) { *out = it->second; return EZKL_OK; }
+    const uint32_t log_e = log_ext - log_n, lr = p->log_radix[0], log_s = log_n - lr;
+    std::vector<fe_t> pow2(log_ext ? log_ext : 1);
+    fe_t w = w_ext;
+    for (uint32_t b = 0; b < log_ext; b++) { pow2[b] = w; w = Fr::sqr(w); }
+    fe_t* d_pow2 = nullptr;
+    EZ_HIP(hipMalloc(&d_pow2, sizeof(fe_t) * pow2.size()));
+    EZ_HIP(hipMemcpyAsync(d_pow2, pow2.data(), sizeof(fe_t) * pow2.size(), hipMemcpyHostToDevice, st));
+    CosetTables t;
+    const fe_t zeta = fr_const(FrConst::ZETA), zeta2 = fr_const(FrConst::ZETA2);
+    const size_t n_pre = (size_t)1 << (lr + log_e);
+    EZ_HIP(hipMalloc(&t.pre, sizeof(fe_t) * n_pre));
+    hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_pre, 256)), dim3(256), 0, st, t.pre, 1u << lr, log_e, log_ext, log_s, 0, d_pow2, zeta, zeta2);
+    if (p->npass > 1) {
+        const size_t n_int = (size_t)1 << log_ext;
+        EZ_HIP(hipMalloc(&t.inter, sizeof(fe_t) * n_int));
+        hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_int, 256)), dim3(256), 0, st, t.inter, 1u << log_n, log_e, log_ext, log_s, 1, d_pow2, zeta, zeta2);
+    }
+    EZ_HIP(hipGetLastError());
+    EZ_HIP(hipStreamSynchronize(st));
+    EZ_HIP(hipFree(d_pow2));
+    g_coset_tables[key] = t;
+    *out = t;
+    return EZKL_OK;
+}
+
+static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_ext, const fe_t& w_n, const fe_t& w_ext, size_t batch,
+                          size_t in_stride, size_t out_stride) {
+    NttPlan* p = nullptr;
+    int rc = plan_get(c, st, log_n, w_n, &p);
+    if (rc) return rc;
+    CosetTables ct;
+    if ((rc = coset_tables_get(c, st, p, log_n, log_ext, w_ext, &ct))) return rc;
+    const uint32_t log_e = log_ext - log_n;
+    const size_t n = (size_t)1 << log_n, blocks = batch << log_e;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    fe_t* work = nullptr;
+    if (p->npass > 1) {
+        rc = arena_reserve(c->scratch, blocks * n * sizeof(fe_t), st, (void**)&work);
+        if (rc) return rc;
+    }
+    uint32_t log_m = log_n;
+    hipEvent_t e0, e1;
+    if ((rc = ev_pair(c, "coset_ntt", &e0, &e1))) return rc;
+    EZ_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < p->npass; i++) {
+        PassArgs a;
+        memset(&a, 0, sizeof a);
+        const bool first = (i == 0), last = (i + 1 == p->npass);
+        a.in = first ? in : work;
+        a.in_stride = first ? in_stride : n;
+        a.out = last ? out : work;
+        a.out_stride = last ? out_stride : n;
+        a.tw_local = p->tw_local[i];
+        a.tw_inter = first ? ct.inter : p->tw_inter[i];
+        a.log_n = log_n;
+        a.log_r = p->log_radix[i];
+        a.log_m = log_m;
+        a.log_tile = p->npass == 1 ? log_n : NTT_LOG_TILE;
+        if (a.log_tile < a.log_r) a.log_tile = a.log_r;
+        a.first = first;
+        a.last = last;
+        a.in_log_len = log_n;
+        a.npass = (uint32_t)p->npass;
+        for (int q = 0; q < 4; q++) a.log_radix[q] = p->log_radix[q];
+        a.cm = 1;
+        a.cm_log_e = log_e;
+        a.tw_pre = ct.pre;
+        if (last) {
+            const uint32_t logC = a.log_tile - a.log_r;
+            a.k1_major = (p->npass >= 2 && p->log_radix[0] >= logC) ? 1u : 0u;
+        }
+        const uint32_t tiles = 1u << (log_n - a.log_tile);
+        const size_t lds = 32u * ((size_t)1 << a.log_tile) + 32u * (a.log_r ? ((size_t)1 << (a.log_r - 1)) : 1);
+        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)blocks), dim3(NTT_THREADS), lds, st, a);
+        log_m -= a.log_r;
+    }
+    EZ_HIP(hipGetLastError());
+    EZ_HIP(hipEventRecord(e1, st));
+    if (work) return arena_done(c->scratch, st);
+    return EZKL_OK;
+}
+// `batch` coefficient columns (2^log_n each, in_stride apart) -> their coset-major extended forms (2^log_ext each, out_stride apart)
+int coset_cm_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_ext, const fe_t& w_n, const fe_t& w_ext, size_t batch,
+                 size_t in_stride, size_t out_stride) {
+    if (log_ext > 28 || log_n > log_ext || log_ext - log_n > 6 || batch == 0) return EZKL_ERR_INVALID;
+    size_t group = ((size_t)4 << 30) / ((size_t)32 << log_ext);
+    if (group < 1) group = 1;
+    if ((group << (log_ext - log_n)) > 32768) group = 32768 >> (log_ext - log_n);
+    for (size_t b0 = 0; b0 < batch; b0 += group) {
+        const size_t nb = batch - b0 < group ? batch - b0 : group;
+        int rc = coset_cm_chunk(c, st, in + b0 * in_stride, out + b0 * out_stride, log_n, log_ext, w_n, w_ext, nb, in_stride, out_stride);
+        if (rc) return rc;
+    }
+    return EZKL_OK;
+}
+int cm_transpose(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_e, bool to_natural) {
+    (void)c;
+    if (in == out || log_n + log_e > 28) return EZKL_ERR_INVALID;
+    hipLaunchKernelGGL(ntt_cm_transpose_kernel, dim3(cdiv((size_t)1 << log_n, 256)), dim3(256), 0, st, in, out, log_n, log_e, to_natural ? 1 : 0);
+    EZ_HIP(hipGetLastError());
     return EZKL_OK;
 }
 

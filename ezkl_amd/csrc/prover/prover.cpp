@@ -520,7 +520,11 @@ struct Backend {
         fill(o->ptr(), Fe::zero(), m);
         return o;
     }
-    std::vector<G1> commit_with(ezkl_bases_t b, const std::vector<Col>& hs) const {
+    // small = witness-shaped columns (advice, multiplicities): the batch runs as fused groups (ezkl_hip_msm_g1_batch_small_dev)
+    int msm_batch(ezkl_bases_t b, size_t first, const void* const* ptrs, size_t m, size_t len, void* out, bool small) const {
+        return small ? ezkl_hip_msm_g1_batch_small_dev(b, first, ptrs, m, len, out, nullptr) : ezkl_hip_msm_g1_batch_dev(b, first, ptrs, m, len, out, nullptr);
+    }
+    std::vector<G1> commit_with(ezkl_bases_t b, const std::vector<Col>& hs, bool small = false) const {
         std::vector<G1> out(hs.size());                      // zero bytes = the identity: what a rank contributes for work it does not do
         if (hs.empty()) return out;
         uint32_t rank = 0, log_world = 0;
@@ -531,7 +535,7 @@ struct Backend {
                 std::vector<uint32_t> mine;
                 for (uint32_t i = rank; i < m; i += world) { ptrs.push_back(hs[i]->ptr()); mine.push_back(i); }
                 std::vector<G1> part(ptrs.size());
-                check(ezkl_hip_msm_g1_batch_dev(b, 0, ptrs.data(), ptrs.size(), n, part.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+                check(msm_batch(b, 0, ptrs.data(), ptrs.size(), n, part.data(), small), "ezkl_hip_msm_g1_batch_dev");
                 for (size_t j = 0; j < mine.size(); j++) out[mine[j]] = part[j];
             } else {                                         // fewer columns than ranks: 2^t ranks per column, each a point range
                 uint32_t pieces = 1;
@@ -548,12 +552,12 @@ struct Backend {
         }
         std::vector<const void*> ptrs;
         for (auto& h : hs) ptrs.push_back(at(h, commit_first()));
-        check(ezkl_hip_msm_g1_batch_dev(b, shard.on() && shard.full_bases ? commit_first() : 0, ptrs.data(), ptrs.size(), commit_count(), out.data(), nullptr),
+        check(msm_batch(b, shard.on() && shard.full_bases ? commit_first() : 0, ptrs.data(), ptrs.size(), commit_count(), out.data(), small),
               "ezkl_hip_msm_g1_batch_dev");
         fold(out);
         return out;
     }
-    std::vector<G1> commit_lagrange(const std::vector<Col>& hs) const { return commit_with(gl, hs); }
+    std::vector<G1> commit_lagrange(const std::vector<Col>& hs, bool small = false) const { return commit_with(gl, hs, small); }
     std::vector<G1> commit(const std::vector<Col>& hs) const { return commit_with(g, hs); }
     Col lagrange_to_coeff(const Col& h) const {
         Col o = clone(h);
@@ -1480,13 +1484,17 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     std::vector<Col> inst_cols;
     for (uint32_t i = 0; i < cs.n_instance; i++) {
         invalid(instance_lens[i] > u, "too many instance values");
-        std::vector<U256> col(n, U256{0, 0, 0, 0});
+        std::vector<U256> vals(instance_lens[i]);
         for (uint32_t j = 0; j < instance_lens[i]; j++) {
-            std::memcpy(col[j].data(), (const uint8_t*)instances[i] + 32 * j, 32);
-            invalid(cmp(col[j], FR.p) >= 0, "non-canonical instance value");
-            T.common_scalar(Fe{col[j]});
+            std::memcpy(vals[j].data(), (const uint8_t*)instances[i] + 32 * j, 32);
+            invalid(cmp(vals[j], FR.p) >= 0, "non-canonical instance value");
+            T.common_scalar(Fe{vals[j]});
         }
-        inst_cols.push_back(be.upload(col));
+        // the column is zero outside its few public values: filled on the device, only the values cross PCIe (a zeroed 2^k-row host
+        // vector + a pageable 32 MiB copy cost ~5 ms of host time at k = 20 before the first advice column could move)
+        Col col = be.zeros(n);
+        be.set_rows(col, 0, vals);
+        inst_cols.push_back(col);
     }
     // 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges
     std::vector<Col> adv_cols(cs.n_advice);
@@ -1558,7 +1566,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         if (cs.shard.on() && cs.shard.full_bases) {         // divided by columns: the copies have landed (upload_end drains them)
             std::vector<Col> cols_;
             for (uint32_t c : idxs) cols_.push_back(adv_cols[c]);
-            commits = be.commit_lagrange(cols_);
+            commits = be.commit_lagrange(cols_, true);
         } else
             be.fold(commits);
         for (auto& p : commits) T.write_point(p);
@@ -1588,7 +1596,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         std::vector<Col> ms;
         for (auto& st : lk) ms.push_back(st.m);
         for (auto& st : lk) st.m_forms = be.forms_async(st.m, cs.ext_k);
-        for (auto& p : be.commit_lagrange(ms)) T.write_point(p);
+        for (auto& p : be.commit_lagrange(ms, true)) T.write_point(p);
     }
     sw.lap(1);
     // 3. beta, gamma

@@ -109,6 +109,11 @@ int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t bat
  * pipelined over several streams so the short reduce/sort kernels of one overlap the accumulation of the next */
 int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* const* scalars_dev, size_t batch, size_t n,
                               void* out_affine, void* stream);
+/* the same for WITNESS-SHAPED columns -- the caller knows that most scalars are small (advice columns, lookup multiplicities: one or
+ * two non-zero window digits each).  Such an MSM is a chain of ~17 latency-bound launches whatever its length, so the batch runs as
+ * fused groups of four columns per chain.  Any scalars are accepted (the result is the same); uniform ones just run a little slower. */
+int ezkl_hip_msm_g1_batch_small_dev(ezkl_bases_t h, size_t base_offset, const void* const* scalars_dev, size_t batch, size_t n,
+                                    void* out_affine, void* stream);
 /* the same pipeline fed one column at a time, for callers that PRODUCE columns one by one on the device (compressed
  * lookup columns, grand products): the MSM of column j runs while column j+1 is being computed.  (It does not help for
  * columns arriving through blocking copies from pageable host memory: those queue behind the kernels in flight --
@@ -159,6 +164,17 @@ int ezkl_hip_coset_ntt_batch(const void* const* in, void* const* out, size_t bat
                              uint32_t log_n, uint32_t log_n_ext, int inverse);
 int ezkl_hip_coset_ntt_dev(const void* in_dev, void* out_dev, size_t batch, size_t in_stride_elems,
                            size_t out_stride_elems, uint32_t log_n, uint32_t log_n_ext, int inverse, void* stream);
+
+/* coeff_to_extended with the result in COSET-MAJOR order: the extended domain {zeta w_ext^i} is the union of E = 2^(log_n_ext - log_n)
+ * cosets c_b H (c_b = zeta w_ext^b, H = <omega>), natural index i = E j + b; out[b 2^log_n + j] = p(c_b omega^j).  Computed as E
+ * transforms of 2^log_n points (the zero-padding stages of the 2^log_n_ext-point transform never run).  A rotation by r rows of the
+ * 2^log_n domain is a shift by r inside a coset, so ezkl_hip_eval_h_dev run with k = ext_k = log_n on the b-th cosets of its columns IS
+ * the quotient sweep of coset b (and a coset is the unit a multi-GPU prover hands to a rank).  in != out.
+ * ezkl_hip_cosets_transpose_dev converts one extended column between the two orders (to_natural = 1: coset-major -> natural, the order
+ * of halo2's pk.key `*_cosets` sections and of ezkl_hip_coset_ntt_dev). */
+int ezkl_hip_coeff_to_cosets_dev(const void* in_dev, void* out_dev, size_t batch, size_t in_stride_elems, size_t out_stride_elems,
+                                 uint32_t log_n, uint32_t log_n_ext, void* stream);
+int ezkl_hip_cosets_transpose_dev(const void* in_dev, void* out_dev, uint32_t log_n, uint32_t log_n_ext, int to_natural, void* stream);
 
 /* ---- element-wise Fr vector ops (icicle vec-ops surface) on device-resident data ---- */
 #define EZKL_VEC_ADD 0

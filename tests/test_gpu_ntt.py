@@ -189,3 +189,50 @@ def test_extended_2_24_full_oracle_compare(hip):
     assert (ext == ob.coeff_to_extended(p, 22, 24)).all()
     back = d.extended_to_coeff(ext)
     assert (back[: 1 << 22] == p).all() and (back[1 << 22:] == 0).all()
+
+
+def _to_cm(nat, k, ek):
+    """natural-order extended column -> coset-major: cm[b 2^k + j] = nat[E j + b]"""
+    E = 1 << (ek - k)
+    return np.ascontiguousarray(nat.reshape(1 << k, E, 4).transpose(1, 0, 2)).reshape(1 << ek, 4)
+
+
+@pytest.mark.parametrize("k,ek", [(1, 2), (3, 5), (6, 9), (8, 10), (10, 11), (11, 13), (12, 14), (13, 16), (16, 18), (17, 19)])
+def test_coset_major_matches_oracle(hip, golden_pk, k, ek):
+    """ezkl_hip_coeff_to_cosets_dev: E transforms of 2^k points = EvaluationDomain::coeff_to_extended with the cosets stored one after
+    the other -- byte-compared with the oracle's natural-order transform (and, at k = 6, with the reference's pk.key cosets), batched"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(900 + k)
+    n, ne, batch = 1 << k, 1 << ek, 3
+    polys = [rand_fr(rng, n) for _ in range(batch)]
+    if (k, ek) == (6, 9):
+        polys = [np.ascontiguousarray(golden_pk["fixed_polys"][i]) for i in range(batch)]
+    din = B.DeviceBuffer.from_numpy(np.stack(polys))
+    dout = B.DeviceBuffer.from_numpy(np.zeros((batch, ne, 4), np.uint64))
+    B.coeff_to_cosets_dev(din.ptr, dout.ptr, k, ek, batch=batch)
+    got = dout.to_numpy(shape=(batch, ne, 4))
+    for b in range(batch):
+        want = ob.coeff_to_extended(polys[b], k, ek)
+        if (k, ek) == (6, 9):
+            assert (want == golden_pk["fixed_cosets"][b]).all()
+        assert (got[b] == _to_cm(want, k, ek)).all()
+    # the transposition both ways
+    dnat = B.DeviceBuffer.from_numpy(np.zeros((ne, 4), np.uint64))
+    B.cosets_transpose_dev(dout.ptr, dnat.ptr, k, ek, to_natural=True)
+    assert (dnat.to_numpy(shape=(ne, 4)) == ob.coeff_to_extended(polys[0], k, ek)).all()
+    dcm = B.DeviceBuffer.from_numpy(np.zeros((ne, 4), np.uint64))
+    B.cosets_transpose_dev(dnat.ptr, dcm.ptr, k, ek, to_natural=False)
+    assert (dcm.to_numpy(shape=(ne, 4)) == got[0]).all()
+
+
+@pytest.mark.parametrize("k,ek", [(20, 22), (22, 24)])
+def test_coset_major_full_oracle_compare(hip, k, ek):
+    """the extended domains of the k = 20 and k = 22 circuits (degree 5): the coset-major transform against the oracle's
+    coeff_to_extended over the WHOLE output"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(5000 + k)
+    p = rand_fr(rng, 1 << k)
+    din = B.DeviceBuffer.from_numpy(p)
+    dout = B.DeviceBuffer.from_numpy(np.zeros((1 << ek, 4), np.uint64))
+    B.coeff_to_cosets_dev(din.ptr, dout.ptr, k, ek)
+    assert (dout.to_numpy(shape=(1 << ek, 4)) == _to_cm(ob.coeff_to_extended(p, k, ek), k, ek)).all()

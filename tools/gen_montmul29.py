@@ -13,12 +13,18 @@ FR = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 MASK = (1 << 29) - 1
 
 
-def gen(name, mod, square=False):
-    """square=True: r = a^2 / 2^261.  Column k of a square is sum_{i<j} (2 a_i) a_j + a_{k/2}^2: with the doubled limbs d_i = 2 a_i
+def gen(name, mod, square=False, ilp2=False):
+    """ilp2=True: two accumulator chains.  The product above is ONE dependent chain of ~190 instructions through v[16:17]; a dependent
+    v_mad_u64_u32 issues 16 cycles after its producer, so a wave alone runs at a quarter of the issue rate and three waves per SIMD (the
+    MSM's accumulate kernel) at three quarters.  The partial products a_i b_(k-i) of a column do not depend on the reduction: they are
+    summed in a second accumulator v[18:19] (a fresh chain per column, emitted interleaved with the previous column's reduction chain)
+    and enter the main chain with one 64-bit addition: 17 more instructions, critical path 141 instead of 190.
+    square=True: r = a^2 / 2^261.  Column k of a square is sum_{i<j} (2 a_i) a_j + a_{k/2}^2: with the doubled limbs d_i = 2 a_i
     prepared once (8 shifts; limbs < 2^31) the 81 partial products become 45 -- 159 issue slots instead of 186."""
     p = [(mod >> (29 * i)) & MASK for i in range(9)]
     pinv = (-pow(mod, -1, 1 << 29)) % (1 << 29)
     A0, A1 = 16, 17                      # accumulator pair (even aligned): the only fixed VGPRs
+    T0, T1 = 18, 19                      # ilp2: the a*b column sums
     # m_k lives in the register of output r_k: m_k is last read in column k + 8, r_k is written in column k + 9
     M = ["%%[r%d]" % i for i in range(9)]
     SP = [16 + i for i in range(9)]
@@ -38,7 +44,42 @@ def gen(name, mod, square=False):
     if square:
         for i in range(8):
             L.append("v_lshlrev_b32 %%[d%d], 1, %%[a%d]" % (i, i))
-    for k in range(17):
+    if ilp2:
+        def tchain(k):
+            out, fresh = [], True
+            for i in range(max(0, k - 8), min(k, 8) + 1):
+                if not square: ops = ("%%[a%d]" % i, "%%[b%d]" % (k - i))
+                elif i < k - i: ops = ("%%[d%d]" % i, "%%[a%d]" % (k - i))
+                elif i == k - i: ops = ("%%[a%d]" % i, "%%[a%d]" % i)
+                else: continue
+                out.append("v_mad_u64_u32 v[%d:%d], vcc, %s, %s, %s" % (T0, T1, ops[0], ops[1], "0" if fresh else "v[%d:%d]" % (T0, T1)))
+                fresh = False
+            return out
+        def achain(k):
+            out = []
+            if k == 0: out.append("v_mov_b32 v%d, v%d" % (A0, T0)); out.append("v_mov_b32 v%d, v%d" % (A1, T1))
+            else: out.append("v_lshl_add_u64 v[%d:%d], v[%d:%d], 0, v[%d:%d]" % (A0, A1, T0, T1, A0, A1))
+            for i in (range(0, k) if k < 9 else range(k - 8, 9)):
+                out.append("v_mad_u64_u32 v[%d:%d], vcc, %s, s%d, v[%d:%d]" % (A0, A1, M[i], SP[k - i], A0, A1))
+            if k < 9:
+                out.append("v_mul_lo_u32 %s, v%d, s%d" % (M[k], A0, SINV))
+                out.append("v_and_b32 %s, s%d, %s" % (M[k], SMASK, M[k]))
+                out.append("v_mad_u64_u32 v[%d:%d], vcc, %s, s%d, v[%d:%d]" % (A0, A1, M[k], SP[0], A0, A1))
+            else:
+                out.append("v_and_b32 %%[r%d], s%d, v%d" % (k - 9, SMASK, A0))
+            out.append("v_lshrrev_b64 v[%d:%d], 29, v[%d:%d]" % (A0, A1, A0, A1))
+            return out
+        L += tchain(0)
+        for k in range(17):
+            a, t = achain(k), (tchain(k + 1) if k < 16 else [])
+            # the first instruction of the reduction chain reads the finished column sum: it goes first, then the two chains alternate
+            L.append(a[0])
+            if k == 0: L.append(a[1]); a = a[1:]
+            ai, ti = 1, 0
+            while ai < len(a) or ti < len(t):
+                if ti < len(t): L.append(t[ti]); ti += 1
+                if ai < len(a): L.append(a[ai]); ai += 1
+    for k in range(17 if not ilp2 else 0):
         for i in range(max(0, k - 8), min(k, 8) + 1):
             if not square:
                 mac("%%[a%d]" % i, "%%[b%d]" % (k - i))
@@ -67,7 +108,7 @@ def gen(name, mod, square=False):
     o.append("    asm(" + body)
     o.append("        : " + ", ".join('[r%d] "=&v"(r[%d])' % (i, i) for i in range(9)) + (", " + ", ".join('[d%d] "=&v"(d[%d])' % (i, i) for i in range(8)) if square else ""))
     o.append("        : " + ", ".join('[a%d] "v"(a[%d])' % (i, i) for i in range(9)) + ("" if square else ", " + ", ".join('[b%d] "v"(b[%d])' % (i, i) for i in range(9))))
-    o.append('        : "v16", "v17", ' + ", ".join('"s%d"' % s for s in range(16, 27)) + ', "vcc");')
+    o.append('        : "v16", "v17", ' + ('"v18", "v19", ' if ilp2 else "") + ", ".join('"s%d"' % s for s in range(16, 27)) + ', "vcc");')
     o.append("}")
     return "\n".join(o) + "\n"
 
@@ -107,7 +148,8 @@ def consts(tag, mod):
 
 
 hdr = "// GENERATED by tools/gen_montmul29.py -- do not edit\n#pragma once\n#ifndef __HIPCC_RTC__            // hiprtc (the eval_h JIT) supplies the fixed-width types itself\n#include <stdint.h>\n#endif\nnamespace ezkl {\n"
-text = hdr + consts("Fq", FQ) + consts("Fr", FR) + gen("mont_mul29_fq", FQ) + gen("mont_mul29_fr", FR) + gen("mont_sqr29_fq", FQ, True) + gen("mont_sqr29_fr", FR, True) + "}  // namespace ezkl\n"
+text = (hdr + consts("Fq", FQ) + consts("Fr", FR) + gen("mont_mul29_fq", FQ) + gen("mont_mul29_fr", FR) + gen("mont_sqr29_fq", FQ, True) + gen("mont_sqr29_fr", FR, True) +
+        gen("mont_mul29i_fq", FQ, ilp2=True) + gen("mont_sqr29i_fq", FQ, True, ilp2=True) + gen("mont_mul29i_fr", FR, ilp2=True) + "}  // namespace ezkl\n")
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ezkl_amd", "csrc", "montmul29_gen.hpp")
 open(path, "w").write(text)
 print("wrote", path, len(text.splitlines()), "lines")

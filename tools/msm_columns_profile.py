@@ -67,7 +67,11 @@ def reduce(db_path):
             msms.append(curm)
         if curm is not None and short in KERNELS:
             curm[short] = curm.get(short, 0.0) + (e - s) / 1e3
-    order = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])["order"] if len(sys.argv) > 3 else None
+    order = None
+    if len(sys.argv) > 3:
+        for line in open(sys.argv[3]):
+            if line.startswith('{"order"'):
+                order = json.loads(line)["order"]
     msms = msms[1:]                                   # the warm-up MSM
     print("%-12s" % "column" + "".join("%9s" % k.replace("msm_", "").replace("_kernel", "")[:8] for k in KERNELS) + "%9s%9s" % ("non-acc", "total"))
     for i in range(REPS - 1, len(msms), REPS):        # the last repetition of each column
