@@ -201,6 +201,57 @@ int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root) {
     return EZKL_OK;
 }
 
+int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes) {
+    if (!buf_host || bytes == 0 || bytes > ((size_t)1 << 24)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (!g_comm.comm) return EZKL_ERR_INVALID;
+    const size_t total = bytes * (size_t)g_comm.world;
+    if (g_comm.stage_bytes < total) {
+        if (g_comm.stage) EZ_HIP(hipFree(g_comm.stage));
+        EZ_HIP(hipMalloc(&g_comm.stage, total));
+        g_comm.stage_bytes = total;
+    }
+    char* st = (char*)g_comm.stage;
+    char* h = (char*)buf_host;
+    EZ_HIP(hipMemcpyAsync(st + bytes * (size_t)g_comm.rank, h + bytes * (size_t)g_comm.rank, bytes, hipMemcpyHostToDevice, g_comm.st));
+    EZ_RCCL(g_rccl.AllGather(st + bytes * (size_t)g_comm.rank, st, bytes, ncclUint8, g_comm.comm, g_comm.st));
+    EZ_HIP(hipMemcpyAsync(h, st, total, hipMemcpyDeviceToHost, g_comm.st));
+    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    return EZKL_OK;
+}
+
+// all-to-all with any number of segments per peer (see include/ezkl_hip.h): matching is by order per (sender, receiver) pair, which is
+// how ncclSend / ncclRecv inside one group match; the segments to self are matched the same way and copied device-to-device.
+int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
+    if ((n_sends && !sends) || (n_recvs && !recvs)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (!g_comm.comm) return EZKL_ERR_INVALID;
+    const int me = g_comm.rank;
+    for (size_t i = 0; i < n_sends; i++)
+        if (sends[i].peer < 0 || sends[i].peer >= g_comm.world || (!sends[i].ptr && sends[i].bytes)) return EZKL_ERR_INVALID;
+    for (size_t i = 0; i < n_recvs; i++)
+        if (recvs[i].peer < 0 || recvs[i].peer >= g_comm.world || (!recvs[i].ptr && recvs[i].bytes)) return EZKL_ERR_INVALID;
+    EZ_HIP(hipStreamSynchronize(c->stream));          // what the library stream produced is what gets sent
+    {
+        size_t j = 0;                                 // self segments, in order
+        for (size_t i = 0; i < n_sends; i++) {
+            if (sends[i].peer != me) continue;
+            while (j < n_recvs && recvs[j].peer != me) j++;
+            if (j == n_recvs || recvs[j].bytes != sends[i].bytes) return EZKL_ERR_INVALID;
+            if (sends[i].bytes) EZ_HIP(hipMemcpyAsync(recvs[j].ptr, sends[i].ptr, sends[i].bytes, hipMemcpyDeviceToDevice, g_comm.st));
+            j++;
+        }
+    }
+    EZ_RCCL(g_rccl.GroupStart());
+    for (size_t i = 0; i < n_sends; i++)
+        if (sends[i].peer != me && sends[i].bytes) EZ_RCCL(g_rccl.Send(sends[i].ptr, sends[i].bytes, ncclUint8, sends[i].peer, g_comm.comm, g_comm.st));
+    for (size_t i = 0; i < n_recvs; i++)
+        if (recvs[i].peer != me && recvs[i].bytes) EZ_RCCL(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, ncclUint8, recvs[i].peer, g_comm.comm, g_comm.st));
+    EZ_RCCL(g_rccl.GroupEnd());
+    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    return EZKL_OK;
+}
+
 // all-to-all on device pointers: for every peer p, send_len[p] bytes at send_dev + send_off[p] go to p, recv_len[p] bytes from p land
 // at recv_dev + recv_off[p].  All peers at once (grouped ncclSend / ncclRecv); the slice to self is a device-to-device copy.
 int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, const size_t* send_len, void* recv_dev, const size_t* recv_off,

@@ -104,6 +104,8 @@ struct Fe {
 // canonical 2^28-th root of unity ROOT = 7^((r-1)/2^28) and DELTA = 7^(2^28), Montgomery form
 constexpr U256 FR_ROOT = {0x9632c7c5b639feb8ull, 0x985ce3400d0ff299ull, 0xb2dd880001b0ecd8ull, 0x1d69070d6d98ce29ull};
 constexpr U256 FR_DELTA = {0x9a0c322befd78855ull, 0x46e82d14249b563cull, 0x5983a663e0b0b7a7ull, 0x22ab452baaa111adull};
+// ZETA: the primitive cube root of unity halo2 uses as the generator of the extended coset (EvaluationDomain::g_coset), Montgomery form
+constexpr U256 FR_ZETA = {0x0363f29955fcd653ull, 0x73e7950b5fc1e200ull, 0xc5fce83e576d9d24ull, 0x059c805da1c3a4d4ull};
 inline Fe omega(uint32_t k) {
     Fe w{FR_ROOT};
     for (uint32_t i = k; i < 28; i++) w = w * w;

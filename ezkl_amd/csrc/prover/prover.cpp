@@ -56,7 +56,12 @@ struct Shard {
     void* user = nullptr;
     ezkl_gather_fn gather = nullptr;  // optional: the quotient sweep sharded by rows (ezkl_prover_cs_set_sweep_gather)
     void* gather_user = nullptr;
+    // optional: columns and arguments have owners (ezkl_prover_cs_set_shard_exchange)
+    ezkl_allgather_host_fn allgather_host = nullptr;
+    ezkl_exchange_fn exchange = nullptr;
+    void* xuser = nullptr;
     mutable uint64_t sharded_sweeps = 0;
+    mutable uint64_t stats[4] = {0, 0, 0, 0};     // ezkl_prover_cs_shard_stats
     // the SRS handles hold ALL 2^k points on every rank (ezkl_prover_cs_set_shard_full_bases; 288 GB of HBM per GPU: a 2^22 base set
     // with its window tables is 3.5 GB): a commit batch is then divided by COLUMNS -- whole MSMs, which keep the per-call tail of a
     // 2^k-point MSM off the critical path instead of paying it on every 2^k / world slice -- and by point ranges inside a column
@@ -74,6 +79,14 @@ struct Shard {
         while ((1u << log_world) < world) log_world++;
         return true;
     }
+};
+// Who does what in one proof.  One rank (or a sharded prover without the exchange callbacks): everything is mine.  Owner mode: witness
+// column / argument number i belongs to rank i mod world; only its owner computes, transforms and commits it.
+struct Topo {
+    uint32_t world = 1, rank = 0, log_world = 0;
+    bool owners = false;
+    bool mine(size_t i) const { return !owners || (uint32_t)(i % world) == rank; }
+    uint32_t owner(size_t i) const { return owners ? (uint32_t)(i % world) : rank; }
 };
 struct ConstraintSystem {
     uint32_t k = 0, n = 0, n_advice = 0, n_fixed = 0, n_instance = 0, n_challenges = 0;
@@ -443,8 +456,16 @@ struct Backend {
     uint32_t k, n;
     ezkl_bases_t g, gl;
     Shard shard;
+    Topo topo;
     Fe one = Fe::one();
-    Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_, const Shard& sh = Shard()) : k(k_), n(n_), g(g_), gl(gl_), shard(sh) {}
+    Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_, const Shard& sh = Shard()) : k(k_), n(n_), g(g_), gl(gl_), shard(sh) {
+        uint32_t r = 0, lw = 0;
+        if (shard.on() && shard.geometry(n, r, lw)) {
+            topo.world = 1u << lw; topo.rank = r; topo.log_world = lw;
+            // owner mode needs complete base sets on every rank (whole MSMs by the owner) and the exchange callbacks
+            topo.owners = topo.world > 1 && shard.full_bases && shard.exchange && shard.allgather_host && shard.gather;
+        }
+    }
     Backend(const Backend&) = delete;
     ~Backend() {
         if (aux) {                             // also on unwinding: nothing queued on the aux stream may outlive its columns
@@ -468,7 +489,8 @@ struct Backend {
     struct Forms {
         Col poly, coset;
     };
-    // lagrange -> (coefficients, extended coset), stream-ordered on the aux stream; `lagrange` must stay untouched until aux_sync()
+    // lagrange -> (coefficients, extended cosets in COSET-MAJOR order: element b n + j = p(zeta w_ext^b omega^j)), stream-ordered on the aux
+    // stream; `lagrange` must stay untouched until aux_sync()
     Forms forms_alloc(uint32_t ext_k) const { return Forms{alloc(n), alloc((size_t)1 << ext_k)}; }
     Forms forms_async(const Col& lagrange, uint32_t ext_k, const Forms* pre = nullptr) {
         Forms f = pre ? *pre : forms_alloc(ext_k);
@@ -481,7 +503,7 @@ struct Backend {
         const Fe winv = omega(k).inv();
         check(ezkl_hip_vec_scale_dev(lagrange->ptr(), one.v.data(), f.poly->ptr(), n, st), "ezkl_hip_vec_scale_dev");
         check(ezkl_hip_ntt_dev(f.poly->ptr(), k, winv.v.data(), 1, 1, n, st), "ezkl_hip_ntt_dev");
-        check(ezkl_hip_coset_ntt_dev(f.poly->ptr(), f.coset->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, 0, st), "ezkl_hip_coset_ntt_dev");
+        check(ezkl_hip_coeff_to_cosets_dev(f.poly->ptr(), f.coset->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, st), "ezkl_hip_coeff_to_cosets_dev");
         return f;
     }
     size_t commit_first() const { return shard.on() ? shard.lo : 0; }
@@ -559,21 +581,76 @@ struct Backend {
     }
     std::vector<G1> commit_lagrange(const std::vector<Col>& hs, bool small = false) const { return commit_with(gl, hs, small); }
     std::vector<G1> commit(const std::vector<Col>& hs) const { return commit_with(g, hs); }
+    // owner mode: hs[i] is a column on its owner and null elsewhere; every rank commits what it holds (whole MSMs), the identity for
+    // the rest, and the fold sums the partials -- the commitments of the batch on every rank
+    std::vector<G1> commit_owned(ezkl_bases_t b, const std::vector<Col>& hs, bool small) const {
+        std::vector<G1> out(hs.size());
+        std::vector<const void*> ptrs;
+        std::vector<size_t> where;
+        for (size_t i = 0; i < hs.size(); i++)
+            if (hs[i]) { ptrs.push_back(hs[i]->ptr()); where.push_back(i); }
+        if (!ptrs.empty()) {
+            std::vector<G1> part(ptrs.size());
+            check(msm_batch(b, 0, ptrs.data(), ptrs.size(), n, part.data(), small), "ezkl_hip_msm_g1_batch_dev");
+            for (size_t j = 0; j < where.size(); j++) out[where[j]] = part[j];
+        }
+        fold(out);
+        return out;
+    }
+    // a batch of witness columns in whichever mode the prover runs: by owner, or replicated (commit_with: one rank, by points, by columns)
+    std::vector<G1> commit_columns(ezkl_bases_t b, const std::vector<Col>& hs, bool small) const {
+        return topo.owners ? commit_owned(b, hs, small) : commit_with(b, hs, small);
+    }
+    // owner mode: the commitment of the SUM over ranks of a per-rank partial polynomial (SHPLONK's h and L: linear in the polynomials
+    // each rank owns): every rank commits its own partial with the whole base set, the fold adds the points
+    G1 commit_sum(ezkl_bases_t b, const Col& h) const {
+        if (!topo.owners) return commit_with(b, {h})[0];
+        std::vector<G1> out(1);
+        const void* ptr = h->ptr();
+        check(msm_batch(b, 0, &ptr, 1, n, out.data(), false), "ezkl_hip_msm_g1_batch_dev");
+        fold(out);
+        return out[0];
+    }
+    // all_gather of `per` field elements per rank (host): v[r * per + i] valid on rank r going in, everywhere coming out
+    void allgather_fe(std::vector<Fe>& v, size_t per) const {
+        if (!topo.owners || per == 0) return;
+        if (shard.allgather_host(shard.xuser, v.data(), per * sizeof(Fe)) != 0) throw Error(EZKL_ERR_INVALID, "allgather callback failed");
+    }
     Col lagrange_to_coeff(const Col& h) const {
         Col o = clone(h);
         const Fe winv = omega(k).inv();
         check(ezkl_hip_ntt_dev(o->ptr(), k, winv.v.data(), 1, 1, n, nullptr), "ezkl_hip_ntt_dev");
         return o;
     }
+    // The extended domain lives in COSET-MAJOR order everywhere in this prover (ezkl_hip_coeff_to_cosets_dev): E = 2^(ext_k - k) cosets
+    // of n rows, coset b = {zeta w_ext^b omega^j}.  A rotation is a shift inside a coset, the vanishing polynomial is a constant on a
+    // coset, and a coset (or a row range of one) is the unit of the quotient sweep.
     Col coeff_to_extended(const Col& h, uint32_t ext_k) const {
         Col o = alloc((size_t)1 << ext_k);
-        check(ezkl_hip_coset_ntt_dev(h->ptr(), o->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, 0, nullptr), "ezkl_hip_coset_ntt_dev");
+        check(ezkl_hip_coeff_to_cosets_dev(h->ptr(), o->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, nullptr), "ezkl_hip_coeff_to_cosets_dev");
         return o;
     }
-    void extended_to_coeff(const Col& h, uint32_t ext_k) const {
-        check(ezkl_hip_coset_ntt_dev(h->ptr(), h->ptr(), 1, (size_t)1 << ext_k, (size_t)1 << ext_k, k, ext_k, 1, nullptr), "ezkl_hip_coset_ntt_dev");
+    // coset-major evaluations -> the 2^ext_k coefficients (natural order): transposed into the natural order of the extended domain,
+    // then EvaluationDomain::extended_to_coeff as one inverse transform (one column per proof: h)
+    Col extended_to_coeff(const Col& h, uint32_t ext_k) const {
+        Col o = alloc((size_t)1 << ext_k);
+        if (ext_k == k) scale_into(h->ptr(), one, o->ptr(), n);
+        else check(ezkl_hip_cosets_transpose_dev(h->ptr(), o->ptr(), k, ext_k, 1, nullptr), "ezkl_hip_cosets_transpose_dev");
+        check(ezkl_hip_coset_ntt_dev(o->ptr(), o->ptr(), 1, (size_t)1 << ext_k, (size_t)1 << ext_k, k, ext_k, 1, nullptr), "ezkl_hip_coset_ntt_dev");
+        return o;
     }
-    void divide_by_vanishing(const Col& h, uint32_t ext_k) const { check(ezkl_hip_divide_by_vanishing_dev(h->ptr(), k, ext_k, nullptr), "ezkl_hip_divide_by_vanishing_dev"); }
+    // natural <-> coset-major order of one extended column (key files hold halo2's natural order)
+    Col cosets_reorder(const Col& h, uint32_t ext_k, bool to_natural) const {
+        Col o = alloc((size_t)1 << ext_k);
+        if (ext_k == k) scale_into(h->ptr(), one, o->ptr(), n);
+        else check(ezkl_hip_cosets_transpose_dev(h->ptr(), o->ptr(), k, ext_k, to_natural ? 1 : 0, nullptr), "ezkl_hip_cosets_transpose_dev");
+        return o;
+    }
+    // 1 / Z_H on coset b: Z_H(c_b omega^j) = c_b^n - 1, c_b = zeta w_ext^b (EvaluationDomain::divide_by_vanishing_poly's t_evaluations)
+    Fe vanishing_inv(uint32_t ext_k, uint32_t b) const {
+        const Fe cb = Fe{FR_ZETA} * omega(ext_k).pow((uint64_t)b);
+        return (cb.pow((uint64_t)n) - Fe::one()).inv();
+    }
     Fe eval_poly(const Col& h, size_t m, const Fe& x) const {
         Fe out;
         check(ezkl_hip_eval_poly_dev(h->ptr(), m, x.v.data(), out.v.data(), nullptr), "ezkl_hip_eval_poly_dev");
@@ -658,22 +735,29 @@ struct Backend {
         return d_num;
     }
     // all chunks of the permutation argument at once: the denominators of every chunk share ONE batch inversion (see
-    // lookup_grand_sums); chunk j starts from the value chunk j-1 reaches on row `usable` (the chaining of permutation::prover::commit)
+    // lookup_grand_sums); chunk j starts from the value chunk j-1 reaches on row `usable` (the chaining of permutation::prover::commit).
+    // Owner mode: a rank computes the chunks it owns as UNCHAINED running products z'_j (z'_j[0] = 1); z_j = z'_j * prod_{i<j} z'_i[usable],
+    // so the only thing the ranks exchange is one field element per chunk.  zs[j] is null for chunks of other ranks.
     std::vector<Col> permutation_products(const std::vector<std::vector<Col>>& values, const std::vector<std::vector<Col>>& sigmas, const Fe& beta,
                                           const Fe& gamma, const Col& omega_col, uint32_t usable) const {
         const size_t nch = values.size();
-        std::vector<Col> zs;
+        std::vector<Col> zs(nch);
         if (!nch) return zs;
-        Col dens = alloc(nch * n);
+        std::vector<size_t> mine;
+        for (size_t c = 0; c < nch; c++)
+            if (topo.mine(c)) mine.push_back(c);
+        Col dens = mine.empty() ? Col() : alloc(mine.size() * n);
         const Fe delta{FR_DELTA};
-        uint32_t first = 0;
-        for (size_t c = 0; c < nch; c++) {
+        std::vector<uint32_t> first(nch, 0);
+        for (size_t c = 1; c < nch; c++) first[c] = first[c - 1] + (uint32_t)values[c - 1].size();
+        for (size_t q = 0; q < mine.size(); q++) {
+            const size_t c = mine[q];
             const uint32_t m = (uint32_t)values[c].size();
             std::vector<Col> cols(values[c]);
             cols.insert(cols.end(), sigmas[c].begin(), sigmas[c].end());
             cols.push_back(omega_col);
             std::vector<Fe> chal = {beta, gamma};
-            Fe dp = delta.pow(first);
+            Fe dp = delta.pow(first[c]);
             for (uint32_t j = 0; j < m; j++) { chal.push_back(beta * dp); dp = dp * delta; }
             Program den(k, k), num(k, k);
             Src acc{}, accn{};
@@ -684,18 +768,24 @@ struct Backend {
                 accn = j == 0 ? tn : num.mul(accn, tn);
             }
             Col d_num = alloc(n);
-            den.run(cols, chal, at(dens, c * n));
+            den.run(cols, chal, at(dens, q * n));
             num.run(cols, chal, d_num->ptr());
-            zs.push_back(d_num);
-            first += m;
+            zs[c] = d_num;
         }
-        invert(dens->ptr(), nch * n);
-        Fe last = Fe::one();
-        for (size_t c = 0; c < nch; c++) {
-            vec(EZKL_VEC_MUL, zs[c]->ptr(), at(dens, c * n), zs[c]->ptr(), n);
+        if (!mine.empty()) invert(dens->ptr(), mine.size() * n);
+        std::vector<Fe> lasts((size_t)topo.world * nch, Fe::zero());       // slice r: the unchained z'_c[usable] of rank r's chunks
+        for (size_t q = 0; q < mine.size(); q++) {
+            const size_t c = mine[q];
+            vec(EZKL_VEC_MUL, zs[c]->ptr(), at(dens, q * n), zs[c]->ptr(), n);
             scan(EZKL_VEC_MUL, true, zs[c]->ptr(), zs[c]->ptr(), n);
-            if (c) scale(zs[c], last, n);
-            if (c + 1 < nch) last = get_row(zs[c], usable);
+        }
+        for (size_t c : mine)
+            if (c + 1 < nch) lasts[(size_t)topo.rank * nch + c] = get_row(zs[c], usable);
+        allgather_fe(lasts, nch);
+        Fe run = Fe::one();
+        for (size_t c = 0; c < nch; c++) {
+            if (c && zs[c]) scale(zs[c], run, n);
+            if (c + 1 < nch) run = run * lasts[(size_t)topo.owner(c) * nch + c];
         }
         return zs;
     }
@@ -900,9 +990,16 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
         for (auto& c : cols) put_poly(c, m);
     };
     const size_t n = cs.n, ne = (size_t)1 << cs.ext_k;
-    put_poly(pk.l0, ne); put_poly(pk.l_last, ne); put_poly(pk.l_active, ne);
-    put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_vec(pk.fixed_cosets, ne);
-    put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_vec(pk.sigma_cosets, ne);
+    // the resident extended columns are coset-major; the file holds halo2's natural order of the extended domain
+    auto nat = [&](const Col& c) { return be.cosets_reorder(c, cs.ext_k, true); };
+    auto put_ext_vec = [&](const std::vector<Col>& cols) {
+        put_be32(o, (uint32_t)cols.size());
+        for (size_t i = 0; i < cols.size(); i++) put_be32(o, (uint32_t)ne);
+        for (auto& c : cols) put_poly(nat(c), ne);
+    };
+    put_poly(nat(pk.l0), ne); put_poly(nat(pk.l_last), ne); put_poly(nat(pk.l_active), ne);
+    put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_vec(pk.fixed_cosets);
+    put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(pk.sigma_cosets);
     return o;
 }
 static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* buf, size_t len) {
@@ -957,9 +1054,13 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
         for (size_t i = 0; i < count; i++) cols.push_back(get_poly(m));
     };
     const size_t n = cs.n, ne = (size_t)1 << cs.ext_k;
-    pk->l0 = get_poly(ne); pk->l_last = get_poly(ne); pk->l_active = get_poly(ne);
+    // extended columns: natural order in the file, coset-major in HBM
+    auto cm = [&](const Col& c) { return be.cosets_reorder(c, cs.ext_k, false); };
+    pk->l0 = cm(get_poly(ne)); pk->l_last = cm(get_poly(ne)); pk->l_active = cm(get_poly(ne));
     get_vec(pk->fixed_values, cs.n_fixed, n); get_vec(pk->fixed_polys, cs.n_fixed, n); get_vec(pk->fixed_cosets, cs.n_fixed, ne);
     get_vec(pk->sigma_values, cs.perm.size(), n); get_vec(pk->sigma_polys, cs.perm.size(), n); get_vec(pk->sigma_cosets, cs.perm.size(), ne);
+    for (auto& c : pk->fixed_cosets) c = cm(c);
+    for (auto& c : pk->sigma_cosets) c = cm(c);
     invalid(off != len, "trailing bytes in the proving key");
     // derived columns that the file does not hold
     pk->omega_col = be.omega_powers();
@@ -1164,11 +1265,13 @@ struct Rng {
 // ------------------------------------------------------------------ SHPLONK (BDFG20) multi-point opening
 struct OpenQuery {
     std::vector<uint32_t> key;       // polynomial identity (kind, index)
-    Col poly;
+    Col poly;                        // null on ranks that do not own the polynomial (owner mode)
     Fe point, eval;
+    bool mine = true;                // this rank carries the polynomial through the opening (every polynomial has exactly one such rank)
 };
 struct PolyEvals {
     Col poly;
+    bool mine;
     std::map<U256, std::pair<Fe, Fe>> ev;      // canonical point -> (point, eval)
 };
 static bool u256_less(const U256& a, const U256& b) { return cmp(a, b) < 0; }
@@ -1199,6 +1302,11 @@ static Fe eval_small(const std::vector<Fe>& c, const Fe& x) {
     for (size_t i = c.size(); i-- > 0;) acc = acc * x + c[i];
     return acc;
 }
+// The opening is LINEAR in the polynomials: q_S = sum_i ys^i p_i, h = sum_S v^S (q_S - r_S) / Z_S, L = sum_S c_S (q_S - r_S(u)) - c h.
+// A sharded prover in owner mode therefore never moves a polynomial: every rank forms the same expressions over the polynomials it
+// owns (with the global coefficients ys^i, v^S, c_S and the partial evaluations of ITS polynomials: each partial q_S - r_S still
+// vanishes on S, so the divisions stay exact), commits its partial h and L with the whole base set, and the two folds add the
+// points.  With one rank (or replicated columns) every polynomial is `mine` and this is the plain prover.
 static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQuery>& qs, uint32_t n) {
     // group queries by polynomial (first appearance), then polynomials by their point set (first appearance)
     std::vector<PolyEvals> polys;
@@ -1207,7 +1315,7 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
         auto it = by_key.find(q.key);
         if (it == by_key.end()) {
             it = by_key.emplace(q.key, polys.size()).first;
-            polys.push_back(PolyEvals{q.poly, {}});
+            polys.push_back(PolyEvals{q.poly, q.mine, {}});
         }
         polys[it->second].ev[q.point.canonical()] = {q.point, q.eval};
     }
@@ -1242,22 +1350,27 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
     for (auto& gr : groups)
         for (size_t i = 0; i < gr.pts.size(); i++) pt_fe[gr.pts[i]] = gr.pts_fe[i];
     struct Combo {
-        Col q;
+        Col q;                 // null: this rank owns no member of the group
         std::vector<Fe> r;
     };
     std::vector<Combo> combos;
     for (auto& gr : groups) {
-        Col q = be.alloc(n);
         std::vector<Fe> evs(gr.pts.size(), Fe::zero()), cf;
         std::vector<Col> members;
         Fe pw = Fe::one();
         for (size_t mi : gr.members) {
-            members.push_back(polys[mi].poly);
-            cf.push_back(pw);
-            for (size_t i = 0; i < gr.pts.size(); i++) evs[i] = evs[i] + pw * polys[mi].ev[gr.pts[i]].second;
+            if (polys[mi].mine) {
+                members.push_back(polys[mi].poly);
+                cf.push_back(pw);
+                for (size_t i = 0; i < gr.pts.size(); i++) evs[i] = evs[i] + pw * polys[mi].ev[gr.pts[i]].second;
+            }
             pw = pw * ys;
         }
-        be.lincomb(q, members, cf, n, false);
+        Col q;
+        if (!members.empty()) {
+            q = be.alloc(n);
+            be.lincomb(q, members, cf, n, false);
+        }
         combos.push_back(Combo{q, interpolate(gr.pts_fe, evs)});
     }
     const Fe v = T.squeeze_challenge();
@@ -1267,16 +1380,19 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
         std::vector<Col> ts;
         std::vector<Fe> cf;
         for (size_t gi = 0; gi < groups.size(); gi++) {
-            Col t = be.clone(combos[gi].q);
-            be.sub_low(t, combos[gi].r);
-            for (auto& z : groups[gi].pts_fe) be.kate_div(t, z, n);
-            ts.push_back(t);
-            cf.push_back(pw);
+            if (combos[gi].q) {
+                Col t = be.clone(combos[gi].q);
+                be.sub_low(t, combos[gi].r);
+                for (auto& z : groups[gi].pts_fe) be.kate_div(t, z, n);
+                ts.push_back(t);
+                cf.push_back(pw);
+            }
             pw = pw * v;
         }
-        be.lincomb(h, ts, cf, n, false);
+        if (ts.empty()) be.fill(h->ptr(), Fe::zero(), n);
+        else be.lincomb(h, ts, cf, n, false);
     }
-    T.write_point(be.commit({h})[0]);
+    T.write_point(be.commit_sum(be.g, h));
     const Fe u = T.squeeze_challenge();
     Fe zt_u = Fe::one();
     for (auto& z : all_pts) zt_u = zt_u * (u - pt_fe[z]);
@@ -1293,9 +1409,11 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
                 if (!std::binary_search(groups[gi].pts.begin(), groups[gi].pts.end(), z, u256_less)) zdiff = zdiff * (u - pt_fe[z]);
             if (gi == 0) norm = zdiff.inv();
             const Fe c = pw * zdiff * norm;
-            terms.push_back(combos[gi].q);
-            cf.push_back(c);
-            const_term = const_term + c * eval_small(combos[gi].r, u);
+            if (combos[gi].q) {
+                terms.push_back(combos[gi].q);
+                cf.push_back(c);
+                const_term = const_term + c * eval_small(combos[gi].r, u);
+            }
             pw = pw * v;
         }
         terms.push_back(h);
@@ -1304,34 +1422,44 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
     }
     be.sub_low(L, {const_term});
     be.kate_div(L, u, n);
-    T.write_point(be.commit({L})[0]);
+    T.write_point(be.commit_sum(be.g, L));
 }
 
 // ------------------------------------------------------------------ the numerator of h(X)
 struct Quotient {
     Program prog;
-    std::vector<Col> cols;
+    std::vector<Col> cols;         // coset-major extended columns (null: a witness column this rank does not own)
+    std::vector<int> owner;        // per slot: the rank holding the column, -1 = resident on every rank (key columns, replicated provers)
     std::vector<Fe> chal;
 };
 // ONE straight-line program over the extended-coset columns: custom gates, then the permutation and lookup
-// constraints, folded with y (value = value*y + constraint), as Evaluator::evaluate_h does
+// constraints, folded with y (value = value*y + constraint), as Evaluator::evaluate_h does.  The program is written for ONE coset
+// (k = ext_k = cs.k: a rotation by r is a shift by r rows inside the coset) and run once per coset of the extended domain.
+// *_owner: owner rank of the witness columns (advice by column, z by chunk, m / phi by lookup), -1 = every rank holds them.
 static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& pk, const std::vector<Col>& adv_cosets, const std::vector<Col>& z_cosets,
                                  const Fe& beta, const Fe& gamma, const Fe& y, const Fe& theta, const std::vector<Col>& m_cosets,
-                                 const std::vector<Col>& phi_cosets, const std::vector<Col>& inst_cosets, const std::vector<Fe>& user_chal) {
-    Quotient Q{Program(cs.k, cs.ext_k), {}, {y, beta, gamma}};
+                                 const std::vector<Col>& phi_cosets, const std::vector<Col>& inst_cosets, const std::vector<Fe>& user_chal,
+                                 const std::vector<int>& adv_owner = {}, const std::vector<int>& z_owner = {}, const std::vector<int>& lk_owner = {},
+                                 int inst_owner = -1) {
+    Quotient Q{Program(cs.k, cs.k), {}, {}, {y, beta, gamma}};
     Program& prog = Q.prog;
     Q.chal.insert(Q.chal.end(), user_chal.begin(), user_chal.end());
     std::map<std::vector<uint32_t>, uint32_t> index;
-    auto slot = [&](std::vector<uint32_t> name, const Col& h) {
+    auto own = [](const std::vector<int>& v, uint32_t i) { return i < v.size() ? v[i] : -1; };
+    auto slot = [&](std::vector<uint32_t> name, const Col& h, int owner = -1) {
         auto it = index.find(name);
         if (it != index.end()) return it->second;
         index[name] = (uint32_t)Q.cols.size();
         Q.cols.push_back(h);
+        Q.owner.push_back(owner);
         return (uint32_t)Q.cols.size() - 1;
     };
     enum : uint32_t { S_L0 = 100, S_LLAST, S_LACT, S_X, S_Z, S_SIGMA, S_PHI, S_M };
     Lowering low{cs, prog,
-                 [&](uint32_t kind, uint32_t c) { return slot({kind, c}, kind == N_ADV ? adv_cosets[c] : kind == N_INST ? inst_cosets[c] : pk.fixed_cosets[c]); },
+                 [&](uint32_t kind, uint32_t c) {
+                     return kind == N_ADV ? slot({kind, c}, adv_cosets[c], own(adv_owner, c)) : kind == N_INST ? slot({kind, c}, inst_cosets[c], inst_owner)
+                                                                                                              : slot({kind, c}, pk.fixed_cosets[c]);
+                 },
                  [&](uint32_t idx) { return prog.challenge(3 + idx); },
                  {}};
     const Src Y = prog.challenge(0), BETA = prog.challenge(1), GAMMA = prog.challenge(2);
@@ -1343,7 +1471,7 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
         const Src one = prog.constant(Fe::one());
         const uint32_t nz = (uint32_t)z_cosets.size();
         std::vector<uint32_t> zc;
-        for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j]));
+        for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j], own(z_owner, j)));
         terms.push_back(prog.mul(l0, prog.sub(one, prog.column(zc[0]))));
         const Src zl = prog.column(zc[nz - 1]);
         terms.push_back(prog.mul(llast, prog.sub(prog.calc(EZKL_OP_SQUARE, zl), zl)));
@@ -1372,7 +1500,7 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
         const Src THETA = prog.challenge((uint32_t)Q.chal.size() - 1);
         for (uint32_t i = 0; i < cs.lookups.size(); i++) {
             const Lookup& lk = cs.lookups[i];
-            const uint32_t phi_s = slot({S_PHI, i}, phi_cosets[i]), m_s = slot({S_M, i}, m_cosets[i]);
+            const uint32_t phi_s = slot({S_PHI, i}, phi_cosets[i], own(lk_owner, i)), m_s = slot({S_M, i}, m_cosets[i], own(lk_owner, i));
             const Src phi = prog.column(phi_s), phi_next = prog.column(phi_s, 1), mcol = prog.column(m_s);
             std::vector<Src> fb;
             for (auto& t : lk.inputs) fb.push_back(prog.add(low.compress(t, THETA), BETA));
@@ -1406,7 +1534,6 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
 // columns has the code bytes create_proof will build.  Best effort: a failure only means the first proof compiles it itself.
 static void prepare_quotient(const ProvingKey& pk) {
     const ConstraintSystem& cs = *pk.cs;
-    if (cs.shard.on() && cs.shard.gather) return;       // a row-sharded sweep runs per-shard programs
     try {
         std::vector<Col> adv(cs.n_advice), zc(cs.n_chunks), mc(cs.lookups.size()), pc(cs.lookups.size()), ic(cs.n_instance);
         std::vector<Fe> uc(cs.n_challenges, Fe::zero());
@@ -1459,6 +1586,11 @@ struct Stopwatch {
         if (out) out[10] = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     }
 };
+// the centred representative of a rotation inside a coset of n rows: in (-n/2, n/2]
+static int64_t centred(int64_t rot, int64_t n) {
+    int64_t r = ((rot % n) + n) % n;
+    return r > n / 2 ? r - n : r;
+}
 static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_bases_t gl, const void* const* advice, ezkl_advice_fn advice_fn, void* advice_user,
                                          const void* const* instances, const uint32_t* instance_lens, Rng& rng, double* timings) {
     ConstraintSystem& cs = *pk.cs;
@@ -1477,6 +1609,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
     } async_calls;
     Backend be(k, n, g, gl, cs.shard);
+    const Topo& topo = be.topo;
+    const bool owners = topo.owners;
+    for (auto& x : cs.shard.stats) x = 0;
     Stopwatch sw(timings);
     EvmTranscript T;
     T.common_scalar(pk.digest);
@@ -1496,9 +1631,11 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         be.set_rows(col, 0, vals);
         inst_cols.push_back(col);
     }
-    // 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges
+    // 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges.  Every rank uploads every column (the
+    //    lookup / permutation arguments it owns read them); in owner mode only the owner transforms and commits a column.
     std::vector<Col> adv_cols(cs.n_advice);
     std::vector<Backend::Forms> adv_forms(cs.n_advice);
+    std::vector<int> adv_owner(cs.n_advice, -1);
     std::vector<Fe> user_chal;
     for (uint32_t phase = 0; phase < 2; phase++) {
         std::vector<uint32_t> idxs;
@@ -1532,9 +1669,11 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         std::vector<std::vector<U256>> tails;
         std::vector<const void*> hostp, tailp;
         std::vector<void*> devp;
-        for (uint32_t c : idxs) {
+        for (size_t j = 0; j < idxs.size(); j++) {
+            const uint32_t c = idxs[j];
             invalid(src[c] == nullptr, "missing advice column");
             adv_cols[c] = be.alloc(n);
+            if (owners) adv_owner[c] = (int)topo.owner(j);
             if (cs.unblinded[c]) tails.push_back(std::vector<U256>(n - u, Fe::one().v));   // Blind::default() (polycommit.rs:57-61), no randomness drawn
             else tails.push_back(rng.vec(n - u));               // blinding rows [u, n)
             hostp.push_back(src[c]);
@@ -1542,19 +1681,23 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
         for (auto& t : tails) tailp.push_back(t.data());
         std::vector<G1> commits(idxs.size());
+        const bool by_batch = cs.shard.on() && cs.shard.full_bases;       // sharded with complete base sets: commit after the copies have landed
         {
             // the phase in steps (ezkl_hip_upload_commit_batch in one call): every copy is queued, the NTTs of column j are queued
             // behind ITS copy on the aux stream, then the commits run -- PCIe, MSMs and NTTs overlap
             ezkl_upload_t up = nullptr;
             check(ezkl_hip_upload_begin(hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, &up), "ezkl_hip_upload_begin");
             int rc = EZKL_OK;
-            for (size_t j = 0; j < idxs.size(); j++) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);     // before the copies are in flight
+            for (size_t j = 0; j < idxs.size(); j++)
+                if (topo.mine(j)) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);     // before the copies are in flight
             try {
                 for (size_t j = 0; j < idxs.size(); j++) {
+                    if (!topo.mine(j)) continue;
                     check(ezkl_hip_upload_wait(up, j, be.aux_stream()), "ezkl_hip_upload_wait");
                     adv_forms[idxs[j]] = be.forms_async(adv_cols[idxs[j]], cs.ext_k, &adv_forms[idxs[j]]);
+                    cs.shard.stats[0]++;
                 }
-                if (!(cs.shard.on() && cs.shard.full_bases)) rc = ezkl_hip_upload_commit(up, gl, be.commit_first(), be.commit_count(), commits.data());
+                if (!by_batch) rc = ezkl_hip_upload_commit(up, gl, be.commit_first(), be.commit_count(), commits.data());
             } catch (...) {
                 (void)ezkl_hip_upload_end(up);
                 throw;
@@ -1563,47 +1706,59 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             check(rc, "ezkl_hip_upload_commit");
             check(rc2, "ezkl_hip_upload_end");
         }
-        if (cs.shard.on() && cs.shard.full_bases) {         // divided by columns: the copies have landed (upload_end drains them)
+        if (by_batch) {                                     // divided by columns / by owner: the copies have landed (upload_end drains them)
             std::vector<Col> cols_;
-            for (uint32_t c : idxs) cols_.push_back(adv_cols[c]);
-            commits = be.commit_lagrange(cols_, true);
+            for (size_t j = 0; j < idxs.size(); j++) cols_.push_back(topo.mine(j) ? adv_cols[idxs[j]] : Col());
+            commits = be.commit_columns(gl, cols_, true);
         } else
             be.fold(commits);
         for (auto& p : commits) T.write_point(p);
         if (phase == 0)
             for (uint32_t i = 0; i < cs.n_challenges; i++) user_chal.push_back(T.squeeze_challenge());
     }
+    cs.shard.stats[1] += cs.n_advice;
     sw.lap(0);
     auto col_handle = [&](uint32_t kind, uint32_t c) -> Col { return kind == N_ADV ? adv_cols[c] : kind == N_INST ? inst_cols[c] : pk.fixed_values[c]; };
-    // 2. theta; mv-lookup multiplicities m(X)
+    // 2. theta; mv-lookup multiplicities m(X): argument i on its owner
     Fe theta = Fe::zero();
     struct LookupState {
         std::vector<Col> inputs;
         Col table, m, phi;
         Backend::Forms m_forms, phi_forms;
+        bool mine = true;
     };
-    std::vector<LookupState> lk;
-    if (!cs.lookups.empty()) {
+    const size_t nl = cs.lookups.size();
+    std::vector<LookupState> lk(nl);
+    std::vector<int> lk_owner(nl, -1);
+    if (nl) {
         theta = T.squeeze_challenge();
-        for (auto& l : cs.lookups) {
-            LookupState st;
+        for (size_t i = 0; i < nl; i++) {
+            const Lookup& l = cs.lookups[i];
+            LookupState& st = lk[i];
+            st.mine = topo.mine(i);
+            if (owners) lk_owner[i] = (int)topo.owner(i);
+            const std::vector<U256> blind = rng.vec(n - u);             // every rank draws every argument's randomness: one stream, same order
+            if (!st.mine) continue;
             for (auto& t : l.inputs) st.inputs.push_back(compress_column(cs, be, t, theta, col_handle, user_chal));
             st.table = compress_column(cs, be, l.table, theta, col_handle, user_chal);
             st.m = be.lookup_multiplicity(st.inputs, st.table, u);
-            be.set_rows(st.m, u, rng.vec(n - u));
-            lk.push_back(st);
+            be.set_rows(st.m, u, blind);
+            cs.shard.stats[3]++;
         }
         std::vector<Col> ms;
         for (auto& st : lk) ms.push_back(st.m);
-        for (auto& st : lk) st.m_forms = be.forms_async(st.m, cs.ext_k);
-        for (auto& p : be.commit_lagrange(ms, true)) T.write_point(p);
+        for (auto& st : lk)
+            if (st.mine) { st.m_forms = be.forms_async(st.m, cs.ext_k); cs.shard.stats[0]++; }
+        for (auto& p : be.commit_columns(gl, ms, true)) T.write_point(p);
+        cs.shard.stats[1] += 2 * nl;
     }
     sw.lap(1);
     // 3. beta, gamma
     const Fe beta = T.squeeze_challenge(), gamma = T.squeeze_challenge();
-    // 4. permutation grand products, chained across chunks
+    // 4. permutation grand products, chained across chunks: chunk j on its owner
     std::vector<Col> zs;
     std::vector<Backend::Forms> z_forms;
+    std::vector<int> z_owner;
     {
         uint32_t pos = 0;
         std::vector<std::vector<Col>> vals_all, sigs_all;
@@ -1616,92 +1771,180 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             pos += (uint32_t)chunk.size();
         }
         zs = be.permutation_products(vals_all, sigs_all, beta, gamma, pk.omega_col, u);
-        for (auto& z : zs) be.set_rows(z, u + 1, rng.vec(n - u - 1));
-        for (auto& z : zs) z_forms.push_back(be.forms_async(z, cs.ext_k));
-        for (auto& p : be.commit_lagrange(zs)) T.write_point(p);
+        z_forms.resize(zs.size());
+        for (size_t j = 0; j < zs.size(); j++) {
+            z_owner.push_back(owners ? (int)topo.owner(j) : -1);
+            const std::vector<U256> blind = rng.vec(n - u - 1);
+            if (zs[j]) be.set_rows(zs[j], u + 1, blind);
+        }
+        for (size_t j = 0; j < zs.size(); j++)
+            if (zs[j]) { z_forms[j] = be.forms_async(zs[j], cs.ext_k); cs.shard.stats[0]++; cs.shard.stats[3]++; }
+        for (auto& p : be.commit_columns(gl, zs, false)) T.write_point(p);
+        cs.shard.stats[1] += zs.size();
     }
     sw.lap(2);
-    // 4b. mv-lookup running sums phi(X)
+    // 4b. mv-lookup running sums phi(X): on the owner of the argument
     {
-        std::vector<Col> phis;
+        std::vector<Col> phis(nl);
         {
             std::vector<std::vector<Col>> ins;
             std::vector<Col> tabs, ms_;
-            for (auto& st : lk) { ins.push_back(st.inputs); tabs.push_back(st.table); ms_.push_back(st.m); }
+            std::vector<size_t> which;
+            for (size_t i = 0; i < nl; i++)
+                if (lk[i].mine) { ins.push_back(lk[i].inputs); tabs.push_back(lk[i].table); ms_.push_back(lk[i].m); which.push_back(i); }
             std::vector<Col> sums = be.lookup_grand_sums(ins, tabs, ms_, beta);
-            for (size_t i = 0; i < lk.size(); i++) {
-                lk[i].phi = sums[i];
-                be.set_rows(lk[i].phi, u + 1, rng.vec(n - u - 1));       // same draw order as one lookup after the other
-                phis.push_back(lk[i].phi);
+            for (size_t q = 0; q < which.size(); q++) lk[which[q]].phi = sums[q];
+            for (size_t i = 0; i < nl; i++) {
+                const std::vector<U256> blind = rng.vec(n - u - 1);       // same draw order as one lookup after the other
+                if (lk[i].mine) be.set_rows(lk[i].phi, u + 1, blind);
+                phis[i] = lk[i].phi;
             }
         }
-        for (auto& st : lk) st.phi_forms = be.forms_async(st.phi, cs.ext_k);
-        for (auto& p : be.commit_lagrange(phis)) T.write_point(p);
+        for (auto& st : lk)
+            if (st.mine) { st.phi_forms = be.forms_async(st.phi, cs.ext_k); cs.shard.stats[0]++; }
+        for (auto& p : be.commit_columns(gl, phis, false)) T.write_point(p);
     }
     sw.lap(3);
-    // 5. vanishing argument: random polynomial;  6. y
+    // 5. vanishing argument: random polynomial (every rank expands the same keystream: a replicated column);  6. y
     Col rnd = rng.column(be, n);
     T.write_point(be.commit({rnd})[0]);
     const Fe y = T.squeeze_challenge();
     sw.lap(4);
     // 7. quotient
-    std::vector<Col> adv_polys, inst_cosets, z_polys, adv_cosets, z_cosets, m_polys, phi_polys, m_cosets, phi_cosets;
-    for (auto& h : inst_cols) inst_cosets.push_back(be.coeff_to_extended(be.lagrange_to_coeff(h), cs.ext_k));
+    const uint32_t log_e = cs.ext_k - k, E = 1u << log_e;
+    const size_t ne = (size_t)1 << cs.ext_k;
+    const int inst_owner = owners ? 0 : -1;
+    std::vector<Col> adv_polys(cs.n_advice), adv_cosets(cs.n_advice), inst_cosets, z_polys(zs.size()), z_cosets(zs.size()), m_polys(nl), phi_polys(nl), m_cosets(nl),
+        phi_cosets(nl);
+    for (auto& h : inst_cols) inst_cosets.push_back((!owners || topo.rank == 0) ? be.coeff_to_extended(be.lagrange_to_coeff(h), cs.ext_k) : Col());
     be.aux_sync();                                   // the forms queued behind each finished column (Backend::forms_async)
-    for (auto& f : adv_forms) { adv_polys.push_back(f.poly); adv_cosets.push_back(f.coset); }
-    for (auto& f : z_forms) { z_polys.push_back(f.poly); z_cosets.push_back(f.coset); }
-    for (auto& st : lk) { m_polys.push_back(st.m_forms.poly); m_cosets.push_back(st.m_forms.coset); }
-    for (auto& st : lk) { phi_polys.push_back(st.phi_forms.poly); phi_cosets.push_back(st.phi_forms.coset); }
+    for (uint32_t c = 0; c < cs.n_advice; c++) { adv_polys[c] = adv_forms[c].poly; adv_cosets[c] = adv_forms[c].coset; }
+    for (size_t j = 0; j < zs.size(); j++) { z_polys[j] = z_forms[j].poly; z_cosets[j] = z_forms[j].coset; }
+    for (size_t i = 0; i < nl; i++) { m_polys[i] = lk[i].m_forms.poly; m_cosets[i] = lk[i].m_forms.coset; phi_polys[i] = lk[i].phi_forms.poly; phi_cosets[i] = lk[i].phi_forms.coset; }
     sw.lap(5);
-    Col hnum = be.zeros((size_t)1 << cs.ext_k);
+    Col hnum = be.zeros(ne);
     {
-        Quotient Q = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal);
-        uint32_t rank = 0, log_world = 0;
-        if (cs.shard.gather && cs.shard.geometry(n, rank, log_world) && log_world > 0 && log_world <= cs.k) {
-            // the sweep sharded by ROWS: this rank evaluates its rows of the extended domain from windows of the
-            // (replicated) coset columns -- an offset pointer, or a stitched copy where the window wraps around -- and the ranks
-            // all_gather their rows of h through the caller's collective
-            std::vector<std::pair<uint32_t, int64_t>> windows;
-            const Program sub = Q.prog.row_sharded(log_world, windows);
-            const int64_t ne = (int64_t)1 << cs.ext_k, rows = ne >> log_world, rlo = (int64_t)rank * rows;
-            std::vector<const void*> ptrs;
-            std::vector<Col> stitched;
-            for (auto& w : windows) {
-                const int64_t start = (((rlo + w.second) % ne) + ne) % ne;
-                const Col& col = Q.cols[w.first];
-                if (start + rows <= ne) {
-                    ptrs.push_back(Backend::at(col, (size_t)start));
-                } else {
-                    Col t = be.alloc((size_t)rows);
-                    const size_t first = (size_t)(ne - start);
-                    be.scale_into(Backend::at(col, (size_t)start), be.one, t->ptr(), first);
-                    be.scale_into(col->ptr(), be.one, Backend::at(t, first), (size_t)rows - first);
-                    stitched.push_back(t);
-                    ptrs.push_back(t->ptr());
+        Quotient Q = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal, adv_owner, z_owner, lk_owner,
+                                      inst_owner);
+        // The sweep runs in UNITS of rows of one coset.  One rank: the E cosets.  Sharded by rows (set_sweep_gather, equal power-of-two
+        // slices): max(E, world) units -- rank r sweeps E / world whole cosets, or, with more ranks than cosets, one of the
+        // world / E row ranges of a coset -- and h is all_gathered (units are in rank order, so the shards are equal slices of the
+        // coset-major h).  Columns resident on this rank are read in place (a row range whose rotated window wraps around the coset
+        // is stitched); in owner mode the columns of other ranks arrive through ONE exchange, one slab of rows (+ the halo its
+        // rotations reach) per (unit, column).
+        const bool shard_sweep = cs.shard.on() && cs.shard.gather && topo.world > 1 && (topo.world <= E || (topo.world / E) <= n / 2);
+        invalid(owners && !shard_sweep, "owner mode needs the row-sharded sweep");
+        const uint32_t split = shard_sweep && topo.world > E ? topo.world / E : 1;        // row ranges per coset
+        uint32_t log_split = 0;
+        while ((1u << log_split) < split) log_split++;
+        const uint32_t len = n / split, n_units = E * split;
+        auto unit_rank = [&](uint32_t un) { return shard_sweep ? un * topo.world / n_units : topo.rank; };
+        const size_t ns = Q.cols.size();
+        // halo of every slot: the rotations the program reads it with, centred
+        std::vector<int64_t> hn(ns, 0), hp(ns, 0);
+        for (size_t i = 0; i < Q.prog.code.size(); i += 8)
+            for (size_t sidx : {(size_t)2, (size_t)5})
+                if (Q.prog.code[i + sidx] == EZKL_SRC_COLUMN) {
+                    const uint32_t sl = Q.prog.code[i + sidx + 1];
+                    const int64_t r = centred(Q.prog.rotations[Q.prog.code[i + sidx + 2]], n);
+                    hn[sl] = std::max(hn[sl], -r);
+                    hp[sl] = std::max(hp[sl], r);
+                }
+        auto remote = [&](size_t sl) { return owners && Q.owner[sl] >= 0 && (uint32_t)Q.owner[sl] != topo.rank; };
+        // slabs of the columns other ranks own, one per (my unit, remote slot); the exchange lists in the SAME order on both sides:
+        // by receiving unit, then by slot, then by piece
+        std::vector<std::vector<Col>> slab(n_units, std::vector<Col>(ns));
+        if (owners && shard_sweep) {
+            std::vector<ezkl_comm_seg_t> sends, recvs;
+            for (uint32_t un = 0; un < n_units; un++) {
+                const uint32_t b = un / split, part = un % split, dst = unit_rank(un);
+                for (size_t sl = 0; sl < ns; sl++) {
+                    if (Q.owner[sl] < 0) continue;
+                    const uint32_t own_r = (uint32_t)Q.owner[sl];
+                    if (own_r == dst) continue;                                  // read in place by its owner
+                    if (own_r != topo.rank && dst != topo.rank) continue;
+                    const int64_t lo = (int64_t)part * len - (split > 1 ? hn[sl] : 0), rows = (int64_t)len + (split > 1 ? hn[sl] + hp[sl] : 0);
+                    invalid(rows > (int64_t)n, "rotation halo larger than a coset");
+                    const int64_t start = ((lo % (int64_t)n) + n) % n, first = std::min<int64_t>(rows, (int64_t)n - start);
+                    if (dst == topo.rank) {
+                        slab[un][sl] = be.alloc((size_t)rows);
+                        recvs.push_back({(int)own_r, slab[un][sl]->ptr(), (size_t)first * 32});
+                        if (rows > first) recvs.push_back({(int)own_r, Backend::at(slab[un][sl], (size_t)first), (size_t)(rows - first) * 32});
+                        cs.shard.stats[2] += (uint64_t)rows * 32;
+                    } else {
+                        invalid(!Q.cols[sl], "owned column missing");
+                        sends.push_back({(int)dst, Backend::at(Q.cols[sl], (size_t)b * n + (size_t)start), (size_t)first * 32});
+                        if (rows > first) sends.push_back({(int)dst, Backend::at(Q.cols[sl], (size_t)b * n), (size_t)(rows - first) * 32});
+                    }
                 }
             }
-            sub.run_ptrs(ptrs, Q.chal, Backend::at(hnum, (size_t)rlo));
-            invalid(cs.shard.gather(cs.shard.gather_user, hnum->ptr(), (size_t)ne * 32, (size_t)rlo * 32, (size_t)rows * 32) != 0, "gather callback failed");
+            check(ezkl_hip_synchronize(), "ezkl_hip_synchronize");               // the columns to send are complete (library + aux streams)
+            invalid(cs.shard.exchange(cs.shard.xuser, sends.data(), sends.size(), recvs.data(), recvs.size()) != 0, "exchange callback failed");
+        }
+        std::vector<Col> stitched;
+        for (uint32_t un = 0; un < n_units; un++) {
+            if (unit_rank(un) != topo.rank) continue;
+            const uint32_t b = un / split, part = un % split;
+            const size_t rlo = (size_t)part * len;
+            void* out = Backend::at(hnum, (size_t)b * n + rlo);
+            std::vector<const void*> ptrs;
+            if (split == 1) {                                                     // a whole coset: the program as it is
+                for (size_t sl = 0; sl < ns; sl++) ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : Backend::at(Q.cols[sl], (size_t)b * n));
+                Q.prog.run_ptrs(ptrs, Q.chal, out);
+            } else {                                                              // a row range: every (column, rotation) becomes a window at rotation 0
+                std::vector<std::pair<uint32_t, int64_t>> windows;
+                const Program sub = Q.prog.row_sharded(log_split, windows);
+                for (auto& w : windows) {
+                    const size_t sl = w.first;
+                    const int64_t sh = centred(w.second, n);
+                    if (remote(sl)) {
+                        ptrs.push_back(Backend::at(slab[un][sl], (size_t)(hn[sl] + sh)));
+                        continue;
+                    }
+                    const int64_t start = ((((int64_t)rlo + sh) % (int64_t)n) + n) % n;
+                    const Col& col = Q.cols[sl];
+                    if (start + (int64_t)len <= (int64_t)n) {
+                        ptrs.push_back(Backend::at(col, (size_t)b * n + (size_t)start));
+                    } else {                                                      // the window wraps around the coset
+                        Col t = be.alloc(len);
+                        const size_t first = (size_t)((int64_t)n - start);
+                        be.scale_into(Backend::at(col, (size_t)b * n + (size_t)start), be.one, t->ptr(), first);
+                        be.scale_into(Backend::at(col, (size_t)b * n), be.one, Backend::at(t, first), len - first);
+                        stitched.push_back(t);
+                        ptrs.push_back(t->ptr());
+                    }
+                }
+                sub.run_ptrs(ptrs, Q.chal, out);
+            }
+            // divide by the vanishing polynomial: a constant on the coset
+            be.scale_into(out, be.vanishing_inv(cs.ext_k, b), out, len);
+        }
+        if (shard_sweep) {
+            const size_t per = ne / topo.world * 32;
+            invalid(cs.shard.gather(cs.shard.gather_user, hnum->ptr(), ne * 32, (size_t)topo.rank * per, per) != 0, "gather callback failed");
             cs.shard.sharded_sweeps++;
-        } else {
-            Q.prog.run(Q.cols, Q.chal, hnum->ptr());
         }
     }
     sw.lap(6);
     adv_cosets.clear(); z_cosets.clear(); m_cosets.clear(); phi_cosets.clear(); inst_cosets.clear();
-    be.divide_by_vanishing(hnum, cs.ext_k);
-    be.extended_to_coeff(hnum, cs.ext_k);
+    for (auto& f : adv_forms) f.coset.reset();
+    for (auto& f : z_forms) f.coset.reset();
+    for (auto& st : lk) { st.m_forms.coset.reset(); st.phi_forms.coset.reset(); }
+    Col hcoef = be.extended_to_coeff(hnum, cs.ext_k);
+    hnum.reset();
     const uint32_t npieces = cs.degree - 1;
     std::vector<Col> pieces;
-    for (uint32_t i = 0; i < npieces; i++) pieces.push_back(be.slice_copy(hnum, (size_t)i * n, n));
+    for (uint32_t i = 0; i < npieces; i++) pieces.push_back(be.slice_copy(hcoef, (size_t)i * n, n));
     for (auto& p : be.commit(pieces)) T.write_point(p);
-    hnum.reset();
+    hcoef.reset();
     sw.lap(7);
     // 8. x
     const Fe x = T.squeeze_challenge();
     const Fe w = omega(k);
     auto rot_point = [&](int32_t r) { return x * w.pow((uint64_t)(r >= 0 ? (uint32_t)r % n : n - ((uint32_t)(-r) % n))); };
-    // 9. evaluations: every (polynomial, point) of this round in ONE batched call, then written in transcript order
+    // 9. evaluations: every (polynomial, point) of this round in ONE batched call per rank, then written in transcript order.  Owner
+    //    mode: a polynomial is evaluated by the rank that holds it (replicated ones -- key columns, the random polynomial, h -- are
+    //    dealt round-robin) and the scalars are all_gathered.
     const Fe xn = x.pow((uint64_t)n);
     Col hcomb = be.alloc(n);                       // h(X) = sum_i x^(n i) * piece_i(X): what the verifier reconstructs from the pieces
     {
@@ -1712,25 +1955,59 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     }
     std::vector<Col> ev_polys;
     std::vector<Fe> ev_pts;
-    auto want = [&](const Col& poly, const Fe& pt) { ev_polys.push_back(poly); ev_pts.push_back(pt); return ev_polys.size() - 1; };
+    std::vector<uint32_t> ev_owner;
+    uint32_t deal = 0;                             // round-robin over the replicated polynomials
+    std::map<const void*, uint32_t> dealt;
+    auto owner_of = [&](const Col& poly, int own) -> uint32_t {
+        if (!owners) return topo.rank;
+        if (own >= 0) return (uint32_t)own;
+        auto it = dealt.find(poly.get());
+        if (it == dealt.end()) it = dealt.emplace(poly.get(), deal++ % topo.world).first;
+        return it->second;
+    };
+    auto want = [&](const Col& poly, const Fe& pt, uint32_t own) { ev_polys.push_back(poly); ev_pts.push_back(pt); ev_owner.push_back(own); return ev_polys.size() - 1; };
     const Fe x_next = rot_point(1), x_last = rot_point((int32_t)u);
-    for (auto& q : cs.advice_queries) want(adv_polys[q.col], rot_point(q.rot));
-    for (auto& q : cs.fixed_queries) want(pk.fixed_polys[q.col], rot_point(q.rot));
-    want(rnd, x);
-    for (auto& h : pk.sigma_polys) want(h, x);
+    // owners of the polynomials, fixed once (evaluation and opening must agree); replicated polynomials are keyed by their column handle
+    std::vector<uint32_t> fix_own(cs.n_fixed), sig_own(pk.sigma_polys.size());
+    for (uint32_t c = 0; c < cs.n_fixed; c++) fix_own[c] = owner_of(pk.fixed_polys[c], -1);
+    for (size_t i = 0; i < pk.sigma_polys.size(); i++) sig_own[i] = owner_of(pk.sigma_polys[i], -1);
+    const uint32_t rnd_own = owner_of(rnd, -1), h_own = owner_of(hcomb, -1);
+    for (auto& q : cs.advice_queries) want(adv_polys[q.col], rot_point(q.rot), owner_of(adv_polys[q.col], adv_owner[q.col]));
+    for (auto& q : cs.fixed_queries) want(pk.fixed_polys[q.col], rot_point(q.rot), fix_own[q.col]);
+    want(rnd, x, rnd_own);
+    for (size_t i = 0; i < pk.sigma_polys.size(); i++) want(pk.sigma_polys[i], x, sig_own[i]);
     for (size_t j = 0; j < z_polys.size(); j++) {
-        want(z_polys[j], x);
-        want(z_polys[j], x_next);
-        if (j + 1 < z_polys.size()) want(z_polys[j], x_last);
+        const uint32_t o = owner_of(z_polys[j], z_owner[j]);
+        want(z_polys[j], x, o);
+        want(z_polys[j], x_next, o);
+        if (j + 1 < z_polys.size()) want(z_polys[j], x_last, o);
     }
-    for (size_t i = 0; i < lk.size(); i++) {
-        want(phi_polys[i], x);                     // mv_lookup::prover::Committed::evaluate: phi(x), phi(wx), m(x)
-        want(phi_polys[i], x_next);
-        want(m_polys[i], x);
+    for (size_t i = 0; i < nl; i++) {
+        const uint32_t o = owner_of(phi_polys[i], lk_owner[i]);
+        want(phi_polys[i], x, o);                  // mv_lookup::prover::Committed::evaluate: phi(x), phi(wx), m(x)
+        want(phi_polys[i], x_next, o);
+        want(m_polys[i], x, o);
     }
     const size_t n_written = ev_polys.size();
-    const size_t h_slot = want(hcomb, x);          // not part of the proof: the verifier derives it
-    const std::vector<Fe> ev = be.eval_poly_batch(ev_polys, ev_pts, n);
+    const size_t h_slot = want(hcomb, x, h_own);          // not part of the proof: the verifier derives it
+    std::vector<Fe> ev(ev_polys.size(), Fe::zero());
+    {
+        std::vector<Col> my_polys;
+        std::vector<Fe> my_pts;
+        std::vector<size_t> my_idx;
+        for (size_t i = 0; i < ev_polys.size(); i++)
+            if (ev_owner[i] == topo.rank) { my_polys.push_back(ev_polys[i]); my_pts.push_back(ev_pts[i]); my_idx.push_back(i); }
+        const std::vector<Fe> mine = be.eval_poly_batch(my_polys, my_pts, n);
+        if (!owners) {
+            for (size_t q = 0; q < my_idx.size(); q++) ev[my_idx[q]] = mine[q];
+        } else {
+            const size_t per = ev_polys.size();
+            std::vector<Fe> all((size_t)topo.world * per, Fe::zero());
+            for (size_t q = 0; q < my_idx.size(); q++) all[(size_t)topo.rank * per + my_idx[q]] = mine[q];
+            be.allgather_fe(all, per);
+            for (size_t i = 0; i < per; i++) ev[i] = all[(size_t)ev_owner[i] * per + i];
+        }
+    }
     for (size_t i = 0; i < n_written; i++) T.write_scalar(ev[i]);
     size_t cursor = 0;
     std::map<std::pair<uint32_t, int32_t>, Fe> adv_evals, fix_evals;
@@ -1751,7 +2028,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         z_evals.push_back(ze);
     }
     std::vector<std::array<Fe, 3>> lk_evals;
-    for (size_t i = 0; i < lk.size(); i++) {
+    for (size_t i = 0; i < nl; i++) {
         lk_evals.push_back({ev[cursor], ev[cursor + 1], ev[cursor + 2]});
         cursor += 3;
     }
@@ -1762,22 +2039,26 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     // halo2's query order -- advice, permutation products, lookups, fixed, sigma, h, random -- fixes the order of SHPLONK's rotation
     // sets (first appearance) and of the commitments inside each; pinned on the reference's generated EVM verifier
     // (tests/test_evm_verifier.py).  The verifier rebuilds the same list with commitments for polynomials.
+    auto is_mine = [&](uint32_t own) { return own == topo.rank; };
     std::vector<OpenQuery> qs;
-    for (auto& q : cs.advice_queries) qs.push_back({{K_ADV, q.col}, adv_polys[q.col], rot_point(q.rot), adv_evals[{q.col, q.rot}]});
+    for (auto& q : cs.advice_queries)
+        qs.push_back({{K_ADV, q.col}, adv_polys[q.col], rot_point(q.rot), adv_evals[{q.col, q.rot}], is_mine(owner_of(adv_polys[q.col], adv_owner[q.col]))});
     for (uint32_t j = 0; j < z_polys.size(); j++) {
-        qs.push_back({{K_Z, j}, z_polys[j], x, z_evals[j].e0});
-        qs.push_back({{K_Z, j}, z_polys[j], rot_point(1), z_evals[j].e1});
-        if (z_evals[j].has2) qs.push_back({{K_Z, j}, z_polys[j], rot_point((int32_t)u), z_evals[j].e2});
+        const bool mn = is_mine(owner_of(z_polys[j], z_owner[j]));
+        qs.push_back({{K_Z, j}, z_polys[j], x, z_evals[j].e0, mn});
+        qs.push_back({{K_Z, j}, z_polys[j], rot_point(1), z_evals[j].e1, mn});
+        if (z_evals[j].has2) qs.push_back({{K_Z, j}, z_polys[j], rot_point((int32_t)u), z_evals[j].e2, mn});
     }
-    for (uint32_t i = 0; i < lk.size(); i++) {
-        qs.push_back({{K_PHI, i}, phi_polys[i], x, lk_evals[i][0]});
-        qs.push_back({{K_PHI, i}, phi_polys[i], rot_point(1), lk_evals[i][1]});
-        qs.push_back({{K_M, i}, m_polys[i], x, lk_evals[i][2]});
+    for (uint32_t i = 0; i < nl; i++) {
+        const bool mn = is_mine(owner_of(phi_polys[i], lk_owner[i]));
+        qs.push_back({{K_PHI, i}, phi_polys[i], x, lk_evals[i][0], mn});
+        qs.push_back({{K_PHI, i}, phi_polys[i], rot_point(1), lk_evals[i][1], mn});
+        qs.push_back({{K_M, i}, m_polys[i], x, lk_evals[i][2], mn});
     }
-    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, pk.fixed_polys[q.col], rot_point(q.rot), fix_evals[{q.col, q.rot}]});
-    for (uint32_t i = 0; i < pk.sigma_polys.size(); i++) qs.push_back({{K_SIGMA, i}, pk.sigma_polys[i], x, sigma_evals[i]});
-    qs.push_back({{K_H}, hcomb, x, h_eval});
-    qs.push_back({{K_RND}, rnd, x, random_eval});
+    for (auto& q : cs.fixed_queries) qs.push_back({{K_FIX, q.col}, pk.fixed_polys[q.col], rot_point(q.rot), fix_evals[{q.col, q.rot}], is_mine(fix_own[q.col])});
+    for (uint32_t i = 0; i < pk.sigma_polys.size(); i++) qs.push_back({{K_SIGMA, i}, pk.sigma_polys[i], x, sigma_evals[i], is_mine(sig_own[i])});
+    qs.push_back({{K_H}, hcomb, x, h_eval, is_mine(h_own)});
+    qs.push_back({{K_RND}, rnd, x, random_eval, is_mine(rnd_own)});
     shplonk_prove(be, T, qs, n);
     sw.lap(9);
     sw.total();
@@ -2128,6 +2409,11 @@ int ezkl_prover_cs_set_shard(ezkl_cs_t h, uint32_t lo, uint32_t hi, ezkl_fold_fn
 // the same sharding with the library's own RCCL communicator (include/ezkl_hip.h ezkl_hip_comm_*): no caller callbacks, no torch
 static int comm_fold(void*, void* points, uint32_t count) { return ezkl_hip_comm_fold_points(points, count); }
 static int comm_gather(void*, void* buf, size_t total, size_t, size_t) { return ezkl_hip_comm_allgather_dev(buf, total); }
+static int comm_allgather_host(void*, void* buf, size_t per) { return ezkl_hip_comm_allgather_host(buf, per); }
+// the sweep exchange of the column-sharded prover: ezkl_hip_comm_alltoallv_dev (grouped ncclSend / ncclRecv over xGMI, all peers at once)
+static int comm_alltoall(void*, const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
+    return ezkl_hip_comm_alltoallv_dev(sends, n_sends, recvs, n_recvs);
+}
 int ezkl_prover_cs_set_shard_comm(ezkl_cs_t h) {
     if (!h) return EZKL_ERR_INVALID;
     int world = 0, rank = 0;
@@ -2139,7 +2425,24 @@ int ezkl_prover_cs_set_shard_comm(ezkl_cs_t h) {
     const uint32_t lo = (uint32_t)rank * base + std::min((uint32_t)rank, rem), hi = lo + base + ((uint32_t)rank < rem ? 1 : 0);
     rc = ezkl_prover_cs_set_shard(h, lo, hi, comm_fold, nullptr);
     if (rc) return rc;
-    if (world > 1 && (world & (world - 1)) == 0 && n % (uint32_t)world == 0) return ezkl_prover_cs_set_sweep_gather(h, comm_gather, nullptr);
+    if (world > 1 && (world & (world - 1)) == 0 && n % (uint32_t)world == 0) {
+        rc = ezkl_prover_cs_set_sweep_gather(h, comm_gather, nullptr);
+        if (rc) return rc;
+        // columns and arguments by owner (takes effect once the caller declares complete base sets: ezkl_prover_cs_set_shard_full_bases)
+        return ezkl_prover_cs_set_shard_exchange(h, comm_allgather_host, comm_alltoall, nullptr);
+    }
+    return EZKL_OK;
+}
+int ezkl_prover_cs_set_shard_exchange(ezkl_cs_t h, ezkl_allgather_host_fn allgather_host, ezkl_exchange_fn exchange, void* user) {
+    if (!h || ((allgather_host == nullptr) != (exchange == nullptr))) return EZKL_ERR_INVALID;
+    h->cs->shard.allgather_host = allgather_host;
+    h->cs->shard.exchange = exchange;
+    h->cs->shard.xuser = user;
+    return EZKL_OK;
+}
+int ezkl_prover_cs_shard_stats(ezkl_cs_t h, uint64_t out[4]) {
+    if (!h || !out) return EZKL_ERR_INVALID;
+    for (int i = 0; i < 4; i++) out[i] = h->cs->shard.stats[i];
     return EZKL_OK;
 }
 int ezkl_prover_cs_set_shard_full_bases(ezkl_cs_t h, int on) {

@@ -227,3 +227,53 @@ def probe_direct_gather(dist, device):
         ok = False
     _direct_gather_ok[0] = agree(ok)
     return _direct_gather_ok[0]
+
+
+# ---- the callbacks of the column-sharded C++ prover (include/ezkl_prover.h ezkl_prover_cs_set_shard_exchange), torch.distributed
+#      versions: what a prover uses when the library communicator is not available (gloo; two ranks sharing one GPU in the tests) ----
+def allgather_host_bytes(ptr, per, dist, device):
+    """in place on a HOST buffer of world * per bytes: rank r's slice is valid going in, every slice coming out"""
+    import ctypes
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    buf = (ctypes.c_uint8 * (world * per)).from_address(ptr)
+    arr = np.frombuffer(buf, np.uint8)
+    mine = torch.from_numpy(arr[rank * per:(rank + 1) * per].copy()).to(device)
+    recv = torch.empty(world * per, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, mine)
+    arr[:] = recv.cpu().numpy()
+
+
+def exchange_segments(sends, recvs, dist, device):
+    """sends / recvs: lists of (peer, device pointer, bytes) in the matching order of ezkl_hip_comm_alltoallv_dev.  Host-staged: every
+    segment is copied to the host, the ranks all_gather how much each sends to each, one all_to_all_single of flat byte buffers
+    (gloo: emulated with all_gather of padded buffers) moves the data, and the segments are copied back to the device."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out_by_peer = [[] for _ in range(world)]
+    for peer, ptr, nbytes in sends:
+        out_by_peer[peer].append(_b.memcpy_d2h(ptr, nbytes) if nbytes else np.zeros(0, np.uint8))
+    flat = [np.concatenate(x) if x else np.zeros(0, np.uint8) for x in out_by_peer]
+    lens = torch.tensor([len(f) for f in flat], dtype=torch.int64, device=device)
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens)
+    all_lens = torch.stack(all_lens).cpu().numpy()                  # [src][dst]
+    width = int(all_lens.max()) if all_lens.size else 0
+    got = [np.zeros(0, np.uint8) for _ in range(world)]
+    if width:
+        # every rank contributes a (world, width) block: row d = what it sends to rank d; all_gather, then pick column `rank`
+        block = np.zeros((world, width), np.uint8)
+        for d in range(world):
+            block[d, :len(flat[d])] = flat[d]
+        send_t = torch.from_numpy(block.reshape(-1)).to(device)
+        recv_t = torch.empty(world * world * width, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(recv_t, send_t)
+        full = recv_t.cpu().numpy().reshape(world, world, width)
+        got = [full[src, rank, :int(all_lens[src][rank])] for src in range(world)]
+    cursor = [0] * world
+    for peer, ptr, nbytes in recvs:
+        if nbytes:
+            _b.memcpy_h2d(ptr, np.ascontiguousarray(got[peer][cursor[peer]:cursor[peer] + nbytes]))
+        cursor[peer] += nbytes
+    for peer in range(world):
+        assert cursor[peer] == len(got[peer]), "exchange: segment lists of ranks %d and %d do not match" % (peer, rank)

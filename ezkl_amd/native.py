@@ -14,12 +14,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
-           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
+           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 FOLD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
 GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t)
+ALLGATHER_HOST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class CommSeg(C.Structure):
+    _fields_ = [("peer", C.c_int), ("ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(CommSeg), C.c_size_t, C.POINTER(CommSeg), C.c_size_t)
 STAGES = ["advice_commit", "lookup_m", "permutation_z", "lookup_phi", "random_poly", "intt_and_coset_ntt", "quotient_sweep", "h_split_commit",
           "evaluations", "shplonk", "total"]
 
@@ -108,6 +116,37 @@ class NativeCircuit:
             self.direct_gather = D.probe_direct_gather(dist, device)               # RCCL on the library's pointers, verified once
             _check(load().ezkl_prover_cs_set_sweep_gather(self.h, self._gather, None), "ezkl_prover_cs_set_sweep_gather")
         return lo, hi
+
+    def set_shard_exchange(self, dist, device):
+        """columns and arguments by owner (ezkl_prover_cs_set_shard_exchange) with torch.distributed moving the data (host-staged):
+        call after set_shard + set_shard_full_bases(True) on a power-of-two world"""
+        from . import dist as D
+
+        def _agh(_user, buf, per):
+            try:
+                D.allgather_host_bytes(int(buf), int(per), dist, device)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        def _xch(_user, sends, n_sends, recvs, n_recvs):
+            try:
+                D.exchange_segments([(sends[i].peer, int(sends[i].ptr or 0), int(sends[i].bytes)) for i in range(n_sends)],
+                                    [(recvs[i].peer, int(recvs[i].ptr or 0), int(recvs[i].bytes)) for i in range(n_recvs)], dist, device)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._agh, self._xch = ALLGATHER_HOST_FN(_agh), EXCHANGE_FN(_xch)
+        _check(load().ezkl_prover_cs_set_shard_exchange(self.h, self._agh, self._xch, None), "ezkl_prover_cs_set_shard_exchange")
+
+    def shard_stats(self):
+        """counters of the last create_proof on this rank"""
+        out = (C.c_uint64 * 4)()
+        _check(load().ezkl_prover_cs_shard_stats(self.h, out), "ezkl_prover_cs_shard_stats")
+        return dict(zip(["columns_transformed_here", "witness_columns", "exchange_bytes_received", "arguments_computed_here"], [int(x) for x in out]))
 
     def set_shard_comm(self):
         """shard over the library's RCCL communicator (backend.comm_init first): returns this rank's slice of the SRS"""

@@ -267,6 +267,17 @@ int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root);
 int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, const size_t* send_len, void* recv_dev, const size_t* recv_off,
                                const size_t* recv_len);
 
+/* all_gather of small HOST buffers: buf_host holds world x bytes_per_rank bytes, rank r has filled slice r; on return every slice is
+ * filled on every rank (the evaluations a rank computed for the polynomials it owns; the chaining values of the permutation chunks) */
+int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes_per_rank);
+/* all-to-all with ANY NUMBER of contiguous device segments per peer, sent from and received to where the data lives (no packing):
+ * sends[i] goes to sends[i].peer, recvs[j] arrives from recvs[j].peer; the k-th segment this rank sends to peer p is the k-th segment
+ * p receives from this rank, and their sizes must agree.  A column-sharded prover moves the cosets (or halo-extended row windows) of the
+ * columns it transformed to the ranks that sweep those rows with ONE such call: grouped ncclSend / ncclRecv, all peers and all
+ * xGMI links at once.  Segments with peer == own rank are copied device-to-device (same matching rule). */
+typedef struct { int peer; void* ptr; size_t bytes; } ezkl_comm_seg_t;
+int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs);
+
 /* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
 /* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */
 int ezkl_hip_last_kernel_ms(const char* which, float* out_ms);

@@ -86,6 +86,25 @@ typedef int (*ezkl_gather_fn)(void* user, void* buf_dev, size_t total_bytes, siz
 int ezkl_prover_cs_set_sweep_gather(ezkl_cs_t cs, ezkl_gather_fn gather, void* user);
 int ezkl_prover_cs_sharded_sweeps(ezkl_cs_t cs, uint64_t* out);
 
+/* ---- multi-GPU, the full form: columns and arguments have OWNERS ("NTT by columns", the sweep by rows) ----
+ * On top of set_shard* with complete base sets (set_shard_full_bases) and a power-of-two world: every witness-dependent column has
+ * one owner rank -- advice column j of a phase: j mod world; lookup argument i (its compressed inputs, m_i, phi_i): i mod world;
+ * permutation chunk j (z_j): j mod world.  Only the owner computes the column, its coefficient form and its extended cosets, and
+ * commits it (whole MSMs; the others contribute the identity to the fold).  The extended domain is stored coset-major
+ * (ezkl_hip_coeff_to_cosets_dev) and the quotient sweep is divided into max(E, world) units of rows -- whole cosets, or row ranges of
+ * a coset when there are more ranks than cosets; ONE all-to-all (`exchange`: ezkl_hip_comm_alltoallv_dev's contract) moves every
+ * owned column's rows of a unit (plus the few halo rows its rotations reach) to the rank that sweeps the unit; h is all_gathered
+ * (set_sweep_gather); evaluations are computed by owners and all_gathered as scalars (`allgather_host`:
+ * ezkl_hip_comm_allgather_host's contract); SHPLONK is linear in the polynomials, so every rank carries the partial sums over the
+ * polynomials it owns through both quotients and commits its partial -- two more 64-byte folds, no polynomial ever moves.
+ * The proof bytes are those of the one-GPU prover.  set_shard_comm installs the library communicator's versions by itself. */
+typedef int (*ezkl_allgather_host_fn)(void* user, void* buf_host, size_t bytes_per_rank);
+typedef int (*ezkl_exchange_fn)(void* user, const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs);
+int ezkl_prover_cs_set_shard_exchange(ezkl_cs_t cs, ezkl_allgather_host_fn allgather_host, ezkl_exchange_fn exchange, void* user);
+/* counters of the last create_proof on this rank: out[0] = witness columns this rank transformed (iNTT + cosets), out[1] = witness
+ * columns in the proof, out[2] = bytes this rank received in the sweep exchange, out[3] = lookup / permutation arguments it computed */
+int ezkl_prover_cs_shard_stats(ezkl_cs_t cs, uint64_t out[4]);
+
 /* How advice_fn hands over its columns.  Off (default): `columns[c]` points at a zeroed host buffer of 2^k x 32 B the callback fills.
  * On: `columns` arrives as an array of NULL pointers and the callback STORES, for every column c of the phase, a pointer to its own
  * host column (it may be page-locked, ezkl_hip_host_malloc) that stays valid until create_proof returns: no allocation, no copy --
