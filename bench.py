@@ -208,6 +208,33 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
             out["prove"] = prove_leg()
+        # the three kernels that dominate the metric's own workload (the k = 20 MLP proof), each against the HBM roof: algorithmic bytes per
+        # launch / the launch's HIP-event time measured in THIS run; `traffic` = PMC bytes per launch of the same kernel inside a proof
+        # (tools/pmc_prove.sh: counters need their own rocprofv3 passes, so the tracked reduction is reported with its source)
+        pk_, pm_ = {}, None
+        ppath = os.path.join(ROOT, "profiles", "r03_pmc_prove.json")
+        if os.path.exists(ppath):
+            try:
+                pm_ = json.load(open(ppath))
+                pk_ = pm_.get("kernels", {})
+            except Exception:
+                pm_ = None
+        def rk(kernel, workload, alg_bytes, ms, traffic, extra=None):
+            d = {"kernel": kernel, "workload": workload, "bound": "hbm", "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
+                 "achieved": (alg_bytes / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": (alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": traffic,
+                 "traffic_source": ("profiles/r03_pmc_prove.json: " + str(pm_.get("source"))) if (pm_ and traffic) else None}
+            d.update(extra or {})
+            return d
+        ntt_pass_ms = float(np.mean(ntt_ms)) / 3.0                     # a 2^22 transform is three launches of ntt_pass_kernel
+        rks = [rk("ntt_pass_kernel", "one pass of the 2^22-point NTT of the timed region (64 B per element: read + write)", NTT_BYTES_PER_ELEM * n_ntt, ntt_pass_ms,
+                  (pk_.get("ntt_pass_kernel") or {}).get("bytes_per_launch_mean"), {"note": "traffic: mean over the passes of every transform of a k = 20 MLP proof (2^20- and 2^22-point cosets)"})]
+        sk = ((out.get("prove") or {}).get("mlp_k20") or {}).get("sweep_kernel")
+        if sk:
+            rks.append(rk("evalh_jit", "quotient sweep of the k = 20 MLP key: one coset of 2^20 rows, %d columns read + 1 written (32 B each)" % sk["columns"],
+                          sk["algorithmic_bytes_per_launch"], sk["avg_launch_ms"], (pm_ or {}).get("evalh_jit_sweep", {}).get("bytes_per_launch_mean")))
+        rks.append(rk("msm_accumulate_kernel", "2^20-point MSM of the timed region (96 B per point)", MSM_BYTES_PER_POINT * n_msm, acc_avg_ms, traffic))
+        out["roofline_kernels"] = rks
         if prove_multi is not None:
             out["prove"] = prove_multi
         if strong is not None:
@@ -294,7 +321,7 @@ def prove_leg():
             out["mlp_k20"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
                               "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
                               "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"],
-                              "breakdown_seconds": j["prove_breakdown_seconds"], "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds")}
+                              "breakdown_seconds": j["prove_breakdown_seconds"], "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds"), "sweep_kernel": j.get("sweep_kernel")}
     except Exception as e:
         out["mlp_k20"] = {"error": repr(e)[:300]}
     try:                                               # BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17
@@ -309,13 +336,15 @@ def prove_leg():
 
 def prove_leg_multi(world, rank, local_rank, args):
     """BASELINE configs[3]: the reference's accum_einsum_matmul bench circuit at k = 20 proved by libezkl_prover.so across `world` GPUs --
-    every rank holds the complete SRS (288 GB of HBM: base sets + window tables are < 2 GB), each commit batch is divided by columns
-    (point ranges when it has fewer columns than ranks) and folded with one all_gather of 64-byte partials, the quotient sweep is divided
-    by rows and h all_gathered in place, through the library's own RCCL communicator (csrc/comm.hip).  Every rank emits the same proof
-    bytes; rank 0 verifies them.  Runs in child processes (EZKL_BENCH_MULTI_CIRCUIT=mlp / synthetic selects another circuit)."""
+    every rank holds the complete SRS (288 GB of HBM: base sets + window tables are < 2 GB); every witness column is transformed and
+    committed by ONE rank, lookup / permutation arguments run on their owner, the quotient sweep is divided into row units fed by one
+    all-to-all, h is all_gathered in place, SHPLONK travels as two 64-byte folds -- through the library's own RCCL communicator
+    (csrc/comm.hip).  Every rank emits the same proof bytes; rank 0 verifies them.  Runs in child processes
+    (EZKL_BENCH_MULTI_CIRCUIT=mlp selects another circuit)."""
     circuit = os.environ.get("EZKL_BENCH_MULTI_CIRCUIT", "einsum")
     out = _prove_multi_one(world, rank, local_rank, args, circuit, os.environ.get("EZKL_BENCH_MULTI_K", "20"), 1)
-    # ... and the north star's k = 20 MLP circuit the same way (every rank lays the circuit out itself: ~40 s of Python)
+    # ... and the north star's k = 20 MLP circuit the same way (laid out ONCE: the first rank to take the lock writes
+    # bench_cache/mlp_k20_s1.npz, the others read it -- tools/bench_circuits.py)
     if circuit == "einsum" and os.environ.get("EZKL_BENCH_MULTI_MLP20", "1") != "0":
         m = _prove_multi_one(world, rank, local_rank, args, "mlp", "20", 2)
         if rank == 0 and out is not None:
@@ -324,18 +353,23 @@ def prove_leg_multi(world, rank, local_rank, args):
 
 
 def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
+    """tools/prove_multi.py in a child per rank: libezkl_prover.so with columns and arguments BY OWNER (NTTs by columns, lookup / permutation
+    arguments by owner, the sweep in row units fed by one all-to-all, SHPLONK as per-rank partial sums); EZKL_BENCH_MULTI_MODE=replicated
+    selects the round-2 mode (commit batches by columns, everything else replicated)"""
     import subprocess
-    env = dict(os.environ, K=k, BLOCKS="4", CIRCUIT=circuit, REPS="3", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+    env = dict(os.environ, K=k, CIRCUIT=circuit, REPS="3", MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(local_rank))
     for k_ in list(env):                       # the children rendezvous on their own: no torchrun agent store behind the new port
         if k_.startswith("TORCHELASTIC_") or k_ in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE",
                                                       "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
             env.pop(k_)
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "prove_bench.py"), "--native", "--pinned"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "prove_multi.py"), "--pinned"]
     if args.backend != "nccl":
         cmd.append("--gloo")
     if args.share_device:
         cmd.append("--share-device")
+    if os.environ.get("EZKL_BENCH_MULTI_MODE") == "replicated":
+        cmd.append("--replicated")
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300" if circuit != "mlp" else "600")))
         if rank != 0:
@@ -344,16 +378,9 @@ def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
         if not lines:
             raise RuntimeError(r.stderr[-300:])
         j = json.loads(lines[-1])
-        if circuit == "synthetic":
-            nv = j.get("native_prover", {})
-            return {"circuit": "k=20, 4 matmul-accumulation blocks + 2^15-row ReLU mv-lookup, 14 advice / 11 fixed columns, degree 5", "n_gpus": j["n_gpus"],
-                    "commit_sharding": nv.get("commit_sharding"), "collectives": nv.get("collectives"), "sharded_sweeps": nv.get("sharded_sweeps"),
-                    "prove_seconds_gpu": nv.get("prove_seconds_library_rng"), "all_ranks_same_proof": nv.get("all_ranks_same_proof"),
-                    "verifier_accepts": nv.get("library_rng_proof_verifies"), "breakdown_seconds": nv.get("breakdown_seconds_library_rng"), "proof_bytes": j["proof_bytes"]}
-        m = j.get("multi_gpu", {})
-        return {"circuit": j["circuit"], "n_gpus": j["n_gpus"], "host": "libezkl_prover.so (C++) over the C ABI", "commit_sharding": m.get("commit_sharding"),
-                "sweep_sharding": m.get("sweep_sharding"), "collectives": m.get("collectives"), "sharded_sweeps": m.get("sharded_sweeps"),
-                "prove_seconds_gpu": j["prove_seconds_gpu"], "prove_seconds_gpu_runs": j.get("prove_seconds_gpu_runs"), "all_ranks_same_proof": m.get("all_ranks_same_proof"),
+        return {"circuit": j["circuit"], "n_gpus": j["n_gpus"], "host": "libezkl_prover.so (C++) over the C ABI", "sharding": j["mode"], "collectives": j["collectives"],
+                "sharded_sweeps": min(p_["sharded_sweeps"] for p_ in j["per_rank"]), "per_rank": j["per_rank"],
+                "prove_seconds_gpu": j["prove_seconds_gpu"], "prove_seconds_gpu_runs": j.get("prove_seconds_gpu_runs"), "all_ranks_same_proof": j["all_ranks_same_proof"],
                 "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "proof_sha256": j.get("proof_sha256"),
                 "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"]}
     except Exception as e:

@@ -245,9 +245,10 @@ def allgather_host_bytes(ptr, per, dist, device):
 
 
 def exchange_segments(sends, recvs, dist, device):
-    """sends / recvs: lists of (peer, device pointer, bytes) in the matching order of ezkl_hip_comm_alltoallv_dev.  Host-staged: every
-    segment is copied to the host, the ranks all_gather how much each sends to each, one all_to_all_single of flat byte buffers
-    (gloo: emulated with all_gather of padded buffers) moves the data, and the segments are copied back to the device."""
+    """sends / recvs: lists of (peer, device pointer, bytes) in the matching order of ezkl_hip_comm_alltoallv_dev.  Host-staged: the
+    segments for one peer are concatenated into one buffer, the ranks all_gather how much each sends to each, the buffers travel as
+    point-to-point sends / receives (one per ordered pair of ranks, all posted at once), and the received bytes are copied back to
+    the device segment by segment."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     out_by_peer = [[] for _ in range(world)]
@@ -258,18 +259,13 @@ def exchange_segments(sends, recvs, dist, device):
     all_lens = [torch.empty_like(lens) for _ in range(world)]
     dist.all_gather(all_lens, lens)
     all_lens = torch.stack(all_lens).cpu().numpy()                  # [src][dst]
-    width = int(all_lens.max()) if all_lens.size else 0
-    got = [np.zeros(0, np.uint8) for _ in range(world)]
-    if width:
-        # every rank contributes a (world, width) block: row d = what it sends to rank d; all_gather, then pick column `rank`
-        block = np.zeros((world, width), np.uint8)
-        for d in range(world):
-            block[d, :len(flat[d])] = flat[d]
-        send_t = torch.from_numpy(block.reshape(-1)).to(device)
-        recv_t = torch.empty(world * world * width, dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(recv_t, send_t)
-        full = recv_t.cpu().numpy().reshape(world, world, width)
-        got = [full[src, rank, :int(all_lens[src][rank])] for src in range(world)]
+    send_t = {d: torch.from_numpy(flat[d]).to(device) for d in range(world) if d != rank and len(flat[d])}
+    recv_t = {s_: torch.empty(int(all_lens[s_][rank]), dtype=torch.uint8, device=device) for s_ in range(world) if s_ != rank and all_lens[s_][rank]}
+    ops = [dist.P2POp(dist.isend, t, d) for d, t in send_t.items()] + [dist.P2POp(dist.irecv, t, s_) for s_, t in recv_t.items()]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    got = [recv_t[s_].cpu().numpy() if s_ in recv_t else (flat[rank] if s_ == rank else np.zeros(0, np.uint8)) for s_ in range(world)]
     cursor = [0] * world
     for peer, ptr, nbytes in recvs:
         if nbytes:

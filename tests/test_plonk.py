@@ -408,5 +408,6 @@ def test_bench_contract_two_ranks(hip):
     assert abs(j["value"] - 2 * (1 << 20) * 3 / (j["ms_per_step"] * 3e-3)) < 1e-3 * j["value"]
     assert j["prove"].get("verifier_accepts") is True and j["prove"]["n_gpus"] == 2
     assert j["prove"]["all_ranks_same_proof"] is True and j["prove"]["sharded_sweeps"] >= 2 and "accum_einsum_matmul" in j["prove"]["circuit"]["circuit"]
-    assert j["prove"]["commit_sharding"].startswith("by columns")
+    assert j["prove"]["sharding"] == "columns and arguments by owner"         # NTTs by columns, arguments by owner, one all-to-all for the sweep
+    assert all(r["stats"]["exchange_bytes_received"] > 0 and r["stats"]["columns_transformed_here"] < r["stats"]["witness_columns"] for r in j["prove"]["per_rank"])
     assert j["prove"]["prove_seconds_gpu"] > 0
