@@ -227,7 +227,8 @@ def main():
             d.update(extra or {})
             return d
         ntt_pass_ms = float(np.mean(ntt_ms)) / 3.0                     # a 2^22 transform is three launches of ntt_pass_kernel
-        rks = [rk("ntt_pass_kernel", "one pass of the 2^22-point NTT of the timed region (64 B per element: read + write)", NTT_BYTES_PER_ELEM * n_ntt, ntt_pass_ms,
+        rks = [rk("ntt_pass_kernel", "one of the three passes of the 2^22-point NTT of the timed region (the transform's 64 B per element, read once + written once, divided over its three launches)",
+                  NTT_BYTES_PER_ELEM * n_ntt / 3.0, ntt_pass_ms,
                   (pk_.get("ntt_pass_kernel") or {}).get("bytes_per_launch_mean"), {"note": "traffic: mean over the passes of every transform of a k = 20 MLP proof (2^20- and 2^22-point cosets)"})]
         sk = ((out.get("prove") or {}).get("mlp_k20") or {}).get("sweep_kernel")
         if sk:

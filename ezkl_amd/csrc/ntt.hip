@@ -19,7 +19,7 @@
 
 namespace ezkl {
 
-static constexpr int NTT_THREADS = 256;
+// workgroup sizes: 256 threads for tiles of 1024 elements (and single-pass transforms), 512 / 1024 for the 2048- / 4096-element tiles of radix 2^9 / 2^10 passes
 static constexpr uint32_t NTT_LOG_TILE = 10;   // multi-pass tile: 1024 elements = 32 KiB of LDS -> 4 workgroups (16 waves) per CU
 static constexpr uint32_t NTT_LOG_SINGLE = 11; // a transform up to 2^11 runs as ONE pass in a 64 KiB tile
 
@@ -38,9 +38,10 @@ struct PassArgs {
     uint32_t k1_major;      // last pass: tile owns C blocks with consecutive leading digit
     fe_t zeta[2];           // zeta, zeta^2
     fe_t post_c[3];
-    // coset-major extended evaluation (coset_cm_run): blockIdx.y = column * E + coset; the first pass multiplies row i1 by
-    // tw_pre[coset][i1] = c_b^(S * i1) and its inter-pass table is per coset (tw_inter + coset * 2^log_n holds w^(i2 k1) * c_b^i2)
-    uint32_t cm, cm_log_e;
+    // coset-major extended evaluation (coset_cm_run): blockIdx.y = column * E + coset; the first pass is a TWISTED DIT transform (dit = 1,
+    // stage twiddles of coset b at tw_pre + b * R: ntt_superstage_dit) and its inter-pass table is per coset (tw_inter + coset * 2^log_n
+    // holds w^(i2 k1) * c_b^i2): the coset scaling c_b^j costs no product
+    uint32_t cm, cm_log_e, dit;
     const fe_t* tw_pre;
 };
 
@@ -62,7 +63,7 @@ EZ_D fe_t lds_get(const uint2* d, uint32_t tile, uint32_t e) {
 // G consecutive DIF stages (s .. s+G-1) of the R-point column FFTs on 2^G elements held in registers.
 // Group members are rows r0 + i*hG (hG = R >> (s+G)); at sub-stage t the partner distance is 2^(G-1-t) members
 // and the low element at in-block position pos = j + (i & (half-1))*hG takes twiddle w_R^(pos << (s+t)).
-template <int G>
+template <int G, int NTT_THREADS>
 __device__ __forceinline__ void ntt_superstage(uint2* data, const fe_t* tloc, uint32_t TILE, uint32_t logC, uint32_t log_r,
                                                uint32_t s, uint32_t tid) {
     constexpr uint32_t M = 1u << G;
@@ -99,6 +100,45 @@ __device__ __forceinline__ void ntt_superstage(uint2* data, const fe_t* tloc, ui
     }
 }
 
+// G consecutive DIT stages (s .. s+G-1, 1-based: stage s joins blocks of 2^(s-1) rows) of a TWISTED R-point column transform
+// X[k] = sum_i x_i d^i w_R^(ik) = P(d w_R^k): with P(t) = Pe(t^2) + t Po(t^2) the twist is absorbed by the twiddles -- stage s multiplies
+// by d^(R/2^s) w_(2^s)^o (table entry 2^(s-1) - 1 + o) -- so evaluating on a coset costs no product beyond the plain transform's.
+// Input rows are in bit-reversed order (the loader permutes), output rows in natural order.  Stages below log_r read the twiddles staged in
+// LDS, the last stage (R/2 entries, each used once per column) reads them from the table in global memory.
+template <int G, int NTT_THREADS>
+__device__ __forceinline__ void ntt_superstage_dit(uint2* data, const fe_t* tloc, const fe_t* tglob, uint32_t TILE, uint32_t logC, uint32_t log_r, uint32_t s,
+                                                   uint32_t tid) {
+    constexpr uint32_t M = 1u << G;
+    const uint32_t C = 1u << logC;
+    const uint32_t lh = s - 1, h = 1u << lh;
+    const uint32_t ngroups = TILE >> G;
+    for (uint32_t gid = tid; gid < ngroups; gid += NTT_THREADS) {
+        const uint32_t c = gid & (C - 1), q = gid >> logC;
+        const uint32_t o = q & (h - 1), blk = q >> lh;
+        const uint32_t r0 = (blk << (lh + G)) + o;
+        fe_t x[M];
+#pragma unroll
+        for (uint32_t i = 0; i < M; i++) x[i] = lds_get(data, TILE, ((r0 + i * h) << logC) + c);
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const uint32_t half = 1u << t, st = s + t;
+            const uint32_t base = (1u << (st - 1)) - 1u;
+#pragma unroll
+            for (uint32_t i = 0; i < M; i++) {
+                if (i & half) continue;
+                const uint32_t off = o + (i & (half - 1)) * h;
+                const fe_t w = st == log_r ? ld_fe(tglob + base + off) : tloc[base + off];
+                const fe_t u = x[i], v = Fr::mul_lazy(x[i + half], w);        // everything in [0, 2p)
+                x[i] = Fr::add_lazy(u, v);
+                x[i + half] = Fr::reduce_2p(Fr::sub_lazy(u, v));
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < M; i++) lds_put(data, TILE, ((r0 + i * h) << logC) + c, x[i]);
+    }
+}
+
+template <int NTT_THREADS>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t TILE = 1u << a.log_tile, R = 1u << a.log_r;
@@ -113,9 +153,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     const fe_t* in = a.in + (size_t)((a.cm && a.first) ? cm_col : blockIdx.y) * a.in_stride;
     fe_t* out = (a.cm && a.last) ? a.out + (size_t)cm_col * a.out_stride + ((size_t)cm_b << a.log_n) : a.out + (size_t)blockIdx.y * a.out_stride;
     const fe_t* tw_inter = a.tw_inter ? a.tw_inter + ((a.cm && a.first) ? ((size_t)cm_b << a.log_n) : 0) : nullptr;
-    const fe_t* tw_pre = (a.cm && a.first) ? a.tw_pre + ((size_t)cm_b << a.log_r) : nullptr;
 
-    for (uint32_t j = tid; j < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(a.tw_local + j);
+    if (a.dit) {                    // twisted DIT pass (coset-major first pass): stages 1 .. log_r - 1 of this coset's table
+        const fe_t* tw = a.tw_pre + ((size_t)cm_b << a.log_r);
+        for (uint32_t j = tid; j + 1 < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(tw + j);
+    } else {
+        for (uint32_t j = tid; j < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(a.tw_local + j);
+    }
 
     // ---- block / column geometry of this tile ----
     // non-last: colid = tile*C + c ; base(c) = (colid >> log_s) * M + (colid & (S-1)), rows strided by S
@@ -153,7 +197,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
             uint32_t m3 = (uint32_t)(addr % 3);
             if (m3) x = Fr::mul(x, a.zeta[m3 - 1]);
         }
-        if (tw_pre) x = Fr::mul(x, ld_fe(tw_pre + (e >> logC)));      // coset-major: row i1 of the column FFT times c_b^(S i1)
+        // twisted DIT pass: the row of input i1 is its bit reversal
+        if (a.dit) e = (a.log_r ? ((__brev(e >> logC) >> (32 - a.log_r)) << logC) : 0u) | (e & (C - 1));
         lds_put(data, TILE, e, x);     // LDS index = i1*C + c
     };
     if (TILE == 4 * NTT_THREADS) {
@@ -173,10 +218,20 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     __syncthreads();
 
     // ---- r DIF stages, up to three at a time in registers (radix-8 groups), one LDS round trip per group ----
+    if (a.dit) {
+        const fe_t* tglob = a.tw_pre + ((size_t)cm_b << a.log_r);
+        for (uint32_t s = 1; s <= a.log_r;) {
+            const uint32_t g = a.log_r - s >= 1 ? 2u : 1u;
+            if (g == 2) ntt_superstage_dit<2, NTT_THREADS>(data, tloc, tglob, TILE, logC, a.log_r, s, tid);
+            else ntt_superstage_dit<1, NTT_THREADS>(data, tloc, tglob, TILE, logC, a.log_r, s, tid);
+            __syncthreads();
+            s += g;
+        }
+    } else
     for (uint32_t s = 0; s < a.log_r;) {
         const uint32_t g = a.log_r - s >= 2 ? 2u : a.log_r - s;      // radix-4 groups: 32 data VGPRs, 4 waves/SIMD
-        if (g == 2) ntt_superstage<2>(data, tloc, TILE, logC, a.log_r, s, tid);
-        else ntt_superstage<1>(data, tloc, TILE, logC, a.log_r, s, tid);
+        if (g == 2) ntt_superstage<2, NTT_THREADS>(data, tloc, TILE, logC, a.log_r, s, tid);
+        else ntt_superstage<1, NTT_THREADS>(data, tloc, TILE, logC, a.log_r, s, tid);
         __syncthreads();
         s += g;
     }
@@ -184,7 +239,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     // ---- store: y[k1] sits at row bitrev(k1) ----
     auto store_one = [&](uint32_t e, const fe_t* twp) {
         uint32_t c = e & (C - 1), k1 = e >> logC;
-        uint32_t row = a.log_r ? (__brev(k1) >> (32 - a.log_r)) : 0u;
+        uint32_t row = a.dit ? k1 : (a.log_r ? (__brev(k1) >> (32 - a.log_r)) : 0u);       // DIT leaves the outputs in natural order
         fe_t x = lds_get(data, TILE, (row << logC) + c);
         if (!a.last) {
             uint32_t colid = tile * C + c;
@@ -239,7 +294,8 @@ __global__ void ntt_twiddle_kernel(fe_t* out, uint32_t count, uint64_t mult, uin
 
 
 // coset-major tables: out[b * cnt + m] = w_ext^(e mod 2^log_ext) * zeta^(z mod 3) with
-//   mode 0 (first-pass row factors, cnt = R1):   j = m * S,            e = b * j,              z = j          -> c_b^(S m)
+//   mode 0 (stage twiddles of the twisted DIT first pass, cnt = R1): m = 2^(s-1) - 1 + o (stage s, offset o), q = n / 2^s,
+//                                                 e = q * (b + E * o),     z = q          -> c_b^q * w_(2^s)^o
 //   mode 1 (first-pass inter-pass table, cnt = n): m = k1 * S + i2,     e = E * i2 * k1 + b * i2, z = i2        -> w_n^(i2 k1) * c_b^i2
 // for the coset generators c_b = zeta * w_ext^b, b < E = 2^log_e
 __global__ void ntt_coset_table_kernel(fe_t* out, uint32_t cnt, uint32_t log_e, uint32_t log_ext, uint32_t log_s, int mode, const fe_t* pow2tab,
@@ -249,9 +305,13 @@ __global__ void ntt_coset_table_kernel(fe_t* out, uint32_t cnt, uint32_t log_e, 
     const uint64_t b = idx / cnt, m = idx % cnt;
     uint64_t e, z;
     if (mode == 0) {
-        const uint64_t j = m << log_s;
-        e = b * j;
-        z = j % 3;
+        uint32_t st = 1;                                                  // stage of entry m: 2^(st-1) - 1 <= m < 2^st - 1
+        while (((uint64_t)1 << st) - 1 <= m) st++;
+        const uint64_t o = m - (((uint64_t)1 << (st - 1)) - 1), log_nn = log_ext - log_e;
+        if (st > log_nn) { st_fe(out + idx, Fr::zero()); return; }     // padding entry
+        const uint64_t q = (uint64_t)1 << (log_nn - st);
+        e = q * (b + (o << log_e));
+        z = q % 3;
     } else {
         const uint64_t i2 = m & (((uint64_t)1 << log_s) - 1), k1 = m >> log_s;
         e = ((i2 * k1) << log_e) + b * i2;
@@ -287,17 +347,50 @@ struct NttPlan {
 
 static std::map<std::string, NttPlan*> g_plans;   // guarded by the ctx mutex
 
+// Pass radices.  A pass of radix 2^r works on tiles of 2^r rows x 4 adjacent columns (128-byte row segments) held in LDS; r <= 8 is a
+// 32 KiB tile for a workgroup of 256 threads (4 workgroups per CU), r = 9 / 10 a 64 / 128 KiB tile for 512 / 1024 threads (16 waves per
+// CU in every case).  Radix 2^10 would make 2^17 .. 2^20 two passes instead of three (one inter-pass twiddle product per element and a
+// third of the traffic less) and was MEASURED: it is slower -- 2^20 -> 2^22 cosets 0.519 vs 0.494 ms per column, the k = 20 MLP proof
+// 0.091 vs 0.087 s (profiles/r03j_ntt_ab.log): sixteen waves behind one barrier wait for each other where four independent 4-wave
+// workgroups fill each other's stalls, and the pass is issue-bound, not traffic-bound.  Default 8; EZKL_NTT_MAXR=9 / 10 select the larger tiles.
+static uint32_t ntt_max_radix() {
+    static const uint32_t v = [] {
+        const char* e = getenv("EZKL_NTT_MAXR");
+        const int x = e ? atoi(e) : 0;
+        return (uint32_t)(x >= 6 && x <= 10 ? x : 8);
+    }();
+    return v;
+}
 static void plan_radices(uint32_t log_n, NttPlan* p) {
     if (log_n <= NTT_LOG_SINGLE) {
         p->npass = 1;
         p->log_radix[0] = log_n;
         return;
     }
-    int np = (int)((log_n + 7) / 8);
+    const uint32_t maxr = ntt_max_radix();
+    int np = (int)((log_n + maxr - 1) / maxr);
     if (np < 2) np = 2;
+    if (np > 4) np = 4;
     p->npass = np;
     uint32_t base = log_n / np, extra = log_n % np;
     for (int i = 0; i < np; i++) p->log_radix[i] = base + ((uint32_t)i < extra ? 1 : 0);
+}
+// tile of a multi-pass plan's pass of radix 2^r: at least 1024 elements, 4 columns
+static uint32_t pass_log_tile(uint32_t log_r) { return log_r + 2 > NTT_LOG_TILE ? log_r + 2 : NTT_LOG_TILE; }
+static void launch_pass(const PassArgs& a, uint32_t tiles, unsigned blocks_y, size_t lds, hipStream_t st) {
+    if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
+    else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
+}
+static int ntt_kernel_attrs() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    return EZKL_OK;
 }
 
 static int plan_get(Ctx* c, hipStream_t st, uint32_t log_n, const fe_t& omega, NttPlan** out) {
@@ -366,11 +459,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     int rc = plan_get(c, st, log_n, omega, &p);
     if (rc) return rc;
     const size_t n = (size_t)1 << log_n;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if ((rc = ntt_kernel_attrs())) return rc;
     fe_t* work = nullptr;
     if (p->npass > 1) {
         rc = arena_reserve(c->scratch, batch * n * sizeof(fe_t), st, (void**)&work);
@@ -395,7 +484,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
         a.log_n = log_n;
         a.log_r = p->log_radix[i];
         a.log_m = log_m;
-        a.log_tile = p->npass == 1 ? log_n : NTT_LOG_TILE;
+        a.log_tile = p->npass == 1 ? log_n : pass_log_tile(a.log_r);
         if (a.log_tile < a.log_r) a.log_tile = a.log_r;
         a.first = first;
         a.last = last;
@@ -418,7 +507,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
         }
         const uint32_t tiles = 1u << (log_n - a.log_tile);
         const size_t lds = 32u * ((size_t)1 << a.log_tile) + 32u * (a.log_r ? ((size_t)1 << (a.log_r - 1)) : 1);
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)batch), dim3(NTT_THREADS), lds, st, a);
+        launch_pass(a, tiles, (unsigned)batch, lds, st);
         log_m -= a.log_r;
     }
     EZ_HIP(hipGetLastError());
@@ -478,11 +567,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
     if ((rc = coset_tables_get(c, st, p, log_n, log_ext, w_ext, &ct))) return rc;
     const uint32_t log_e = log_ext - log_n;
     const size_t n = (size_t)1 << log_n, blocks = batch << log_e;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if ((rc = ntt_kernel_attrs())) return rc;
     fe_t* work = nullptr;
     if (p->npass > 1) {
         rc = arena_reserve(c->scratch, blocks * n * sizeof(fe_t), st, (void**)&work);
@@ -505,7 +590,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         a.log_n = log_n;
         a.log_r = p->log_radix[i];
         a.log_m = log_m;
-        a.log_tile = p->npass == 1 ? log_n : NTT_LOG_TILE;
+        a.log_tile = p->npass == 1 ? log_n : pass_log_tile(a.log_r);
         if (a.log_tile < a.log_r) a.log_tile = a.log_r;
         a.first = first;
         a.last = last;
@@ -514,6 +599,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         for (int q = 0; q < 4; q++) a.log_radix[q] = p->log_radix[q];
         a.cm = 1;
         a.cm_log_e = log_e;
+        a.dit = first ? 1u : 0u;
         a.tw_pre = ct.pre;
         if (last) {
             const uint32_t logC = a.log_tile - a.log_r;
@@ -521,7 +607,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         }
         const uint32_t tiles = 1u << (log_n - a.log_tile);
         const size_t lds = 32u * ((size_t)1 << a.log_tile) + 32u * (a.log_r ? ((size_t)1 << (a.log_r - 1)) : 1);
-        hipLaunchKernelGGL(ntt_pass_kernel, dim3(tiles, (unsigned)blocks), dim3(NTT_THREADS), lds, st, a);
+        launch_pass(a, tiles, (unsigned)blocks, lds, st);
         log_m -= a.log_r;
     }
     EZ_HIP(hipGetLastError());

@@ -1427,22 +1427,32 @@ static void shplonk_prove(Backend& be, EvmTranscript& T, const std::vector<OpenQ
 
 // ------------------------------------------------------------------ the numerator of h(X)
 struct Quotient {
-    Program prog;
+    std::vector<Program> progs;    // run one after the other on the same output: program p continues the Horner chain from PreviousValue
     std::vector<Col> cols;         // coset-major extended columns (null: a witness column this rank does not own)
     std::vector<int> owner;        // per slot: the rank holding the column, -1 = resident on every rank (key columns, replicated provers)
     std::vector<Fe> chal;
 };
-// ONE straight-line program over the extended-coset columns: custom gates, then the permutation and lookup
-// constraints, folded with y (value = value*y + constraint), as Evaluator::evaluate_h does.  The program is written for ONE coset
-// (k = ext_k = cs.k: a rotation by r is a shift by r rows inside the coset) and run once per coset of the extended domain.
+// how many constraint terms go into one sweep kernel (EZKL_PROVER_SWEEP_TERMS; 0 = all in one kernel)
+static uint32_t sweep_terms_per_program() {
+    static const uint32_t v = [] {
+        const char* e = getenv("EZKL_PROVER_SWEEP_TERMS");
+        const int x = e ? atoi(e) : -1;
+        return (uint32_t)(x >= 0 ? x : 0);
+    }();
+    return v;
+}
+// Straight-line programs over the extended-coset columns: custom gates, then the permutation and lookup constraints, folded with y
+// (value = value*y + constraint), as Evaluator::evaluate_h does.  The programs are written for ONE coset (k = ext_k = cs.k: a rotation
+// by r is a shift by r rows inside the coset) and run once per coset of the extended domain.  The Horner fold starts from
+// ValueSource::PreviousValue, so the list of terms can be cut anywhere: kernel p+1 continues where kernel p stopped (smaller kernels
+// compile much faster -- hiprtc time grows faster than linearly with the program -- and each reads only the columns of its own terms).
 // *_owner: owner rank of the witness columns (advice by column, z by chunk, m / phi by lookup), -1 = every rank holds them.
 static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& pk, const std::vector<Col>& adv_cosets, const std::vector<Col>& z_cosets,
                                  const Fe& beta, const Fe& gamma, const Fe& y, const Fe& theta, const std::vector<Col>& m_cosets,
                                  const std::vector<Col>& phi_cosets, const std::vector<Col>& inst_cosets, const std::vector<Fe>& user_chal,
                                  const std::vector<int>& adv_owner = {}, const std::vector<int>& z_owner = {}, const std::vector<int>& lk_owner = {},
                                  int inst_owner = -1) {
-    Quotient Q{Program(cs.k, cs.k), {}, {}, {y, beta, gamma}};
-    Program& prog = Q.prog;
+    Quotient Q{{}, {}, {}, {y, beta, gamma}};
     Q.chal.insert(Q.chal.end(), user_chal.begin(), user_chal.end());
     std::map<std::vector<uint32_t>, uint32_t> index;
     auto own = [](const std::vector<int>& v, uint32_t i) { return i < v.size() ? v[i] : -1; };
@@ -1455,82 +1465,113 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
         return (uint32_t)Q.cols.size() - 1;
     };
     enum : uint32_t { S_L0 = 100, S_LLAST, S_LACT, S_X, S_Z, S_SIGMA, S_PHI, S_M };
-    Lowering low{cs, prog,
-                 [&](uint32_t kind, uint32_t c) {
-                     return kind == N_ADV ? slot({kind, c}, adv_cosets[c], own(adv_owner, c)) : kind == N_INST ? slot({kind, c}, inst_cosets[c], inst_owner)
-                                                                                                              : slot({kind, c}, pk.fixed_cosets[c]);
-                 },
-                 [&](uint32_t idx) { return prog.challenge(3 + idx); },
-                 {}};
-    const Src Y = prog.challenge(0), BETA = prog.challenge(1), GAMMA = prog.challenge(2);
-    std::vector<Src> terms;
-    for (uint32_t g : cs.gates) terms.push_back(low.lower(g));
+    auto col_slot = [&](uint32_t kind, uint32_t c) {
+        return kind == N_ADV ? slot({kind, c}, adv_cosets[c], own(adv_owner, c)) : kind == N_INST ? slot({kind, c}, inst_cosets[c], inst_owner)
+                                                                                                 : slot({kind, c}, pk.fixed_cosets[c]);
+    };
+    // an emitter appends the terms of one gate / one permutation chunk / one lookup argument to the program it is handed; sub-expressions
+    // are shared inside an emitter's program (Lowering's memo), never across programs
+    using Emit = std::function<void(Program&, Lowering&, std::vector<Src>&)>;
+    std::vector<std::pair<Emit, uint32_t>> emitters;          // (emitter, number of terms it appends)
+    for (uint32_t g : cs.gates) emitters.push_back({[g](Program&, Lowering& low, std::vector<Src>& terms) { terms.push_back(low.lower(g)); }, 1});
     if (!cs.perm.empty()) {
-        const Src l0 = prog.column(slot({S_L0}, pk.l0)), llast = prog.column(slot({S_LLAST}, pk.l_last)), lact = prog.column(slot({S_LACT}, pk.l_active));
-        const Src X = prog.column(slot({S_X}, pk.x_coset));
-        const Src one = prog.constant(Fe::one());
+        const uint32_t s_l0 = slot({S_L0}, pk.l0), s_ll = slot({S_LLAST}, pk.l_last), s_la = slot({S_LACT}, pk.l_active), s_x = slot({S_X}, pk.x_coset);
         const uint32_t nz = (uint32_t)z_cosets.size();
         std::vector<uint32_t> zc;
         for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j], own(z_owner, j)));
-        terms.push_back(prog.mul(l0, prog.sub(one, prog.column(zc[0]))));
-        const Src zl = prog.column(zc[nz - 1]);
-        terms.push_back(prog.mul(llast, prog.sub(prog.calc(EZKL_OP_SQUARE, zl), zl)));
-        for (uint32_t j = 1; j < nz; j++) terms.push_back(prog.mul(l0, prog.sub(prog.column(zc[j]), prog.column(zc[j - 1], (int32_t)cs.usable))));
-        uint32_t pos = 0;
+        const uint32_t usable = cs.usable;
+        emitters.push_back({[=](Program& prog, Lowering&, std::vector<Src>& terms) {
+                                const Src l0 = prog.column(s_l0), llast = prog.column(s_ll), one = prog.constant(Fe::one());
+                                terms.push_back(prog.mul(l0, prog.sub(one, prog.column(zc[0]))));
+                                const Src zl = prog.column(zc[nz - 1]);
+                                terms.push_back(prog.mul(llast, prog.sub(prog.calc(EZKL_OP_SQUARE, zl), zl)));
+                                for (uint32_t j = 1; j < nz; j++) terms.push_back(prog.mul(l0, prog.sub(prog.column(zc[j]), prog.column(zc[j - 1], (int32_t)usable))));
+                            },
+                            1 + nz});
+        uint32_t pos = 0, j = 0;
         const Fe delta{FR_DELTA};
-        uint32_t j = 0;
         for (auto& chunk : cs.perm_chunks()) {
-            Src left = prog.column(zc[j], 1), right = prog.column(zc[j]);
+            std::vector<uint32_t> v_slots, s_slots, bd_idx;
             for (uint32_t i = 0; i < chunk.size(); i++) {
-                const Src vv = prog.column(low.col_slot(chunk[i].first, chunk[i].second));
-                const Src sg = prog.column(slot({S_SIGMA, pos + i}, pk.sigma_cosets[pos + i]));
-                left = prog.mul(left, prog.add(prog.add(vv, prog.mul(BETA, sg)), GAMMA));
+                v_slots.push_back(col_slot(chunk[i].first, chunk[i].second));
+                s_slots.push_back(slot({S_SIGMA, pos + i}, pk.sigma_cosets[pos + i]));
                 Q.chal.push_back(beta * delta.pow(pos + i));
-                const Src bd = prog.challenge((uint32_t)Q.chal.size() - 1);
-                right = prog.mul(right, prog.add(prog.add(vv, prog.mul(bd, X)), GAMMA));
+                bd_idx.push_back((uint32_t)Q.chal.size() - 1);
             }
-            terms.push_back(prog.mul(lact, prog.sub(left, right)));
+            const uint32_t zj = zc[j];
+            emitters.push_back({[=](Program& prog, Lowering&, std::vector<Src>& terms) {
+                                    const Src BETA = prog.challenge(1), GAMMA = prog.challenge(2), X = prog.column(s_x), lact = prog.column(s_la);
+                                    Src left = prog.column(zj, 1), right = prog.column(zj);
+                                    for (size_t i = 0; i < v_slots.size(); i++) {
+                                        const Src vv = prog.column(v_slots[i]), sg = prog.column(s_slots[i]);
+                                        left = prog.mul(left, prog.add(prog.add(vv, prog.mul(BETA, sg)), GAMMA));
+                                        right = prog.mul(right, prog.add(prog.add(vv, prog.mul(prog.challenge(bd_idx[i]), X)), GAMMA));
+                                    }
+                                    terms.push_back(prog.mul(lact, prog.sub(left, right)));
+                                },
+                                1});
             pos += (uint32_t)chunk.size();
             j++;
         }
     }
     if (!cs.lookups.empty()) {
-        const Src l0 = prog.column(slot({S_L0}, pk.l0)), llast = prog.column(slot({S_LLAST}, pk.l_last)), lact = prog.column(slot({S_LACT}, pk.l_active));
+        const uint32_t s_l0 = slot({S_L0}, pk.l0), s_ll = slot({S_LLAST}, pk.l_last), s_la = slot({S_LACT}, pk.l_active);
         Q.chal.push_back(theta);
-        const Src THETA = prog.challenge((uint32_t)Q.chal.size() - 1);
+        const uint32_t theta_idx = (uint32_t)Q.chal.size() - 1;
         for (uint32_t i = 0; i < cs.lookups.size(); i++) {
-            const Lookup& lk = cs.lookups[i];
+            const Lookup* lk = &cs.lookups[i];
             const uint32_t phi_s = slot({S_PHI, i}, phi_cosets[i], own(lk_owner, i)), m_s = slot({S_M, i}, m_cosets[i], own(lk_owner, i));
-            const Src phi = prog.column(phi_s), phi_next = prog.column(phi_s, 1), mcol = prog.column(m_s);
-            std::vector<Src> fb;
-            for (auto& t : lk.inputs) fb.push_back(prog.add(low.compress(t, THETA), BETA));
-            const Src tb = prog.add(low.compress(lk.table, THETA), BETA);
-            Src prodf = fb[0];
-            for (size_t f = 1; f < fb.size(); f++) prodf = prog.mul(prodf, fb[f]);
-            Src ssum{};                                       // sum_j prod_{i != j} (f_i + beta)
-            for (size_t jj = 0; jj < fb.size(); jj++) {
-                bool have = false;
-                Src pj{};
-                for (size_t i2 = 0; i2 < fb.size(); i2++) {
-                    if (i2 == jj) continue;
-                    pj = have ? prog.mul(pj, fb[i2]) : fb[i2];
-                    have = true;
-                }
-                if (!have) pj = prog.constant(Fe::one());
-                ssum = jj == 0 ? pj : prog.add(ssum, pj);
-            }
-            const Src lhs = prog.mul(prog.mul(prog.sub(phi_next, phi), prodf), tb);
-            const Src rhs = prog.sub(prog.mul(ssum, tb), prog.mul(mcol, prodf));
-            terms.push_back(prog.mul(l0, phi));
-            terms.push_back(prog.mul(llast, phi));
-            terms.push_back(prog.mul(lact, prog.sub(lhs, rhs)));
+            emitters.push_back({[=](Program& prog, Lowering& low, std::vector<Src>& terms) {
+                                    const Src l0 = prog.column(s_l0), llast = prog.column(s_ll), lact = prog.column(s_la), BETA = prog.challenge(1),
+                                              THETA = prog.challenge(theta_idx);
+                                    const Src phi = prog.column(phi_s), phi_next = prog.column(phi_s, 1), mcol = prog.column(m_s);
+                                    std::vector<Src> fb;
+                                    for (auto& t : lk->inputs) fb.push_back(prog.add(low.compress(t, THETA), BETA));
+                                    const Src tb = prog.add(low.compress(lk->table, THETA), BETA);
+                                    Src prodf = fb[0];
+                                    for (size_t f = 1; f < fb.size(); f++) prodf = prog.mul(prodf, fb[f]);
+                                    Src ssum{};                                       // sum_j prod_{i != j} (f_i + beta)
+                                    for (size_t jj = 0; jj < fb.size(); jj++) {
+                                        bool have = false;
+                                        Src pj{};
+                                        for (size_t i2 = 0; i2 < fb.size(); i2++) {
+                                            if (i2 == jj) continue;
+                                            pj = have ? prog.mul(pj, fb[i2]) : fb[i2];
+                                            have = true;
+                                        }
+                                        if (!have) pj = prog.constant(Fe::one());
+                                        ssum = jj == 0 ? pj : prog.add(ssum, pj);
+                                    }
+                                    const Src lhs = prog.mul(prog.mul(prog.sub(phi_next, phi), prodf), tb);
+                                    const Src rhs = prog.sub(prog.mul(ssum, tb), prog.mul(mcol, prodf));
+                                    terms.push_back(prog.mul(l0, phi));
+                                    terms.push_back(prog.mul(llast, phi));
+                                    terms.push_back(prog.mul(lact, prog.sub(lhs, rhs)));
+                                },
+                                3});
         }
     }
-    prog.horner(prog.previous(), terms, Y);
+    // cut the emitter list into programs of at most `limit` terms (0: one program)
+    const uint32_t limit = sweep_terms_per_program();
+    size_t e0 = 0;
+    while (e0 < emitters.size() || Q.progs.empty()) {
+        Q.progs.emplace_back(cs.k, cs.k);
+        Program& prog = Q.progs.back();
+        Lowering low{cs, prog, col_slot, [&prog](uint32_t idx) { return prog.challenge(3 + idx); }, {}};
+        std::vector<Src> terms;
+        uint32_t count = 0;
+        while (e0 < emitters.size() && (count == 0 || limit == 0 || count + emitters[e0].second <= limit)) {
+            emitters[e0].first(prog, low, terms);
+            count += emitters[e0].second;
+            e0++;
+        }
+        prog.horner(prog.previous(), terms, prog.challenge(0));
+        if (emitters.empty()) break;
+    }
     return Q;
 }
-// keygen / key loading: have the sweep kernel of this circuit compiled (and on disk) before the first proof asks for it.  The program
-// is a function of the constraint system alone (challenges and columns are run-time operands), so what is built here with placeholder
+// keygen / key loading: have the sweep kernels of this circuit compiled (and on disk) before the first proof asks for them.  The programs
+// are a function of the constraint system alone (challenges and columns are run-time operands), so what is built here with placeholder
 // columns has the code bytes create_proof will build.  Best effort: a failure only means the first proof compiles it itself.
 static void prepare_quotient(const ProvingKey& pk) {
     const ConstraintSystem& cs = *pk.cs;
@@ -1538,7 +1579,7 @@ static void prepare_quotient(const ProvingKey& pk) {
         std::vector<Col> adv(cs.n_advice), zc(cs.n_chunks), mc(cs.lookups.size()), pc(cs.lookups.size()), ic(cs.n_instance);
         std::vector<Fe> uc(cs.n_challenges, Fe::zero());
         Quotient Q = quotient_program(cs, pk, adv, zc, Fe::one(), Fe::one(), Fe::one(), Fe::one(), mc, pc, ic, uc);
-        Q.prog.prepare(Q.cols.size(), Q.chal.size());
+        for (auto& prog : Q.progs) prog.prepare(Q.cols.size(), Q.chal.size());
     } catch (const Error& e) {
         if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_prover] sweep kernel not prepared at keygen: %s\n", e.what());
     }
@@ -1842,14 +1883,15 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         const size_t ns = Q.cols.size();
         // halo of every slot: the rotations the program reads it with, centred
         std::vector<int64_t> hn(ns, 0), hp(ns, 0);
-        for (size_t i = 0; i < Q.prog.code.size(); i += 8)
-            for (size_t sidx : {(size_t)2, (size_t)5})
-                if (Q.prog.code[i + sidx] == EZKL_SRC_COLUMN) {
-                    const uint32_t sl = Q.prog.code[i + sidx + 1];
-                    const int64_t r = centred(Q.prog.rotations[Q.prog.code[i + sidx + 2]], n);
-                    hn[sl] = std::max(hn[sl], -r);
-                    hp[sl] = std::max(hp[sl], r);
-                }
+        for (auto& prog : Q.progs)
+            for (size_t i = 0; i < prog.code.size(); i += 8)
+                for (size_t sidx : {(size_t)2, (size_t)5})
+                    if (prog.code[i + sidx] == EZKL_SRC_COLUMN) {
+                        const uint32_t sl = prog.code[i + sidx + 1];
+                        const int64_t r = centred(prog.rotations[prog.code[i + sidx + 2]], n);
+                        hn[sl] = std::max(hn[sl], -r);
+                        hp[sl] = std::max(hp[sl], r);
+                    }
         auto remote = [&](size_t sl) { return owners && Q.owner[sl] >= 0 && (uint32_t)Q.owner[sl] != topo.rank; };
         // slabs of the columns other ranks own, one per (my unit, remote slot); the exchange lists in the SAME order on both sides:
         // by receiving unit, then by slot, then by piece
@@ -1887,34 +1929,37 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             const uint32_t b = un / split, part = un % split;
             const size_t rlo = (size_t)part * len;
             void* out = Backend::at(hnum, (size_t)b * n + rlo);
-            std::vector<const void*> ptrs;
-            if (split == 1) {                                                     // a whole coset: the program as it is
-                for (size_t sl = 0; sl < ns; sl++) ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : Backend::at(Q.cols[sl], (size_t)b * n));
-                Q.prog.run_ptrs(ptrs, Q.chal, out);
+            if (split == 1) {                                                     // a whole coset: the programs as they are
+                std::vector<const void*> ptrs;
+                for (size_t sl = 0; sl < ns; sl++) ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : (Q.cols[sl] ? Backend::at(Q.cols[sl], (size_t)b * n) : nullptr));
+                for (auto& prog : Q.progs) prog.run_ptrs(ptrs, Q.chal, out);
             } else {                                                              // a row range: every (column, rotation) becomes a window at rotation 0
-                std::vector<std::pair<uint32_t, int64_t>> windows;
-                const Program sub = Q.prog.row_sharded(log_split, windows);
-                for (auto& w : windows) {
-                    const size_t sl = w.first;
-                    const int64_t sh = centred(w.second, n);
-                    if (remote(sl)) {
-                        ptrs.push_back(Backend::at(slab[un][sl], (size_t)(hn[sl] + sh)));
-                        continue;
+                for (auto& prog : Q.progs) {
+                    std::vector<const void*> ptrs;
+                    std::vector<std::pair<uint32_t, int64_t>> windows;
+                    const Program sub = prog.row_sharded(log_split, windows);
+                    for (auto& w : windows) {
+                        const size_t sl = w.first;
+                        const int64_t sh = centred(w.second, n);
+                        if (remote(sl)) {
+                            ptrs.push_back(Backend::at(slab[un][sl], (size_t)(hn[sl] + sh)));
+                            continue;
+                        }
+                        const int64_t start = ((((int64_t)rlo + sh) % (int64_t)n) + n) % n;
+                        const Col& col = Q.cols[sl];
+                        if (start + (int64_t)len <= (int64_t)n) {
+                            ptrs.push_back(Backend::at(col, (size_t)b * n + (size_t)start));
+                        } else {                                                  // the window wraps around the coset
+                            Col t = be.alloc(len);
+                            const size_t first = (size_t)((int64_t)n - start);
+                            be.scale_into(Backend::at(col, (size_t)b * n + (size_t)start), be.one, t->ptr(), first);
+                            be.scale_into(Backend::at(col, (size_t)b * n), be.one, Backend::at(t, first), len - first);
+                            stitched.push_back(t);
+                            ptrs.push_back(t->ptr());
+                        }
                     }
-                    const int64_t start = ((((int64_t)rlo + sh) % (int64_t)n) + n) % n;
-                    const Col& col = Q.cols[sl];
-                    if (start + (int64_t)len <= (int64_t)n) {
-                        ptrs.push_back(Backend::at(col, (size_t)b * n + (size_t)start));
-                    } else {                                                      // the window wraps around the coset
-                        Col t = be.alloc(len);
-                        const size_t first = (size_t)((int64_t)n - start);
-                        be.scale_into(Backend::at(col, (size_t)b * n + (size_t)start), be.one, t->ptr(), first);
-                        be.scale_into(Backend::at(col, (size_t)b * n), be.one, Backend::at(t, first), len - first);
-                        stitched.push_back(t);
-                        ptrs.push_back(t->ptr());
-                    }
+                    sub.run_ptrs(ptrs, Q.chal, out);
                 }
-                sub.run_ptrs(ptrs, Q.chal, out);
             }
             // divide by the vanishing polynomial: a constant on the coset
             be.scale_into(out, be.vanishing_inv(cs.ext_k, b), out, len);
