@@ -766,6 +766,20 @@ def comm_init(unique_id, world, rank):
     _l.check(_l.load().ezkl_hip_comm_init(bytes(unique_id), C.c_int(world), C.c_int(rank)), "ezkl_hip_comm_init")
 
 
+def contexts_configure(devices):
+    """the context table of libezkl_hip.so, before its first use: context i on device devices[i] (several may share a device)"""
+    arr = (C.c_int * len(devices))(*devices)
+    _l.check(_l.load().ezkl_hip_contexts_configure(C.c_int(len(devices)), arr), "ezkl_hip_contexts_configure")
+
+
+def context_count():
+    return int(_l.load().ezkl_hip_context_count())
+
+
+def set_context(index):
+    _l.check(_l.load().ezkl_hip_set_context(C.c_int(index)), "ezkl_hip_set_context")
+
+
 def comm_init_from_torch(dist, device):
     """rank 0 creates the id, torch.distributed (any backend) broadcasts its 128 bytes, every rank joins"""
     import torch

@@ -6,7 +6,16 @@
 namespace ezkl {
 
 static std::mutex g_init_mu;
-static Ctx* g_ctx = nullptr;
+// The context table.  One context = one device + everything the library keeps for it (streams, arenas, MSM tables, NTT plans, JIT
+// modules, the column pool) behind its own mutex.  A process launched per GPU (torchrun: LOCAL_RANK) has ONE context; a single-process
+// multi-GPU prover (ezkl_hip_init(-1) without LOCAL_RANK: /root/reference/src/execute.rs:1575-1627 is one process) gets one per visible
+// device, and every host thread works on the context it bound itself to (ezkl_hip_set_context; threads start on context 0).  Several
+// contexts may name the same device (ezkl_hip_contexts_configure): that is how the multi-device prover is tested on a one-GPU box.
+static constexpr int MAX_CTX = 64;
+static Ctx* g_ctxs[MAX_CTX] = {nullptr};
+static int g_ctx_device[MAX_CTX];
+static int g_n_ctx = 0;               // 0: table not configured yet
+static thread_local int t_ctx = 0;
 static std::atomic<int> g_last_hip_err{0};
 
 int set_hip_error(hipError_t e, const char* what, const char* file, int line) {
@@ -16,43 +25,94 @@ int set_hip_error(hipError_t e, const char* what, const char* file, int line) {
     return e == hipErrorOutOfMemory ? EZKL_ERR_NOMEM : EZKL_ERR_HIP;
 }
 
-int ctx_init(int device) {
-    std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_ctx) return (device < 0 || g_ctx->device == device) ? EZKL_OK : EZKL_ERR_INVALID;
+static int device_count_checked(int* n) {
     // The prover keeps ~10 streams busy (6 MSM slots, copy, NTT aux, table, caller); the HIP runtime multiplexes streams onto
     // GPU_MAX_HW_QUEUES hardware queues (default 4), and the latency-bound MSM tails of different slots then wait for each other:
     // 8 queues took the k = 17 MLP proof from 44.5 to 38.3 ms (more slots did not help).  Only effective if this is the first HIP call
     // of the process; a user setting wins.
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess || *n <= 0) {
         g_last_hip_err.store((int)e);
         (void)hipGetLastError();
         return EZKL_ERR_NO_DEVICE;
     }
-    if (device < 0) {
-        const char* lr = getenv("LOCAL_RANK");
-        device = lr ? atoi(lr) % n : 0;
+    return EZKL_OK;
+}
+// explicit table: context i on device devices[i]; only before any context exists
+int ctx_configure(int n_ctx, const int* devices) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (n_ctx < 1 || n_ctx > MAX_CTX || !devices) return EZKL_ERR_INVALID;
+    for (int i = 0; i < MAX_CTX; i++)
+        if (g_ctxs[i]) return EZKL_ERR_INVALID;
+    int n = 0;
+    int rc = device_count_checked(&n);
+    if (rc) return rc;
+    for (int i = 0; i < n_ctx; i++)
+        if (devices[i] < 0 || devices[i] >= n) return EZKL_ERR_INVALID;
+    for (int i = 0; i < n_ctx; i++) g_ctx_device[i] = devices[i];
+    g_n_ctx = n_ctx;
+    return EZKL_OK;
+}
+// ezkl_hip_init(device): device >= 0 -> ONE context on that device.  device < 0 -> LOCAL_RANK set (one process per GPU): one context on
+// device LOCAL_RANK; otherwise ALL visible devices, context i on device i.  Idempotent; a second call may not contradict the first.
+int ctx_init(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_n_ctx) {                                  // already configured: fine unless the caller names a device no context is on
+        if (device < 0) return EZKL_OK;
+        for (int i = 0; i < g_n_ctx; i++)
+            if (g_ctx_device[i] == device) return EZKL_OK;
+        return EZKL_ERR_INVALID;
     }
+    int n = 0;
+    int rc = device_count_checked(&n);
+    if (rc) return rc;
     if (device >= n) return EZKL_ERR_INVALID;
+    if (device >= 0) {
+        g_ctx_device[0] = device;
+        g_n_ctx = 1;
+    } else if (const char* lr = getenv("LOCAL_RANK")) {
+        g_ctx_device[0] = atoi(lr) % n;
+        g_n_ctx = 1;
+    } else {
+        g_n_ctx = n < MAX_CTX ? n : MAX_CTX;
+        for (int i = 0; i < g_n_ctx; i++) g_ctx_device[i] = i;
+    }
+    return EZKL_OK;
+}
+static int ctx_create(int idx) {
+    const int device = g_ctx_device[idx];
     EZ_HIP(hipSetDevice(device));
     Ctx* c = new Ctx();
     c->device = device;
+    c->index = idx;
     EZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     EZ_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
-    g_ctx = c;
+    g_ctxs[idx] = c;
     return EZKL_OK;
 }
 
 Ctx* ctx() {
-    if (!g_ctx) {
-        if (ctx_init(-1) != EZKL_OK) return nullptr;
+    if (!g_n_ctx && ctx_init(-1) != EZKL_OK) return nullptr;
+    const int idx = t_ctx;
+    if (idx < 0 || idx >= g_n_ctx) return nullptr;
+    if (!g_ctxs[idx]) {
+        std::lock_guard<std::mutex> lk(g_init_mu);
+        if (!g_ctxs[idx] && ctx_create(idx) != EZKL_OK) return nullptr;
     }
-    return g_ctx;
+    return g_ctxs[idx];
 }
+int ctx_count() { return g_n_ctx; }
+int ctx_bind(int idx) {
+    if (!g_n_ctx && ctx_init(-1) != EZKL_OK) return EZKL_ERR_NO_DEVICE;
+    if (idx < 0 || idx >= g_n_ctx) return EZKL_ERR_INVALID;
+    t_ctx = idx;
+    return EZKL_OK;
+}
+int ctx_device_of(int idx) { return idx >= 0 && idx < g_n_ctx ? g_ctx_device[idx] : -1; }
 
 int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out) {
     if (!a.last_event) EZ_HIP(hipEventCreateWithFlags(&a.last_event, hipEventDisableTiming));
@@ -111,6 +171,25 @@ using namespace ezkl;
 extern "C" {
 
 int ezkl_hip_init(int device) { return ctx_init(device); }
+int ezkl_hip_contexts_configure(int n_contexts, const int* devices) { return ctx_configure(n_contexts, devices); }
+int ezkl_hip_context_count(void) {
+    if (!ctx_count() && ctx_init(-1) != EZKL_OK) return 0;
+    return ctx_count();
+}
+int ezkl_hip_set_context(int index) { return ctx_bind(index); }
+int ezkl_hip_context_device(int index) { return ctx_device_of(index); }
+// device-to-device copy between two contexts (their devices may differ: the peer copy of a single-process multi-GPU prover's exchange);
+// synchronous: the source must be complete (the caller synchronised its context), the data is in place on return
+int ezkl_hip_memcpy_peer(void* dst_dev, int dst_context, const void* src_dev, int src_context, size_t bytes) {
+    if ((!dst_dev || !src_dev) && bytes) return EZKL_ERR_INVALID;
+    const int dd = ctx_device_of(dst_context), sd = ctx_device_of(src_context);
+    if (dd < 0 || sd < 0) return EZKL_ERR_INVALID;
+    if (!bytes) return EZKL_OK;
+    EZ_HIP(hipSetDevice(dd));
+    if (dd == sd) EZ_HIP(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
+    else EZ_HIP(hipMemcpyPeer(dst_dev, dd, src_dev, sd, bytes));
+    return EZKL_OK;
+}
 
 int ezkl_hip_device_count(void) {
     int n = 0;
@@ -181,12 +260,23 @@ int ezkl_hip_enabled(uint32_t k) {
 // is freed; a caller that used it on ITS OWN stream synchronises that stream before freeing it.  (hipFree's implicit
 // device-wide sync on every reuse was measured at 0.3 ms per allocation with the library's ten streams alive, and it turned
 // every allocation into a barrier for work in flight on other streams; EZKL_HIP_POOL_SYNC=1 brings it back for debugging.)
+extern "C++" {
 namespace {
-std::map<size_t, std::vector<void*>> g_pool;          // guarded by the ctx mutex
-std::map<void*, size_t> g_sizes;
-size_t g_pool_bytes = 0;
+struct PoolState {
+    std::map<size_t, std::vector<void*>> pool;        // guarded by the context's mutex
+    std::map<void*, size_t> sizes;
+    size_t pool_bytes = 0;
+};
+PoolState& pool_state(Ctx* c) {
+    if (!c->pool_state) c->pool_state = new PoolState();
+    return *static_cast<PoolState*>(c->pool_state);
+}
 const size_t POOL_CAP = (size_t)48 << 30;
 }
+}
+#define g_pool (pool_state(c).pool)
+#define g_sizes (pool_state(c).sizes)
+#define g_pool_bytes (pool_state(c).pool_bytes)
 int ezkl_hip_malloc(void** dptr, size_t bytes) {
     if (!dptr) return EZKL_ERR_INVALID;
     EZ_CTX(c);
@@ -226,6 +316,9 @@ int ezkl_hip_free(void* dptr) {
     EZ_HIP(hipFree(dptr));
     return EZKL_OK;
 }
+#undef g_pool
+#undef g_sizes
+#undef g_pool_bytes
 int ezkl_hip_host_malloc(void** p, size_t bytes) {
     if (!p) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -34,10 +34,21 @@ struct Ctx {
         bool in_use = false;
     };
     Arena scratch, aux;
+    // Everything a module keeps between calls lives in the context it was made for (MSM window tables, slots and streams; NTT plans and
+    // coset tables; JIT modules; the column pool): several contexts -- one per device of a single-process multi-GPU prover, or several
+    // on one device -- never share device state.  The modules own these (created on first use, see msm.hip / ntt.hip / evalh.hip / capi.hip).
+    void* msm_state = nullptr;
+    void* ntt_state = nullptr;
+    void* jit_state = nullptr;
+    void* pool_state = nullptr;
+    int index = 0;                    // position in the context table (ezkl_hip_set_context)
 };
 
-Ctx* ctx();                 // lazily initialised singleton (nullptr + last error set if no device)
+Ctx* ctx();                 // the context the CALLING THREAD is bound to (ezkl_hip_set_context; default 0), lazily initialised (nullptr + last error set if no device)
 int ctx_init(int device);
+int ctx_count();
+int ctx_bind(int idx);
+int ctx_device_of(int idx);
 int set_hip_error(hipError_t e, const char* what, const char* file, int line);
 int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out);   // acquire for work on stream st
 int arena_done(Ctx::Arena& a, hipStream_t st);                               // mark the end of that work

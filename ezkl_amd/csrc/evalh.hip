@@ -236,8 +236,20 @@ struct JitKernel {
     std::string key;          // the bytes the hash was taken of (code words + rotations): compared on a hit, a hash collision is a miss
     bool failed = false;      // negative cache: a program that did not compile is not compiled again on every sweep
 };
-static std::multimap<uint64_t, JitKernel> g_jit;    // guarded by the ctx mutex
-static uint64_t g_jit_compiled = 0, g_jit_from_disk = 0, g_jit_hits = 0;
+// per-context state (Ctx::jit_state): a hipModule_t belongs to the device it was loaded on
+struct JitState {
+    std::multimap<uint64_t, JitKernel> jit;
+    uint64_t compiled = 0, from_disk = 0, hits = 0;
+};
+static JitState& jit_state() {
+    Ctx* c = ctx();
+    if (!c->jit_state) c->jit_state = new JitState();
+    return *static_cast<JitState*>(c->jit_state);
+}
+#define g_jit (jit_state().jit)
+#define g_jit_compiled (jit_state().compiled)
+#define g_jit_from_disk (jit_state().from_disk)
+#define g_jit_hits (jit_state().hits)
 void eval_jit_stats(uint64_t* compiled, uint64_t* from_disk, uint64_t* hits) { *compiled = g_jit_compiled; *from_disk = g_jit_from_disk; *hits = g_jit_hits; }
 
 static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {

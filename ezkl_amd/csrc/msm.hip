@@ -87,7 +87,74 @@ struct MsmTable {
     hipEvent_t ready = nullptr;   // recorded after the build
     bool synced = false;          // a host wait on `ready` has happened
 };
-static std::map<const Bases*, MsmTable> g_tables;   // guarded by the ctx mutex
+// ---- per-context state: window tables, stream slots, the open upload phase / batch (Ctx::msm_state; one per context, so that the
+// contexts of a single-process multi-GPU prover never share device objects).  The names below are what the code uses.
+struct MsmSlot;
+struct MsmUpload;
+struct MsmBatch;
+struct MsmState;
+static MsmState& msm_state();
+#define g_tables (msm_state().tables)
+#define g_table_stream (msm_state().table_stream)
+#define g_slots (msm_state().slots)
+#define g_call_slots (msm_state().call_slots)
+#define g_call_claimed (msm_state().call_claimed)
+#define g_call_order_ev (msm_state().call_order_ev)
+#define g_copy_st (msm_state().copy_st)
+#define g_tail_pinned (msm_state().tail_pinned)
+#define g_tail_pinned_elems (msm_state().tail_pinned_elems)
+#define g_open_upload (msm_state().open_upload)
+#define g_open_batch (msm_state().open_batch)
+
+// One in-flight MSM: its own scratch arena, a pinned landing buffer for the plane sums and a completion event.
+// A batch (one commit phase of the prover) is pipelined over MSM_SLOTS of these on separate streams so that the
+// latency-bound sort / reduce tails of one MSM and the host Horner overlap the accumulate kernel of the next.
+static constexpr int MSM_MAX_SLOTS = 16;
+// how many MSMs of a batch are in flight: EZKL_MSM_SLOTS (1..16) overrides the default
+static int msm_slots_init() {
+    int v = 6;
+    if (const char* e = getenv("EZKL_MSM_SLOTS")) {
+        const int x = atoi(e);
+        if (x >= 1 && x <= MSM_MAX_SLOTS) v = x;
+    }
+    return v;
+}
+static const int MSM_SLOTS = msm_slots_init();
+struct MsmSlot {
+    hipStream_t st = nullptr;
+    uint8_t* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint32_t* pinned = nullptr;       // per MSM of the group: 1 + 22 planes of 36 limbs (g1x29_t), 32 records apart
+    size_t pinned_msms = 0;
+    const fe_t** list_pinned = nullptr;   // the group's scalar-column pointers, staged for the device
+    hipEvent_t done = nullptr;
+    uint32_t bits = 0;
+    uint32_t count = 0;               // MSMs in flight in this slot (one fused group)
+    void* out = nullptr;              // where msm_finish puts the group's `count` affine results (64 B each)
+    bool busy = false;
+};
+static constexpr int MSM_CALL_SLOTS = 4;
+struct MsmState {
+    std::map<const Bases*, MsmTable> tables;
+    hipStream_t table_stream = nullptr;
+    MsmSlot slots[MSM_MAX_SLOTS];
+    MsmSlot call_slots[MSM_CALL_SLOTS];
+    bool call_claimed[MSM_CALL_SLOTS] = {false, false, false, false};
+    hipEvent_t call_order_ev = nullptr;
+    hipStream_t copy_st = nullptr;
+    fe_t* tail_pinned = nullptr;
+    size_t tail_pinned_elems = 0;
+    MsmUpload* open_upload = nullptr;
+    MsmBatch* open_batch = nullptr;
+    bool attrs_set = false;
+    int acc_blocks_per_cu = 0;
+};
+static MsmState& msm_state() {
+    Ctx* c = ctx();                   // the calling thread's context: every user of this state runs under that context's lock (EZ_CTX)
+    if (!c->msm_state) c->msm_state = new MsmState();
+    return *static_cast<MsmState*>(c->msm_state);
+}
+
 
 static WinPlan pick_plan(size_t n) {
     // cost model in point additions: n*W bucket additions + ~4 per bucket for the reduce phase (2^(cmax-1) buckets);
@@ -760,7 +827,6 @@ static int table_get(Ctx* c, hipStream_t st, const Bases* b, MsmTable** out) {
     *out = &it->second;
     return EZKL_OK;
 }
-static hipStream_t g_table_stream = nullptr;
 int msm_table_prepare(Ctx* c, const Bases* b) {
     if (g_tables.count(b)) return EZKL_OK;
     if (!g_table_stream) EZ_HIP(hipStreamCreateWithFlags(&g_table_stream, hipStreamNonBlocking));
@@ -774,35 +840,6 @@ void msm_table_drop(const Bases* b) {
         g_tables.erase(it);
     }
 }
-
-// One in-flight MSM: its own scratch arena, a pinned landing buffer for the plane sums and a completion event.
-// A batch (one commit phase of the prover) is pipelined over MSM_SLOTS of these on separate streams so that the
-// latency-bound sort / reduce tails of one MSM and the host Horner overlap the accumulate kernel of the next.
-static constexpr int MSM_MAX_SLOTS = 16;
-// how many MSMs of a batch are in flight: EZKL_MSM_SLOTS (1..16) overrides the default
-static int msm_slots_init() {
-    int v = 6;
-    if (const char* e = getenv("EZKL_MSM_SLOTS")) {
-        const int x = atoi(e);
-        if (x >= 1 && x <= MSM_MAX_SLOTS) v = x;
-    }
-    return v;
-}
-static const int MSM_SLOTS = msm_slots_init();
-struct MsmSlot {
-    hipStream_t st = nullptr;
-    uint8_t* scratch = nullptr;
-    size_t scratch_bytes = 0;
-    uint32_t* pinned = nullptr;       // per MSM of the group: 1 + 22 planes of 36 limbs (g1x29_t), 32 records apart
-    size_t pinned_msms = 0;
-    const fe_t** list_pinned = nullptr;   // the group's scalar-column pointers, staged for the device
-    hipEvent_t done = nullptr;
-    uint32_t bits = 0;
-    uint32_t count = 0;               // MSMs in flight in this slot (one fused group)
-    void* out = nullptr;              // where msm_finish puts the group's `count` affine results (64 B each)
-    bool busy = false;
-};
-static MsmSlot g_slots[MSM_MAX_SLOTS];
 
 static constexpr size_t MSM_MAX_GROUP = 16;       // MSMs fused into one sequence of launches (gridDim.z)
 static int slot_prepare(MsmSlot& sl, size_t bytes, size_t msms = 1) {
@@ -880,7 +917,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const size_t npairs = n * W;
     const uint32_t PB = bits < MSM_MAX_PART_BITS ? bits : MSM_MAX_PART_BITS, LB = bits - PB, NP = 1u << PB;
     // ---- lane length for the accumulate kernel: fill the resident lanes an integer number of times ----
-    static int acc_blocks_per_cu = 0;
+    int& acc_blocks_per_cu = msm_state().acc_blocks_per_cu;
     if (!acc_blocks_per_cu) {
         EZ_HIP(hipFuncSetAttribute((const void*)msm_binsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         EZ_HIP(hipFuncSetAttribute((const void*)msm_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -1086,10 +1123,6 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
 // wait for the GPU and the host tail run outside the lock, on a call slot of the caller's own (streams, scratch, pinned planes), so
 // the latency-bound tails of one thread's MSM overlap the accumulation of another's -- the overlap the batch entry points give a
 // single-threaded caller.  The slots are separate from the batch slots: a batch never finishes (or reuses) a caller's slot.
-static constexpr int MSM_CALL_SLOTS = 4;
-static MsmSlot g_call_slots[MSM_CALL_SLOTS];
-static bool g_call_claimed[MSM_CALL_SLOTS] = {false, false, false, false};
-static hipEvent_t g_call_order_ev = nullptr;
 int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {
     if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
@@ -1144,9 +1177,6 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
 // an event); the MSM of column j waits for that event on its slot stream, so PCIe traffic for column j+1.. runs under the
 // kernels of column j.  The host columns should be page-locked (ezkl_hip_host_malloc) for the copies to be truly asynchronous;
 // pageable memory still works (the runtime stages it).
-static hipStream_t g_copy_st = nullptr;
-static fe_t* g_tail_pinned = nullptr;
-static size_t g_tail_pinned_elems = 0;
 // One upload phase in flight: the copies are queued by begin(), a caller stream can be made to wait for a column
 // (wait), the columns are committed (commit: each MSM waits for its own copy) and end() drains the copy stream.
 struct MsmUpload {
@@ -1154,7 +1184,6 @@ struct MsmUpload {
     std::vector<fe_t*> dev_cols;
     size_t n = 0;
 };
-static MsmUpload* g_open_upload = nullptr;
 int msm_upload_end(MsmUpload* u) {
     if (!u || u != g_open_upload) return EZKL_ERR_INVALID;
     hipError_t e = g_copy_st ? hipStreamSynchronize(g_copy_st) : hipSuccess;
@@ -1230,7 +1259,6 @@ struct MsmBatch {
     size_t base_offset = 0, n = 0, pushed = 0, retired = 0;
     std::vector<h64::aff> results;
 };
-static MsmBatch* g_open_batch = nullptr;
 static MsmBatch* g_open_batch_fwd() { return g_open_batch; }
 bool msm_batch_is_open() { return g_open_batch != nullptr; }
 int msm_batch_begin(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, size_t n, MsmBatch** out) {

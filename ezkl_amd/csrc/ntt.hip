@@ -345,7 +345,23 @@ struct NttPlan {
     fe_t n_inv;
 };
 
-static std::map<std::string, NttPlan*> g_plans;   // guarded by the ctx mutex
+// per-context state (Ctx::ntt_state): the twiddle tables are device memory of the context's device
+struct CosetTables {
+    fe_t* pre = nullptr;      // E x R1: the stage twiddles of the twisted DIT first pass
+    fe_t* inter = nullptr;    // E x n (nullptr for single-pass transforms)
+};
+struct NttState {
+    std::map<std::string, NttPlan*> plans;
+    std::map<uint64_t, CosetTables> coset_tables;       // key log_n | log_ext << 8
+    bool attrs_set = false;
+};
+static NttState& ntt_state() {
+    Ctx* c = ctx();
+    if (!c->ntt_state) c->ntt_state = new NttState();
+    return *static_cast<NttState*>(c->ntt_state);
+}
+#define g_plans (ntt_state().plans)
+#define g_coset_tables (ntt_state().coset_tables)
 
 // Pass radices.  A pass of radix 2^r works on tiles of 2^r rows x 4 adjacent columns (128-byte row segments) held in LDS; r <= 8 is a
 // 32 KiB tile for a workgroup of 256 threads (4 workgroups per CU), r = 9 / 10 a 64 / 128 KiB tile for 512 / 1024 threads (16 waves per
@@ -383,7 +399,7 @@ static void launch_pass(const PassArgs& a, uint32_t tiles, unsigned blocks_y, si
     else hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
 }
 static int ntt_kernel_attrs() {
-    static bool attr_set = false;
+    bool& attr_set = ntt_state().attrs_set;               // function attributes are per device
     if (!attr_set) {
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -523,11 +539,6 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
 // 4n-point transform never run, and a rotation by r rows is a shift by r INSIDE a coset, so the quotient sweep of coset b touches
 // nothing but coset b of every column.  Output layout: out[b n + j] = p(c_b w_n^j).  The scaling c_b^j with j = i1 S + i2 is split:
 // c_b^(S i1) multiplies the rows at the first pass's load, c_b^i2 is folded into that pass's (per-coset) inter-pass twiddle table.
-struct CosetTables {
-    fe_t* pre = nullptr;      // E x R1
-    fe_t* inter = nullptr;    // E x n (nullptr for single-pass transforms)
-};
-static std::map<uint64_t, CosetTables> g_coset_tables;   // key log_n | log_ext << 8; guarded by the ctx mutex
 
 static int coset_tables_get(Ctx* c, hipStream_t st, NttPlan* p, uint32_t log_n, uint32_t log_ext, const fe_t& w_ext, CosetTables* out) {
     const uint64_t key = (uint64_t)log_n | ((uint64_t)log_ext << 8);

@@ -13,6 +13,9 @@
 #include <random>
 #include <set>
 #include <unordered_map>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -1678,6 +1681,28 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     std::vector<Backend::Forms> adv_forms(cs.n_advice);
     std::vector<int> adv_owner(cs.n_advice, -1);
     std::vector<Fe> user_chal;
+    // owner mode: which advice columns THIS rank reads in Lagrange form at all -- the ones it owns (forms + commitment), the ones the
+    // lookup arguments it owns compress, the ones in the permutation chunks it owns.  Only those cross its PCIe link (at 8 ranks about
+    // half of the k = 20 MLP's witness: the upload is the one stage every rank would otherwise repeat in full).
+    std::vector<uint8_t> adv_needed(cs.n_advice, owners ? 0 : 1);
+    if (owners) {
+        std::vector<uint8_t> seen(cs.nodes.size(), 0);
+        std::set<Query> qs_[3];
+        for (size_t i = 0; i < cs.lookups.size(); i++) {
+            if (!topo.mine(i)) continue;
+            for (auto& t : cs.lookups[i].inputs)
+                for (uint32_t e : t) cs.collect(e, qs_, seen);
+            for (uint32_t e : cs.lookups[i].table) cs.collect(e, qs_, seen);
+        }
+        for (auto& q : qs_[0]) adv_needed[q.col] = 1;
+        size_t j = 0;
+        for (auto& chunk : cs.perm_chunks()) {
+            if (topo.mine(j))
+                for (auto& pc : chunk)
+                    if (pc.first == N_ADV) adv_needed[pc.second] = 1;
+            j++;
+        }
+    }
     for (uint32_t phase = 0; phase < 2; phase++) {
         std::vector<uint32_t> idxs;
         for (uint32_t c = 0; c < cs.n_advice; c++)
@@ -1710,13 +1735,17 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         std::vector<std::vector<U256>> tails;
         std::vector<const void*> hostp, tailp;
         std::vector<void*> devp;
+        std::vector<size_t> up_of(idxs.size(), SIZE_MAX);       // position of column j of the phase in the upload (owner mode: only what this rank reads)
         for (size_t j = 0; j < idxs.size(); j++) {
             const uint32_t c = idxs[j];
             invalid(src[c] == nullptr, "missing advice column");
-            adv_cols[c] = be.alloc(n);
             if (owners) adv_owner[c] = (int)topo.owner(j);
-            if (cs.unblinded[c]) tails.push_back(std::vector<U256>(n - u, Fe::one().v));   // Blind::default() (polycommit.rs:57-61), no randomness drawn
-            else tails.push_back(rng.vec(n - u));               // blinding rows [u, n)
+            std::vector<U256> tail = cs.unblinded[c] ? std::vector<U256>(n - u, Fe::one().v)     // Blind::default() (polycommit.rs:57-61), no randomness drawn
+                                                     : rng.vec(n - u);                           // blinding rows [u, n): drawn on every rank, same stream
+            if (!(topo.mine(j) || adv_needed[c])) continue;
+            adv_cols[c] = be.alloc(n);
+            up_of[j] = hostp.size();
+            tails.push_back(std::move(tail));
             hostp.push_back(src[c]);
             devp.push_back(adv_cols[c]->ptr());
         }
@@ -1727,14 +1756,14 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             // the phase in steps (ezkl_hip_upload_commit_batch in one call): every copy is queued, the NTTs of column j are queued
             // behind ITS copy on the aux stream, then the commits run -- PCIe, MSMs and NTTs overlap
             ezkl_upload_t up = nullptr;
-            check(ezkl_hip_upload_begin(hostp.data(), devp.data(), idxs.size(), n, tailp.data(), u, n - u, &up), "ezkl_hip_upload_begin");
+            check(ezkl_hip_upload_begin(hostp.data(), devp.data(), hostp.size(), n, tailp.data(), u, n - u, &up), "ezkl_hip_upload_begin");
             int rc = EZKL_OK;
             for (size_t j = 0; j < idxs.size(); j++)
                 if (topo.mine(j)) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);     // before the copies are in flight
             try {
                 for (size_t j = 0; j < idxs.size(); j++) {
                     if (!topo.mine(j)) continue;
-                    check(ezkl_hip_upload_wait(up, j, be.aux_stream()), "ezkl_hip_upload_wait");
+                    check(ezkl_hip_upload_wait(up, up_of[j], be.aux_stream()), "ezkl_hip_upload_wait");
                     adv_forms[idxs[j]] = be.forms_async(adv_cols[idxs[j]], cs.ext_k, &adv_forms[idxs[j]]);
                     cs.shard.stats[0]++;
                 }
@@ -2630,4 +2659,263 @@ int ezkl_prover_keccak256(const void* data, size_t len, void* out32) {
     return EZKL_OK;
 }
 const char* ezkl_prover_last_error(void) { return g_last_error.c_str(); }
+}
+
+
+// ------------------------------------------------------------------ one process, several GPUs: the prover group
+// `ezkl prove` is ONE process (/root/reference/src/execute.rs:1575-1627).  A group is the owner-mode prover above run by N host threads
+// of that process, thread r bound to context r of libezkl_hip.so (ezkl_hip_set_context; normally one context per device,
+// ezkl_hip_init(-1)).  The collectives are in-process: commitments are folded and scalars gathered through shared host memory behind a
+// barrier, h is all_gathered and the sweep's row slabs are exchanged by peer copies (ezkl_hip_memcpy_peer, every thread PULLING what
+// it needs into its own device memory).  No RCCL, no second process, no shared-memory hand-off of the witness: every thread reads
+// the caller's advice columns in place.
+namespace ezkl_prover {
+struct ThreadComm {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    bool failed = false;
+    std::vector<std::vector<uint8_t>> host;                 // per rank: what it contributes to a fold / host all_gather
+    std::vector<void*> dev_ptr;                             // per rank: the device buffer of an in-place all_gather
+    std::vector<const ezkl_comm_seg_t*> sends;              // per rank: its send list of the current exchange
+    std::vector<size_t> n_sends;
+    explicit ThreadComm(int w) : world(w), host(w), dev_ptr(w, nullptr), sends(w, nullptr), n_sends(w, 0) {}
+    // all threads of the group arrive, or (after a failure anywhere) nobody waits for the missing ones
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
+        const uint64_t gen = generation;
+        if (++waiting == world) {
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen || failed; });
+        }
+        return !failed;
+    }
+    void fail() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
+    }
+};
+struct ThreadRank {
+    ThreadComm* comm;
+    int rank;
+};
+static int tc_fold(void* user, void* points, uint32_t count) {
+    ThreadRank* tr = (ThreadRank*)user;
+    ThreadComm& C = *tr->comm;
+    C.host[tr->rank].assign((const uint8_t*)points, (const uint8_t*)points + 64 * (size_t)count);
+    if (!C.barrier()) return 1;
+    uint8_t* out = (uint8_t*)points;
+    for (uint32_t j = 0; j < count; j++) {
+        uint8_t acc[64];
+        std::memcpy(acc, C.host[0].data() + 64 * (size_t)j, 64);
+        for (int r = 1; r < C.world; r++) (void)ezkl_hip_g1_add_affine(acc, C.host[r].data() + 64 * (size_t)j, acc);
+        std::memcpy(out + 64 * (size_t)j, acc, 64);
+    }
+    return C.barrier() ? 0 : 1;                              // nobody overwrites its contribution while others still read it
+}
+static int tc_allgather_host(void* user, void* buf, size_t per) {
+    ThreadRank* tr = (ThreadRank*)user;
+    ThreadComm& C = *tr->comm;
+    const uint8_t* mine = (const uint8_t*)buf + per * (size_t)tr->rank;
+    C.host[tr->rank].assign(mine, mine + per);
+    if (!C.barrier()) return 1;
+    for (int r = 0; r < C.world; r++)
+        if (r != tr->rank) std::memcpy((uint8_t*)buf + per * (size_t)r, C.host[r].data(), per);
+    return C.barrier() ? 0 : 1;
+}
+static int tc_gather(void* user, void* buf_dev, size_t total, size_t, size_t bytes) {
+    ThreadRank* tr = (ThreadRank*)user;
+    ThreadComm& C = *tr->comm;
+    if (total != bytes * (size_t)C.world) return 1;
+    if (ezkl_hip_synchronize() != EZKL_OK) { C.fail(); return 1; }          // my slice is complete before anybody pulls it
+    C.dev_ptr[tr->rank] = buf_dev;
+    if (!C.barrier()) return 1;
+    for (int r = 0; r < C.world; r++) {
+        if (r == tr->rank) continue;
+        if (ezkl_hip_memcpy_peer((uint8_t*)buf_dev + bytes * (size_t)r, tr->rank, (const uint8_t*)C.dev_ptr[r] + bytes * (size_t)r, r, bytes) != EZKL_OK) {
+            C.fail();
+            return 1;
+        }
+    }
+    return C.barrier() ? 0 : 1;
+}
+static int tc_exchange(void* user, const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
+    ThreadRank* tr = (ThreadRank*)user;
+    ThreadComm& C = *tr->comm;
+    if (ezkl_hip_synchronize() != EZKL_OK) { C.fail(); return 1; }
+    C.sends[tr->rank] = sends;
+    C.n_sends[tr->rank] = n_sends;
+    if (!C.barrier()) return 1;
+    // pull: my j-th segment from peer p is p's k-th segment to me, k = how many of my earlier receives came from p
+    std::vector<size_t> cursor(C.world, 0);
+    bool ok = true;
+    for (size_t j = 0; j < n_recvs && ok; j++) {
+        const int p = recvs[j].peer;
+        size_t& k = cursor[p];
+        while (k < C.n_sends[p] && C.sends[p][k].peer != tr->rank) k++;
+        if (k == C.n_sends[p] || C.sends[p][k].bytes != recvs[j].bytes) { ok = false; break; }
+        ok = ezkl_hip_memcpy_peer(recvs[j].ptr, tr->rank, C.sends[p][k].ptr, p, recvs[j].bytes) == EZKL_OK;
+        k++;
+    }
+    if (!ok) { C.fail(); return 1; }
+    return C.barrier() ? 0 : 1;                              // the send lists stay valid until everybody has pulled
+}
+}  // namespace ezkl_prover
+
+struct ezkl_prover_group {
+    int world = 1;
+    std::vector<ezkl_cs_t> cs;
+    std::vector<ezkl_bases_t> g, gl;
+    std::vector<ezkl_pk_t> pk;
+    std::unique_ptr<ThreadComm> comm;
+    std::vector<ThreadRank> ranks;
+    std::string error;
+    // run f(rank) on every context's thread; the first error wins
+    template <class F>
+    int run(F&& f) {
+        std::vector<int> rc(world, EZKL_OK);
+        std::vector<std::string> msg(world);
+        std::vector<std::thread> th;
+        {
+            std::lock_guard<std::mutex> lk(comm->mu);        // a fresh run after a failed one
+            comm->failed = false;
+            comm->waiting = 0;
+        }
+        for (int r = 0; r < world; r++)
+            th.emplace_back([&, r] {
+                rc[r] = ezkl_hip_set_context(r);
+                if (rc[r] == EZKL_OK) rc[r] = f(r);
+                if (rc[r] != EZKL_OK) {
+                    msg[r] = ezkl_prover_last_error();
+                    comm->fail();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < world; r++)
+            if (rc[r] != EZKL_OK) {
+                error = "context " + std::to_string(r) + ": " + msg[r];
+                g_last_error = error;
+                return rc[r];
+            }
+        return EZKL_OK;
+    }
+};
+extern "C" {
+int ezkl_prover_group_create(const void* blob, size_t len, int n_contexts, ezkl_group_t* out) {
+    if (!blob || !out || n_contexts < 1) return EZKL_ERR_INVALID;
+    const int avail = ezkl_hip_context_count();
+    if (avail < 1) return EZKL_ERR_NO_DEVICE;
+    if (n_contexts > avail) return EZKL_ERR_INVALID;
+    int world = 1;
+    while (world * 2 <= n_contexts) world *= 2;              // the owner mode shards over a power of two
+    auto grp = std::make_unique<ezkl_prover_group>();
+    grp->world = world;
+    grp->comm = std::make_unique<ThreadComm>(world);
+    grp->cs.assign(world, nullptr);
+    grp->g.assign(world, nullptr);
+    grp->gl.assign(world, nullptr);
+    grp->pk.assign(world, nullptr);
+    grp->ranks.resize(world);
+    int rc = EZKL_OK;
+    for (int r = 0; r < world && !rc; r++) {
+        grp->ranks[r] = ThreadRank{grp->comm.get(), r};
+        rc = ezkl_prover_cs_parse(blob, len, &grp->cs[r]);
+        if (rc || world == 1) continue;
+        const uint32_t n = grp->cs[r]->cs->n, per = n / (uint32_t)world;
+        if (per == 0) { rc = EZKL_ERR_INVALID; break; }
+        rc = ezkl_prover_cs_set_shard(grp->cs[r], (uint32_t)r * per, (uint32_t)(r + 1) * per, tc_fold, &grp->ranks[r]);
+        if (!rc) rc = ezkl_prover_cs_set_sweep_gather(grp->cs[r], tc_gather, &grp->ranks[r]);
+        if (!rc) rc = ezkl_prover_cs_set_shard_exchange(grp->cs[r], tc_allgather_host, tc_exchange, &grp->ranks[r]);
+        if (!rc) rc = ezkl_prover_cs_set_shard_full_bases(grp->cs[r], 1);
+    }
+    if (rc) {
+        for (auto c : grp->cs) (void)ezkl_prover_cs_free(c);
+        return rc;
+    }
+    *out = grp.release();
+    return EZKL_OK;
+}
+int ezkl_prover_group_size(ezkl_group_t grp) { return grp ? grp->world : 0; }
+int ezkl_prover_group_free(ezkl_group_t grp) {
+    if (!grp) return EZKL_OK;
+    (void)grp->run([&](int r) {                               // device objects are released on the context that made them
+        if (grp->pk[r]) (void)ezkl_prover_pk_free(grp->pk[r]);
+        if (grp->g[r]) (void)ezkl_hip_bases_free(grp->g[r]);
+        if (grp->gl[r]) (void)ezkl_hip_bases_free(grp->gl[r]);
+        return EZKL_OK;
+    });
+    for (auto c : grp->cs) (void)ezkl_prover_cs_free(c);
+    delete grp;
+    return EZKL_OK;
+}
+int ezkl_prover_group_load_srs(ezkl_group_t grp, const void* g_points, const void* g_lagrange_points, size_t n) {
+    if (!grp || !g_points || !g_lagrange_points || n == 0) return EZKL_ERR_INVALID;
+    return grp->run([&](int r) {
+        if (grp->g[r]) { (void)ezkl_hip_bases_free(grp->g[r]); grp->g[r] = nullptr; }
+        if (grp->gl[r]) { (void)ezkl_hip_bases_free(grp->gl[r]); grp->gl[r] = nullptr; }
+        int rc = ezkl_hip_bases_upload(g_points, n, &grp->g[r]);
+        if (!rc) rc = ezkl_hip_bases_upload(g_lagrange_points, n, &grp->gl[r]);
+        if (!rc) rc = ezkl_hip_bases_prepare(grp->g[r]);
+        if (!rc) rc = ezkl_hip_bases_prepare(grp->gl[r]);
+        return rc;
+    });
+}
+int ezkl_prover_group_keygen(ezkl_group_t grp, const void* const* fixed_values, const uint32_t* copies, size_t n_copies) {
+    if (!grp) return EZKL_ERR_INVALID;
+    return grp->run([&](int r) {
+        if (!grp->g[r]) return (int)EZKL_ERR_INVALID;
+        if (grp->pk[r]) { (void)ezkl_prover_pk_free(grp->pk[r]); grp->pk[r] = nullptr; }
+        return ezkl_prover_keygen(grp->cs[r], grp->g[r], fixed_values, copies, n_copies, &grp->pk[r]);
+    });
+}
+int ezkl_prover_group_pk(ezkl_group_t grp, int rank, ezkl_pk_t* out) {
+    if (!grp || !out || rank < 0 || rank >= grp->world || !grp->pk[rank]) return EZKL_ERR_INVALID;
+    *out = grp->pk[rank];
+    return EZKL_OK;
+}
+int ezkl_prover_group_create_proof(ezkl_group_t grp, const void* const* advice, const void* const* instances, const uint32_t* instance_lens, uint64_t seed,
+                                   void* proof_out, size_t cap, size_t* proof_len, double* timings, uint64_t* stats) {
+    if (!grp || !advice || !proof_len) return EZKL_ERR_INVALID;
+    // ONE source of randomness for every thread: the det-prove seed, or a 256-bit OS-entropy key drawn here
+    Rng master(nullptr, nullptr, seed);
+    std::vector<std::vector<uint8_t>> proofs(grp->world);
+    std::vector<std::array<double, 12>> tm(grp->world);
+    int rc = grp->run([&](int r) {
+        if (!grp->pk[r] || !grp->g[r] || !grp->gl[r]) return (int)EZKL_ERR_INVALID;
+        if (grp->pk[r]->pk->cs->n_instance && (!instances || !instance_lens)) return (int)EZKL_ERR_INVALID;
+        return guarded([&] {
+            Rng rng = master;
+            proofs[r] = create_proof(*grp->pk[r]->pk, grp->g[r], grp->gl[r], advice, nullptr, nullptr, instances, instance_lens, rng, tm[r].data());
+        });
+    });
+    if (rc) return rc;
+    for (int r = 1; r < grp->world; r++)
+        if (proofs[r] != proofs[0]) {
+            g_last_error = "the contexts of the group produced different proofs";
+            return EZKL_ERR_INVALID;
+        }
+    if (timings) {
+        for (int i = 0; i < 12; i++) {
+            double m = 0;
+            for (int r = 0; r < grp->world; r++) m = std::max(m, tm[r][i]);
+            timings[i] = m;
+        }
+    }
+    if (stats)
+        for (int r = 0; r < grp->world; r++) (void)ezkl_prover_cs_shard_stats(grp->cs[r], stats + 4 * r);
+    *proof_len = proofs[0].size();
+    if (proofs[0].size() > cap || !proof_out) {
+        g_last_error = "proof buffer too small";
+        return EZKL_ERR_NOMEM;
+    }
+    std::memcpy(proof_out, proofs[0].data(), proofs[0].size());
+    return EZKL_OK;
+}
 }

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
-           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
+           "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_group_create", "ezkl_prover_group_size", "ezkl_prover_group_free",
+           "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -242,6 +243,72 @@ class NativeProvingKey:
     def free(self):
         if self.h:
             load().ezkl_prover_pk_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _BorrowedKey:
+    """the key of one context of a group (owned by the group): enough of NativeProvingKey for vk() and verify_proof"""
+
+    def __init__(self, circuit, h):
+        self.circuit, self.h = circuit, h
+
+    vk = NativeProvingKey.vk
+
+
+class NativeGroup:
+    """One process, several GPUs (include/ezkl_prover.h "the prover group"): the owner-mode prover on n contexts of libezkl_hip.so, one
+    host thread per context inside this process.  backend.contexts_configure / ezkl_hip_init(-1) decide what the contexts are."""
+
+    def __init__(self, cs, n_contexts):
+        self.cs = cs
+        self.circuit = type("C", (), {"cs": cs})()
+        blob = serialize_cs(cs)
+        self.h = C.c_void_p()
+        _check(load().ezkl_prover_group_create(blob, C.c_size_t(len(blob)), C.c_int(n_contexts), C.byref(self.h)), "ezkl_prover_group_create")
+        self.world = int(load().ezkl_prover_group_size(self.h))
+
+    def load_srs(self, g, g_lagrange):
+        g, gl = np.ascontiguousarray(g, np.uint64), np.ascontiguousarray(g_lagrange, np.uint64)
+        assert g.shape == gl.shape
+        _check(load().ezkl_prover_group_load_srs(self.h, g.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p), C.c_size_t(g.shape[0])), "ezkl_prover_group_load_srs")
+
+    def keygen(self, fixed_values, copies):
+        fixed = [np.ascontiguousarray(v, np.uint64) for v in fixed_values]
+        cp = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4))
+        _check(load().ezkl_prover_group_keygen(self.h, _ptr_array(fixed), cp.ctypes.data_as(C.c_void_p), C.c_size_t(cp.shape[0])), "ezkl_prover_group_keygen")
+
+    def pk(self, context=0):
+        h = C.c_void_p()
+        _check(load().ezkl_prover_group_pk(self.h, C.c_int(context), C.byref(h)), "ezkl_prover_group_pk")
+        return _BorrowedKey(self.circuit, h)
+
+    def create_proof(self, advice_values, seed=0, instances=(), timings=None, stats=None):
+        keep = [np.ascontiguousarray(a, np.uint64) for a in advice_values]
+        inst = [np.stack([_pl.to_mont(v) for v in vals]) if len(vals) else np.zeros((0, 4), np.uint64) for vals in instances]
+        lens = (C.c_uint32 * max(1, len(inst)))(*[a.shape[0] for a in inst])
+        cap = 1 << 20
+        buf = (C.c_uint8 * cap)()
+        plen = C.c_size_t(0)
+        tm = (C.c_double * 12)()
+        st = (C.c_uint64 * (4 * self.world))()
+        _check(load().ezkl_prover_group_create_proof(self.h, _ptr_array(keep), _ptr_array(inst), lens, C.c_uint64(seed), buf, C.c_size_t(cap), C.byref(plen), tm, st),
+               "ezkl_prover_group_create_proof")
+        if timings is not None:
+            timings.update(dict(zip(STAGES, list(tm))))
+        if stats is not None:
+            names = ["columns_transformed_here", "witness_columns", "exchange_bytes_received", "arguments_computed_here"]
+            stats.extend(dict(zip(names, [int(st[4 * r + i]) for i in range(4)])) for r in range(self.world))
+        return bytes(buf[:plen.value])
+
+    def free(self):
+        if self.h:
+            load().ezkl_prover_group_free(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

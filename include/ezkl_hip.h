@@ -36,7 +36,22 @@ typedef struct ezkl_bases_s* ezkl_bases_t;     /* device-resident G1 base set (S
 
 /* ---- device management: replaces icicle try_load_and_set_backend_device("CUDA") + warmup(),
  *      /root/reference/src/execute.rs:88-95 ---- */
-int ezkl_hip_init(int device);                 /* idempotent, thread-safe; device = ordinal (LOCAL_RANK) */
+/* ezkl_hip_init(device >= 0): one context on that device.  ezkl_hip_init(-1): ALL visible devices, one context per device (context i
+ * on device i) -- `ezkl prove` is one process (src/execute.rs:1575-1627) -- unless LOCAL_RANK is set (a launcher started one process
+ * per GPU): then one context on device LOCAL_RANK.  Idempotent, thread-safe. */
+int ezkl_hip_init(int device);
+/* ---- contexts: single-process multi-GPU ----
+ * A context = one device + everything the library keeps for it (streams, scratch arenas, MSM window tables and slots, NTT plans,
+ * JIT modules, the column pool), behind its own lock.  Every host thread works on the context it bound itself to
+ * (ezkl_hip_set_context; new threads start on context 0), so N threads drive N GPUs concurrently and handles (bases, device pointers,
+ * upload phases, batches) belong to the context they were made on.  ezkl_hip_contexts_configure(n, devices) sets the table
+ * explicitly BEFORE first use -- several contexts may name the same device (how the multi-device prover is tested on a one-GPU box).
+ * ezkl_hip_memcpy_peer: synchronous device-to-device copy between two contexts (hipMemcpyPeer across devices). */
+int ezkl_hip_contexts_configure(int n_contexts, const int* devices);
+int ezkl_hip_context_count(void);
+int ezkl_hip_set_context(int index);
+int ezkl_hip_context_device(int index);                /* device ordinal of a context, -1 if out of range */
+int ezkl_hip_memcpy_peer(void* dst_dev, int dst_context, const void* src_dev, int src_context, size_t bytes);
 int ezkl_hip_warmup(void);
 int ezkl_hip_device_count(void);
 int ezkl_hip_synchronize(void);

@@ -105,6 +105,25 @@ int ezkl_prover_cs_set_shard_exchange(ezkl_cs_t cs, ezkl_allgather_host_fn allga
  * columns in the proof, out[2] = bytes this rank received in the sweep exchange, out[3] = lookup / permutation arguments it computed */
 int ezkl_prover_cs_shard_stats(ezkl_cs_t cs, uint64_t out[4]);
 
+/* ---- one process, several GPUs: the prover group ----
+ * `ezkl prove` is one process (/root/reference/src/execute.rs:1575-1627; set_device() :84-97 runs once).  A group runs the owner-mode
+ * prover above on N contexts of libezkl_hip.so (ezkl_hip_init(-1): one per visible device) with one host thread per context INSIDE the
+ * caller's process: commitments are folded and scalars gathered through host memory, h and the sweep's row slabs move by peer copies
+ * (ezkl_hip_memcpy_peer).  No launcher, no RCCL, no worker processes; every thread reads the caller's advice columns in place.
+ * group_create uses the first 2^t <= n_contexts contexts (n_contexts <= ezkl_hip_context_count()); load_srs uploads the two base sets to
+ * every context and starts their window tables; keygen makes one resident key per context; create_proof returns the proof every
+ * context produced (they are compared) -- the bytes of the one-GPU prover.  timings: the maximum over the contexts per stage;
+ * stats (may be NULL): 4 counters per context as in ezkl_prover_cs_shard_stats.  seed = 0: a 256-bit OS-entropy key shared by all. */
+typedef struct ezkl_prover_group* ezkl_group_t;
+int ezkl_prover_group_create(const void* cs_blob, size_t len, int n_contexts, ezkl_group_t* out);
+int ezkl_prover_group_size(ezkl_group_t group);
+int ezkl_prover_group_free(ezkl_group_t group);
+int ezkl_prover_group_load_srs(ezkl_group_t group, const void* g_points, const void* g_lagrange_points, size_t n);
+int ezkl_prover_group_keygen(ezkl_group_t group, const void* const* fixed_values, const uint32_t* copies, size_t n_copies);
+int ezkl_prover_group_pk(ezkl_group_t group, int context, ezkl_pk_t* out);          /* borrowed: the key of one context (vk, verify_proof) */
+int ezkl_prover_group_create_proof(ezkl_group_t group, const void* const* advice, const void* const* instances, const uint32_t* instance_lens,
+                                   uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings, uint64_t* stats);
+
 /* How advice_fn hands over its columns.  Off (default): `columns[c]` points at a zeroed host buffer of 2^k x 32 B the callback fills.
  * On: `columns` arrives as an array of NULL pointers and the callback STORES, for every column c of the phase, a pointer to its own
  * host column (it may be page-locked, ezkl_hip_host_malloc) that stays valid until create_proof returns: no allocation, no copy --

@@ -176,3 +176,66 @@ def test_column_sharded_prover_world2_and_4_emit_the_single_rank_proof():
         assert all(r[1] == want for r in res), "world %d: sharded proof differs from the single-rank proof" % world
         assert sum(r[2] for r in res) == n_cols + (70 + 3) * world       # every witness column transformed by exactly ONE rank (+ keygen's columns on all)
         assert all(r[3] == 1 for r in res)
+
+
+# ---- the exchange callbacks of the owner-mode C++ prover (ezkl_amd/dist.py exchange_segments / allgather_host_bytes) ----
+class _FakeDevice:
+    """device memory for the CPU test: `pointers` are keys into a dict of byte arrays"""
+    mem = {}
+
+    @staticmethod
+    def memcpy_d2h(ptr, n):
+        return _FakeDevice.mem[ptr][:n].copy()
+
+    @staticmethod
+    def memcpy_h2d(ptr, arr):
+        _FakeDevice.mem[ptr][:len(arr)] = arr
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes
+    from ezkl_amd import dist as D
+    D._b = _FakeDevice
+    # every rank sends two segments of different sizes to every rank (itself included); the k-th segment sent to p is the k-th p receives from us
+    sends, recvs = [], []
+    for p in range(world):
+        for seg in range(2):
+            key = ("s", p, seg)
+            _FakeDevice.mem[key] = np.full(100 + 10 * p + seg, (rank * 16 + p) % 251, np.uint8)
+            sends.append((p, key, len(_FakeDevice.mem[key])))
+            key = ("r", p, seg)
+            _FakeDevice.mem[key] = np.zeros(100 + 10 * rank + seg, np.uint8)
+            recvs.append((p, key, 100 + 10 * rank + seg))
+    D.exchange_segments(sends, recvs, dist, torch.device("cpu"))
+    ok = all((_FakeDevice.mem[("r", p, seg)] == (p * 16 + rank) % 251).all() for p in range(world) for seg in range(2))
+    # allgather_host_bytes on a real host buffer
+    per = 24
+    buf = (ctypes.c_uint8 * (world * per))()
+    for i in range(per):
+        buf[rank * per + i] = rank + 1
+    D.allgather_host_bytes(ctypes.addressof(buf), per, dist, torch.device("cpu"))
+    ok = ok and all(buf[r * per + i] == r + 1 for r in range(world) for i in range(per))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_callbacks_world3():
+    """the host-staged all-to-all (segment lists matched by order per pair of ranks) and the host all_gather the owner-mode prover's
+    callbacks use when the library communicator is not available"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True), (2, True)]
