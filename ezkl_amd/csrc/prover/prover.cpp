@@ -2643,6 +2643,43 @@ int ezkl_prover_verify_proof(ezkl_pk_t pk, const void* g2, const void* s_g2, con
         *accepted = ok ? 1 : 0;
     });
 }
+// verify_proof from the verifying key ALONE (the reference's `verify` reads settings + vk.key, /root/reference/src/execute.rs:1651): the vk
+// file is halo2's raw-bytes layout [3, k, compress] | u32 LE #fixed | #fixed x G1 | #perm x G1 | selector bits; the constraint system
+// supplies the counts.  Host only: no device, no proving key, no private data.
+int ezkl_prover_verify_proof_vk(ezkl_cs_t cs, const void* vk_buf, size_t vk_len, const void* g2, const void* s_g2, const void* proof, size_t proof_len,
+                                const void* const* instances, const uint32_t* instance_lens, int* accepted) {
+    if (!cs || !vk_buf || !g2 || !s_g2 || !proof || !accepted) return EZKL_ERR_INVALID;
+    *accepted = 0;
+    if (cs->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
+    return guarded([&] {
+        ConstraintSystem& c = *cs->cs;
+        const uint8_t* b = (const uint8_t*)vk_buf;
+        const size_t np = c.perm.size(), want = 7 + 64 * ((size_t)c.n_fixed + np);
+        invalid(vk_len < want, "verifying key truncated");
+        invalid(b[0] != 3, "unsupported key version");
+        invalid(b[1] != c.k, "key was made for another k");
+        uint32_t nf = 0;
+        for (int i = 0; i < 4; i++) nf |= (uint32_t)b[3 + i] << (8 * i);
+        invalid(nf != c.n_fixed, "key has another number of fixed columns");
+        ProvingKey vk;                                   // only the verifying-key part is filled
+        vk.cs = &c;
+        vk.fixed_commitments.resize(nf);
+        vk.sigma_commitments.resize(np);
+        if (nf) std::memcpy(vk.fixed_commitments.data(), b + 7, 64 * (size_t)nf);
+        if (np) std::memcpy(vk.sigma_commitments.data(), b + 7 + 64 * (size_t)nf, 64 * np);
+        const Fe digest = vk_digest(vk);
+        const bn::G2 a = bn::g2_from_bytes((const uint8_t*)g2), bb = bn::g2_from_bytes((const uint8_t*)s_g2);
+        if (!bn::g2_on_curve(a) || !bn::g2_on_curve(bb) || a.inf || bb.inf) throw Error(EZKL_ERR_INVALID, "g2 / s_g2 not on the twist");
+        bool ok = false;
+        try {
+            ok = verify_proof(c, vk.fixed_commitments, vk.sigma_commitments, digest, a, bb, (const uint8_t*)proof, proof_len, instances, instance_lens);
+        } catch (const Error& e) {
+            if (e.code != EZKL_ERR_INVALID) throw;
+            g_last_error = e.what();
+        }
+        *accepted = ok ? 1 : 0;
+    });
+}
 int ezkl_prover_g2_mul_generator(const void* scalar, void* out128) {
     if (!scalar || !out128) return EZKL_ERR_INVALID;
     return guarded([&] {

@@ -143,18 +143,22 @@ def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_m
     return proof
 
 
-def verify(proof_path, compiled_circuit, pk_path, srs_path, recommit=False):
-    """-> True / False.  The key file supplies the verifying key (vk.key is its prefix)."""
+def verify(proof_path, compiled_circuit, vk_path, srs_path, recommit=False):
+    """-> True / False, from the proof, the compiled circuit (settings), vk.key and the SRS's g2 / s_g2 -- what the reference's `verify`
+    reads (src/execute.rs:1651).  Host only: no GPU, no proving key, none of the prover's private weights.  A pk.key path works too (vk.key
+    is its prefix).  recommit=True (a key whose commitments were made under another SRS, re-committed by `prove`) needs the proving key and
+    a device: the fixed / permutation polynomials are committed again under this SRS first."""
     circuit, j = _load_circuit(compiled_circuit)
     pr = codecs.read_proof_json(open(proof_path).read())
     srs = codecs.read_srs(open(srs_path, "rb").read())
-    bg = B.Bases(srs["g"]) if recommit else None
+    if not recommit:
+        return NV.verify_proof_vk(NV.NativeCircuit(_plonk_cs(circuit)), open(vk_path, "rb").read(), srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])
+    bg = B.Bases(srs["g"])
     try:
-        pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(_plonk_cs(circuit)), open(pk_path, "rb").read(), recommit=bg)
+        pk = NV.NativeProvingKey.from_bytes(NV.NativeCircuit(_plonk_cs(circuit)), open(vk_path, "rb").read(), recommit=bg)
         return NV.verify_proof(pk, srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])
     finally:
-        if bg is not None:
-            bg.free()
+        bg.free()
 
 
 def _plonk_cs(circuit):

@@ -16,7 +16,7 @@ _lib = None
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_group_create", "ezkl_prover_group_size", "ezkl_prover_group_free",
            "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
-           "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
+           "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_verify_proof_vk", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 FOLD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
@@ -333,6 +333,17 @@ def verify_proof(pk, g2, s_g2, proof, instances=()):
     proof = bytes(proof)
     _check(load().ezkl_prover_verify_proof(pk.h, bytes(g2), bytes(s_g2), proof, C.c_size_t(len(proof)), _ptr_array(inst), lens, C.byref(ok)),
            "ezkl_prover_verify_proof")
+    return bool(ok.value)
+
+
+def verify_proof_vk(circuit, vk_bytes, g2, s_g2, proof, instances=()):
+    """verify from vk.key alone (the reference's `verify`: settings + vk, src/execute.rs:1651): host only, no GPU, no proving key"""
+    inst = [np.stack([_pl.to_mont(v) for v in vals]) if len(vals) else np.zeros((0, 4), np.uint64) for vals in instances]
+    lens = (C.c_uint32 * max(1, len(inst)))(*[a.shape[0] for a in inst])
+    ok = C.c_int(0)
+    vk_bytes, proof = bytes(vk_bytes), bytes(proof)
+    _check(load().ezkl_prover_verify_proof_vk(circuit.h, vk_bytes, C.c_size_t(len(vk_bytes)), bytes(g2), bytes(s_g2), proof, C.c_size_t(len(proof)),
+                                              _ptr_array(inst), lens, C.byref(ok)), "ezkl_prover_verify_proof_vk")
     return bool(ok.value)
 
 

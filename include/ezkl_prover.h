@@ -191,6 +191,11 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
  * pairing check passes; a malformed proof is a rejection (0), not an error. */
 int ezkl_prover_verify_proof(ezkl_pk_t pk, const void* g2, const void* s_g2, const void* proof, size_t proof_len, const void* const* instances,
                              const uint32_t* instance_lens, int* accepted);
+/* The same from the verifying key ALONE, as the reference's `verify` does (settings + vk.key, /root/reference/src/execute.rs:1651): vk_buf
+ * is halo2's raw-bytes vk.key ([3, k, compress] | u32 LE #fixed | commitments | selector bits; the prefix of pk.key).  Host only: no
+ * device, no proving key, none of the prover's private data. */
+int ezkl_prover_verify_proof_vk(ezkl_cs_t cs, const void* vk_buf, size_t vk_len, const void* g2, const void* s_g2, const void* proof, size_t proof_len,
+                                const void* const* instances, const uint32_t* instance_lens, int* accepted);
 /* [s] G2 for a Montgomery Fr scalar s: the `s_g2` of a test SRS (gen_srs, src/pfsys/srs.rs:13-16); s = 1 gives the generator g2. */
 int ezkl_prover_g2_mul_generator(const void* scalar, void* out128);
 /* keccak256 of a byte string (exposed so the transcript can be tested against the Python restatement without a GPU) */

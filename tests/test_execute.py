@@ -33,13 +33,16 @@ def test_setup_prove_verify_on_files(hip, tmp_path):
     assert pj["proof"] == proof and pj["instances"] == [[0, 0, 0, 0]]
     ref_pj = json.load(open(os.path.join(FX.G, "proof_k6.json")))
     assert pj["raw"]["instances"] == ref_pj["instances"] and len(pj["raw"]["hex_proof"]) == len(ref_pj["hex_proof"])
-    assert X.verify(str(proof_path), str(compiled), str(pk_path), srs)
+    assert X.verify(str(proof_path), str(compiled), str(vk_path), srs)          # from vk.key alone: host only, no proving key
+    assert X.verify(str(proof_path), str(compiled), str(pk_path), srs)          # pk.key starts with the vk
+    with pytest.raises(RuntimeError, match="truncated"):
+        X.verify(str(proof_path), str(compiled), str(tmp_path / "short.key") if (tmp_path / "short.key").write_bytes(vk_path.read_bytes()[:100]) else "", srs)
     j = json.loads(proof_path.read_text())
     j["proof"][4000] ^= 1
     j["hex_proof"] = "0x" + bytes(j["proof"]).hex()
     bad = tmp_path / "bad.json"
     bad.write_text(json.dumps(j))
-    assert not X.verify(str(bad), str(compiled), str(pk_path), srs)
+    assert not X.verify(str(bad), str(compiled), str(vk_path), srs)
     # a witness file whose outputs disagree with the circuit is refused before proving
     w = json.load(open(wit)); w["outputs"][0][0] = "01" + "00" * 31
     wb = tmp_path / "w.json"; wb.write_text(json.dumps(w))
