@@ -178,19 +178,22 @@ int ezkl_hip_context_count(void) {
 }
 int ezkl_hip_set_context(int index) { return ctx_bind(index); }
 int ezkl_hip_context_device(int index) { return ctx_device_of(index); }
-// device-to-device copy between two contexts (their devices may differ: the peer copy of a single-process multi-GPU prover's exchange);
-// synchronous: the source must be complete (the caller synchronised its context), the data is in place on return
+// device-to-device copy INTO the calling thread's context from another context (their devices may differ: the peer copy of a
+// single-process multi-GPU prover's exchange).  Stream-ordered on the calling context's library stream: later library-stream work of this
+// context sees the data; the SOURCE may be reused only after this context has synchronised (ezkl_hip_synchronize).  A plain hipMemcpy
+// device-to-device is asynchronous with respect to the host and unordered with the library's non-blocking streams: an earlier version
+// raced at k = 20 (32 MiB slabs) and passed at k = 17.
 int ezkl_hip_memcpy_peer(void* dst_dev, int dst_context, const void* src_dev, int src_context, size_t bytes) {
     if ((!dst_dev || !src_dev) && bytes) return EZKL_ERR_INVALID;
     const int dd = ctx_device_of(dst_context), sd = ctx_device_of(src_context);
     if (dd < 0 || sd < 0) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (c->index != dst_context) return EZKL_ERR_INVALID;          // the destination is the caller's own context
     if (!bytes) return EZKL_OK;
-    EZ_HIP(hipSetDevice(dd));
-    if (dd == sd) EZ_HIP(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
-    else EZ_HIP(hipMemcpyPeer(dst_dev, dd, src_dev, sd, bytes));
+    if (dd == sd) EZ_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+    else EZ_HIP(hipMemcpyPeerAsync(dst_dev, dd, src_dev, sd, bytes, c->stream));
     return EZKL_OK;
 }
-
 int ezkl_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -2781,6 +2781,7 @@ static int tc_gather(void* user, void* buf_dev, size_t total, size_t, size_t byt
             return 1;
         }
     }
+    if (ezkl_hip_synchronize() != EZKL_OK) { C.fail(); return 1; }          // my pulls are done: the others may go on writing their buffers
     return C.barrier() ? 0 : 1;
 }
 static int tc_exchange(void* user, const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
@@ -2801,6 +2802,7 @@ static int tc_exchange(void* user, const ezkl_comm_seg_t* sends, size_t n_sends,
         ok = ezkl_hip_memcpy_peer(recvs[j].ptr, tr->rank, C.sends[p][k].ptr, p, recvs[j].bytes) == EZKL_OK;
         k++;
     }
+    if (ok) ok = ezkl_hip_synchronize() == EZKL_OK;         // the peer copies are stream-ordered: done before the sources may change
     if (!ok) { C.fail(); return 1; }
     return C.barrier() ? 0 : 1;                              // the send lists stay valid until everybody has pulled
 }

@@ -46,7 +46,9 @@ int ezkl_hip_init(int device);
  * (ezkl_hip_set_context; new threads start on context 0), so N threads drive N GPUs concurrently and handles (bases, device pointers,
  * upload phases, batches) belong to the context they were made on.  ezkl_hip_contexts_configure(n, devices) sets the table
  * explicitly BEFORE first use -- several contexts may name the same device (how the multi-device prover is tested on a one-GPU box).
- * ezkl_hip_memcpy_peer: synchronous device-to-device copy between two contexts (hipMemcpyPeer across devices). */
+ * ezkl_hip_memcpy_peer: device-to-device copy INTO the calling thread's context (dst_context must be it) from another context
+ * (hipMemcpyPeerAsync across devices), ordered on the calling context's library stream; the source may be reused once this context has
+ * synchronised (ezkl_hip_synchronize). */
 int ezkl_hip_contexts_configure(int n_contexts, const int* devices);
 int ezkl_hip_context_count(void);
 int ezkl_hip_set_context(int index);
