@@ -325,6 +325,20 @@ def prove_leg():
                               "breakdown_seconds": j["prove_breakdown_seconds"], "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds"), "sweep_kernel": j.get("sweep_kernel")}
     except Exception as e:
         out["mlp_k20"] = {"error": repr(e)[:300]}
+    if os.environ.get("EZKL_BENCH_K22") == "1":
+        # BASELINE configs[4]'s shape (nanoGPT-tiny, k = 22, /root/reference/tests/integration_tests.rs:172-181): the MLP generator scaled to 5
+        # blocks -> 30-36 advice columns, 20-24 lookup arguments, ext 2^24.  Opt-in: the Python layout engine needs minutes per 10 M cells
+        # (EZKL_BENCH_K22_FILL = percent of the cells actually laid out, default 25; the column allocation is that of the full model) and
+        # the CPU prover beside it (EZKL_BENCH_K22_CPU=1) tens of minutes
+        try:
+            j = child({"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": os.environ.get("EZKL_BENCH_K22_FILL", "25"), "REPS": "2"},
+                      ["--pinned"] + (["--cpu"] if os.environ.get("EZKL_BENCH_K22_CPU") == "1" else []), 7200)
+            out["mlp_k22"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
+                              "prove_seconds_cpu": j.get("prove_seconds_cpu"), "proofs_identical_gpu_cpu": j.get("proofs_identical"), "verifier_accepts": j["verifier_accepts"],
+                              "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"],
+                              "hbm_in_use_gib_after_prove": j.get("hbm_in_use_gib_after_prove")}
+        except Exception as e:
+            out["mlp_k22"] = {"error": repr(e)[:300]}
     try:                                               # BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17
         j = child({"CIRCUIT": "conv", "K": "17"}, ["--cpu", "--pinned"], 900)
         out["conv2d_mnist"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],

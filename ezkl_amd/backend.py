@@ -644,9 +644,11 @@ class GraphProgram:
         """host-only: the instruction order the library executes this program in (ezkl_hip_eval_h_schedule)"""
         code, consts, rots = self.arrays()
         cols = (C.c_void_p * max(1, n_columns))()
-        ch = np.zeros((1, 4), np.uint64)
+        # every entry point validates the whole program (operand indices included): declare as many challenges as the code reads
+        n_chal = 1 + max([int(ins[3 + 3 * q]) for ins in code.tolist() for q in (0, 1) if ins[2 + 3 * q] == CHALLENGE] + [0])
+        ch = np.zeros((n_chal, 4), np.uint64)
         pr = _Prog(_p(code), code.shape[0], self.n_intermediates, _p(consts), consts.shape[0], _p(rots), rots.shape[0],
-                   C.cast(cols, _vp), n_columns, _p(ch), 1, self.k, self.ext_k)
+                   C.cast(cols, _vp), n_columns, _p(ch), n_chal, self.k, self.ext_k)
         out = np.zeros_like(code)
         _l.check(_l.load().ezkl_hip_eval_h_schedule(C.byref(pr), out.ctypes.data_as(C.c_void_p)), "ezkl_hip_eval_h_schedule")
         return out
@@ -764,6 +766,13 @@ def comm_unique_id():
 
 def comm_init(unique_id, world, rank):
     _l.check(_l.load().ezkl_hip_comm_init(bytes(unique_id), C.c_int(world), C.c_int(rank)), "ezkl_hip_comm_init")
+
+
+def mem_info():
+    """(free, total) bytes of the calling context's device"""
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    _l.check(_l.load().ezkl_hip_mem_info(C.byref(f), C.byref(t)), "ezkl_hip_mem_info")
+    return int(f.value), int(t.value)
 
 
 def contexts_configure(devices):

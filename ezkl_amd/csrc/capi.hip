@@ -194,6 +194,14 @@ int ezkl_hip_memcpy_peer(void* dst_dev, int dst_context, const void* src_dev, in
     else EZ_HIP(hipMemcpyPeerAsync(dst_dev, dd, src_dev, sd, bytes, c->stream));
     return EZKL_OK;
 }
+// free / total bytes of the calling context's device (hipMemGetInfo): the HBM high-water mark of a proof = total - free after it,
+// the column pool included
+int ezkl_hip_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    EZ_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return EZKL_OK;
+}
 int ezkl_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -338,6 +338,10 @@ static std::string jit_source_r29(const ezkl_program_t* p, const std::vector<uin
     s.reserve(1024 + (size_t)p->n_instr * 160);
     const int waves = jit_knob("EZKL_EVALH_WAVES", 4), barrier = jit_knob("EZKL_EVALH_BARRIER", 1);
     const std::string MUL = jit_knob("EZKL_EVALH_R29", 2) == 2 ? "Fr29::mul_cold(" : "Fr29::mul(";      // 2: the product as a call (small code)
+    // the compiler barrier that makes every term reload its columns (no scratch, 4 waves per SIMD) after every N-th Horner step: N > 1 lets
+    // neighbouring terms share loaded values at the price of registers
+    const int barrier_every = jit_knob("EZKL_EVALH_BARRIER_EVERY", 1) > 0 ? jit_knob("EZKL_EVALH_BARRIER_EVERY", 1) : 1;
+    int horner_steps = 0;
     s += std::string("#define XCD_MAP ") + (jit_knob("EZKL_EVALH_XCD", 0) ? "1" : "0") + "\n";
     s += "#include \"field29.hpp\"\nusing namespace ezkl;\n"
          "__device__ __forceinline__ f29_t ld29(const fe_t* q) {\n"
@@ -427,8 +431,10 @@ static std::string jit_source_r29(const ezkl_program_t* p, const std::vector<uin
             while (1 + a.L > 6) normalize(a);
             while (am + a.alpha > 160 && a.var >= 0) reduce(a);
             s += "    " + t.expr + " = Fr29::add(" + MUL + t.expr + ", " + b.expr + "), " + a.expr + ");\n";
-            if (barrier == 1) s += "    asm volatile(\"\" ::: \"memory\");\n";
-            else if (barrier == 2) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+            if (++horner_steps % barrier_every == 0) {
+                if (barrier == 1) s += "    asm volatile(\"\" ::: \"memory\");\n";
+                else if (barrier == 2) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+            }
             A[tv] = (int)(am + a.alpha);
             Ls[tv] = 1 + a.L;
             last = tv;
@@ -545,7 +551,8 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     key.append((const char*)rot.data(), rot.size() * 4);
     const uint64_t build = jit_build_digest();
     key.append((const char*)&build, sizeof build);
-    const int knobs[4] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2), jit_knob("EZKL_EVALH_XCD", 0)};      // code-generation options are part of the identity
+    const int knobs[5] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2), jit_knob("EZKL_EVALH_XCD", 0),
+                          jit_knob("EZKL_EVALH_BARRIER_EVERY", 1)};      // code-generation options are part of the identity
     key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
     if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_hip] sweep kernel %016llx: %u instructions, %u columns, ext_k %u\n", (unsigned long long)h, p->n_instr, p->n_columns, p->ext_k);

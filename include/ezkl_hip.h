@@ -56,6 +56,7 @@ int ezkl_hip_context_device(int index);                /* device ordinal of a co
 int ezkl_hip_memcpy_peer(void* dst_dev, int dst_context, const void* src_dev, int src_context, size_t bytes);
 int ezkl_hip_warmup(void);
 int ezkl_hip_device_count(void);
+int ezkl_hip_mem_info(size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo of the calling context's device */
 int ezkl_hip_synchronize(void);
 /* caller streams for the `stream` arguments below (a hipStream_t created by the caller works just as well; these exist so
  * that a client of this header alone can use the stream-ordered mode): work queued on one is asynchronous */

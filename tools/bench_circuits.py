@@ -155,13 +155,17 @@ def _build(kind, k, gpu, seed, store, **kw):
         info = dict(circuit="accum_einsum_matmul (benches/accum_einsum_matmul.rs) ij,jk->ik len %d, Freivalds, k=%d" % (L, k), rows_used=rows)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=advice, instances=[], info=info)
     if kind == "mlp":
-        layers, N, blocks = kw.get("layers", 9), kw.get("width"), kw.get("blocks") or 2
-        if N is None:                                  # fill about (blocks - 0.1) blocks of 2 x (2^k - 6) cells: 3 x 2 x blocks advice columns
-            N = int((((blocks - 0.1) * 2 * ((1 << k) - 6)) / layers) ** 0.5)
+        layers, N, blocks, fill = kw.get("layers", 9), kw.get("width"), kw.get("blocks") or 2, kw.get("fill")
+        cap = 2 * ((1 << k) - 6)                       # cells of one block of two inner columns
+        if N is None:                                  # fill about (blocks - 0.1) blocks: 3 x 2 x blocks advice columns
+            N = int((((blocks - 0.1) * (fill or 100) / 100.0 * cap) / layers) ** 0.5)
         Ws = [sparse_weights(rng, N, N) for _ in range(layers)]
         bs = [rng.integers(-20, 20, N).tolist() for _ in range(layers)]
         x = rng.integers(-60, 60, N).tolist()
-        c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2)
+        # fill (percent): lay out only that share of the cells but keep the column allocation of `blocks` full blocks (total_assignments is
+        # what gen-settings would report for the full model): the Python layout engine needs ~15 us per cell, and every kernel of the
+        # prover except the witness MSMs costs the same whatever the cells hold
+        c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2, total_assignments=int((blocks - 0.1) * cap) if fill else None)
         cs, fixed, copies, reg = c.keygen_inputs(x, with_witness=True)      # one synthesis pass for the key and the witness
         adv, inst = c.witness_of(reg)
         info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),

@@ -59,7 +59,8 @@ if CIRCUIT != "synthetic":
     if os.environ.get("LAYERS"): kw["layers"] = int(os.environ["LAYERS"])
     if os.environ.get("WIDTH"): kw["width"] = int(os.environ["WIDTH"])
     if os.environ.get("LENGTH"): kw["length"] = int(os.environ["LENGTH"])
-    if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])      # 3 x 2 x blocks advice columns (k = 22, 5 blocks: BASELINE configs[4]'s shape)
+    if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
+    if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])      # 3 x 2 x blocks advice columns (k = 22, 5 blocks: BASELINE configs[4]'s shape)
     built = BC.build(CIRCUIT, k, gpu=B, **kw)
     cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
     circuit_info = dict(built["info"], **BC.describe(cs), layout_seconds_python=round(time.time() - t0, 1))
@@ -215,6 +216,8 @@ if not SYNTH:
     # the quotient sweep of this key, for the roofline: HIP events around the last eval_h launch of the proof = the last coset's sweep
     n_sweep_cols = (cs.n_advice + len({c for c, _ in cs.fixed_queries}) + cs.n_instance + (4 if (cs.perm or cs.lookups) else 0) + cs.n_chunks + len(cs.perm)
                     + 2 * len(cs.lookups))
+    free_b, total_b = B.mem_info()
+    out["hbm_in_use_gib_after_prove"] = round((total_b - free_b) / 2**30, 2)          # keys, SRS + window tables, and the column pool's high-water mark
     out["sweep_kernel"] = {"kernel": "evalh_jit", "avg_launch_ms": round(B.last_kernel_ms("eval_h"), 4), "rows_per_launch": n, "launches_per_proof": 1 << (cs.ext_k - k),
                            "columns": n_sweep_cols, "algorithmic_bytes_per_launch": 32 * (n_sweep_cols + 1) * n}
     if "--cold" in sys.argv:

@@ -20,6 +20,7 @@ import bench_circuits as BC
 CIRCUIT, k = os.environ.get("CIRCUIT", "mlp"), int(os.environ.get("K", "12"))
 kw = {}
 if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
+if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])
 built = BC.build(CIRCUIT, k, gpu=B, **kw)
 cs, fixed, copies, adv, instances, info = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"], built["info"]
 n = 1 << k

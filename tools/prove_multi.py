@@ -44,6 +44,7 @@ else:
     import bench_circuits as BC
     kw = {a.lower(): int(os.environ[a]) for a in ("LAYERS", "WIDTH", "LENGTH") if os.environ.get(a)}
     if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
+    if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])
     built = BC.build(CIRCUIT, k, gpu=B, **kw)
     cs, fixed, copies, adv, instances, info = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"], built["info"]
 n = 1 << k
