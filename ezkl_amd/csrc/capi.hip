@@ -282,7 +282,21 @@ PoolState& pool_state(Ctx* c) {
     if (!c->pool_state) c->pool_state = new PoolState();
     return *static_cast<PoolState*>(c->pool_state);
 }
-const size_t POOL_CAP = (size_t)48 << 30;
+// how much freed column memory a context keeps parked: 60 % of the device (EZKL_HIP_POOL_CAP_GB overrides).  A k = 22 proof with 30 advice
+// columns cycles through > 100 GB of columns; with the old 48 GiB cap the 512 MiB extended columns were hipFree'd at the end of every
+// proof and hipMalloc'ed again by the next (30 x ~20 ms: the advice phase took 0.85 s instead of 0.2 s)
+size_t pool_cap(Ctx* c) {
+    static size_t cap[64] = {0};
+    size_t& v = cap[c->index & 63];
+    if (!v) {
+        if (const char* e = getenv("EZKL_HIP_POOL_CAP_GB")) v = (size_t)strtoull(e, nullptr, 10) << 30;
+        if (!v) {
+            size_t fr = 0, tot = 0;
+            v = hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? tot / 10 * 6 : (size_t)48 << 30;
+        }
+    }
+    return v;
+}
 }
 }
 #define g_pool (pool_state(c).pool)
@@ -318,7 +332,7 @@ int ezkl_hip_free(void* dptr) {
     EZ_CTX(c);
     auto it = g_sizes.find(dptr);
     if (it == g_sizes.end()) { EZ_HIP(hipFree(dptr)); return EZKL_OK; }
-    if (g_pool_bytes + it->second <= POOL_CAP) {
+    if (g_pool_bytes + it->second <= pool_cap(c)) {
         g_pool[it->second].push_back(dptr);
         g_pool_bytes += it->second;
         return EZKL_OK;

@@ -32,7 +32,13 @@ def busy(a, b):
         tot += max(0, min(b, iv[i][1]) - max(a, iv[i][0]))
         i += 1
     return tot / (b - a)
-regs = sorted((s, e, n) for n, s, e in cur.execute("select name, start, end from regions") if e >= t0)
+import json as _json
+def _label(name, ext):
+    try:
+        return _json.loads(ext).get("message") or name          # roctx ranges: the message is the C-ABI entry point
+    except Exception:
+        return name
+regs = sorted((s, e, _label(n, x)) for n, s, e, x in cur.execute("select name, start, end, extdata from regions") if e >= t0)
 # keep outermost ranges only (nested calls: batch entry points call others)
 outer, last_end = [], 0
 for s, e, n in regs:
