@@ -821,6 +821,25 @@ def comm_fold_points(points):
     return a
 
 
+class _CommSeg(C.Structure):
+    _fields_ = [("peer", C.c_int), ("ptr", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+def comm_alltoallv_dev(sends, recvs):
+    """sends / recvs: lists of (peer, device pointer, bytes); the k-th segment sent to p is the k-th p receives from this rank"""
+    sa = (_CommSeg * max(1, len(sends)))(*[_CommSeg(p, ptr, n) for p, ptr, n in sends])
+    ra = (_CommSeg * max(1, len(recvs)))(*[_CommSeg(p, ptr, n) for p, ptr, n in recvs])
+    _l.check(_l.load().ezkl_hip_comm_alltoallv_dev(sa, C.c_size_t(len(sends)), ra, C.c_size_t(len(recvs))), "ezkl_hip_comm_alltoallv_dev")
+
+
+def comm_allgather_host(arr):
+    """in place on a (world, ...) numpy array: row r valid on rank r going in, every row coming out"""
+    arr = np.ascontiguousarray(arr)
+    world = comm_info()[0]
+    _l.check(_l.load().ezkl_hip_comm_allgather_host(_p(arr), C.c_size_t(arr.nbytes // max(1, world))), "ezkl_hip_comm_allgather_host")
+    return arr
+
+
 def comm_alltoall_dev(send_ptr, send_off, send_len, recv_ptr, recv_off, recv_len):
     arr = lambda v: (C.c_size_t * len(v))(*[int(x) for x in v])
     _l.check(_l.load().ezkl_hip_comm_alltoall_dev(_vp(send_ptr), arr(send_off), arr(send_len), _vp(recv_ptr), arr(recv_off), arr(recv_len)),

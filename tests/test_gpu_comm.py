@@ -24,6 +24,15 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
         B.comm_alltoall_dev(buf.ptr, [256], [4096], dst.ptr, [512], [4096])
         got = dst.to_numpy()
         assert (got[64:64 + 512] == np.arange(32, 32 + 512, dtype=np.uint64)).all()
+        # the multi-segment all-to-all and the host all_gather (world = 1: the self segments, matched by order)
+        a, b_ = B.DeviceBuffer.from_numpy(np.arange(100, 164, dtype=np.uint64)), B.DeviceBuffer.from_numpy(np.arange(500, 532, dtype=np.uint64))
+        ra, rb = B.DeviceBuffer(64 * 8), B.DeviceBuffer(32 * 8)
+        B.comm_alltoallv_dev([(0, a.ptr, 64 * 8), (0, b_.ptr, 32 * 8)], [(0, ra.ptr, 64 * 8), (0, rb.ptr, 32 * 8)])
+        assert (ra.to_numpy() == np.arange(100, 164, dtype=np.uint64)).all() and (rb.to_numpy() == np.arange(500, 532, dtype=np.uint64)).all()
+        with pytest.raises(Exception):                                     # mismatched sizes are refused, not truncated
+            B.comm_alltoallv_dev([(0, a.ptr, 64 * 8)], [(0, ra.ptr, 32 * 8)])
+        h = np.arange(12, dtype=np.uint64).reshape(1, 12)
+        assert (B.comm_allgather_host(h.copy()) == h).all()
         # the C++ host prover over the library communicator: same bytes as the unsharded prover
         cs = TP.lookup_circuit(6)
         adv, fixed, copies = TP.lookup_witness(cs, 4)
@@ -32,6 +41,7 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
         want = NV.create_proof(plain, bg, bgl, adv, seed=9)
         nc = NV.NativeCircuit(cs)
         assert nc.set_shard_comm() == (0, cs.n)
+        nc.set_shard_full_bases(True)                                      # world 1 stays the plain prover; the owner mode needs world > 1
         pk = NV.NativeProvingKey(nc, bg, fixed, copies)
         assert NV.create_proof(pk, bg, bgl, adv, seed=9) == want
         # seed 0 on a sharded prover: rank 0's 256-bit OS-entropy key is broadcast over the communicator (not a 64-bit seed)

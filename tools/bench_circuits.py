@@ -165,7 +165,9 @@ def _build(kind, k, gpu, seed, store, **kw):
         # fill (percent): lay out only that share of the cells but keep the column allocation of `blocks` full blocks (total_assignments is
         # what gen-settings would report for the full model): the Python layout engine needs ~15 us per cell, and every kernel of the
         # prover except the witness MSMs costs the same whatever the cells hold
-        c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2, total_assignments=int((blocks - 0.1) * cap) if fill else None)
+        c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2)
+        if fill and c.settings.total_assignments < int((blocks - 0.1) * cap):
+            c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2, total_assignments=int((blocks - 0.1) * cap))
         cs, fixed, copies, reg = c.keygen_inputs(x, with_witness=True)      # one synthesis pass for the key and the witness
         adv, inst = c.witness_of(reg)
         info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),
