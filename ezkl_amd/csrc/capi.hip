@@ -152,6 +152,44 @@ int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1) {
     return EZKL_OK;
 }
 
+struct StagingBlock {
+    uint8_t* host = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+struct StagingState {
+    static constexpr unsigned N = 32;
+    StagingBlock ring[N];
+    unsigned next = 0;
+};
+uint8_t* staging_acquire(Ctx* c, size_t bytes, void** token) {
+    if (!c->staging_state) c->staging_state = new StagingState();
+    StagingState& ss = *static_cast<StagingState*>(c->staging_state);
+    StagingBlock& s = ss.ring[ss.next++ % StagingState::N];
+    if (s.pending) {
+        if (hipEventSynchronize(s.done) != hipSuccess) return nullptr;
+        s.pending = false;
+    }
+    if (s.bytes < bytes) {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr;
+        s.bytes = 0;
+        const size_t want = bytes < (64u << 10) ? (64u << 10) : bytes;
+        if (hipHostMalloc((void**)&s.host, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s.host = nullptr; return nullptr; }
+        s.bytes = want;
+    }
+    if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    *token = &s;
+    return s.host;
+}
+int staging_release(void* token, hipStream_t st) {
+    StagingBlock* s = static_cast<StagingBlock*>(token);
+    EZ_HIP(hipEventRecord(s->done, st));
+    s->pending = true;
+    return EZKL_OK;
+}
+
 // calls made on the library stream are synchronous (unless ezkl_hip_set_async(1): then they are ordered on that one stream and the
 // caller synchronises where it needs to -- every entry point that returns host data or borrows host memory still does by itself);
 // calls on a caller stream are stream-ordered
@@ -368,6 +406,15 @@ static hipError_t copy_sync(Ctx* c, void* dst, const void* src, size_t bytes, hi
 }
 int ezkl_hip_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     EZ_CTX(c);
+    // asynchronous mode, a few rows (blinding factors, boundary values): through pinned staging, ordered on the library stream
+    if (t_async_library_stream && bytes && bytes <= (64u << 10)) {
+        void* stg = nullptr;
+        if (uint8_t* H = staging_acquire(c, bytes, &stg)) {
+            memcpy(H, src, bytes);
+            EZ_HIP(hipMemcpyAsync(dst, H, bytes, hipMemcpyHostToDevice, c->stream));
+            return staging_release(stg, c->stream);
+        }
+    }
     EZ_HIP(copy_sync(c, dst, src, bytes, hipMemcpyHostToDevice));
     return EZKL_OK;
 }
@@ -567,6 +614,13 @@ int ezkl_hip_stream_create(void** out) {
     *out = st;
     return EZKL_OK;
 }
+int ezkl_hip_context_stream(void** out) {
+    if (!out) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (!c->side_stream) EZ_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    *out = c->side_stream;
+    return EZKL_OK;
+}
 int ezkl_hip_stream_synchronize(void* stream) {
     if (!stream) return EZKL_ERR_INVALID;
     EZ_CTX(c);
@@ -738,7 +792,18 @@ int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_i
         if (!inputs_dev[j]) return EZKL_ERR_INVALID;
     EZ_CTX(c);
     return lookup_multiplicity(c, pick_stream(c, stream), (const fe_t* const*)inputs_dev, n_inputs, (const fe_t*)table_dev, n_rows,
-                               usable_rows, (fe_t*)m_out_dev, out_missing);
+                               usable_rows, (fe_t*)m_out_dev, out_missing, nullptr);
+}
+int ezkl_hip_lookup_multiplicity_acc_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
+                                         uint32_t usable_rows, void* m_out_dev, void* missing_dev, void* stream) {
+    if (!table_dev || !m_out_dev || !missing_dev || (n_inputs && !inputs_dev)) return EZKL_ERR_INVALID;
+    for (uint32_t j = 0; j < n_inputs; j++)
+        if (!inputs_dev[j]) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = lookup_multiplicity(c, st, (const fe_t* const*)inputs_dev, n_inputs, (const fe_t*)table_dev, n_rows, usable_rows,
+                                 (fe_t*)m_out_dev, nullptr, (uint32_t*)missing_dev);
+    return rc ? rc : finish(c, st, stream);
 }
 
 int ezkl_hip_eval_poly_dev(const void* coeffs, size_t n, const void* x, void* out, void* stream) {
@@ -795,7 +860,7 @@ int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in, void* out, s
 int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out, void* stream) {
     if (!prog || !out) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    return eval_program(c, pick_stream(c, stream), prog, (fe_t*)out);
+    return eval_program(c, pick_stream(c, stream), prog, (fe_t*)out, stream != nullptr || t_async_library_stream);
 }
 
 int ezkl_hip_eval_h_check(const ezkl_program_t* prog) {

@@ -42,6 +42,8 @@ struct Ctx {
     void* jit_state = nullptr;
     void* pool_state = nullptr;
     int index = 0;                    // position in the context table (ezkl_hip_set_context)
+    void* staging_state = nullptr;    // pinned staging ring for small host -> device copies (capi.hip)
+    hipStream_t side_stream = nullptr;  // ezkl_hip_context_stream: a second stream that lives as long as the context
 };
 
 Ctx* ctx();                 // the context the CALLING THREAD is bound to (ezkl_hip_set_context; default 0), lazily initialised (nullptr + last error set if no device)
@@ -53,6 +55,10 @@ int set_hip_error(hipError_t e, const char* what, const char* file, int line);
 int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out);   // acquire for work on stream st
 int arena_done(Ctx::Arena& a, hipStream_t st);                               // mark the end of that work
 int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1);
+// Pinned staging for small host arrays a call borrows: acquire a block (nullptr: none to be had -- copy from the caller's memory and
+// synchronise instead), fill it, queue the copy out of it on `st`, release it on `st` (the block is reused once that copy has run).
+uint8_t* staging_acquire(Ctx* c, size_t bytes, void** token);
+int staging_release(void* token, hipStream_t st);
 
 #define EZ_HIP(call)                                                              \
     do {                                                                          \
@@ -108,7 +114,7 @@ int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, siz
 int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
 int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
-                        uint32_t usable, fe_t* m_out, uint32_t* missing_host);
+                        uint32_t usable, fe_t* m_out, uint32_t* missing_host, uint32_t* missing_dev);
 int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& x, void* out_host);
 int prefix_scan(Ctx* c, hipStream_t st, int op, int exclusive, const fe_t* in, fe_t* out, size_t n);
 int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_t* xs, uint32_t m, size_t n, void* out_host);
@@ -117,7 +123,7 @@ int kate_division(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& z, fe_t* ou
 int chacha20_fr(Ctx* c, hipStream_t st, const uint32_t key[8], uint64_t stream, size_t first, fe_t* out, size_t n);
 bool msm_upload_is_open();
 int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host);
-int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out);
+int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out, bool ordered);
 int eval_jit_compile_only(const ezkl_program_t* p);
 int eval_prepare(Ctx* c, const ezkl_program_t* p);
 int eval_schedule_only(const ezkl_program_t* p, uint32_t* out_code);

@@ -714,7 +714,8 @@ int eval_prepare(Ctx* c, const ezkl_program_t* p0) {
     return jit_get(c, &scheduled, rot, &fn);
 }
 
-int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
+// `ordered`: the call is stream-ordered (a caller stream, or the library stream in asynchronous mode) and returns once queued
+int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out, bool ordered) {
     if (int vrc = validate_program(p)) return vrc;          // before it touches the device
     if (p->n_instr == 0) return EZKL_OK;
     const size_t ne = (size_t)1 << p->ext_k;
@@ -748,11 +749,27 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     uint8_t* S = nullptr;
     int rc = arena_reserve(c->scratch, total, st, (void**)&S);
     if (rc) return rc;
-    EZ_HIP(hipMemcpyAsync(S + o_code, code.data(), (size_t)p->n_instr * 32, hipMemcpyHostToDevice, st));
-    if (p->n_constants) EZ_HIP(hipMemcpyAsync(S + o_const, p->constants, (size_t)p->n_constants * 32, hipMemcpyHostToDevice, st));
-    EZ_HIP(hipMemcpyAsync(S + o_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice, st));
-    if (p->n_columns) EZ_HIP(hipMemcpyAsync(S + o_cols, p->columns, (size_t)p->n_columns * 8, hipMemcpyHostToDevice, st));
-    if (p->n_challenges) EZ_HIP(hipMemcpyAsync(S + o_chal, p->challenges, (size_t)p->n_challenges * 32, hipMemcpyHostToDevice, st));
+    // The caller's arrays are borrowed only for the call: they are packed into a pinned block that stays valid until the copy engine
+    // has read it, so a host can queue many sweeps / helper programs without waiting for any of them (the lookup and permutation
+    // phases of a proof run ~20 small programs back to back)
+    void* stg = nullptr;
+    uint8_t* H = staging_acquire(c, o_int, &stg);
+    if (H) {                                                   // one copy from a pinned block the library owns
+        memcpy(H + o_code, code.data(), (size_t)p->n_instr * 32);
+        if (p->n_constants) memcpy(H + o_const, p->constants, (size_t)p->n_constants * 32);
+        memcpy(H + o_rot, rot.data(), rot.size() * 4);
+        if (p->n_columns) memcpy(H + o_cols, p->columns, (size_t)p->n_columns * 8);
+        if (p->n_challenges) memcpy(H + o_chal, p->challenges, (size_t)p->n_challenges * 32);
+        EZ_HIP(hipMemcpyAsync(S, H, o_int, hipMemcpyHostToDevice, st));
+        if ((rc = staging_release(stg, st))) return rc;
+    } else {
+        ordered = false;                                       // the arrays are read where they lie: synchronise below
+        EZ_HIP(hipMemcpyAsync(S + o_code, code.data(), (size_t)p->n_instr * 32, hipMemcpyHostToDevice, st));
+        if (p->n_constants) EZ_HIP(hipMemcpyAsync(S + o_const, p->constants, (size_t)p->n_constants * 32, hipMemcpyHostToDevice, st));
+        EZ_HIP(hipMemcpyAsync(S + o_rot, rot.data(), rot.size() * 4, hipMemcpyHostToDevice, st));
+        if (p->n_columns) EZ_HIP(hipMemcpyAsync(S + o_cols, p->columns, (size_t)p->n_columns * 8, hipMemcpyHostToDevice, st));
+        if (p->n_challenges) EZ_HIP(hipMemcpyAsync(S + o_chal, p->challenges, (size_t)p->n_challenges * 32, hipMemcpyHostToDevice, st));
+    }
     EvalArgs a;
     a.code = (const uint32_t*)(S + o_code);
     a.n_instr = p->n_instr;
@@ -785,7 +802,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out) {
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
     if ((rc = arena_done(c->scratch, st))) return rc;
-    EZ_HIP(hipStreamSynchronize(st));   // the host-side program arrays are borrowed only for the call
+    if (!ordered) EZ_HIP(hipStreamSynchronize(st));
     return EZKL_OK;
 }
 

@@ -472,8 +472,7 @@ struct Backend {
     Backend(const Backend&) = delete;
     ~Backend() {
         if (aux) {                             // also on unwinding: nothing queued on the aux stream may outlive its columns
-            (void)ezkl_hip_stream_synchronize(aux);
-            (void)ezkl_hip_stream_destroy(aux);
+            (void)ezkl_hip_stream_synchronize(aux);   // the stream itself belongs to the context
         }
     }
     std::vector<Col> aux_keep;                 // inputs / outputs of work queued on the aux stream, alive until the stream is drained
@@ -482,7 +481,7 @@ struct Backend {
     // is PCIe-bound, single MSMs leave the GPU half empty during their sort / reduce tails); step 7 only waits for the stream.
     void* aux = nullptr;
     void* aux_stream() {
-        if (!aux) check(ezkl_hip_stream_create(&aux), "ezkl_hip_stream_create");
+        if (!aux) check(ezkl_hip_context_stream(&aux), "ezkl_hip_context_stream");
         return aux;
     }
     void aux_sync() {
@@ -839,15 +838,20 @@ struct Backend {
         }
         return out;
     }
-    Col lookup_multiplicity(const std::vector<Col>& inputs, const Col& table, uint32_t usable) const {
+    // `missing`: a resident counter (first u32 of a zeroed column) that collects the inputs absent from the table over all the lookup
+    // arguments of a proof; nothing comes back to the host here, the caller checks it once (lookup_check)
+    Col lookup_multiplicity(const std::vector<Col>& inputs, const Col& table, uint32_t usable, const Col& missing) const {
         Col out = alloc(n);
         std::vector<const void*> ptrs;
         for (auto& c : inputs) ptrs.push_back(c->ptr());
-        uint32_t missing = 0;
-        check(ezkl_hip_lookup_multiplicity_dev(ptrs.data(), (uint32_t)ptrs.size(), table->ptr(), n, usable, out->ptr(), &missing, nullptr), "ezkl_hip_lookup_multiplicity_dev");
-        // the reference's mv-lookup prover fails here too (a witness with an input outside the table has no valid proof)
-        if (missing != 0) throw Error(EZKL_ERR_INVALID, "lookup input not in table (" + std::to_string(missing) + " rows)");
+        check(ezkl_hip_lookup_multiplicity_acc_dev(ptrs.data(), (uint32_t)ptrs.size(), table->ptr(), n, usable, out->ptr(), missing->ptr(), nullptr),
+              "ezkl_hip_lookup_multiplicity_acc_dev");
         return out;
+    }
+    void lookup_check(const Col& missing) const {
+        const Fe v = get_row(missing, 0);
+        // the reference's mv-lookup prover fails here too (a witness with an input outside the table has no valid proof)
+        if (v.v[0] != 0) throw Error(EZKL_ERR_INVALID, "lookup input not in table (" + std::to_string((uint32_t)v.v[0]) + " rows)");
     }
     // q(X) = p(X) / (X - z) in place (halo2's kate_division)
     void kate_div(const Col& h, const Fe& z, size_t m) const {
@@ -1802,6 +1806,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     std::vector<int> lk_owner(nl, -1);
     if (nl) {
         theta = T.squeeze_challenge();
+        const Col missing = be.zeros(1);
         for (size_t i = 0; i < nl; i++) {
             const Lookup& l = cs.lookups[i];
             LookupState& st = lk[i];
@@ -1811,7 +1816,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             if (!st.mine) continue;
             for (auto& t : l.inputs) st.inputs.push_back(compress_column(cs, be, t, theta, col_handle, user_chal));
             st.table = compress_column(cs, be, l.table, theta, col_handle, user_chal);
-            st.m = be.lookup_multiplicity(st.inputs, st.table, u);
+            st.m = be.lookup_multiplicity(st.inputs, st.table, u, missing);
             be.set_rows(st.m, u, blind);
             cs.shard.stats[3]++;
         }
@@ -1819,7 +1824,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         for (auto& st : lk) ms.push_back(st.m);
         for (auto& st : lk)
             if (st.mine) { st.m_forms = be.forms_async(st.m, cs.ext_k); cs.shard.stats[0]++; }
-        for (auto& p : be.commit_columns(gl, ms, true)) T.write_point(p);
+        const auto m_commits = be.commit_columns(gl, ms, true);
+        be.lookup_check(missing);                                       // after the commit's own synchronisation: no extra round trip
+        for (auto& p : m_commits) T.write_point(p);
         cs.shard.stats[1] += 2 * nl;
     }
     sw.lap(1);

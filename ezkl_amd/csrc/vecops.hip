@@ -359,14 +359,16 @@ __global__ __launch_bounds__(256) void counts_to_fr_kernel(const uint32_t* count
     st_fe(out + i, counts[i] ? Fr::to_mont(t) : t);
 }
 int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
-                        uint32_t usable, fe_t* m_out, uint32_t* missing_host) {
+                        uint32_t usable, fe_t* m_out, uint32_t* missing_host, uint32_t* missing_dev) {
+    // missing_dev (device u32, ACCUMULATED into): the stream-ordered form -- nothing comes back to the host, so the call does not
+    // synchronise; the caller reads the counter once after queuing all its lookups
     if (usable > n_rows) return EZKL_ERR_INVALID;
     uint32_t cap = 16;
     while (cap < 2 * (usable ? usable : 1)) cap <<= 1;
     uint32_t* d = nullptr;
     int rc = arena_reserve(c->aux, ((size_t)cap + n_rows + 1) * 4, st, (void**)&d);
     if (rc) return rc;
-    uint32_t *slots = d, *counts = d + cap, *missing = counts + n_rows;
+    uint32_t *slots = d, *counts = d + cap, *missing = missing_dev ? missing_dev : counts + n_rows;
     EZ_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, st));
     EZ_HIP(hipMemsetAsync(counts, 0, ((size_t)n_rows + 1) * 4, st));
     if (usable) hipLaunchKernelGGL(ht_build_kernel, dim3(cdiv(usable, 256)), dim3(256), 0, st, table, usable, slots, cap - 1);
@@ -374,6 +376,10 @@ int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint3
         if (usable) hipLaunchKernelGGL(ht_count_kernel, dim3(cdiv(usable, 256)), dim3(256), 0, st, inputs[j], usable, table, slots, cap - 1, counts, missing);
     hipLaunchKernelGGL(counts_to_fr_kernel, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, counts, n_rows, m_out);
     hipError_t e = hipGetLastError();
+    if (missing_dev) {
+        if (e != hipSuccess) return set_hip_error(e, "lookup_multiplicity", __FILE__, __LINE__);
+        return arena_done(c->aux, st);
+    }
     uint32_t miss = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&miss, missing, 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);

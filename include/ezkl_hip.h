@@ -63,6 +63,10 @@ int ezkl_hip_synchronize(void);
 int ezkl_hip_stream_create(void** out_stream);
 int ezkl_hip_stream_synchronize(void* stream);
 int ezkl_hip_stream_destroy(void* stream);
+/* A second stream owned by the calling thread's context, created on first use and alive as long as the context: creating and
+ * destroying a HIP stream costs ~2 ms each (measured, profiles/r03v_hosttrace.txt), which a per-proof auxiliary stream would pay in
+ * every proof.  Not to be destroyed by the caller; one per context, so two concurrent users of one context must agree on it. */
+int ezkl_hip_context_stream(void** out_stream);
 /* Asynchronous library stream.  By default a call with stream == NULL returns when its work is done.  A host that issues hundreds of
  * small device-only calls per proof (vec ops, scans, NTTs, inversions: the lookup / permutation helper chains) pays a host round trip
  * for each; ezkl_hip_set_async(1, &prev) makes those calls return as soon as they are queued on the library stream -- still in order
@@ -212,6 +216,10 @@ int ezkl_hip_prefix_scan_dev(int op, int exclusive, const void* in_dev, void* ou
  * are 0).  *out_missing (may be NULL) = number of input values absent from the table (a failing witness). */
 int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
                                      uint32_t usable_rows, void* m_out_dev, uint32_t* out_missing, void* stream);
+/* the same with the count of absent input values ADDED to a device u32 (missing_dev, zeroed by the caller): nothing returns to the
+ * host, so the call is stream-ordered like the other helpers; a prover queues all its lookup arguments and reads the counter once */
+int ezkl_hip_lookup_multiplicity_acc_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
+                                         uint32_t usable_rows, void* m_out_dev, void* missing_dev, void* stream);
 /* halo2 eval_polynomial(poly, x): sum_i coeffs[i] * x^i for a resident coefficient vector; x and the 32-byte result
  * are host memory (create_proof evaluates every queried (column, rotation) this way before SHPLONK) */
 int ezkl_hip_eval_poly_dev(const void* coeffs_dev, size_t n, const void* x_host, void* out_host, void* stream);
@@ -250,7 +258,9 @@ typedef struct {
     const void* challenges;     uint32_t n_challenges;    /* n x 32 B Fr, host */
     uint32_t k, ext_k;
 } ezkl_program_t;
-/* out_dev[r] = program(row r) with ValueSource::PreviousValue = old out_dev[r]; 2^ext_k rows */
+/* out_dev[r] = program(row r) with ValueSource::PreviousValue = old out_dev[r]; 2^ext_k rows.  The host arrays of `prog` are borrowed
+ * for the call only (packed into pinned staging the library owns); on a caller stream, or on the library stream in asynchronous mode
+ * (ezkl_hip_set_async), the call returns once the launch is queued -- the columns and out_dev must stay valid until it has run. */
 int ezkl_hip_eval_h_dev(const ezkl_program_t* prog, void* out_dev, void* stream);
 /* the sweep is JIT-compiled (hiprtc) into straight-line gfx950 code, once per program; this host-only call
  * checks that a program lowers and compiles (column pointers are not dereferenced; no GPU needed) */
