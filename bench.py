@@ -360,11 +360,25 @@ def prove_leg_multi(world, rank, local_rank, args):
     out = _prove_multi_one(world, rank, local_rank, args, circuit, os.environ.get("EZKL_BENCH_MULTI_K", "20"), 1)
     # ... and the north star's k = 20 MLP circuit the same way (laid out ONCE: the first rank to take the lock writes
     # bench_cache/mlp_k20_s1.npz, the others read it -- tools/bench_circuits.py)
-    if circuit == "einsum" and os.environ.get("EZKL_BENCH_MULTI_MLP20", "1") != "0":
+    # (skipped when the first leg failed: the same communicator would fail or hang again, and every rank must take the same branch --
+    # rank 0 alone knows the outcome, so it is shared through the ranks' process group)
+    ok = _all_ranks_agree(world, rank, out is not None and "error" not in out)
+    if ok and circuit == "einsum" and os.environ.get("EZKL_BENCH_MULTI_MLP20", "1") != "0":
         m = _prove_multi_one(world, rank, local_rank, args, "mlp", "20", 2)
         if rank == 0 and out is not None:
             out["mlp_k20"] = m
     return out
+
+
+def _all_ranks_agree(world, rank, flag_rank0):
+    import torch
+    import torch.distributed as dist
+    if world == 1 or not dist.is_initialized():
+        return bool(flag_rank0)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if (flag_rank0 or rank != 0) else 0], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=0)
+    return bool(int(t.item()))
 
 
 def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
@@ -386,7 +400,7 @@ def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
     if os.environ.get("EZKL_BENCH_MULTI_MODE") == "replicated":
         cmd.append("--replicated")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300" if circuit != "mlp" else "600")))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300")))
         if rank != 0:
             return None
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1183,12 +1183,20 @@ struct MsmUpload {
     std::vector<hipEvent_t> ev;
     std::vector<fe_t*> dev_cols;
     size_t n = 0;
+    bool broken = false;
 };
 int msm_upload_end(MsmUpload* u) {
     if (!u || u != g_open_upload) return EZKL_ERR_INVALID;
-    hipError_t e = g_copy_st ? hipStreamSynchronize(g_copy_st) : hipSuccess;
-    for (auto ev : u->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    // Wait on the copies' own events, newest first, not on the stream: with more streams than hardware queues a stream synchronise
+    // queues a marker behind whatever shares the copy stream's queue (measured: 5.3 ms behind the auxiliary stream's NTTs, long after
+    // the last copy had landed -- profiles/r03w_hosttrace.txt); an event that has already fired returns at once.
+    hipError_t e = u->broken && g_copy_st ? hipStreamSynchronize(g_copy_st) : hipSuccess;   // a copy without its event: drain the stream
+    for (size_t j = u->ev.size(); j-- > 0;)
+        if (u->ev[j]) {
+            const hipError_t ej = hipEventSynchronize(u->ev[j]);
+            if (e == hipSuccess) e = ej;
+            (void)hipEventDestroy(u->ev[j]);
+        }
     g_open_upload = nullptr;
     delete u;
     if (e != hipSuccess) return set_hip_error(e, "msm_upload_end", __FILE__, __LINE__);
@@ -1220,6 +1228,7 @@ int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols
         }
         if (e == hipSuccess) e = hipEventRecord(u->ev[j], g_copy_st);
         if (e != hipSuccess) {
+            u->broken = true;
             (void)msm_upload_end(u);
             return set_hip_error(e, "msm_upload_begin", __FILE__, __LINE__);
         }
