@@ -232,7 +232,11 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
     for (size_t i = 0; i < n_recvs; i++)
         if (recvs[i].peer < 0 || recvs[i].peer >= g_comm.world || (!recvs[i].ptr && recvs[i].bytes)) return EZKL_ERR_INVALID;
     EZ_HIP(hipStreamSynchronize(c->stream));          // what the library stream produced is what gets sent
-    {
+    // EZKL_COMM_SELF_VIA_RCCL=1 (testing): the segments to self take the grouped ncclSend / ncclRecv path too, so that a one-GPU box
+    // exercises RCCL's matching of MANY sends and receives per peer inside one group (tests/test_gpu_comm.py)
+    const char* via = getenv("EZKL_COMM_SELF_VIA_RCCL");
+    const int skip = via && *via == '1' ? -1 : me;    // the peer whose segments are plain copies
+    if (skip == me) {
         size_t j = 0;                                 // self segments, in order
         for (size_t i = 0; i < n_sends; i++) {
             if (sends[i].peer != me) continue;
@@ -244,9 +248,9 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
     }
     EZ_RCCL(g_rccl.GroupStart());
     for (size_t i = 0; i < n_sends; i++)
-        if (sends[i].peer != me && sends[i].bytes) EZ_RCCL(g_rccl.Send(sends[i].ptr, sends[i].bytes, ncclUint8, sends[i].peer, g_comm.comm, g_comm.st));
+        if (sends[i].peer != skip && sends[i].bytes) EZ_RCCL(g_rccl.Send(sends[i].ptr, sends[i].bytes, ncclUint8, sends[i].peer, g_comm.comm, g_comm.st));
     for (size_t i = 0; i < n_recvs; i++)
-        if (recvs[i].peer != me && recvs[i].bytes) EZ_RCCL(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, ncclUint8, recvs[i].peer, g_comm.comm, g_comm.st));
+        if (recvs[i].peer != skip && recvs[i].bytes) EZ_RCCL(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, ncclUint8, recvs[i].peer, g_comm.comm, g_comm.st));
     EZ_RCCL(g_rccl.GroupEnd());
     EZ_HIP(hipStreamSynchronize(g_comm.st));
     return EZKL_OK;

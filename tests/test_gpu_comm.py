@@ -2,6 +2,8 @@
 runs through librccl (unique id, ncclCommInitRank, ncclAllGather, grouped send / recv with only the self slice), and the C++ host
 prover sharded over it emits the unsharded proof.  World > 1 needs one GPU per rank (RCCL refuses two ranks on a device); the same
 sharding logic is covered with gloo on CPU (tests/test_dist_cpu.py) and with two gloo ranks sharing the GPU (tests/test_plonk.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -33,6 +35,18 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
             B.comm_alltoallv_dev([(0, a.ptr, 64 * 8)], [(0, ra.ptr, 32 * 8)])
         h = np.arange(12, dtype=np.uint64).reshape(1, 12)
         assert (B.comm_allgather_host(h.copy()) == h).all()
+        # the shape of the prover's exchange -- hundreds of segments of very different sizes per peer in ONE group -- through RCCL's own
+        # ncclSend / ncclRecv matching (EZKL_COMM_SELF_VIA_RCCL: the self segments take the RCCL path instead of a device copy)
+        rng = np.random.default_rng(5)
+        sizes = [int(x) * 32 for x in rng.integers(1, 1 << 15, 300)] + [1 << 24, 32, 1 << 22]
+        src = [B.DeviceBuffer.from_numpy(rng.integers(0, 1 << 63, sz // 8, dtype=np.uint64)) for sz in sizes]
+        dst = [B.DeviceBuffer(sz) for sz in sizes]
+        os.environ["EZKL_COMM_SELF_VIA_RCCL"] = "1"
+        try:
+            B.comm_alltoallv_dev([(0, s_.ptr, sz) for s_, sz in zip(src, sizes)], [(0, d_.ptr, sz) for d_, sz in zip(dst, sizes)])
+        finally:
+            del os.environ["EZKL_COMM_SELF_VIA_RCCL"]
+        assert all((s_.to_numpy() == d_.to_numpy()).all() for s_, d_ in zip(src, dst))
         # the C++ host prover over the library communicator: same bytes as the unsharded prover
         cs = TP.lookup_circuit(6)
         adv, fixed, copies = TP.lookup_witness(cs, 4)
