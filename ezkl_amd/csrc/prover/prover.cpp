@@ -544,6 +544,13 @@ struct Backend {
         fill(o->ptr(), Fe::zero(), m);
         return o;
     }
+    // the n-row indicator of rows [lo, hi), filled on the device (l0, l_last, l_active_row, the coefficients of X: a 32 MiB host
+    // vector per column and its pageable upload cost ~20 ms each at k = 20 -- a fifth of the key load of a one-shot prove)
+    Col indicator(size_t lo, size_t hi) const {
+        Col o = zeros(n);
+        if (hi > lo) fill(at(o, lo), one, hi - lo);
+        return o;
+    }
     // small = witness-shaped columns (advice, multiplicities): the batch runs as fused groups (ezkl_hip_msm_g1_batch_small_dev)
     int msm_batch(ezkl_bases_t b, size_t first, const void* const* ptrs, size_t m, size_t len, void* out, bool small) const {
         return small ? ezkl_hip_msm_g1_batch_small_dev(b, first, ptrs, m, len, out, nullptr) : ezkl_hip_msm_g1_batch_dev(b, first, ptrs, m, len, out, nullptr);
@@ -940,18 +947,12 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
         pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
     }
     // l0, l_last, l_active_row on the extended coset
-    auto lag = [&](uint32_t lo, uint32_t hi) {
-        std::vector<U256> v(n, U256{0, 0, 0, 0});
-        for (uint32_t r = lo; r < hi; r++) v[r] = FR.one;
-        return be.coeff_to_extended(be.lagrange_to_coeff(be.upload(v)), cs.ext_k);
-    };
+    auto lag = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
     pk->l0 = lag(0, 1);
     pk->l_last = lag(cs.usable, cs.usable + 1);
     pk->l_active = lag(0, cs.usable);
     // the identity column X on the extended coset (from coefficients [0, 1, 0, ...])
-    std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
-    xcoef[1] = FR.one;
-    pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
+    pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
     pk->fixed_commitments = be.commit(pk->fixed_polys);
     pk->sigma_commitments = be.commit(pk->sigma_polys);
     pk->digest = vk_digest(*pk);
@@ -1071,9 +1072,7 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
     invalid(off != len, "trailing bytes in the proving key");
     // derived columns that the file does not hold
     pk->omega_col = be.omega_powers();
-    std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
-    xcoef[1] = FR.one;
-    pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
+    pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
     pk->digest = vk_digest(*pk);
     return pk;
 }
@@ -1089,8 +1088,8 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     struct stat sb;
     if (fstat(fd, &sb) != 0) { close(fd); throw Error(EZKL_ERR_INVALID, "cannot stat proving key"); }
     const size_t len = (size_t)sb.st_size;
-    void* map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
+    struct Close { int fd; ~Close() { close(fd); } } close_fd{fd};
+    void* map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);              // the headers are parsed through the mapping
     if (map == MAP_FAILED) throw Error(EZKL_ERR_INVALID, "cannot map proving key");
     struct Unmap { void* p; size_t l; ~Unmap() { munmap(p, l); } } unmap{map, len};
     (void)madvise(map, len, MADV_SEQUENTIAL);
@@ -1134,21 +1133,16 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
         invalid(be32() != count, "vector of unexpected length in the key");
         for (size_t i = 0; i < count; i++) invalid(be32() != m, "polynomial of unexpected length in the key");
     };
+    // the n-row sections are only LOCATED here; they travel afterwards, all at once (load_sections below)
+    struct Section { size_t off; Col dst; };
+    std::vector<Section> sections;
     auto load_values = [&](std::vector<Col>& cols, size_t count) {
         vec_header(count, n);
         for (size_t i = 0; i < count; i++) {
             invalid(be32() != n, "polynomial of unexpected length in the key");
             need(32 * n);
-            const uint64_t* e = (const uint64_t*)(buf + off);       // canonical residues: the top limb decides all but 2^-60 of the cases
-            for (size_t r = 0; r < n; r++) {
-                const uint64_t top = e[4 * r + 3];
-                if (top >= FR.p[3]) {
-                    U256 v;
-                    std::memcpy(v.data(), e + 4 * r, 32);
-                    invalid(cmp(v, FR.p) >= 0, "non-canonical field element in the key");
-                }
-            }
-            cols.push_back(be.upload(buf + off, n));
+            cols.push_back(be.alloc(n));
+            sections.push_back(Section{off, cols.back()});
             off += 32 * n;
         }
     };
@@ -1162,6 +1156,75 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     load_values(pk->sigma_values, np);
     skip_vec(np, n); skip_vec(np, ne);
     invalid(off != len, "trailing bytes in the proving key");
+    // File -> HBM as a pipeline: a few reader threads pread their sections into page-locked buffers (one copy out of the page cache,
+    // no page fault per 4 KiB as through the mapping) and check them (canonical residues: the top limb decides all but 2^-60 of the
+    // cases), this thread uploads each buffer as it fills (PCIe at the pinned rate).  Measured on the k = 20 MLP key (34 sections of
+    // 32 MiB inside a 7.8 GB file): DESIGN.md §4.7.
+    {
+        const size_t bytes = 32 * n, N = sections.size();
+        for (auto& sec : sections) (void)posix_fadvise(fd, (off_t)sec.off, (off_t)bytes, POSIX_FADV_WILLNEED);   // a key not in the page cache: read ahead
+        const size_t T = std::min<size_t>({N, 6, std::max(1u, std::thread::hardware_concurrency())});
+        std::vector<void*> pinned(T, nullptr);
+        struct Free { std::vector<void*>& v; ~Free() { for (void* q : v) if (q) (void)ezkl_hip_host_free(q); } } free_pinned{pinned};
+        for (auto& q : pinned) check(ezkl_hip_host_malloc(&q, bytes), "ezkl_hip_host_malloc");
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<long> holds(T, -1);                              // section held by buffer t (filled, not yet uploaded)
+        std::string failure;
+        bool stop = false;
+        auto reader = [&](size_t t) {
+            for (size_t i = t; i < N; i += T) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return holds[t] < 0 || stop; });
+                    if (stop) return;
+                }
+                std::string err;
+                uint8_t* q = (uint8_t*)pinned[t];
+                for (size_t got = 0; got < bytes && err.empty();) {
+                    const ssize_t m = pread(fd, q + got, bytes - got, (off_t)(sections[i].off + got));
+                    if (m <= 0) err = "cannot read the proving key";
+                    else got += (size_t)m;
+                }
+                const uint64_t* e = (const uint64_t*)q;
+                for (size_t r = 0; r < n && err.empty(); r++)
+                    if (e[4 * r + 3] >= FR.p[3]) {
+                        U256 v;
+                        std::memcpy(v.data(), e + 4 * r, 32);
+                        if (cmp(v, FR.p) >= 0) err = "non-canonical field element in the key";
+                    }
+                std::lock_guard<std::mutex> lk(mu);
+                if (!err.empty()) { failure = err; stop = true; }
+                else holds[t] = (long)i;
+                cv.notify_all();
+                if (stop) return;
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; t++) th.emplace_back(reader, t);
+        struct Join {
+            std::vector<std::thread>& th; std::mutex& mu; std::condition_variable& cv; bool& stop;
+            ~Join() {
+                { std::lock_guard<std::mutex> lk(mu); stop = true; }
+                cv.notify_all();
+                for (auto& x : th) if (x.joinable()) x.join();
+            }
+        } join{th, mu, cv, stop};
+        for (size_t i = 0; i < N; i++) {
+            const size_t t = i % T;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return holds[t] == (long)i || stop; });
+                if (stop) throw Error(EZKL_ERR_INVALID, failure.empty() ? "proving key read failed" : failure);
+            }
+            check(ezkl_hip_memcpy_h2d(sections[i].dst->ptr(), pinned[t], bytes), "ezkl_hip_memcpy_h2d");
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                holds[t] = -1;
+            }
+            cv.notify_all();
+        }
+    }
     for (auto& v : pk->fixed_values) {
         pk->fixed_polys.push_back(be.lagrange_to_coeff(v));
         pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
@@ -1170,18 +1233,12 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
         pk->sigma_polys.push_back(be.lagrange_to_coeff(v));
         pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
     }
-    auto lag = [&](uint32_t lo, uint32_t hi) {
-        std::vector<U256> v(n, U256{0, 0, 0, 0});
-        for (uint32_t r = lo; r < hi; r++) v[r] = FR.one;
-        return be.coeff_to_extended(be.lagrange_to_coeff(be.upload(v)), cs.ext_k);
-    };
+    auto lag = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
     pk->l0 = lag(0, 1);
     pk->l_last = lag(cs.usable, cs.usable + 1);
     pk->l_active = lag(0, cs.usable);
     pk->omega_col = be.omega_powers();
-    std::vector<U256> xcoef(n, U256{0, 0, 0, 0});
-    xcoef[1] = FR.one;
-    pk->x_coset = be.coeff_to_extended(be.upload(xcoef), cs.ext_k);
+    pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
     pk->digest = vk_digest(*pk);
     return pk;
 }

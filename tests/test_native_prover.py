@@ -304,6 +304,25 @@ def test_native_key_file_roundtrip(hip, golden_srs):
     evil = bytearray(data); evil[off:off + 32] = b"\xff" * 32
     with pytest.raises(RuntimeError):
         N.NativeProvingKey.from_bytes(pk.circuit, bytes(evil))
+    # the one-shot loader (ezkl_prover_pk_read_file: reader threads -> pinned buffers -> HBM, everything but the n-row sections recomputed)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "pk.key")
+        open(path, "wb").write(data)
+        pk3 = N.NativeProvingKey.from_file(pk.circuit, path)
+        assert pk3.vk()[2] == pk.vk()[2] and pk3.to_bytes() == data
+        assert N.create_proof(pk3, g, gl, adv, rng=det_rng(9)) == N.create_proof(pk, g, gl, adv, rng=det_rng(9))
+        # a non-canonical element in an n-row section (the first fixed column: after l0 / l_last / l_active and the vector header)
+        n, ne = cs.n, 1 << cs.ext_k
+        off = len(vkb) + 3 * (4 + 32 * ne) + 4 + 4 * cs.n_fixed + 4 + 32 * 7
+        evil = bytearray(data); evil[off:off + 32] = b"\xff" * 32
+        open(path, "wb").write(bytes(evil))
+        with pytest.raises(RuntimeError):
+            N.NativeProvingKey.from_file(pk.circuit, path)
+        open(path, "wb").write(data[:-5])
+        with pytest.raises(RuntimeError):
+            N.NativeProvingKey.from_file(pk.circuit, path)
 
 
 @pytest.mark.gpu
