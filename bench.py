@@ -225,16 +225,27 @@ def main():
                  "frac": (alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": traffic,
                  "traffic_source": ("profiles/r03_pmc_prove.json: " + str(pm_.get("source"))) if (pm_ and traffic) else None}
             d.update(extra or {})
+            # the roof these kernels actually sit under: 254-bit Montgomery products per second against the product peak MEASURED IN THIS
+            # RUN (extra.modmul29_per_s: ezkl_hip_ubench, every lane issuing the radix-2^29 product the kernels use, nothing else)
+            if ms and d.get("products_per_launch") and modmul29:
+                d["valu"] = {"bound": "valu (Montgomery products)", "achieved": d["products_per_launch"] / (ms * 1e-3), "peak": modmul29, "unit": "products/s",
+                             "frac": d["products_per_launch"] / (ms * 1e-3) / modmul29}
             return d
         ntt_pass_ms = float(np.mean(ntt_ms)) / 3.0                     # a 2^22 transform is three launches of ntt_pass_kernel
         rks = [rk("ntt_pass_kernel", "one of the three passes of the 2^22-point NTT of the timed region (the transform's 64 B per element, read once + written once, divided over its three launches)",
                   NTT_BYTES_PER_ELEM * n_ntt / 3.0, ntt_pass_ms,
-                  (pk_.get("ntt_pass_kernel") or {}).get("bytes_per_launch_mean"), {"note": "traffic: mean over the passes of every transform of a k = 20 MLP proof (2^20- and 2^22-point cosets)"})]
+                  (pk_.get("ntt_pass_kernel") or {}).get("bytes_per_launch_mean"),
+                  {"note": "traffic: mean over the passes of every transform of a k = 20 MLP proof (2^20- and 2^22-point cosets)",
+                   # 22 butterfly stages of n/2 twiddle products + the inter-pass twiddle of 2 of the 3 passes, over three launches
+                   "products_per_launch": (LOG_NTT * n_ntt / 2 + 2 * n_ntt) / 3.0})]
         sk = ((out.get("prove") or {}).get("mlp_k20") or {}).get("sweep_kernel")
         if sk:
             rks.append(rk("evalh_jit", "quotient sweep of the k = 20 MLP key: one coset of 2^20 rows, %d columns read + 1 written (32 B each)" % sk["columns"],
-                          sk["algorithmic_bytes_per_launch"], sk["avg_launch_ms"], (pm_ or {}).get("evalh_jit_sweep", {}).get("bytes_per_launch_mean")))
-        rks.append(rk("msm_accumulate_kernel", "2^20-point MSM of the timed region (96 B per point)", MSM_BYTES_PER_POINT * n_msm, acc_avg_ms, traffic))
+                          sk["algorithmic_bytes_per_launch"], sk["avg_launch_ms"], (pm_ or {}).get("evalh_jit_sweep", {}).get("bytes_per_launch_mean"),
+                          {"products_per_launch": sk.get("products_per_launch"), "products_per_row": sk.get("products_per_row")}))
+        # W = 13 signed-digit windows: n W mixed XYZZ additions of 8M + 2S = 10 products each
+        rks.append(rk("msm_accumulate_kernel", "2^20-point MSM of the timed region (96 B per point)", MSM_BYTES_PER_POINT * n_msm, acc_avg_ms, traffic,
+                      {"products_per_launch": 13 * n_msm * 10}))
         out["roofline_kernels"] = rks
         if prove_multi is not None:
             out["prove"] = prove_multi

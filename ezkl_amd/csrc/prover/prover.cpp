@@ -1648,6 +1648,22 @@ static void prepare_quotient(const ProvingKey& pk) {
         if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_prover] sweep kernel not prepared at keygen: %s\n", e.what());
     }
 }
+// what one launch of this key's sweep does per row: [instructions, Montgomery products (MUL, SQUARE, HORNER_STEP), column slots, programs]
+static void sweep_stats(const ProvingKey& pk, uint64_t out[4]) {
+    const ConstraintSystem& cs = *pk.cs;
+    std::vector<Col> adv(cs.n_advice), zc(cs.n_chunks), mc(cs.lookups.size()), pc(cs.lookups.size()), ic(cs.n_instance);
+    std::vector<Fe> uc(cs.n_challenges, Fe::zero());
+    Quotient Q = quotient_program(cs, pk, adv, zc, Fe::one(), Fe::one(), Fe::one(), Fe::one(), mc, pc, ic, uc);
+    out[0] = out[1] = 0;
+    for (auto& prog : Q.progs)
+        for (size_t i = 0; i + 8 <= prog.code.size(); i += 8) {
+            out[0]++;
+            const uint32_t op = prog.code[i];
+            if (op == EZKL_OP_MUL || op == EZKL_OP_SQUARE || op == EZKL_OP_HORNER_STEP) out[1]++;
+        }
+    out[2] = Q.cols.size();
+    out[3] = Q.progs.size();
+}
 // the theta-compressed lookup column over the n rows of the Lagrange domain (a gate program with ext_k = k)
 static Col compress_column(const ConstraintSystem& cs, const Backend& be, const std::vector<uint32_t>& tuple, const Fe& theta,
                            const std::function<Col(uint32_t, uint32_t)>& col_handle, const std::vector<Fe>& user_chal) {
@@ -2611,6 +2627,10 @@ int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_va
         *out = new ezkl_prover_pk{keygen(*cs->cs, g, fixed_values, copies, n_copies)};
         prepare_quotient(*(*out)->pk);      // `setup` pays hiprtc for the circuit's sweep kernel (cached on disk): the first `prove` does not
     });
+}
+int ezkl_prover_pk_sweep_stats(ezkl_pk_t pk, uint64_t out[4]) {
+    if (!pk || !out) return EZKL_ERR_INVALID;
+    return guarded([&] { sweep_stats(*pk->pk, out); });
 }
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len) {
     if (!pk || !len) return EZKL_ERR_INVALID;

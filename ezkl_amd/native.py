@@ -15,7 +15,7 @@ _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_group_create", "ezkl_prover_group_size", "ezkl_prover_group_free",
-           "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
+           "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_sweep_stats", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_verify_proof_vk", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -204,6 +204,12 @@ class NativeProvingKey:
         if recommit is not None:
             _check(load().ezkl_prover_pk_recommit(self.h, recommit.h), "ezkl_prover_pk_recommit")
         return self
+
+    def sweep_stats(self):
+        """per extended row of this key's quotient sweep: (instructions, Montgomery products, column slots, kernels)"""
+        out = (C.c_uint64 * 4)()
+        _check(load().ezkl_prover_pk_sweep_stats(self.h, out), "ezkl_prover_pk_sweep_stats")
+        return tuple(int(x) for x in out)
 
     @classmethod
     def from_file(cls, circuit, path, recommit=None):

@@ -141,6 +141,9 @@ int ezkl_prover_pk_free(ezkl_pk_t pk);
  * l_active_row, fixed values / polys / cosets, permutation values / polys / cosets.  write: EZKL_ERR_NOMEM with *len set if
  * cap is too small (a k = 20 key is GiBs).  read: the cs supplies what the file does not hold (column counts, extended_k);
  * every element is checked to be a canonical residue; columns go straight to HBM. */
+/* the quotient sweep of this key, per extended row: out = [instructions, Montgomery products, column slots read, kernels].  For rooflines
+ * (bench.py): one launch of the sweep runs 2^k rows of it. */
+int ezkl_prover_pk_sweep_stats(ezkl_pk_t pk, uint64_t out[4]);
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len);
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out);
 /* load_pk for a one-shot `prove`: maps the key file and uploads only its n-row sections (fixed values, permutations); coefficient forms,

@@ -220,6 +220,11 @@ if not SYNTH:
     out["hbm_in_use_gib_after_prove"] = round((total_b - free_b) / 2**30, 2)          # keys, SRS + window tables, and the column pool's high-water mark
     out["sweep_kernel"] = {"kernel": "evalh_jit", "avg_launch_ms": round(B.last_kernel_ms("eval_h"), 4), "rows_per_launch": n, "launches_per_proof": 1 << (cs.ext_k - k),
                            "columns": n_sweep_cols, "algorithmic_bytes_per_launch": 32 * (n_sweep_cols + 1) * n}
+    try:
+        ins, prods, slots, kernels = npk.sweep_stats()
+        out["sweep_kernel"].update({"instructions_per_row": ins, "products_per_row": prods, "products_per_launch": prods * n, "kernels": kernels})
+    except Exception as e:
+        out["sweep_kernel"]["stats_error"] = repr(e)[:100]
     if "--cold" in sys.argv:
         # the one-shot `ezkl prove`: artefact files on disk, a FRESH process (tools/prove_cold.py) reads SRS + pk into HBM and proves once
         import subprocess, tempfile, shutil
