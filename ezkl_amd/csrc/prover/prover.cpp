@@ -899,11 +899,22 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     Backend be(k, n, g, nullptr, cs.shard);
     auto pk = std::make_unique<ProvingKey>();
     pk->cs = &cs;
+    // EZKL_PROVER_KEYGEN_TIMING=1: stage times on stderr
+    const bool timing = getenv("EZKL_PROVER_KEYGEN_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)ezkl_hip_synchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ezkl_prover] keygen %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     for (uint32_t c = 0; c < cs.n_fixed; c++) {
         pk->fixed_values.push_back(be.upload(fixed_values[c], n));
         pk->fixed_polys.push_back(be.lagrange_to_coeff(pk->fixed_values.back()));
         pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
     }
+    lap("fixed columns");
     // permutation: cycle structure over (colpos, row) cells numbered c * n + r; `nxt` is the cycle successor, `root` a
     // cycle label, `size` the cycle length (halo2 permutation::keygen::Assembly::copy)
     const size_t m = cs.perm.size(), cells = m * n;
@@ -924,6 +935,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
         } while (cur != b);
         std::swap(nxt[a], nxt[b]);
     }
+    lap("copy cycles (host)");
     // sigma[c][r] = delta^c' * omega^r' for (c', r') = nxt[(c, r)]: gather from the m columns delta^c * omega^row
     pk->omega_col = be.omega_powers();
     const std::vector<U256> wcol = be.download(pk->omega_col, n);
@@ -936,6 +948,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
         dcols[c] = be.download(h, n);
         dp = dp * delta;
     }
+    lap("delta^c omega^r columns");
     for (size_t c = 0; c < m; c++) {
         std::vector<U256> sig(n);
         for (uint32_t r = 0; r < n; r++) {
@@ -946,6 +959,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
         pk->sigma_polys.push_back(be.lagrange_to_coeff(pk->sigma_values.back()));
         pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
     }
+    lap("sigma gather + forms");
     // l0, l_last, l_active_row on the extended coset
     auto lag = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
     pk->l0 = lag(0, 1);
@@ -953,9 +967,11 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     pk->l_active = lag(0, cs.usable);
     // the identity column X on the extended coset (from coefficients [0, 1, 0, ...])
     pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
+    lap("l0 / l_last / l_active / X");
     pk->fixed_commitments = be.commit(pk->fixed_polys);
     pk->sigma_commitments = be.commit(pk->sigma_polys);
     pk->digest = vk_digest(*pk);
+    lap("commitments");
     return pk;
 }
 

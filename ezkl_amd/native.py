@@ -181,13 +181,22 @@ class NativeCircuit:
             pass
 
 
+def _copies_array(copies):
+    """copy constraints as the (count, 4) uint32 array ezkl_prover_keygen takes: from pairs ((column position, row), (column position, row)),
+    or from anything with such an `.array` already (a circuit read back from disk: converting 10^7 pairs through Python tuples costs more
+    than the keygen itself)"""
+    if hasattr(copies, "array"):
+        return np.ascontiguousarray(copies.array, np.uint32).reshape(-1, 4)
+    return np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4))
+
+
 class NativeProvingKey:
     """keygen_vk + keygen_pk on the GPU; `g` is a backend.Bases handle of the coefficient-basis SRS"""
 
     def __init__(self, circuit, g, fixed_values, copies):
         self.circuit = circuit
         fixed = [np.ascontiguousarray(v, np.uint64) for v in fixed_values]
-        cp = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4))
+        cp = _copies_array(copies)
         self.h = C.c_void_p()
         _check(load().ezkl_prover_keygen(circuit.h, g.h, _ptr_array(fixed), cp.ctypes.data_as(C.c_void_p), C.c_size_t(cp.shape[0]), C.byref(self.h)),
                "ezkl_prover_keygen")
@@ -286,7 +295,7 @@ class NativeGroup:
 
     def keygen(self, fixed_values, copies):
         fixed = [np.ascontiguousarray(v, np.uint64) for v in fixed_values]
-        cp = np.ascontiguousarray(np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4))
+        cp = _copies_array(copies)
         _check(load().ezkl_prover_group_keygen(self.h, _ptr_array(fixed), cp.ctypes.data_as(C.c_void_p), C.c_size_t(cp.shape[0])), "ezkl_prover_group_keygen")
 
     def pk(self, context=0):

@@ -21,7 +21,7 @@ def test_cached_circuit_is_the_circuit(tmp_path, monkeypatch):
     again = BC.build("mlp", 8)                       # reads
     assert "read from" in again["info"].get("layout", "")
     assert NV.serialize_cs(first["cs"]) == NV.serialize_cs(again["cs"])
-    assert first["copies"] == again["copies"] and first["instances"] == again["instances"]
+    assert list(first["copies"]) == list(again["copies"]) and first["instances"] == again["instances"]
     for a, b in zip(first["fixed"] + first["advice"], again["fixed"] + again["advice"]):
         assert (np.asarray(a) == np.asarray(b)).all()
     # other generator options are another key, another file

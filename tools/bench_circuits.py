@@ -93,8 +93,23 @@ def _cache_load(path, gpu):
         meta = pickle.loads(z["meta"].tobytes())
         fixed = _unpack_cols([z["f%d" % i] for i in range(meta["n_fixed"])], gpu)
         advice = _unpack_cols([z["a%d" % i] for i in range(meta["n_advice"])], gpu)
-        copies = [((int(a), int(b)), (int(c), int(d))) for a, b, c, d in z["copies"]]
+        copies = CopyPairs(z["copies"])
     return dict(cs=meta["cs"], fixed=fixed, copies=copies, advice=advice, instances=meta["instances"], info=dict(meta["info"], layout="read from " + os.path.basename(path)))
+
+
+class CopyPairs:
+    """the copy constraints of a stored circuit: iterates as ((column position, row), (column position, row)) pairs like the layout engine's
+    list, and hands the (count, 4) uint32 array itself to consumers that can take it (ezkl_amd.native.NativeProvingKey)"""
+
+    def __init__(self, array):
+        self.array = np.ascontiguousarray(array, np.uint32).reshape(-1, 4)
+
+    def __len__(self):
+        return int(self.array.shape[0])
+
+    def __iter__(self):
+        for a, b, c, d in self.array.tolist():
+            yield ((a, b), (c, d))
 
 
 def _cache_store(path, cs, fixed_raw, copies, adv_raw, instances, info):
