@@ -353,6 +353,12 @@ def vec_op(op, a_ptr, b_ptr, out_ptr, n, stream=None):
                                             _stream_ptr(stream)), "ezkl_hip_vec_op_dev")
 
 
+def permutation_sigma_dev(next_ptr, omega_col_ptr, delta_pows_ptr, n_columns, log_n, out_ptr, stream=None):
+    """out[r] = delta^(t >> log_n) * omega^(t mod 2^log_n), t = next[r]: one sigma column from the cycle successors of its cells (u32, device)"""
+    _l.check(_l.load().ezkl_hip_permutation_sigma_dev(_vp(next_ptr), _vp(omega_col_ptr), _vp(delta_pows_ptr), C.c_uint32(n_columns), C.c_uint32(log_n),
+                                                      _vp(out_ptr), _stream_ptr(stream)), "ezkl_hip_permutation_sigma_dev")
+
+
 def vec_scale(a_ptr, scalar, out_ptr, n, stream=None):
     _l.check(_l.load().ezkl_hip_vec_scale_dev(_vp(a_ptr), _p(_fe(scalar)), _vp(out_ptr), C.c_size_t(n), _stream_ptr(stream)), "ezkl_hip_vec_scale_dev")
 

@@ -763,6 +763,15 @@ int ezkl_hip_vec_fill_dev(void* o, const void* v, size_t n, void* stream) {
     int rc = vec_fill(c, st, (fe_t*)o, val, n);
     return rc ? rc : finish(c, st, stream);
 }
+int ezkl_hip_permutation_sigma_dev(const void* next_dev, const void* omega_col_dev, const void* delta_pows_dev, uint32_t n_columns, uint32_t log_n,
+                                   void* out_dev, void* stream) {
+    if (!next_dev || !omega_col_dev || !delta_pows_dev || !out_dev || n_columns == 0 || log_n > 28) return EZKL_ERR_INVALID;
+    if (((uint64_t)n_columns << log_n) > ((uint64_t)1 << 32)) return EZKL_ERR_INVALID;         // cells are numbered in 32 bits
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = perm_sigma(c, st, (const uint32_t*)next_dev, (const fe_t*)omega_col_dev, (const fe_t*)delta_pows_dev, log_n, n_columns, (fe_t*)out_dev);
+    return rc ? rc : finish(c, st, stream);
+}
 int ezkl_hip_vec_scale_dev(const void* a, const void* s, void* o, size_t n, void* stream) {
     if (!a || !s || !o) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -111,6 +111,7 @@ int msm_batch_finish(Ctx* c, MsmBatch* mb, void* out_host, size_t capacity);
 int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o, size_t n);
 int vec_fill(Ctx* c, hipStream_t st, fe_t* o, const fe_t& v, size_t n);
 int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, size_t n);
+int perm_sigma(Ctx* c, hipStream_t st, const uint32_t* next, const fe_t* omega_col, const fe_t* delta_pows, uint32_t log_n, uint32_t m, fe_t* out);
 int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
 int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,

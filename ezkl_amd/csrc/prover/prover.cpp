@@ -936,28 +936,28 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
         std::swap(nxt[a], nxt[b]);
     }
     lap("copy cycles (host)");
-    // sigma[c][r] = delta^c' * omega^r' for (c', r') = nxt[(c, r)]: gather from the m columns delta^c * omega^row
+    // sigma[c][r] = delta^c' * omega^r' for (c', r') = nxt[(c, r)]: gathered on the device (ezkl_hip_permutation_sigma_dev) from the
+    // resident omega^r column and the m powers of delta; only the successor map travels (4 B per cell)
     pk->omega_col = be.omega_powers();
-    const std::vector<U256> wcol = be.download(pk->omega_col, n);
-    std::vector<std::vector<U256>> dcols(m);
-    const Fe delta{FR_DELTA};
-    Fe dp = Fe::one();
-    for (size_t c = 0; c < m; c++) {
-        Col h = be.upload(wcol);
-        be.scale(h, dp, n);
-        dcols[c] = be.download(h, n);
-        dp = dp * delta;
-    }
-    lap("delta^c omega^r columns");
-    for (size_t c = 0; c < m; c++) {
-        std::vector<U256> sig(n);
-        for (uint32_t r = 0; r < n; r++) {
-            const uint32_t t = nxt[c * n + r];
-            sig[r] = dcols[t / n][t % n];
+    {
+        std::vector<U256> dpv(m ? m : 1, U256{0, 0, 0, 0});
+        const Fe delta{FR_DELTA};
+        Fe dp = Fe::one();
+        for (size_t c = 0; c < m; c++) {
+            dpv[c] = dp.v;
+            dp = dp * delta;
         }
-        pk->sigma_values.push_back(be.upload(sig));
-        pk->sigma_polys.push_back(be.lagrange_to_coeff(pk->sigma_values.back()));
-        pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+        const Col dpc = be.upload(dpv);
+        const Col next = be.alloc((n + 7) / 8);                      // n u32 successors
+        lap("delta powers");
+        for (size_t c = 0; c < m; c++) {
+            check(ezkl_hip_memcpy_h2d(next->ptr(), nxt.data() + c * n, (size_t)n * 4), "ezkl_hip_memcpy_h2d");
+            Col sig = be.alloc(n);
+            check(ezkl_hip_permutation_sigma_dev(next->ptr(), pk->omega_col->ptr(), dpc->ptr(), (uint32_t)m, k, sig->ptr(), nullptr), "ezkl_hip_permutation_sigma_dev");
+            pk->sigma_values.push_back(sig);
+            pk->sigma_polys.push_back(be.lagrange_to_coeff(pk->sigma_values.back()));
+            pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+        }
     }
     lap("sigma gather + forms");
     // l0, l_last, l_active_row on the extended coset

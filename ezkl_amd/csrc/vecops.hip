@@ -25,6 +25,14 @@ __global__ __launch_bounds__(256) void vec_periodic_mul_kernel(fe_t* a, const fe
         st_fe(a + i, Fr::mul(ld_fe(a + i), ld_fe(t + (i & mask))));
 }
 
+// sigma column of the permutation argument from the cycle successor map: out[r] = delta^(t >> log_n) * omega^(t & (n - 1)), t = next[r]
+__global__ __launch_bounds__(256) void perm_sigma_kernel(const uint32_t* next, const fe_t* omega_col, const fe_t* delta_pows, uint32_t log_n, uint32_t m,
+                                                         fe_t* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t t = next[i], c = t >> log_n, r = t & (uint32_t)(n - 1);
+        st_fe(out + i, c < m ? Fr::mul(ld_fe(omega_col + r), ld_fe(delta_pows + c)) : Fr::zero());     // a successor outside the m columns: no read
+    }
+}
 __global__ __launch_bounds__(256) void vec_fill_kernel(fe_t* o, fe_t v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) st_fe(o + i, v);
 }
@@ -46,6 +54,12 @@ int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o
 int vec_fill(Ctx* c, hipStream_t st, fe_t* o, const fe_t& v, size_t n) {
     if (n == 0) return EZKL_OK;
     hipLaunchKernelGGL(vec_fill_kernel, dim3(stream_grid(c, n)), dim3(256), 0, st, o, v, n);
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+int perm_sigma(Ctx* c, hipStream_t st, const uint32_t* next, const fe_t* omega_col, const fe_t* delta_pows, uint32_t log_n, uint32_t m, fe_t* out) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(perm_sigma_kernel, dim3(stream_grid(c, n)), dim3(256), 0, st, next, omega_col, delta_pows, log_n, m, out, n);
     EZ_HIP(hipGetLastError());
     return EZKL_OK;
 }

@@ -205,6 +205,12 @@ int ezkl_hip_cosets_transpose_dev(const void* in_dev, void* out_dev, uint32_t lo
 int ezkl_hip_vec_op_dev(int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n, void* stream);
 int ezkl_hip_vec_scale_dev(const void* a_dev, const void* scalar_host, void* out_dev, size_t n, void* stream);
 int ezkl_hip_vec_fill_dev(void* out_dev, const void* value_host, size_t n, void* stream);   /* out[i] = value */
+/* One sigma column of the permutation argument (halo2 permutation::keygen::Assembly::build_pk: sigma_c[r] = delta^c' omega^r' where
+ * (c', r') is the cycle successor of cell (c, r)): cells are numbered column position * 2^log_n + row; next_dev = the successors of the
+ * 2^log_n cells of this column (u32, device), omega_col_dev[r] = omega^r, delta_pows_dev[c] = delta^c (n_columns entries).
+ * out_dev[r] = delta_pows[t >> log_n] * omega_col[t mod 2^log_n], t = next_dev[r] (zero for a successor outside the n_columns). */
+int ezkl_hip_permutation_sigma_dev(const void* next_dev, const void* omega_col_dev, const void* delta_pows_dev, uint32_t n_columns, uint32_t log_n,
+                                   void* out_dev, void* stream);
 /* a[i] *= t[i mod 2^(ext_k-k)], t = 1/((zeta*omega_ext^j)^n - 1): EvaluationDomain::divide_by_vanishing_poly */
 int ezkl_hip_divide_by_vanishing_dev(void* a_dev, uint32_t k, uint32_t ext_k, void* stream);
 /* running sum (EZKL_VEC_ADD) / running product (EZKL_VEC_MUL): out[i] = in[0] o ... o in[i] (inclusive) or

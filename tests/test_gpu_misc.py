@@ -350,3 +350,34 @@ def test_pinned_host_memory(hip):
     d = B.DeviceBuffer.from_numpy(pa.array)
     assert (d.to_numpy(shape=(1 << 12, 4)) == pa.array).all()
     pa.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,m", [(4, 1), (9, 5), (14, 3)])
+def test_permutation_sigma_column(hip, k, m):
+    """sigma_c[r] = delta^c' omega^r' for the cycle successor (c', r') of cell (c, r) (halo2 permutation keygen), from the successor map:
+    against big-integer arithmetic, with fixed points, successors in other columns and one successor outside the columns (-> 0)"""
+    from ezkl_amd import backend as B
+    from conftest import fe_to_int
+    from oracle import pyref as pr
+    n = 1 << k
+    rng = np.random.default_rng(100 * k + m)
+    w = pr.omega(k)
+    wcol = np.stack([fe_from_int(pow(w, r, R)) for r in range(n)])
+    dpow = np.stack([fe_from_int(pow(pr.DELTA, c, R)) for c in range(m)])
+    d_w, d_d = B.DeviceBuffer.from_numpy(wcol), B.DeviceBuffer.from_numpy(dpow)
+    for c in range(m):
+        nxt = (c * n + np.arange(n)).astype(np.uint32)                 # fixed points ...
+        moved = rng.random(n) < 0.4
+        nxt[moved] = rng.integers(0, m * n, size=int(moved.sum()), dtype=np.uint32)   # ... and successors anywhere in the m columns
+        nxt[1] = m * n + 3                                             # outside: the kernel must not read there
+        d_n = B.DeviceBuffer.from_numpy(nxt)
+        out = B.DeviceBuffer(32 * n)
+        B.permutation_sigma_dev(d_n.ptr, d_w.ptr, d_d.ptr, m, k, out.ptr)
+        got = out.to_numpy(shape=(n, 4))
+        for r in list(range(8)) + [int(x) for x in rng.integers(0, n, 40)]:
+            t = int(nxt[r])
+            want = 0 if t >= m * n else pow(pr.DELTA, t // n, R) * pow(w, t % n, R) % R
+            assert fe_to_int(got[r]) == want
+    with pytest.raises(Exception):
+        B.permutation_sigma_dev(d_n.ptr, d_w.ptr, d_d.ptr, 0, k, out.ptr)
