@@ -176,6 +176,12 @@ class MsmBatch:
         _l.check(_l.load().ezkl_hip_msm_batch_push_dev(self.h, _vp(scalars_ptr)), "ezkl_hip_msm_batch_push_dev")
         self.count += 1
 
+    def push_many(self, scalar_ptrs):
+        """several columns at once (fused into groups like a one-call batch); returns once their MSMs are queued"""
+        arr = (C.c_void_p * max(1, len(scalar_ptrs)))(*[_vp(p) for p in scalar_ptrs])
+        _l.check(_l.load().ezkl_hip_msm_batch_push_many_dev(self.h, arr, C.c_size_t(len(scalar_ptrs))), "ezkl_hip_msm_batch_push_many_dev")
+        self.count += len(scalar_ptrs)
+
     def finish(self, capacity=None):
         cap = self.count if capacity is None else capacity
         out = np.zeros((max(cap, 1), 8), np.uint64)
@@ -345,6 +351,14 @@ def ntt_dev(ptr, log_n, omega, inverse=False, batch=1, stride=None, stream=None)
     stride = (1 << log_n) if stride is None else stride
     _l.check(_l.load().ezkl_hip_ntt_dev(_vp(ptr), C.c_uint32(log_n), _p(w), C.c_int(1 if inverse else 0),
                                          C.c_size_t(batch), C.c_size_t(stride), _stream_ptr(stream)), "ezkl_hip_ntt_dev")
+
+
+def set_async(on):
+    """ezkl_hip_set_async for the calling thread: library-stream calls return once queued (True) / when done (False, which drains the
+    stream).  Returns the previous setting."""
+    prev = C.c_int(0)
+    _l.check(_l.load().ezkl_hip_set_async(C.c_int(1 if on else 0), C.byref(prev)), "ezkl_hip_set_async")
+    return bool(prev.value)
 
 
 def vec_op(op, a_ptr, b_ptr, out_ptr, n, stream=None):

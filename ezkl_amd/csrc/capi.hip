@@ -646,8 +646,14 @@ int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_
 int ezkl_hip_msm_batch_push_dev(ezkl_msm_batch_t batch, const void* scalars_dev) {
     if (!batch || !scalars_dev) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    EZ_HIP(hipStreamSynchronize(c->stream));          // the column was produced on the library stream
-    return msm_batch_push(c, reinterpret_cast<MsmBatch*>(batch), (const fe_t*)scalars_dev);
+    return msm_batch_push(c, reinterpret_cast<MsmBatch*>(batch), (const fe_t*)scalars_dev);   // ordered behind the library stream by an event
+}
+int ezkl_hip_msm_batch_push_many_dev(ezkl_msm_batch_t batch, const void* const* scalars_dev, size_t count) {
+    if (!batch || (count && !scalars_dev)) return EZKL_ERR_INVALID;
+    for (size_t i = 0; i < count; i++)
+        if (!scalars_dev[i]) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return msm_batch_push_many(c, reinterpret_cast<MsmBatch*>(batch), (const fe_t* const*)scalars_dev, count, c->stream);
 }
 int ezkl_hip_msm_batch_finish(ezkl_msm_batch_t batch, void* out, size_t capacity) {
     if (!batch || (!out && capacity)) return EZKL_ERR_INVALID;

@@ -107,6 +107,7 @@ int msm_upload_end(MsmUpload* u);
 struct MsmBatch;
 int msm_batch_begin(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, size_t n, MsmBatch** out);
 int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev);
+int msm_batch_push_many(Ctx* c, MsmBatch* mb, const fe_t* const* cols, size_t count, hipStream_t after);
 int msm_batch_finish(Ctx* c, MsmBatch* mb, void* out_host, size_t capacity);
 int vec_op(Ctx* c, hipStream_t st, int op, const fe_t* a, const fe_t* b, fe_t* o, size_t n);
 int vec_fill(Ctx* c, hipStream_t st, fe_t* o, const fe_t& v, size_t n);

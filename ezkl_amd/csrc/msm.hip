@@ -30,6 +30,7 @@
 //                      one overlap the accumulation of the next.
 // Order of additions differs from the CPU Pippenger, the group element (and its canonical affine bytes) does not.
 #include "common.hpp"
+#include <deque>
 #include <thread>
 #include "curve.hpp"
 #include "curve29.hpp"
@@ -1265,8 +1266,15 @@ bool msm_upload_is_open() { return g_open_upload != nullptr; }
 struct MsmBatch {
     const Bases* b = nullptr;
     MsmTable* T = nullptr;
-    size_t base_offset = 0, n = 0, pushed = 0, retired = 0;
-    std::vector<h64::aff> results;
+    size_t base_offset = 0, n = 0, pushed = 0;      // pushed: columns
+    // one entry per fused group in flight or retired; a slot writes its group's affine results here (std::deque: stable addresses)
+    struct Group {
+        uint8_t out[64 * MSM_MAX_GROUP];
+        uint32_t count = 0;
+    };
+    std::deque<Group> groups;
+    size_t retired = 0;                             // groups
+    hipEvent_t order_ev = nullptr;                  // "the pushed columns are final": recorded on the producing stream at every push
 };
 static MsmBatch* g_open_batch_fwd() { return g_open_batch; }
 bool msm_batch_is_open() { return g_open_batch != nullptr; }
@@ -1284,24 +1292,40 @@ int msm_batch_begin(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, 
     return EZKL_OK;
 }
 static int msm_batch_retire_one(MsmBatch* mb) {
-    h64::aff r;
-    int rc = msm_finish(g_slots[mb->retired % MSM_SLOTS], &r);
+    int rc = msm_finish(g_slots[mb->retired % MSM_SLOTS]);          // -> the group's `out`
     if (rc) return rc;
-    mb->results.push_back(r);
     mb->retired++;
     return EZKL_OK;
 }
-int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev) {
+// `count` resident columns, produced by work queued on `after` so far: their MSMs start behind it WITHOUT a host synchronisation (an
+// event), as fused groups on the slot streams -- the caller goes on queuing unrelated work on `after` (the prover: the next argument's
+// helper chain) while they run
+int msm_batch_push_many(Ctx* c, MsmBatch* mb, const fe_t* const* cols, size_t count, hipStream_t after) {
     if (mb != g_open_batch) return EZKL_ERR_INVALID;
-    if (mb->n == 0) { mb->pushed++; return EZKL_OK; }
-    int rc;
-    if (mb->pushed - mb->retired >= (size_t)MSM_SLOTS && (rc = msm_batch_retire_one(mb))) return rc;
-    MsmSlot& sl = g_slots[mb->pushed % MSM_SLOTS];
-    if ((rc = slot_prepare(sl, 0))) return rc;
-    if ((rc = msm_enqueue(c, sl, sl.st, mb->T, mb->base_offset, &scalars_dev, 1, mb->n, false))) return rc;
-    mb->pushed++;
+    if (count == 0) return EZKL_OK;
+    if (mb->n == 0) { mb->pushed += count; return EZKL_OK; }
+    if (!mb->order_ev) EZ_HIP(hipEventCreateWithFlags(&mb->order_ev, hipEventDisableTiming));
+    EZ_HIP(hipEventRecord(mb->order_ev, after));
+    const size_t G = msm_group_size(mb->T, mb->n, false);
+    int rc = EZKL_OK;
+    for (size_t j0 = 0; j0 < count; j0 += G) {
+        const size_t cnt = count - j0 < G ? count - j0 : G;
+        if (mb->groups.size() - mb->retired >= (size_t)MSM_SLOTS && (rc = msm_batch_retire_one(mb))) return rc;
+        MsmSlot& sl = g_slots[mb->groups.size() % MSM_SLOTS];
+        if ((rc = slot_prepare(sl, 0))) return rc;
+        EZ_HIP(hipStreamWaitEvent(sl.st, mb->order_ev, 0));
+        mb->groups.emplace_back();
+        mb->groups.back().count = (uint32_t)cnt;
+        sl.out = mb->groups.back().out;
+        if ((rc = msm_enqueue(c, sl, sl.st, mb->T, mb->base_offset, cols + j0, cnt, mb->n, false))) {
+            mb->groups.pop_back();
+            return rc;
+        }
+        mb->pushed += cnt;
+    }
     return EZKL_OK;
 }
+int msm_batch_push(Ctx* c, MsmBatch* mb, const fe_t* scalars_dev) { return msm_batch_push_many(c, mb, &scalars_dev, 1, c->stream); }
 // drains the pipeline, writes `pushed` affine results (capacity checked) and closes the batch -- also on error
 int msm_batch_finish(Ctx* c, MsmBatch* mb, void* out_host, size_t capacity) {
     (void)c;
@@ -1310,13 +1334,20 @@ int msm_batch_finish(Ctx* c, MsmBatch* mb, void* out_host, size_t capacity) {
     if (mb->n == 0) {
         if (capacity < mb->pushed) rc = EZKL_ERR_INVALID; else memset(out_host, 0, 64 * mb->pushed);
     } else {
-        while (!rc && mb->retired < mb->pushed) rc = msm_batch_retire_one(mb);
+        while (!rc && mb->retired < mb->groups.size()) rc = msm_batch_retire_one(mb);
         if (!rc && capacity < mb->pushed) rc = EZKL_ERR_INVALID;
-        if (!rc && mb->pushed) memcpy(out_host, mb->results.data(), 64 * mb->pushed);
+        if (!rc) {
+            uint8_t* o = (uint8_t*)out_host;
+            for (auto& g : mb->groups) {
+                memcpy(o, g.out, 64 * (size_t)g.count);
+                o += 64 * (size_t)g.count;
+            }
+        }
         if (rc)                                              // leave no slot marked busy behind a failed batch
             for (auto& sl : g_slots)
                 if (sl.busy) { (void)hipStreamSynchronize(sl.st); sl.busy = false; }
     }
+    if (mb->order_ev) (void)hipEventDestroy(mb->order_ev);
     g_open_batch = nullptr;
     delete mb;
     return rc;

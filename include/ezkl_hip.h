@@ -164,9 +164,16 @@ int ezkl_hip_upload_begin(const void* const* host_cols, void* const* dev_cols, s
 int ezkl_hip_upload_wait(ezkl_upload_t upload, size_t column, void* stream);
 int ezkl_hip_upload_commit(ezkl_upload_t upload, ezkl_bases_t h, size_t commit_first, size_t commit_count, void* out_affine);
 int ezkl_hip_upload_end(ezkl_upload_t upload);
+/* A commit batch fed as its columns become final: begin; push (one column / several: fused into groups as the one-call batch does) any
+ * number of times; finish returns the points in push order and closes the batch (also after an error).  A push returns once the MSMs
+ * are QUEUED: they start behind everything queued on the library stream so far (an event, no host synchronisation), on the MSM slot
+ * streams, so the caller can go on queuing unrelated library-stream work while they run -- the prover commits the permutation
+ * products z while the lookup arguments' running sums are still being computed.  The pushed columns must stay untouched until finish.
+ * One batch may be open per context; the other MSM entry points refuse (EZKL_ERR_INVALID) until it is finished. */
 typedef struct ezkl_msm_batch_s* ezkl_msm_batch_t;
 int ezkl_hip_msm_batch_begin(ezkl_bases_t h, size_t base_offset, size_t n, ezkl_msm_batch_t* out_batch);
 int ezkl_hip_msm_batch_push_dev(ezkl_msm_batch_t batch, const void* scalars_dev);
+int ezkl_hip_msm_batch_push_many_dev(ezkl_msm_batch_t batch, const void* const* scalars_dev, size_t count);
 int ezkl_hip_msm_batch_finish(ezkl_msm_batch_t batch, void* out_affine, size_t capacity);
 /* out = a + b on affine points (host, used to fold per-GPU partial sums after the all-gather) */
 int ezkl_hip_g1_add_affine(const void* a, const void* b, void* out);

@@ -316,6 +316,29 @@ def test_incremental_commit_batch(hip):
     mb.push(devs[0].ptr)
     assert (mb.finish()[0] == ob.msm(cols[0][: n // 2], pts[n // 4: n // 4 + n // 2])).all()
     assert B.MsmBatch(bases, n).finish().shape == (0, 8)
+    # several columns per push (fused groups at this size: 9 columns = groups of 4, 4, 1 over the slots), mixed with single pushes, and
+    # queued behind library-stream work that is still running when push returns (asynchronous mode): the MSMs must see its result
+    mb = B.MsmBatch(bases, n)
+    mb.push_many([d.ptr for d in devs[:5]])
+    mb.push(devs[5].ptr)
+    mb.push_many([d.ptr for d in devs[6:]])
+    mb.push_many([])
+    got = mb.finish()
+    assert got.shape == (9, 8) and (got == want).all()
+    work = B.DeviceBuffer.from_numpy(cols[0])
+    prev = B.set_async(True)
+    try:
+        mb = B.MsmBatch(bases, n)
+        for _ in range(20):                                   # a chain on the library stream: work = cols[0] + 20 * cols[1]
+            B.vec_op("add", work.ptr, devs[1].ptr, work.ptr, n)
+        mb.push_many([work.ptr, devs[2].ptr])
+        got = mb.finish()
+    finally:
+        B.set_async(prev)
+    from conftest import fe_to_int, fe_from_int
+    acc = np.stack([fe_from_int((fe_to_int(a) + 20 * fe_to_int(b)) % R) for a, b in zip(cols[0][:64], cols[1][:64])])
+    assert (work.to_numpy(shape=(n, 4))[:64] == acc).all()
+    assert (got[0] == B.msm_g1_dev(bases, work.ptr, n)).all() and (got[1] == want[2]).all()
     bases.free()
 
 
