@@ -411,7 +411,7 @@ def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
     if os.environ.get("EZKL_BENCH_MULTI_MODE") == "replicated":
         cmd.append("--replicated")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300")))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300" if circuit != "mlp" else "600")))  # the MLP may have to be laid out first
         if rank != 0:
             return None
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
