@@ -91,6 +91,20 @@ static int ctx_create(int idx) {
     hipDeviceProp_t prop;
     EZ_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
+    // one process driving several GPUs (the prover group): let this device read the other contexts' devices directly, so that
+    // ezkl_hip_memcpy_peer is one xGMI transfer instead of a copy staged through host memory.  Best effort: without peer access the
+    // copies still work.
+    for (int j = 0; j < g_n_ctx; j++) {
+        const int other = g_ctx_device[j];
+        if (other == device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, other) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && getenv("EZKL_HIP_DEBUG"))
+                fprintf(stderr, "[ezkl_hip] no peer access %d -> %d: %s\n", device, other, hipGetErrorString(e));
+        }
+        (void)hipGetLastError();
+    }
     g_ctxs[idx] = c;
     return EZKL_OK;
 }
