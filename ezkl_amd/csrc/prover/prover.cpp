@@ -1273,13 +1273,18 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
             cv.notify_all();
         }
     }
-    for (auto& v : pk->fixed_values) {
-        pk->fixed_polys.push_back(be.lagrange_to_coeff(v));
-        pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
-    }
-    for (auto& v : pk->sigma_values) {
-        pk->sigma_polys.push_back(be.lagrange_to_coeff(v));
-        pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+    // (the transforms run AFTER the uploads: queuing each column's behind its upload, under the readers, was measured slower on the same
+    // box and artefacts -- key load 0.184 against 0.160 s, 4 runs each, gpurun_out/r03ai_cold_ab.log: the uploads then wait for the
+    // transforms queued before them on the library stream)
+    {
+        for (auto& v : pk->fixed_values) {
+            pk->fixed_polys.push_back(be.lagrange_to_coeff(v));
+            pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
+        }
+        for (auto& v : pk->sigma_values) {
+            pk->sigma_polys.push_back(be.lagrange_to_coeff(v));
+            pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+        }
     }
     auto lag = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
     pk->l0 = lag(0, 1);

@@ -256,6 +256,15 @@ if not SYNTH:
             if "proof_sha256" in cj:
                 cj["same_proof_as_warm"] = cj["proof_sha256"] == __import__("hashlib").sha256(proof).hexdigest()[:16]
             cj["artifact_bytes"] = size; cj["artifact_write_seconds"] = round(t_write, 2)
+            if os.environ.get("EZKL_COLD_AB"):                           # A/B of an environment switch on the SAME artefacts and box: VAR=VALUE
+                var, val = os.environ["EZKL_COLD_AB"].split("=", 1)
+                ab = {"default": [], os.environ["EZKL_COLD_AB"]: []}
+                for _ in range(int(os.environ.get("EZKL_COLD_AB_REPS", "3"))):
+                    for name, env_ in (("default", {}), (os.environ["EZKL_COLD_AB"], {var: val})):
+                        c_ = cold_child(env_)
+                        ab[name].append({"cold_seconds": c_.get("cold_seconds"), "pk_read_to_hbm": (c_.get("stages") or {}).get("pk_read_to_hbm"),
+                                         "create_proof": (c_.get("stages") or {}).get("create_proof"), "device_init": (c_.get("stages") or {}).get("device_init")})
+                cj["ab"] = ab
             out["cold"] = cj
         finally:
             shutil.rmtree(d, ignore_errors=True)
