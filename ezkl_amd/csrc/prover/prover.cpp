@@ -1274,7 +1274,7 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
         }
     }
     // (the transforms run AFTER the uploads: queuing each column's behind its upload, under the readers, was measured slower on the same
-    // box and artefacts -- key load 0.184 against 0.160 s, 4 runs each, gpurun_out/r03ai_cold_ab.log: the uploads then wait for the
+    // box and artefacts -- key load 0.184 against 0.160 s, 4 runs each, profiles/r03ai_cold_ab.log: the uploads then wait for the
     // transforms queued before them on the library stream)
     {
         for (auto& v : pk->fixed_values) {
