@@ -169,7 +169,7 @@ def main():
         # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (the guide: never together with the
         # kernel trace), so bench.py cannot measure them itself; it reports the tracked reduction of those passes WITH its source label
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # PMC passes over THIS workload (tools/pmc_run.sh: the 2^20-point uniform MSM of the timed region)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -208,11 +208,19 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
             out["prove"] = prove_leg()
+            # BASELINE.json's metric leads with "ezkl prove wall-seconds (k = 20 MLP)": that number next to `value`, with the CPU prover of
+            # the same run beside it (a CPU restatement on this box's host cores, not halo2) and whether the two proofs are the same bytes
+            m20 = out["prove"].get("mlp_k20") or {}
+            out["prove_seconds_k20_mlp"] = {"gpu": m20.get("prove_seconds_gpu"), "cpu": m20.get("prove_seconds_cpu"), "cpu_threads": m20.get("cpu_threads"),
+                                            "identical": m20.get("proofs_identical_gpu_cpu"), "verifier_accepts": m20.get("verifier_accepts"),
+                                            "unit": "s", "higher_is_better": False, "error": m20.get("error")}
         # the three kernels that dominate the metric's own workload (the k = 20 MLP proof), each against the HBM roof: algorithmic bytes per
         # launch / the launch's HIP-event time measured in THIS run; `traffic` = PMC bytes per launch of the same kernel inside a proof
         # (tools/pmc_prove.sh: counters need their own rocprofv3 passes, so the tracked reduction is reported with its source)
         pk_, pm_ = {}, None
-        ppath = os.path.join(ROOT, "profiles", "r03_pmc_prove.json")
+        ppath = os.path.join(ROOT, "profiles", "r04_pmc_prove.json")
+        if not os.path.exists(ppath):
+            ppath = os.path.join(ROOT, "profiles", "r03_pmc_prove.json")
         if os.path.exists(ppath):
             try:
                 pm_ = json.load(open(ppath))
@@ -223,7 +231,7 @@ def main():
             d = {"kernel": kernel, "workload": workload, "bound": "hbm", "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
                  "achieved": (alg_bytes / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": (alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": traffic,
-                 "traffic_source": ("profiles/r03_pmc_prove.json: " + str(pm_.get("source"))) if (pm_ and traffic) else None}
+                 "traffic_source": ("profiles/%s: %s" % (os.path.basename(ppath), pm_.get("source"))) if (pm_ and traffic) else None}
             d.update(extra or {})
             # the roof these kernels actually sit under: 254-bit Montgomery products per second against the product peak MEASURED IN THIS
             # RUN (extra.modmul29_per_s: ezkl_hip_ubench, every lane issuing the radix-2^29 product the kernels use, nothing else)
@@ -286,77 +294,105 @@ def strong_scaling(world, rank, dist, dev, B, D, torch, args, barrier_sync):
 def prove_leg():
     """End-to-end `prove` of ezkl circuits (tools/prove_bench.py, tools/bench_circuits.py) in CHILD processes, so that the per-kernel
     averages rocprofv3 reports for this process stay those of the timed MSM / NTT regions.  Part of the checker leg: each child
-    verifies its proof with the oracle's pairing verifier.
-      * `einsum`: the reference's own criterion bench circuit benches/accum_einsum_matmul.rs raised to k = 20 (BASELINE configs[3]):
-        warm prove, the COLD one-shot prove (fresh process, SRS + pk files -> HBM -> proof.json), and the same create_proof on the host
-        cores (C oracle kernels, OpenMP) with identical proof bytes;
-      * `mlp`: an MLP over the ezkl gate set (range-check lookups, permutation over ~20 columns) at k = 17 (BASELINE configs[2]'s size),
-        GPU and CPU;
-      * `mlp_k20`: the north star's "k = 20 MLP circuit" (9 x Gemm 665 x 665 + bias + ReLU over the ezkl gate set), GPU and CPU;
-      * `conv2d_mnist`: BASELINE configs[2] itself, examples/conv2d_mnist/main.rs's Config and layout at k = 17, GPU and CPU."""
+    verifies its proof with the oracle's pairing verifier.  The legs run in the order of their weight for BASELINE.json's metric and
+    each one only if the run's time budget (EZKL_BENCH_BUDGET_S, default 150 s from process start) still covers its estimated cost, so
+    that the default `python bench.py` ends within minutes on a fresh box; what was skipped is listed under "skipped":
+      * `mlp_k20`: the metric's own configuration, "ezkl prove wall-seconds (k = 20 MLP)" -- 9 x (Gemm 665 x 665 + bias + ReLU) over the ezkl
+        gate set, laid out once and shipped as bench_cache/mlp_k20_s1.npz; warm prove on the GPU, then the same create_proof on the host
+        cores (Python host + C oracle kernels, OpenMP) with identical proof bytes;
+      * `conv2d_mnist`: BASELINE configs[2], examples/conv2d_mnist/main.rs's Config and layout at k = 17, GPU and CPU;
+      * `einsum`: the reference's own criterion bench circuit benches/accum_einsum_matmul.rs raised to k = 20 (BASELINE configs[3]), GPU and
+        CPU; with budget left also the COLD one-shot prove (fresh process, SRS + pk files -> HBM -> proof.json);
+      * `mlp`: the MLP at k = 17 (BASELINE configs[2]'s size), GPU and CPU."""
     import subprocess
     tool = os.path.join(ROOT, "tools", "prove_bench.py")
-    def child(env_extra, flags, timeout):
+    budget = float(os.environ.get("EZKL_BENCH_BUDGET_S", "150"))
+    left = lambda: budget - (time.time() - T_PROCESS_START)
+    leg_seconds, skipped = {}, []
+
+    def child(name, env_extra, flags, timeout):
         env = dict(os.environ, **env_extra)
-        r = subprocess.run([sys.executable, tool] + flags, env=env, capture_output=True, text=True, timeout=timeout)
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, tool] + flags, env=env, capture_output=True, text=True, timeout=timeout)
+        finally:
+            leg_seconds[name] = round(time.time() - t0, 1)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not lines:
             raise RuntimeError(r.stderr[-300:])
         return json.loads(lines[-1])
+
+    def pick(j, keys):
+        return {a: j.get(a) for a in keys if a in j}
+
+    common = ["circuit", "prove_seconds_gpu", "prove_seconds_gpu_runs", "first_prove_seconds_gpu", "prove_seconds_cpu", "cpu_threads", "verifier_accepts", "proof_bytes",
+              "keygen_seconds_gpu", "cpu_breakdown_seconds", "hbm_in_use_gib_after_prove", "hbm_pool_high_water_gib", "host_peak_rss_gib"]
+
+    def shape(j, extra=()):
+        d = pick(j, common + list(extra))
+        d["proofs_identical_gpu_cpu"] = j.get("proofs_identical")
+        d["breakdown_seconds"] = j.get("prove_breakdown_seconds")
+        return d
+
     out = {}
+    # 1. the metric's own configuration.  Estimated cost on a fresh box: ~25 s for the GPU side (imports, SRS, key generation, 1 + 3 proofs, the
+    #    Python verifier), ~60 s more with the CPU prover (its key generation + one proof on 16 threads)
     try:
-        k_e = os.environ.get("EZKL_BENCH_EINSUM_K", "20")
-        j = child({"CIRCUIT": "einsum", "K": k_e}, ["--cold", "--cpu"], 900)
-        out = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
-               "cold_seconds": (j.get("cold") or {}).get("cold_seconds"), "cold": j.get("cold"),
-               "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "cpu_prover": j.get("cpu_prover"),
-               "proofs_identical_gpu_cpu": j.get("proofs_identical"), "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds"),
-               "host": "libezkl_prover.so (C++) over the C ABI; ChaCha20 randomness expanded on the device", "verifier_accepts": j["verifier_accepts"],
-               "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"]}
-    except Exception as e:          # the headline line must still be printed
-        out = {"error": repr(e)[:300]}
-    try:
-        k_m = os.environ.get("EZKL_BENCH_MLP_K", "17")
-        j = child({"CIRCUIT": "mlp", "K": k_m}, ["--cpu", "--pinned"], 900)
-        out["mlp"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
-                      "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
-                      "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "breakdown_seconds": j["prove_breakdown_seconds"]}
-    except Exception as e:
-        out["mlp"] = {"error": repr(e)[:300]}
-    try:
-        # the north star's own end-to-end configuration: a k = 20 MLP circuit, the CPU prover timed beside it in the same run.  The Python
-        # layout of its 4.1 M cells takes ~40 s and the CPU prover ~55 s (keygen + proof): EZKL_BENCH_MLP20=0 skips the leg,
-        # EZKL_BENCH_MLP20_CPU=0 (or a bench that has already run for three minutes) leaves the CPU side out
         if os.environ.get("EZKL_BENCH_MLP20", "1") != "0":
-            with_cpu = os.environ.get("EZKL_BENCH_MLP20_CPU", "1") != "0" and time.time() - T_PROCESS_START < 180
-            j = child({"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned"] + (["--cpu"] if with_cpu else []), 900)
-            out["mlp_k20"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
-                              "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
-                              "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"],
-                              "breakdown_seconds": j["prove_breakdown_seconds"], "cpu_breakdown_seconds": j.get("cpu_breakdown_seconds"), "sweep_kernel": j.get("sweep_kernel")}
+            with_cpu = os.environ.get("EZKL_BENCH_MLP20_CPU", "1") != "0" and left() > 95
+            j = child("mlp_k20", {"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned"] + (["--cpu"] if with_cpu else []), 600)
+            out["mlp_k20"] = shape(j, ["sweep_kernel"])
+            if not with_cpu:
+                skipped.append("mlp_k20 CPU prover")
     except Exception as e:
         out["mlp_k20"] = {"error": repr(e)[:300]}
+    # 2. BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17 (~12 s with its CPU prover)
+    if left() > 20:
+        try:
+            out["conv2d_mnist"] = shape(child("conv2d_mnist", {"CIRCUIT": "conv", "K": "17"}, ["--cpu", "--pinned"], 300))
+        except Exception as e:
+            out["conv2d_mnist"] = {"error": repr(e)[:300]}
+    else:
+        skipped.append("conv2d_mnist")
+    # 3. BASELINE configs[3]: the reference's bench circuit at k = 20 (~30 s with the CPU prover; the cold one-shot adds ~25 s: it writes
+    #    4 GB of artefacts and starts two fresh processes)
+    k_e = os.environ.get("EZKL_BENCH_EINSUM_K", "20")
+    if left() > 45:
+        try:
+            cold = os.environ.get("EZKL_BENCH_COLD", "auto")
+            with_cold = cold == "1" or (cold == "auto" and left() > 75)
+            j = child("einsum", {"CIRCUIT": "einsum", "K": k_e}, ["--cpu"] + (["--cold"] if with_cold else []), 600)
+            out["einsum"] = shape(j)
+            out["einsum"].update({"cold_seconds": (j.get("cold") or {}).get("cold_seconds"), "cold": j.get("cold"), "cpu_prover": j.get("cpu_prover"),
+                                  "host": "libezkl_prover.so (C++) over the C ABI; ChaCha20 randomness expanded on the device"})
+            if not with_cold:
+                skipped.append("einsum cold one-shot")
+        except Exception as e:
+            out["einsum"] = {"error": repr(e)[:300]}
+    else:
+        skipped.append("einsum k=%s" % k_e)
+    # 4. the MLP at k = 17 (~15 s)
+    if left() > 25:
+        try:
+            out["mlp"] = shape(child("mlp_k17", {"CIRCUIT": "mlp", "K": os.environ.get("EZKL_BENCH_MLP_K", "17")}, ["--cpu", "--pinned"], 300))
+        except Exception as e:
+            out["mlp"] = {"error": repr(e)[:300]}
+    else:
+        skipped.append("mlp k=17")
     if os.environ.get("EZKL_BENCH_K22") == "1":
         # BASELINE configs[4]'s shape (nanoGPT-tiny, k = 22, /root/reference/tests/integration_tests.rs:172-181): the MLP generator scaled to 5
         # blocks -> 30-36 advice columns, 20-24 lookup arguments, ext 2^24.  Opt-in: the Python layout engine needs minutes per 10 M cells
         # (EZKL_BENCH_K22_FILL = percent of the cells actually laid out, default 25; the column allocation is that of the full model) and
         # the CPU prover beside it (EZKL_BENCH_K22_CPU=1) tens of minutes
         try:
-            j = child({"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": os.environ.get("EZKL_BENCH_K22_FILL", "25"), "REPS": "2"},
+            j = child("mlp_k22", {"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": os.environ.get("EZKL_BENCH_K22_FILL", "25"), "REPS": "2"},
                       ["--pinned"] + (["--cpu"] if os.environ.get("EZKL_BENCH_K22_CPU") == "1" else []), 7200)
-            out["mlp_k22"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
-                              "prove_seconds_cpu": j.get("prove_seconds_cpu"), "proofs_identical_gpu_cpu": j.get("proofs_identical"), "verifier_accepts": j["verifier_accepts"],
-                              "proof_bytes": j["proof_bytes"], "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"],
-                              "hbm_in_use_gib_after_prove": j.get("hbm_in_use_gib_after_prove")}
+            out["mlp_k22"] = shape(j)
         except Exception as e:
             out["mlp_k22"] = {"error": repr(e)[:300]}
-    try:                                               # BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17
-        j = child({"CIRCUIT": "conv", "K": "17"}, ["--cpu", "--pinned"], 900)
-        out["conv2d_mnist"] = {"circuit": j["circuit"], "prove_seconds_gpu": j["prove_seconds_gpu"], "first_prove_seconds_gpu": j["first_prove_seconds_gpu"],
-                               "prove_seconds_cpu": j.get("prove_seconds_cpu"), "cpu_threads": j.get("cpu_threads"), "proofs_identical_gpu_cpu": j.get("proofs_identical"),
-                               "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "breakdown_seconds": j["prove_breakdown_seconds"]}
-    except Exception as e:
-        out["conv2d_mnist"] = {"error": repr(e)[:300]}
+    out["leg_seconds"] = leg_seconds
+    out["skipped"] = skipped
+    out["budget_seconds"] = budget
     return out
 
 

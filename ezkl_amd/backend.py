@@ -795,6 +795,17 @@ def mem_info():
     return int(f.value), int(t.value)
 
 
+def pool_stats():
+    """the calling context's column pool: dict(live, live_peak, parked, bound) in bytes (ezkl_hip_pool_stats)"""
+    out = (C.c_size_t * 4)()
+    _l.check(_l.load().ezkl_hip_pool_stats(out), "ezkl_hip_pool_stats")
+    return dict(live=int(out[0]), live_peak=int(out[1]), parked=int(out[2]), bound=int(out[3]))
+
+
+def pool_trim():
+    _l.check(_l.load().ezkl_hip_pool_trim(), "ezkl_hip_pool_trim")
+
+
 def contexts_configure(devices):
     """the context table of libezkl_hip.so, before its first use: context i on device devices[i] (several may share a device)"""
     arr = (C.c_int * len(devices))(*devices)

@@ -2,6 +2,8 @@
 #include "common.hpp"
 #include <string.h>
 #include <atomic>
+#include <algorithm>
+#include <iterator>
 
 namespace ezkl {
 
@@ -12,9 +14,10 @@ static std::mutex g_init_mu;
 // device, and every host thread works on the context it bound itself to (ezkl_hip_set_context; threads start on context 0).  Several
 // contexts may name the same device (ezkl_hip_contexts_configure): that is how the multi-device prover is tested on a one-GPU box.
 static constexpr int MAX_CTX = 64;
-static Ctx* g_ctxs[MAX_CTX] = {nullptr};
+// (entries are published with release / read with acquire: N group threads call ctx() concurrently while another creates its context)
+static std::atomic<Ctx*> g_ctxs[MAX_CTX];
 static int g_ctx_device[MAX_CTX];
-static int g_n_ctx = 0;               // 0: table not configured yet
+static std::atomic<int> g_n_ctx{0};   // 0: table not configured yet
 static thread_local int t_ctx = 0;
 static std::atomic<int> g_last_hip_err{0};
 
@@ -45,23 +48,23 @@ int ctx_configure(int n_ctx, const int* devices) {
     std::lock_guard<std::mutex> lk(g_init_mu);
     if (n_ctx < 1 || n_ctx > MAX_CTX || !devices) return EZKL_ERR_INVALID;
     for (int i = 0; i < MAX_CTX; i++)
-        if (g_ctxs[i]) return EZKL_ERR_INVALID;
+        if (g_ctxs[i].load(std::memory_order_acquire)) return EZKL_ERR_INVALID;
     int n = 0;
     int rc = device_count_checked(&n);
     if (rc) return rc;
     for (int i = 0; i < n_ctx; i++)
         if (devices[i] < 0 || devices[i] >= n) return EZKL_ERR_INVALID;
     for (int i = 0; i < n_ctx; i++) g_ctx_device[i] = devices[i];
-    g_n_ctx = n_ctx;
+    g_n_ctx.store(n_ctx, std::memory_order_release);
     return EZKL_OK;
 }
 // ezkl_hip_init(device): device >= 0 -> ONE context on that device.  device < 0 -> LOCAL_RANK set (one process per GPU): one context on
 // device LOCAL_RANK; otherwise ALL visible devices, context i on device i.  Idempotent; a second call may not contradict the first.
 int ctx_init(int device) {
     std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_n_ctx) {                                  // already configured: fine unless the caller names a device no context is on
+    if (const int have = g_n_ctx.load(std::memory_order_acquire)) {     // already configured: fine unless the caller names a device no context is on
         if (device < 0) return EZKL_OK;
-        for (int i = 0; i < g_n_ctx; i++)
+        for (int i = 0; i < have; i++)
             if (g_ctx_device[i] == device) return EZKL_OK;
         return EZKL_ERR_INVALID;
     }
@@ -71,13 +74,14 @@ int ctx_init(int device) {
     if (device >= n) return EZKL_ERR_INVALID;
     if (device >= 0) {
         g_ctx_device[0] = device;
-        g_n_ctx = 1;
+        g_n_ctx.store(1, std::memory_order_release);
     } else if (const char* lr = getenv("LOCAL_RANK")) {
         g_ctx_device[0] = atoi(lr) % n;
-        g_n_ctx = 1;
+        g_n_ctx.store(1, std::memory_order_release);
     } else {
-        g_n_ctx = n < MAX_CTX ? n : MAX_CTX;
-        for (int i = 0; i < g_n_ctx; i++) g_ctx_device[i] = i;
+        const int m = n < MAX_CTX ? n : MAX_CTX;
+        for (int i = 0; i < m; i++) g_ctx_device[i] = i;
+        g_n_ctx.store(m, std::memory_order_release);
     }
     return EZKL_OK;
 }
@@ -94,7 +98,7 @@ static int ctx_create(int idx) {
     // one process driving several GPUs (the prover group): let this device read the other contexts' devices directly, so that
     // ezkl_hip_memcpy_peer is one xGMI transfer instead of a copy staged through host memory.  Best effort: without peer access the
     // copies still work.
-    for (int j = 0; j < g_n_ctx; j++) {
+    for (int j = 0; j < g_n_ctx.load(std::memory_order_acquire); j++) {
         const int other = g_ctx_device[j];
         if (other == device) continue;
         int can = 0;
@@ -105,28 +109,33 @@ static int ctx_create(int idx) {
         }
         (void)hipGetLastError();
     }
-    g_ctxs[idx] = c;
+    g_ctxs[idx].store(c, std::memory_order_release);
     return EZKL_OK;
 }
 
 Ctx* ctx() {
-    if (!g_n_ctx && ctx_init(-1) != EZKL_OK) return nullptr;
+    if (!g_n_ctx.load(std::memory_order_acquire) && ctx_init(-1) != EZKL_OK) return nullptr;
     const int idx = t_ctx;
-    if (idx < 0 || idx >= g_n_ctx) return nullptr;
-    if (!g_ctxs[idx]) {
+    if (idx < 0 || idx >= g_n_ctx.load(std::memory_order_acquire)) return nullptr;
+    Ctx* c = g_ctxs[idx].load(std::memory_order_acquire);
+    if (!c) {
         std::lock_guard<std::mutex> lk(g_init_mu);
-        if (!g_ctxs[idx] && ctx_create(idx) != EZKL_OK) return nullptr;
+        c = g_ctxs[idx].load(std::memory_order_acquire);
+        if (!c) {
+            if (ctx_create(idx) != EZKL_OK) return nullptr;
+            c = g_ctxs[idx].load(std::memory_order_acquire);
+        }
     }
-    return g_ctxs[idx];
+    return c;
 }
-int ctx_count() { return g_n_ctx; }
+int ctx_count() { return g_n_ctx.load(std::memory_order_acquire); }
 int ctx_bind(int idx) {
-    if (!g_n_ctx && ctx_init(-1) != EZKL_OK) return EZKL_ERR_NO_DEVICE;
-    if (idx < 0 || idx >= g_n_ctx) return EZKL_ERR_INVALID;
+    if (!ctx_count() && ctx_init(-1) != EZKL_OK) return EZKL_ERR_NO_DEVICE;
+    if (idx < 0 || idx >= ctx_count()) return EZKL_ERR_INVALID;
     t_ctx = idx;
     return EZKL_OK;
 }
-int ctx_device_of(int idx) { return idx >= 0 && idx < g_n_ctx ? g_ctx_device[idx] : -1; }
+int ctx_device_of(int idx) { return idx >= 0 && idx < ctx_count() ? g_ctx_device[idx] : -1; }
 
 int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out) {
     if (!a.last_event) EZ_HIP(hipEventCreateWithFlags(&a.last_event, hipEventDisableTiming));
@@ -328,74 +337,149 @@ namespace {
 struct PoolState {
     std::map<size_t, std::vector<void*>> pool;        // guarded by the context's mutex
     std::map<void*, size_t> sizes;
-    size_t pool_bytes = 0;
+    size_t pool_bytes = 0;                            // parked
+    size_t live_bytes = 0, live_peak = 0;             // handed out and not yet freed; its high-water mark
+    size_t floor_bytes = 0;                           // the share of the device this context may always keep parked
+    std::map<size_t, uint64_t> last_use;              // per size class: tick of the last allocation (eviction is least-recently-used class first)
+    uint64_t tick = 0;
+    size_t bound() const { return std::max(floor_bytes, live_peak + live_peak / 2); }
 };
 PoolState& pool_state(Ctx* c) {
     if (!c->pool_state) c->pool_state = new PoolState();
     return *static_cast<PoolState*>(c->pool_state);
 }
-// how much freed column memory a context keeps parked: 60 % of the device (EZKL_HIP_POOL_CAP_GB overrides).  A k = 22 proof with 30 advice
-// columns cycles through > 100 GB of columns; with the old 48 GiB cap the 512 MiB extended columns were hipFree'd at the end of every
-// proof and hipMalloc'ed again by the next (30 x ~20 ms: the advice phase took 0.85 s instead of 0.2 s)
-size_t pool_cap(Ctx* c) {
-    static size_t cap[64] = {0};
-    size_t& v = cap[c->index & 63];
-    if (!v) {
-        if (const char* e = getenv("EZKL_HIP_POOL_CAP_GB")) v = (size_t)strtoull(e, nullptr, 10) << 30;
-        if (!v) {
+// How much freed column memory a context keeps parked.  The context's FOOTPRINT (live + parked) is held to
+//     max(floor, 1.5 x high-water mark of its live bytes)
+// (1.5: the phases of a proof use different size classes -- 2^k-row columns first, extended ones later -- and a bound of exactly the
+// peak would make each phase evict the other's blocks, every proof)
+// where floor = 25 % of the device divided by the number of contexts that share the device (EZKL_HIP_POOL_CAP_GB overrides the floor).
+// A prover that runs the same proof again finds every block of the last one parked (the footprint of a proof is its own peak: the
+// k = 22 / 30-column proof cycles through > 100 GB of columns, and freeing / reallocating its 512 MiB extended columns between proofs
+// cost 0.65 s per proof, profiles/r03p_k22_gantt_poolcap48.txt), while nothing is retained beyond what some call actually needed at
+// once: after a k = 20 proof the pool holds that proof's columns, not 60 % of HBM (round 3's fixed cap).
+size_t pool_floor(Ctx* c) {
+    PoolState& ps = pool_state(c);
+    if (!ps.floor_bytes) {
+        if (const char* e = getenv("EZKL_HIP_POOL_CAP_GB")) ps.floor_bytes = (size_t)strtoull(e, nullptr, 10) << 30;
+        if (!ps.floor_bytes) {
             size_t fr = 0, tot = 0;
-            v = hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? tot / 10 * 6 : (size_t)48 << 30;
+            int sharing = 0;
+            for (int i = 0; i < ctx_count(); i++) sharing += ctx_device_of(i) == c->device ? 1 : 0;
+            if (sharing < 1) sharing = 1;
+            ps.floor_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? tot / 4 : (size_t)48 << 30) / (size_t)sharing;
         }
     }
-    return v;
+    return ps.floor_bytes;
+}
+void pool_drop_parked(PoolState& ps) {
+    for (auto& kv : ps.pool)
+        for (void* p : kv.second) { (void)hipFree(p); ps.sizes.erase(p); }
+    ps.pool.clear();
+    ps.pool_bytes = 0;
+}
+// out of memory: give back what EVERY context on this device has parked (one context could fail while another sat on idle
+// GBs).  The caller holds its own context's lock; the others are taken one at a time with try_lock -- a context that is busy right now
+// keeps its blocks (no lock order to get wrong, no deadlock), an idle one gives them up.
+void pool_trim_device(Ctx* self) {
+    pool_drop_parked(pool_state(self));
+    for (int i = 0; i < ctx_count(); i++) {
+        Ctx* o = g_ctxs[i].load(std::memory_order_acquire);
+        if (!o || o == self || o->device != self->device || !o->pool_state) continue;
+        if (!o->mu.try_lock()) continue;
+        pool_drop_parked(*static_cast<PoolState*>(o->pool_state));
+        o->mu.unlock();
+    }
 }
 }
 }
-#define g_pool (pool_state(c).pool)
-#define g_sizes (pool_state(c).sizes)
-#define g_pool_bytes (pool_state(c).pool_bytes)
 int ezkl_hip_malloc(void** dptr, size_t bytes) {
     if (!dptr) return EZKL_ERR_INVALID;
     EZ_CTX(c);
     if (!bytes) bytes = 1;
-    auto it = g_pool.find(bytes);
-    if (it != g_pool.end() && !it->second.empty()) {
+    PoolState& ps = pool_state(c);
+    auto it = ps.pool.find(bytes);
+    if (it != ps.pool.end() && !it->second.empty()) {
         *dptr = it->second.back();
         it->second.pop_back();
-        g_pool_bytes -= bytes;
+        ps.pool_bytes -= bytes;
+        ps.live_bytes += bytes;
+        ps.last_use[bytes] = ++ps.tick;
+        if (ps.live_bytes > ps.live_peak) ps.live_peak = ps.live_bytes;
         static const bool pool_sync = getenv("EZKL_HIP_POOL_SYNC") != nullptr;
         if (pool_sync) EZ_HIP(hipDeviceSynchronize());
         return EZKL_OK;
     }
+    // a new block would take the footprint past its bound: parked blocks of the least recently used size classes go first, so that a
+    // process that moves from one problem size to another does not keep both sets
+    ps.last_use[bytes] = ++ps.tick;
+    (void)pool_floor(c);
+    while (ps.pool_bytes && ps.live_bytes + ps.pool_bytes + bytes > ps.bound()) {
+        auto victim = ps.pool.end();
+        uint64_t oldest = UINT64_MAX;
+        for (auto k = ps.pool.begin(); k != ps.pool.end();) {
+            if (k->second.empty()) { k = ps.pool.erase(k); continue; }
+            const uint64_t t = ps.last_use[k->first];
+            if (t < oldest) { oldest = t; victim = k; }
+            ++k;
+        }
+        if (victim == ps.pool.end()) break;
+        void* p = victim->second.back();
+        victim->second.pop_back();
+        ps.pool_bytes -= victim->first;
+        ps.sizes.erase(p);
+        (void)hipFree(p);
+    }
     hipError_t e = hipMalloc(dptr, bytes);
-    if (e == hipErrorOutOfMemory && g_pool_bytes) {      // give the parked blocks back and retry once
+    if (e == hipErrorOutOfMemory) {                      // give the parked blocks of this device back and retry once
         (void)hipGetLastError();
-        for (auto& kv : g_pool) for (void* p : kv.second) { (void)hipFree(p); g_sizes.erase(p); }
-        g_pool.clear();
-        g_pool_bytes = 0;
+        pool_trim_device(c);
         e = hipMalloc(dptr, bytes);
     }
     if (e != hipSuccess) return set_hip_error(e, "hipMalloc", __FILE__, __LINE__);
-    g_sizes[*dptr] = bytes;
+    ps.sizes[*dptr] = bytes;
+    ps.live_bytes += bytes;
+    if (ps.live_bytes > ps.live_peak) ps.live_peak = ps.live_bytes;
     return EZKL_OK;
 }
 int ezkl_hip_free(void* dptr) {
     if (!dptr) return EZKL_OK;
     EZ_CTX(c);
-    auto it = g_sizes.find(dptr);
-    if (it == g_sizes.end()) { EZ_HIP(hipFree(dptr)); return EZKL_OK; }
-    if (g_pool_bytes + it->second <= pool_cap(c)) {
-        g_pool[it->second].push_back(dptr);
-        g_pool_bytes += it->second;
+    PoolState& ps = pool_state(c);
+    auto it = ps.sizes.find(dptr);
+    if (it == ps.sizes.end()) { EZ_HIP(hipFree(dptr)); return EZKL_OK; }
+    const size_t bytes = it->second;
+    ps.live_bytes -= std::min(ps.live_bytes, bytes);
+    (void)pool_floor(c);
+    if (ps.live_bytes + ps.pool_bytes + bytes <= ps.bound()) {
+        ps.pool[bytes].push_back(dptr);
+        ps.pool_bytes += bytes;
         return EZKL_OK;
     }
-    g_sizes.erase(it);
+    ps.sizes.erase(it);
     EZ_HIP(hipFree(dptr));
     return EZKL_OK;
 }
-#undef g_pool
-#undef g_sizes
-#undef g_pool_bytes
+// the column pool of the calling context: out[0] = bytes handed out now, out[1] = their high-water mark since the context was made
+// (or since the last ezkl_hip_pool_trim), out[2] = bytes parked, out[3] = the bound on live + parked; with hipMemGetInfo (ezkl_hip_mem_info) this is the
+// HBM high-water report of a proof or a test run
+int ezkl_hip_pool_stats(size_t out[4]) {
+    if (!out) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    PoolState& ps = pool_state(c);
+    (void)pool_floor(c);
+    out[0] = ps.live_bytes; out[1] = ps.live_peak; out[2] = ps.pool_bytes; out[3] = ps.bound();
+    return EZKL_OK;
+}
+// hipFree every parked block of the calling context and forget the high-water mark (a long-lived process that has finished with its
+// large circuit; between the size classes of a test run)
+int ezkl_hip_pool_trim(void) {
+    EZ_CTX(c);
+    PoolState& ps = pool_state(c);
+    EZ_HIP(hipDeviceSynchronize());
+    pool_drop_parked(ps);
+    ps.live_peak = ps.live_bytes;
+    return EZKL_OK;
+}
 int ezkl_hip_host_malloc(void** p, size_t bytes) {
     if (!p) return EZKL_ERR_INVALID;
     EZ_CTX(c);

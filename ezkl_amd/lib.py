@@ -7,7 +7,7 @@ _LIB = None
 
 # every symbol include/ezkl_hip.h declares (tests assert the .so exports all of them)
 SYMBOLS = [
-    "ezkl_hip_init", "ezkl_hip_contexts_configure", "ezkl_hip_context_count", "ezkl_hip_set_context", "ezkl_hip_context_device", "ezkl_hip_memcpy_peer", "ezkl_hip_warmup", "ezkl_hip_device_count", "ezkl_hip_mem_info", "ezkl_hip_synchronize", "ezkl_hip_stream_create", "ezkl_hip_stream_synchronize", "ezkl_hip_stream_destroy", "ezkl_hip_context_stream", "ezkl_hip_strerror",
+    "ezkl_hip_init", "ezkl_hip_contexts_configure", "ezkl_hip_context_count", "ezkl_hip_set_context", "ezkl_hip_context_device", "ezkl_hip_memcpy_peer", "ezkl_hip_warmup", "ezkl_hip_device_count", "ezkl_hip_mem_info", "ezkl_hip_pool_stats", "ezkl_hip_pool_trim", "ezkl_hip_synchronize", "ezkl_hip_stream_create", "ezkl_hip_stream_synchronize", "ezkl_hip_stream_destroy", "ezkl_hip_context_stream", "ezkl_hip_strerror",
     "ezkl_hip_last_hip_error", "ezkl_hip_version", "ezkl_hip_enabled", "ezkl_hip_malloc", "ezkl_hip_free", "ezkl_hip_memcpy_h2d",
     "ezkl_hip_memcpy_d2h", "ezkl_hip_bases_upload", "ezkl_hip_bases_prepare", "ezkl_hip_bases_free", "ezkl_hip_bases_len", "ezkl_hip_bases_generate",
     "ezkl_hip_bases_download", "ezkl_hip_bases_from_scalars", "ezkl_hip_msm_g1",

@@ -594,6 +594,71 @@ def serialize_cs(cs):
     return bytes(out)
 
 
+def deserialize_cs(blob):
+    """the inverse of serialize_cs: EZCS blob (version 2) -> ConstraintSystem with the shared sub-expressions shared again, so that
+    serialize_cs(deserialize_cs(b)) == b.  A laid-out circuit can then be stored as plain data (tools/bench_circuits.py: the blob +
+    JSON, nothing a reader has to unpickle)."""
+    import struct
+    off = [0]
+
+    def u32(m=1):
+        v = struct.unpack_from("<%dI" % m, blob, off[0]); off[0] += 4 * m
+        return v if m != 1 else v[0]
+
+    def s32(v): return v - (1 << 32) if v >= (1 << 31) else v
+
+    magic, version, k, n_advice, n_fixed, n_instance, n_challenges = u32(7)
+    if magic != 0x53435a45 or version != 2:
+        raise ValueError("not a version-2 EZCS blob")
+    advice_phase = list(u32(n_advice)) if n_advice != 1 else [u32()]
+    blinding, minimum_degree, nu = u32(3)
+    unblinded = [u32() for _ in range(nu)]
+    n_selectors = u32()
+    nn = u32()
+    names = {v: a for a, v in _OPS.items()}
+    nodes = []
+    for _ in range(nn):
+        op, a, b, _pad = u32(4)
+        cst = blob[off[0]:off[0] + 32]; off[0] += 32
+        name = names[op]
+        if name == "const": e = Expr(("const", int.from_bytes(cst, "little") * RINV % R))
+        elif name in ("adv", "fix", "inst"): e = Expr((name, a, s32(b)))
+        elif name == "chal": e = Expr(("chal", a))
+        elif name == "neg": e = Expr(("neg", nodes[a]))
+        else: e = Expr((name, nodes[a], nodes[b]))
+        nodes.append(e)
+
+    def id_list():
+        m = u32()
+        return [nodes[u32()] for _ in range(m)]
+
+    gates = id_list()
+    kinds = {v: a for a, v in _KINDS.items()}
+    perm = []
+    for _ in range(u32()):
+        kind, col = u32(2)
+        perm.append((kinds[kind], col))
+    lookups = []
+    for _ in range(u32()):
+        ni = u32()
+        ins = [id_list() for _ in range(ni)]
+        lookups.append((ins, id_list()))
+    query_order = None
+    if u32():
+        query_order = []
+        for _ in range(3):
+            m = u32()
+            q = []
+            for _ in range(m):
+                c, r = u32(2)
+                q.append((c, s32(r)))
+            query_order.append(q)
+    if off[0] != len(blob):
+        raise ValueError("trailing bytes in the EZCS blob")
+    return ConstraintSystem(k, n_advice, n_fixed, gates, perm, lookups, n_instance=n_instance, advice_phase=advice_phase, n_challenges=n_challenges,
+                            query_order=query_order, blinding=blinding, minimum_degree=minimum_degree or None, unblinded=unblinded, n_selectors=n_selectors)
+
+
 def vk_digest(vk):
     """keccak256(keccak256(constraint-system blob) || fixed commitments || permutation commitments) mod r: the whole circuit
     description (gates, lookups, permutation, query order) is bound into the transcript, the role of halo2's

@@ -57,6 +57,14 @@ int ezkl_hip_memcpy_peer(void* dst_dev, int dst_context, const void* src_dev, in
 int ezkl_hip_warmup(void);
 int ezkl_hip_device_count(void);
 int ezkl_hip_mem_info(size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo of the calling context's device */
+/* The column pool of the calling context (ezkl_hip_malloc / ezkl_hip_free recycle blocks by exact size; icicle's DeviceVec allocations
+ * behind the reference's wrappers play this role).  live + parked bytes are held to max(25 % of the device / contexts sharing it,
+ * 1.5 x the high-water mark of the live bytes); least recently used size classes are released first; an out-of-memory hipMalloc
+ * releases what every idle context of the device has parked and retries once.  EZKL_HIP_POOL_CAP_GB overrides the 25 %.
+ * ezkl_hip_pool_stats: out[0] = bytes handed out now, out[1] = their high-water mark, out[2] = bytes parked, out[3] = the bound.
+ * ezkl_hip_pool_trim: release every parked block of the calling context and forget the high-water mark. */
+int ezkl_hip_pool_stats(size_t out[4]);
+int ezkl_hip_pool_trim(void);
 int ezkl_hip_synchronize(void);
 /* caller streams for the `stream` arguments below (a hipStream_t created by the caller works just as well; these exist so
  * that a client of this header alone can use the stream-ordered mode): work queued on one is asynchronous */

@@ -18,6 +18,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """end of a GPU run: HBM in use (hipMemGetInfo), the column pool's high-water mark and the host's peak RSS go into the tracked log
+    (a suite that can exhaust a box must show that it does not)"""
+    import resource
+    lines = ["host peak RSS %.2f GiB (children %.2f GiB)" % (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20,
+                                                           resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 2**20)]
+    try:
+        from ezkl_amd import lib as _lib
+        if _lib._LIB is not None and _lib._LIB.ezkl_hip_device_count() > 0:
+            from ezkl_amd import backend as B
+            free_b, total_b = B.mem_info()
+            ps = B.pool_stats()
+            lines.append("HBM in use at the end %.2f GiB of %.0f; column pool: live %.2f GiB, live high-water %.2f GiB, parked %.2f GiB, bound %.2f GiB"
+                         % ((total_b - free_b) / 2**30, total_b / 2**30, ps["live"] / 2**30, ps["live_peak"] / 2**30, ps["parked"] / 2**30, ps["bound"] / 2**30))
+    except Exception as e:                                   # never turn a report into a failure
+        lines.append("memory report unavailable: %r" % (e,))
+    terminalreporter.write_sep("-", "memory")
+    for l in lines:
+        terminalreporter.write_line(l)
+
+
 def fe_from_int(x, mod=R):
     """canonical integer -> Montgomery 4 x u64"""
     return np.frombuffer((x * MONT % mod).to_bytes(32, "little"), np.uint64).copy()
@@ -35,15 +56,16 @@ def rand_fr(rng, n):
 
 
 def witness_like(rng, n):
-    """SURVEY.md §8(d) distribution W: 70% small signed ints via integer_rep_to_felt, 20% zero, 10% uniform"""
+    """SURVEY.md §8(d) distribution W: 70% small signed ints via integer_rep_to_felt, 20% zero, 10% uniform
+    (vectorised: |x| < 2^15, so x*R mod r is a table lookup of 2^16 Montgomery residues, not a Python loop)"""
     out = rand_fr(rng, n)
     kind = rng.random(n)
     small = rng.integers(-(1 << 15) + 1, 1 << 15, size=n)
-    for i in range(n):
-        if kind[i] < 0.7:
-            out[i] = fe_from_int(int(small[i]) % R)
-        elif kind[i] < 0.9:
-            out[i] = 0
+    lo = -(1 << 15) + 1
+    table = np.frombuffer(b"".join(((v % R) * MONT % R).to_bytes(32, "little") for v in range(lo, 1 << 15)), np.uint64).reshape(-1, 4)
+    is_small = kind < 0.7
+    out[is_small] = table[small[is_small] - lo]
+    out[(kind >= 0.7) & (kind < 0.9)] = 0
     return out
 
 

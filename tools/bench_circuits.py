@@ -88,13 +88,17 @@ def _unpack_cols(cols, gpu, pinned=False):
 
 
 def _cache_load(path, gpu):
-    import pickle
+    """plain data only: the constraint system as its EZCS blob (plonk.deserialize_cs), everything else as JSON -- the cache directory
+    travels to the GPU box, so nothing in it is unpickled"""
+    import json
     with np.load(path, allow_pickle=False) as z:
-        meta = pickle.loads(z["meta"].tobytes())
+        meta = json.loads(z["meta"].tobytes().decode())
+        cs = P.deserialize_cs(z["cs"].tobytes())
         fixed = _unpack_cols([z["f%d" % i] for i in range(meta["n_fixed"])], gpu)
         advice = _unpack_cols([z["a%d" % i] for i in range(meta["n_advice"])], gpu)
         copies = CopyPairs(z["copies"])
-    return dict(cs=meta["cs"], fixed=fixed, copies=copies, advice=advice, instances=meta["instances"], info=dict(meta["info"], layout="read from " + os.path.basename(path)))
+    instances = [[int(v) for v in col] for col in meta["instances"]]
+    return dict(cs=cs, fixed=fixed, copies=copies, advice=advice, instances=instances, info=dict(meta["info"], layout="read from " + os.path.basename(path)))
 
 
 class CopyPairs:
@@ -113,9 +117,10 @@ class CopyPairs:
 
 
 def _cache_store(path, cs, fixed_raw, copies, adv_raw, instances, info):
-    import pickle
-    arrs = {"meta": np.frombuffer(pickle.dumps(dict(cs=cs, instances=instances, info=info, n_fixed=len(fixed_raw), n_advice=len(adv_raw))), np.uint8),
-            "copies": np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4)}
+    import json
+    meta = dict(instances=[[str(int(v)) for v in col] for col in instances], info=info, n_fixed=len(fixed_raw), n_advice=len(adv_raw))
+    arrs = {"meta": np.frombuffer(json.dumps(meta).encode(), np.uint8), "cs": np.frombuffer(P.serialize_cs(cs), np.uint8),
+            "copies": copies.array if isinstance(copies, CopyPairs) else np.array([[a[0], a[1], b[0], b[1]] for a, b in copies], np.uint32).reshape(-1, 4)}
     for i, c in enumerate(fixed_raw):
         arrs["f%d" % i] = _pack_col(c)
     for i, c in enumerate(adv_raw):
@@ -139,8 +144,11 @@ def build(kind, k, gpu=None, seed=1, **kw):
         try:
             fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
         except FileExistsError:                      # another process (rank) is laying the circuit out: wait for its file
-            if time.time() - os.path.getmtime(lock) > 900:
-                os.unlink(lock)
+            try:
+                if time.time() - os.path.getmtime(lock) > 900:
+                    os.unlink(lock)
+            except FileNotFoundError:                # the other process finished in between
+                pass
             time.sleep(0.5)
             continue
         try:

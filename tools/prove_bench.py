@@ -217,7 +217,10 @@ if not SYNTH:
     n_sweep_cols = (cs.n_advice + len({c for c, _ in cs.fixed_queries}) + cs.n_instance + (4 if (cs.perm or cs.lookups) else 0) + cs.n_chunks + len(cs.perm)
                     + 2 * len(cs.lookups))
     free_b, total_b = B.mem_info()
-    out["hbm_in_use_gib_after_prove"] = round((total_b - free_b) / 2**30, 2)          # keys, SRS + window tables, and the column pool's high-water mark
+    out["hbm_in_use_gib_after_prove"] = round((total_b - free_b) / 2**30, 2)          # keys, SRS + window tables, and what the column pool keeps parked
+    out["hbm_pool_high_water_gib"] = round(B.pool_stats()["live_peak"] / 2**30, 2)     # most column bytes alive at once during these proofs
+    import resource
+    out["host_peak_rss_gib"] = round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20, 2)
     out["sweep_kernel"] = {"kernel": "evalh_jit", "avg_launch_ms": round(B.last_kernel_ms("eval_h"), 4), "rows_per_launch": n, "launches_per_proof": 1 << (cs.ext_k - k),
                            "columns": n_sweep_cols, "algorithmic_bytes_per_launch": 32 * (n_sweep_cols + 1) * n}
     try:
