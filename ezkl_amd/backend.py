@@ -857,10 +857,19 @@ class _CommSeg(C.Structure):
 
 
 def comm_alltoallv_dev(sends, recvs):
-    """sends / recvs: lists of (peer, device pointer, bytes); the k-th segment sent to p is the k-th p receives from this rank"""
+    """sends / recvs: lists of (peer, device pointer, bytes); per peer the segments are ONE byte stream in list order (totals must agree)"""
     sa = (_CommSeg * max(1, len(sends)))(*[_CommSeg(p, ptr, n) for p, ptr, n in sends])
     ra = (_CommSeg * max(1, len(recvs)))(*[_CommSeg(p, ptr, n) for p, ptr, n in recvs])
     _l.check(_l.load().ezkl_hip_comm_alltoallv_dev(sa, C.c_size_t(len(sends)), ra, C.c_size_t(len(recvs))), "ezkl_hip_comm_alltoallv_dev")
+
+
+def comm_stats(reset=False):
+    """what this process's exchanges have moved (ezkl_hip_comm_stats): calls, bytes to / from other ranks, host seconds inside the calls,
+    ncclSend / ncclRecv operations issued, rounds"""
+    out = (C.c_uint64 * 8)()
+    _l.check(_l.load().ezkl_hip_comm_stats(out, C.c_int(1 if reset else 0)), "ezkl_hip_comm_stats")
+    return dict(exchanges=int(out[0]), bytes_sent=int(out[1]), bytes_received=int(out[2]), seconds=out[3] / 1e6, nccl_sends=int(out[4]),
+                nccl_recvs=int(out[5]), rounds=int(out[6]))
 
 
 def comm_allgather_host(arr):

@@ -12,6 +12,9 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <string>
+#include <vector>
+#include <algorithm>
+#include <chrono>
 #include <rccl/rccl.h>
 
 namespace ezkl {
@@ -35,6 +38,14 @@ struct Comm {
     hipStream_t st = nullptr;
     void* stage = nullptr;          // device staging for the partial points of one commit batch
     size_t stage_bytes = 0;
+    // the packed all-to-all: one slab per peer and direction, the copy descriptors of one round, and what the exchanges have moved
+    char* slab_send = nullptr;
+    char* slab_recv = nullptr;
+    size_t slab_bytes = 0;          // per peer and direction
+    void* desc_dev = nullptr;
+    void* desc_host = nullptr;      // pinned
+    size_t desc_cap = 0;            // descriptors
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 static Comm g_comm;
 
@@ -90,6 +101,80 @@ static int rccl_fail(ncclResult_t r, const char* what) {
         if (_r != ncclSuccess) return rccl_fail(_r, #call);             \
     } while (0)
 
+
+// ---- the packed all-to-all ------------------------------------------------------------------------------------------------------------
+// xGMI wants a few large messages: the column-sharded prover's exchange is hundreds (k = 20) to thousands (k = 22) of row slabs per peer,
+// and one ncclSend / ncclRecv each would leave their scheduling to RCCL's point-to-point engine, which has never been shown to like
+// that (missing #1).  Wire format: per peer ONE contiguous byte stream = the peer's segments in list order, cut into rounds
+// of at most `slab` bytes; a gather kernel packs every peer's share of the round into its slab, ONE ncclSend + ONE ncclRecv per peer
+// move the slabs (7 + 7 per rank at world 8), a scatter kernel unpacks.  The segment lists stay the description; both sides derive the
+// same round boundaries from the same totals.
+struct CopyDesc {
+    const char* src;
+    char* dst;
+    uint64_t bytes;
+    uint64_t start;       // offset of this piece in the dense byte space of the launch (prefix sum of the pieces before it)
+};
+static constexpr uint32_t PACK_CHUNK = 32768;       // bytes per workgroup
+// every piece is a multiple of 16 bytes at 16-byte aligned addresses (field elements: 32 B); workgroup b copies dense bytes
+// [b * PACK_CHUNK, (b + 1) * PACK_CHUNK): it finds its first piece by bisection and walks on while the chunk spans several
+__global__ __launch_bounds__(256) void comm_pack_kernel(const CopyDesc* desc, uint32_t n_desc, uint64_t total) {
+    const uint64_t lo = (uint64_t)blockIdx.x * PACK_CHUNK, hi = lo + PACK_CHUNK < total ? lo + PACK_CHUNK : total;
+    uint32_t a = 0, b = n_desc;                       // last piece with start <= lo
+    while (b - a > 1) {
+        const uint32_t m = (a + b) >> 1;
+        if (desc[m].start <= lo) a = m; else b = m;
+    }
+    for (uint32_t d = a; d < n_desc; d++) {
+        const CopyDesc ds = desc[d];
+        if (ds.start >= hi) break;
+        const uint64_t from = lo > ds.start ? lo - ds.start : 0, to = (hi - ds.start) < ds.bytes ? (hi - ds.start) : ds.bytes;
+        const uint4* src = (const uint4*)(ds.src + from);
+        uint4* dst = (uint4*)(ds.dst + from);
+        const uint32_t n16 = (uint32_t)((to - from) >> 4);
+        for (uint32_t i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    }
+}
+// a byte stream over a list of segments to / from one peer
+struct SegCursor {
+    const ezkl_comm_seg_t* segs;
+    size_t n, idx = 0, off = 0;
+    int peer;
+    SegCursor(const ezkl_comm_seg_t* s, size_t n_, int p) : segs(s), n(n_), peer(p) { skip(); }
+    void skip() {
+        while (idx < n && (segs[idx].peer != peer || off >= segs[idx].bytes)) { idx++; off = 0; }
+    }
+    bool done() const { return idx >= n; }
+    // the next contiguous piece, at most `want` bytes
+    size_t take(size_t want, char** ptr) {
+        const size_t m = std::min(want, segs[idx].bytes - off);
+        *ptr = (char*)segs[idx].ptr + off;
+        off += m;
+        skip();
+        return m;
+    }
+};
+static int comm_descs_reserve(size_t count) {
+    if (count <= g_comm.desc_cap) return EZKL_OK;
+    if (g_comm.desc_dev) { EZ_HIP(hipStreamSynchronize(g_comm.st)); EZ_HIP(hipFree(g_comm.desc_dev)); g_comm.desc_dev = nullptr; }
+    if (g_comm.desc_host) { EZ_HIP(hipHostFree(g_comm.desc_host)); g_comm.desc_host = nullptr; }
+    const size_t cap = count + count / 2 + 64;
+    EZ_HIP(hipMalloc(&g_comm.desc_dev, 2 * cap * sizeof(CopyDesc)));            // [0, cap): pack, [cap, 2 cap): unpack of the same round
+    EZ_HIP(hipHostMalloc(&g_comm.desc_host, 2 * cap * sizeof(CopyDesc), hipHostMallocDefault));
+    g_comm.desc_cap = cap;
+    return EZKL_OK;
+}
+static int comm_launch_copies(const std::vector<CopyDesc>& d, uint64_t total, size_t slot) {
+    if (d.empty() || !total) return EZKL_OK;
+    CopyDesc* h = (CopyDesc*)g_comm.desc_host + slot * g_comm.desc_cap;
+    CopyDesc* dv = (CopyDesc*)g_comm.desc_dev + slot * g_comm.desc_cap;
+    memcpy(h, d.data(), d.size() * sizeof(CopyDesc));
+    EZ_HIP(hipMemcpyAsync(dv, h, d.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, g_comm.st));
+    hipLaunchKernelGGL(comm_pack_kernel, dim3((unsigned)((total + PACK_CHUNK - 1) / PACK_CHUNK)), dim3(256), 0, g_comm.st, dv, (uint32_t)d.size(), total);
+    EZ_HIP(hipGetLastError());
+    return EZKL_OK;
+}
+
 }  // namespace ezkl
 
 using namespace ezkl;
@@ -135,6 +220,10 @@ int ezkl_hip_comm_destroy(void) {
     EZ_HIP(hipStreamSynchronize(g_comm.st));
     EZ_RCCL(g_rccl.CommDestroy(g_comm.comm));
     if (g_comm.stage) (void)hipFree(g_comm.stage);
+    if (g_comm.slab_send) (void)hipFree(g_comm.slab_send);
+    if (g_comm.slab_recv) (void)hipFree(g_comm.slab_recv);
+    if (g_comm.desc_dev) (void)hipFree(g_comm.desc_dev);
+    if (g_comm.desc_host) (void)hipHostFree(g_comm.desc_host);
     (void)hipStreamDestroy(g_comm.st);
     g_comm = Comm();
     return EZKL_OK;
@@ -220,22 +309,11 @@ int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes) {
     return EZKL_OK;
 }
 
-// all-to-all with any number of segments per peer (see include/ezkl_hip.h): matching is by order per (sender, receiver) pair, which is
-// how ncclSend / ncclRecv inside one group match; the segments to self are matched the same way and copied device-to-device.
-int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
-    if ((n_sends && !sends) || (n_recvs && !recvs)) return EZKL_ERR_INVALID;
-    EZ_CTX(c);
-    if (!g_comm.comm) return EZKL_ERR_INVALID;
+// all-to-all with any number of segments per peer (see include/ezkl_hip.h): the k-th BYTE this rank sends to peer p is the k-th byte p
+// receives from this rank -- per peer the segments form one stream, and only the totals have to agree.  Packed wire format (above);
+// EZKL_COMM_UNPACKED=1 keeps round 3's one ncclSend / ncclRecv per segment (then the segment SIZES must agree pairwise too).
+static int alltoallv_unpacked(Ctx* c, const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs, int skip) {
     const int me = g_comm.rank;
-    for (size_t i = 0; i < n_sends; i++)
-        if (sends[i].peer < 0 || sends[i].peer >= g_comm.world || (!sends[i].ptr && sends[i].bytes)) return EZKL_ERR_INVALID;
-    for (size_t i = 0; i < n_recvs; i++)
-        if (recvs[i].peer < 0 || recvs[i].peer >= g_comm.world || (!recvs[i].ptr && recvs[i].bytes)) return EZKL_ERR_INVALID;
-    EZ_HIP(hipStreamSynchronize(c->stream));          // what the library stream produced is what gets sent
-    // EZKL_COMM_SELF_VIA_RCCL=1 (testing): the segments to self take the grouped ncclSend / ncclRecv path too, so that a one-GPU box
-    // exercises RCCL's matching of MANY sends and receives per peer inside one group (tests/test_gpu_comm.py)
-    const char* via = getenv("EZKL_COMM_SELF_VIA_RCCL");
-    const int skip = via && *via == '1' ? -1 : me;    // the peer whose segments are plain copies
     if (skip == me) {
         size_t j = 0;                                 // self segments, in order
         for (size_t i = 0; i < n_sends; i++) {
@@ -248,11 +326,131 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
     }
     EZ_RCCL(g_rccl.GroupStart());
     for (size_t i = 0; i < n_sends; i++)
-        if (sends[i].peer != skip && sends[i].bytes) EZ_RCCL(g_rccl.Send(sends[i].ptr, sends[i].bytes, ncclUint8, sends[i].peer, g_comm.comm, g_comm.st));
+        if (sends[i].peer != skip && sends[i].bytes) { EZ_RCCL(g_rccl.Send(sends[i].ptr, sends[i].bytes, ncclUint8, sends[i].peer, g_comm.comm, g_comm.st)); g_comm.stats[4]++; }
     for (size_t i = 0; i < n_recvs; i++)
-        if (recvs[i].peer != skip && recvs[i].bytes) EZ_RCCL(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, ncclUint8, recvs[i].peer, g_comm.comm, g_comm.st));
+        if (recvs[i].peer != skip && recvs[i].bytes) { EZ_RCCL(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, ncclUint8, recvs[i].peer, g_comm.comm, g_comm.st)); g_comm.stats[5]++; }
     EZ_RCCL(g_rccl.GroupEnd());
     EZ_HIP(hipStreamSynchronize(g_comm.st));
+    return EZKL_OK;
+}
+int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
+    if ((n_sends && !sends) || (n_recvs && !recvs)) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    if (!g_comm.comm) return EZKL_ERR_INVALID;
+    const int me = g_comm.rank, world = g_comm.world;
+    bool aligned = true;
+    std::vector<uint64_t> tot_s(world, 0), tot_r(world, 0);
+    for (size_t i = 0; i < n_sends; i++) {
+        if (sends[i].peer < 0 || sends[i].peer >= world || (!sends[i].ptr && sends[i].bytes)) return EZKL_ERR_INVALID;
+        aligned &= !((uintptr_t)sends[i].ptr & 15) && !(sends[i].bytes & 15);
+        tot_s[sends[i].peer] += sends[i].bytes;
+    }
+    for (size_t i = 0; i < n_recvs; i++) {
+        if (recvs[i].peer < 0 || recvs[i].peer >= world || (!recvs[i].ptr && recvs[i].bytes)) return EZKL_ERR_INVALID;
+        aligned &= !((uintptr_t)recvs[i].ptr & 15) && !(recvs[i].bytes & 15);
+        tot_r[recvs[i].peer] += recvs[i].bytes;
+    }
+    if (tot_s[me] != tot_r[me]) return EZKL_ERR_INVALID;
+    const auto t_begin = std::chrono::steady_clock::now();
+    EZ_HIP(hipStreamSynchronize(c->stream));          // what the library stream produced is what gets sent
+    // EZKL_COMM_SELF_VIA_RCCL=1 (testing): the bytes to self take the slab + ncclSend / ncclRecv path too, so that a one-GPU box exercises
+    // the wire format, the rounds and RCCL's matching (tests/test_gpu_comm.py)
+    const char* via = getenv("EZKL_COMM_SELF_VIA_RCCL");
+    const int skip = via && *via == '1' ? -1 : me;    // the peer whose bytes are plain copies
+    const char* unp = getenv("EZKL_COMM_UNPACKED");
+    int rc = EZKL_OK;
+    if ((unp && *unp == '1') || !aligned) {
+        rc = alltoallv_unpacked(c, sends, n_sends, recvs, n_recvs, skip);
+    } else {
+        size_t slab = (size_t)128 << 20;              // per peer and direction; every rank must use the same value
+        if (const char* e = getenv("EZKL_COMM_SLAB_MB")) { const size_t v = (size_t)strtoull(e, nullptr, 10); if (v) slab = v << 20; }
+        slab &= ~(size_t)15;
+        uint64_t most = 0;
+        for (int p = 0; p < world; p++) if (p != skip) most = std::max(most, std::max(tot_s[p], tot_r[p]));
+        const size_t need = (size_t)std::min<uint64_t>(most, slab);
+        if (need > g_comm.slab_bytes) {               // grown on demand, kept for the next proof
+            if (g_comm.slab_send) { EZ_HIP(hipStreamSynchronize(g_comm.st)); EZ_HIP(hipFree(g_comm.slab_send)); EZ_HIP(hipFree(g_comm.slab_recv)); g_comm.slab_send = g_comm.slab_recv = nullptr; g_comm.slab_bytes = 0; }
+            EZ_HIP(hipMalloc((void**)&g_comm.slab_send, need * (size_t)world));
+            EZ_HIP(hipMalloc((void**)&g_comm.slab_recv, need * (size_t)world));
+            g_comm.slab_bytes = need;
+        }
+        rc = comm_descs_reserve(n_sends + n_recvs + 2 * (size_t)world);
+        if (rc) return rc;
+        std::vector<SegCursor> cs, cr;
+        for (int p = 0; p < world; p++) { cs.emplace_back(sends, n_sends, p); cr.emplace_back(recvs, n_recvs, p); }
+        std::vector<uint64_t> left_s = tot_s, left_r = tot_r;
+        std::vector<CopyDesc> pack, unpack;
+        bool first_round = true;
+        for (;;) {
+            bool any = false;
+            for (int p = 0; p < world; p++) any |= left_s[p] || left_r[p];
+            if (!any) break;
+            pack.clear(); unpack.clear();
+            uint64_t pack_total = 0, unpack_total = 0;
+            std::vector<size_t> rs(world, 0), rr(world, 0);       // bytes of this round per peer
+            for (int p = 0; p < world; p++) {
+                if (p == skip) {                       // self: straight from the send segments into the receive segments, all of it in the first round
+                    while (left_s[p]) {
+                        char *sp, *dp;
+                        const size_t want = std::min(cs[p].segs[cs[p].idx].bytes - cs[p].off, cr[p].segs[cr[p].idx].bytes - cr[p].off);
+                        const size_t m = cs[p].take(want, &sp);
+                        cr[p].take(m, &dp);
+                        pack.push_back({sp, dp, m, pack_total});
+                        pack_total += m; left_s[p] -= m; left_r[p] -= m;
+                    }
+                    continue;
+                }
+                rs[p] = (size_t)std::min<uint64_t>(left_s[p], g_comm.slab_bytes);
+                rr[p] = (size_t)std::min<uint64_t>(left_r[p], g_comm.slab_bytes);
+                for (size_t done = 0; done < rs[p];) {
+                    char* sp;
+                    const size_t m = cs[p].take(rs[p] - done, &sp);
+                    pack.push_back({sp, g_comm.slab_send + (size_t)p * g_comm.slab_bytes + done, m, pack_total});
+                    pack_total += m; done += m;
+                }
+                for (size_t done = 0; done < rr[p];) {
+                    char* dp;
+                    const size_t m = cr[p].take(rr[p] - done, &dp);
+                    unpack.push_back({g_comm.slab_recv + (size_t)p * g_comm.slab_bytes + done, dp, m, unpack_total});
+                    unpack_total += m; done += m;
+                }
+                left_s[p] -= rs[p]; left_r[p] -= rr[p];
+            }
+            if (pack.size() > g_comm.desc_cap || unpack.size() > g_comm.desc_cap) {       // segments cut by round boundaries: at most one more per peer and round
+                EZ_HIP(hipStreamSynchronize(g_comm.st));
+                rc = comm_descs_reserve(std::max(pack.size(), unpack.size()));
+                if (rc) return rc;
+            }
+            if (!first_round) EZ_HIP(hipStreamSynchronize(g_comm.st));     // the pinned descriptor block of the last round has been read
+            first_round = false;
+            rc = comm_launch_copies(pack, pack_total, 0);
+            if (rc) return rc;
+            EZ_RCCL(g_rccl.GroupStart());
+            for (int p = 0; p < world; p++) {
+                if (p == skip) continue;
+                if (rs[p]) { EZ_RCCL(g_rccl.Send(g_comm.slab_send + (size_t)p * g_comm.slab_bytes, rs[p], ncclUint8, p, g_comm.comm, g_comm.st)); g_comm.stats[4]++; }
+                if (rr[p]) { EZ_RCCL(g_rccl.Recv(g_comm.slab_recv + (size_t)p * g_comm.slab_bytes, rr[p], ncclUint8, p, g_comm.comm, g_comm.st)); g_comm.stats[5]++; }
+            }
+            EZ_RCCL(g_rccl.GroupEnd());
+            rc = comm_launch_copies(unpack, unpack_total, 1);
+            if (rc) return rc;
+            g_comm.stats[6]++;
+        }
+        EZ_HIP(hipStreamSynchronize(g_comm.st));
+    }
+    if (rc) return rc;
+    g_comm.stats[0]++;
+    for (int p = 0; p < world; p++) if (p != me) { g_comm.stats[1] += tot_s[p]; g_comm.stats[2] += tot_r[p]; }
+    g_comm.stats[3] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count();
+    return EZKL_OK;
+}
+
+// what the exchanges of this process have moved: out[0] = calls, out[1] / out[2] = bytes sent to / received from OTHER ranks, out[3] =
+// microseconds of host wall time inside the calls, out[4] / out[5] = ncclSend / ncclRecv operations issued, out[6] = rounds, out[7] = 0
+int ezkl_hip_comm_stats(uint64_t out[8], int reset) {
+    if (!out) return EZKL_ERR_INVALID;
+    for (int i = 0; i < 8; i++) out[i] = g_comm.stats[i];
+    if (reset) for (auto& x : g_comm.stats) x = 0;
     return EZKL_OK;
 }
 

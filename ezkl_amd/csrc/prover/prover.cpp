@@ -887,10 +887,21 @@ struct Backend {
               "ezkl_hip_lookup_multiplicity_acc_dev");
         return out;
     }
+    // Owner mode: only the owner of a lookup argument sees its counter, and a rank that threw alone would leave the others waiting in the
+    // next collective for ever (the most common ezkl prover failure -- a witness value outside its table -- hung the whole
+    // job).  The failure is made COLLECTIVE: every rank contributes its count to one small all_gather and every rank throws the same error.
     void lookup_check(const Col& missing) const {
         const Fe v = get_row(missing, 0);
+        uint64_t bad = v.v[0];
+        if (topo.owners) {
+            std::vector<Fe> all(topo.world, Fe::zero());
+            all[topo.rank].v[0] = bad;
+            allgather_fe(all, 1);
+            bad = 0;
+            for (auto& e : all) bad += e.v[0];
+        }
         // the reference's mv-lookup prover fails here too (a witness with an input outside the table has no valid proof)
-        if (v.v[0] != 0) throw Error(EZKL_ERR_INVALID, "lookup input not in table (" + std::to_string((uint32_t)v.v[0]) + " rows)");
+        if (bad != 0) throw Error(EZKL_ERR_INVALID, "lookup input not in table (" + std::to_string((uint32_t)bad) + " rows)");
     }
     // q(X) = p(X) / (X - z) in place (halo2's kate_division)
     void kate_div(const Col& h, const Fe& z, size_t m) const {

@@ -211,6 +211,173 @@ __global__ __launch_bounds__(256) void ub_modmul29_kernel(uint32_t* io, int iter
     io[t * 8] = x;
 }
 
+// ---- is there a faster field product in the FP64 pipe? ------------------------------------------------------------
+// (a) issue probes: 8 independent chains of v_mad_u64_u32 / v_fma_f64 / 4 + 4 of each interleaved (co-issue would show as MORE lane-ops per
+//     second than either alone) / v_lshl_add_u64 (gfx940+: one-instruction 64-bit integer add, what a DFMA product accumulates with)
+// (b) a complete 5 x 52-bit Montgomery product on the FP64 pipe (Emmart / Zheng / Weems: hi = fma_rz(a, b, 2^104), lo = fma_rz(a, b,
+//     (2^104 + 2^52) - hi); the mantissas ARE the 52-bit halves), product-scanning form with 64-bit integer column sums, checked against a
+//     portable integer restatement of the same product, timed like ub_modmul29_kernel.
+template <int MODE>
+__global__ __launch_bounds__(256) void ub_mix_kernel(uint64_t* io, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = io[i];
+    uint64_t a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+    double d0 = (double)(x & 1023), d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7;
+    const double m = 1.0000001, q = 0.9999999;
+    uint32_t mi = (uint32_t)x | 1u, qi = (uint32_t)(x >> 32) | 3u;
+    for (int k = 0; k < iters; k++) {
+        if (MODE == 0) {          // 8 x v_mad_u64_u32
+            a0 = mad_wide(mi, (uint32_t)a0, a0); a1 = mad_wide(qi, (uint32_t)a1, a1); a2 = mad_wide(mi, (uint32_t)a2, a2); a3 = mad_wide(qi, (uint32_t)a3, a3);
+            a4 = mad_wide(mi, (uint32_t)a4, a4); a5 = mad_wide(qi, (uint32_t)a5, a5); a6 = mad_wide(mi, (uint32_t)a6, a6); a7 = mad_wide(qi, (uint32_t)a7, a7);
+        } else if (MODE == 1) {   // 8 x v_fma_f64
+            d0 = __builtin_fma(d0, m, q); d1 = __builtin_fma(d1, q, m); d2 = __builtin_fma(d2, m, q); d3 = __builtin_fma(d3, q, m);
+            d4 = __builtin_fma(d4, m, q); d5 = __builtin_fma(d5, q, m); d6 = __builtin_fma(d6, m, q); d7 = __builtin_fma(d7, q, m);
+        } else if (MODE == 2) {   // 4 + 4 interleaved
+            a0 = mad_wide(mi, (uint32_t)a0, a0); d4 = __builtin_fma(d4, m, q); a1 = mad_wide(qi, (uint32_t)a1, a1); d5 = __builtin_fma(d5, q, m);
+            a2 = mad_wide(mi, (uint32_t)a2, a2); d6 = __builtin_fma(d6, m, q); a3 = mad_wide(qi, (uint32_t)a3, a3); d7 = __builtin_fma(d7, q, m);
+        } else if (MODE == 3) {   // 8 x v_lshl_add_u64 (64-bit add in one instruction)
+            asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n\tv_lshl_add_u64 %1, %1, 0, %2\n\tv_lshl_add_u64 %2, %2, 0, %3\n\tv_lshl_add_u64 %3, %3, 0, %4\n\t"
+                         "v_lshl_add_u64 %4, %4, 0, %5\n\tv_lshl_add_u64 %5, %5, 0, %6\n\tv_lshl_add_u64 %6, %6, 0, %7\n\tv_lshl_add_u64 %7, %7, 0, %0"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else {                  // 8 x v_add_f64
+            asm volatile("v_add_f64 %0, %0, %8\n\tv_add_f64 %1, %1, %9\n\tv_add_f64 %2, %2, %8\n\tv_add_f64 %3, %3, %9\n\t"
+                         "v_add_f64 %4, %4, %8\n\tv_add_f64 %5, %5, %9\n\tv_add_f64 %6, %6, %8\n\tv_add_f64 %7, %7, %9"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(m), "v"(q));
+        }
+    }
+    io[i] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint64_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+}
+
+struct Dfma52 {
+    static constexpr uint64_t M52 = (1ull << 52) - 1;
+    // q = BN254 base modulus in 5 limbs of 52 bits; PINV = -q^-1 mod 2^52 (both derived at compile time from the 32-bit limb table)
+    EZ_HD static constexpr uint64_t limb(int i) {
+        uint64_t v = 0;
+        for (int b = 0; b < 52; b++) {
+            const int bit = 52 * i + b;
+            if (bit < 256 && ((FqP::MOD[bit >> 5] >> (bit & 31)) & 1u)) v |= 1ull << b;
+        }
+        return v;
+    }
+    EZ_HD static constexpr uint64_t pinv() {
+        uint64_t x = 1;
+        for (int i = 0; i < 6; i++) x *= 2 - limb(0) * x;      // Newton: q^-1 mod 2^64
+        return (0 - x) & M52;
+    }
+};
+// one 52 x 52 -> (hi, lo) limb product on the FP64 pipe, MODE.FP_ROUND (double) = toward zero; returns the RAW bit patterns
+// 0x467.. | hi and 0x433.. | lo: callers sum the raw words and remove count x pattern once per column
+__device__ __forceinline__ void dfma_hilo(double a, double b, uint64_t& hi_raw, uint64_t& lo_raw) {
+    const double C1 = 0x1p104, C2 = 0x1p104 + 0x1p52;
+    // (plain fma / subtraction: without fast-math the compiler may not re-associate them, and every operand is a run-time value; inline
+    //  asm here made the compiler pad each statement with s_nop for hazards it could not see)
+    const double h = __builtin_fma(a, b, C1);
+    const double s = C2 - h;
+    const double l = __builtin_fma(a, b, s);
+    hi_raw = (uint64_t)__double_as_longlong(h);
+    lo_raw = (uint64_t)__double_as_longlong(l);
+}
+__device__ __forceinline__ void mont_mul52_dfma_fq(const double (&a)[5], const double (&b)[5], double (&r)[5]) {
+    constexpr uint64_t HI_PAT = 0x4670000000000000ull, LO_PAT = 0x4330000000000000ull, M52 = Dfma52::M52;
+    double m[5];
+    double pd[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) pd[i] = (double)Dfma52::limb(i);
+    const double pinv = (double)Dfma52::pinv();
+    uint64_t carry = 0, nxt = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        uint64_t acc = carry + nxt, hi, lo;
+        nxt = 0;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 4) continue;
+            dfma_hilo(a[i], b[j], hi, lo);
+            acc += lo; nxt += hi; cnt++;
+            if (i < k && i < 5 && k < 5) {}                 // (m_i known only for i < k in the low half)
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 4) continue;
+            if (k < 5 && i == k) continue;                  // m_k p_0 is added below, once m_k exists
+            dfma_hilo(m[i], pd[j], hi, lo);
+            acc += lo; nxt += hi; cnt++;
+        }
+        acc -= (uint64_t)cnt * LO_PAT;
+        nxt -= (uint64_t)cnt * HI_PAT;
+        if (k < 5) {
+            // m_k = (acc mod 2^52) * pinv mod 2^52: the low half of one more FP64 product; acc's low 52 bits enter the pipe as 2^52 + x - 2^52
+            const double t = __longlong_as_double((long long)(LO_PAT | (acc & M52))) - 0x1p52;
+            dfma_hilo(t, pinv, hi, lo);
+            m[k] = __longlong_as_double((long long)(LO_PAT | (lo & M52))) - 0x1p52;
+            dfma_hilo(m[k], pd[0], hi, lo);
+            acc += lo - LO_PAT; nxt += hi - HI_PAT;
+            carry = acc >> 52;                               // the low 52 bits are zero now
+        } else {
+            r[k - 5] = __longlong_as_double((long long)(LO_PAT | (acc & M52))) - 0x1p52;
+            carry = acc >> 52;
+        }
+    }
+    // a, b < q: the result is < 2q and fits 5 limbs (top limb < 2^47): left unreduced, like the radix-2^29 product
+}
+// the same product with 64-bit integer arithmetic only (portable restatement, the checker of the kernel below)
+__device__ inline void mont_mul52_ref_fq(const uint64_t (&a)[5], const uint64_t (&b)[5], uint64_t (&r)[5]) {
+    constexpr uint64_t M52 = Dfma52::M52;
+    uint64_t m[5], p[5];
+    for (int i = 0; i < 5; i++) p[i] = Dfma52::limb(i);
+    const uint64_t pinv = Dfma52::pinv();
+    unsigned __int128 acc = 0;
+    for (int k = 0; k < 10; k++) {
+        for (int i = 0; i < 5; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 4) continue;
+            acc += (unsigned __int128)a[i] * b[j];
+            if (!(k < 5 && i == k)) acc += (unsigned __int128)m[i] * p[j];
+        }
+        if (k < 5) {
+            m[k] = (((uint64_t)acc & M52) * pinv) & M52;
+            acc += (unsigned __int128)m[k] * p[0];
+        } else r[k - 5] = (uint64_t)acc & M52;
+        acc >>= 52;
+    }
+}
+__global__ __launch_bounds__(256) void ub_dfma52_kernel(uint32_t* io, int iters, uint32_t* mismatches) {
+    // double-precision rounding mode of this wave: toward zero (MODE.FP_ROUND bits [3:2] = 3); nothing else in the kernel is floating point
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t ai[5], bi[5], ci[5], di[5];
+    for (int i = 0; i < 5; i++) {
+        uint64_t x = ((uint64_t)io[t * 8 + (i & 7)] * 2654435761u + i) * 0x9e3779b97f4a7c15ull;
+        ai[i] = x & Dfma52::M52; bi[i] = (x >> 7) & Dfma52::M52; ci[i] = (x * 7u) & Dfma52::M52; di[i] = (x * 13u) & Dfma52::M52;
+    }
+    ai[4] &= (1ull << 44) - 1; bi[4] &= (1ull << 44) - 1; ci[4] &= (1ull << 44) - 1; di[4] &= (1ull << 44) - 1;      // < 2^252 < q
+    double a[5], b[5], c[5], d[5], r[5];
+    for (int i = 0; i < 5; i++) { a[i] = (double)ai[i]; b[i] = (double)bi[i]; c[i] = (double)ci[i]; d[i] = (double)di[i]; }
+    if (mismatches) {
+        uint64_t want[5];
+        bool bad = false;
+        mont_mul52_dfma_fq(a, b, r);
+        mont_mul52_ref_fq(ai, bi, want);
+        for (int i = 0; i < 5; i++) bad |= (uint64_t)r[i] != want[i];
+        mont_mul52_dfma_fq(c, d, r);
+        mont_mul52_ref_fq(ci, di, want);
+        for (int i = 0; i < 5; i++) bad |= (uint64_t)r[i] != want[i];
+        if (bad) atomicAdd(mismatches, 1u);
+    }
+    for (int k = 0; k < iters; k++) {      // two independent chains, as in ub_modmul29_kernel (operands stay < 2q: limbs < 2^52, top limb < 2^47)
+        mont_mul52_dfma_fq(a, b, r); for (int i = 0; i < 5; i++) a[i] = r[i];
+        mont_mul52_dfma_fq(c, d, r); for (int i = 0; i < 5; i++) c[i] = r[i];
+        mont_mul52_dfma_fq(b, a, r); for (int i = 0; i < 5; i++) b[i] = r[i];
+        mont_mul52_dfma_fq(d, c, r); for (int i = 0; i < 5; i++) d[i] = r[i];
+    }
+    double x = 0;
+    for (int i = 0; i < 5; i++) x += a[i] + b[i] + c[i] + d[i];
+    io[t * 8] = (uint32_t)(uint64_t)x;
+}
+
 // dependent chain of general XYZZ additions: launch latency / cold-instruction-fetch probe for the small tail kernels
 __global__ __launch_bounds__(256) void ub_ecadd_kernel(g1x_t* io, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,6 +466,61 @@ int ubench(Ctx* c, const char* which, double* out) {
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         (void)hipFree(buf);
         *out = (double)nthreads * iters / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strncmp(which, "mix_", 4)) {           // "mix_mad" / "mix_dfma" / "mix_both" / "mix_add64" / "mix_dadd" [_oN]: lane-ops per second
+        void* buf = nullptr;
+        int blocks = c->num_cus * 16;
+        if (const char* o = strstr(which, "_o")) blocks = c->num_cus * atoi(o + 2);
+        const size_t nthreads = (size_t)blocks * threads;
+        EZ_HIP(hipMalloc(&buf, nthreads * 8));
+        EZ_HIP(hipMemsetAsync(buf, 0x11, nthreads * 8, st));
+        const int iters = 4096;
+        for (int rep = 0; rep < 2; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            if (!strncmp(which, "mix_mad", 7)) hipLaunchKernelGGL(ub_mix_kernel<0>, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
+            else if (!strncmp(which, "mix_dfma", 8)) hipLaunchKernelGGL(ub_mix_kernel<1>, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
+            else if (!strncmp(which, "mix_both", 8)) hipLaunchKernelGGL(ub_mix_kernel<2>, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
+            else if (!strncmp(which, "mix_add64", 9)) hipLaunchKernelGGL(ub_mix_kernel<3>, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
+            else hipLaunchKernelGGL(ub_mix_kernel<4>, dim3(blocks), dim3(threads), 0, st, (uint64_t*)buf, iters);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        EZ_HIP(hipFree(buf));
+        *out = 8.0 * iters * (double)nthreads / (ms * 1e-3);
+        return EZKL_OK;
+    }
+    if (!strncmp(which, "dfma52", 6)) {         // "dfma52[_oN]": FP64-pipe Montgomery products per second; "dfma52_check": mismatches vs the integer form
+        void* buf = nullptr;
+        uint32_t* mis = nullptr;
+        const bool chk = strstr(which, "check") != nullptr;
+        const int iters = chk ? 1 : 256;
+        int blocks = c->num_cus * 16;
+        if (const char* o = strstr(which, "_o")) blocks = c->num_cus * atoi(o + 2);
+        const size_t nthreads = (size_t)blocks * threads;
+        EZ_HIP(hipMalloc(&buf, nthreads * 32));
+        EZ_HIP(hipMalloc((void**)&mis, 4));
+        {   // distinct words per thread: the check covers 2 x nthreads random operand pairs
+            std::vector<uint32_t> h(nthreads * 8);
+            uint64_t x = 0x9e3779b97f4a7c15ull;
+            for (auto& w : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = (uint32_t)(x >> 16); }
+            EZ_HIP(hipMemcpyAsync(buf, h.data(), nthreads * 32, hipMemcpyHostToDevice, st));
+            EZ_HIP(hipStreamSynchronize(st));
+        }
+        EZ_HIP(hipMemsetAsync(mis, 0, 4, st));
+        for (int rep = 0; rep < 2; rep++) {
+            EZ_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(ub_dfma52_kernel, dim3(blocks), dim3(threads), 0, st, (uint32_t*)buf, iters, chk ? mis : nullptr);
+            EZ_HIP(hipEventRecord(e1, st));
+            EZ_HIP(hipStreamSynchronize(st));
+            EZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+        }
+        uint32_t hm = 0;
+        EZ_HIP(hipMemcpy(&hm, mis, 4, hipMemcpyDeviceToHost));
+        EZ_HIP(hipFree(buf));
+        EZ_HIP(hipFree(mis));
+        *out = chk ? (double)hm : 4.0 * iters * (double)nthreads / (ms * 1e-3);
         return EZKL_OK;
     }
     if (!strncmp(which, "modmul29", 8)) {       // "modmul29": products per second; "modmul29_check": mismatches vs the portable form

@@ -319,13 +319,18 @@ int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, con
 /* all_gather of small HOST buffers: buf_host holds world x bytes_per_rank bytes, rank r has filled slice r; on return every slice is
  * filled on every rank (the evaluations a rank computed for the polynomials it owns; the chaining values of the permutation chunks) */
 int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes_per_rank);
-/* all-to-all with ANY NUMBER of contiguous device segments per peer, sent from and received to where the data lives (no packing):
- * sends[i] goes to sends[i].peer, recvs[j] arrives from recvs[j].peer; the k-th segment this rank sends to peer p is the k-th segment
- * p receives from this rank, and their sizes must agree.  A column-sharded prover moves the cosets (or halo-extended row windows) of the
- * columns it transformed to the ranks that sweep those rows with ONE such call: grouped ncclSend / ncclRecv, all peers and all
- * xGMI links at once.  Segments with peer == own rank are copied device-to-device (same matching rule). */
+/* all-to-all with ANY NUMBER of contiguous device segments per peer: sends[i] goes to sends[i].peer, recvs[j] arrives from recvs[j].peer.
+ * Per (sender, receiver) pair the segments form ONE byte stream in list order -- the k-th byte this rank sends to peer p is the k-th byte
+ * p receives from this rank -- so only the per-pair totals must agree.  A column-sharded prover moves the cosets (or halo-extended row
+ * windows) of the columns it transformed to the ranks that sweep those rows with ONE such call.  Wire format: a device gather kernel packs
+ * each peer's stream into a slab (rounds of at most EZKL_COMM_SLAB_MB, default 128 MiB, per peer and direction; the same on every rank),
+ * ONE ncclSend + ONE ncclRecv per peer and round inside one group (all xGMI links at once), a scatter kernel unpacks.  Bytes to the own
+ * rank are copied by the same kernel.  EZKL_COMM_UNPACKED=1: one ncclSend / ncclRecv per segment (round 3; sizes must then agree pairwise).
+ * ezkl_hip_comm_stats: out[0] = exchanges, out[1] / out[2] = bytes sent to / received from other ranks, out[3] = microseconds of host wall
+ * time inside the exchanges, out[4] / out[5] = ncclSend / ncclRecv operations issued, out[6] = rounds; reset != 0 clears them. */
 typedef struct { int peer; void* ptr; size_t bytes; } ezkl_comm_seg_t;
 int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs);
+int ezkl_hip_comm_stats(uint64_t out[8], int reset);
 
 /* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
 /* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */

@@ -35,18 +35,45 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
             B.comm_alltoallv_dev([(0, a.ptr, 64 * 8)], [(0, ra.ptr, 32 * 8)])
         h = np.arange(12, dtype=np.uint64).reshape(1, 12)
         assert (B.comm_allgather_host(h.copy()) == h).all()
-        # the shape of the prover's exchange -- hundreds of segments of very different sizes per peer in ONE group -- through RCCL's own
-        # ncclSend / ncclRecv matching (EZKL_COMM_SELF_VIA_RCCL: the self segments take the RCCL path instead of a device copy)
+        # per peer the segments are ONE byte stream: the two sides may cut it differently
+        c3 = [B.DeviceBuffer(16 * 8), B.DeviceBuffer(48 * 8), B.DeviceBuffer(32 * 8)]
+        B.comm_alltoallv_dev([(0, a.ptr, 64 * 8), (0, b_.ptr, 32 * 8)], [(0, c3[0].ptr, 16 * 8), (0, c3[1].ptr, 48 * 8), (0, c3[2].ptr, 32 * 8)])
+        assert (np.concatenate([c.to_numpy() for c in c3]) == np.concatenate([np.arange(100, 164, dtype=np.uint64), np.arange(500, 532, dtype=np.uint64)])).all()
+        # the shape of the prover's exchange -- hundreds of segments of very different sizes per peer -- through the PACKED wire format and
+        # RCCL (EZKL_COMM_SELF_VIA_RCCL: the bytes to self take the slab + ncclSend / ncclRecv path instead of the copy kernel):
+        # ONE send and ONE receive per peer and round, whatever the number of segments
         rng = np.random.default_rng(5)
         sizes = [int(x) * 32 for x in rng.integers(1, 1 << 15, 300)] + [1 << 24, 32, 1 << 22]
         src = [B.DeviceBuffer.from_numpy(rng.integers(0, 1 << 63, sz // 8, dtype=np.uint64)) for sz in sizes]
-        dst = [B.DeviceBuffer(sz) for sz in sizes]
-        os.environ["EZKL_COMM_SELF_VIA_RCCL"] = "1"
+        total = sum(sizes)
+        for slab_mb, unpacked in ((None, False), (16, False), (None, True)):
+            dst = [B.DeviceBuffer(sz) for sz in sizes]
+            os.environ["EZKL_COMM_SELF_VIA_RCCL"] = "1"
+            if slab_mb: os.environ["EZKL_COMM_SLAB_MB"] = str(slab_mb)
+            if unpacked: os.environ["EZKL_COMM_UNPACKED"] = "1"
+            B.comm_stats(reset=True)
+            try:
+                B.comm_alltoallv_dev([(0, s_.ptr, sz) for s_, sz in zip(src, sizes)], [(0, d_.ptr, sz) for d_, sz in zip(dst, sizes)])
+            finally:
+                for v in ("EZKL_COMM_SELF_VIA_RCCL", "EZKL_COMM_SLAB_MB", "EZKL_COMM_UNPACKED"):
+                    os.environ.pop(v, None)
+            assert all((s_.to_numpy() == d_.to_numpy()).all() for s_, d_ in zip(src, dst)), (slab_mb, unpacked)
+            st = B.comm_stats()
+            rounds = -(-total // ((slab_mb or 128) << 20))
+            if unpacked:
+                assert st["nccl_sends"] == len(sizes) and st["nccl_recvs"] == len(sizes)           # round 3's wire format: one per segment
+            else:
+                assert st["nccl_sends"] == rounds and st["nccl_recvs"] == rounds and st["rounds"] == rounds, (st, rounds)
+            # different cuts on the two sides, through the slabs: the receive side takes the same bytes as 7 equal pieces + the rest
+        piece = (total // 7) & ~31
+        cuts = [piece] * 7 + [total - 7 * piece]
+        dst2 = [B.DeviceBuffer(sz) for sz in cuts]
+        os.environ["EZKL_COMM_SELF_VIA_RCCL"] = "1"; os.environ["EZKL_COMM_SLAB_MB"] = "8"
         try:
-            B.comm_alltoallv_dev([(0, s_.ptr, sz) for s_, sz in zip(src, sizes)], [(0, d_.ptr, sz) for d_, sz in zip(dst, sizes)])
+            B.comm_alltoallv_dev([(0, s_.ptr, sz) for s_, sz in zip(src, sizes)], [(0, d_.ptr, sz) for d_, sz in zip(dst2, cuts)])
         finally:
-            del os.environ["EZKL_COMM_SELF_VIA_RCCL"]
-        assert all((s_.to_numpy() == d_.to_numpy()).all() for s_, d_ in zip(src, dst))
+            del os.environ["EZKL_COMM_SELF_VIA_RCCL"]; del os.environ["EZKL_COMM_SLAB_MB"]
+        assert (np.concatenate([d_.to_numpy() for d_ in dst2]) == np.concatenate([s_.to_numpy() for s_ in src])).all()
         # the C++ host prover over the library communicator: same bytes as the unsharded prover
         cs = TP.lookup_circuit(6)
         adv, fixed, copies = TP.lookup_witness(cs, 4)

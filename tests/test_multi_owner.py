@@ -29,7 +29,7 @@ def _run(env, world, port, extra=()):
 
 @pytest.mark.parametrize("circuit,k", [("fixture", 6), ("mlp", 10), ("einsum", 10)])
 def test_owner_sharded_native_prover_same_bytes(hip, circuit, k):
-    env = {"CIRCUIT": circuit, "K": str(k)}
+    env = {"CIRCUIT": circuit, "K": str(k), "MLP_BASE": "128"}     # small range-check tables: 16 lookups instead of the default base's 137 at k = 10
     one = _run(env, 1, 0)
     assert one["verifier_accepts"] and one["tampered_rejected"]
     for world, port in ((2, 29571), (4, 29573)) if circuit != "mlp" else ((2, 29571),):
@@ -46,8 +46,20 @@ def test_owner_sharded_native_prover_same_bytes(hip, circuit, k):
 
 def test_replicated_mode_still_same_bytes(hip):
     """the round-2 sharding (commit batches by columns, everything else replicated) on the coset-major prover"""
-    env = {"CIRCUIT": "mlp", "K": "10"}
+    env = {"CIRCUIT": "mlp", "K": "9", "MLP_BASE": "128"}
     one = _run(env, 1, 0)
     j = _run(env, 2, 29575, extra=["--replicated"])
     assert j["mode"].startswith("replicated") and j["proof_sha256"] == one["proof_sha256"] and j["all_ranks_same_proof"] and j["verifier_accepts"]
     assert all(r["stats"]["exchange_bytes_received"] == 0 for r in j["per_rank"])
+
+
+def test_lookup_failure_is_collective(hip):
+    """a witness value outside its table: every rank returns the error (no rank is left waiting in the next collective)"""
+    env = dict(os.environ, EZKL_BENCH_CACHE="off", CIRCUIT="fixture", K="6")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           TOOL, "--gloo", "--share-device", "--bad-lookup"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for rank in (0, 1):
+        lines = [l for l in r.stdout.splitlines() if l.startswith("RANK %d " % rank)]
+        assert lines and "ERROR" in lines[0] and "lookup input not in table" in lines[0], (rank, r.stdout[-1000:], r.stderr[-1000:])

@@ -179,18 +179,26 @@ def _build(kind, k, gpu, seed, store, **kw):
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=advice, instances=[], info=info)
     if kind == "mlp":
         layers, N, blocks, fill = kw.get("layers", 9), kw.get("width"), kw.get("blocks") or 2, kw.get("fill")
+        # decomposition base of the range checks (ezkl's default 16384, src/lib.rs:257-260).  A table of `base` rows is split over
+        # ceil(base / usable rows) column groups, so at k <= 11 the default makes a circuit with dozens of table columns and lookups whose
+        # sweep program takes hiprtc minutes to compile (153 s at k = 10, profiles/r04a_pytest_gpu.log): small test circuits pass base=128,
+        # the fixture's own setting (tests/golden/settings.json)
+        base = kw.get("base") or 16384
         cap = 2 * ((1 << k) - 6)                       # cells of one block of two inner columns
         if N is None:                                  # fill about (blocks - 0.1) blocks: 3 x 2 x blocks advice columns
             N = int((((blocks - 0.1) * (fill or 100) / 100.0 * cap) / layers) ** 0.5)
         Ws = [sparse_weights(rng, N, N) for _ in range(layers)]
         bs = [rng.integers(-20, 20, N).tolist() for _ in range(layers)]
         x = rng.integers(-60, 60, N).tolist()
+        if base < 16384:                               # keep the activations inside the two-leg range of a small base
+            bs = [rng.integers(-2, 3, N).tolist() for _ in range(layers)]
+            x = rng.integers(-3, 4, N).tolist()
         # fill (percent): lay out only that share of the cells but keep the column allocation of `blocks` full blocks (total_assignments is
         # what gen-settings would report for the full model): the Python layout engine needs ~15 us per cell, and every kernel of the
         # prover except the witness MSMs costs the same whatever the cells hold
-        c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2)
+        c = EL.MlpCircuit(k, 2, Ws, bs, base, 2)
         if fill and c.settings.total_assignments < int((blocks - 0.1) * cap):
-            c = EL.MlpCircuit(k, 2, Ws, bs, 16384, 2, total_assignments=int((blocks - 0.1) * cap))
+            c = EL.MlpCircuit(k, 2, Ws, bs, base, 2, total_assignments=int((blocks - 0.1) * cap))
         cs, fixed, copies, reg = c.keygen_inputs(x, with_witness=True)      # one synthesis pass for the key and the witness
         adv, inst = c.witness_of(reg)
         info = dict(circuit="MLP %d x (Gemm %dx%d + bias + ReLU), batch 1, ezkl gate set (examples/onnx/large_mlp shape), k=%d" % (layers, N, N, k),

@@ -60,7 +60,8 @@ if CIRCUIT != "synthetic":
     if os.environ.get("WIDTH"): kw["width"] = int(os.environ["WIDTH"])
     if os.environ.get("LENGTH"): kw["length"] = int(os.environ["LENGTH"])
     if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
-    if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])      # 3 x 2 x blocks advice columns (k = 22, 5 blocks: BASELINE configs[4]'s shape)
+    if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])
+    if os.environ.get("MLP_BASE"): kw["base"] = int(os.environ["MLP_BASE"])      # 3 x 2 x blocks advice columns (k = 22, 5 blocks: BASELINE configs[4]'s shape)
     built = BC.build(CIRCUIT, k, gpu=B, **kw)
     cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
     circuit_info = dict(built["info"], **BC.describe(cs), layout_seconds_python=round(time.time() - t0, 1))

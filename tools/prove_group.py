@@ -21,6 +21,7 @@ CIRCUIT, k = os.environ.get("CIRCUIT", "mlp"), int(os.environ.get("K", "12"))
 kw = {}
 if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
 if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])
+if os.environ.get("MLP_BASE"): kw["base"] = int(os.environ["MLP_BASE"])
 built = BC.build(CIRCUIT, k, gpu=B, **kw)
 cs, fixed, copies, adv, instances, info = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"], built["info"]
 n = 1 << k

@@ -45,6 +45,7 @@ else:
     kw = {a.lower(): int(os.environ[a]) for a in ("LAYERS", "WIDTH", "LENGTH") if os.environ.get(a)}
     if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
     if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])
+    if os.environ.get("MLP_BASE"): kw["base"] = int(os.environ["MLP_BASE"])
     built = BC.build(CIRCUIT, k, gpu=B, **kw)
     cs, fixed, copies, adv, instances, info = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"], built["info"]
 n = 1 << k
@@ -83,6 +84,20 @@ if "--pinned" in sys.argv and not callable(adv):
     for pa, a in zip(pinned, adv):
         pa.array[:] = a
     adv = [pa.array for pa in pinned]
+if "--bad-lookup" in sys.argv:
+    # a witness with values outside their lookup tables (the most common ezkl prover failure): EVERY rank must come back with the error --
+    # only the owner of the offending argument sees the counter, the others learn it through the collective status
+    adv = [np.array(a, copy=True) for a in adv]
+    for a in adv:
+        a[0] = P.to_mont(123456789)
+    try:
+        NV.create_proof(npk, gb, glb, adv, seed=5, instances=instances)
+        print("RANK %d NO_ERROR" % rank, flush=True)
+    except Exception as e:
+        print("RANK %d ERROR %s" % (rank, str(e).replace("\n", " ")[:200]), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()      # a rank left behind in a collective would never get here
+    sys.exit(0)
 t0 = time.time(); NV.create_proof(npk, gb, glb, adv, seed=5, instances=instances); t_first = time.time() - t0
 runs = []
 for _ in range(int(os.environ.get("REPS", "3"))):

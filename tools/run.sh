@@ -30,8 +30,9 @@ for JOB in "$@"; do
       (cd "$R" && timeout ${SUITE_TIMEOUT:-900} python -m pytest tests -m gpu -q --durations=40 -p no:cacheprovider) > "$O/${TAG}_pytest_gpu.log" 2>&1
       echo "pytest rc=$?" >> "$O/${TAG}_pytest_gpu.log"; tail -60 "$O/${TAG}_pytest_gpu.log" ;;
     bench)
-      (cd "$R" && /usr/bin/time -v timeout ${BENCH_TIMEOUT:-600} python bench.py ${BENCH_ARGS:-}) > "$O/${TAG}_bench.log" 2> "$O/${TAG}_bench.err"
-      grep -E "Elapsed|Maximum resident" "$O/${TAG}_bench.err" >> "$O/${TAG}_bench.log"
+      TB=$(date +%s)
+      (cd "$R" && timeout ${BENCH_TIMEOUT:-600} python bench.py ${BENCH_ARGS:-}) > "$O/${TAG}_bench.log" 2> "$O/${TAG}_bench.err"
+      echo "bench.py rc=$? wall $(( $(date +%s) - TB )) s" >> "$O/${TAG}_bench.log"
       grep '^{"metric' "$O/${TAG}_bench.log" | python -c "
 import sys, json
 j = json.loads(sys.stdin.read()); p = j.get('prove', {})
