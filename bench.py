@@ -455,6 +455,10 @@ def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
             raise RuntimeError(r.stderr[-300:])
         j = json.loads(lines[-1])
         return {"circuit": j["circuit"], "n_gpus": j["n_gpus"], "host": "libezkl_prover.so (C++) over the C ABI", "sharding": j["mode"], "collectives": j["collectives"],
+                "rccl_ranks_seen": min(p_["stats"].get("rccl_ranks_seen", 0) for p_ in j["per_rank"]),
+                "exchange_ms_per_proof_max": max(p_["stats"].get("exchange_ms_per_proof", 0) for p_ in j["per_rank"]),
+                "exchange_bytes_sent_per_proof_max": max(p_["stats"].get("exchange_bytes_sent_per_proof", 0) for p_ in j["per_rank"]),
+                "nccl_sends_per_proof_max": max(p_["stats"].get("nccl_sends_per_proof", 0) for p_ in j["per_rank"]),
                 "sharded_sweeps": min(p_["sharded_sweeps"] for p_ in j["per_rank"]), "per_rank": j["per_rank"],
                 "prove_seconds_gpu": j["prove_seconds_gpu"], "prove_seconds_gpu_runs": j.get("prove_seconds_gpu_runs"), "all_ranks_same_proof": j["all_ranks_same_proof"],
                 "verifier_accepts": j["verifier_accepts"], "proof_bytes": j["proof_bytes"], "proof_sha256": j.get("proof_sha256"),

@@ -400,8 +400,8 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
                     }
                     continue;
                 }
-                rs[p] = (size_t)std::min<uint64_t>(left_s[p], g_comm.slab_bytes);
-                rr[p] = (size_t)std::min<uint64_t>(left_r[p], g_comm.slab_bytes);
+                rs[p] = (size_t)std::min<uint64_t>(left_s[p], slab);      // the ROUND size is the agreed slab size, not what happens to be allocated here
+                rr[p] = (size_t)std::min<uint64_t>(left_r[p], slab);
                 for (size_t done = 0; done < rs[p];) {
                     char* sp;
                     const size_t m = cs[p].take(rs[p] - done, &sp);

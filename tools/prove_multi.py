@@ -89,7 +89,7 @@ if "--bad-lookup" in sys.argv:
     # only the owner of the offending argument sees the counter, the others learn it through the collective status
     adv = [np.array(a, copy=True) for a in adv]
     for a in adv:
-        a[0] = P.to_mont(123456789)
+        a[:32] = P.to_mont(123456789)
     try:
         NV.create_proof(npk, gb, glb, adv, seed=5, instances=instances)
         print("RANK %d NO_ERROR" % rank, flush=True)
@@ -107,6 +107,14 @@ for _ in range(int(os.environ.get("REPS", "3"))):
     t0 = time.time(); proof = NV.create_proof(npk, gb, glb, adv, seed=5, instances=instances, timings=tm); runs.append((time.time() - t0, tm))
 t_prove, tm = min(runs, key=lambda r: r[0])
 stats = nc.shard_stats()
+# what the library's RCCL communicator saw and moved for the LAST proof's worth of exchanges (ezkl_hip_comm_info / ezkl_hip_comm_stats):
+# `rccl_ranks_seen` is the world size of the ncclComm the exchanges ran on (0 = torch.distributed callbacks), so a SCALE run can be checked
+cw, cr = B.comm_info()
+cst = B.comm_stats()
+nproofs = 1 + len(runs)
+stats = dict(stats, rccl_ranks_seen=cw, rccl_rank=cr, exchange_calls_per_proof=cst["exchanges"] / nproofs, exchange_bytes_sent_per_proof=cst["bytes_sent"] / nproofs,
+             exchange_ms_per_proof=round(1e3 * cst["seconds"] / nproofs, 3), nccl_sends_per_proof=cst["nccl_sends"] / nproofs, nccl_recvs_per_proof=cst["nccl_recvs"] / nproofs,
+             exchange_rounds_per_proof=cst["rounds"] / nproofs)
 sha = hashlib.sha256(proof).hexdigest()
 if world > 1:
     import torch
