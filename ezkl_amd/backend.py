@@ -396,6 +396,13 @@ def coeff_to_cosets_dev(in_ptr, out_ptr, k, ext_k, batch=1, stream=None):
                                                      C.c_uint32(k), C.c_uint32(ext_k), _stream_ptr(stream)), "ezkl_hip_coeff_to_cosets_dev")
 
 
+def coeff_to_cosets_range_dev(in_ptr, out_ptr, k, ext_k, first_coset, n_cosets, batch=1, stream=None):
+    """cosets [first_coset, first_coset + n_cosets) of coeff_to_cosets_dev only (n_cosets a power of two): out[(b - first) 2^k + j]"""
+    _l.check(_l.load().ezkl_hip_coeff_to_cosets_range_dev(_vp(in_ptr), _vp(out_ptr), C.c_size_t(batch), C.c_size_t(1 << k), C.c_size_t(n_cosets << k),
+                                                           C.c_uint32(k), C.c_uint32(ext_k), C.c_uint32(first_coset), C.c_uint32(n_cosets), _stream_ptr(stream)),
+             "ezkl_hip_coeff_to_cosets_range_dev")
+
+
 def cosets_transpose_dev(in_ptr, out_ptr, k, ext_k, to_natural=True, stream=None):
     _l.check(_l.load().ezkl_hip_cosets_transpose_dev(_vp(in_ptr), _vp(out_ptr), C.c_uint32(k), C.c_uint32(ext_k), C.c_int(1 if to_natural else 0),
                                                       _stream_ptr(stream)), "ezkl_hip_cosets_transpose_dev")

@@ -821,6 +821,17 @@ int ezkl_hip_coeff_to_cosets_dev(const void* in, void* out, size_t batch, size_t
     if (rc) return rc;
     return finish(c, st, stream);
 }
+int ezkl_hip_coeff_to_cosets_range_dev(const void* in, void* out, size_t batch, size_t in_stride, size_t out_stride, uint32_t log_n, uint32_t log_n_ext,
+                                       uint32_t first_coset, uint32_t n_cosets, void* stream) {
+    if (!in || !out || in == out || batch == 0 || log_n > log_n_ext || log_n_ext > 28 || log_n_ext - log_n > 6) return EZKL_ERR_INVALID;
+    if (n_cosets == 0 || (n_cosets & (n_cosets - 1)) || (uint64_t)first_coset + n_cosets > (1ull << (log_n_ext - log_n))) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = coset_cm_run(c, st, (const fe_t*)in, (fe_t*)out, log_n, log_n_ext, domain_omega(log_n, false), domain_omega(log_n_ext, false), batch, in_stride, out_stride,
+                          first_coset, n_cosets);
+    if (rc) return rc;
+    return finish(c, st, stream);
+}
 int ezkl_hip_cosets_transpose_dev(const void* in, void* out, uint32_t log_n, uint32_t log_n_ext, int to_natural, void* stream) {
     if (!in || !out || in == out || log_n > log_n_ext || log_n_ext > 28) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -92,7 +92,7 @@ struct Bases {
 int ntt_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, const fe_t& omega, bool inverse_scale,
             size_t batch, size_t in_stride, size_t out_stride, uint32_t in_log_len, int coset_mode);
 int coset_cm_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_ext, const fe_t& w_n, const fe_t& w_ext, size_t batch,
-                 size_t in_stride, size_t out_stride);
+                 size_t in_stride, size_t out_stride, uint32_t first_coset = 0, uint32_t n_cosets = 0);
 int cm_transpose(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_e, bool to_natural);
 int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe_t* scalars_dev, size_t n,
             void* out_affine_host);

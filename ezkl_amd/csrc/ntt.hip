@@ -41,7 +41,9 @@ struct PassArgs {
     // coset-major extended evaluation (coset_cm_run): blockIdx.y = column * E + coset; the first pass is a TWISTED DIT transform (dit = 1,
     // stage twiddles of coset b at tw_pre + b * R: ntt_superstage_dit) and its inter-pass table is per coset (tw_inter + coset * 2^log_n
     // holds w^(i2 k1) * c_b^i2): the coset scaling c_b^j costs no product
-    uint32_t cm, cm_log_e, dit;
+    // a RANGE of cosets (ezkl_hip_coeff_to_cosets_range_dev: a rank of a sharded prover holds only the cosets of the key columns that
+    // it sweeps): blockIdx.y = column * 2^cm_log_cnt + local coset, coset = cm_first + local; the output holds 2^cm_log_cnt cosets
+    uint32_t cm, cm_log_e, dit, cm_first, cm_log_cnt;
     const fe_t* tw_pre;
 };
 
@@ -147,11 +149,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     uint2* data = reinterpret_cast<uint2*>(smem);
     fe_t* tloc = reinterpret_cast<fe_t*>(smem + 32u * TILE);
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
-    const uint32_t cm_b = a.cm ? (blockIdx.y & ((1u << a.cm_log_e) - 1u)) : 0u, cm_col = a.cm ? (blockIdx.y >> a.cm_log_e) : blockIdx.y;
+    const uint32_t cm_l = a.cm ? (blockIdx.y & ((1u << a.cm_log_cnt) - 1u)) : 0u, cm_col = a.cm ? (blockIdx.y >> a.cm_log_cnt) : blockIdx.y;
+    const uint32_t cm_b = a.cm_first + cm_l;                       // the coset this block evaluates on; cm_l = its place in the output
     // coset-major: the first pass reads column cm_col (one copy of the coefficients serves all E cosets), the last pass writes coset
     // cm_b of that column's extended form; the work buffer in between holds one 2^log_n block per (column, coset)
     const fe_t* in = a.in + (size_t)((a.cm && a.first) ? cm_col : blockIdx.y) * a.in_stride;
-    fe_t* out = (a.cm && a.last) ? a.out + (size_t)cm_col * a.out_stride + ((size_t)cm_b << a.log_n) : a.out + (size_t)blockIdx.y * a.out_stride;
+    fe_t* out = (a.cm && a.last) ? a.out + (size_t)cm_col * a.out_stride + ((size_t)cm_l << a.log_n) : a.out + (size_t)blockIdx.y * a.out_stride;
     const fe_t* tw_inter = a.tw_inter ? a.tw_inter + ((a.cm && a.first) ? ((size_t)cm_b << a.log_n) : 0) : nullptr;
 
     if (a.dit) {                    // twisted DIT pass (coset-major first pass): stages 1 .. log_r - 1 of this coset's table
@@ -570,14 +573,14 @@ static int coset_tables_get(Ctx* c, hipStream_t st, NttPlan* p, uint32_t log_n, 
 }
 
 static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_ext, const fe_t& w_n, const fe_t& w_ext, size_t batch,
-                          size_t in_stride, size_t out_stride) {
+                          size_t in_stride, size_t out_stride, uint32_t first_coset, uint32_t log_count) {
     NttPlan* p = nullptr;
     int rc = plan_get(c, st, log_n, w_n, &p);
     if (rc) return rc;
     CosetTables ct;
     if ((rc = coset_tables_get(c, st, p, log_n, log_ext, w_ext, &ct))) return rc;
     const uint32_t log_e = log_ext - log_n;
-    const size_t n = (size_t)1 << log_n, blocks = batch << log_e;
+    const size_t n = (size_t)1 << log_n, blocks = batch << log_count;
     if ((rc = ntt_kernel_attrs())) return rc;
     fe_t* work = nullptr;
     if (p->npass > 1) {
@@ -610,6 +613,8 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         for (int q = 0; q < 4; q++) a.log_radix[q] = p->log_radix[q];
         a.cm = 1;
         a.cm_log_e = log_e;
+        a.cm_first = first_coset;
+        a.cm_log_cnt = log_count;
         a.dit = first ? 1u : 0u;
         a.tw_pre = ct.pre;
         if (last) {
@@ -628,14 +633,19 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
 }
 // `batch` coefficient columns (2^log_n each, in_stride apart) -> their coset-major extended forms (2^log_ext each, out_stride apart)
 int coset_cm_run(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint32_t log_n, uint32_t log_ext, const fe_t& w_n, const fe_t& w_ext, size_t batch,
-                 size_t in_stride, size_t out_stride) {
+                 size_t in_stride, size_t out_stride, uint32_t first_coset, uint32_t n_cosets) {
     if (log_ext > 28 || log_n > log_ext || log_ext - log_n > 6 || batch == 0) return EZKL_ERR_INVALID;
-    size_t group = ((size_t)4 << 30) / ((size_t)32 << log_ext);
+    const uint32_t E = 1u << (log_ext - log_n);
+    if (n_cosets == 0) { first_coset = 0; n_cosets = E; }              // all of them
+    if ((n_cosets & (n_cosets - 1)) || first_coset + n_cosets > E) return EZKL_ERR_INVALID;
+    uint32_t log_count = 0;
+    while ((1u << log_count) < n_cosets) log_count++;
+    size_t group = ((size_t)4 << 30) / ((size_t)32 << (log_n + log_count));
     if (group < 1) group = 1;
-    if ((group << (log_ext - log_n)) > 32768) group = 32768 >> (log_ext - log_n);
+    if ((group << log_count) > 32768) group = 32768 >> log_count;
     for (size_t b0 = 0; b0 < batch; b0 += group) {
         const size_t nb = batch - b0 < group ? batch - b0 : group;
-        int rc = coset_cm_chunk(c, st, in + b0 * in_stride, out + b0 * out_stride, log_n, log_ext, w_n, w_ext, nb, in_stride, out_stride);
+        int rc = coset_cm_chunk(c, st, in + b0 * in_stride, out + b0 * out_stride, log_n, log_ext, w_n, w_ext, nb, in_stride, out_stride, first_coset, log_count);
         if (rc) return rc;
     }
     return EZKL_OK;

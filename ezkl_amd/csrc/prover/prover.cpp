@@ -671,6 +671,24 @@ struct Backend {
         check(ezkl_hip_coeff_to_cosets_dev(h->ptr(), o->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, nullptr), "ezkl_hip_coeff_to_cosets_dev");
         return o;
     }
+    // the cosets of the extended domain whose rows THIS rank sweeps (create_proof's units): all of them unless columns have owners; by
+    // owner, world <= E: E / world whole cosets; world > E: the one coset its row range lies in
+    void key_range(uint32_t ext_k, uint32_t& first, uint32_t& count) const {
+        const uint32_t E = 1u << (ext_k - k);
+        first = 0; count = E;
+        if (!topo.owners) return;
+        if (topo.world <= E) { count = E / topo.world; first = topo.rank * count; }
+        else { count = 1; first = topo.rank / (topo.world / E); }
+    }
+    // coeff_to_extended restricted to key_range: out[(b - first) n + j]
+    Col key_cosets(const Col& h, uint32_t ext_k) const {
+        uint32_t first, count;
+        key_range(ext_k, first, count);
+        if (count == (1u << (ext_k - k))) return coeff_to_extended(h, ext_k);
+        Col o = alloc((size_t)count * n);
+        check(ezkl_hip_coeff_to_cosets_range_dev(h->ptr(), o->ptr(), 1, n, (size_t)count * n, k, ext_k, first, count, nullptr), "ezkl_hip_coeff_to_cosets_range_dev");
+        return o;
+    }
     // coset-major evaluations -> the 2^ext_k coefficients (natural order): transposed into the natural order of the extended domain,
     // then EvaluationDomain::extended_to_coeff as one inverse transform (one column per proof: h)
     Col extended_to_coeff(const Col& h, uint32_t ext_k) const {
@@ -914,6 +932,10 @@ struct ProvingKey {
     ConstraintSystem* cs = nullptr;
     std::vector<Col> fixed_values, fixed_polys, fixed_cosets, sigma_values, sigma_polys, sigma_cosets;
     Col omega_col, l0, l_last, l_active, x_coset;
+    // which cosets of the extended domain the *_cosets / l0 / l_last / l_active / x_coset columns hold: [coset_first, coset_first +
+    // coset_count), coset-major.  One rank / replicated provers: all E of them.  Owner mode: only the cosets this rank sweeps
+    // (Backend::key_range) -- at k = 22 the 77 key columns of the 30-column circuit are 39 GB per GPU in full, 1 / world of that by owner
+    uint32_t coset_first = 0, coset_count = 0;
     std::vector<G1> fixed_commitments, sigma_commitments;
     std::vector<uint8_t> selector_bits;      // n_selectors x n/8 bytes, bit-packed rows as in halo2's vk files (zero if the key was made here)
     Fe digest;
@@ -955,7 +977,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     for (uint32_t c = 0; c < cs.n_fixed; c++) {
         pk->fixed_values.push_back(be.upload(fixed_values[c], n));
         pk->fixed_polys.push_back(be.lagrange_to_coeff(pk->fixed_values.back()));
-        pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
+        pk->fixed_cosets.push_back(be.key_cosets(pk->fixed_polys.back(), cs.ext_k));
     }
     lap("fixed columns");
     // permutation: cycle structure over (colpos, row) cells numbered c * n + r; `nxt` is the cycle successor, `root` a
@@ -999,17 +1021,18 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
             check(ezkl_hip_permutation_sigma_dev(next->ptr(), pk->omega_col->ptr(), dpc->ptr(), (uint32_t)m, k, sig->ptr(), nullptr), "ezkl_hip_permutation_sigma_dev");
             pk->sigma_values.push_back(sig);
             pk->sigma_polys.push_back(be.lagrange_to_coeff(pk->sigma_values.back()));
-            pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+            pk->sigma_cosets.push_back(be.key_cosets(pk->sigma_polys.back(), cs.ext_k));
         }
     }
     lap("sigma gather + forms");
     // l0, l_last, l_active_row on the extended coset
-    auto lag = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
+    auto lag = [&](uint32_t lo, uint32_t hi) { return be.key_cosets(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
     pk->l0 = lag(0, 1);
     pk->l_last = lag(cs.usable, cs.usable + 1);
     pk->l_active = lag(0, cs.usable);
     // the identity column X on the extended coset (from coefficients [0, 1, 0, ...])
-    pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
+    pk->x_coset = be.key_cosets(be.indicator(1, 2), cs.ext_k);
+    be.key_range(cs.ext_k, pk->coset_first, pk->coset_count);
     lap("l0 / l_last / l_active / X");
     pk->fixed_commitments = be.commit(pk->fixed_polys);
     pk->sigma_commitments = be.commit(pk->sigma_polys);
@@ -1064,9 +1087,22 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
         for (size_t i = 0; i < cols.size(); i++) put_be32(o, (uint32_t)ne);
         for (auto& c : cols) put_poly(nat(c), ne);
     };
-    put_poly(nat(pk.l0), ne); put_poly(nat(pk.l_last), ne); put_poly(nat(pk.l_active), ne);
-    put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_vec(pk.fixed_cosets);
-    put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(pk.sigma_cosets);
+    if (pk.coset_count == (1u << (cs.ext_k - cs.k))) {
+        put_poly(nat(pk.l0), ne); put_poly(nat(pk.l_last), ne); put_poly(nat(pk.l_active), ne);
+        put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_vec(pk.fixed_cosets);
+        put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(pk.sigma_cosets);
+    } else {
+        // a key held by owner (a range of cosets): the file still gets the complete extended columns, recomputed from the coefficient forms
+        auto full = [&](const std::vector<Col>& polys) {
+            std::vector<Col> out;
+            for (auto& p_ : polys) out.push_back(be.coeff_to_extended(p_, cs.ext_k));
+            return out;
+        };
+        auto lagf = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
+        put_poly(nat(lagf(0, 1)), ne); put_poly(nat(lagf(cs.usable, cs.usable + 1)), ne); put_poly(nat(lagf(0, cs.usable)), ne);
+        put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_vec(full(pk.fixed_polys));
+        put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(full(pk.sigma_polys));
+    }
     return o;
 }
 static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* buf, size_t len) {
@@ -1132,6 +1168,8 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
     // derived columns that the file does not hold
     pk->omega_col = be.omega_powers();
     pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
+    pk->coset_first = 0;
+    pk->coset_count = 1u << (cs.ext_k - cs.k);               // the file's complete extended columns
     pk->digest = vk_digest(*pk);
     return pk;
 }
@@ -1153,7 +1191,7 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     struct Unmap { void* p; size_t l; ~Unmap() { munmap(p, l); } } unmap{map, len};
     (void)madvise(map, len, MADV_SEQUENTIAL);
     const uint8_t* buf = (const uint8_t*)map;
-    Backend be(cs.k, cs.n, nullptr, nullptr);
+    Backend be(cs.k, cs.n, nullptr, nullptr, cs.shard);       // owner mode: only the cosets this rank sweeps are computed and kept
     size_t off = 0;
     auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
     need(7);
@@ -1290,19 +1328,20 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     {
         for (auto& v : pk->fixed_values) {
             pk->fixed_polys.push_back(be.lagrange_to_coeff(v));
-            pk->fixed_cosets.push_back(be.coeff_to_extended(pk->fixed_polys.back(), cs.ext_k));
+            pk->fixed_cosets.push_back(be.key_cosets(pk->fixed_polys.back(), cs.ext_k));
         }
         for (auto& v : pk->sigma_values) {
             pk->sigma_polys.push_back(be.lagrange_to_coeff(v));
-            pk->sigma_cosets.push_back(be.coeff_to_extended(pk->sigma_polys.back(), cs.ext_k));
+            pk->sigma_cosets.push_back(be.key_cosets(pk->sigma_polys.back(), cs.ext_k));
         }
     }
-    auto lag = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
+    auto lag = [&](uint32_t lo, uint32_t hi) { return be.key_cosets(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
     pk->l0 = lag(0, 1);
     pk->l_last = lag(cs.usable, cs.usable + 1);
     pk->l_active = lag(0, cs.usable);
     pk->omega_col = be.omega_powers();
-    pk->x_coset = be.coeff_to_extended(be.indicator(1, 2), cs.ext_k);
+    pk->x_coset = be.key_cosets(be.indicator(1, 2), cs.ext_k);
+    be.key_range(cs.ext_k, pk->coset_first, pk->coset_count);
     pk->digest = vk_digest(*pk);
     return pk;
 }
@@ -1558,6 +1597,7 @@ struct Quotient {
     std::vector<Program> progs;    // run one after the other on the same output: program p continues the Horner chain from PreviousValue
     std::vector<Col> cols;         // coset-major extended columns (null: a witness column this rank does not own)
     std::vector<int> owner;        // per slot: the rank holding the column, -1 = resident on every rank (key columns, replicated provers)
+    std::vector<uint8_t> key;      // per slot: a key column (holds cosets [pk.coset_first, +pk.coset_count) only)
     std::vector<Fe> chal;
 };
 // how many constraint terms go into one sweep kernel (EZKL_PROVER_SWEEP_TERMS; 0 = all in one kernel)
@@ -1580,22 +1620,23 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
                                  const std::vector<Col>& phi_cosets, const std::vector<Col>& inst_cosets, const std::vector<Fe>& user_chal,
                                  const std::vector<int>& adv_owner = {}, const std::vector<int>& z_owner = {}, const std::vector<int>& lk_owner = {},
                                  int inst_owner = -1) {
-    Quotient Q{{}, {}, {}, {y, beta, gamma}};
+    Quotient Q{{}, {}, {}, {}, {y, beta, gamma}};
     Q.chal.insert(Q.chal.end(), user_chal.begin(), user_chal.end());
     std::map<std::vector<uint32_t>, uint32_t> index;
     auto own = [](const std::vector<int>& v, uint32_t i) { return i < v.size() ? v[i] : -1; };
-    auto slot = [&](std::vector<uint32_t> name, const Col& h, int owner = -1) {
+    auto slot = [&](std::vector<uint32_t> name, const Col& h, int owner = -1, bool is_key = false) {
         auto it = index.find(name);
         if (it != index.end()) return it->second;
         index[name] = (uint32_t)Q.cols.size();
         Q.cols.push_back(h);
         Q.owner.push_back(owner);
+        Q.key.push_back(is_key ? 1 : 0);
         return (uint32_t)Q.cols.size() - 1;
     };
     enum : uint32_t { S_L0 = 100, S_LLAST, S_LACT, S_X, S_Z, S_SIGMA, S_PHI, S_M };
     auto col_slot = [&](uint32_t kind, uint32_t c) {
         return kind == N_ADV ? slot({kind, c}, adv_cosets[c], own(adv_owner, c)) : kind == N_INST ? slot({kind, c}, inst_cosets[c], inst_owner)
-                                                                                                 : slot({kind, c}, pk.fixed_cosets[c]);
+                                                                                                 : slot({kind, c}, pk.fixed_cosets[c], -1, true);
     };
     // an emitter appends the terms of one gate / one permutation chunk / one lookup argument to the program it is handed; sub-expressions
     // are shared inside an emitter's program (Lowering's memo), never across programs
@@ -1603,7 +1644,8 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
     std::vector<std::pair<Emit, uint32_t>> emitters;          // (emitter, number of terms it appends)
     for (uint32_t g : cs.gates) emitters.push_back({[g](Program&, Lowering& low, std::vector<Src>& terms) { terms.push_back(low.lower(g)); }, 1});
     if (!cs.perm.empty()) {
-        const uint32_t s_l0 = slot({S_L0}, pk.l0), s_ll = slot({S_LLAST}, pk.l_last), s_la = slot({S_LACT}, pk.l_active), s_x = slot({S_X}, pk.x_coset);
+        const uint32_t s_l0 = slot({S_L0}, pk.l0, -1, true), s_ll = slot({S_LLAST}, pk.l_last, -1, true), s_la = slot({S_LACT}, pk.l_active, -1, true),
+                       s_x = slot({S_X}, pk.x_coset, -1, true);
         const uint32_t nz = (uint32_t)z_cosets.size();
         std::vector<uint32_t> zc;
         for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j], own(z_owner, j)));
@@ -1622,7 +1664,7 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
             std::vector<uint32_t> v_slots, s_slots, bd_idx;
             for (uint32_t i = 0; i < chunk.size(); i++) {
                 v_slots.push_back(col_slot(chunk[i].first, chunk[i].second));
-                s_slots.push_back(slot({S_SIGMA, pos + i}, pk.sigma_cosets[pos + i]));
+                s_slots.push_back(slot({S_SIGMA, pos + i}, pk.sigma_cosets[pos + i], -1, true));
                 Q.chal.push_back(beta * delta.pow(pos + i));
                 bd_idx.push_back((uint32_t)Q.chal.size() - 1);
             }
@@ -1643,7 +1685,7 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
         }
     }
     if (!cs.lookups.empty()) {
-        const uint32_t s_l0 = slot({S_L0}, pk.l0), s_ll = slot({S_LLAST}, pk.l_last), s_la = slot({S_LACT}, pk.l_active);
+        const uint32_t s_l0 = slot({S_L0}, pk.l0, -1, true), s_ll = slot({S_LLAST}, pk.l_last, -1, true), s_la = slot({S_LACT}, pk.l_active, -1, true);
         Q.chal.push_back(theta);
         const uint32_t theta_idx = (uint32_t)Q.chal.size() - 1;
         for (uint32_t i = 0; i < cs.lookups.size(); i++) {
@@ -2084,6 +2126,12 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
                         hp[sl] = std::max(hp[sl], r);
                     }
         auto remote = [&](size_t sl) { return owners && Q.owner[sl] >= 0 && (uint32_t)Q.owner[sl] != topo.rank; };
+        // first row of coset b inside a resident column: key columns hold cosets [pk.coset_first, +pk.coset_count) only
+        auto coset_row = [&](size_t sl, uint32_t b) -> size_t {
+            if (!Q.key[sl]) return (size_t)b * n;
+            invalid(b < pk.coset_first || b >= pk.coset_first + pk.coset_count, "the proving key was loaded for another sharding (it does not hold this coset)");
+            return (size_t)(b - pk.coset_first) * n;
+        };
         // slabs of the columns other ranks own, one per (my unit, remote slot); the exchange lists in the SAME order on both sides:
         // by receiving unit, then by slot, then by piece
         std::vector<std::vector<Col>> slab(n_units, std::vector<Col>(ns));
@@ -2122,7 +2170,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             void* out = Backend::at(hnum, (size_t)b * n + rlo);
             if (split == 1) {                                                     // a whole coset: the programs as they are
                 std::vector<const void*> ptrs;
-                for (size_t sl = 0; sl < ns; sl++) ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : (Q.cols[sl] ? Backend::at(Q.cols[sl], (size_t)b * n) : nullptr));
+                for (size_t sl = 0; sl < ns; sl++) ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : (Q.cols[sl] ? Backend::at(Q.cols[sl], coset_row(sl, b)) : nullptr));
                 for (auto& prog : Q.progs) prog.run_ptrs(ptrs, Q.chal, out);
             } else {                                                              // a row range: every (column, rotation) becomes a window at rotation 0
                 for (auto& prog : Q.progs) {
@@ -2138,13 +2186,14 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
                         }
                         const int64_t start = ((((int64_t)rlo + sh) % (int64_t)n) + n) % n;
                         const Col& col = Q.cols[sl];
+                        const size_t row0 = coset_row(sl, b);
                         if (start + (int64_t)len <= (int64_t)n) {
-                            ptrs.push_back(Backend::at(col, (size_t)b * n + (size_t)start));
+                            ptrs.push_back(Backend::at(col, row0 + (size_t)start));
                         } else {                                                  // the window wraps around the coset
                             Col t = be.alloc(len);
                             const size_t first = (size_t)((int64_t)n - start);
-                            be.scale_into(Backend::at(col, (size_t)b * n + (size_t)start), be.one, t->ptr(), first);
-                            be.scale_into(Backend::at(col, (size_t)b * n), be.one, Backend::at(t, first), len - first);
+                            be.scale_into(Backend::at(col, row0 + (size_t)start), be.one, t->ptr(), first);
+                            be.scale_into(Backend::at(col, row0), be.one, Backend::at(t, first), len - first);
                             stitched.push_back(t);
                             ptrs.push_back(t->ptr());
                         }
@@ -2710,6 +2759,19 @@ int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_va
         prepare_quotient(*(*out)->pk);      // `setup` pays hiprtc for the circuit's sweep kernel (cached on disk): the first `prove` does not
     });
 }
+// which cosets of the extended domain the key's extended columns hold (owner mode: the ones this rank sweeps) and how many bytes of HBM
+// the key occupies: out[0] = first coset, out[1] = count, out[2] = E, out[3] = resident key bytes
+int ezkl_prover_pk_residency(ezkl_pk_t pk, uint64_t out[4]) {
+    if (!pk || !out) return EZKL_ERR_INVALID;
+    const ProvingKey& k_ = *pk->pk;
+    const ConstraintSystem& cs = *k_.cs;
+    const uint64_t E = 1ull << (cs.ext_k - cs.k), n = cs.n;
+    out[0] = k_.coset_first; out[1] = k_.coset_count; out[2] = E;
+    const uint64_t small = (uint64_t)(k_.fixed_values.size() + k_.fixed_polys.size() + k_.sigma_values.size() + k_.sigma_polys.size() + 1) * n * 32;
+    const uint64_t ext = (uint64_t)(k_.fixed_cosets.size() + k_.sigma_cosets.size() + 4) * k_.coset_count * n * 32;
+    out[3] = small + ext;
+    return EZKL_OK;
+}
 int ezkl_prover_pk_sweep_stats(ezkl_pk_t pk, uint64_t out[4]) {
     if (!pk || !out) return EZKL_ERR_INVALID;
     return guarded([&] { sweep_stats(*pk->pk, out); });
@@ -3078,6 +3140,20 @@ int ezkl_prover_group_keygen(ezkl_group_t grp, const void* const* fixed_values, 
         if (!grp->g[r]) return (int)EZKL_ERR_INVALID;
         if (grp->pk[r]) { (void)ezkl_prover_pk_free(grp->pk[r]); grp->pk[r] = nullptr; }
         return ezkl_prover_keygen(grp->cs[r], grp->g[r], fixed_values, copies, n_copies, &grp->pk[r]);
+    });
+}
+// load_pk for the group (/root/reference/src/pfsys/mod.rs:615-636: execute::prove READS pk.key, it does not run keygen): every context's
+// thread maps the file and loads it through ezkl_prover_pk_read_file -- the n-row sections cross that context's PCIe link, the coefficient
+// forms are recomputed on its device, and of the extended columns only the cosets that context sweeps are computed and kept (key bytes in
+// HBM / world).  recommit != 0: the fixed / permutation commitments are recomputed under the group's SRS (a key file made with another SRS).
+int ezkl_prover_group_pk_read_file(ezkl_group_t grp, const char* path, int recommit) {
+    if (!grp || !path) return EZKL_ERR_INVALID;
+    return grp->run([&](int r) {
+        if (recommit && !grp->g[r]) return (int)EZKL_ERR_INVALID;
+        if (grp->pk[r]) { (void)ezkl_prover_pk_free(grp->pk[r]); grp->pk[r] = nullptr; }
+        int rc = ezkl_prover_pk_read_file(grp->cs[r], path, &grp->pk[r]);
+        if (!rc && recommit) rc = ezkl_prover_pk_recommit(grp->pk[r], grp->g[r]);
+        return rc;
     });
 }
 int ezkl_prover_group_pk(ezkl_group_t grp, int rank, ezkl_pk_t* out) {

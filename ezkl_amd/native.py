@@ -15,7 +15,7 @@ _lib = None
 
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_group_create", "ezkl_prover_group_size", "ezkl_prover_group_free",
-           "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_sweep_stats", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
+           "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_pk_read_file", "ezkl_prover_pk_residency", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_sweep_stats", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
            "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_verify_proof_vk", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -214,6 +214,12 @@ class NativeProvingKey:
             _check(load().ezkl_prover_pk_recommit(self.h, recommit.h), "ezkl_prover_pk_recommit")
         return self
 
+    def residency(self):
+        """dict(first_coset, cosets, E, key_bytes): what of the extended key columns this key holds in HBM (ezkl_prover_pk_residency)"""
+        out = (C.c_uint64 * 4)()
+        _check(load().ezkl_prover_pk_residency(self.h, out), "ezkl_prover_pk_residency")
+        return dict(first_coset=int(out[0]), cosets=int(out[1]), E=int(out[2]), key_bytes=int(out[3]))
+
     def sweep_stats(self):
         """per extended row of this key's quotient sweep: (instructions, Montgomery products, column slots, kernels)"""
         out = (C.c_uint64 * 4)()
@@ -274,6 +280,7 @@ class _BorrowedKey:
         self.circuit, self.h = circuit, h
 
     vk = NativeProvingKey.vk
+    residency = NativeProvingKey.residency
 
 
 class NativeGroup:
@@ -297,6 +304,10 @@ class NativeGroup:
         fixed = [np.ascontiguousarray(v, np.uint64) for v in fixed_values]
         cp = _copies_array(copies)
         _check(load().ezkl_prover_group_keygen(self.h, _ptr_array(fixed), cp.ctypes.data_as(C.c_void_p), C.c_size_t(cp.shape[0])), "ezkl_prover_group_keygen")
+
+    def pk_read_file(self, path, recommit=False):
+        """load_pk for the group: every context reads the key file on its own thread and keeps only the cosets it sweeps"""
+        _check(load().ezkl_prover_group_pk_read_file(self.h, os.fsencode(path), C.c_int(1 if recommit else 0)), "ezkl_prover_group_pk_read_file")
 
     def pk(self, context=0):
         h = C.c_void_p()

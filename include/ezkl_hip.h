@@ -212,6 +212,11 @@ int ezkl_hip_coset_ntt_dev(const void* in_dev, void* out_dev, size_t batch, size
 int ezkl_hip_coeff_to_cosets_dev(const void* in_dev, void* out_dev, size_t batch, size_t in_stride_elems, size_t out_stride_elems,
                                  uint32_t log_n, uint32_t log_n_ext, void* stream);
 int ezkl_hip_cosets_transpose_dev(const void* in_dev, void* out_dev, uint32_t log_n, uint32_t log_n_ext, int to_natural, void* stream);
+/* the same for a RANGE of cosets: out[(b - first_coset) 2^log_n + j] = p(c_b omega^j) for b in [first_coset, first_coset + n_cosets),
+ * n_cosets a power of two (out_stride_elems >= n_cosets 2^log_n).  A rank of a sharded prover sweeps only some cosets of the extended
+ * domain and needs only those cosets of the key columns (fixed, sigma, l0 / l_last / l_active): 1 / world of the bytes and of the work. */
+int ezkl_hip_coeff_to_cosets_range_dev(const void* in_dev, void* out_dev, size_t batch, size_t in_stride_elems, size_t out_stride_elems,
+                                       uint32_t log_n, uint32_t log_n_ext, uint32_t first_coset, uint32_t n_cosets, void* stream);
 
 /* ---- element-wise Fr vector ops (icicle vec-ops surface) on device-resident data ---- */
 #define EZKL_VEC_ADD 0

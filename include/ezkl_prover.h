@@ -120,6 +120,10 @@ int ezkl_prover_group_size(ezkl_group_t group);
 int ezkl_prover_group_free(ezkl_group_t group);
 int ezkl_prover_group_load_srs(ezkl_group_t group, const void* g_points, const void* g_lagrange_points, size_t n);
 int ezkl_prover_group_keygen(ezkl_group_t group, const void* const* fixed_values, const uint32_t* copies, size_t n_copies);
+/* load_pk for the group (/root/reference/src/pfsys/mod.rs:615-636: `ezkl prove` reads pk.key): every context loads the file through
+ * ezkl_prover_pk_read_file on its own thread and keeps, of the extended columns, only the cosets it sweeps (key bytes in HBM / contexts);
+ * recommit != 0 recomputes the commitments under the group's SRS (ezkl_prover_pk_recommit) */
+int ezkl_prover_group_pk_read_file(ezkl_group_t group, const char* path, int recommit);
 int ezkl_prover_group_pk(ezkl_group_t group, int context, ezkl_pk_t* out);          /* borrowed: the key of one context (vk, verify_proof) */
 int ezkl_prover_group_create_proof(ezkl_group_t group, const void* const* advice, const void* const* instances, const uint32_t* instance_lens,
                                    uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings, uint64_t* stats);
@@ -144,6 +148,10 @@ int ezkl_prover_pk_free(ezkl_pk_t pk);
 /* the quotient sweep of this key, per extended row: out = [instructions, Montgomery products, column slots read, kernels].  For rooflines
  * (bench.py): one launch of the sweep runs 2^k rows of it. */
 int ezkl_prover_pk_sweep_stats(ezkl_pk_t pk, uint64_t out[4]);
+/* which cosets of the extended domain the key's extended columns hold and what the key occupies in HBM: out = [first coset, count, E,
+ * resident key bytes].  One prover per GPU holds all E cosets; in owner mode (ezkl_prover_cs_set_shard_exchange / _comm before keygen or
+ * pk_read_file) a rank computes and keeps only the cosets it sweeps. */
+int ezkl_prover_pk_residency(ezkl_pk_t pk, uint64_t out[4]);
 int ezkl_prover_pk_write(ezkl_pk_t pk, void* out, size_t cap, size_t* len);
 int ezkl_prover_pk_read(ezkl_cs_t cs, const void* buf, size_t len, ezkl_pk_t* out);
 /* load_pk for a one-shot `prove`: maps the key file and uploads only its n-row sections (fixed values, permutations); coefficient forms,

@@ -216,6 +216,19 @@ def test_coset_major_matches_oracle(hip, golden_pk, k, ek):
         if (k, ek) == (6, 9):
             assert (want == golden_pk["fixed_cosets"][b]).all()
         assert (got[b] == _to_cm(want, k, ek)).all()
+    # a RANGE of cosets (what one rank of a sharded prover keeps of a key column): every aligned power-of-two range equals the slice
+    E = 1 << (ek - k)
+    cnt = 1
+    while cnt <= E:
+        for first in range(0, E, cnt):
+            dr = B.DeviceBuffer.from_numpy(np.zeros((batch, cnt * n, 4), np.uint64))
+            B.coeff_to_cosets_range_dev(din.ptr, dr.ptr, k, ek, first, cnt, batch=batch)
+            assert (dr.to_numpy(shape=(batch, cnt * n, 4)) == got[:, first * n:(first + cnt) * n]).all(), (first, cnt)
+            if E > 8 and first >= 2 * cnt:
+                break
+        cnt *= 2
+    with pytest.raises(Exception):
+        B.coeff_to_cosets_range_dev(din.ptr, dout.ptr, k, ek, E - 1, 2)
     # the transposition both ways
     dnat = B.DeviceBuffer.from_numpy(np.zeros((ne, 4), np.uint64))
     B.cosets_transpose_dev(dout.ptr, dnat.ptr, k, ek, to_natural=True)

@@ -27,25 +27,59 @@ else:                                           # one context per visible device
     L.check(L.load().ezkl_hip_init(-1), "init")
 assert B.context_count() >= world, (B.context_count(), world)
 import bench_circuits as BC
-built = BC.build(circuit, k, gpu=B, base=128)         # small range-check tables (16-20 lookups): the default base makes a 137-lookup circuit at k = 10 whose sweep program takes hiprtc minutes
-cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
 s = 0x1234567890abcdef1234567890abcdef % P.R
+key_file = None
+if circuit == "fixture":                        # the reference's own circuit, witness and pk.key (tests/golden): load_pk, not keygen
+    sys.path.insert(0, os.path.join(os.environ["EZKL_ROOT"], "tests"))
+    import fixture_k6 as FX
+    fx = FX.load()
+    k, cs = 6, fx["cs"]
+    adv_i, instances, _ = FX.witness(fx)
+    adv = FX.mont_cols(adv_i)
+    key_file = os.path.join(FX.G, "pk_k6.key")
+else:
+    built = BC.build(circuit, k, gpu=B, base=128)     # small range-check tables (16-20 lookups): the default base makes a 137-lookup circuit at k = 10 whose sweep program takes hiprtc minutes
+    cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
 gb, glb = B.gen_srs(k, s)
 g, gl = gb.download(), glb.download()
 # the one-context prover: the reference bytes
-npk = NV.NativeProvingKey(NV.NativeCircuit(cs), gb, fixed, copies)
+if key_file:
+    npk = NV.NativeProvingKey.from_file(NV.NativeCircuit(cs), key_file, recommit=gb)      # the file's commitments were made under the public SRS
+else:
+    npk = NV.NativeProvingKey(NV.NativeCircuit(cs), gb, fixed, copies)
 want = NV.create_proof(npk, gb, glb, adv, seed=7, instances=instances)
 grp = NV.NativeGroup(cs, world)
 grp.load_srs(g, gl)
-grp.keygen(fixed, copies)
+if key_file:
+    grp.pk_read_file(key_file, recommit=True)
+else:
+    grp.keygen(fixed, copies)
 stats, tm = [], {}
 got = grp.create_proof(adv, seed=7, instances=instances, timings=tm, stats=stats)
 again = grp.create_proof(adv, seed=7, instances=instances)
 ok = NV.verify_proof(grp.pk(0), NV.g2_mul_generator(1), NV.g2_mul_generator(s), got, instances)
 fresh = grp.create_proof(adv, seed=0, instances=instances)          # OS entropy: one 256-bit key shared by the threads
 ok_fresh = NV.verify_proof(grp.pk(0), NV.g2_mul_generator(1), NV.g2_mul_generator(s), fresh, instances)
+# load_pk for the group (ezkl_prover_group_pk_read_file): the key written by the one-context prover, read back by every context --
+# same proof bytes, and each context holds only the cosets it sweeps
+import tempfile
+with tempfile.TemporaryDirectory() as d:
+    path = key_file or os.path.join(d, "pk.key")
+    if not key_file:
+        open(path, "wb").write(npk.to_bytes())
+    grp2 = NV.NativeGroup(cs, world)
+    grp2.load_srs(g, gl)
+    grp2.pk_read_file(path, recommit=bool(key_file))
+    from_file = grp2.create_proof(adv, seed=7, instances=instances)
+    res = [grp2.pk(r).residency() for r in range(grp2.world)]
+    rewritten_equal = None
+    if not key_file:                            # a key held by owner writes the same file (the complete extended columns are recomputed)
+        pk0 = grp2.pk(0)
+        rewritten_equal = NV.NativeProvingKey.to_bytes(pk0) == npk.to_bytes()
+    grp2.free()
 print(json.dumps({"world": grp.world, "contexts": B.context_count(), "same_bytes": got == want, "repeatable": again == got, "verifier_accepts": bool(ok),
-                  "fresh_randomness_differs": fresh != got, "fresh_verifies": bool(ok_fresh), "stats": stats, "total_seconds": tm.get("total")}))
+                  "fresh_randomness_differs": fresh != got, "fresh_verifies": bool(ok_fresh), "stats": stats, "total_seconds": tm.get("total"),
+                  "from_file_same_bytes": from_file == want, "residency": res, "one_context_residency": npk.residency(), "rewritten_equal": rewritten_equal}))
 grp.free()
 '''
 
@@ -59,7 +93,7 @@ def _run(mode, world, circuit, k):
     return json.loads(lines[-1])
 
 
-@pytest.mark.parametrize("world,circuit,k", [(2, "mlp", 9), (4, "mlp", 10)])
+@pytest.mark.parametrize("world,circuit,k", [(2, "mlp", 9), (4, "mlp", 10), (2, "fixture", 6)])
 def test_group_of_contexts_on_one_device_same_bytes(hip, world, circuit, k):
     """(k = 20 with 2 and 4 contexts: tools/prove_group.py, DESIGN.md §5.2 -- too slow for the suite)"""
     j = _run("same-device", world, circuit, k)
@@ -69,6 +103,14 @@ def test_group_of_contexts_on_one_device_same_bytes(hip, world, circuit, k):
     done = [s["columns_transformed_here"] for s in j["stats"]]
     assert sum(done) == total and max(done) < total
     assert all(s["exchange_bytes_received"] > 0 for s in j["stats"])
+    # load_pk for the group: same bytes from the key FILE, and every context holds only its share of the extended key columns
+    assert j["from_file_same_bytes"] and j["rewritten_equal"] in (True, None)
+    E = j["one_context_residency"]["E"]
+    assert j["one_context_residency"]["cosets"] == E
+    per = max(1, E // world)
+    assert [r["cosets"] for r in j["residency"]] == [per] * world
+    assert sorted({r["first_coset"] for r in j["residency"]}) == sorted({(q * E // world) if world <= E else q // (world // E) for q in range(world)})
+    assert all(r["key_bytes"] < j["one_context_residency"]["key_bytes"] for r in j["residency"])
 
 
 def test_group_one_context_per_device(hip):

@@ -115,6 +115,10 @@ nproofs = 1 + len(runs)
 stats = dict(stats, rccl_ranks_seen=cw, rccl_rank=cr, exchange_calls_per_proof=cst["exchanges"] / nproofs, exchange_bytes_sent_per_proof=cst["bytes_sent"] / nproofs,
              exchange_ms_per_proof=round(1e3 * cst["seconds"] / nproofs, 3), nccl_sends_per_proof=cst["nccl_sends"] / nproofs, nccl_recvs_per_proof=cst["nccl_recvs"] / nproofs,
              exchange_rounds_per_proof=cst["rounds"] / nproofs)
+res = npk.residency()
+free_b, total_b = B.mem_info()
+stats = dict(stats, key_cosets_held="%d of %d" % (res["cosets"], res["E"]), key_gib=round(res["key_bytes"] / 2**30, 3), hbm_in_use_gib=round((total_b - free_b) / 2**30, 2),
+             hbm_pool_high_water_gib=round(B.pool_stats()["live_peak"] / 2**30, 2))
 sha = hashlib.sha256(proof).hexdigest()
 if world > 1:
     import torch
