@@ -128,6 +128,18 @@ class _Bases:
         self.h = h
         return self
 
+    def downsize(self, new_k):
+        """halo2 ParamsKZG::downsize on a coefficient-basis set: (first 2^new_k points, Lagrange basis of the 2^new_k domain) as new
+        resident base sets -- the Lagrange basis is an inverse NTT over G1 on the device (ezkl_hip_bases_downsize)"""
+        hg, hl = _vp(), _vp()
+        _l.check(_l.load().ezkl_hip_bases_downsize(self.h, C.c_uint32(new_k), C.byref(hg), C.byref(hl)), "ezkl_hip_bases_downsize")
+        out = []
+        for h in (hg, hl):
+            b = type(self).__new__(type(self))
+            b.n, b.h = 1 << new_k, h
+            out.append(b)
+        return tuple(out)
+
     def download(self):
         out = np.empty((self.n, 8), np.uint64)
         _l.check(_l.load().ezkl_hip_bases_download(self.h, _p(out)), "ezkl_hip_bases_download")
@@ -291,6 +303,18 @@ class ParamsKZG:
         g = np.frombuffer(buf, np.uint64, count=8 * n, offset=4).reshape(n, 8)
         gl = np.frombuffer(buf, np.uint64, count=8 * n, offset=4 + 64 * n).reshape(n, 8)
         return cls(k, g, gl)
+
+    def downsize(self, new_k):
+        """ParamsKZG::downsize (halo2; /root/reference/src/execute.rs:1739-1750 calls it whenever the SRS file is larger than the circuit):
+        truncate g, rebuild g_lagrange for the smaller domain (an inverse NTT over G1, on the device).  In place, like halo2's."""
+        if new_k > self.k:
+            raise ValueError("cannot downsize a k=%d SRS to k=%d" % (self.k, new_k))
+        if new_k == self.k:
+            return self
+        g, gl = self._g.downsize(new_k)
+        self._g.free(); self._gl.free()
+        self._g, self._gl, self.k, self.n = g, gl, new_k, 1 << new_k
+        return self
 
     def commit_lagrange(self, poly):
         """MSM against g_lagrange; returns the canonical affine point (8 x u64). Blind is ignored by KZG."""

@@ -46,8 +46,9 @@ def write_srs(srs):
 
 
 def downsize_srs(srs, k):
-    """ParamsKZG::downsize for the coefficient basis (src/execute.rs:1739-1750).  g_lagrange of the smaller domain is
-    NOT a prefix of the larger one; halo2 recomputes it with an inverse FFT over G1, which is out of scope here."""
+    """ParamsKZG::downsize for the coefficient basis only (src/execute.rs:1739-1750).  g_lagrange of the smaller domain is NOT a prefix
+    of the larger one: halo2 recomputes it with an inverse FFT over G1 -- on the device: ezkl_amd.backend.ParamsKZG.downsize /
+    execute.load_params_prover (ezkl_hip_bases_downsize)."""
     if k > srs["k"]:
         raise ValueError("cannot upsize")
     return dict(k=k, g=srs["g"][: 1 << k], g_lagrange=None, g2=srs["g2"], s_g2=srs["s_g2"])

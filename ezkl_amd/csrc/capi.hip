@@ -585,6 +585,51 @@ int ezkl_hip_bases_from_scalars(const void* base_point, const void* scalars_dev,
     *out = reinterpret_cast<ezkl_bases_t>(b);
     return EZKL_OK;
 }
+// ParamsKZG::downsize (see g1_to_lagrange in msm.hip): out_g = the first 2^new_k points of g (a device copy), out_g_lagrange = the
+// Lagrange basis of the 2^new_k-point domain = the inverse NTT over G1 of those points
+static fe_t domain_omega(uint32_t k, bool inverse);
+int ezkl_hip_bases_downsize(ezkl_bases_t g, uint32_t new_k, ezkl_bases_t* out_g, ezkl_bases_t* out_g_lagrange) {
+    if (!g || !out_g_lagrange || new_k > 28) return EZKL_ERR_INVALID;
+    Bases* src = reinterpret_cast<Bases*>(g);
+    const size_t n = (size_t)1 << new_k;
+    if (src->n < n) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    Bases *bg = nullptr, *bl = new Bases();
+    bl->n = n;
+    fe_t* tw = nullptr;
+    int rc = EZKL_OK;
+    hipError_t e = hipMalloc(&bl->pts, n * 64);
+    if (e == hipSuccess && n > 1) e = hipMalloc(&tw, (n / 2) * sizeof(fe_t));
+    if (e != hipSuccess) rc = set_hip_error(e, "ezkl_hip_bases_downsize", __FILE__, __LINE__);
+    if (!rc && n > 1) {                                    // tw[e] = omega^-e: fill with omega^-1, exclusive product scan
+        rc = vec_fill(c, c->stream, tw, domain_omega(new_k, true), n / 2);
+        if (!rc) rc = prefix_scan(c, c->stream, EZKL_VEC_MUL, 1, tw, tw, n / 2);
+    }
+    if (!rc) {
+        fe_t ninv = Fr::one();
+        const fe_t half = Fr::inv(Fr::add(Fr::one(), Fr::one()));
+        for (uint32_t i = 0; i < new_k; i++) ninv = Fr::mul(ninv, half);
+        rc = g1_to_lagrange(c, c->stream, src->pts, new_k, tw, ninv, bl->pts);
+    }
+    if (!rc && out_g) {
+        bg = new Bases();
+        bg->n = n;
+        e = hipMalloc(&bg->pts, n * 64);
+        if (e == hipSuccess) e = hipMemcpyAsync(bg->pts, src->pts, n * 64, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = set_hip_error(e, "ezkl_hip_bases_downsize", __FILE__, __LINE__);
+    }
+    if (tw) (void)hipFree(tw);
+    if (rc) {
+        if (bl->pts) (void)hipFree(bl->pts);
+        delete bl;
+        if (bg) { if (bg->pts) (void)hipFree(bg->pts); delete bg; }
+        return rc;
+    }
+    if (out_g) *out_g = reinterpret_cast<ezkl_bases_t>(bg);
+    *out_g_lagrange = reinterpret_cast<ezkl_bases_t>(bl);
+    return EZKL_OK;
+}
 size_t ezkl_hip_bases_len(ezkl_bases_t h) { return h ? reinterpret_cast<Bases*>(h)->n : 0; }
 
 int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, void* out, void* stream) {

@@ -1426,6 +1426,74 @@ int g1_mul_fixed(Ctx* c, hipStream_t st, const void* base_host, const fe_t* scal
     return EZKL_OK;
 }
 
+// ---- ParamsKZG::downsize: g_lagrange of a smaller domain = the INVERSE NTT OVER G1 of the first 2^k' points of g ----------------------
+// halo2's ParamsKZG::downsize(new_k) (called by load_params_prover, /root/reference/src/execute.rs:1739-1750, whenever the SRS file is
+// larger than the circuit -- the normal case with a shared kzg22.srs) truncates g and rebuilds g_lagrange with g_to_lagrange: an FFT on
+// projective points with omega^-1 followed by a scaling by 1 / n'.  Here: decimation in time on XYZZ points in HBM (bit-reversed load,
+// natural-order result), one thread per butterfly (P, Q) -> (P + w Q, P - w Q) with w Q by double-and-add over the canonical bits of
+// the twiddle, then one more pass that scales by 1 / n' and normalises to affine.  n' / 2 * k' + n' scalar multiplications of ~380 group
+// operations each: 0.5 s at k' = 20 -- a load-time operation (the CPU reference spends minutes here), bound by the field-product rate.
+__device__ __forceinline__ g1x_t g1x_scalar_mul(const g1x_t& p, const fe_t& s_canon) {
+    g1x_t acc = g1x_identity();
+    bool started = false;
+#pragma unroll 1
+    for (int b = 253; b >= 0; b--) {
+        if (started) acc = g1x_double(acc);
+        if ((s_canon.v[b >> 5] >> (b & 31)) & 1) {
+            acc = started ? g1x_add(acc, p) : p;
+            started = true;
+        }
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void ecntt_load_kernel(const g1a_t* g, g1x_t* work, uint32_t log_n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << log_n)) return;
+    const uint32_t r = log_n ? (__brev(i) >> (32 - log_n)) : 0u;
+    st_g1x(work + r, g1x_from_affine(ld_g1a(g + i)));
+}
+// stage s (1-based): blocks of len = 2^s; butterfly j of a block takes twiddle tw[j << (log_n - s)] (tw[e] = omega^-e, canonical)
+__global__ __launch_bounds__(256) void ecntt_stage_kernel(g1x_t* work, const fe_t* tw, uint32_t log_n, uint32_t s) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (1u << (log_n - 1))) return;
+    const uint32_t half = 1u << (s - 1), j = t & (half - 1), blk = t >> (s - 1);
+    const uint32_t lo = (blk << s) + j, hi = lo + half;
+    const g1x_t P = ld_g1x(work + lo);
+    g1x_t Q = ld_g1x(work + hi);
+    if (j) Q = g1x_scalar_mul(Q, ld_fe(tw + ((size_t)j << (log_n - s))));       // j = 0: twiddle 1 (wave-uniform only in the first stages; correct everywhere)
+    g1x_t nQ = Q;
+    nQ.y = Fq::neg(Q.y);
+    st_g1x(work + lo, g1x_add(P, Q));
+    st_g1x(work + hi, g1x_add(P, nQ));
+}
+__global__ __launch_bounds__(256) void ecntt_finish_kernel(const g1x_t* work, fe_t ninv_canon, g1a_t* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_g1a(out + i, g1x_to_affine(g1x_scalar_mul(ld_g1x(work + i), ninv_canon)));
+}
+__global__ __launch_bounds__(256) void ecntt_twiddle_kernel(fe_t* tw, uint32_t count) {      // Montgomery -> canonical, in place
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) st_fe(tw + i, Fr::from_mont(ld_fe(tw + i)));
+}
+// out (n' affine points) = g_to_lagrange(g[0 .. n')), n' = 2^log_n.  tw_mont: n' / 2 resident Montgomery powers omega^-e, e < n' / 2
+// (consumed: converted in place); ninv_mont = 1 / n'
+int g1_to_lagrange(Ctx* c, hipStream_t st, const void* g_dev, uint32_t log_n, fe_t* tw_mont, const fe_t& ninv_mont, void* out_dev) {
+    (void)c;
+    const uint32_t n = 1u << log_n;
+    g1x_t* work = nullptr;
+    EZ_HIP(hipMalloc(&work, (size_t)n * sizeof(g1x_t)));
+    hipLaunchKernelGGL(ecntt_load_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const g1a_t*)g_dev, work, log_n);
+    if (n > 1) hipLaunchKernelGGL(ecntt_twiddle_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, st, tw_mont, n / 2);
+    for (uint32_t s = 1; s <= log_n; s++)
+        hipLaunchKernelGGL(ecntt_stage_kernel, dim3(cdiv(n / 2, 256)), dim3(256), 0, st, work, (const fe_t*)tw_mont, log_n, s);
+    hipLaunchKernelGGL(ecntt_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const g1x_t*)work, Fr::from_mont(ninv_mont), (g1a_t*)out_dev, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(work);
+    if (e != hipSuccess) return set_hip_error(e, "g1_to_lagrange", __FILE__, __LINE__);
+    return EZKL_OK;
+}
+
 void g1_add_affine_host(const void* a, const void* b, void* out) {
     h64::aff p, q;
     memcpy(&p, a, 64);

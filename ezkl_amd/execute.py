@@ -14,6 +14,7 @@ is refused by name.  On the fixture model that layout reproduces the reference's
 description of the same family ({"model": "mlp", "run_args": {...}, "weights": [...], "biases": [...]}) is accepted as well.
 Errors surface as exceptions with the reference's wording where it has one."""
 import json
+import os
 
 import numpy as np
 
@@ -88,12 +89,23 @@ def _mlp_of_graph(model):
 
 
 def load_params_prover(srs_path, logrows):
-    """execute.rs:1739-1750: read the SRS, downsize if the file is larger (coefficient basis only: see codecs.downsize_srs)"""
+    """execute.rs:1739-1750: read the SRS and, if the file is larger than the circuit (the normal case with a shared kzg22.srs),
+    `params.downsize(logrows)`: the coefficient basis is truncated, the Lagrange basis of the smaller domain is rebuilt on the device by an
+    inverse NTT over G1 (ezkl_hip_bases_downsize = halo2's g_to_lagrange)"""
     srs = codecs.read_srs(open(srs_path, "rb").read())
     if srs["k"] < logrows:
         raise ValueError("SRS too small: k=%d < logrows=%d" % (srs["k"], logrows))
     if srs["k"] > logrows:
-        raise ValueError("downsizing g_lagrange needs an inverse FFT over G1 (halo2 ParamsKZG::downsize): supply an SRS of k=%d" % logrows)
+        n = 1 << logrows
+        big = B.Bases(np.ascontiguousarray(srs["g"][:n]))
+        try:
+            g, gl = big.downsize(logrows)
+            try:
+                srs = dict(k=logrows, g=g.download(), g_lagrange=gl.download(), g2=srs["g2"], s_g2=srs["s_g2"])
+            finally:
+                g.free(); gl.free()
+        finally:
+            big.free()
     return srs
 
 
@@ -129,8 +141,7 @@ def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_m
     if w["outputs"] and inst != w["outputs"]:
         raise ValueError("the witness file's outputs do not match the circuit's outputs")
     ncs = _plonk_cs(circuit)
-    srs_bytes = open(srs_path, "rb").read()
-    srs = codecs.read_srs(srs_bytes)
+    srs = load_params_prover(srs_path, circuit.k)                               # downsizes an SRS file larger than the circuit
     bg, bgl = B.Bases(srs["g"]), B.Bases(srs["g_lagrange"])
     try:
         # recommit: the key file's commitments were made under ANOTHER SRS (the reference's fixture key: the public powers of tau)
@@ -143,14 +154,22 @@ def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_m
     return proof
 
 
-def verify(proof_path, compiled_circuit, vk_path, srs_path, recommit=False):
+def verify(proof_path, compiled_circuit, vk_path=None, srs_path=None, recommit=False, pk_path=None):
     """-> True / False, from the proof, the compiled circuit (settings), vk.key and the SRS's g2 / s_g2 -- what the reference's `verify`
     reads (src/execute.rs:1651).  Host only: no GPU, no proving key, none of the prover's private weights.  A pk.key path works too (vk.key
     is its prefix).  recommit=True (a key whose commitments were made under another SRS, re-committed by `prove`) needs the proving key and
     a device: the fixed / permutation polynomials are committed again under this SRS first."""
+    if vk_path is None:
+        vk_path = pk_path                                                       # the parameter's former name (ADVICE r03): keyword callers keep working
+    if vk_path is None or srs_path is None:
+        raise TypeError("verify needs a vk.key (or pk.key) path and an SRS path")
     circuit, j = _load_circuit(compiled_circuit)
     pr = codecs.read_proof_json(open(proof_path).read())
     srs = codecs.read_srs(open(srs_path, "rb").read())
+    if recommit:
+        vk_len = 7 + 64 * (_plonk_cs(circuit).n_fixed + len(_plonk_cs(circuit).perm))
+        if os.path.getsize(vk_path) < 4 * vk_len:                               # a vk-only file has no polynomials to commit again
+            raise ValueError("recommit=True needs the PROVING key file (its polynomials are committed again under this SRS); %s is a verifying key" % vk_path)
     if not recommit:
         return NV.verify_proof_vk(NV.NativeCircuit(_plonk_cs(circuit)), open(vk_path, "rb").read(), srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])
     bg = B.Bases(srs["g"])

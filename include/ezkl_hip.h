@@ -126,6 +126,12 @@ int ezkl_hip_bases_download(ezkl_bases_t h, void* out_host /* n x 64 B */);
  * generation for tests (gen_srs -> ParamsKZG::setup, /root/reference/src/pfsys/srs.rs:14-16): g[i] = s^i G,
  * g_lagrange[i] = L_i(s) G */
 int ezkl_hip_bases_from_scalars(const void* base_point, const void* scalars_dev, size_t n, ezkl_bases_t* out_handle);
+/* ParamsKZG::downsize(new_k) -- halo2; called by load_params_prover (/root/reference/src/execute.rs:1739-1750) whenever the SRS file is
+ * larger than the circuit, the normal case with a shared kzg22.srs: `g` (at least 2^new_k points of the coefficient basis s^i G) ->
+ * out_g = its first 2^new_k points (may be NULL), out_g_lagrange = the Lagrange basis of the 2^new_k-point domain, L_i(s) G, computed as
+ * halo2's g_to_lagrange does: an inverse NTT over G1 (omega^-1 butterflies on group elements, scaled by 1 / 2^new_k).  New handles,
+ * freed with ezkl_hip_bases_free. */
+int ezkl_hip_bases_downsize(ezkl_bases_t g, uint32_t new_k, ezkl_bases_t* out_g, ezkl_bases_t* out_g_lagrange);
 /* sum_i scalars[i] * bases[offset + i], i < n.  scalars: n x 32 B Montgomery Fr (host pointer, borrowed).
  * out_affine: 64 B, caller-allocated, canonical affine ((0,0) if the sum is the identity). */
 int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out_affine);

@@ -67,3 +67,29 @@ def test_prove_from_the_reference_artefact_files_only(hip, tmp_path):
     X.setup(g("model_k6.compiled"), g("kzg_k6.srs"), str(vk_path), str(pk_path))
     mine, ref = pk_path.read_bytes(), open(g("pk_k6.key"), "rb").read()
     assert len(mine) == len(ref) and mine[:7] == ref[:7] and mine[7 + 64 * 70:] == ref[7 + 64 * 70:]
+
+
+def test_prove_with_a_larger_srs_file_downsizes(hip, tmp_path):
+    """load_params_prover (src/execute.rs:1739-1750): an SRS file larger than the circuit is downsized -- same key file and the same proof
+    bytes (det-prove seed) as with an SRS file of exactly the circuit's size made from the same secret"""
+    from ezkl_amd import backend as B, codecs, execute as X, native as NV, plonk as P
+    st = json.load(open(os.path.join(FX.G, "settings_k6.json")))
+    compiled = tmp_path / "model.compiled.json"
+    compiled.write_text(json.dumps({"model": "mlp", "run_args": st["run_args"], "weights": [FIXTURE_W], "biases": [FIXTURE_B],
+                                    "total_assignments": st["total_assignments"]}))
+    s_ = 0x0123456789abcdef0fedcba987654321 % P.R
+    files = {}
+    for k in (6, 9):
+        g, gl = B.gen_srs(k, s_)
+        path = tmp_path / ("kzg%d.srs" % k)
+        path.write_bytes(codecs.write_srs(dict(k=k, g=g.download(), g_lagrange=gl.download(), g2=NV.g2_mul_generator(1), s_g2=NV.g2_mul_generator(s_))))
+        g.free(); gl.free()
+        files[k] = str(path)
+    out = {}
+    for k in (6, 9):
+        vk_path, pk_path, proof_path = tmp_path / ("vk%d.key" % k), tmp_path / ("pk%d.key" % k), tmp_path / ("proof%d.json" % k)
+        X.setup(str(compiled), files[k], str(vk_path), str(pk_path))
+        proof = X.prove(os.path.join(FX.G, "witness_k6.json"), str(compiled), str(pk_path), str(proof_path), files[k], X.CheckMode.SAFE, seed=42)
+        assert X.verify(str(proof_path), str(compiled), str(vk_path), files[k])
+        out[k] = (pk_path.read_bytes(), proof)
+    assert out[6][0] == out[9][0] and out[6][1] == out[9][1]

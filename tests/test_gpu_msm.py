@@ -474,3 +474,48 @@ def test_concurrent_callers_overlap(hip):
     assert all((a == b).all() for a, b in zip(got, want))
     print("4 MSMs of 2^18: serial %.3f ms, 4 threads %.3f ms" % (t_serial * 1e3, t_par * 1e3))
     assert t_par < 1.25 * t_serial      # (measured 0.73x; a loose bound: the round-end run is on another box and must not flake)
+
+
+def test_params_downsize_matches_the_reference_srs_and_the_oracle(hip, golden_srs):
+    """ParamsKZG::downsize (halo2; /root/reference/src/execute.rs:1739-1750): g_lagrange of a smaller domain = inverse NTT over G1 of the
+    truncated g (ezkl_hip_bases_downsize).  Pinned three ways: (1) on the REFERENCE's k = 6 SRS file, "downsizing" to k = 6 must rebuild
+    the file's own g_lagrange section byte for byte; (2) k' = 4, 5: every point equals the oracle's MSM of the Lagrange polynomial's
+    coefficients against g, the sum of the points is g[0], and commit_lagrange(v) == commit(iNTT v) on the downsized set; (3) a device-made
+    SRS with a known secret at k = 9 downsized to 7 equals the SRS made directly at k = 7 (L_i(s) G from the closed form)."""
+    from ezkl_amd import backend as B
+    g, gl = golden_srs["g"], golden_srs["g_lagrange"]
+    bg = B.Bases(g)
+    g6, gl6 = bg.downsize(6)
+    assert (g6.download() == g).all() and (gl6.download() == gl).all()             # (1) the reference's own Lagrange basis
+    g6.free(); gl6.free()
+    rng = np.random.default_rng(77)
+    for kk in (0, 1, 4, 5):
+        n2 = 1 << kk
+        g2_, gl2 = bg.downsize(kk)
+        got = gl2.download()
+        assert (g2_.download() == g[:n2]).all()
+        acc = got[0]
+        for i in range(n2):
+            e = np.zeros((n2, 4), np.uint64); e[i] = fe_from_int(1)
+            coeffs = ob.lagrange_to_coeff(e, kk) if kk else e
+            assert (got[i] == ob.msm(coeffs, g[:n2])).all(), (kk, i)                # (2) L_i(s) G through the oracle
+            if i: acc = B.g1_add_affine(acc, got[i])
+        assert (acc == g[0]).all()
+        if kk >= 4:
+            v = rand_fr(rng, n2)
+            assert (B.msm_g1(gl2, v) == B.msm_g1(g2_, ob.lagrange_to_coeff(v, kk))).all()
+        g2_.free(); gl2.free()
+    with pytest.raises(Exception):
+        bg.downsize(7)                                                              # larger than the set
+    bg.free()
+    s_ = 0x1234567890abcdef1234567890abcdef % R
+    g9, gl9 = B.gen_srs(9, s_)
+    g7, gl7 = B.gen_srs(7, s_)
+    d7, dl7 = g9.downsize(7)
+    assert (d7.download() == g7.download()).all() and (dl7.download() == gl7.download()).all()      # (3)
+    p = hip.ParamsKZG(9, g9.download(), gl9.download())
+    p.downsize(7)
+    v = rand_fr(rng, 128)
+    assert p.k == 7 and (p.commit_lagrange(v) == B.msm_g1(gl7, v)).all()
+    for b in (g9, gl9, g7, gl7, d7, dl7): b.free()
+    p.free()
