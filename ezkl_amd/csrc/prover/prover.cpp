@@ -1609,6 +1609,19 @@ static uint32_t sweep_terms_per_program() {
     }();
     return v;
 }
+// ... and how many INSTRUCTIONS at most (EZKL_PROVER_SWEEP_INSTRS, default 640; 0 = no limit): hiprtc's time grows much faster than the
+// program -- the 529-instruction sweep of the k = 20 MLP compiles in 1.6 s, the ~1300-instruction one of the k = 22 / 30-column circuit took
+// 50 s of a 51 s key generation (profiles/r03y_mlp_k22_30cols_full.log), and hiprtc serialises concurrent compilations (4 threads: 4.7,
+// 9.7, 14.2, 18.5 s), so threads do not help -- while a sweep cut at term boundaries only re-reads the columns two kernels share.  A
+// program is closed once it has reached the limit (it may exceed it by its last emitter).
+static uint32_t sweep_instrs_per_program() {
+    static const uint32_t v = [] {
+        const char* e = getenv("EZKL_PROVER_SWEEP_INSTRS");
+        const int x = e ? atoi(e) : -1;
+        return (uint32_t)(x >= 0 ? x : 640);
+    }();
+    return v;
+}
 // Straight-line programs over the extended-coset columns: custom gates, then the permutation and lookup constraints, folded with y
 // (value = value*y + constraint), as Evaluator::evaluate_h does.  The programs are written for ONE coset (k = ext_k = cs.k: a rotation
 // by r is a shift by r rows inside the coset) and run once per coset of the extended domain.  The Horner fold starts from
@@ -1730,10 +1743,12 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
         Lowering low{cs, prog, col_slot, [&prog](uint32_t idx) { return prog.challenge(3 + idx); }, {}};
         std::vector<Src> terms;
         uint32_t count = 0;
+        const uint32_t instr_limit = sweep_instrs_per_program();
         while (e0 < emitters.size() && (count == 0 || limit == 0 || count + emitters[e0].second <= limit)) {
             emitters[e0].first(prog, low, terms);
             count += emitters[e0].second;
             e0++;
+            if (instr_limit && prog.code.size() / 8 + terms.size() >= instr_limit) break;
         }
         prog.horner(prog.previous(), terms, prog.challenge(0));
         if (emitters.empty()) break;
@@ -2756,7 +2771,11 @@ int ezkl_prover_keygen(ezkl_cs_t cs, ezkl_bases_t g, const void* const* fixed_va
     return guarded([&] {
         invalid(ezkl_hip_bases_len(g) < (cs->cs->shard.on() ? cs->cs->shard.hi - cs->cs->shard.lo : cs->cs->n), "SRS smaller than 2^k (or than this rank's slice)");
         *out = new ezkl_prover_pk{keygen(*cs->cs, g, fixed_values, copies, n_copies)};
+        const auto t0 = std::chrono::steady_clock::now();
         prepare_quotient(*(*out)->pk);      // `setup` pays hiprtc for the circuit's sweep kernel (cached on disk): the first `prove` does not
+        if (getenv("EZKL_PROVER_KEYGEN_TIMING"))
+            fprintf(stderr, "[ezkl_prover] keygen %-36s %8.1f ms\n", "sweep kernels (hiprtc or disk cache)",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     });
 }
 // which cosets of the extended domain the key's extended columns hold (owner mode: the ones this rank sweeps) and how many bytes of HBM

@@ -19,6 +19,7 @@
 #   group        prover group, 2 and 4 contexts on one device, k = 20 MLP            -> <tag>_group{2,4}.json
 #   multi2       two owner-mode ranks (gloo) sharing the device, k = 20 MLP          -> <tag>_multi2.json
 #   k22          K=22 MLP_BLOCKS=5 MLP_FILL=25 proof + HBM high-water (opt-in size)  -> <tag>_mlp_k22.log
+#   sh:<file>    bash tools/<file> (an A/B script)                                    -> <tag>_<file>.log
 #   tests:<a,b>  pytest -m gpu on the listed files                                  -> <tag>_pytest_subset.log
 #   py:<file>    python <file> (a probe under tools/)                                -> <tag>_<file>.log
 R=$(cd "$(dirname "$0")/.." && pwd); O="$R/gpurun_out"; mkdir -p "$O"
@@ -84,6 +85,8 @@ j = json.loads(sys.stdin.read()); print(j['prove_seconds_gpu_runs'], j['prove_br
     k22)
       (cd "$R" && CIRCUIT=mlp K=22 MLP_BLOCKS=5 MLP_FILL=${K22_FILL:-25} REPS=2 timeout 1500 python tools/prove_bench.py --pinned) > "$O/${TAG}_mlp_k22.log" 2>&1
       tail -1 "$O/${TAG}_mlp_k22.log" | cut -c1-1500 ;;
+    sh:*)
+      F=${JOB#sh:}; bash "$R/tools/$F" > "$O/${TAG}_${F%.sh}.log" 2>&1; tail -40 "$O/${TAG}_${F%.sh}.log" ;;
     tests:*)
       F=${JOB#tests:}; (cd "$R" && timeout ${SUITE_TIMEOUT:-900} python -m pytest $(echo "$F" | tr ',' ' ') -m gpu -q --durations=15 -p no:cacheprovider) > "$O/${TAG}_pytest_subset.log" 2>&1
       echo "pytest rc=$?" >> "$O/${TAG}_pytest_subset.log"; tail -40 "$O/${TAG}_pytest_subset.log" ;;
