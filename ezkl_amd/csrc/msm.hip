@@ -892,19 +892,28 @@ static int msm_finish(MsmSlot& sl, void* out_host = nullptr, bool release = true
 
 // how many MSMs of this size are fused into one group (gridDim.z): small MSMs are launch- and latency-bound (at 2^17 points a lone MSM
 // is 0.12 ms of accumulation inside a 0.6 ms chain of ~17 launches)
-static size_t msm_group_size(const MsmTable* T, size_t n, bool small_scalars) {
+static size_t msm_group_size(const MsmTable* T, size_t n, bool small_scalars, size_t batch = 0) {
     if (const char* e = getenv("EZKL_MSM_GROUP")) {
         const int v = atoi(e);
         if (v >= 1 && v <= (int)MSM_MAX_GROUP) return (size_t)v;
     }
-    // measured (k = 17 MLP proof, 56 MSMs, 7 proofs per setting): groups of 4 on the six slot streams 40.4-41.9 ms, no fusing 43.0-46.3,
-    // groups of 16 41.2-45.7 (one group per phase leaves nothing for the other slots to overlap); at 2^20 points the sort / fixup /
-    // reduce kernels are throughput-bound, a fused group serialises what separate streams overlap (1.50 vs 1.35 ms per MSM): no fusing
-    // witness-shaped columns (the caller's hint: advice columns, multiplicities -- one or two non-zero digits per scalar) leave every
-    // kernel of the chain latency-bound whatever n is (serial profile of the k = 20 MLP's advice columns: accumulate 0.09-0.11 ms inside
-    // 0.55-0.93 ms of device time): four of them share one chain (k = 20 MLP proof: advice phase 17.3 -> 11.3 ms)
-    if (small_scalars) return 4;
-    return n * T->wp.W <= ((size_t)4 << 20) ? 4 : 1;
+    // Round 4, measured on whole proofs (tools/msm_group_ab*.sh, profiles/r04*_msm_group_ab*.log; 8 proofs per setting, same proof bytes):
+    //   * general scalars (z, phi, h pieces): groups of FOUR at every size.  Round 3 left batches of 2^20 points unfused (a lone fused
+    //     group is 1.50 against 1.35 ms per MSM), but inside a proof the five to eight chains of an unfused batch occupy five or six slot
+    //     streams next to the library, auxiliary (NTT), copy and table streams -- more streams than the 8 hardware queues the runtime maps
+    //     them to -- and the helper chain of the NEXT argument then queues behind the NTT burst of the previous one: k = 20 MLP 81.5 ->
+    //     76.5 ms (the multiplicity phase alone 12.1 -> 6.4 ms), einsum k = 20 31.8 -> 30.8, k = 17 and k = 22 circuits unchanged.  More
+    //     hardware queues instead (GPU_MAX_HW_QUEUES = 12 .. 24) shorten that phase too but lengthen the z / phi phases: 83-84 ms.
+    //   * witness-shaped columns (advice, multiplicities: one or two non-zero digits per scalar, every kernel of the chain latency-bound
+    //     whatever n is): groups of SIX (12 advice columns = 2 chains, 8 multiplicity columns = 6 + 2): 81.0 against 82.0 ms with four.
+    // EZKL_MSM_GROUP_SMALL / EZKL_MSM_GROUP_BIG override one class, EZKL_MSM_GROUP both.
+    (void)T; (void)n; (void)batch;
+    if (small_scalars) {
+        static const int small = [] { const char* e = getenv("EZKL_MSM_GROUP_SMALL"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)MSM_MAX_GROUP ? v : 6; }();
+        return (size_t)small;
+    }
+    static const int big = [] { const char* e = getenv("EZKL_MSM_GROUP_BIG"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= (int)MSM_MAX_GROUP ? v : 4; }();
+    return (size_t)big;
 }
 // `count` MSMs of n points each (scalar columns cols[0..count)) as ONE sequence of launches with gridDim.z = count
 static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t base_offset, const fe_t* const* cols, size_t count, size_t n, bool timed) {
@@ -1081,7 +1090,9 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
 // after wait_ev[j] (the upload phase's copy events).
 static int msm_run_groups(Ctx* c, MsmTable* T, size_t base_offset, const fe_t* const* cols, size_t batch, size_t n, void* out_host,
                           const hipEvent_t* wait_ev, bool small_scalars) {
-    const size_t G = msm_group_size(T, n, small_scalars);
+    const size_t G = msm_group_size(T, n, small_scalars, batch);
+    static const bool dbg = getenv("EZKL_MSM_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[ezkl_hip] msm batch: %zu columns of %zu points, %s scalars, groups of %zu\n", batch, n, small_scalars ? "witness-shaped" : "general", G);
     int rc = EZKL_OK;
     size_t gi = 0;
     for (size_t j0 = 0; j0 < batch && !rc; j0 += G, gi++) {
