@@ -91,7 +91,7 @@ static int ctx_create(int idx) {
     Ctx* c = new Ctx();
     c->device = device;
     c->index = idx;
-    EZ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    EZ_HIP(stream_create_prio(&c->stream, "EZKL_HIP_PRIO_LIB", 0));
     hipDeviceProp_t prop;
     EZ_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
@@ -760,7 +760,7 @@ int ezkl_hip_stream_create(void** out) {
 int ezkl_hip_context_stream(void** out) {
     if (!out) return EZKL_ERR_INVALID;
     EZ_CTX(c);
-    if (!c->side_stream) EZ_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    if (!c->side_stream) EZ_HIP(stream_create_prio(&c->side_stream, "EZKL_HIP_PRIO_AUX", 0));
     *out = c->side_stream;
     return EZKL_OK;
 }

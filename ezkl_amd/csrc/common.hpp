@@ -80,6 +80,19 @@ struct RoctxRange {
     std::lock_guard<std::recursive_mutex> _lk(c->mu); \
     EZ_HIP(hipSetDevice(c->device))
 
+// Stream priorities (EZKL_HIP_PRIO_<LIB|AUX|MSM> = -1 high / 0 normal / 1 low, clamped to the device's range): the library stream carries
+// the helper chains every commitment of a proof waits for, the context's side stream the NTT forms that are only needed by the quotient
+// sweep, the MSM slot streams the commitments themselves.
+static inline hipError_t stream_create_prio(hipStream_t* st, const char* env_name, int dflt) {
+    int prio = dflt;
+    if (const char* e = getenv(env_name)) prio = atoi(e);
+    int lo = 0, hi = 0;                                   // lo = least priority (largest number), hi = greatest
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
+    if (prio > lo) prio = lo;
+    if (prio < hi) prio = hi;
+    if (prio == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+}
 static inline hipStream_t pick_stream(Ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

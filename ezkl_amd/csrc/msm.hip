@@ -845,7 +845,7 @@ void msm_table_drop(const Bases* b) {
 static constexpr size_t MSM_MAX_GROUP = 16;       // MSMs fused into one sequence of launches (gridDim.z)
 static int slot_prepare(MsmSlot& sl, size_t bytes, size_t msms = 1) {
     if (!sl.st) {
-        EZ_HIP(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        EZ_HIP(stream_create_prio(&sl.st, "EZKL_HIP_PRIO_MSM", 0));
         EZ_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         EZ_HIP(hipHostMalloc((void**)&sl.list_pinned, MSM_MAX_GROUP * sizeof(void*), hipHostMallocDefault));
     }

@@ -2731,6 +2731,17 @@ int ezkl_prover_cs_set_shard_comm(ezkl_cs_t h) {
         // columns and arguments by owner (takes effect once the caller declares complete base sets: ezkl_prover_cs_set_shard_full_bases)
         return ezkl_prover_cs_set_shard_exchange(h, comm_allgather_host, comm_alltoall, nullptr);
     }
+    if (world > 1) {
+        // Columns and arguments by owner, and the row-sharded sweep, divide the 2^k rows and the 2^(ext_k - k) cosets into equal parts: they
+        // need a power-of-two number of ranks that divides 2^k.  Any other world still proves -- every commitment sharded by point ranges and
+        // folded, everything else replicated on every rank (round 1's mode) -- and says so once instead of silently being slower.
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "[ezkl_prover] %d ranks: the owner mode (columns / arguments by owner, row-sharded sweep) needs a power-of-two number of ranks; "
+                            "this run shards the commitments by point ranges and replicates the rest\n", world);
+        }
+    }
     return EZKL_OK;
 }
 int ezkl_prover_cs_set_shard_exchange(ezkl_cs_t h, ezkl_allgather_host_fn allgather_host, ezkl_exchange_fn exchange, void* user) {
