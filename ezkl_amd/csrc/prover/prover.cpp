@@ -2925,6 +2925,19 @@ int ezkl_prover_verify_proof_vk(ezkl_cs_t cs, const void* vk_buf, size_t vk_len,
         vk.sigma_commitments.resize(np);
         if (nf) std::memcpy(vk.fixed_commitments.data(), b + 7, 64 * (size_t)nf);
         if (np) std::memcpy(vk.sigma_commitments.data(), b + 7 + 64 * (size_t)nf, 64 * np);
+        // a damaged or foreign key is rejected here, not fed to the pairing arithmetic: every commitment must be the identity
+        // encoding (0, 0) or a canonical point of the curve, and what follows the commitments must be a complete selector section (a vk.key
+        // ends there; a pk.key -- whose prefix the vk is -- goes on with the polynomials)
+        auto check_point = [&](const G1& p) {
+            invalid(cmp(p.x, FQ.p) >= 0 || cmp(p.y, FQ.p) >= 0, "non-canonical coordinate in the verifying key");
+            const bn::Fq x{p.x}, y{p.y};
+            if (x.is_zero() && y.is_zero()) return;
+            invalid(!(y * y == x * x * x + bn::Fq::from_u64(3)), "a commitment of the verifying key is not on the curve");
+        };
+        for (auto& p_ : vk.fixed_commitments) check_point(p_);
+        for (auto& p_ : vk.sigma_commitments) check_point(p_);
+        const size_t sel_bytes = (size_t)c.n_selectors * ((c.n + 7) / 8);
+        invalid(vk_len < want + sel_bytes, "verifying key truncated (selector section)");
         const Fe digest = vk_digest(vk);
         const bn::G2 a = bn::g2_from_bytes((const uint8_t*)g2), bb = bn::g2_from_bytes((const uint8_t*)s_g2);
         if (!bn::g2_on_curve(a) || !bn::g2_on_curve(bb) || a.inf || bb.inf) throw Error(EZKL_ERR_INVALID, "g2 / s_g2 not on the twist");

@@ -37,6 +37,11 @@ def test_setup_prove_verify_on_files(hip, tmp_path):
     assert X.verify(str(proof_path), str(compiled), str(pk_path), srs)          # pk.key starts with the vk
     with pytest.raises(RuntimeError, match="truncated"):
         X.verify(str(proof_path), str(compiled), str(tmp_path / "short.key") if (tmp_path / "short.key").write_bytes(vk_path.read_bytes()[:100]) else "", srs)
+    dmg = bytearray(vk_path.read_bytes()); dmg[7 + 64 * 3 + 5] ^= 1            # one bit of a fixed commitment: no longer a point of the curve
+    (tmp_path / "damaged.key").write_bytes(bytes(dmg))
+    with pytest.raises(RuntimeError, match="curve|canonical"):
+        X.verify(str(proof_path), str(compiled), str(tmp_path / "damaged.key"), srs)
+    assert X.verify(str(proof_path), str(compiled), pk_path=str(pk_path), srs_path=srs)     # the parameter's former name still works
     j = json.loads(proof_path.read_text())
     j["proof"][4000] ^= 1
     j["hex_proof"] = "0x" + bytes(j["proof"]).hex()
