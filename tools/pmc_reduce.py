@@ -19,7 +19,11 @@ from collections import defaultdict
 def load(path):
     d = defaultdict(list)
     for r in csv.DictReader(open(path)):
-        d[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]) * 1024.0)      # KiB -> bytes
+        name = r["Kernel_Name"].split("(")[0]
+        if name.startswith("void "):                 # templated kernels are reported with their return type and arguments
+            name = name[5:]
+        name = name.split("<")[0]
+        d[name].append(float(r["Counter_Value"]) * 1024.0)      # KiB -> bytes
     return {k: v for k, v in d.items()}
 
 
