@@ -355,6 +355,17 @@ def polycommit_commit(message, num_unusable_rows, params):
     return out
 
 
+def msm_g2(points, scalars):
+    """sum_i scalars[i] * points[i] over G2: points (n, 16) u64 affine (x.c0, x.c1, y.c0, y.c1 Montgomery Fq, the SRS file's layout),
+    scalars (n, 4) Montgomery Fr -> (16,) u64 affine (ezkl_hip_msm_g2)"""
+    points, scalars = _fe(points, 16), _fe(scalars)
+    if points.shape[0] != scalars.shape[0]:
+        raise ValueError("one scalar per point")
+    out = np.zeros(16, np.uint64)
+    _l.check(_l.load().ezkl_hip_msm_g2(_p(points), _p(scalars), C.c_size_t(points.shape[0]), _p(out)), "ezkl_hip_msm_g2")
+    return out
+
+
 def g1_add_affine(a, b):
     a, b = _fe(a, 8), _fe(b, 8)
     out = np.zeros(8, np.uint64)

@@ -630,6 +630,12 @@ int ezkl_hip_bases_downsize(ezkl_bases_t g, uint32_t new_k, ezkl_bases_t* out_g,
     *out_g_lagrange = reinterpret_cast<ezkl_bases_t>(bl);
     return EZKL_OK;
 }
+// sum_i scalars[i] * points[i] over G2 (host buffers; csrc/g2.hip): the G2 side of the SRS (gen_srs: s_g2 = [s] g2 is n = 1)
+int ezkl_hip_msm_g2(const void* points_affine, const void* scalars, size_t n, void* out_affine) {
+    if (!out_affine || (n && (!points_affine || !scalars))) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    return g2_msm(c, c->stream, points_affine, scalars, n, out_affine);
+}
 size_t ezkl_hip_bases_len(ezkl_bases_t h) { return h ? reinterpret_cast<Bases*>(h)->n : 0; }
 
 int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, void* out, void* stream) {

@@ -150,5 +150,6 @@ int g1_mul_fixed(Ctx* c, hipStream_t st, const void* base_host, const fe_t* scal
 int gen_bases(Ctx* c, hipStream_t st, uint64_t seed, size_t first, size_t n, void* out_dev);
 int g1_to_lagrange(Ctx* c, hipStream_t st, const void* g_dev, uint32_t log_n, fe_t* tw_mont, const fe_t& ninv_mont, void* out_dev);
 void g1_add_affine_host(const void* a, const void* b, void* out);
+int g2_msm(Ctx* c, hipStream_t st, const void* pts_host, const void* scalars_host, size_t n, void* out_host);
 
 }  // namespace ezkl

@@ -132,6 +132,12 @@ int ezkl_hip_bases_from_scalars(const void* base_point, const void* scalars_dev,
  * halo2's g_to_lagrange does: an inverse NTT over G1 (omega^-1 butterflies on group elements, scaled by 1 / 2^new_k).  New handles,
  * freed with ezkl_hip_bases_free. */
 int ezkl_hip_bases_downsize(ezkl_bases_t g, uint32_t new_k, ezkl_bases_t* out_g, ezkl_bases_t* out_g_lagrange);
+/* sum_i scalars[i] * points[i] over G2 (the twist over Fq2).  points: n x 128 B affine -- x.c0, x.c1, y.c0, y.c1 as 32-byte little-endian
+ * Montgomery Fq, the layout of the g2 / s_g2 tail of an SRS file, (0, 0) = identity; scalars: n x 32 B Montgomery Fr; out: 128 B canonical
+ * affine.  Host pointers, borrowed.  On the reference's prove path G2 is data (the verifier's pairing consumes g2 and s_g2); the one G2
+ * computation is gen_srs's s_g2 = [s] g2 (/root/reference/src/pfsys/srs.rs:14-16 -> ParamsKZG::setup), i.e. n = 1.  A plain
+ * double-and-add per pair with a tree fold: not a Pippenger pipeline, not a hot path. */
+int ezkl_hip_msm_g2(const void* points_affine, const void* scalars, size_t n, void* out_affine);
 /* sum_i scalars[i] * bases[offset + i], i < n.  scalars: n x 32 B Montgomery Fr (host pointer, borrowed).
  * out_affine: 64 B, caller-allocated, canonical affine ((0,0) if the sum is the identity). */
 int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out_affine);

@@ -1,7 +1,7 @@
 """GPU parity: HIP fixed-base Pippenger MSM (through the C ABI) vs the oracle and the golden SRS."""
 import numpy as np
 import pytest
-from conftest import R, Q, SEED, fe_from_int, rand_fr, witness_like
+from conftest import R, Q, SEED, fe_from_int, fe_to_int, rand_fr, witness_like
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
@@ -519,3 +519,50 @@ def test_params_downsize_matches_the_reference_srs_and_the_oracle(hip, golden_sr
     assert p.k == 7 and (p.commit_lagrange(v) == B.msm_g1(gl7, v)).all()
     for b in (g9, gl9, g7, gl7, d7, dl7): b.free()
     p.free()
+
+
+def test_g2_msm_matches_the_oracle_and_the_host_pairing_code(hip):
+    """BN254 G2 on the device (ezkl_hip_msm_g2, csrc/g2.hip): sum_i s_i P_i over the twist against the oracle's Python G2 arithmetic
+    (oracle/pairing.py) and the product's host C++ (ezkl_prover_g2_mul_generator: gen_srs's s_g2 = [s] g2, /root/reference/src/pfsys/srs.rs:14-16);
+    identity points, zero scalars, repeated points (the doubling branch of the fold) and P + (-P)."""
+    from ezkl_amd import backend as B, native as NV
+    from oracle import pairing as E
+    rng = np.random.default_rng(2024)
+    G2 = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
+          (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
+    assert E.g2_on_curve(G2)
+    def enc(pt):                                   # oracle point -> 16 x u64 (x.c0, x.c1, y.c0, y.c1 Montgomery Fq; identity = zeros)
+        if pt is None:
+            return np.zeros(16, np.uint64)
+        return np.concatenate([fe_from_int(c, Q) for c in (pt[0][0], pt[0][1], pt[1][0], pt[1][1])])
+    def dec(a):
+        v = [fe_to_int(a[4 * i:4 * i + 4], Q) for i in range(4)]
+        return None if not any(v) else ((v[0], v[1]), (v[2], v[3]))
+    # n = 1: [s] g2 as the SRS generator makes it, three ways
+    s_ = int(rng.integers(1, 1 << 62)) * int(rng.integers(1, 1 << 62)) % R
+    got = B.msm_g2(enc(G2)[None], fe_from_int(s_)[None])
+    assert dec(got) == E.g2_mul(G2, s_) and got.tobytes() == NV.g2_mul_generator(s_)
+    # a batch with every special case in it
+    ks = [int(x) for x in rng.integers(1, 1 << 40, 37)]
+    pts = [E.g2_mul(G2, k) for k in ks]
+    sc = [int(x) * int(y) % R for x, y in zip(rng.integers(1, 1 << 62, 37), rng.integers(1, 1 << 62, 37))]
+    pts[3], ks[3] = None, 0                        # identity point
+    sc[5] = 0                                      # zero scalar
+    pts[8], ks[8], sc[8] = pts[7], ks[7], sc[7]    # the same (point, scalar) twice
+    pts[11], ks[11], sc[11] = (pts[10][0], E.f2_neg(pts[10][1])), R - ks[10], sc[10]      # P and -P with the same scalar cancel
+    sc[12] = R - 1
+    want = E.g2_mul(G2, sum(s * k for s, k in zip(sc, ks)) % R)
+    got = B.msm_g2(np.stack([enc(p) for p in pts]), np.stack([fe_from_int(s) for s in sc]))
+    assert dec(got) == want
+    # all zero scalars / no points: the identity
+    assert not B.msm_g2(np.stack([enc(p) for p in pts]), np.zeros((37, 4), np.uint64)).any()
+    # more pairs than threads of the partial kernel (1024): the strided sums + the tree
+    n = 1500
+    ks2 = [int(x) for x in rng.integers(1, 1 << 20, 8)]
+    base = [E.g2_mul(G2, k) for k in ks2]
+    idx = rng.integers(0, 8, n)
+    sc2 = [int(x) for x in rng.integers(0, 1 << 62, n)]
+    want2 = E.g2_mul(G2, sum(s * ks2[i] for s, i in zip(sc2, idx)) % R)
+    benc = [enc(p) for p in base]
+    got2 = B.msm_g2(np.stack([benc[i] for i in idx]), np.stack([fe_from_int(s) for s in sc2]))
+    assert dec(got2) == want2
