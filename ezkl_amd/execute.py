@@ -1,6 +1,7 @@
 """The command bodies around the prove hot path, with the reference's names and argument meaning
 (/root/reference/src/execute.rs): artefact FILES in, artefact files out, everything O(n) on the GPU through libezkl_prover.so.
 
+    gen_srs(srs_path, logrows)                                                  execute.rs gen_srs -> pfsys::srs::gen_srs (srs.rs:13-16)
     setup(compiled_circuit, srs_path, vk_path, pk_path)                         execute.rs:1543-1572 -> pfsys::create_keys (mod.rs:376-400)
     prove(witness, compiled_circuit, pk_path, proof_path, srs_path, check_mode)  execute.rs:1575-1627 -> create_proof_circuit (mod.rs:404-489)
     verify(proof_path, compiled_circuit, pk_path, srs_path)                      execute.rs:1651-1722 -> verify_proof_circuit (mod.rs:557-590)
@@ -86,6 +87,31 @@ def _mlp_of_graph(model):
     if model["outputs"][0] != (cur, 0) or not weights:
         raise ValueError("unsupported compiled circuit: output node")
     return weights, biases, relu_last
+
+
+G2_GENERATOR = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
+                (0x12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa, 0x090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b))
+
+
+def gen_srs(srs_path, logrows, secret=None):
+    """`ezkl gen-srs` (/root/reference/src/execute.rs gen_srs -> pfsys::srs::gen_srs, src/pfsys/srs.rs:13-16 -> ParamsKZG::setup): an INSECURE
+    test SRS from a secret s -- g[i] = s^i G, g_lagrange[i] = L_i(s) G and s_g2 = [s] g2, all on the device (the G1 sets by
+    backend.gen_srs, the G2 point by ezkl_hip_msm_g2) -- written in halo2's raw-bytes layout.  secret=None draws s from OS entropy."""
+    R_ = EL.R
+    if secret is None:
+        secret = int.from_bytes(os.urandom(40), "little")
+    secret %= R_
+    mont_q = lambda v: np.frombuffer((v * (1 << 256) % B._Q).to_bytes(32, "little"), np.uint64)
+    mont_r = lambda v: np.frombuffer((v * (1 << 256) % R_).to_bytes(32, "little"), np.uint64)
+    g2 = np.concatenate([mont_q(c) for c in (G2_GENERATOR[0][0], G2_GENERATOR[0][1], G2_GENERATOR[1][0], G2_GENERATOR[1][1])])
+    s_g2 = B.msm_g2(g2[None], mont_r(secret)[None])
+    g, gl = B.gen_srs(logrows, secret)
+    try:
+        data = codecs.write_srs(dict(k=logrows, g=g.download(), g_lagrange=gl.download(), g2=g2.tobytes(), s_g2=s_g2.tobytes()))
+    finally:
+        g.free(); gl.free()
+    open(srs_path, "wb").write(data)
+    return len(data)
 
 
 def load_params_prover(srs_path, logrows):

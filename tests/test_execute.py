@@ -85,10 +85,10 @@ def test_prove_with_a_larger_srs_file_downsizes(hip, tmp_path):
     s_ = 0x0123456789abcdef0fedcba987654321 % P.R
     files = {}
     for k in (6, 9):
-        g, gl = B.gen_srs(k, s_)
         path = tmp_path / ("kzg%d.srs" % k)
-        path.write_bytes(codecs.write_srs(dict(k=k, g=g.download(), g_lagrange=gl.download(), g2=NV.g2_mul_generator(1), s_g2=NV.g2_mul_generator(s_))))
-        g.free(); gl.free()
+        X.gen_srs(str(path), k, secret=s_)                      # `ezkl gen-srs`: G1 sets and s_g2 = [s] g2 on the device
+        srs = codecs.read_srs(path.read_bytes())
+        assert srs["k"] == k and srs["g2"] == NV.g2_mul_generator(1) and srs["s_g2"] == NV.g2_mul_generator(s_)      # the host pairing code's G2
         files[k] = str(path)
     out = {}
     for k in (6, 9):
