@@ -340,7 +340,7 @@ static std::string jit_source_r29(const ezkl_program_t* p, const std::vector<uin
     const std::string MUL = jit_knob("EZKL_EVALH_R29", 2) == 2 ? "Fr29::mul_cold(" : "Fr29::mul(";      // 2: the product as a call (small code)
     // the compiler barrier that makes every term reload its columns (no scratch, 4 waves per SIMD) after every N-th Horner step: N > 1 lets
     // neighbouring terms share loaded values at the price of registers
-    const int barrier_every = jit_knob("EZKL_EVALH_BARRIER_EVERY", 1) > 0 ? jit_knob("EZKL_EVALH_BARRIER_EVERY", 1) : 1;
+    const int barrier_every = jit_knob("EZKL_EVALH_BARRIER_EVERY", 4) > 0 ? jit_knob("EZKL_EVALH_BARRIER_EVERY", 4) : 1;     // 4: k = 20 MLP sweep 2.54 -> 2.41 ms per coset (profiles/r04p_evalh_ab.log)
     int horner_steps = 0;
     s += std::string("#define XCD_MAP ") + (jit_knob("EZKL_EVALH_XCD", 0) ? "1" : "0") + "\n";
     s += "#include \"field29.hpp\"\nusing namespace ezkl;\n"
@@ -552,7 +552,7 @@ static int jit_get(Ctx* c, const ezkl_program_t* p, const std::vector<uint32_t>&
     const uint64_t build = jit_build_digest();
     key.append((const char*)&build, sizeof build);
     const int knobs[5] = {jit_knob("EZKL_EVALH_WAVES", 4), jit_knob("EZKL_EVALH_BARRIER", 1), jit_knob("EZKL_EVALH_R29", 2), jit_knob("EZKL_EVALH_XCD", 0),
-                          jit_knob("EZKL_EVALH_BARRIER_EVERY", 1)};      // code-generation options are part of the identity
+                          jit_knob("EZKL_EVALH_BARRIER_EVERY", 4)};      // code-generation options are part of the identity
     key.append((const char*)knobs, sizeof knobs);
     const uint64_t h = fnv1a(key.data(), key.size(), 1469598103934665603ull);
     if (getenv("EZKL_HIP_JIT_DEBUG")) fprintf(stderr, "[ezkl_hip] sweep kernel %016llx: %u instructions, %u columns, ext_k %u\n", (unsigned long long)h, p->n_instr, p->n_columns, p->ext_k);

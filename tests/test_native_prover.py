@@ -52,6 +52,33 @@ def test_constraint_system_analysis_random_circuits(seed):
                         n_advice_queries=len(cs.advice_queries), n_fixed_queries=len(cs.fixed_queries), n_instance_queries=len(cs.instance_queries))
 
 
+@pytest.mark.parametrize("seed", range(70, 82))
+def test_constraint_system_blob_round_trips(seed):
+    """plonk.deserialize_cs is the inverse of serialize_cs (the laid-out bench circuits are stored as this blob + JSON, nothing a reader
+    unpickles): blob -> ConstraintSystem -> the same blob, same derived quantities, sub-expressions shared again; the reference's fixture
+    circuit (query order given, unblinded columns, selectors) included"""
+    from ezkl_amd import plonk as P
+    if seed == 70:
+        import fixture_k6 as FX
+        cs = FX.load()["cs"]
+    elif seed == 71:
+        cs = instance_phase_circuit(6)
+    elif seed == 72:
+        cs = lookup_circuit(7)
+    else:
+        cs = random_circuit(seed, k=6 + seed % 4)[0]
+    blob = P.serialize_cs(cs)
+    back = P.deserialize_cs(blob)
+    assert P.serialize_cs(back) == blob
+    for a in ("k", "n_advice", "n_fixed", "n_instance", "n_challenges", "advice_phase", "degree", "ext_k", "chunk", "n_chunks", "usable", "blinding",
+              "advice_queries", "fixed_queries", "instance_queries", "perm", "unblinded", "n_selectors", "queries_given"):
+        assert getattr(back, a) == getattr(cs, a), a
+    assert N.NativeCircuit(back).info() == N.NativeCircuit(cs).info()
+    for bad in (blob[:-1], blob + b"\0", b"\0" * 28 + blob[28:]):
+        with pytest.raises(Exception):
+            P.deserialize_cs(bad)
+
+
 def test_malformed_circuit_descriptions_are_rejected():
     import ctypes as C
     good = N.serialize_cs(lookup_circuit(6))
