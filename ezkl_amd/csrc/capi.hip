@@ -654,6 +654,30 @@ int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_
     EZ_CTX(c);
     return msm_run(c, pick_stream(c, stream), b, base_offset, (const fe_t*)scalars_dev, n, out);
 }
+// one MSM in two halves (msm_call_start / msm_call_finish): the launches are queued behind the library stream's work so far and the call
+// returns; finish waits for them and writes the point.  In between the caller may issue any other call, batches and upload phases included
+// (the MSM runs on a call slot of its own).  `token` is the slot (0 .. 3).
+int ezkl_hip_msm_g1_start_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, int* token) {
+    if (!h || !scalars_dev || !token || n == 0) return EZKL_ERR_INVALID;
+    Bases* b = reinterpret_cast<Bases*>(h);
+    if (base_offset + n > b->n) return EZKL_ERR_INVALID;
+    ::ezkl::RoctxRange _roctx(__func__);
+    Ctx* c = ctx();
+    if (!c) return EZKL_ERR_NO_DEVICE;
+    std::unique_lock<std::recursive_mutex> lk(c->mu);
+    EZ_HIP(hipSetDevice(c->device));
+    if (msm_upload_is_open()) return EZKL_ERR_INVALID;
+    return msm_call_start(c, lk, b, base_offset, (const fe_t*)scalars_dev, n, token);
+}
+int ezkl_hip_msm_g1_finish(int token, void* out) {
+    if (!out) return EZKL_ERR_INVALID;
+    ::ezkl::RoctxRange _roctx(__func__);
+    Ctx* c = ctx();
+    if (!c) return EZKL_ERR_NO_DEVICE;
+    std::unique_lock<std::recursive_mutex> lk(c->mu);
+    EZ_HIP(hipSetDevice(c->device));
+    return msm_call_finish(c, lk, token, out);
+}
 int ezkl_hip_msm_g1(ezkl_bases_t h, const void* scalars, size_t n, void* out) {
     if (!h || !out || (!scalars && n)) return EZKL_ERR_INVALID;
     Bases* b = reinterpret_cast<Bases*>(h);

@@ -138,6 +138,8 @@ int kate_division(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& z, fe_t* ou
 int chacha20_fr(Ctx* c, hipStream_t st, const uint32_t key[8], uint64_t stream, size_t first, fe_t* out, size_t n);
 bool msm_upload_is_open();
 int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host);
+int msm_call_start(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, int* slot_out);
+int msm_call_finish(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, int slot, void* out_host);
 int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out, bool ordered);
 int eval_jit_compile_only(const ezkl_program_t* p);
 int eval_prepare(Ctx* c, const ezkl_program_t* p);

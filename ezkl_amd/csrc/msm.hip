@@ -1135,9 +1135,11 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
 // wait for the GPU and the host tail run outside the lock, on a call slot of the caller's own (streams, scratch, pinned planes), so
 // the latency-bound tails of one thread's MSM overlap the accumulation of another's -- the overlap the batch entry points give a
 // single-threaded caller.  The slots are separate from the batch slots: a batch never finishes (or reuses) a caller's slot.
-int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {
-    if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
-    if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
+// the two halves of it, for a caller that has other work to queue in between (ezkl_hip_msm_g1_start_dev / _finish: the prover commits
+// the vanishing argument's random polynomial -- which depends on nothing but the randomness -- under the upload of the witness):
+// start claims a call slot, orders it behind the library stream and queues the launches; finish waits and runs the host tail.
+int msm_call_start(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, int* slot_out) {
+    if (g_open_batch_fwd() || n == 0) return EZKL_ERR_INVALID;
     MsmTable* T = nullptr;
     int rc = table_get(c, c->stream, b, &T);
     if (rc) return rc;
@@ -1158,16 +1160,31 @@ int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const
         if (!g_call_order_ev) e = hipEventCreateWithFlags(&g_call_order_ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(g_call_order_ev, c->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(sl.st, g_call_order_ev, 0);
-        if (e != hipSuccess) rc = set_hip_error(e, "msm_run_concurrent", __FILE__, __LINE__);
+        if (e != hipSuccess) rc = set_hip_error(e, "msm_call_start", __FILE__, __LINE__);
     }
     if (!rc) rc = msm_enqueue(c, sl, sl.st, T, base_offset, &scalars, 1, n, true);
     if (rc) { g_call_claimed[k] = false; return rc; }
+    *slot_out = k;
+    return EZKL_OK;
+}
+int msm_call_finish(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, int k, void* out_host) {
+    (void)c;
+    if (k < 0 || k >= MSM_CALL_SLOTS || !g_call_claimed[k]) return EZKL_ERR_INVALID;
+    MsmSlot& sl = g_call_slots[k];
     lk.unlock();
-    rc = msm_finish(sl, out_host, false);             // GPU wait + host Horner: no library state touched
+    const int rc = msm_finish(sl, out_host, false);   // GPU wait + host Horner: no library state touched
     lk.lock();
     sl.busy = false;
     g_call_claimed[k] = false;
     return rc;
+}
+int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {
+    if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
+    if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
+    int k = -1;
+    int rc = msm_call_start(c, lk, b, base_offset, scalars, n, &k);
+    if (rc) return rc;
+    return msm_call_finish(c, lk, k, out_host);
 }
 
 // `batch` independent MSMs against the same bases (the advice-column commits of one prover phase), pipelined

@@ -1873,6 +1873,29 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         be.set_rows(col, 0, vals);
         inst_cols.push_back(col);
     }
+    // 5'. The vanishing argument's random polynomial depends on nothing but the randomness, and the library's generator addresses its
+    //     requests by index (request number k = ChaCha stream k): its column is expanded and its commitment STARTED here, so that the one
+    //     uniform-scalar MSM of that step (≈ 1.5 ms + its stage's round trips) runs under the upload of the witness, when the GPU has
+    //     little else to do; step 5 below collects the point and writes it at the same place of the transcript, drawn at the same place of
+    //     the random stream.  One prover on one GPU with the library's generator only (a caller's rng callback is sequential; a sharded
+    //     prover commits this column by point ranges).  EZKL_PROVER_NO_EARLY_RANDOM=1: off.
+    struct EarlyRandom {
+        Col col;
+        int token = -1;
+        uint64_t stream = 0;
+        ~EarlyRandom() {                             // unwinding: give the call slot back
+            if (token >= 0) { G1 sink; (void)ezkl_hip_msm_g1_finish(token, &sink); }
+        }
+    } early;
+    if (!rng.fn && !cs.shard.on() && !getenv("EZKL_PROVER_NO_EARLY_RANDOM")) {
+        uint64_t draws = 0;                          // the requests that precede it: blinding rows of advice / m / z / phi
+        for (uint32_t c = 0; c < cs.n_advice; c++) draws += cs.unblinded[c] ? 0 : 1;
+        draws += 2 * (uint64_t)cs.lookups.size() + cs.n_chunks;
+        early.stream = rng.calls + draws;
+        early.col = be.alloc(n);
+        check(ezkl_hip_chacha20_fr_dev(rng.key, early.stream, 0, early.col->ptr(), n, nullptr), "ezkl_hip_chacha20_fr_dev");
+        check(ezkl_hip_msm_g1_start_dev(g, 0, early.col->ptr(), n, &early.token), "ezkl_hip_msm_g1_start_dev");
+    }
     // 1. advice columns, phase by phase; the phase-0 commitments seed the user challenges.  Every rank uploads every column (the
     //    lookup / permutation arguments it owns read them); in owner mode only the owner transforms and commits a column.
     std::vector<Col> adv_cols(cs.n_advice);
@@ -2095,8 +2118,20 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     }
     sw.lap(3);
     // 5. vanishing argument: random polynomial (every rank expands the same keystream: a replicated column);  6. y
-    Col rnd = rng.column(be, n);
-    T.write_point(be.commit({rnd})[0]);
+    Col rnd;
+    if (early.token >= 0) {                          // started under the witness upload (step 5' above)
+        invalid(rng.calls != early.stream, "internal: the random polynomial was expanded at another place of the random stream");
+        rng.calls++;
+        rnd = early.col;
+        G1 pt;
+        const int tok = early.token;
+        early.token = -1;
+        check(ezkl_hip_msm_g1_finish(tok, &pt), "ezkl_hip_msm_g1_finish");
+        T.write_point(pt);
+    } else {
+        rnd = rng.column(be, n);
+        T.write_point(be.commit({rnd})[0]);
+    }
     const Fe y = T.squeeze_challenge();
     sw.lap(4);
     // 7. quotient

@@ -147,6 +147,13 @@ int ezkl_hip_msm_g1_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_
                         void* out_affine, void* stream);
 /* batch of `batch` scalar vectors against the same bases (one commit per advice column) */
 int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t batch, size_t n, void* out_affine);
+/* One MSM in two halves: start queues it behind what the library stream has been asked to do so far (the scalar column may still be in
+ * the making there) and returns a token; finish waits and writes the 64-byte affine point.  In between the caller may issue any other
+ * call of this header -- commit batches and upload phases included: the MSM runs on a call slot with its own stream and scratch.  At most
+ * four may be in flight per context.  (The prover commits the vanishing argument's random polynomial, which depends on nothing but the
+ * randomness, under the upload of the witness: halo2 draws it at the same place of the RNG stream either way.) */
+int ezkl_hip_msm_g1_start_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, int* token);
+int ezkl_hip_msm_g1_finish(int token, void* out_affine);
 /* the same with every scalar vector resident in HBM (array of DEVICE pointers held in host memory); the MSMs are
  * pipelined over several streams so the short reduce/sort kernels of one overlap the accumulation of the next */
 int ezkl_hip_msm_g1_batch_dev(ezkl_bases_t h, size_t base_offset, const void* const* scalars_dev, size_t batch, size_t n,
