@@ -34,6 +34,11 @@ struct Ctx {
         bool in_use = false;
     };
     Arena scratch, aux;
+    // `scratch` as seen from a stream other than the library stream: an arena of its own per stream.  The prover transforms every finished
+    // column on the context's side stream while the helper programs of the next argument run on the library stream; with ONE arena the
+    // rule above made each side wait for everything the other had queued -- a gate program of a few kilobytes of arguments waited for a
+    // 10 ms burst of NTTs whose work buffer it never touches (round 4: the multiplicity phase of the k = 20 MLP, 12 -> 6 ms).
+    std::map<hipStream_t, Arena> scratch_by_stream;
     // Everything a module keeps between calls lives in the context it was made for (MSM window tables, slots and streams; NTT plans and
     // coset tables; JIT modules; the column pool): several contexts -- one per device of a single-process multi-GPU prover, or several
     // on one device -- never share device state.  The modules own these (created on first use, see msm.hip / ntt.hip / evalh.hip / capi.hip).
@@ -93,6 +98,7 @@ static inline hipError_t stream_create_prio(hipStream_t* st, const char* env_nam
     if (prio == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
 }
+static inline Ctx::Arena& scratch_arena(Ctx* c, hipStream_t st) { return st == c->stream ? c->scratch : c->scratch_by_stream[st]; }
 static inline hipStream_t pick_stream(Ctx* c, void* s) { return s ? (hipStream_t)s : c->stream; }
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -747,7 +747,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out, boo
     size_t o_int = o_chal + al((size_t)(p->n_challenges ? p->n_challenges : 1) * 32);
     size_t total = o_int + al((size_t)(n_spill ? n_spill : 1) * T * 32);
     uint8_t* S = nullptr;
-    int rc = arena_reserve(c->scratch, total, st, (void**)&S);
+    int rc = arena_reserve(scratch_arena(c, st), total, st, (void**)&S);
     if (rc) return rc;
     // The caller's arrays are borrowed only for the call: they are packed into a pinned block that stays valid until the copy engine
     // has read it, so a host can queue many sweeps / helper programs without waiting for any of them (the lookup and permutation
@@ -801,7 +801,7 @@ int eval_program(Ctx* c, hipStream_t st, const ezkl_program_t* p, fe_t* out, boo
     }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
-    if ((rc = arena_done(c->scratch, st))) return rc;
+    if ((rc = arena_done(scratch_arena(c, st), st))) return rc;
     if (!ordered) EZ_HIP(hipStreamSynchronize(st));
     return EZKL_OK;
 }

@@ -111,9 +111,12 @@ static MsmState& msm_state();
 // A batch (one commit phase of the prover) is pipelined over MSM_SLOTS of these on separate streams so that the
 // latency-bound sort / reduce tails of one MSM and the host Horner overlap the accumulate kernel of the next.
 static constexpr int MSM_MAX_SLOTS = 16;
-// how many MSMs of a batch are in flight: EZKL_MSM_SLOTS (1..16) overrides the default
+// how many groups of a batch are in flight: EZKL_MSM_SLOTS (1..16) overrides the default.  Four since round 4 (six before): with commit
+// batches fused in groups of 4 / 6 a phase has two or three groups, and every slot is one more stream next to the library, side, copy and
+// call-slot streams for the runtime to fold onto its 8 hardware queues (k = 20 MLP, early random commitment, groups of 1 / 2 / 4: 74.1-75.0
+// ms with four slots, 75.4-77.7 with three, 74.1-76.2 with two, 73.1-77.2 with six: profiles/r04u_*, r04v_slots_ab.log)
 static int msm_slots_init() {
-    int v = 6;
+    int v = 4;
     if (const char* e = getenv("EZKL_MSM_SLOTS")) {
         const int x = atoi(e);
         if (x >= 1 && x <= MSM_MAX_SLOTS) v = x;

@@ -481,7 +481,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     if ((rc = ntt_kernel_attrs())) return rc;
     fe_t* work = nullptr;
     if (p->npass > 1) {
-        rc = arena_reserve(c->scratch, batch * n * sizeof(fe_t), st, (void**)&work);
+        rc = arena_reserve(scratch_arena(c, st), batch * n * sizeof(fe_t), st, (void**)&work);
         if (rc) return rc;
     }
     const fe_t zeta = fr_const(FrConst::ZETA), zeta2 = fr_const(FrConst::ZETA2);
@@ -531,7 +531,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
-    if (work) return arena_done(c->scratch, st);
+    if (work) return arena_done(scratch_arena(c, st), st);
     return EZKL_OK;
 }
 
@@ -584,7 +584,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
     if ((rc = ntt_kernel_attrs())) return rc;
     fe_t* work = nullptr;
     if (p->npass > 1) {
-        rc = arena_reserve(c->scratch, blocks * n * sizeof(fe_t), st, (void**)&work);
+        rc = arena_reserve(scratch_arena(c, st), blocks * n * sizeof(fe_t), st, (void**)&work);
         if (rc) return rc;
     }
     uint32_t log_m = log_n;
@@ -628,7 +628,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
     }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipEventRecord(e1, st));
-    if (work) return arena_done(c->scratch, st);
+    if (work) return arena_done(scratch_arena(c, st), st);
     return EZKL_OK;
 }
 // `batch` coefficient columns (2^log_n each, in_stride apart) -> their coset-major extended forms (2^log_ext each, out_stride apart)
