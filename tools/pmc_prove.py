@@ -11,7 +11,10 @@ import bench_circuits as BC
 ezkl_amd.init(0)
 print("copy", B.ubench("copy"), "gather64", B.ubench("gather64"))
 k = int(os.environ.get("K", "20"))
-built = BC.build(os.environ.get("CIRCUIT", "mlp"), k, gpu=B)
+kw = {}
+if os.environ.get("MLP_BLOCKS"): kw["blocks"] = int(os.environ["MLP_BLOCKS"])
+if os.environ.get("MLP_FILL"): kw["fill"] = int(os.environ["MLP_FILL"])
+built = BC.build(os.environ.get("CIRCUIT", "mlp"), k, gpu=B, **kw)
 cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
 gb, glb = B.gen_srs(k, 0x1234567890abcdef1234567890abcdef % P.R)
 npk = NV.NativeProvingKey(NV.NativeCircuit(cs), gb, fixed, copies)

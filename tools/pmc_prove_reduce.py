@@ -3,7 +3,7 @@
 separate runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB units; FETCH_SIZE counts half of a coalesced streaming read and
 64-byte gathers in full -- both factors re-calibrated in the same run with kernels of known byte counts).
     python tools/pmc_prove_reduce.py <fetch csv> <write csv> <out json> <label>"""
-import csv, json, sys
+import csv, json, os, sys
 
 
 def load(path):
@@ -32,7 +32,7 @@ per = {}
 for (_, n, f), (_, _, w) in zip(tf, tw):
     d = per.setdefault(n, [])
     d.append((f, w))
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_prove.py (one k = 20 MLP proof, C++ host), " + (sys.argv[4] if len(sys.argv) > 4 else ""),
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_prove.py (one k = " + os.environ.get("K", "20") + " MLP proof, C++ host), " + (sys.argv[4] if len(sys.argv) > 4 else ""),
        "units": "bytes per launch (HBM read + write), corrected", "calibration": {"stream_factor": stream_factor, "gather_factor": gather_factor, "write_factor": write_factor},
        "kernels": {}}
 n_ext, n = 1 << 22, 1 << 20
@@ -43,8 +43,9 @@ for name, v in sorted(per.items(), key=lambda kv: -sum(f for f, _ in kv[1])):
                             "read_factor_applied": "gather" if ff == gather_factor else "stream"}
 # the sweep: the evalh_jit launches with the most traffic are the cosets of the quotient numerator (the others are n-row helper programs)
 if "evalh_jit" in per:
-    sw = sorted((f * stream_factor + w * write_factor for f, w in per["evalh_jit"]), reverse=True)[:4]
-    out["evalh_jit_sweep"] = {"launches": len(sw), "bytes_per_launch_mean": sum(sw) / len(sw), "rows_per_launch": n}
+    # (SWEEP_LAUNCHES: cosets x kernels per coset when the program is cut -- 8 for the k = 22 / 30-column circuit; K: its rows)
+    sw = sorted((f * stream_factor + w * write_factor for f, w in per["evalh_jit"]), reverse=True)[:int(os.environ.get("SWEEP_LAUNCHES", "4"))]
+    out["evalh_jit_sweep"] = {"launches": len(sw), "bytes_per_launch_mean": sum(sw) / len(sw), "bytes_total": sum(sw), "rows_per_launch": 1 << int(os.environ.get("K", "20"))}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for name, d in list(out["kernels"].items())[:14]:
     print("%-34s %5d launches  %10.1f MB per launch  %10.1f MB total" % (name, d["launches"], d["bytes_per_launch_mean"] / 1e6, d["bytes_total"] / 1e6))
