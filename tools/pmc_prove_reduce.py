@@ -46,6 +46,10 @@ if "evalh_jit" in per:
     # (SWEEP_LAUNCHES: cosets x kernels per coset when the program is cut -- 8 for the k = 22 / 30-column circuit; K: its rows)
     sw = sorted((f * stream_factor + w * write_factor for f, w in per["evalh_jit"]), reverse=True)[:int(os.environ.get("SWEEP_LAUNCHES", "4"))]
     out["evalh_jit_sweep"] = {"launches": len(sw), "bytes_per_launch_mean": sum(sw) / len(sw), "bytes_total": sum(sw), "rows_per_launch": 1 << int(os.environ.get("K", "20"))}
+for name in list(out["kernels"]):                       # a templated kernel with one instantiation is also listed under its plain name
+    base = name.split("<")[0]
+    if base != name and sum(1 for n_ in out["kernels"] if n_.split("<")[0] == base) == 1:
+        out["kernels"][base] = out["kernels"][name]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for name, d in list(out["kernels"].items())[:14]:
     print("%-34s %5d launches  %10.1f MB per launch  %10.1f MB total" % (name, d["launches"], d["bytes_per_launch_mean"] / 1e6, d["bytes_total"] / 1e6))
