@@ -1098,8 +1098,17 @@ static int msm_run_groups(Ctx* c, MsmTable* T, size_t base_offset, const fe_t* c
     if (dbg) fprintf(stderr, "[ezkl_hip] msm batch: %zu columns of %zu points, %s scalars, groups of %zu\n", batch, n, small_scalars ? "witness-shaped" : "general", G);
     int rc = EZKL_OK;
     size_t gi = 0;
-    for (size_t j0 = 0; j0 < batch && !rc; j0 += G, gi++) {
-        const size_t cnt = batch - j0 < G ? batch - j0 : G;
+    // An upload phase (wait_ev: column j becomes available when ITS copy lands, 0.6 ms apart at 2^20 rows over PCIe) is cut into TAPERED
+    // groups -- G, then half of what is left, ... down to single columns -- so that what remains to be done after the last copy has landed
+    // is the short chain of one column, not of a full group: twelve advice columns go as 6 + 3 + 2 + 1 (the groups start at 3.6, 5.4, 6.6
+    // and 7.2 ms and overlap on their slots) instead of 6 + 6 (the second group could not start before 7.2 ms and then ran for ~3 ms).
+    static const bool taper = getenv("EZKL_MSM_NO_TAPER") == nullptr;
+    for (size_t j0 = 0; j0 < batch && !rc; gi++) {
+        size_t cnt = batch - j0 < G ? batch - j0 : G;
+        if (wait_ev && taper && j0 > 0) {
+            const size_t left = batch - j0;
+            cnt = left <= 2 ? 1 : std::min(G, (left + 1) / 2);
+        }
         MsmSlot& sl = g_slots[gi % MSM_SLOTS];
         if (sl.busy) rc = msm_finish(sl);
         if (!rc) rc = slot_prepare(sl, 0);
@@ -1109,6 +1118,7 @@ static int msm_run_groups(Ctx* c, MsmTable* T, size_t base_offset, const fe_t* c
             sl.out = (uint8_t*)out_host + 64 * j0;
             rc = msm_enqueue(c, sl, sl.st, T, base_offset, cols + j0, cnt, n, false);
         }
+        j0 += cnt;
     }
     for (size_t k = 0; k < (size_t)MSM_SLOTS; k++) {     // drain in launch order
         MsmSlot& sl = g_slots[(gi + k) % MSM_SLOTS];
