@@ -101,9 +101,9 @@ def main():
 
     acc_ms, msm_ms = [], []
     # clock warm-up before the W contract warm-up steps: an idle MI355X sits at ~600 MHz (rocm-smi on the bench boxes) and a timed region of
-    # K = 20 steps is 30 ms long -- 0.25 s of the same MSM first, untimed, so that the K steps are measured at the clocks a prover runs at
-    t_w = time.perf_counter()
-    while time.perf_counter() - t_w < 0.25:
+    # K = 20 steps is 30 ms long -- 150 steps (~0.25 s) of the same MSM first, untimed, so that the K steps are measured at the clocks a prover runs at
+    # (a fixed COUNT, not a duration: with N ranks every step ends in a collective, so every rank must run the same number of them)
+    for _ in range(150):
         msm_step()
     for _ in range(args.warmup):
         msm_step()
@@ -116,8 +116,7 @@ def main():
     barrier_sync()
     t_msm = time.perf_counter() - t0
 
-    t_w = time.perf_counter()
-    while time.perf_counter() - t_w < 0.1:
+    for _ in range(200):
         ntt_step()
     for _ in range(args.warmup):
         ntt_step()
