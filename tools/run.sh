@@ -19,7 +19,8 @@
 #   group        prover group, 2 and 4 contexts on one device, k = 20 MLP            -> <tag>_group{2,4}.json
 #   multi2       two owner-mode ranks (gloo) sharing the device, k = 20 MLP          -> <tag>_multi2.json
 #   k22          K=22 MLP_BLOCKS=5 MLP_FILL=25 proof + HBM high-water (opt-in size)  -> <tag>_mlp_k22.log
-#   sh:<file>    bash tools/<file> (an A/B script)                                    -> <tag>_<file>.log
+#   ab:<name>    an A/B experiment of tools/ab.sh (group, circuits, hwq, prio, evalh, ...)  -> <tag>_ab_<name>.log
+#   sh:<file>    bash tools/<file>                                                    -> <tag>_<file>.log
 #   tests:<a,b>  pytest -m gpu on the listed files                                  -> <tag>_pytest_subset.log
 #   py:<file>    python <file> (a probe under tools/)                                -> <tag>_<file>.log
 R=$(cd "$(dirname "$0")/.." && pwd); O="$R/gpurun_out"; mkdir -p "$O"
@@ -85,6 +86,8 @@ j = json.loads(sys.stdin.read()); print(j['prove_seconds_gpu_runs'], j['prove_br
     k22)
       (cd "$R" && CIRCUIT=mlp K=22 MLP_BLOCKS=5 MLP_FILL=${K22_FILL:-25} REPS=2 timeout 1500 python tools/prove_bench.py --pinned) > "$O/${TAG}_mlp_k22.log" 2>&1
       tail -1 "$O/${TAG}_mlp_k22.log" | cut -c1-1500 ;;
+    ab:*)
+      F=${JOB#ab:}; bash "$R/tools/ab.sh" "$F" > "$O/${TAG}_ab_${F}.log" 2>&1; tail -40 "$O/${TAG}_ab_${F}.log" ;;
     sh:*)
       F=${JOB#sh:}; bash "$R/tools/$F" > "$O/${TAG}_${F%.sh}.log" 2>&1; tail -40 "$O/${TAG}_${F%.sh}.log" ;;
     tests:*)
