@@ -900,13 +900,12 @@ static size_t msm_group_size(const MsmTable* T, size_t n, bool small_scalars, si
         const int v = atoi(e);
         if (v >= 1 && v <= (int)MSM_MAX_GROUP) return (size_t)v;
     }
-    // Round 4, measured on whole proofs (tools/msm_group_ab*.sh, profiles/r04*_msm_group_ab*.log; 8 proofs per setting, same proof bytes):
-    //   * general scalars (z, phi, h pieces): groups of FOUR at every size.  Round 3 left batches of 2^20 points unfused (a lone fused
-    //     group is 1.50 against 1.35 ms per MSM), but inside a proof the five to eight chains of an unfused batch occupy five or six slot
-    //     streams next to the library, auxiliary (NTT), copy and table streams -- more streams than the 8 hardware queues the runtime maps
-    //     them to -- and the helper chain of the NEXT argument then queues behind the NTT burst of the previous one: k = 20 MLP 81.5 ->
-    //     76.5 ms (the multiplicity phase alone 12.1 -> 6.4 ms), einsum k = 20 31.8 -> 30.8, k = 17 and k = 22 circuits unchanged.  More
-    //     hardware queues instead (GPU_MAX_HW_QUEUES = 12 .. 24) shorten that phase too but lengthen the z / phi phases: 83-84 ms.
+    // Round 4, measured on whole proofs (tools/ab.sh group | circuits | matrix | slots, profiles/r04[e-v]_*; 8 proofs per setting, same bytes):
+    //   * general scalars (z, phi, h pieces): groups of FOUR at every size (round 3 left 2^20-point batches unfused: a lone fused group is
+    //     1.50 against 1.35 ms per MSM).  With the false dependency between the NTT stream and the helper programs gone (one scratch arena
+    //     per stream, capi.hip / common.hpp) groups of 1 / 2 / 4 on 2 / 3 / 4 / 6 slots all land within +-1.5 ms on the k = 20 MLP proof
+    //     (73-77 ms, box-to-box variation included); four keeps a phase to two or three streams and is best or tied at k = 20 (einsum, MLP)
+    //     and k = 22.
     //   * witness-shaped columns (advice, multiplicities: one or two non-zero digits per scalar, every kernel of the chain latency-bound
     //     whatever n is): groups of SIX (12 advice columns = 2 chains, 8 multiplicity columns = 6 + 2): 81.0 against 82.0 ms with four.
     // EZKL_MSM_GROUP_SMALL / EZKL_MSM_GROUP_BIG override one class, EZKL_MSM_GROUP both.
