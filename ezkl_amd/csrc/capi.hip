@@ -803,6 +803,13 @@ int ezkl_hip_stream_synchronize(void* stream) {
 int ezkl_hip_stream_destroy(void* stream) {
     if (!stream) return EZKL_OK;
     EZ_CTX(c);
+    auto it = c->scratch_by_stream.find((hipStream_t)stream);        // the stream's scratch arena goes with it
+    if (it != c->scratch_by_stream.end()) {
+        EZ_HIP(hipStreamSynchronize((hipStream_t)stream));
+        if (it->second.ptr) (void)hipFree(it->second.ptr);
+        if (it->second.last_event) (void)hipEventDestroy(it->second.last_event);
+        c->scratch_by_stream.erase(it);
+    }
     EZ_HIP(hipStreamDestroy((hipStream_t)stream));
     return EZKL_OK;
 }
