@@ -433,3 +433,29 @@ def test_keygen_prepares_the_sweep_kernel(hip, golden_srs, tmp_path, monkeypatch
     compiled, from_disk, hits = json.loads(r.stdout.strip().splitlines()[-1])
     if files:
         assert compiled == 0 and from_disk == 1
+
+
+@pytest.mark.gpu
+def test_swap_proof_commitments_cross_check(hip, golden_srs):
+    """The reference's one cross-check between two code paths of this boundary (tests/integration_tests.rs:699-707, 1380-1392
+    `swap-proof-commitments` after kzg_prove_and_verify_kzg_output; src/pfsys/mod.rs:540): PolyCommitChip::commit of a message
+    (gen-witness: the unusable rows hold Blind::default() = 1) must EQUAL the prover's commitment of the advice column that holds the
+    message with polycommit visibility (an unblinded column).  Here: the first advice column of a small circuit is unblinded; the first
+    64 bytes of the proof (big-endian x | y of the first advice commitment) are polycommit_commit's first point."""
+    from ezkl_amd import backend as B
+    from conftest import fe_from_int
+    k = 6
+    a, b, c = P.adv(0), P.adv(1), P.adv(2)
+    cs = P.ConstraintSystem(k, 3, 3, [P.fix(0) * (c - a * b), P.fix(1) * (c - P.adv(2, -1) - a * b)], [("adv", 0), ("adv", 1), ("adv", 2), ("fix", 2)], unblinded=(0,))
+    adv, fixed, copies = witness(cs, 7)
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    proof = N.create_proof(pk, g, gl, adv, seed=3)
+    u = cs.usable
+    params = hip.ParamsKZG.read(golden_srs["buf"])
+    pts = B.polycommit_commit(np.ascontiguousarray(adv[0][:u]), cs.n - u, params)          # the message = the column's usable rows
+    x, y = P.point_to_ints(pts[0])
+    assert proof[:64] == x.to_bytes(32, "big") + y.to_bytes(32, "big")
+    # a blinded column commits to something else (random unusable rows): the equality is a property of the unblinded column
+    x1, y1 = P.point_to_ints(B.polycommit_commit(np.ascontiguousarray(adv[1][:u]), cs.n - u, params)[0])
+    assert proof[64:128] != x1.to_bytes(32, "big") + y1.to_bytes(32, "big")
+    params.free()
