@@ -99,6 +99,21 @@ def msm(scalars, bases, naive=False):
     return o
 
 
+def g1_to_lagrange(g, k):
+    """ParamsKZG::downsize's g_to_lagrange, restated naively (halo2: an FFT with omega^-1 over the projective points, scaled by 1 / n;
+    called through /root/reference/src/execute.rs:1739-1750): g_lagrange[i] = sum_j c_ij g[j] with c_i the coefficients of the i-th
+    Lagrange basis polynomial of the 2^k-point domain -- one oracle MSM per output point, O(n^2): for the small sizes the tests compare
+    the device's inverse NTT over G1 against (ezkl_hip_bases_downsize)."""
+    n = 1 << k
+    g = np.ascontiguousarray(g[:n], np.uint64)
+    one = np.frombuffer(((1 << 256) % 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001).to_bytes(32, "little"), np.uint64)
+    out = np.empty((n, 8), np.uint64)
+    for i in range(n):
+        e = np.zeros((n, 4), np.uint64); e[i] = one
+        out[i] = msm(lagrange_to_coeff(e, k) if k else e, g)
+    return out
+
+
 def fft(a, log_n, omega_mont):
     a = _fe(a).copy(); assert a.shape == (1 << log_n, 4)
     w = _fe(omega_mont)

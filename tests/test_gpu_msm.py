@@ -494,12 +494,10 @@ def test_params_downsize_matches_the_reference_srs_and_the_oracle(hip, golden_sr
         g2_, gl2 = bg.downsize(kk)
         got = gl2.download()
         assert (g2_.download() == g[:n2]).all()
+        assert (got == ob.g1_to_lagrange(g, kk)).all(), kk                           # (2) L_i(s) G through the oracle's naive restatement
         acc = got[0]
-        for i in range(n2):
-            e = np.zeros((n2, 4), np.uint64); e[i] = fe_from_int(1)
-            coeffs = ob.lagrange_to_coeff(e, kk) if kk else e
-            assert (got[i] == ob.msm(coeffs, g[:n2])).all(), (kk, i)                # (2) L_i(s) G through the oracle
-            if i: acc = B.g1_add_affine(acc, got[i])
+        for i in range(1, n2):
+            acc = B.g1_add_affine(acc, got[i])
         assert (acc == g[0]).all()
         if kk >= 4:
             v = rand_fr(rng, n2)

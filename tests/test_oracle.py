@@ -230,3 +230,20 @@ def test_sweep_schedule_keeps_the_value(seed):
         gconsts = np.zeros((1, 4), np.uint64)
     assert (ob.eval_program(gsched, gp.n_intermediates, gconsts, grots, cols, chal, k, ek, previous=prev) ==
             ob.eval_program(gcode, gp.n_intermediates, gconsts, grots, cols, chal, k, ek, previous=prev)).all()
+
+
+def test_g1_to_lagrange_reproduces_the_reference_srs(golden_srs):
+    """the oracle's naive ParamsKZG::downsize / g_to_lagrange (oracle.binding.g1_to_lagrange: one MSM of Lagrange-polynomial
+    coefficients per point) pinned on the reference's k = 6 SRS file: from `g` it must rebuild the file's own `g_lagrange` section,
+    and the k' = 4 Lagrange basis must commit like the coefficient basis (commit_lagrange(v) == commit(iNTT v))"""
+    from oracle import binding as ob
+    g, gl = golden_srs["g"], golden_srs["g_lagrange"]
+    assert (ob.g1_to_lagrange(g, 6) == gl).all()
+    gl4 = ob.g1_to_lagrange(g, 4)
+    rng = np.random.default_rng(4)
+    v = rand_fr(rng, 16)
+    assert (ob.msm(v, gl4) == ob.msm(ob.lagrange_to_coeff(v, 4), g[:16])).all()
+    acc = gl4[0]
+    for i in range(1, 16):
+        acc = ob.g1_add(acc, gl4[i])
+    assert (acc == g[0]).all()
