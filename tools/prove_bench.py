@@ -249,6 +249,7 @@ if not SYNTH:
             prove_cold.write(d, k, g, gl, g2, s_g2, cs, npk.to_bytes(), by_phase, instances, 5)
             t_write = time.time() - t0
             size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+            B.pool_trim()                                               # the children share this device: give the parked columns back first
             def cold_child(extra_env):
                 r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "prove_cold.py"), "run", d],
                                    capture_output=True, text=True, timeout=900, env=dict(os.environ, **extra_env))
