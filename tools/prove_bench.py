@@ -250,7 +250,9 @@ if not SYNTH:
             t_write = time.time() - t0
             size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
             B.pool_trim()                                               # the children share this device: give the parked columns back first
+            gap = float(os.environ.get("EZKL_COLD_GAP_S", "0"))          # let the driver finish releasing the previous process's VRAM first
             def cold_child(extra_env):
+                time.sleep(gap)
                 r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "prove_cold.py"), "run", d],
                                    capture_output=True, text=True, timeout=900, env=dict(os.environ, **extra_env))
                 return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}

@@ -19,7 +19,7 @@
 #   group        prover group, 2 and 4 contexts on one device, k = 20 MLP            -> <tag>_group{2,4}.json
 #   multi2       two owner-mode ranks (gloo) sharing the device, k = 20 MLP          -> <tag>_multi2.json
 #   k22          K=22 MLP_BLOCKS=5 MLP_FILL=25 proof + HBM high-water (opt-in size)  -> <tag>_mlp_k22.log
-#   k22cold      the same with the cold one-shot (writes ~45 GB of artefacts to /tmp) -> <tag>_mlp_k22_cold.log
+#   k22cold      the same with the cold one-shot (writes 68 GB of artefacts to /tmp) -> <tag>_mlp_k22_cold.log
 #   ab:<name>    an A/B experiment of tools/ab.sh (group, circuits, hwq, prio, evalh, ...)  -> <tag>_ab_<name>.log
 #   sh:<file>    bash tools/<file>                                                    -> <tag>_<file>.log
 #   tests:<a,b>  pytest -m gpu on the listed files                                  -> <tag>_pytest_subset.log
@@ -95,7 +95,7 @@ j = json.loads(sys.stdin.read()); print(j['prove_seconds_gpu_runs'], j['prove_br
       F=${JOB#tests:}; (cd "$R" && timeout ${SUITE_TIMEOUT:-900} python -m pytest $(echo "$F" | tr ',' ' ') -m gpu -q --durations=15 -p no:cacheprovider) > "$O/${TAG}_pytest_subset.log" 2>&1
       echo "pytest rc=$?" >> "$O/${TAG}_pytest_subset.log"; tail -40 "$O/${TAG}_pytest_subset.log" ;;
     k22cold)
-      (cd "$R" && CIRCUIT=mlp K=22 MLP_BLOCKS=5 MLP_FILL=${K22_FILL:-25} REPS=2 EZKL_COLD_DIR=${EZKL_COLD_DIR:-/tmp} timeout 1800 python tools/prove_bench.py --pinned --cold) > "$O/${TAG}_mlp_k22_cold.log" 2>&1
+      (cd "$R" && CIRCUIT=mlp K=22 MLP_BLOCKS=5 MLP_FILL=${K22_FILL:-25} REPS=2 EZKL_COLD_GAP_S=${EZKL_COLD_GAP_S:-10} EZKL_COLD_DIR=${EZKL_COLD_DIR:-/tmp} timeout 1800 python tools/prove_bench.py --pinned --cold) > "$O/${TAG}_mlp_k22_cold.log" 2>&1
       tail -1 "$O/${TAG}_mlp_k22_cold.log" | python -c "
 import sys, json
 j = json.loads(sys.stdin.read()); print(j['prove_seconds_gpu_runs'], 'cold', json.dumps(j.get('cold'))[:1500])"; df -h /tmp | tail -1 ;;
