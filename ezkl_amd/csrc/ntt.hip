@@ -15,6 +15,7 @@
 // minimum is 64 B.  Arithmetic: (log2 N)/2 + (P-1) Montgomery products per element --
 // the kernel is integer-VALU bound, not HBM bound.
 #include "common.hpp"
+#include "field29.hpp"
 #include <string.h>
 
 namespace ezkl {
@@ -45,6 +46,12 @@ struct PassArgs {
     // it sweeps): blockIdx.y = column * 2^cm_log_cnt + local coset, coset = cm_first + local; the output holds 2^cm_log_cnt cosets
     uint32_t cm, cm_log_e, dit, cm_first, cm_log_cnt;
     const fe_t* tw_pre;
+    // radix-2^29 pass (ntt_pass29_kernel): stage-major twiddles w_(2^s)^o at 2^(s-1) - 1 + o as unpacked limbs in the 2^261 domain --
+    // one table serves every pass of a plan (tw_stage29); the twisted first pass of the coset-major transform takes coset b's at
+    // tw_pre29 + b * R.  Stages 1 .. lds_stages are staged in LDS, the later ones are read from the table.
+    const f29_t* tw_stage29;
+    const f29_t* tw_pre29;
+    uint32_t lds_stages;
 };
 
 EZ_D void lds_put(uint2* d, uint32_t tile, uint32_t e, const fe_t& x) {
@@ -280,16 +287,223 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     }
 }
 
+// ---- the same pass in radix 2^29 (field29.hpp) ------------------------------------------------------------------------------------
+// 87 % of what the radix-2^32 pass issues is its 281-slot Montgomery product; the lazily reduced 9 x 29-bit product
+// takes 186.  Round 2 lost that gain to conversions and range control because it kept the decimation-in-frequency butterfly, whose sums
+// double in size every stage.  This pass runs every column transform decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The
+// product comes first, so t < 2p whatever v was, a value grows by at most 4p per stage (< 54p after the 11 stages of the largest tile,
+// far below the 1000p the product accepts) and limbs grow by at most 2 units of 2^29 per stage: the only range control is ONE carry
+// propagation per element at the end of a two-stage register group -- no comparison, no conditional subtraction inside the transform.
+// Elements are 8 x 32-bit words in HBM (the files' 2^256 Montgomery domain, untouched: the twiddles carry the 2^261 of the product) and
+// 9 limbs in LDS (four 8-byte planes + one 4-byte plane); the inter-pass product brings a value back below 2p for the work buffer, the last
+// pass subtracts floor(top limb / (p >> 232)) p and once more p conditionally.  The stage-1 twiddles of a plain transform are 1: no product.
+// tools/ntt29_model.py replays this arithmetic with every register checked for overflow (tests/test_ntt29_model.py).
+EZ_D void lds_put29(uint2* d, uint32_t* d8, uint32_t tile, uint32_t e, const f29_t& x) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) d[q * tile + e] = make_uint2(x.v[2 * q], x.v[2 * q + 1]);
+    d8[e] = x.v[8];
+}
+EZ_D f29_t lds_get29(const uint2* d, const uint32_t* d8, uint32_t tile, uint32_t e) {
+    f29_t x;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint2 t = d[q * tile + e];
+        x.v[2 * q] = t.x;
+        x.v[2 * q + 1] = t.y;
+    }
+    x.v[8] = d8[e];
+    return x;
+}
+// normalized x < 2^261 -> [0, p): q = floor(x[8] / ((p >> 232) + 1)) is floor(x / p) or one less; x + q (2^261 - p) mod 2^261 = x - q p
+EZ_D f29_t fr29_canonical(const f29_t& x) {
+    constexpr uint32_t D = (uint32_t)(Fr29C::P[8] + 1u);                                   // limb 8 of p = p >> 232
+    constexpr uint64_t MAGIC = (((uint64_t)1 << 51) + D - 1) / D;                          // exact quotients for x[8] < 2^29
+    const uint32_t q = (uint32_t)(((uint64_t)x.v[8] * MAGIC) >> 51);
+    f29_t r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc += (uint64_t)q * Fr29C::CSUB[0][i] + x.v[i];
+        r.v[i] = (uint32_t)acc & M29;
+        acc >>= 29;
+    }
+    return Fr29::cond_sub<0>(r);
+}
+
+// G consecutive DIT stages (s .. s+G-1, 1-based) of the R-point column transforms, 2^G elements per lane in registers; same geometry as
+// ntt_superstage_dit.  tw: the stage-major table -- its copy in LDS for the groups up to stage lds_stages, the table itself (FROM_TABLE)
+// for the later ones (lds_stages is even or the last stage, groups start at odd stages: a group never straddles).
+template <int G, int NTT_THREADS, bool FROM_TABLE>
+__device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, const f29_t* tw, uint32_t TILE, uint32_t logC, bool unit1, uint32_t s, uint32_t tid) {
+    constexpr uint32_t M = 1u << G;
+    const uint32_t C = 1u << logC;
+    const uint32_t lh = s - 1, h = 1u << lh;
+    const uint32_t ngroups = TILE >> G;
+    for (uint32_t gid = tid; gid < ngroups; gid += NTT_THREADS) {
+        const uint32_t c = gid & (C - 1), q = gid >> logC;
+        const uint32_t o = q & (h - 1), blk = q >> lh;
+        const uint32_t r0 = (blk << (lh + G)) + o;
+        f29_t x[M];
+#pragma unroll
+        for (uint32_t i = 0; i < M; i++) x[i] = lds_get29(data, d8, TILE, ((r0 + i * h) << logC) + c);
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const uint32_t half = 1u << t, st = s + t;
+            const uint32_t base = (1u << (st - 1)) - 1u;
+#pragma unroll
+            for (uint32_t i = 0; i < M; i++) {
+                if (i & half) continue;
+                if (unit1 && st == 1) {                              // w = 1; the partner is a loaded value, anything below 2^256 < 7p
+                    const f29_t v = x[i + half];
+                    x[i + half] = Fr29::sub<2>(x[i], v);
+                    x[i] = Fr29::add(x[i], v);
+                } else {
+                    const uint32_t off = o + (i & (half - 1)) * h;
+                    const f29_t w = ld_f29(tw + base + off);
+                    const f29_t v = Fr29::mul(x[i + half], w);       // limbs of x below 6 units of 2^29 (two stages since the last carry pass); v < 2p
+                    x[i + half] = Fr29::sub<1>(x[i], v);
+                    x[i] = Fr29::add(x[i], v);
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < M; i++) lds_put29(data, d8, TILE, ((r0 + i * h) << logC) + c, Fr29::normalize(x[i]));
+    }
+}
+
+template <int NTT_THREADS>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass29_kernel(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t TILE = 1u << a.log_tile;
+    const uint32_t logC = a.log_tile - a.log_r, C = 1u << logC;
+    const uint32_t log_s = a.log_m - a.log_r, S = 1u << log_s;
+    uint2* data = reinterpret_cast<uint2*>(smem);
+    uint32_t* d8 = reinterpret_cast<uint32_t*>(smem + 32u * TILE);
+    f29_t* tloc = reinterpret_cast<f29_t*>(smem + 36u * TILE);
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const uint32_t cm_l = a.cm ? (blockIdx.y & ((1u << a.cm_log_cnt) - 1u)) : 0u, cm_col = a.cm ? (blockIdx.y >> a.cm_log_cnt) : blockIdx.y;
+    const uint32_t cm_b = a.cm_first + cm_l;
+    const bool twisted = a.cm && a.first;                         // coset-major first pass: coset b's own stage table and inter-pass table
+    const fe_t* in = a.in + (size_t)(twisted ? cm_col : blockIdx.y) * a.in_stride;
+    fe_t* out = (a.cm && a.last) ? a.out + (size_t)cm_col * a.out_stride + ((size_t)cm_l << a.log_n) : a.out + (size_t)blockIdx.y * a.out_stride;
+    const fe_t* tw_inter = a.tw_inter ? a.tw_inter + (twisted ? ((size_t)cm_b << a.log_n) : 0) : nullptr;
+    const f29_t* tws = twisted ? a.tw_pre29 + ((size_t)cm_b << a.log_r) : a.tw_stage29;
+    for (uint32_t j = tid; j + 1 < (1u << a.lds_stages); j += NTT_THREADS) st_f29(tloc + j, ld_f29(tws + j));
+
+    uint32_t n_blocks = 1u << (a.log_n - a.log_r);               // last pass only
+    uint32_t sblk = a.npass >= 2 ? (n_blocks >> a.log_radix[0]) : 1u;
+    auto col_base = [&](uint32_t c) -> size_t {
+        if (!a.last) {
+            uint32_t colid = tile * C + c;
+            return ((size_t)(colid >> log_s) << a.log_m) + (colid & (S - 1));
+        }
+        uint32_t blk;
+        if (a.k1_major) {
+            uint32_t rest = tile % sblk, k10 = (tile / sblk) * C;
+            blk = (k10 + c) * sblk + rest;
+        } else {
+            blk = tile * C + c;
+        }
+        return (size_t)blk << a.log_r;
+    };
+
+    // ---- load: row i1 of the tile goes to LDS row bitrev(i1), as limbs ----
+    const size_t in_len = (size_t)1 << a.in_log_len;
+    auto load_one = [&](uint32_t e, size_t& addr_out) -> fe_t {
+        uint32_t c = e & (C - 1), i1 = e >> logC;
+        size_t addr = col_base(c) + ((size_t)i1 << log_s);
+        addr_out = addr;
+        if (!a.first || addr < in_len) return ld_fe(in + addr);
+        return Fr::zero();
+    };
+    auto put_one = [&](uint32_t e, size_t addr, const fe_t& raw) {
+        f29_t x = Fr29::unpack(raw);
+        if (a.first && a.coset_pre && addr < in_len) {
+            uint32_t m3 = (uint32_t)(addr % 3);
+            if (m3) x = Fr29::mul(x, Fr29::unpack(a.zeta[m3 - 1]));
+        }
+        e = (a.log_r ? ((__brev(e >> logC) >> (32 - a.log_r)) << logC) : 0u) | (e & (C - 1));
+        lds_put29(data, d8, TILE, e, x);
+    };
+    if (TILE == 4 * NTT_THREADS) {
+        fe_t x[4];
+        size_t ad[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = load_one(tid + i * NTT_THREADS, ad[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) put_one(tid + i * NTT_THREADS, ad[i], x[i]);
+    } else {
+        for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+            size_t ad;
+            fe_t x = load_one(e, ad);
+            put_one(e, ad, x);
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t s = 1; s <= a.log_r;) {
+        const uint32_t g = a.log_r - s >= 1 ? 2u : 1u;
+        if (s > a.lds_stages) {
+            if (g == 2) ntt_superstage29<2, NTT_THREADS, true>(data, d8, tws, TILE, logC, !twisted, s, tid);
+            else ntt_superstage29<1, NTT_THREADS, true>(data, d8, tws, TILE, logC, !twisted, s, tid);
+        } else {
+            if (g == 2) ntt_superstage29<2, NTT_THREADS, false>(data, d8, tloc, TILE, logC, !twisted, s, tid);
+            else ntt_superstage29<1, NTT_THREADS, false>(data, d8, tloc, TILE, logC, !twisted, s, tid);
+        }
+        __syncthreads();
+        s += g;
+    }
+
+    // ---- store: y[k1] sits at row k1 ----
+    auto store_one = [&](uint32_t e, const fe_t* twp) {
+        uint32_t c = e & (C - 1), k1 = e >> logC;
+        f29_t x = lds_get29(data, d8, TILE, (k1 << logC) + c);
+        if (!a.last) {
+            uint32_t colid = tile * C + c;
+            uint32_t pos = (k1 << log_s) + (colid & (S - 1));        // position inside the block
+            x = Fr29::mul(x, Fr29::unpack(twp ? *twp : ld_fe(tw_inter + pos)));          // below 2p: the work buffer holds 256-bit words
+            st_fe(out + (((size_t)(colid >> log_s) << a.log_m) + pos), Fr29::pack(x));
+        } else {
+            uint32_t blk = (uint32_t)(col_base(c) >> a.log_r);
+            size_t oidx = 0;
+            uint32_t rem = blk, lw = a.log_n - a.log_r, shift = 0;
+            for (uint32_t p = 0; p + 1 < a.npass; p++) {
+                lw -= a.log_radix[p];
+                uint32_t kp = rem >> lw;
+                rem &= (1u << lw) - 1;
+                oidx += (size_t)kp << shift;
+                shift += a.log_radix[p];
+            }
+            oidx += (size_t)k1 << shift;
+            x = a.post ? Fr29::cond_sub<0>(Fr29::mul(x, Fr29::unpack(a.post_c[oidx % 3]))) : fr29_canonical(x);
+            st_fe(out + oidx, Fr29::pack(x));
+        }
+    };
+    if (TILE == 4 * NTT_THREADS && !a.last) {
+        fe_t tw[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t e = tid + i * NTT_THREADS, c = e & (C - 1), k1 = e >> logC;
+            tw[i] = ld_fe(tw_inter + ((k1 << log_s) + ((tile * C + c) & (S - 1))));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) store_one(tid + i * NTT_THREADS, &tw[i]);
+    } else {
+        for (uint32_t e = tid; e < TILE; e += NTT_THREADS) store_one(e, nullptr);
+    }
+}
+
 // out[idx] = w^(e(idx)):  mode 0: e = idx * mult ;  mode 1: idx = k1*S + i2, e = i2 * k1 * mult  (mod 2^log_n)
+// init: 1 in the domain the table is wanted in (Fr::one() = the files' 2^256 domain; 32 there = the 2^261 domain of the radix-2^29 product)
 __global__ void ntt_twiddle_kernel(fe_t* out, uint32_t count, uint64_t mult, uint32_t log_n, uint32_t log_s,
-                                   int mode, const fe_t* pow2tab) {
+                                   int mode, const fe_t* pow2tab, fe_t init) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
     uint64_t e;
     if (mode == 0) e = (uint64_t)idx * mult;
     else e = (uint64_t)(idx & ((1u << log_s) - 1)) * (uint64_t)(idx >> log_s) * mult;
     e &= ((uint64_t)1 << log_n) - 1;
-    fe_t acc = Fr::one();
+    fe_t acc = init;
     for (uint32_t b = 0; b < log_n; b++)
         if ((e >> b) & 1) acc = Fr::mul(acc, ld_fe(pow2tab + b));
     st_fe(out + idx, acc);
@@ -301,8 +515,10 @@ __global__ void ntt_twiddle_kernel(fe_t* out, uint32_t count, uint64_t mult, uin
 //                                                 e = q * (b + E * o),     z = q          -> c_b^q * w_(2^s)^o
 //   mode 1 (first-pass inter-pass table, cnt = n): m = k1 * S + i2,     e = E * i2 * k1 + b * i2, z = i2        -> w_n^(i2 k1) * c_b^i2
 // for the coset generators c_b = zeta * w_ext^b, b < E = 2^log_e
-__global__ void ntt_coset_table_kernel(fe_t* out, uint32_t cnt, uint32_t log_e, uint32_t log_ext, uint32_t log_s, int mode, const fe_t* pow2tab,
-                                       fe_t zeta, fe_t zeta2) {
+// z0, z1, z2: zeta^0, zeta^1, zeta^2 in the wanted domain (all three = 1 for the stage table of a plain transform: log_e = 0, w_ext = w_n);
+// out29: the entries as unpacked radix-2^29 limbs instead of 256-bit words
+__global__ void ntt_coset_table_kernel(fe_t* out, f29_t* out29, uint32_t cnt, uint32_t log_e, uint32_t log_ext, uint32_t log_s, int mode, const fe_t* pow2tab,
+                                       fe_t z0, fe_t z1, fe_t z2) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ((size_t)cnt << log_e)) return;
     const uint64_t b = idx / cnt, m = idx % cnt;
@@ -311,7 +527,11 @@ __global__ void ntt_coset_table_kernel(fe_t* out, uint32_t cnt, uint32_t log_e, 
         uint32_t st = 1;                                                  // stage of entry m: 2^(st-1) - 1 <= m < 2^st - 1
         while (((uint64_t)1 << st) - 1 <= m) st++;
         const uint64_t o = m - (((uint64_t)1 << (st - 1)) - 1), log_nn = log_ext - log_e;
-        if (st > log_nn) { st_fe(out + idx, Fr::zero()); return; }     // padding entry
+        if (st > log_nn) {                                              // padding entry
+            if (out29) st_f29(out29 + idx, Fr29::zero());
+            else st_fe(out + idx, Fr::zero());
+            return;
+        }
         const uint64_t q = (uint64_t)1 << (log_nn - st);
         e = q * (b + (o << log_e));
         z = q % 3;
@@ -321,10 +541,11 @@ __global__ void ntt_coset_table_kernel(fe_t* out, uint32_t cnt, uint32_t log_e, 
         z = i2 % 3;
     }
     e &= ((uint64_t)1 << log_ext) - 1;
-    fe_t acc = z == 0 ? Fr::one() : (z == 1 ? zeta : zeta2);
+    fe_t acc = z == 0 ? z0 : (z == 1 ? z1 : z2);
     for (uint32_t q = 0; q < log_ext; q++)
         if ((e >> q) & 1) acc = Fr::mul(acc, ld_fe(pow2tab + q));
-    st_fe(out + idx, acc);
+    if (out29) st_f29(out29 + idx, Fr29::unpack(acc));
+    else st_fe(out + idx, acc);
 }
 // natural <-> coset-major order of an extended column: nat[E j + b] = cm[b n + j].  One thread per j moves E elements: the coset-major
 // side is coalesced across the wave, the natural side is E * 32 contiguous bytes per thread.
@@ -345,12 +566,14 @@ struct NttPlan {
     uint32_t log_radix[4] = {0, 0, 0, 0};
     fe_t* tw_local[4] = {nullptr, nullptr, nullptr, nullptr};
     fe_t* tw_inter[4] = {nullptr, nullptr, nullptr, nullptr};
+    f29_t* stage29 = nullptr;     // radix-2^29 passes: the stage-major table (2^max radix entries), tw_inter then in the 2^261 domain
     fe_t n_inv;
 };
 
 // per-context state (Ctx::ntt_state): the twiddle tables are device memory of the context's device
 struct CosetTables {
     fe_t* pre = nullptr;      // E x R1: the stage twiddles of the twisted DIT first pass
+    f29_t* pre29 = nullptr;   // the same as limbs in the 2^261 domain (radix-2^29 passes; inter is in that domain too then)
     fe_t* inter = nullptr;    // E x n (nullptr for single-pass transforms)
 };
 struct NttState {
@@ -365,6 +588,22 @@ static NttState& ntt_state() {
 }
 #define g_plans (ntt_state().plans)
 #define g_coset_tables (ntt_state().coset_tables)
+
+// EZKL_NTT_29=0 selects the radix-2^32 decimation-in-frequency pass (the A/B baseline); the tables of a plan are built for one of the two
+static bool ntt_use29() {
+    static const bool v = [] {
+        const char* e = getenv("EZKL_NTT_29");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+// stages whose twiddles are staged in LDS (2^6 - 1 = 63 entries of 36 B: a 1024-element tile + table = 38.3 KiB, four workgroups per CU)
+static uint32_t ntt_lds_stages(uint32_t log_r) { return log_r < 6 ? log_r : 6; }
+static size_t ntt_lds_bytes(uint32_t log_tile, uint32_t log_r) {
+    if (ntt_use29()) return 36u * ((size_t)1 << log_tile) + 36u * ((size_t)1 << ntt_lds_stages(log_r));
+    return 32u * ((size_t)1 << log_tile) + 32u * (log_r ? ((size_t)1 << (log_r - 1)) : 1);
+}
+static fe_t ntt_domain_one() { return ntt_use29() ? Fr::from_u64(32) : Fr::one(); }          // 2^261 = 32 * 2^256
 
 // Pass radices.  A pass of radix 2^r works on tiles of 2^r rows x 4 adjacent columns (128-byte row segments) held in LDS; r <= 8 is a
 // 32 KiB tile for a workgroup of 256 threads (4 workgroups per CU), r = 9 / 10 a 64 / 128 KiB tile for 512 / 1024 threads (16 waves per
@@ -397,6 +636,12 @@ static void plan_radices(uint32_t log_n, NttPlan* p) {
 // tile of a multi-pass plan's pass of radix 2^r: at least 1024 elements, 4 columns
 static uint32_t pass_log_tile(uint32_t log_r) { return log_r + 2 > NTT_LOG_TILE ? log_r + 2 : NTT_LOG_TILE; }
 static void launch_pass(const PassArgs& a, uint32_t tiles, unsigned blocks_y, size_t lds, hipStream_t st) {
+    if (ntt_use29()) {
+        if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass29_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
+        else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass29_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(ntt_pass29_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
+        return;
+    }
     if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
     else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
@@ -407,6 +652,9 @@ static int ntt_kernel_attrs() {
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass29_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass29_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass29_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     return EZKL_OK;
@@ -429,17 +677,27 @@ static int plan_get(Ctx* c, hipStream_t st, uint32_t log_n, const fe_t& omega, N
     EZ_HIP(hipMalloc(&d_pow2, sizeof(fe_t) * pow2.size()));
     EZ_HIP(hipMemcpyAsync(d_pow2, pow2.data(), sizeof(fe_t) * pow2.size(), hipMemcpyHostToDevice, st));
     uint32_t log_m = log_n;
+    const fe_t one = ntt_domain_one();
+    if (ntt_use29()) {
+        uint32_t maxlr = 0;
+        for (int i = 0; i < p->npass; i++) maxlr = p->log_radix[i] > maxlr ? p->log_radix[i] : maxlr;
+        const uint32_t cnt = 1u << maxlr;                       // w_(2^s)^o = omega^(o n / 2^s) whatever the pass: its first R - 1 entries serve a pass of radix R
+        EZ_HIP(hipMalloc(&p->stage29, sizeof(f29_t) * cnt));
+        hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, st, (fe_t*)nullptr, p->stage29, cnt, 0u, log_n, 0u, 0, d_pow2, one, one, one);
+    }
     for (int i = 0; i < p->npass; i++) {
         uint32_t lr = p->log_radix[i];
         uint32_t half = lr ? (1u << (lr - 1)) : 1u;
-        EZ_HIP(hipMalloc(&p->tw_local[i], sizeof(fe_t) * half));
-        hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(cdiv(half, 256)), dim3(256), 0, st, p->tw_local[i], half,
-                           (uint64_t)1 << (log_n - lr), log_n, 0u, 0, d_pow2);
+        if (!ntt_use29()) {
+            EZ_HIP(hipMalloc(&p->tw_local[i], sizeof(fe_t) * half));
+            hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(cdiv(half, 256)), dim3(256), 0, st, p->tw_local[i], half,
+                               (uint64_t)1 << (log_n - lr), log_n, 0u, 0, d_pow2, one);
+        }
         if (i + 1 < p->npass) {
             uint32_t cnt = 1u << log_m;
             EZ_HIP(hipMalloc(&p->tw_inter[i], sizeof(fe_t) * (size_t)cnt));
             hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(cdiv(cnt, 256)), dim3(256), 0, st, p->tw_inter[i], cnt,
-                               (uint64_t)1 << (log_n - log_m), log_n, log_m - lr, 1, d_pow2);
+                               (uint64_t)1 << (log_n - log_m), log_n, log_m - lr, 1, d_pow2, one);
         }
         log_m -= lr;
     }
@@ -484,7 +742,8 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
         rc = arena_reserve(scratch_arena(c, st), batch * n * sizeof(fe_t), st, (void**)&work);
         if (rc) return rc;
     }
-    const fe_t zeta = fr_const(FrConst::ZETA), zeta2 = fr_const(FrConst::ZETA2);
+    const fe_t dom = ntt_domain_one();                      // constants that enter a product carry the product's domain
+    const fe_t zeta = Fr::mul(fr_const(FrConst::ZETA), dom), zeta2 = Fr::mul(fr_const(FrConst::ZETA2), dom);
     uint32_t log_m = log_n;
     hipEvent_t e0, e1;
     rc = ev_pair(c, coset_mode ? "coset_ntt" : "ntt", &e0, &e1);
@@ -500,8 +759,10 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
         a.out_stride = last ? out_stride : n;
         a.tw_local = p->tw_local[i];
         a.tw_inter = p->tw_inter[i];
+        a.tw_stage29 = p->stage29;
         a.log_n = log_n;
         a.log_r = p->log_radix[i];
+        a.lds_stages = ntt_lds_stages(a.log_r);
         a.log_m = log_m;
         a.log_tile = p->npass == 1 ? log_n : pass_log_tile(a.log_r);
         if (a.log_tile < a.log_r) a.log_tile = a.log_r;
@@ -518,15 +779,14 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
             a.k1_major = (p->npass >= 2 && p->log_radix[0] >= logC) ? 1u : 0u;
             if (inverse_scale || coset_mode == 2) {
                 a.post = 1;
-                fe_t s = inverse_scale || coset_mode == 2 ? p->n_inv : Fr::one();
+                fe_t s = Fr::mul(inverse_scale || coset_mode == 2 ? p->n_inv : Fr::one(), dom);
                 a.post_c[0] = s;
-                a.post_c[1] = coset_mode == 2 ? Fr::mul(s, zeta2) : s;   // zeta^-1 = zeta^2
-                a.post_c[2] = coset_mode == 2 ? Fr::mul(s, zeta) : s;    // zeta^-2 = zeta
+                a.post_c[1] = coset_mode == 2 ? Fr::mul(s, fr_const(FrConst::ZETA2)) : s;   // zeta^-1 = zeta^2
+                a.post_c[2] = coset_mode == 2 ? Fr::mul(s, fr_const(FrConst::ZETA)) : s;    // zeta^-2 = zeta
             }
         }
         const uint32_t tiles = 1u << (log_n - a.log_tile);
-        const size_t lds = 32u * ((size_t)1 << a.log_tile) + 32u * (a.log_r ? ((size_t)1 << (a.log_r - 1)) : 1);
-        launch_pass(a, tiles, (unsigned)batch, lds, st);
+        launch_pass(a, tiles, (unsigned)batch, ntt_lds_bytes(a.log_tile, a.log_r), st);
         log_m -= a.log_r;
     }
     EZ_HIP(hipGetLastError());
@@ -555,14 +815,15 @@ static int coset_tables_get(Ctx* c, hipStream_t st, NttPlan* p, uint32_t log_n, 
     EZ_HIP(hipMalloc(&d_pow2, sizeof(fe_t) * pow2.size()));
     EZ_HIP(hipMemcpyAsync(d_pow2, pow2.data(), sizeof(fe_t) * pow2.size(), hipMemcpyHostToDevice, st));
     CosetTables t;
-    const fe_t zeta = fr_const(FrConst::ZETA), zeta2 = fr_const(FrConst::ZETA2);
+    const fe_t one = ntt_domain_one(), zeta = Fr::mul(fr_const(FrConst::ZETA), one), zeta2 = Fr::mul(fr_const(FrConst::ZETA2), one);
     const size_t n_pre = (size_t)1 << (lr + log_e);
-    EZ_HIP(hipMalloc(&t.pre, sizeof(fe_t) * n_pre));
-    hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_pre, 256)), dim3(256), 0, st, t.pre, 1u << lr, log_e, log_ext, log_s, 0, d_pow2, zeta, zeta2);
+    if (ntt_use29()) EZ_HIP(hipMalloc(&t.pre29, sizeof(f29_t) * n_pre));
+    else EZ_HIP(hipMalloc(&t.pre, sizeof(fe_t) * n_pre));
+    hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_pre, 256)), dim3(256), 0, st, t.pre, t.pre29, 1u << lr, log_e, log_ext, log_s, 0, d_pow2, one, zeta, zeta2);
     if (p->npass > 1) {
         const size_t n_int = (size_t)1 << log_ext;
         EZ_HIP(hipMalloc(&t.inter, sizeof(fe_t) * n_int));
-        hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_int, 256)), dim3(256), 0, st, t.inter, 1u << log_n, log_e, log_ext, log_s, 1, d_pow2, zeta, zeta2);
+        hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_int, 256)), dim3(256), 0, st, t.inter, (f29_t*)nullptr, 1u << log_n, log_e, log_ext, log_s, 1, d_pow2, one, zeta, zeta2);
     }
     EZ_HIP(hipGetLastError());
     EZ_HIP(hipStreamSynchronize(st));
@@ -601,8 +862,11 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         a.out_stride = last ? out_stride : n;
         a.tw_local = p->tw_local[i];
         a.tw_inter = first ? ct.inter : p->tw_inter[i];
+        a.tw_stage29 = p->stage29;
+        a.tw_pre29 = ct.pre29;
         a.log_n = log_n;
         a.log_r = p->log_radix[i];
+        a.lds_stages = ntt_lds_stages(a.log_r);
         a.log_m = log_m;
         a.log_tile = p->npass == 1 ? log_n : pass_log_tile(a.log_r);
         if (a.log_tile < a.log_r) a.log_tile = a.log_r;
@@ -622,8 +886,7 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
             a.k1_major = (p->npass >= 2 && p->log_radix[0] >= logC) ? 1u : 0u;
         }
         const uint32_t tiles = 1u << (log_n - a.log_tile);
-        const size_t lds = 32u * ((size_t)1 << a.log_tile) + 32u * (a.log_r ? ((size_t)1 << (a.log_r - 1)) : 1);
-        launch_pass(a, tiles, (unsigned)blocks, lds, st);
+        launch_pass(a, tiles, (unsigned)blocks, ntt_lds_bytes(a.log_tile, a.log_r), st);
         log_m -= a.log_r;
     }
     EZ_HIP(hipGetLastError());

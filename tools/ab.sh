@@ -6,7 +6,7 @@
 #   | prio (stream priorities) | evalh (sweep code generation) | merged (z committed under the lookup sums) | early (random polynomial
 #   committed under the witness upload x priorities) | matrix (early x groups, k = 20 / 22) | slots (batch slots x groups) | taper (upload
 #   phases in tapered groups) | benchvar (bench.py twice with 4 and 6 slots: box-to-box and run-to-run variation) | msmdebug (the batches
-#   of one proof as the library sees them)
+#   of one proof as the library sees them) | ntt29 (radix-2^29 DIT pass against the radix-2^32 DIF pass)
 R=$(cd "$(dirname "$0")/.." && pwd)
 run() {   # label, then VAR=value ... (CIRCUIT / K / REPS included)
   L=$1; shift
@@ -56,6 +56,12 @@ case "$1" in
   slots)
     for S in 2 3 4 6; do for BIG in 1 2 4; do run "SLOTS=$S BIG=$BIG" $M EZKL_MSM_SLOTS=$S EZKL_MSM_GROUP_BIG=$BIG; done; done
     run "mlp17 SLOTS=2" EZKL_MSM_SLOTS=2 CIRCUIT=mlp K=17 REPS=8; run "mlp17 SLOTS=4" EZKL_MSM_SLOTS=4 CIRCUIT=mlp K=17 REPS=8 ;;
+  ntt29)
+    # the radix-2^29 DIT pass against the radix-2^32 DIF pass: the NTT parity tests on the new pass, kernel times per column, then proofs
+    (cd "$R" && timeout 900 python -m pytest tests/test_gpu_ntt.py -m gpu -x -q 2>&1 | tail -4)
+    for V in 1 0; do echo "== EZKL_NTT_29=$V"; (cd "$R" && EZKL_NTT_29=$V timeout 300 python tools/ntt_ab.py 2>&1 | tail -5); done
+    for V in 1 0; do run "mlp20 NTT_29=$V" $M EZKL_NTT_29=$V; done
+    for V in 1 0; do run "mlp17 NTT_29=$V" CIRCUIT=mlp K=17 REPS=8 EZKL_NTT_29=$V; done ;;
   taper)
     for T in taper equal; do
       if [ $T = equal ]; then X="EZKL_MSM_NO_TAPER=1"; else X="A=1"; fi
