@@ -360,7 +360,7 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
                 } else {
                     const uint32_t off = o + (i & (half - 1)) * h;
                     const f29_t w = ld_f29(tw + base + off);
-                    const f29_t v = Fr29::mul(x[i + half], w);       // limbs of x below 6 units of 2^29 (two stages since the last carry pass); v < 2p
+                    const f29_t v = Fr29::mul(x[i + half], w);       // limbs of x below 6 units of 2^29 (at most two stages since the last carry pass); v < 2p
                     x[i + half] = Fr29::sub<1>(x[i], v);
                     x[i] = Fr29::add(x[i], v);
                 }
@@ -441,6 +441,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass29_kernel(PassArgs a) {
     }
     __syncthreads();
 
+    // register groups of two stages (radix 4): 36 data VGPRs, 96 in all.  Three stages between carry passes are possible arithmetically (limbs
+    // reach 7 units of 2^29, still 32 bits; tools/ntt29_model.py) but eight elements in registers take the kernel to 250 VGPRs, or to
+    // 100-190 spills under a 128 / 168 cap.
     for (uint32_t s = 1; s <= a.log_r;) {
         const uint32_t g = a.log_r - s >= 1 ? 2u : 1u;
         if (s > a.lds_stages) {

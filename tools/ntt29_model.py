@@ -149,16 +149,30 @@ def brev(x, bits):
     return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
 
 
+LDS_STAGES = 6
+GROUP = 2
+
+
+def group_stages(s, log_r):
+    """stages the register group starting at stage s covers.  The kernel uses GROUP = 2 (36 data VGPRs); 3 is checked here as well: the limbs
+    stay inside 32 bits for three stages between carry passes, it is the register file that says no (250 VGPRs)"""
+    left = log_r - s + 1
+    if s <= min(log_r, LDS_STAGES):
+        left = min(left, min(log_r, LDS_STAGES) - s + 1)
+        return min(GROUP, left)
+    return min(2, left)
+
+
 def dit_column(col, log_r, table, unit1, stats=None):
-    """the R-point column transform of one tile column as ntt_superstage29 runs it: rows loaded in bit-reversed order, radix-4 register groups
-    (two stages, then a normalisation), natural order out.  col: R numbers < 2^256 (the data's Montgomery domain)."""
+    """the R-point column transform of one tile column as ntt_superstage29 runs it: rows loaded in bit-reversed order, register groups of up
+    to three stages with ONE carry propagation at the end, natural order out.  col: R numbers < 2^256 (the data's Montgomery domain)."""
     R = 1 << log_r
     rows = [None] * R
     for i1 in range(R):
         rows[brev(i1, log_r)] = unpack(col[i1])
     s = 1
     while s <= log_r:
-        g = 2 if log_r - s >= 1 else 1
+        g = group_stages(s, log_r)
         M, h = 1 << g, 1 << (s - 1)
         for q in range(R >> g):
             o, blk = q & (h - 1), q >> (s - 1)
@@ -189,7 +203,9 @@ def dit_column(col, log_r, table, unit1, stats=None):
     return rows
 
 
-def selftest(seed=1, log_rs=(1, 2, 3, 5, 6, 8, 11)):
+def selftest(seed=1, log_rs=(1, 2, 3, 5, 6, 8, 11), group=2):
+    global GROUP
+    GROUP = group
     rnd = random.Random(seed)
     gen = pow(7, (P - 1) >> 28, P)
     worst = {}
