@@ -3,17 +3,17 @@
 // Replaces halo2curves::fft::best_fft and the EvaluationDomain wrappers around it (SURVEY.md §8(a) A11;
 // type used in-tree at /root/reference/src/circuit/modules/polycommit.rs:52).  Natural order in and out.
 //
-// Decomposition (decimation in frequency, N = R_1 * ... * R_P, R_p = 2^r_p <= 256):
+// Decomposition (N = R_1 * ... * R_P, R_p = 2^r_p <= 256, Cooley-Tukey across the passes):
 //   pass p works on contiguous blocks of size M_p = N / (R_1..R_{p-1}); inside a block, index
 //   i = i1 * S + i2 (S = M_p / R_p).  A workgroup owns a TILE of C = TILE/R_p adjacent columns i2 (so each
-//   global row segment is C*32 B contiguous -> coalesced), loads it into LDS as 4 planes of 8-byte limb
-//   pairs (conflict-free ds_read_b64), runs the r_p butterfly stages there with the R_p/2 local twiddles
-//   staged in LDS, multiplies by the inter-pass twiddle w_M^(i2*k1) (table streamed alongside the data) and
-//   writes back in place.  The last pass (S = 1) owns C whole blocks chosen with consecutive leading digit
-//   so that its digit-reversed (natural-order) output is written C*32 B at a time as well.
+//   global row segment is C*32 B contiguous -> coalesced), loads it into LDS, runs the R_p-point column
+//   transforms there (decimation in time, radix-2^29 lazy limbs: see ntt_pass_kernel), multiplies by the
+//   inter-pass twiddle w_M^(i2*k1) (table streamed alongside the data) and writes back.  The last pass
+//   (S = 1) owns C whole blocks chosen with consecutive leading digit so that its digit-reversed
+//   (natural-order) output is written C*32 B at a time as well.
 // HBM traffic per element: P x (32 B read + 32 B write) + 32 B twiddle in non-last passes; algorithmic
 // minimum is 64 B.  Arithmetic: (log2 N)/2 + (P-1) Montgomery products per element --
-// the kernel is integer-VALU bound, not HBM bound (DESIGN.md §roofline).
+// the kernel is integer-VALU bound, not HBM bound (DESIGN.md §4.2).
 #include "common.hpp"
 #include "field29.hpp"
 #include <string.h>
@@ -28,7 +28,6 @@ struct PassArgs {
     const fe_t* in;
     fe_t* out;
     size_t in_stride, out_stride;
-    const fe_t* tw_local;   // R/2 entries: w_R^j
     const fe_t* tw_inter;   // M entries: w_M^(i2*k1) at k1*S + i2 (null in last pass)
     uint32_t log_n, log_r, log_m, log_tile;
     uint32_t last, first;
@@ -39,14 +38,13 @@ struct PassArgs {
     uint32_t k1_major;      // last pass: tile owns C blocks with consecutive leading digit
     fe_t zeta[2];           // zeta, zeta^2
     fe_t post_c[3];
-    // coset-major extended evaluation (coset_cm_run): blockIdx.y = column * E + coset; the first pass is a TWISTED DIT transform (dit = 1,
-    // stage twiddles of coset b at tw_pre + b * R: ntt_superstage_dit) and its inter-pass table is per coset (tw_inter + coset * 2^log_n
-    // holds w^(i2 k1) * c_b^i2): the coset scaling c_b^j costs no product
+    // coset-major extended evaluation (coset_cm_run): blockIdx.y = column * E + coset; the first pass is a TWISTED transform (stage
+    // twiddles of coset b at tw_pre29 + b * R) and its inter-pass table is per coset (tw_inter + coset * 2^log_n holds w^(i2 k1) * c_b^i2):
+    // the coset scaling c_b^j costs no product
     // a RANGE of cosets (ezkl_hip_coeff_to_cosets_range_dev: a rank of a sharded prover holds only the cosets of the key columns that
     // it sweeps): blockIdx.y = column * 2^cm_log_cnt + local coset, coset = cm_first + local; the output holds 2^cm_log_cnt cosets
-    uint32_t cm, cm_log_e, dit, cm_first, cm_log_cnt;
-    const fe_t* tw_pre;
-    // radix-2^29 pass (ntt_pass29_kernel): stage-major twiddles w_(2^s)^o at 2^(s-1) - 1 + o as unpacked limbs in the 2^261 domain --
+    uint32_t cm, cm_log_e, cm_first, cm_log_cnt;
+    // stage-major twiddles w_(2^s)^o at 2^(s-1) - 1 + o as unpacked limbs in the 2^261 domain --
     // one table serves every pass of a plan (tw_stage29); the twisted first pass of the coset-major transform takes coset b's at
     // tw_pre29 + b * R.  Stages 1 .. lds_stages are staged in LDS, the later ones are read from the table.
     const f29_t* tw_stage29;
@@ -54,243 +52,11 @@ struct PassArgs {
     uint32_t lds_stages;
 };
 
-EZ_D void lds_put(uint2* d, uint32_t tile, uint32_t e, const fe_t& x) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) d[q * tile + e] = make_uint2(x.v[2 * q], x.v[2 * q + 1]);
-}
-EZ_D fe_t lds_get(const uint2* d, uint32_t tile, uint32_t e) {
-    fe_t x;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint2 t = d[q * tile + e];
-        x.v[2 * q] = t.x;
-        x.v[2 * q + 1] = t.y;
-    }
-    return x;
-}
-
-// G consecutive DIF stages (s .. s+G-1) of the R-point column FFTs on 2^G elements held in registers.
-// Group members are rows r0 + i*hG (hG = R >> (s+G)); at sub-stage t the partner distance is 2^(G-1-t) members
-// and the low element at in-block position pos = j + (i & (half-1))*hG takes twiddle w_R^(pos << (s+t)).
-template <int G, int NTT_THREADS>
-__device__ __forceinline__ void ntt_superstage(uint2* data, const fe_t* tloc, uint32_t TILE, uint32_t logC, uint32_t log_r,
-                                               uint32_t s, uint32_t tid) {
-    constexpr uint32_t M = 1u << G;
-    const uint32_t C = 1u << logC;
-    const uint32_t lhG = log_r - s - G, hG = 1u << lhG;        // rows between adjacent group members
-    const uint32_t ngroups = TILE >> G;
-    for (uint32_t gid = tid; gid < ngroups; gid += NTT_THREADS) {
-        const uint32_t c = gid & (C - 1), q = gid >> logC;
-        const uint32_t j = q & (hG - 1), blk = q >> lhG;
-        const uint32_t r0 = (blk << (log_r - s)) + j;
-        fe_t x[M];
-#pragma unroll
-        for (uint32_t i = 0; i < M; i++) x[i] = lds_get(data, TILE, ((r0 + i * hG) << logC) + c);
-#pragma unroll
-        for (int t = 0; t < G; t++) {
-            const uint32_t half = 1u << (G - 1 - t);
-            const bool need_tw = (s + t + 1 != log_r);            // last stage of the column FFT: twiddle = 1
-#pragma unroll
-            for (uint32_t i = 0; i < M; i++) {
-                if (i & half) continue;
-                // lazily reduced butterfly: everything lives in [0, 2p); the difference u - v + 2p goes into the twiddle product
-                // unreduced and the product skips its final subtraction (Field::mul_lazy) -- 281 issue slots instead of 309
-                fe_t u = x[i], v = x[i + half];
-                x[i] = Fr::add_lazy(u, v);
-                fe_t d = Fr::sub_lazy(u, v);
-                // twiddle exponent (j + (i & (half-1))*hG) << (s+t); in the last group hG == 1 and j == 0, so the
-                // members with (i & (half-1)) == 0 multiply by w^0 = 1: skipped (wave-uniform condition)
-                const bool unit = (hG == 1) && ((i & (half - 1)) == 0);
-                x[i + half] = (need_tw && !unit) ? Fr::mul_lazy(d, tloc[(j + (i & (half - 1)) * hG) << (s + t)]) : Fr::reduce_2p(d);
-            }
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < M; i++) lds_put(data, TILE, ((r0 + i * hG) << logC) + c, x[i]);
-    }
-}
-
-// G consecutive DIT stages (s .. s+G-1, 1-based: stage s joins blocks of 2^(s-1) rows) of a TWISTED R-point column transform
-// X[k] = sum_i x_i d^i w_R^(ik) = P(d w_R^k): with P(t) = Pe(t^2) + t Po(t^2) the twist is absorbed by the twiddles -- stage s multiplies
-// by d^(R/2^s) w_(2^s)^o (table entry 2^(s-1) - 1 + o) -- so evaluating on a coset costs no product beyond the plain transform's.
-// Input rows are in bit-reversed order (the loader permutes), output rows in natural order.  Stages below log_r read the twiddles staged in
-// LDS, the last stage (R/2 entries, each used once per column) reads them from the table in global memory.
-template <int G, int NTT_THREADS>
-__device__ __forceinline__ void ntt_superstage_dit(uint2* data, const fe_t* tloc, const fe_t* tglob, uint32_t TILE, uint32_t logC, uint32_t log_r, uint32_t s,
-                                                   uint32_t tid) {
-    constexpr uint32_t M = 1u << G;
-    const uint32_t C = 1u << logC;
-    const uint32_t lh = s - 1, h = 1u << lh;
-    const uint32_t ngroups = TILE >> G;
-    for (uint32_t gid = tid; gid < ngroups; gid += NTT_THREADS) {
-        const uint32_t c = gid & (C - 1), q = gid >> logC;
-        const uint32_t o = q & (h - 1), blk = q >> lh;
-        const uint32_t r0 = (blk << (lh + G)) + o;
-        fe_t x[M];
-#pragma unroll
-        for (uint32_t i = 0; i < M; i++) x[i] = lds_get(data, TILE, ((r0 + i * h) << logC) + c);
-#pragma unroll
-        for (int t = 0; t < G; t++) {
-            const uint32_t half = 1u << t, st = s + t;
-            const uint32_t base = (1u << (st - 1)) - 1u;
-#pragma unroll
-            for (uint32_t i = 0; i < M; i++) {
-                if (i & half) continue;
-                const uint32_t off = o + (i & (half - 1)) * h;
-                const fe_t w = st == log_r ? ld_fe(tglob + base + off) : tloc[base + off];
-                const fe_t u = x[i], v = Fr::mul_lazy(x[i + half], w);        // everything in [0, 2p)
-                x[i] = Fr::add_lazy(u, v);
-                x[i + half] = Fr::reduce_2p(Fr::sub_lazy(u, v));
-            }
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < M; i++) lds_put(data, TILE, ((r0 + i * h) << logC) + c, x[i]);
-    }
-}
-
-template <int NTT_THREADS>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t TILE = 1u << a.log_tile, R = 1u << a.log_r;
-    const uint32_t logC = a.log_tile - a.log_r, C = 1u << logC;
-    const uint32_t log_s = a.log_m - a.log_r, S = 1u << log_s;
-    uint2* data = reinterpret_cast<uint2*>(smem);
-    fe_t* tloc = reinterpret_cast<fe_t*>(smem + 32u * TILE);
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
-    const uint32_t cm_l = a.cm ? (blockIdx.y & ((1u << a.cm_log_cnt) - 1u)) : 0u, cm_col = a.cm ? (blockIdx.y >> a.cm_log_cnt) : blockIdx.y;
-    const uint32_t cm_b = a.cm_first + cm_l;                       // the coset this block evaluates on; cm_l = its place in the output
-    // coset-major: the first pass reads column cm_col (one copy of the coefficients serves all E cosets), the last pass writes coset
-    // cm_b of that column's extended form; the work buffer in between holds one 2^log_n block per (column, coset)
-    const fe_t* in = a.in + (size_t)((a.cm && a.first) ? cm_col : blockIdx.y) * a.in_stride;
-    fe_t* out = (a.cm && a.last) ? a.out + (size_t)cm_col * a.out_stride + ((size_t)cm_l << a.log_n) : a.out + (size_t)blockIdx.y * a.out_stride;
-    const fe_t* tw_inter = a.tw_inter ? a.tw_inter + ((a.cm && a.first) ? ((size_t)cm_b << a.log_n) : 0) : nullptr;
-
-    if (a.dit) {                    // twisted DIT pass (coset-major first pass): stages 1 .. log_r - 1 of this coset's table
-        const fe_t* tw = a.tw_pre + ((size_t)cm_b << a.log_r);
-        for (uint32_t j = tid; j + 1 < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(tw + j);
-    } else {
-        for (uint32_t j = tid; j < (R >> 1); j += NTT_THREADS) tloc[j] = ld_fe(a.tw_local + j);
-    }
-
-    // ---- block / column geometry of this tile ----
-    // non-last: colid = tile*C + c ; base(c) = (colid >> log_s) * M + (colid & (S-1)), rows strided by S
-    // last    : blk(c) ; base(c) = blk * R, rows contiguous
-    uint32_t n_blocks = 1u << (a.log_n - a.log_r);               // last pass only
-    uint32_t sblk = a.npass >= 2 ? (n_blocks >> a.log_radix[0]) : 1u;
-    auto col_base = [&](uint32_t c) -> size_t {
-        if (!a.last) {
-            uint32_t colid = tile * C + c;
-            return ((size_t)(colid >> log_s) << a.log_m) + (colid & (S - 1));
-        }
-        uint32_t blk;
-        if (a.k1_major) {
-            uint32_t rest = tile % sblk, k10 = (tile / sblk) * C;
-            blk = (k10 + c) * sblk + rest;
-        } else {
-            blk = tile * C + c;
-        }
-        return (size_t)blk << a.log_r;
-    };
-
-    // ---- load tile (lanes run over c first: C*32 B contiguous per row) ----
-    // All of a lane's global loads are issued before the first LDS write (4 per lane for the 1024-element
-    // tile), so one HBM latency is paid per phase instead of one per element.
-    const size_t in_len = (size_t)1 << a.in_log_len;
-    auto load_one = [&](uint32_t e, size_t& addr_out) -> fe_t {
-        uint32_t c = e & (C - 1), i1 = e >> logC;
-        size_t addr = col_base(c) + ((size_t)i1 << log_s);
-        addr_out = addr;
-        if (!a.first || addr < in_len) return ld_fe(in + addr);
-        return Fr::zero();
-    };
-    auto put_one = [&](uint32_t e, size_t addr, fe_t x) {
-        if (a.first && a.coset_pre && addr < in_len) {
-            uint32_t m3 = (uint32_t)(addr % 3);
-            if (m3) x = Fr::mul(x, a.zeta[m3 - 1]);
-        }
-        // twisted DIT pass: the row of input i1 is its bit reversal
-        if (a.dit) e = (a.log_r ? ((__brev(e >> logC) >> (32 - a.log_r)) << logC) : 0u) | (e & (C - 1));
-        lds_put(data, TILE, e, x);     // LDS index = i1*C + c
-    };
-    if (TILE == 4 * NTT_THREADS) {
-        fe_t x[4];
-        size_t ad[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = load_one(tid + i * NTT_THREADS, ad[i]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) put_one(tid + i * NTT_THREADS, ad[i], x[i]);
-    } else {
-        for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
-            size_t ad;
-            fe_t x = load_one(e, ad);
-            put_one(e, ad, x);
-        }
-    }
-    __syncthreads();
-
-    // ---- r DIF stages, up to three at a time in registers (radix-8 groups), one LDS round trip per group ----
-    if (a.dit) {
-        const fe_t* tglob = a.tw_pre + ((size_t)cm_b << a.log_r);
-        for (uint32_t s = 1; s <= a.log_r;) {
-            const uint32_t g = a.log_r - s >= 1 ? 2u : 1u;
-            if (g == 2) ntt_superstage_dit<2, NTT_THREADS>(data, tloc, tglob, TILE, logC, a.log_r, s, tid);
-            else ntt_superstage_dit<1, NTT_THREADS>(data, tloc, tglob, TILE, logC, a.log_r, s, tid);
-            __syncthreads();
-            s += g;
-        }
-    } else
-    for (uint32_t s = 0; s < a.log_r;) {
-        const uint32_t g = a.log_r - s >= 2 ? 2u : a.log_r - s;      // radix-4 groups: 32 data VGPRs, 4 waves/SIMD
-        if (g == 2) ntt_superstage<2, NTT_THREADS>(data, tloc, TILE, logC, a.log_r, s, tid);
-        else ntt_superstage<1, NTT_THREADS>(data, tloc, TILE, logC, a.log_r, s, tid);
-        __syncthreads();
-        s += g;
-    }
-
-    // ---- store: y[k1] sits at row bitrev(k1) ----
-    auto store_one = [&](uint32_t e, const fe_t* twp) {
-        uint32_t c = e & (C - 1), k1 = e >> logC;
-        uint32_t row = a.dit ? k1 : (a.log_r ? (__brev(k1) >> (32 - a.log_r)) : 0u);       // DIT leaves the outputs in natural order
-        fe_t x = lds_get(data, TILE, (row << logC) + c);
-        if (!a.last) {
-            uint32_t colid = tile * C + c;
-            uint32_t pos = (k1 << log_s) + (colid & (S - 1));        // position inside the block
-            x = Fr::mul_lazy(x, twp ? *twp : ld_fe(tw_inter + pos));                  // the work buffer holds values in [0, 2p)
-            st_fe(out + (((size_t)(colid >> log_s) << a.log_m) + pos), x);
-        } else {
-            uint32_t blk = (uint32_t)(col_base(c) >> a.log_r);
-            // digits of blk (most significant first) are k_1..k_{P-1}; natural index = sum k_p * (R_1..R_{p-1})
-            size_t oidx = 0;
-            uint32_t rem = blk, lw = a.log_n - a.log_r, shift = 0;
-            for (uint32_t p = 0; p + 1 < a.npass; p++) {
-                lw -= a.log_radix[p];
-                uint32_t kp = rem >> lw;
-                rem &= (1u << lw) - 1;
-                oidx += (size_t)kp << shift;
-                shift += a.log_radix[p];
-            }
-            oidx += (size_t)k1 << shift;
-            x = a.post ? Fr::mul(x, a.post_c[oidx % 3]) : Fr::reduce_once(x);          // [0, 2p) -> canonical
-            st_fe(out + oidx, x);
-        }
-    };
-    if (TILE == 4 * NTT_THREADS && !a.last) {
-        fe_t tw[4];                       // the four inter-pass twiddles of this lane, fetched together
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t e = tid + i * NTT_THREADS, c = e & (C - 1), k1 = e >> logC;
-            tw[i] = ld_fe(tw_inter + ((k1 << log_s) + ((tile * C + c) & (S - 1))));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) store_one(tid + i * NTT_THREADS, &tw[i]);
-    } else {
-        for (uint32_t e = tid; e < TILE; e += NTT_THREADS) store_one(e, nullptr);
-    }
-}
-
-// ---- the same pass in radix 2^29 (field29.hpp) ------------------------------------------------------------------------------------
-// 87 % of what the radix-2^32 pass issues is its 281-slot Montgomery product; the lazily reduced 9 x 29-bit product
-// takes 186.  Round 2 lost that gain to conversions and range control because it kept the decimation-in-frequency butterfly, whose sums
-// double in size every stage.  This pass runs every column transform decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The
+// ---- the pass: column transforms in radix 2^29 (field29.hpp), decimation in time -------------------------------------------------------
+// Until round 4 the pass ran a decimation-in-frequency butterfly on 8 x 32-bit limbs: 87 % of what it issued was its 281-slot Montgomery
+// product; the lazily reduced 9 x 29-bit product takes 205 instructions.  Round 2's attempt to use it lost the gain to
+// conversions and range control because in a DIF butterfly the sums double in size every stage.  Here every column transform runs
+// decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The
 // product comes first, so t < 2p whatever v was, a value grows by at most 4p per stage (< 54p after the 11 stages of the largest tile,
 // far below the 1000p the product accepts) and limbs grow by at most 2 units of 2^29 per stage: the only range control is ONE carry
 // propagation per element at the end of a two-stage register group -- no comparison, no conditional subtraction inside the transform.
@@ -330,8 +96,11 @@ EZ_D f29_t fr29_canonical(const f29_t& x) {
     return Fr29::cond_sub<0>(r);
 }
 
-// G consecutive DIT stages (s .. s+G-1, 1-based) of the R-point column transforms, 2^G elements per lane in registers; same geometry as
-// ntt_superstage_dit.  tw: the stage-major table -- its copy in LDS for the groups up to stage lds_stages, the table itself (FROM_TABLE)
+// G consecutive DIT stages (s .. s+G-1, 1-based: stage s joins blocks of 2^(s-1) rows) of the R-point column transforms, 2^G elements per
+// lane in registers.  A TWISTED transform X[k] = sum_i x_i d^i w_R^(ik) = P(d w_R^k) runs the same code: with P(t) = Pe(t^2) + t Po(t^2) the
+// twist is absorbed by the twiddles -- stage s multiplies by d^(R/2^s) w_(2^s)^o (table entry 2^(s-1) - 1 + o) -- so evaluating on a coset
+// costs no product beyond the plain transform's.  Input rows are in bit-reversed order (the loader permutes), output rows in natural order.
+// tw: the stage-major table -- its copy in LDS for the groups up to stage lds_stages, the table itself (FROM_TABLE)
 // for the later ones (lds_stages is even or the last stage, groups start at odd stages: a group never straddles).
 template <int G, int NTT_THREADS, bool FROM_TABLE>
 __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, const f29_t* tw, uint32_t TILE, uint32_t logC, bool unit1, uint32_t s, uint32_t tid) {
@@ -372,7 +141,7 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
 }
 
 template <int NTT_THREADS>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass29_kernel(PassArgs a) {
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t TILE = 1u << a.log_tile;
     const uint32_t logC = a.log_tile - a.log_r, C = 1u << logC;
@@ -567,17 +336,15 @@ struct NttPlan {
     uint32_t log_n = 0;
     int npass = 0;
     uint32_t log_radix[4] = {0, 0, 0, 0};
-    fe_t* tw_local[4] = {nullptr, nullptr, nullptr, nullptr};
-    fe_t* tw_inter[4] = {nullptr, nullptr, nullptr, nullptr};
-    f29_t* stage29 = nullptr;     // radix-2^29 passes: the stage-major table (2^max radix entries), tw_inter then in the 2^261 domain
+    fe_t* tw_inter[4] = {nullptr, nullptr, nullptr, nullptr};      // 256-bit words holding w 2^261 mod p: the product divides by 2^261
+    f29_t* stage29 = nullptr;     // the stage-major table w_(2^s)^o = omega^(o n / 2^s), 2^(largest radix) entries: its first R - 1 serve a pass of radix R
     fe_t n_inv;
 };
 
 // per-context state (Ctx::ntt_state): the twiddle tables are device memory of the context's device
 struct CosetTables {
-    fe_t* pre = nullptr;      // E x R1: the stage twiddles of the twisted DIT first pass
-    f29_t* pre29 = nullptr;   // the same as limbs in the 2^261 domain (radix-2^29 passes; inter is in that domain too then)
-    fe_t* inter = nullptr;    // E x n (nullptr for single-pass transforms)
+    f29_t* pre29 = nullptr;   // E x R1: the stage twiddles of the twisted first pass, as limbs in the 2^261 domain
+    fe_t* inter = nullptr;    // E x n, same domain (nullptr for single-pass transforms)
 };
 struct NttState {
     std::map<std::string, NttPlan*> plans;
@@ -592,28 +359,19 @@ static NttState& ntt_state() {
 #define g_plans (ntt_state().plans)
 #define g_coset_tables (ntt_state().coset_tables)
 
-// EZKL_NTT_29=0 selects the radix-2^32 decimation-in-frequency pass (the A/B baseline); the tables of a plan are built for one of the two
-static bool ntt_use29() {
-    static const bool v = [] {
-        const char* e = getenv("EZKL_NTT_29");
-        return !(e && e[0] == '0');
-    }();
-    return v;
-}
 // stages whose twiddles are staged in LDS (2^6 - 1 = 63 entries of 36 B: a 1024-element tile + table = 38.3 KiB, four workgroups per CU)
 static uint32_t ntt_lds_stages(uint32_t log_r) { return log_r < 6 ? log_r : 6; }
-static size_t ntt_lds_bytes(uint32_t log_tile, uint32_t log_r) {
-    if (ntt_use29()) return 36u * ((size_t)1 << log_tile) + 36u * ((size_t)1 << ntt_lds_stages(log_r));
-    return 32u * ((size_t)1 << log_tile) + 32u * (log_r ? ((size_t)1 << (log_r - 1)) : 1);
-}
-static fe_t ntt_domain_one() { return ntt_use29() ? Fr::from_u64(32) : Fr::one(); }          // 2^261 = 32 * 2^256
+static size_t ntt_lds_bytes(uint32_t log_tile, uint32_t log_r) { return 36u * ((size_t)1 << log_tile) + 36u * ((size_t)1 << ntt_lds_stages(log_r)); }
+// 1 in the domain of the twiddles: the data are x 2^256 (the files' Montgomery form), the radix-2^29 product divides by 2^261 = 32 * 2^256
+static fe_t ntt_domain_one() { return Fr::from_u64(32); }
 
 // Pass radices.  A pass of radix 2^r works on tiles of 2^r rows x 4 adjacent columns (128-byte row segments) held in LDS; r <= 8 is a
-// 32 KiB tile for a workgroup of 256 threads (4 workgroups per CU), r = 9 / 10 a 64 / 128 KiB tile for 512 / 1024 threads (16 waves per
+// 36 KiB tile for a workgroup of 256 threads (4 workgroups per CU), r = 9 / 10 a 72 / 144 KiB tile for 512 / 1024 threads (16 waves per
 // CU in every case).  Radix 2^10 would make 2^17 .. 2^20 two passes instead of three (one inter-pass twiddle product per element and a
-// third of the traffic less) and was MEASURED: it is slower -- 2^20 -> 2^22 cosets 0.519 vs 0.494 ms per column, the k = 20 MLP proof
-// 0.091 vs 0.087 s (profiles/r03j_ntt_ab.log): sixteen waves behind one barrier wait for each other where four independent 4-wave
-// workgroups fill each other's stalls, and the pass is issue-bound, not traffic-bound.  Default 8; EZKL_NTT_MAXR=9 / 10 select the larger tiles.
+// third of the traffic less) and was MEASURED twice: slower with the round-3 pass (2^20 -> 2^22 cosets 0.519 vs 0.494 ms per column,
+// profiles/r03j_ntt_ab.log), level with this one (0.475 vs 0.472; the k = 20 MLP proof 72.6 vs 71.6 ms, profiles/r04ak_ab_ntt29r.log):
+// sixteen waves behind one barrier wait for each other where four independent 4-wave workgroups fill each other's stalls, and the pass is
+// issue-bound, not traffic-bound.  Default 8; EZKL_NTT_MAXR=9 / 10 select the larger tiles.
 static uint32_t ntt_max_radix() {
     static const uint32_t v = [] {
         const char* e = getenv("EZKL_NTT_MAXR");
@@ -639,12 +397,6 @@ static void plan_radices(uint32_t log_n, NttPlan* p) {
 // tile of a multi-pass plan's pass of radix 2^r: at least 1024 elements, 4 columns
 static uint32_t pass_log_tile(uint32_t log_r) { return log_r + 2 > NTT_LOG_TILE ? log_r + 2 : NTT_LOG_TILE; }
 static void launch_pass(const PassArgs& a, uint32_t tiles, unsigned blocks_y, size_t lds, hipStream_t st) {
-    if (ntt_use29()) {
-        if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass29_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
-        else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass29_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
-        else hipLaunchKernelGGL(ntt_pass29_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
-        return;
-    }
     if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
     else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
@@ -655,9 +407,6 @@ static int ntt_kernel_attrs() {
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass29_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass29_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass29_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     return EZKL_OK;
@@ -681,7 +430,7 @@ static int plan_get(Ctx* c, hipStream_t st, uint32_t log_n, const fe_t& omega, N
     EZ_HIP(hipMemcpyAsync(d_pow2, pow2.data(), sizeof(fe_t) * pow2.size(), hipMemcpyHostToDevice, st));
     uint32_t log_m = log_n;
     const fe_t one = ntt_domain_one();
-    if (ntt_use29()) {
+    {
         uint32_t maxlr = 0;
         for (int i = 0; i < p->npass; i++) maxlr = p->log_radix[i] > maxlr ? p->log_radix[i] : maxlr;
         const uint32_t cnt = 1u << maxlr;                       // w_(2^s)^o = omega^(o n / 2^s) whatever the pass: its first R - 1 entries serve a pass of radix R
@@ -690,12 +439,6 @@ static int plan_get(Ctx* c, hipStream_t st, uint32_t log_n, const fe_t& omega, N
     }
     for (int i = 0; i < p->npass; i++) {
         uint32_t lr = p->log_radix[i];
-        uint32_t half = lr ? (1u << (lr - 1)) : 1u;
-        if (!ntt_use29()) {
-            EZ_HIP(hipMalloc(&p->tw_local[i], sizeof(fe_t) * half));
-            hipLaunchKernelGGL(ntt_twiddle_kernel, dim3(cdiv(half, 256)), dim3(256), 0, st, p->tw_local[i], half,
-                               (uint64_t)1 << (log_n - lr), log_n, 0u, 0, d_pow2, one);
-        }
         if (i + 1 < p->npass) {
             uint32_t cnt = 1u << log_m;
             EZ_HIP(hipMalloc(&p->tw_inter[i], sizeof(fe_t) * (size_t)cnt));
@@ -760,7 +503,6 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
         a.in_stride = first ? in_stride : n;
         a.out = last ? out : work;
         a.out_stride = last ? out_stride : n;
-        a.tw_local = p->tw_local[i];
         a.tw_inter = p->tw_inter[i];
         a.tw_stage29 = p->stage29;
         a.log_n = log_n;
@@ -820,9 +562,8 @@ static int coset_tables_get(Ctx* c, hipStream_t st, NttPlan* p, uint32_t log_n, 
     CosetTables t;
     const fe_t one = ntt_domain_one(), zeta = Fr::mul(fr_const(FrConst::ZETA), one), zeta2 = Fr::mul(fr_const(FrConst::ZETA2), one);
     const size_t n_pre = (size_t)1 << (lr + log_e);
-    if (ntt_use29()) EZ_HIP(hipMalloc(&t.pre29, sizeof(f29_t) * n_pre));
-    else EZ_HIP(hipMalloc(&t.pre, sizeof(fe_t) * n_pre));
-    hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_pre, 256)), dim3(256), 0, st, t.pre, t.pre29, 1u << lr, log_e, log_ext, log_s, 0, d_pow2, one, zeta, zeta2);
+    EZ_HIP(hipMalloc(&t.pre29, sizeof(f29_t) * n_pre));
+    hipLaunchKernelGGL(ntt_coset_table_kernel, dim3(cdiv(n_pre, 256)), dim3(256), 0, st, (fe_t*)nullptr, t.pre29, 1u << lr, log_e, log_ext, log_s, 0, d_pow2, one, zeta, zeta2);
     if (p->npass > 1) {
         const size_t n_int = (size_t)1 << log_ext;
         EZ_HIP(hipMalloc(&t.inter, sizeof(fe_t) * n_int));
@@ -863,7 +604,6 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         a.in_stride = first ? in_stride : n;
         a.out = last ? out : work;
         a.out_stride = last ? out_stride : n;
-        a.tw_local = p->tw_local[i];
         a.tw_inter = first ? ct.inter : p->tw_inter[i];
         a.tw_stage29 = p->stage29;
         a.tw_pre29 = ct.pre29;
@@ -882,8 +622,6 @@ static int coset_cm_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uin
         a.cm_log_e = log_e;
         a.cm_first = first_coset;
         a.cm_log_cnt = log_count;
-        a.dit = first ? 1u : 0u;
-        a.tw_pre = ct.pre;
         if (last) {
             const uint32_t logC = a.log_tile - a.log_r;
             a.k1_major = (p->npass >= 2 && p->log_radix[0] >= logC) ? 1u : 0u;

@@ -6,7 +6,7 @@
 #   | prio (stream priorities) | evalh (sweep code generation) | merged (z committed under the lookup sums) | early (random polynomial
 #   committed under the witness upload x priorities) | matrix (early x groups, k = 20 / 22) | slots (batch slots x groups) | taper (upload
 #   phases in tapered groups) | benchvar (bench.py twice with 4 and 6 slots: box-to-box and run-to-run variation) | msmdebug (the batches
-#   of one proof as the library sees them) | ntt29 (radix-2^29 DIT pass against the radix-2^32 DIF pass)
+#   of one proof as the library sees them) | ntt29r (pass radices under the radix-2^29 NTT pass; the A/B against the radix-2^32 pass it replaced is profiles/r04ai_ab_ntt29.log, run at commit 'NTT: radix-2^29 decimation-in-time pass' where both existed)
 R=$(cd "$(dirname "$0")/.." && pwd)
 run() {   # label, then VAR=value ... (CIRCUIT / K / REPS included)
   L=$1; shift
@@ -56,12 +56,6 @@ case "$1" in
   slots)
     for S in 2 3 4 6; do for BIG in 1 2 4; do run "SLOTS=$S BIG=$BIG" $M EZKL_MSM_SLOTS=$S EZKL_MSM_GROUP_BIG=$BIG; done; done
     run "mlp17 SLOTS=2" EZKL_MSM_SLOTS=2 CIRCUIT=mlp K=17 REPS=8; run "mlp17 SLOTS=4" EZKL_MSM_SLOTS=4 CIRCUIT=mlp K=17 REPS=8 ;;
-  ntt29)
-    # the radix-2^29 DIT pass against the radix-2^32 DIF pass: the NTT parity tests on the new pass, kernel times per column, then proofs
-    (cd "$R" && timeout 900 python -m pytest tests/test_gpu_ntt.py -m gpu -x -q 2>&1 | tail -4)
-    for V in 1 0; do echo "== EZKL_NTT_29=$V"; (cd "$R" && EZKL_NTT_29=$V timeout 300 python tools/ntt_ab.py 2>&1 | tail -5); done
-    for V in 1 0; do run "mlp20 NTT_29=$V" $M EZKL_NTT_29=$V; done
-    for V in 1 0; do run "mlp17 NTT_29=$V" CIRCUIT=mlp K=17 REPS=8 EZKL_NTT_29=$V; done ;;
   ntt29r)
     # pass radices under the radix-2^29 pass: two passes of 2^10 (4096-element tiles, one workgroup of 1024 threads per CU) against three of 2^7
     for X in 8 9 10; do echo "== EZKL_NTT_MAXR=$X"; (cd "$R" && EZKL_NTT_MAXR=$X timeout 300 python tools/ntt_ab.py 2>&1 | tail -4); done
