@@ -102,7 +102,7 @@ EZ_D f29_t fr29_canonical(const f29_t& x) {
 // costs no product beyond the plain transform's.  Input rows are in bit-reversed order (the loader permutes), output rows in natural order.
 // tw: the stage-major table -- its copy in LDS for the groups up to stage lds_stages, the table itself (FROM_TABLE)
 // for the later ones (lds_stages is even or the last stage, groups start at odd stages: a group never straddles).
-template <int G, int NTT_THREADS, bool FROM_TABLE, bool DUAL>
+template <int G, int NTT_THREADS, bool FROM_TABLE>
 __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, const f29_t* tw, uint32_t TILE, uint32_t logC, bool unit1, uint32_t s, uint32_t tid) {
     constexpr uint32_t M = 1u << G;
     const uint32_t C = 1u << logC;
@@ -119,32 +119,17 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
         for (int t = 0; t < G; t++) {
             const uint32_t half = 1u << t, st = s + t;
             const uint32_t base = (1u << (st - 1)) - 1u;
-            if (unit1 && st == 1) {                                  // w = 1; the partners are loaded values, anything below 2^256 < 7p
 #pragma unroll
-                for (uint32_t i = 0; i < M; i++) {
-                    if (i & half) continue;
+            for (uint32_t i = 0; i < M; i++) {
+                if (i & half) continue;
+                if (unit1 && st == 1) {                              // w = 1; the partner is a loaded value, anything below 2^256 < 7p
                     const f29_t v = x[i + half];
                     x[i + half] = Fr29::sub<2>(x[i], v);
                     x[i] = Fr29::add(x[i], v);
-                }
-            } else if (G == 2 && DUAL) {
-                // the stage's two butterflies at once: their products are independent, mul2 interleaves the two dependent chains.
-                // Limbs of the inputs are below 6 units of 2^29 (at most two stages since the last carry pass); v < 2p
-                const uint32_t ia = 0, ib = t == 0 ? 2u : 1u;
-                const f29_t wa = ld_f29(tw + base + o + (ia & (half - 1)) * h), wb = ld_f29(tw + base + o + (ib & (half - 1)) * h);
-                f29_t va, vb;
-                Fr29::mul2(x[ia + half], wa, va, x[ib + half], wb, vb);
-                x[ia + half] = Fr29::sub<1>(x[ia], va);
-                x[ia] = Fr29::add(x[ia], va);
-                x[ib + half] = Fr29::sub<1>(x[ib], vb);
-                x[ib] = Fr29::add(x[ib], vb);
-            } else {
-#pragma unroll
-                for (uint32_t i = 0; i < M; i++) {
-                    if (i & half) continue;
+                } else {
                     const uint32_t off = o + (i & (half - 1)) * h;
                     const f29_t w = ld_f29(tw + base + off);
-                    const f29_t v = Fr29::mul(x[i + half], w);
+                    const f29_t v = Fr29::mul(x[i + half], w);       // limbs of x below 6 units of 2^29 (at most two stages since the last carry pass); v < 2p
                     x[i + half] = Fr29::sub<1>(x[i], v);
                     x[i] = Fr29::add(x[i], v);
                 }
@@ -155,7 +140,7 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
     }
 }
 
-template <int NTT_THREADS, bool DUAL>
+template <int NTT_THREADS>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t TILE = 1u << a.log_tile;
@@ -231,11 +216,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
     for (uint32_t s = 1; s <= a.log_r;) {
         const uint32_t g = a.log_r - s >= 1 ? 2u : 1u;
         if (s > a.lds_stages) {
-            if (g == 2) ntt_superstage29<2, NTT_THREADS, true, DUAL>(data, d8, tws, TILE, logC, !twisted, s, tid);
-            else ntt_superstage29<1, NTT_THREADS, true, DUAL>(data, d8, tws, TILE, logC, !twisted, s, tid);
+            if (g == 2) ntt_superstage29<2, NTT_THREADS, true>(data, d8, tws, TILE, logC, !twisted, s, tid);
+            else ntt_superstage29<1, NTT_THREADS, true>(data, d8, tws, TILE, logC, !twisted, s, tid);
         } else {
-            if (g == 2) ntt_superstage29<2, NTT_THREADS, false, DUAL>(data, d8, tloc, TILE, logC, !twisted, s, tid);
-            else ntt_superstage29<1, NTT_THREADS, false, DUAL>(data, d8, tloc, TILE, logC, !twisted, s, tid);
+            if (g == 2) ntt_superstage29<2, NTT_THREADS, false>(data, d8, tloc, TILE, logC, !twisted, s, tid);
+            else ntt_superstage29<1, NTT_THREADS, false>(data, d8, tloc, TILE, logC, !twisted, s, tid);
         }
         __syncthreads();
         s += g;
@@ -411,30 +396,17 @@ static void plan_radices(uint32_t log_n, NttPlan* p) {
 }
 // tile of a multi-pass plan's pass of radix 2^r: at least 1024 elements, 4 columns
 static uint32_t pass_log_tile(uint32_t log_r) { return log_r + 2 > NTT_LOG_TILE ? log_r + 2 : NTT_LOG_TILE; }
-static bool ntt_dual() {
-    static const bool v = [] { const char* e = getenv("EZKL_NTT_DUAL"); return !(e && e[0] == '0'); }();
-    return v;
-}
 static void launch_pass(const PassArgs& a, uint32_t tiles, unsigned blocks_y, size_t lds, hipStream_t st) {
-    if (!ntt_dual()) {
-        if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL((ntt_pass_kernel<1024, false>), dim3(tiles, blocks_y), dim3(1024), lds, st, a);
-        else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL((ntt_pass_kernel<512, false>), dim3(tiles, blocks_y), dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((ntt_pass_kernel<256, false>), dim3(tiles, blocks_y), dim3(256), lds, st, a);
-        return;
-    }
-    if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL((ntt_pass_kernel<1024, true>), dim3(tiles, blocks_y), dim3(1024), lds, st, a);
-    else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL((ntt_pass_kernel<512, true>), dim3(tiles, blocks_y), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((ntt_pass_kernel<256, true>), dim3(tiles, blocks_y), dim3(256), lds, st, a);
+    if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
+    else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(ntt_pass_kernel<256>, dim3(tiles, blocks_y), dim3(256), lds, st, a);
 }
 static int ntt_kernel_attrs() {
     bool& attr_set = ntt_state().attrs_set;               // function attributes are per device
     if (!attr_set) {
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EZ_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     return EZKL_OK;

@@ -60,10 +60,6 @@ case "$1" in
     # pass radices under the radix-2^29 pass: two passes of 2^10 (4096-element tiles, one workgroup of 1024 threads per CU) against three of 2^7
     for X in 8 9 10; do echo "== EZKL_NTT_MAXR=$X"; (cd "$R" && EZKL_NTT_MAXR=$X timeout 300 python tools/ntt_ab.py 2>&1 | tail -4); done
     for X in 8 10; do run "mlp20 MAXR=$X" $M EZKL_NTT_MAXR=$X; done ;;
-  nttdual)
-    # the two products of a radix-4 group's stage interleaved in one asm block (mont_mul29x2_fr) against two single products, same box
-    for rep in 1 2; do for V in 1 0; do echo "== EZKL_NTT_DUAL=$V"; (cd "$R" && EZKL_NTT_DUAL=$V timeout 300 python tools/ntt_ab.py 2>&1 | tail -3); done; done
-    for V in 1 0 1 0; do run "mlp20 NTT_DUAL=$V" $M EZKL_NTT_DUAL=$V; done ;;
   taper)
     for T in taper equal; do
       if [ $T = equal ]; then X="EZKL_MSM_NO_TAPER=1"; else X="A=1"; fi

@@ -113,52 +113,6 @@ def gen(name, mod, square=False, ilp2=False):
     return "\n".join(o) + "\n"
 
 
-def gen_dual(name, mod):
-    """TWO independent products r = a b / 2^261, q = c d / 2^261 in one block, their instruction streams interleaved one for one: the single
-    product is one dependent chain through its accumulator pair, and a wave that holds two of them (the two butterflies of a radix-4 NTT
-    group's stage) can issue the second chain's instruction while the first one's result is still in the pipeline -- no instruction more
-    than two single products.  Accumulators v[16:17] and v[18:19]."""
-    p = [(mod >> (29 * i)) & MASK for i in range(9)]
-    pinv = (-pow(mod, -1, 1 << 29)) % (1 << 29)
-    SP = [16 + i for i in range(9)]
-    SINV, SMASK = 25, 26
-    head = ["s_mov_b32 s%d, 0x%08x" % (SP[i], p[i]) for i in range(9)] + ["s_mov_b32 s%d, 0x%08x" % (SINV, pinv), "s_mov_b32 s%d, 0x%08x" % (SMASK, MASK)]
-
-    def chain(A0, a, b, r):
-        A1, L, first = A0 + 1, [], [True]
-        M = ["%%[%s%d]" % (r, i) for i in range(9)]
-        def mac(s0, s1):
-            L.append("v_mad_u64_u32 v[%d:%d], vcc, %s, %s, %s" % (A0, A1, s0, s1, "0" if first[0] else "v[%d:%d]" % (A0, A1)))
-            first[0] = False
-        for k in range(17):
-            for i in range(max(0, k - 8), min(k, 8) + 1):
-                mac("%%[%s%d]" % (a, i), "%%[%s%d]" % (b, k - i))
-            for i in (range(0, k) if k < 9 else range(k - 8, 9)):
-                mac(M[i], "s%d" % SP[k - i])
-            if k < 9:
-                L.append("v_mul_lo_u32 %s, v%d, s%d" % (M[k], A0, SINV))
-                L.append("v_and_b32 %s, s%d, %s" % (M[k], SMASK, M[k]))
-                mac(M[k], "s%d" % SP[0])
-            else:
-                L.append("v_and_b32 %%[%s%d], s%d, v%d" % (r, k - 9, SMASK, A0))
-            L.append("v_lshrrev_b64 v[%d:%d], 29, v[%d:%d]" % (A0, A1, A0, A1))
-        L.append("v_mov_b32 %%[%s8], v%d" % (r, A0))
-        return L
-    X, Y = chain(16, "a", "b", "r"), chain(18, "c", "d", "q")
-    L = list(head)
-    for x, y in zip(X, Y):
-        L += [x, y]
-    o = ["// %s: r = a * b / 2^261, q = c * d / 2^261 mod p, two interleaved chains; v16..v19 and s16..s26 clobbered" % name,
-         "__device__ __forceinline__ void %s(const uint32_t (&a)[9], const uint32_t (&b)[9], uint32_t (&r)[9], const uint32_t (&c)[9], const uint32_t (&d)[9], uint32_t (&q)[9]) {" % name]
-    body = "\n        ".join('"%s\\n\\t"' % l for l in L)
-    o.append("    asm(" + body)
-    o.append("        : " + ", ".join('[r%d] "=&v"(r[%d])' % (i, i) for i in range(9)) + ", " + ", ".join('[q%d] "=&v"(q[%d])' % (i, i) for i in range(9)))
-    o.append("        : " + ", ".join('[%s%d] "v"(%s[%d])' % (n, i, n, i) for n in "abcd" for i in range(9)))
-    o.append('        : "v16", "v17", "v18", "v19", ' + ", ".join('"s%d"' % s for s in range(16, 27)) + ', "vcc");')
-    o.append("}")
-    return "\n".join(o) + "\n"
-
-
 def consts(tag, mod):
     """limb tables for the lazy radix-2^29 arithmetic of field29.hpp"""
     def limbs29(x, n=9):
@@ -195,7 +149,7 @@ def consts(tag, mod):
 
 hdr = "// GENERATED by tools/gen_montmul29.py -- do not edit\n#pragma once\n#ifndef __HIPCC_RTC__            // hiprtc (the eval_h JIT) supplies the fixed-width types itself\n#include <stdint.h>\n#endif\nnamespace ezkl {\n"
 text = (hdr + consts("Fq", FQ) + consts("Fr", FR) + gen("mont_mul29_fq", FQ) + gen("mont_mul29_fr", FR) + gen("mont_sqr29_fq", FQ, True) + gen("mont_sqr29_fr", FR, True) +
-        gen("mont_mul29i_fq", FQ, ilp2=True) + gen("mont_sqr29i_fq", FQ, True, ilp2=True) + gen("mont_mul29i_fr", FR, ilp2=True) + gen_dual("mont_mul29x2_fr", FR) + "}  // namespace ezkl\n")
+        gen("mont_mul29i_fq", FQ, ilp2=True) + gen("mont_sqr29i_fq", FQ, True, ilp2=True) + gen("mont_mul29i_fr", FR, ilp2=True) + "}  // namespace ezkl\n")
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ezkl_amd", "csrc", "montmul29_gen.hpp")
 open(path, "w").write(text)
 print("wrote", path, len(text.splitlines()), "lines")
