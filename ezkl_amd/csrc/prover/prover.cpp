@@ -643,10 +643,38 @@ struct Backend {
         return out;
     }
     // owner mode: the commitment of the SUM over ranks of a per-rank partial polynomial (SHPLONK's h and L: linear in the polynomials
-    // each rank owns): every rank commits its own partial with the whole base set, the fold adds the points
+    // each rank owns).  A reduce-scatter by point ranges: rank r receives rows [r n / world, (r + 1) n / world) of every other rank's
+    // partial through the exchange (one segment per peer and direction: 32 n / world bytes), adds them to its own, commits that slice
+    // against the same slice of the base set, and the fold adds the world points -- an n / world-point MSM per rank instead of a whole one
+    // on every rank.  EZKL_PROVER_NO_SUM_SCATTER=1: every rank commits its whole partial (the round-3 form), same point.
     G1 commit_sum(ezkl_bases_t b, const Col& h) const {
         if (!topo.owners) return commit_with(b, {h})[0];
+        static const bool scatter = getenv("EZKL_PROVER_NO_SUM_SCATTER") == nullptr;
         std::vector<G1> out(1);
+        const uint32_t W = topo.world;
+        if (scatter && W > 1 && n % W == 0) {
+            const size_t len = n / W;
+            Col pieces = alloc(len * (W - 1));                  // the peers' rows of my range, in rank order
+            std::vector<ezkl_comm_seg_t> sends, recvs;
+            std::vector<const void*> ptrs = {at(h, (size_t)topo.rank * len)};
+            for (uint32_t p_ = 0; p_ < W; p_++) {
+                if (p_ == topo.rank) continue;
+                void* dst = at(pieces, (size_t)(p_ < topo.rank ? p_ : p_ - 1) * len);
+                sends.push_back({(int)p_, at(h, (size_t)p_ * len), len * 32});
+                recvs.push_back({(int)p_, dst, len * 32});
+                ptrs.push_back(dst);
+            }
+            check(ezkl_hip_synchronize(), "ezkl_hip_synchronize");                 // the partial is complete on every stream
+            if (shard.exchange(shard.xuser, sends.data(), sends.size(), recvs.data(), recvs.size()) != 0) throw Error(EZKL_ERR_INVALID, "exchange callback failed");
+            shard.stats[2] += (uint64_t)(W - 1) * len * 32;
+            const std::vector<U256> ones(W, Fe::one().v);
+            Col sum = alloc(len);
+            check(ezkl_hip_lincomb_dev(ptrs.data(), ones.data(), W, sum->ptr(), len, 0, nullptr), "ezkl_hip_lincomb_dev");
+            const void* ptr = sum->ptr();
+            check(ezkl_hip_msm_g1_batch_dev(b, (size_t)topo.rank * len, &ptr, 1, len, out.data(), nullptr), "ezkl_hip_msm_g1_batch_dev");
+            fold(out);
+            return out[0];
+        }
         const void* ptr = h->ptr();
         check(msm_batch(b, 0, &ptr, 1, n, out.data(), false), "ezkl_hip_msm_g1_batch_dev");
         fold(out);

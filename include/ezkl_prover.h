@@ -102,7 +102,8 @@ typedef int (*ezkl_allgather_host_fn)(void* user, void* buf_host, size_t bytes_p
 typedef int (*ezkl_exchange_fn)(void* user, const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs);
 int ezkl_prover_cs_set_shard_exchange(ezkl_cs_t cs, ezkl_allgather_host_fn allgather_host, ezkl_exchange_fn exchange, void* user);
 /* counters of the last create_proof on this rank: out[0] = witness columns this rank transformed (iNTT + cosets), out[1] = witness
- * columns in the proof, out[2] = bytes this rank received in the sweep exchange, out[3] = lookup / permutation arguments it computed */
+ * columns in the proof, out[2] = bytes this rank received in the sweep exchange and in the two reduce-scatters of SHPLONK's partial
+ * polynomials, out[3] = lookup / permutation arguments it computed */
 int ezkl_prover_cs_shard_stats(ezkl_cs_t cs, uint64_t out[4]);
 
 /* ---- one process, several GPUs: the prover group ----

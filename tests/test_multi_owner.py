@@ -44,6 +44,19 @@ def test_owner_sharded_native_prover_same_bytes(hip, circuit, k):
         assert all(r["sharded_sweeps"] >= 2 for r in j["per_rank"])
 
 
+def test_shplonk_commitments_are_reduce_scattered(hip):
+    """SHPLONK's two commitments of per-rank partial polynomials: every rank receives the other ranks' rows of ITS point range (one segment
+    per peer), commits the summed slice and the fold adds the points -- same bytes as whole MSMs of the partials on every rank, and
+    exactly 2 x (world - 1) x n / world x 32 more bytes through the exchange"""
+    env = {"CIRCUIT": "fixture", "K": "6"}
+    n, world = 64, 4
+    on = _run(env, world, 29579)
+    off = _run(dict(env, EZKL_PROVER_NO_SUM_SCATTER="1"), world, 29581)
+    assert on["proof_sha256"] == off["proof_sha256"] and on["all_ranks_same_proof"] and on["verifier_accepts"]
+    for a, b in zip(on["per_rank"], off["per_rank"]):
+        assert a["stats"]["exchange_bytes_received"] - b["stats"]["exchange_bytes_received"] == 2 * (world - 1) * (n // world) * 32
+
+
 def test_replicated_mode_still_same_bytes(hip):
     """the round-2 sharding (commit batches by columns, everything else replicated) on the coset-major prover"""
     env = {"CIRCUIT": "mlp", "K": "9", "MLP_BASE": "128"}

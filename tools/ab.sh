@@ -6,7 +6,7 @@
 #   | prio (stream priorities) | evalh (sweep code generation) | merged (z committed under the lookup sums) | early (random polynomial
 #   committed under the witness upload x priorities) | matrix (early x groups, k = 20 / 22) | slots (batch slots x groups) | taper (upload
 #   phases in tapered groups) | benchvar (bench.py twice with 4 and 6 slots: box-to-box and run-to-run variation) | msmdebug (the batches
-#   of one proof as the library sees them) | ntt29r (pass radices under the radix-2^29 NTT pass; the A/B against the radix-2^32 pass it replaced is profiles/r04ai_ab_ntt29.log, run at commit 'NTT: radix-2^29 decimation-in-time pass' where both existed)
+#   of one proof as the library sees them) | sumscatter (SHPLONK commitments reduce-scattered across contexts) | ntt29r (pass radices under the radix-2^29 NTT pass; the A/B against the radix-2^32 pass it replaced is profiles/r04ai_ab_ntt29.log, run at commit 'NTT: radix-2^29 decimation-in-time pass' where both existed)
 R=$(cd "$(dirname "$0")/.." && pwd)
 run() {   # label, then VAR=value ... (CIRCUIT / K / REPS included)
   L=$1; shift
@@ -60,6 +60,17 @@ case "$1" in
     # pass radices under the radix-2^29 pass: two passes of 2^10 (4096-element tiles, one workgroup of 1024 threads per CU) against three of 2^7
     for X in 8 9 10; do echo "== EZKL_NTT_MAXR=$X"; (cd "$R" && EZKL_NTT_MAXR=$X timeout 300 python tools/ntt_ab.py 2>&1 | tail -4); done
     for X in 8 10; do run "mlp20 MAXR=$X" $M EZKL_NTT_MAXR=$X; done ;;
+  sumscatter)
+    # SHPLONK's two commitments reduce-scattered by point ranges against whole MSMs of the partials on every rank: 2 and 4 contexts on ONE
+    # device (the contexts share its CUs: what shows here is the MSM work saved, not the exchange over xGMI)
+    for W in 2 4; do for V in 0 1 0 1; do
+      X="A=1"; [ $V = 1 ] && X="EZKL_PROVER_NO_SUM_SCATTER=1"
+      (cd "$R" && env $X CONTEXTS=$(python -c "print(','.join(['0'] * $W))") CIRCUIT=mlp K=20 timeout 600 python tools/prove_group.py --pinned) 2>/dev/null | tail -1 | python -c "
+import sys, json
+j = json.loads(sys.stdin.read()); t = j['group_breakdown_seconds_max_over_contexts']
+print('contexts $W NO_SUM_SCATTER=$V', 'one context', j['prove_seconds_one_context'], 'group', j['prove_seconds_group'], 'shplonk', t.get('shplonk'), 'evaluations', t.get('evaluations'),
+      'same_as_one', j['same_bytes_as_one_context'], j['proof_sha256'], 'bytes received', [c.get('exchange_bytes_received') for c in j['per_context']])"
+    done; done ;;
   taper)
     for T in taper equal; do
       if [ $T = equal ]; then X="EZKL_MSM_NO_TAPER=1"; else X="A=1"; fi
