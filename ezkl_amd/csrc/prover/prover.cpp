@@ -461,6 +461,7 @@ struct Backend {
     Shard shard;
     Topo topo;
     Fe one = Fe::one();
+    uint64_t* recv_bytes = nullptr;       // the constraint system's counter of bytes received through the exchange (create_proof sets it)
     Backend(uint32_t k_, uint32_t n_, ezkl_bases_t g_, ezkl_bases_t gl_, const Shard& sh = Shard()) : k(k_), n(n_), g(g_), gl(gl_), shard(sh) {
         uint32_t r = 0, lw = 0;
         if (shard.on() && shard.geometry(n, r, lw)) {
@@ -666,7 +667,7 @@ struct Backend {
             }
             check(ezkl_hip_synchronize(), "ezkl_hip_synchronize");                 // the partial is complete on every stream
             if (shard.exchange(shard.xuser, sends.data(), sends.size(), recvs.data(), recvs.size()) != 0) throw Error(EZKL_ERR_INVALID, "exchange callback failed");
-            shard.stats[2] += (uint64_t)(W - 1) * len * 32;
+            if (recv_bytes) *recv_bytes += (uint64_t)(W - 1) * len * 32;
             const std::vector<U256> ones(W, Fe::one().v);
             Col sum = alloc(len);
             check(ezkl_hip_lincomb_dev(ptrs.data(), ones.data(), W, sum->ptr(), len, 0, nullptr), "ezkl_hip_lincomb_dev");
@@ -1882,6 +1883,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
     } async_calls;
     Backend be(k, n, g, gl, cs.shard);
+    be.recv_bytes = &cs.shard.stats[2];
     const Topo& topo = be.topo;
     const bool owners = topo.owners;
     for (auto& x : cs.shard.stats) x = 0;
