@@ -87,10 +87,12 @@ struct Fe {
     }
     Fe operator-() const { return zero() - *this; }
     Fe pow(const U256& e) const {
+        int top = 255;                                   // squarings stop at the exponent's highest set bit
+        while (top >= 0 && !((e[top >> 6] >> (top & 63)) & 1)) top--;
         Fe acc = one(), b = *this;
-        for (int i = 0; i < 256; i++) {
+        for (int i = 0; i <= top; i++) {
             if ((e[i >> 6] >> (i & 63)) & 1) acc = acc * b;
-            b = b * b;
+            if (i < top) b = b * b;
         }
         return acc;
     }

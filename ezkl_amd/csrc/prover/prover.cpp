@@ -1477,10 +1477,10 @@ static bool u256_less(const U256& a, const U256& b) { return cmp(a, b) < 0; }
 // coefficients (low first) of the polynomial of degree < len(points) through (points, values)
 static std::vector<Fe> interpolate(const std::vector<Fe>& pts, const std::vector<Fe>& vals) {
     const size_t m = pts.size();
-    std::vector<Fe> coeffs(m, Fe::zero());
+    std::vector<Fe> coeffs(m, Fe::zero()), den(m, Fe::one()), pre(m + 1, Fe::one());
+    std::vector<std::vector<Fe>> nums(m);
     for (size_t i = 0; i < m; i++) {
         std::vector<Fe> num = {Fe::one()};
-        Fe den = Fe::one();
         for (size_t j = 0; j < m; j++) {
             if (j == i) continue;
             std::vector<Fe> nn(num.size() + 1, Fe::zero());
@@ -1489,10 +1489,16 @@ static std::vector<Fe> interpolate(const std::vector<Fe>& pts, const std::vector
                 nn[t] = nn[t] - pts[j] * num[t];
             }
             num = nn;
-            den = den * (pts[i] - pts[j]);
+            den[i] = den[i] * (pts[i] - pts[j]);
         }
-        const Fe s = vals[i] * den.inv();
-        for (size_t t = 0; t < num.size(); t++) coeffs[t] = coeffs[t] + s * num[t];
+        nums[i] = num;
+        pre[i + 1] = pre[i] * den[i];
+    }
+    Fe inv_all = pre[m].inv();                                   // one field inversion (254 squarings on the host) for the m denominators
+    for (size_t i = m; i-- > 0;) {
+        const Fe s = vals[i] * (inv_all * pre[i]);
+        inv_all = inv_all * den[i];
+        for (size_t t = 0; t < nums[i].size(); t++) coeffs[t] = coeffs[t] + s * nums[i][t];
     }
     return coeffs;
 }
@@ -2309,7 +2315,12 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     // 8. x
     const Fe x = T.squeeze_challenge();
     const Fe w = omega(k);
-    auto rot_point = [&](int32_t r) { return x * w.pow((uint64_t)(r >= 0 ? (uint32_t)r % n : n - ((uint32_t)(-r) % n))); };
+    std::map<int32_t, Fe> rot_memo;                 // a handful of distinct rotations, hundreds of queries
+    auto rot_point = [&](int32_t r) {
+        auto it = rot_memo.find(r);
+        if (it == rot_memo.end()) it = rot_memo.emplace(r, x * w.pow((uint64_t)(r >= 0 ? (uint32_t)r % n : n - ((uint32_t)(-r) % n)))).first;
+        return it->second;
+    };
     // 9. evaluations: every (polynomial, point) of this round in ONE batched call per rank, then written in transcript order.  Owner
     //    mode: a polynomial is evaluated by the rank that holds it (replicated ones -- key columns, the random polynomial, h -- are
     //    dealt round-robin) and the scalars are all_gathered.
