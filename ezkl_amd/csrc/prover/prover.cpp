@@ -2096,8 +2096,6 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     // the default stays one phase after the other
     const char* merged_env = getenv("EZKL_PROVER_MERGED_COMMITS");
     const bool merged_commit = merged_env && *merged_env == '1' && !cs.shard.on() && nl > 0 && !cs.perm.empty();
-    const char* ahead_env = getenv("EZKL_PROVER_COMMIT_AHEAD");
-    const bool commit_ahead = ahead_env && *ahead_env == '1' && !cs.shard.on() && !merged_commit;
     Backend::OpenCommit zphi;
     std::vector<Col> zs;
     std::vector<Backend::Forms> z_forms;
@@ -2120,15 +2118,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             const std::vector<U256> blind = rng.vec(n - u - 1);
             if (zs[j]) be.set_rows(zs[j], u + 1, blind);
         }
-        // EZKL_PROVER_COMMIT_AHEAD=1 (one prover on one GPU): the phase's MSMs are QUEUED before the forms of the same columns are, and
-        // collected after -- their sort passes start at once instead of after the host has issued two calls per column
-        Backend::OpenCommit ahead;
-        if (commit_ahead) { be.commit_begin(ahead, gl); be.commit_push(ahead, zs); }
         for (size_t j = 0; j < zs.size(); j++)
             if (zs[j]) { z_forms[j] = be.forms_async(zs[j], cs.ext_k); cs.shard.stats[0]++; cs.shard.stats[3]++; }
-        if (commit_ahead) {
-            for (auto& p : be.commit_finish(ahead)) T.write_point(p);
-        } else if (merged_commit) {                // queued now, collected after the lookup sums below have been computed next to them
+        if (merged_commit) {                       // queued now, collected after the lookup sums below have been computed next to them
             be.commit_begin(zphi, gl);
             be.commit_push(zphi, zs);
         } else {
@@ -2154,13 +2146,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
                 phis[i] = lk[i].phi;
             }
         }
-        Backend::OpenCommit ahead;
-        if (commit_ahead) { be.commit_begin(ahead, gl); be.commit_push(ahead, phis); }
         for (auto& st : lk)
             if (st.mine) { st.phi_forms = be.forms_async(st.phi, cs.ext_k); cs.shard.stats[0]++; }
-        if (commit_ahead) {
-            for (auto& p : be.commit_finish(ahead)) T.write_point(p);
-        } else if (merged_commit) {
+        if (merged_commit) {
             be.commit_push(zphi, phis);
             for (auto& p : be.commit_finish(zphi)) T.write_point(p);      // push order = transcript order: the z, then the phi
         } else {

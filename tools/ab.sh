@@ -6,7 +6,7 @@
 #   | prio (stream priorities) | evalh (sweep code generation) | merged (z committed under the lookup sums) | early (random polynomial
 #   committed under the witness upload x priorities) | matrix (early x groups, k = 20 / 22) | slots (batch slots x groups) | taper (upload
 #   phases in tapered groups) | benchvar (bench.py twice with 4 and 6 slots: box-to-box and run-to-run variation) | msmdebug (the batches
-#   of one proof as the library sees them) | ahead (z / phi MSMs queued before the forms of the same columns) | sumscatter (SHPLONK commitments reduce-scattered across contexts) | ntt29r (pass radices under the radix-2^29 NTT pass; the A/B against the radix-2^32 pass it replaced is profiles/r04ai_ab_ntt29.log, run at commit 'NTT: radix-2^29 decimation-in-time pass' where both existed)
+#   of one proof as the library sees them) | sumscatter (SHPLONK commitments reduce-scattered across contexts) | ntt29r (pass radices under the radix-2^29 NTT pass; the A/B against the radix-2^32 pass it replaced is profiles/r04ai_ab_ntt29.log, run at commit 'NTT: radix-2^29 decimation-in-time pass' where both existed)
 R=$(cd "$(dirname "$0")/.." && pwd)
 run() {   # label, then VAR=value ... (CIRCUIT / K / REPS included)
   L=$1; shift
@@ -71,11 +71,6 @@ j = json.loads(sys.stdin.read()); t = j['group_breakdown_seconds_max_over_contex
 print('contexts $W NO_SUM_SCATTER=$V', 'one context', j['prove_seconds_one_context'], 'group', j['prove_seconds_group'], 'shplonk', t.get('shplonk'), 'evaluations', t.get('evaluations'),
       'same_as_one', j['same_bytes_as_one_context'], j['proof_sha256'], 'bytes received', [c.get('exchange_bytes_received') for c in j['per_context']])"
     done; done ;;
-  ahead)
-    # the z / phi phases: MSMs queued before the forms of the same columns (EZKL_PROVER_COMMIT_AHEAD=1) against after them (default)
-    for V in 0 1 0 1; do run "mlp20 COMMIT_AHEAD=$V" $M EZKL_PROVER_COMMIT_AHEAD=$V; done
-    for V in 0 1; do run "mlp20 COMMIT_AHEAD=$V AUX low" $M EZKL_PROVER_COMMIT_AHEAD=$V EZKL_HIP_PRIO_AUX=1; done
-    for C in "CIRCUIT=einsum K=20" "CIRCUIT=mlp K=17" "CIRCUIT=conv K=17"; do for V in 0 1; do run "$C COMMIT_AHEAD=$V" $C REPS=8 EZKL_PROVER_COMMIT_AHEAD=$V; done; done ;;
   taper)
     for T in taper equal; do
       if [ $T = equal ]; then X="EZKL_MSM_NO_TAPER=1"; else X="A=1"; fi

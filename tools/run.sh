@@ -68,7 +68,6 @@ j = json.loads(sys.stdin.read()); print(j['prove_seconds_gpu_runs'], j['prove_br
       python "$R/tools/hosttrace.py" "$DB" ${WINDOW_MS:-93} 120 > "$O/${TAG}_hosttrace.txt" 2>&1
       python "$R/tools/timeline.py" "$DB" ${WINDOW_MS:-93} > "$O/${TAG}_timeline.txt" 2>&1
       python "$R/tools/gantt.py" "$DB" ${WINDOW_MS:-93} 250 > "$O/${TAG}_gantt.txt" 2>&1
-      [ -n "$EVENTS" ] && python "$R/tools/dump_events.py" "$DB" ${WINDOW_MS:-93} > "$O/${TAG}_events.csv" 2>&1
       rm -rf "$O/${TAG}_prove"; head -30 "$O/${TAG}_timeline.txt" ;;
     msmcols)
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d "$O/${TAG}_msmcols" -- python "$R/tools/msm_columns_profile.py" run) > "$O/${TAG}_msmcols.log" 2>&1
