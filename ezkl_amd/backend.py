@@ -476,6 +476,23 @@ def lookup_multiplicity(input_ptrs, table_ptr, n_rows, usable_rows, stream=None)
     return out, int(miss.value)
 
 
+def lookup_multiplicity_batch(inputs_per_lookup, table_ptrs, n_rows, usable_rows, stream=None):
+    """m(X) of every lookup argument in one call: inputs_per_lookup[l] = the input column pointers of argument l.  Returns
+    ([DeviceBuffer per argument], total number of input values missing from their tables)"""
+    L = len(table_ptrs)
+    outs = [DeviceBuffer(n_rows * 32) for _ in range(L)]
+    flat = [p for ins in inputs_per_lookup for p in ins]
+    which = [l for l, ins in enumerate(inputs_per_lookup) for _ in ins]
+    miss = DeviceBuffer.from_numpy(np.zeros(1, np.uint32))
+    a_in = (C.c_void_p * max(1, len(flat)))(*flat)
+    a_which = (C.c_uint32 * max(1, len(which)))(*which)
+    a_tab = (C.c_void_p * L)(*table_ptrs)
+    a_out = (C.c_void_p * L)(*[o.ptr for o in outs])
+    _l.check(_l.load().ezkl_hip_lookup_multiplicity_batch_dev(a_in, a_which, C.c_uint32(len(flat)), a_tab, C.c_uint32(L), C.c_uint32(n_rows), C.c_uint32(usable_rows),
+                                                               a_out, _vp(miss.ptr), _stream_ptr(stream)), "ezkl_hip_lookup_multiplicity_batch_dev")
+    return outs, int(miss.to_numpy(np.uint32, (1,))[0])
+
+
 def eval_polynomial(coeffs_ptr, n, x, stream=None):
     """halo2 eval_polynomial on a resident coefficient vector"""
     out = np.zeros(4, np.uint64)

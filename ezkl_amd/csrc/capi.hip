@@ -1012,6 +1012,20 @@ int ezkl_hip_lookup_multiplicity_acc_dev(const void* const* inputs_dev, uint32_t
     return rc ? rc : finish(c, st, stream);
 }
 
+int ezkl_hip_lookup_multiplicity_batch_dev(const void* const* inputs_dev, const uint32_t* input_lookup, uint32_t n_inputs, const void* const* tables_dev,
+                                           uint32_t n_lookups, uint32_t n_rows, uint32_t usable_rows, void* const* m_outs_dev, void* missing_dev, void* stream) {
+    if (!tables_dev || !m_outs_dev || !missing_dev || n_lookups == 0 || (n_inputs && (!inputs_dev || !input_lookup))) return EZKL_ERR_INVALID;
+    for (uint32_t j = 0; j < n_inputs; j++)
+        if (!inputs_dev[j]) return EZKL_ERR_INVALID;
+    for (uint32_t l = 0; l < n_lookups; l++)
+        if (!tables_dev[l] || !m_outs_dev[l]) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    hipStream_t st = pick_stream(c, stream);
+    int rc = lookup_multiplicity_batch(c, st, (const fe_t* const*)inputs_dev, input_lookup, n_inputs, (const fe_t* const*)tables_dev, n_lookups, n_rows,
+                                       usable_rows, (fe_t* const*)m_outs_dev, nullptr, (uint32_t*)missing_dev);
+    return rc ? rc : finish(c, st, stream);
+}
+
 int ezkl_hip_eval_poly_dev(const void* coeffs, size_t n, const void* x, void* out, void* stream) {
     if ((!coeffs && n) || !x || !out) return EZKL_ERR_INVALID;
     EZ_CTX(c);

@@ -134,6 +134,8 @@ int vec_scale(Ctx* c, hipStream_t st, const fe_t* a, const fe_t& s, fe_t* o, siz
 int perm_sigma(Ctx* c, hipStream_t st, const uint32_t* next, const fe_t* omega_col, const fe_t* delta_pows, uint32_t log_n, uint32_t m, fe_t* out);
 int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ext_k);
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n);
+int lookup_multiplicity_batch(Ctx* c, hipStream_t st, const fe_t* const* inputs, const uint32_t* which, uint32_t n_items, const fe_t* const* tables,
+                              uint32_t n_lookups, uint32_t n_rows, uint32_t usable, fe_t* const* m_outs, uint32_t* missing_host, uint32_t* missing_dev);
 int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
                         uint32_t usable, fe_t* m_out, uint32_t* missing_host, uint32_t* missing_dev);
 int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& x, void* out_host);

@@ -926,13 +926,23 @@ struct Backend {
     }
     // `missing`: a resident counter (first u32 of a zeroed column) that collects the inputs absent from the table over all the lookup
     // arguments of a proof; nothing comes back to the host here, the caller checks it once (lookup_check)
-    Col lookup_multiplicity(const std::vector<Col>& inputs, const Col& table, uint32_t usable, const Col& missing) const {
-        Col out = alloc(n);
-        std::vector<const void*> ptrs;
-        for (auto& c : inputs) ptrs.push_back(c->ptr());
-        check(ezkl_hip_lookup_multiplicity_acc_dev(ptrs.data(), (uint32_t)ptrs.size(), table->ptr(), n, usable, out->ptr(), missing->ptr(), nullptr),
-              "ezkl_hip_lookup_multiplicity_acc_dev");
-        return out;
+    // the multiplicity columns of several lookup arguments in one call (three launches for all of them)
+    std::vector<Col> lookup_multiplicities(const std::vector<std::vector<Col>>& inputs, const std::vector<Col>& tables, uint32_t usable, const Col& missing) const {
+        std::vector<Col> outs;
+        if (tables.empty()) return outs;
+        std::vector<const void*> in_ptrs, tab_ptrs;
+        std::vector<uint32_t> which;
+        std::vector<void*> out_ptrs;
+        for (size_t l = 0; l < tables.size(); l++) {
+            for (auto& c : inputs[l]) { in_ptrs.push_back(c->ptr()); which.push_back((uint32_t)l); }
+            tab_ptrs.push_back(tables[l]->ptr());
+            outs.push_back(alloc(n));
+            out_ptrs.push_back(outs.back()->ptr());
+        }
+        check(ezkl_hip_lookup_multiplicity_batch_dev(in_ptrs.data(), which.data(), (uint32_t)in_ptrs.size(), tab_ptrs.data(), (uint32_t)tab_ptrs.size(), n, usable,
+                                                     out_ptrs.data(), missing->ptr(), nullptr),
+              "ezkl_hip_lookup_multiplicity_batch_dev");
+        return outs;
     }
     // Owner mode: only the owner of a lookup argument sees its counter, and a rank that threw alone would leave the others waiting in the
     // next collective for ever (the most common ezkl prover failure -- a witness value outside its table -- hung the whole
@@ -2063,18 +2073,27 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     if (nl) {
         theta = T.squeeze_challenge();
         const Col missing = be.zeros(1);
+        std::vector<std::vector<U256>> blinds(nl);
+        std::vector<std::vector<Col>> my_inputs;
+        std::vector<Col> my_tables;
+        std::vector<size_t> my_idx;
         for (size_t i = 0; i < nl; i++) {
             const Lookup& l = cs.lookups[i];
             LookupState& st = lk[i];
             st.mine = topo.mine(i);
             if (owners) lk_owner[i] = (int)topo.owner(i);
-            const std::vector<U256> blind = rng.vec(n - u);             // every rank draws every argument's randomness: one stream, same order
+            blinds[i] = rng.vec(n - u);                                 // every rank draws every argument's randomness: one stream, same order
             if (!st.mine) continue;
             for (auto& t : l.inputs) st.inputs.push_back(compress_column(cs, be, t, theta, col_handle, user_chal));
             st.table = compress_column(cs, be, l.table, theta, col_handle, user_chal);
-            st.m = be.lookup_multiplicity(st.inputs, st.table, u, missing);
-            be.set_rows(st.m, u, blind);
+            my_inputs.push_back(st.inputs); my_tables.push_back(st.table); my_idx.push_back(i);
             cs.shard.stats[3]++;
+        }
+        // the arguments are independent: their hash-table passes run as ONE batch (three launches, not three per argument)
+        const std::vector<Col> my_ms = be.lookup_multiplicities(my_inputs, my_tables, u, missing);
+        for (size_t q = 0; q < my_idx.size(); q++) {
+            lk[my_idx[q]].m = my_ms[q];
+            be.set_rows(my_ms[q], u, blinds[my_idx[q]]);
         }
         std::vector<Col> ms;
         for (auto& st : lk) ms.push_back(st.m);

@@ -309,7 +309,14 @@ EZ_D uint32_t ht_hash(const fe_t& v, uint32_t mask) {
     h ^= h >> 15;
     return h & mask;
 }
-__global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* table, uint32_t usable, uint32_t* slots, uint32_t mask) {
+// Every kernel serves a BATCH of lookup arguments (blockIdx.y): a proof builds one multiplicity column per argument, each call of the
+// one-argument form was three sub-0.2 ms launches that leave most of the machine waiting on random 4- and 32-byte reads, and a k = 20 MLP
+// proof spent 3.3 ms on its eight arguments one after the other (profiles/r04au_events.csv).  tables[l] / slots + l * cap / counts +
+// l * cstride belong to argument l; input item y (blockIdx.y of the count pass) probes the table of argument which[y].
+__global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* const* tables, uint32_t usable, uint32_t* slots, uint32_t cap) {
+    const fe_t* table = tables[blockIdx.y];
+    slots += (size_t)blockIdx.y * cap;
+    const uint32_t mask = cap - 1;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < usable;
     const fe_t key = live ? ld_fe(table + i) : Fr::zero();
@@ -334,8 +341,13 @@ __global__ __launch_bounds__(256) void ht_build_kernel(const fe_t* table, uint32
         h = (h + 1) & mask;
     }
 }
-__global__ __launch_bounds__(256) void ht_count_kernel(const fe_t* input, uint32_t rows, const fe_t* table, const uint32_t* slots,
-                                                       uint32_t mask, uint32_t* counts, uint32_t* missing) {
+__global__ __launch_bounds__(256) void ht_count_kernel(const fe_t* const* inputs, const uint32_t* which, uint32_t rows, const fe_t* const* tables,
+                                                       const uint32_t* slots, uint32_t cap, uint32_t* counts, uint32_t cstride, uint32_t* missing) {
+    const uint32_t l = which[blockIdx.y], mask = cap - 1;
+    const fe_t* input = inputs[blockIdx.y];
+    const fe_t* table = tables[l];
+    slots += (size_t)l * cap;
+    counts += (size_t)l * cstride;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // target: the table row this lane's input equals (HT_EMPTY = not in the table), HT_EMPTY - 1 = lane past the end
     uint32_t target = HT_EMPTY - 1;
@@ -365,30 +377,51 @@ __global__ __launch_bounds__(256) void ht_count_kernel(const fe_t* input, uint32
     }
     if (pending) atomicAdd(target == HT_EMPTY ? missing : &counts[target], 1u);
 }
-__global__ __launch_bounds__(256) void counts_to_fr_kernel(const uint32_t* counts, uint32_t n, fe_t* out) {
+__global__ __launch_bounds__(256) void counts_to_fr_kernel(const uint32_t* counts, uint32_t n, uint32_t cstride, fe_t* const* outs) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t v = counts[(size_t)blockIdx.y * cstride + i];
     fe_t t = Fr::zero();
-    t.v[0] = counts[i];
-    st_fe(out + i, counts[i] ? Fr::to_mont(t) : t);
+    t.v[0] = v;
+    st_fe(outs[blockIdx.y] + i, v ? Fr::to_mont(t) : t);
 }
-int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
-                        uint32_t usable, fe_t* m_out, uint32_t* missing_host, uint32_t* missing_dev) {
+// n_lookups arguments at once: item y of inputs (n_items of them, any number per argument) belongs to argument which[y]
+int lookup_multiplicity_batch(Ctx* c, hipStream_t st, const fe_t* const* inputs, const uint32_t* which, uint32_t n_items, const fe_t* const* tables,
+                              uint32_t n_lookups, uint32_t n_rows, uint32_t usable, fe_t* const* m_outs, uint32_t* missing_host, uint32_t* missing_dev) {
     // missing_dev (device u32, ACCUMULATED into): the stream-ordered form -- nothing comes back to the host, so the call does not
     // synchronise; the caller reads the counter once after queuing all its lookups
-    if (usable > n_rows) return EZKL_ERR_INVALID;
+    if (usable > n_rows || n_lookups == 0 || n_lookups > 65535 || n_items > 65535) return EZKL_ERR_INVALID;
+    for (uint32_t y = 0; y < n_items; y++)
+        if (which[y] >= n_lookups) return EZKL_ERR_INVALID;
     uint32_t cap = 16;
     while (cap < 2 * (usable ? usable : 1)) cap <<= 1;
-    uint32_t* d = nullptr;
-    int rc = arena_reserve(c->aux, ((size_t)cap + n_rows + 1) * 4, st, (void**)&d);
+    const uint32_t cstride = n_rows;
+    // pointer arrays first (8-byte aligned), then the u32 arrays: which[], slots, counts, the missing counter
+    const size_t n_ptr = (size_t)n_items + 2 * (size_t)n_lookups;
+    const size_t words = (size_t)n_items + (size_t)n_lookups * cap + (size_t)n_lookups * cstride + 1;
+    uint8_t* d = nullptr;
+    int rc = arena_reserve(c->aux, n_ptr * 8 + words * 4, st, (void**)&d);
     if (rc) return rc;
-    uint32_t *slots = d, *counts = d + cap, *missing = missing_dev ? missing_dev : counts + n_rows;
-    EZ_HIP(hipMemsetAsync(slots, 0xff, (size_t)cap * 4, st));
-    EZ_HIP(hipMemsetAsync(counts, 0, ((size_t)n_rows + 1) * 4, st));
-    if (usable) hipLaunchKernelGGL(ht_build_kernel, dim3(cdiv(usable, 256)), dim3(256), 0, st, table, usable, slots, cap - 1);
-    for (uint32_t j = 0; j < n_inputs; j++)
-        if (usable) hipLaunchKernelGGL(ht_count_kernel, dim3(cdiv(usable, 256)), dim3(256), 0, st, inputs[j], usable, table, slots, cap - 1, counts, missing);
-    hipLaunchKernelGGL(counts_to_fr_kernel, dim3(cdiv(n_rows, 256)), dim3(256), 0, st, counts, n_rows, m_out);
+    const fe_t** d_inputs = reinterpret_cast<const fe_t**>(d);
+    const fe_t** d_tables = d_inputs + n_items;
+    fe_t** d_outs = const_cast<fe_t**>(d_tables + n_lookups);
+    uint32_t* d_which = reinterpret_cast<uint32_t*>(d + n_ptr * 8);
+    uint32_t *slots = d_which + n_items, *counts = slots + (size_t)n_lookups * cap, *missing = missing_dev ? missing_dev : counts + (size_t)n_lookups * cstride;
+    if (n_items) {
+        EZ_HIP(hipMemcpyAsync(d_inputs, inputs, (size_t)n_items * 8, hipMemcpyHostToDevice, st));
+        EZ_HIP(hipMemcpyAsync(d_which, which, (size_t)n_items * 4, hipMemcpyHostToDevice, st));
+    }
+    EZ_HIP(hipMemcpyAsync(d_tables, tables, (size_t)n_lookups * 8, hipMemcpyHostToDevice, st));
+    EZ_HIP(hipMemcpyAsync(d_outs, m_outs, (size_t)n_lookups * 8, hipMemcpyHostToDevice, st));
+    EZ_HIP(hipMemsetAsync(slots, 0xff, (size_t)n_lookups * cap * 4, st));
+    EZ_HIP(hipMemsetAsync(counts, 0, ((size_t)n_lookups * cstride + (missing_dev ? 0 : 1)) * 4, st));
+    if (usable) {
+        hipLaunchKernelGGL(ht_build_kernel, dim3(cdiv(usable, 256), n_lookups), dim3(256), 0, st, d_tables, usable, slots, cap);
+        if (n_items)
+            hipLaunchKernelGGL(ht_count_kernel, dim3(cdiv(usable, 256), n_items), dim3(256), 0, st, d_inputs, (const uint32_t*)d_which, usable, d_tables,
+                               (const uint32_t*)slots, cap, counts, cstride, missing);
+    }
+    hipLaunchKernelGGL(counts_to_fr_kernel, dim3(cdiv(n_rows, 256), n_lookups), dim3(256), 0, st, (const uint32_t*)counts, n_rows, cstride, (fe_t* const*)d_outs);
     hipError_t e = hipGetLastError();
     if (missing_dev) {
         if (e != hipSuccess) return set_hip_error(e, "lookup_multiplicity", __FILE__, __LINE__);
@@ -401,6 +434,11 @@ int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint3
     if ((rc = arena_done(c->aux, st))) return rc;
     if (missing_host) *missing_host = miss;
     return EZKL_OK;
+}
+int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint32_t n_inputs, const fe_t* table, uint32_t n_rows,
+                        uint32_t usable, fe_t* m_out, uint32_t* missing_host, uint32_t* missing_dev) {
+    const std::vector<uint32_t> which(n_inputs ? n_inputs : 1, 0u);
+    return lookup_multiplicity_batch(c, st, inputs, which.data(), n_inputs, &table, 1, n_rows, usable, &m_out, missing_host, missing_dev);
 }
 
 // ---- polynomial evaluation at a point (halo2 eval_polynomial: hundreds of O(n) Horner reductions per proof,

@@ -265,6 +265,12 @@ int ezkl_hip_lookup_multiplicity_dev(const void* const* inputs_dev, uint32_t n_i
  * host, so the call is stream-ordered like the other helpers; a prover queues all its lookup arguments and reads the counter once */
 int ezkl_hip_lookup_multiplicity_acc_dev(const void* const* inputs_dev, uint32_t n_inputs, const void* table_dev, uint32_t n_rows,
                                          uint32_t usable_rows, void* m_out_dev, void* missing_dev, void* stream);
+/* every lookup argument of a proof in ONE call (mv_lookup::prover::prepare runs once per argument, on independent data): argument l has
+ * the table tables_dev[l] and the output column m_outs_dev[l]; input column j (n_inputs of them in all, any number per argument)
+ * belongs to argument input_lookup[j].  Three launches for the whole batch instead of three per argument -- the passes are random
+ * 4- and 32-byte reads, and one argument alone leaves most of the machine waiting on them.  missing_dev as in _acc_dev. */
+int ezkl_hip_lookup_multiplicity_batch_dev(const void* const* inputs_dev, const uint32_t* input_lookup, uint32_t n_inputs, const void* const* tables_dev,
+                                           uint32_t n_lookups, uint32_t n_rows, uint32_t usable_rows, void* const* m_outs_dev, void* missing_dev, void* stream);
 /* halo2 eval_polynomial(poly, x): sum_i coeffs[i] * x^i for a resident coefficient vector; x and the 32-byte result
  * are host memory (create_proof evaluates every queried (column, rotation) this way before SHPLONK) */
 int ezkl_hip_eval_poly_dev(const void* coeffs_dev, size_t n, const void* x_host, void* out_host, void* stream);

@@ -268,6 +268,34 @@ def test_lookup_multiplicity(hip, k, ninputs):
     assert [fe_to_int(g) for g in got] == [int(w) for w in want]
 
 
+@pytest.mark.parametrize("k", [5, 12, 17])
+def test_lookup_multiplicity_batch(hip, k):
+    """every lookup argument of a proof in one call: the columns and the missing count of one call per argument (arguments with 1, 3, 2
+    and NO input columns, tables with runs of equal rows)"""
+    from ezkl_amd import backend as B
+    rng = np.random.default_rng(100 + k)
+    n = 1 << k
+    usable = n - 6
+    tables, inputs = [], []
+    for l, nin in enumerate((1, 3, 2, 0)):
+        distinct = max(2, n // (2 + l))
+        pool = rand_fr(rng, distinct)
+        t = np.sort(rng.integers(0, distinct, size=n)) if l == 1 else rng.integers(0, distinct, size=n)        # l = 1: long runs of equal rows
+        tables.append(pool[t])
+        inputs.append([tables[-1][rng.integers(0, usable, size=n)] for _ in range(nin)])
+    inputs[1][2][5] = rand_fr(rng, 1)[0]                       # two values that are in no table
+    inputs[2][0][usable - 1] = rand_fr(rng, 1)[0]
+    dt = [B.DeviceBuffer.from_numpy(t) for t in tables]
+    di = [[B.DeviceBuffer.from_numpy(x) for x in ins] for ins in inputs]
+    outs, missing = B.lookup_multiplicity_batch([[d.ptr for d in ins] for ins in di], [d.ptr for d in dt], n, usable)
+    total = 0
+    for l in range(4):
+        m_one, miss_one = B.lookup_multiplicity([d.ptr for d in di[l]], dt[l].ptr, n, usable)
+        total += miss_one
+        assert (outs[l].to_numpy(shape=(n, 4)) == m_one.to_numpy(shape=(n, 4))).all(), l
+    assert missing == total == 2
+
+
 @pytest.mark.parametrize("n,m", [(1, 1), (33, 3), (1000, 17), (1 << 16, 5), ((1 << 18) + 3, 2)])
 def test_eval_polynomial_batch(hip, n, m):
     """the batched form of create_proof's step 10: same values as one call per (polynomial, point)"""
