@@ -924,9 +924,9 @@ struct Backend {
         }
         return out;
     }
-    // `missing`: a resident counter (first u32 of a zeroed column) that collects the inputs absent from the table over all the lookup
-    // arguments of a proof; nothing comes back to the host here, the caller checks it once (lookup_check)
-    // the multiplicity columns of several lookup arguments in one call (three launches for all of them)
+    // the multiplicity columns of several lookup arguments in one call (three launches for all of them).  `missing`: a resident counter
+    // (first u32 of a zeroed column) that collects the inputs absent from their tables over all the arguments; nothing comes back to the
+    // host here, the caller checks it once (lookup_check)
     std::vector<Col> lookup_multiplicities(const std::vector<std::vector<Col>>& inputs, const std::vector<Col>& tables, uint32_t usable, const Col& missing) const {
         std::vector<Col> outs;
         if (tables.empty()) return outs;
