@@ -98,18 +98,45 @@ int divide_by_vanishing(Ctx* c, hipStream_t st, fe_t* a, uint32_t k, uint32_t ex
 // Montgomery batch inversion.  T threads; thread t owns elements {t + j*T}: a coalesced strided chain.
 // forward: pre[t + j*T] = prod_{i<j} a_i (zeros skipped); invert the chain product once (Fermat);
 // backward: a_j^-1 = acc * pre_j ; acc *= a_j.
+// Thread t owns the strided chain a[t], a[t + T], ...: prefix products forward, then the 256 chain products of a workgroup are combined
+// (an inclusive prefix scan and an inclusive suffix scan of them in LDS: 1 / acc_t = 1 / total * prefix_(t-1) * suffix_(t+1)), ONE lane
+// of the workgroup runs the Fermat inversion of the total, and every chain walks back.  Until round 4 every chain ended in its own
+// inversion (~380 dependent products), which capped the launch at one wave per SIMD -- more chains would have bought shorter chains with
+// more inversions -- and left a 16-column batch of a k = 20 proof at 1.25 ms of mostly dependent-issue latency
+// (profiles/r04au_events.csv); one inversion per 256 chains lets four waves per SIMD share the issue slots.
 __global__ __launch_bounds__(256) void batch_invert_kernel(fe_t* a, fe_t* pre, size_t n, size_t T) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
+    __shared__ fe_t pfx[256], sfx[256];
+    __shared__ fe_t inv_total;
+    const uint32_t tid = threadIdx.x;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + tid;
     fe_t acc = Fr::one();
     size_t last = t;
-    for (size_t i = t; i < n; i += T) {
-        st_fe(pre + i, acc);
-        fe_t x = ld_fe(a + i);
-        if (!Fr::is_zero(x)) acc = Fr::mul(acc, x);
-        last = i;
+    const bool have = t < T && t < n;
+    if (have)
+        for (size_t i = t; i < n; i += T) {
+            st_fe(pre + i, acc);
+            fe_t x = ld_fe(a + i);
+            if (!Fr::is_zero(x)) acc = Fr::mul(acc, x);
+            last = i;
+        }
+    pfx[tid] = acc;
+    sfx[tid] = acc;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {           // inclusive Hillis-Steele, prefix and suffix at once
+        fe_t p = pfx[tid], q = sfx[tid];
+        if (tid >= d) p = Fr::mul(pfx[tid - d], p);
+        if (tid + d < 256) q = Fr::mul(q, sfx[tid + d]);
+        __syncthreads();
+        pfx[tid] = p;
+        sfx[tid] = q;
+        __syncthreads();
     }
-    acc = Fr::inv(acc);
+    if (tid == 0) inv_total = Fr::inv(pfx[255]);       // no chain product is zero: zero elements are skipped
+    __syncthreads();
+    if (!have) return;
+    acc = inv_total;
+    if (tid > 0) acc = Fr::mul(acc, pfx[tid - 1]);
+    if (tid < 255) acc = Fr::mul(acc, sfx[tid + 1]);
     for (size_t i = last;; i -= T) {
         fe_t x = ld_fe(a + i);
         if (!Fr::is_zero(x)) {
@@ -121,10 +148,9 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(fe_t* a, fe_t* pre, s
 }
 int batch_invert(Ctx* c, hipStream_t st, fe_t* a, size_t n) {
     if (n == 0) return EZKL_OK;
-    // every chain ends in one Fermat inversion (~380 dependent products, the latency floor of this kernel), so chains are
-    // made short and many -- but no more than one wave per SIMD, beyond which the inversions start to cost throughput
+    // chains of >= 16 elements, at most four workgroups (16 waves) per CU: one Fermat inversion per workgroup, so the chains can be many
     size_t T = n / 16;
-    size_t cap = (size_t)c->num_cus * 256;
+    size_t cap = (size_t)c->num_cus * 1024;
     if (T > cap) T = cap;
     if (T < 1) T = 1;
     fe_t* pre = nullptr;
