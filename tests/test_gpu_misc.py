@@ -18,7 +18,7 @@ def test_vec_ops(hip, n):
         assert (do.to_numpy(shape=(n, 4)) == ob.vec_op(op, a, b)).all()
 
 
-@pytest.mark.parametrize("n", [1, 5, 64, 1000, 1 << 15])
+@pytest.mark.parametrize("n", [1, 5, 64, 1000, 4097, 1 << 15, (1 << 20) + 3, 5 * (1 << 20) + 1])
 def test_batch_invert(hip, n):
     import ctypes as C
     from ezkl_amd import backend as B, lib as L
