@@ -21,8 +21,8 @@
 namespace ezkl {
 
 // workgroup sizes: 256 threads for tiles of 1024 elements (and single-pass transforms), 512 / 1024 for the 2048- / 4096-element tiles of radix 2^9 / 2^10 passes
-static constexpr uint32_t NTT_LOG_TILE = 10;   // multi-pass tile: 1024 elements = 32 KiB of LDS -> 4 workgroups (16 waves) per CU
-static constexpr uint32_t NTT_LOG_SINGLE = 11; // a transform up to 2^11 runs as ONE pass in a 64 KiB tile
+static constexpr uint32_t NTT_LOG_TILE = 10;   // multi-pass tile: 1024 elements = 36 KiB of LDS (9 limbs each) -> 4 workgroups (16 waves) per CU
+static constexpr uint32_t NTT_LOG_SINGLE = 11; // a transform up to 2^11 runs as ONE pass in a 72 KiB tile
 
 struct PassArgs {
     const fe_t* in;
@@ -56,8 +56,7 @@ struct PassArgs {
 // Until round 4 the pass ran a decimation-in-frequency butterfly on 8 x 32-bit limbs: 87 % of what it issued was its 281-slot Montgomery
 // product; the lazily reduced 9 x 29-bit product takes 205 instructions.  Round 2's attempt to use it lost the gain to
 // conversions and range control because in a DIF butterfly the sums double in size every stage.  Here every column transform runs
-// decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The
-// product comes first, so t < 2p whatever v was, a value grows by at most 4p per stage (< 54p after the 11 stages of the largest tile,
+// decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The product comes first, so t < 2p whatever v was, a value grows by at most 4p per stage (< 54p after the 11 stages of the largest tile,
 // far below the 1000p the product accepts) and limbs grow by at most 2 units of 2^29 per stage: the only range control is ONE carry
 // propagation per element at the end of a two-stage register group -- no comparison, no conditional subtraction inside the transform.
 // Elements are 8 x 32-bit words in HBM (the files' 2^256 Montgomery domain, untouched: the twiddles carry the 2^261 of the product) and
