@@ -37,6 +37,26 @@ def test_edge_inputs(hip):
     assert (hip.ntt(top, k, w) == ob.fft(top, k, w)).all()
 
 
+@pytest.mark.parametrize("k", [3, 8, 11, 13, 16])
+def test_words_that_are_not_canonical(hip, k):
+    """The pass takes its elements as 256-bit words (radix-2^29 lazy limbs inside, a canonical result out): words at and above the modulus --
+    what a lazily reduced producer could hand over -- transform like their residues, and the all-ones word does not overflow a limb
+    (single-pass sizes, two and three passes)"""
+    rng = np.random.default_rng(300 + k)
+    n = 1 << k
+    a = rand_fr(rng, n)
+    words = [int.from_bytes(a[i].tobytes(), "little") for i in range(n)]
+    special = [(1 << 256) - 1, R, R + 5, 2 * R - 1, 5 * R + 12345, (1 << 256) - R, 0, R - 1]
+    for j, v in enumerate(special):
+        words[(j * 7919) % n] = v
+    raw = np.array([[(v >> (64 * q)) & 0xFFFFFFFFFFFFFFFF for q in range(4)] for v in words], np.uint64)
+    red = np.array([[((v % R) >> (64 * q)) & 0xFFFFFFFFFFFFFFFF for q in range(4)] for v in words], np.uint64)
+    w = ob.omega(k)
+    assert (hip.ntt(raw, k, w) == ob.fft(red, k, w)).all()
+    d = hip.EvaluationDomain(2, k)
+    assert (d.lagrange_to_coeff(raw) == ob.lagrange_to_coeff(red, k)).all()
+
+
 def test_golden_pk_vectors(hip, golden_pk):
     """reference fixture: fixed_polys == iNTT(fixed_values), fixed_cosets == coeff_to_extended(polys)"""
     d = hip.EvaluationDomain(9, 6)      # degree 9 -> ext_k = 9 as in tests/assets/pk.key
