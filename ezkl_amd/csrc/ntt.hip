@@ -79,22 +79,6 @@ EZ_D f29_t lds_get29(const uint2* d, const uint32_t* d8, uint32_t tile, uint32_t
     x.v[8] = d8[e];
     return x;
 }
-// normalized x < 2^261 -> [0, p): q = floor(x[8] / ((p >> 232) + 1)) is floor(x / p) or one less; x + q (2^261 - p) mod 2^261 = x - q p
-EZ_D f29_t fr29_canonical(const f29_t& x) {
-    constexpr uint32_t D = (uint32_t)(Fr29C::P[8] + 1u);                                   // limb 8 of p = p >> 232
-    constexpr uint64_t MAGIC = (((uint64_t)1 << 51) + D - 1) / D;                          // exact quotients for x[8] < 2^29
-    const uint32_t q = (uint32_t)(((uint64_t)x.v[8] * MAGIC) >> 51);
-    f29_t r;
-    uint64_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        acc += (uint64_t)q * Fr29C::CSUB[0][i] + x.v[i];
-        r.v[i] = (uint32_t)acc & M29;
-        acc >>= 29;
-    }
-    return Fr29::cond_sub<0>(r);
-}
-
 // G consecutive DIT stages (s .. s+G-1, 1-based: stage s joins blocks of 2^(s-1) rows) of the R-point column transforms, 2^G elements per
 // lane in registers.  A TWISTED transform X[k] = sum_i x_i d^i w_R^(ik) = P(d w_R^k) runs the same code: with P(t) = Pe(t^2) + t Po(t^2) the
 // twist is absorbed by the twiddles -- stage s multiplies by d^(R/2^s) w_(2^s)^o (table entry 2^(s-1) - 1 + o) -- so evaluating on a coset
@@ -246,7 +230,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
                 shift += a.log_radix[p];
             }
             oidx += (size_t)k1 << shift;
-            x = a.post ? Fr29::cond_sub<0>(Fr29::mul(x, Fr29::unpack(a.post_c[oidx % 3]))) : fr29_canonical(x);
+            x = a.post ? Fr29::cond_sub<0>(Fr29::mul(x, Fr29::unpack(a.post_c[oidx % 3]))) : Fr29::canonical(x);
             st_fe(out + oidx, Fr29::pack(x));
         }
     };

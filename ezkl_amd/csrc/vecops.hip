@@ -4,6 +4,7 @@
 // All are streaming kernels: one 32-byte element per lane per access (2 x global_load_dwordx4),
 // grid-stride, HBM-bound except batch inversion.
 #include "common.hpp"
+#include "field29.hpp"
 #include <string.h>
 
 namespace ezkl {
@@ -472,14 +473,22 @@ int lookup_multiplicity(Ctx* c, hipStream_t st, const fe_t* const* inputs, uint3
 // lane t evaluates its 32-coefficient segment by Horner, scales it by x^(32 t) (square-and-multiply on the lane
 // index), workgroups tree-sum in LDS; a second launch of the same tree folds the per-workgroup partials.
 static constexpr uint32_t EVP_SEG = 32;
-__global__ __launch_bounds__(256) void eval_poly_kernel(const fe_t* coeffs, size_t n, fe_t x, const fe_t* xpow2, uint32_t npow, fe_t* partial) {
+// Horner over m <= 32 coefficients at x: the segment's 31 dependent products are the kernel, so they run on the radix-2^29 lazy limbs of
+// field29.hpp (205 instructions a product against 281; x carries the 2^261 of that product: x_r261 = 32 x in the Montgomery domain of the
+// data, which is left alone); one canonicalisation at the end of the segment brings the value back to 8 x 32-bit words
+EZ_D fe_t evp_segment(const fe_t* c, uint32_t m, const fe_t& x_r261) {
+    const f29_t x29 = Fr29::unpack(x_r261);
+    f29_t acc = Fr29::unpack(ld_fe(c + m - 1));
+    for (uint32_t j = m - 1; j-- > 0;) acc = Fr29::add(Fr29::mul(acc, x29), Fr29::unpack(ld_fe(c + j)));     // < 2p + p, limbs below 2 units
+    return Fr29::pack(Fr29::canonical(Fr29::normalize(acc)));
+}
+__global__ __launch_bounds__(256) void eval_poly_kernel(const fe_t* coeffs, size_t n, fe_t x_r261, const fe_t* xpow2, uint32_t npow, fe_t* partial) {
     __shared__ fe_t sh[256];
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, base = t * EVP_SEG;
     fe_t acc = Fr::zero();
     if (base < n) {
         const uint32_t m = n - base < EVP_SEG ? (uint32_t)(n - base) : EVP_SEG;
-        acc = ld_fe(coeffs + base + m - 1);
-        for (uint32_t j = m - 1; j-- > 0;) acc = Fr::add(Fr::mul(acc, x), ld_fe(coeffs + base + j));
+        acc = evp_segment(coeffs + base, m, x_r261);
         // x^(32 t): bits of t select precomputed x^(32 * 2^b)
         for (uint32_t b = 0; b < npow; b++)
             if ((t >> b) & 1) acc = Fr::mul(acc, ld_fe(xpow2 + b));
@@ -519,7 +528,7 @@ int eval_poly(Ctx* c, hipStream_t st, const fe_t* coeffs, size_t n, const fe_t& 
     if (rc) return rc;
     fe_t *d_pw = d, *d_part = d + pw.size(), *d_out = d_part + blocks;
     EZ_HIP(hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(fe_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(eval_poly_kernel, dim3(blocks), dim3(256), 0, st, coeffs, n, x, d_pw, npow, d_part);
+    hipLaunchKernelGGL(eval_poly_kernel, dim3(blocks), dim3(256), 0, st, coeffs, n, Fr::mul(x, Fr::from_u64(32)), d_pw, npow, d_part);
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, d_part, (size_t)blocks, d_out);
     hipError_t e = hipMemcpyAsync(out_host, d_out, 32, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -543,8 +552,7 @@ __global__ __launch_bounds__(256) void eval_poly_multi_kernel(const EvalItem* it
     fe_t acc = Fr::zero();
     if (base < n) {
         const uint32_t m = n - base < EVP_SEG ? (uint32_t)(n - base) : EVP_SEG;
-        acc = ld_fe(it.coeffs + base + m - 1);
-        for (uint32_t j = m - 1; j-- > 0;) acc = Fr::add(Fr::mul(acc, it.x), ld_fe(it.coeffs + base + j));
+        acc = evp_segment(it.coeffs + base, m, it.x);
         for (uint32_t b = 0; b < npow; b++)
             if ((t >> b) & 1) acc = Fr::mul(acc, ld_fe(xpow2 + b));
     }
@@ -583,7 +591,7 @@ int eval_poly_batch(Ctx* c, hipStream_t st, const fe_t* const* coeffs, const fe_
     EvalItem* items = reinterpret_cast<EvalItem*>(host.data());
     for (uint32_t j = 0; j < m; j++) {
         items[j].coeffs = coeffs[j];
-        items[j].x = xs[j];
+        items[j].x = Fr::mul(xs[j], Fr::from_u64(32));       // x in the 2^261 domain of the segment's radix-2^29 Horner (evp_segment)
         fe_t p = xs[j];
         for (int i = 0; i < 5; i++) p = Fr::sqr(p);          // x^32
         for (uint32_t b = 0; b < npow; b++) { host[items_fe + j * pws + b] = p; p = Fr::sqr(p); }
