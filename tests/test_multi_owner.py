@@ -68,11 +68,16 @@ def test_replicated_mode_still_same_bytes(hip):
 
 def test_lookup_failure_is_collective(hip):
     """a witness value outside its table: every rank returns the error (no rank is left waiting in the next collective)"""
-    env = dict(os.environ, EZKL_BENCH_CACHE="off", CIRCUIT="fixture", K="6")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
-           TOOL, "--gloo", "--share-device", "--bad-lookup"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    for rank in (0, 1):
-        lines = [l for l in r.stdout.splitlines() if l.startswith("RANK %d " % rank)]
-        assert lines and "ERROR" in lines[0] and "lookup input not in table" in lines[0], (rank, r.stdout[-1000:], r.stderr[-1000:])
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        # every rank leaves its status in a file of its own: the ranks share one stdout pipe with gloo's C-level prints, where lines can run together
+        env = dict(os.environ, EZKL_BENCH_CACHE="off", CIRCUIT="fixture", K="6", EZKL_RANK_STATUS_DIR=d)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+               TOOL, "--gloo", "--share-device", "--bad-lookup"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for rank in (0, 1):
+            path = os.path.join(d, "rank_%d.txt" % rank)
+            assert os.path.exists(path), (rank, r.stdout[-1000:], r.stderr[-1000:])
+            line = open(path).read()
+            assert "ERROR" in line and "lookup input not in table" in line, (rank, line, r.stdout[-1000:])

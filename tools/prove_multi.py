@@ -92,9 +92,13 @@ if "--bad-lookup" in sys.argv:
         a[:32] = P.to_mont(123456789)
     try:
         NV.create_proof(npk, gb, glb, adv, seed=5, instances=instances)
-        print("RANK %d NO_ERROR" % rank, flush=True)
+        status = "RANK %d NO_ERROR" % rank
     except Exception as e:
-        print("RANK %d ERROR %s" % (rank, str(e).replace("\n", " ")[:200]), flush=True)
+        status = "RANK %d ERROR %s" % (rank, str(e).replace("\n", " ")[:200])
+    print(status, flush=True)
+    if os.environ.get("EZKL_RANK_STATUS_DIR"):          # the ranks share one stdout pipe with gloo's own C-level prints: a file per rank cannot interleave
+        with open(os.path.join(os.environ["EZKL_RANK_STATUS_DIR"], "rank_%d.txt" % rank), "w") as f:
+            f.write(status + "\n")
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()      # a rank left behind in a collective would never get here
     sys.exit(0)
