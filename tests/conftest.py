@@ -97,3 +97,19 @@ def hip():
     import ezkl_amd
     ezkl_amd.init()
     return ezkl_amd
+
+
+def json_lines(stdout):
+    """the JSON objects a child printed, one per line -- tolerant of other text in front of the object on the same line: ranks of a
+    torchrun world share one stdout pipe with gloo's C-level prints, and a line of theirs without a trailing newline glues itself to the next"""
+    import json
+    out = []
+    for line in stdout.splitlines():
+        i = line.find('{"')
+        if i < 0:
+            continue
+        try:
+            out.append(json.loads(line[i:]))
+        except ValueError:
+            pass
+    return out

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 import pytest
-from conftest import ROOT
+from conftest import ROOT, json_lines
 
 pytestmark = pytest.mark.gpu
 
@@ -88,9 +88,9 @@ def _run(mode, world, circuit, k):
     env = dict(os.environ, EZKL_ROOT=ROOT)
     env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, "-c", CHILD, mode, str(world), circuit, str(k)], env=env, capture_output=True, text=True, timeout=900)
-    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    assert lines, r.stderr[-3000:]
-    return json.loads(lines[-1])
+    objs = json_lines(r.stdout)
+    assert objs, r.stderr[-3000:]
+    return objs[-1]
 
 
 @pytest.mark.parametrize("world,circuit,k", [(2, "mlp", 9), (4, "mlp", 10), (2, "fixture", 6)])

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 import pytest
-from conftest import ROOT
+from conftest import ROOT, json_lines
 
 pytestmark = pytest.mark.gpu
 TOOL = os.path.join(ROOT, "tools", "prove_multi.py")
@@ -22,9 +22,9 @@ def _run(env, world, port, extra=()):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port), TOOL, "--gloo", "--share-device"] + list(extra)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    assert lines, r.stderr[-3000:]
-    return json.loads(lines[-1])
+    objs = json_lines(r.stdout)
+    assert objs, r.stderr[-3000:]
+    return objs[-1]
 
 
 @pytest.mark.parametrize("circuit,k", [("fixture", 6), ("mlp", 10), ("einsum", 10)])

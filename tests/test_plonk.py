@@ -3,7 +3,7 @@ accepts (the reference's own acceptance criterion), on the refere
 CPU: protocol logic on the oracle backend.  GPU: the same proof BYTES from the HIP kernels."""
 import numpy as np
 import pytest
-from conftest import fe_from_int, R
+from conftest import fe_from_int, R, json_lines
 from ezkl_amd import plonk as P
 from oracle import pairing as E, pyref as pr, verifier as V
 
@@ -346,9 +346,9 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29541", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo", "--native"],
                          env=env, capture_output=True, text=True, timeout=900)
-    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
-    assert lines, two.stderr[-2000:]
-    j2 = json.loads(lines[-1])
+    objs = json_lines(two.stdout)
+    assert objs, two.stderr[-2000:]
+    j2 = objs[-1]
     assert j1["verifier_accepts"] and j2["verifier_accepts"]
     assert j2["n_gpus"] == 2 and j1["proof_sha256"] == j2["proof_sha256"]
     assert "2 sharded sweep(s)" in j2["sweep_sharding"] and "0 sharded" in j1["sweep_sharding"]      # warm-up + timed proof, rows split over the ranks
@@ -361,9 +361,9 @@ def test_msm_sharded_prover_two_ranks_same_proof(hip):
     two_s = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                             "--master-port", "29543", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo", "--native", "--slice-bases"],
                            env=env, capture_output=True, text=True, timeout=900)
-    lines = [l for l in two_s.stdout.strip().splitlines() if l.startswith("{")]
-    assert lines, two_s.stderr[-2000:]
-    j3 = json.loads(lines[-1])
+    objs = json_lines(two_s.stdout)
+    assert objs, two_s.stderr[-2000:]
+    j3 = objs[-1]
     assert j3["native_prover"]["commit_sharding"].startswith("by points") and j3["native_prover"]["proof_identical_to_python_prover"]
     assert j3["native_prover"]["all_ranks_same_proof"] and j3["native_prover"]["library_rng_proof_verifies"]
 
@@ -381,9 +381,9 @@ def test_column_sharded_ntt_prover_two_ranks_same_proof(hip):
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", "29547", os.path.join(ROOT, "tools", "prove_bench.py"), "--share-device", "--gloo", "--shard-columns"],
                          env=env, capture_output=True, text=True, timeout=900)
-    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
-    assert lines, two.stderr[-2000:]
-    j2 = json.loads(lines[-1])
+    objs = json_lines(two.stdout)
+    assert objs, two.stderr[-2000:]
+    j2 = objs[-1]
     assert j1["verifier_accepts"] and j2["verifier_accepts"] and j1["proof_sha256"] == j2["proof_sha256"]
     assert j2["ntt_sharding"].startswith("columns round-robin across 2 ranks") and j1["ntt_sharding"] == "replicated"
 
@@ -398,9 +398,9 @@ def test_bench_contract_two_ranks(hip):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--backend", "gloo", "--share-device"], env=env, capture_output=True, text=True, timeout=900)
-    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stderr[-2000:]
-    j = json.loads(lines[0])
+    objs = json_lines(r.stdout)
+    assert len(objs) == 1, r.stderr[-2000:]
+    j = objs[0]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline"):
         assert key in j
