@@ -1,6 +1,8 @@
-"""The radix-2^29 NTT pass (ezkl_amd/csrc/ntt.hip, ntt_pass29_kernel) as an integer model, tools/ntt29_model.py: the lazily reduced DIT
-butterfly with every 32- / 64-bit register checked, against the plain DFT over Fr.  Host logic only: the kernel itself is compared with
-the oracle by tests/test_gpu_ntt.py on the GPU."""
+"""The NTT pass (ezkl_amd/csrc/ntt.hip, ntt_pass_kernel) as an integer model, tools/ntt29_model.py: the lazily reduced radix-2^29 DIT
+butterfly with every 32- / 64-bit register checked, and the pass plan with the kernel's own index arithmetic (tiles, column bases, digit
+reversal, inter-pass tables, the twisted first pass of the coset-major transform), against the plain DFT over Fr.  Host logic only: the
+kernel itself is compared with the oracle by tests/test_gpu_ntt.py on the GPU."""
+import random
 import os
 import sys
 
@@ -25,3 +27,66 @@ def test_constants_are_the_generated_ones():
     assert row("// 2^261 - 1 p") == M.CSUB_P
     assert row("// 4 p") == M.SUBC[4] and row("// 8 p") == M.SUBC[8]
     assert row("P[9]") == M.limbs29(M.P)
+
+
+GEN = pow(7, (M.P - 1) >> 28, M.P)
+
+
+def _dft(a, w, k):
+    return sum(x * pow(w, i * k, M.P) for i, x in enumerate(a)) % M.P
+
+
+def test_two_pass_plan_indexing_inverse_scale_and_padding():
+    """2^13 = passes of 7 + 6 bits (unequal radices, the k1-major last pass): inverse transform with its 1 / n product in the last pass, and
+    a forward transform of an input zero-padded from 2^11"""
+    rnd = random.Random(11)
+    log_n = 13
+    n = 1 << log_n
+    assert M.plan_radices(log_n) == [7, 6]
+    w = pow(GEN, 1 << (28 - log_n), M.P)
+    winv, ninv = pow(w, -1, M.P), pow(n, -1, M.P)
+    a = [rnd.randrange(M.P) for _ in range(n)]
+    got = M.transform(a, log_n, winv, inverse_scale=True)
+    for k in rnd.sample(range(n), 4):
+        assert got[k] == _dft(a, winv, k) * ninv % M.P
+    got = M.transform(a, log_n, w, in_log_len=11)
+    for k in rnd.sample(range(n), 4):
+        assert got[k] == _dft(a[:1 << 11], w, k)
+
+
+def test_three_pass_plan_indexing():
+    """a middle pass and a three-digit reversal: 2^13 as 5 + 4 + 4 (EZKL_NTT_MAXR=6)"""
+    rnd = random.Random(12)
+    log_n = 13
+    n = 1 << log_n
+    w = pow(GEN, 1 << (28 - log_n), M.P)
+    a = [rnd.randrange(M.P) for _ in range(n)]
+    orig = M.plan_radices
+    M.plan_radices = lambda ln, maxr=6: orig(ln, 6)
+    try:
+        assert M.plan_radices(log_n) == [5, 4, 4]
+        got = M.transform(a, log_n, w)
+    finally:
+        M.plan_radices = orig
+    for k in rnd.sample(range(n), 4):
+        assert got[k] == _dft(a, w, k)
+
+
+def test_coset_major_transform_twisted_first_pass():
+    """coefficients -> the two cosets of a 2^12 -> 2^13 extended domain: coset b at zeta w_ext^b <w_n>, the scaling absorbed by the first
+    pass's stage twiddles and its inter-pass table (no product for it)"""
+    rnd = random.Random(13)
+    log_n, log_e = 12, 1
+    n = 1 << log_n
+    w_ext = pow(GEN, 1 << (28 - log_n - log_e), M.P)
+    w_n = pow(w_ext, 2, M.P)
+    zeta = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+    a = [rnd.randrange(M.P) for _ in range(n)]
+    outs = M.coset_transform(a, log_n, log_e, w_ext, zeta)
+    for b in range(2):
+        for j in rnd.sample(range(n), 3):
+            x = zeta * pow(w_ext, b, M.P) * pow(w_n, j, M.P) % M.P
+            want = 0
+            for c in reversed(a):
+                want = (want * x + c) % M.P
+            assert outs[b][j] == want

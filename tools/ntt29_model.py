@@ -203,6 +203,126 @@ def dit_column(col, log_r, table, unit1, stats=None):
     return rows
 
 
+# ---- a whole transform as the host code plans it and the kernel indexes it (ntt.hip: plan_radices, ntt_run_chunk, coset_cm_chunk, ntt_pass_kernel)
+NTT_LOG_TILE, NTT_LOG_SINGLE = 10, 11
+
+
+def plan_radices(log_n, maxr=8):
+    if log_n <= NTT_LOG_SINGLE:
+        return [log_n]
+    np_ = max(2, min(4, (log_n + maxr - 1) // maxr))
+    base, extra = divmod(log_n, np_)
+    return [base + (1 if i < extra else 0) for i in range(np_)]
+
+
+def inter_table(log_n, log_m, log_r, w_n, twist=1, log_e=0, b=0, w_ext=None):
+    """the inter-pass twiddles of a pass (ntt_twiddle_kernel mode 1; ntt_coset_table_kernel mode 1 for the twisted first pass): entry
+    k1 S + i2 = w_M^(i2 k1) [* c_b^i2 for coset b], in the 2^261 domain"""
+    S = 1 << (log_m - log_r)
+    out = []
+    for idx in range(1 << log_m):
+        i2, k1 = idx & (S - 1), idx >> (log_m - log_r)
+        w = pow(w_n, (i2 * k1 << (log_n - log_m)) % (1 << log_n), P)
+        if twist != 1:
+            w = w * pow(twist, i2, P) % P
+        out.append(limbs29(w * R261 % P))
+    return out
+
+
+def run_pass(src, n_out, log_n, radices, i, table, tw_inter, unit1, in_log_len=None, post=None):
+    """one launch of ntt_pass_kernel over one column: every tile of the grid, the kernel's own index arithmetic"""
+    log_r, npass = radices[i], len(radices)
+    first, last = i == 0, i + 1 == len(radices)
+    log_m = log_n - sum(radices[:i])
+    log_tile = log_n if npass == 1 else max(log_r + 2, NTT_LOG_TILE)
+    log_tile = max(log_tile, log_r)
+    logC = log_tile - log_r
+    C, R, TILE = 1 << logC, 1 << log_r, 1 << log_tile
+    log_s = log_m - log_r
+    S = 1 << log_s
+    in_len = 1 << (log_n if in_log_len is None else in_log_len)
+    k1_major = last and npass >= 2 and radices[0] >= logC
+    n_blocks = 1 << (log_n - log_r)
+    sblk = n_blocks >> radices[0] if npass >= 2 else 1
+    out = [None] * n_out
+    for tile in range(1 << (log_n - log_tile)):
+        def col_base(c):
+            if not last:
+                colid = tile * C + c
+                return ((colid >> log_s) << log_m) + (colid & (S - 1))
+            if k1_major:
+                rest, k10 = tile % sblk, (tile // sblk) * C
+                blk = (k10 + c) * sblk + rest
+            else:
+                blk = tile * C + c
+            return blk << log_r
+        for c in range(C):
+            col = []
+            for i1 in range(R):
+                addr = col_base(c) + (i1 << log_s)
+                col.append(src[addr] if (not first or addr < in_len) else 0)
+            rows = dit_column(col, log_r, table, unit1)
+            for k1 in range(R):
+                x = rows[k1]
+                if not last:
+                    colid = tile * C + c
+                    pos = (k1 << log_s) + (colid & (S - 1))
+                    out[((colid >> log_s) << log_m) + pos] = pack(mont_mul(x, tw_inter[pos]))
+                else:
+                    blk = col_base(c) >> log_r
+                    oidx, rem, lw, shift = 0, blk, log_n - log_r, 0
+                    for p_ in range(npass - 1):
+                        lw -= radices[p_]
+                        kp = rem >> lw
+                        rem &= (1 << lw) - 1
+                        oidx += kp << shift
+                        shift += radices[p_]
+                    oidx += k1 << shift
+                    if post is not None:
+                        y = cond_sub_p(mont_mul(x, limbs29(post * R261 % P)))
+                    else:
+                        y = canonical(x)
+                    out[oidx] = pack(y)
+    assert all(v is not None for v in out)
+    return out
+
+
+def transform(a, log_n, w_n, inverse_scale=False, in_log_len=None):
+    """ntt_run_chunk, coset_mode 0: natural order in and out"""
+    radices = plan_radices(log_n)
+    table = stage_table(max(radices), pow(w_n, 1 << (log_n - max(radices)), P))
+    cur, log_m = list(a), log_n
+    post = pow(1 << log_n, -1, P) if inverse_scale else None
+    for i, lr in enumerate(radices):
+        tw = inter_table(log_n, log_m, lr, w_n) if i + 1 < len(radices) else None
+        cur = run_pass(cur, 1 << log_n, log_n, radices, i, table[:1 << lr], tw, True, in_log_len if i == 0 else None, post)
+        log_m -= lr
+    return cur
+
+
+def coset_transform(a, log_n, log_e, w_ext, zeta):
+    """coset_cm_chunk: coefficients -> E = 2^log_e coset evaluations, coset b at out[b]: p(zeta w_ext^b w_n^j)"""
+    w_n = pow(w_ext, 1 << log_e, P)
+    radices = plan_radices(log_n)
+    plain = stage_table(max(radices), pow(w_n, 1 << (log_n - max(radices)), P))
+    outs = []
+    for b in range(1 << log_e):
+        c_b = zeta * pow(w_ext, b, P) % P
+        cur, log_m = list(a), log_n
+        for i, lr in enumerate(radices):
+            if i == 0:                                   # the twisted first pass: d = c_b^S on the rows, c_b^i2 in the inter-pass table
+                S = 1 << (log_n - lr)
+                table = stage_table(lr, pow(w_n, S, P), pow(c_b, S, P))
+                tw = inter_table(log_n, log_m, lr, w_n, twist=c_b) if len(radices) > 1 else None
+                cur = run_pass(cur, 1 << log_n, log_n, radices, i, table, tw, False)
+            else:
+                tw = inter_table(log_n, log_m, lr, w_n) if i + 1 < len(radices) else None
+                cur = run_pass(cur, 1 << log_n, log_n, radices, i, plain[:1 << lr], tw, True)
+            log_m -= lr
+        outs.append(cur)
+    return outs
+
+
 def selftest(seed=1, log_rs=(1, 2, 3, 5, 6, 8, 11), group=2):
     global GROUP
     GROUP = group
