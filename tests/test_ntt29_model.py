@@ -90,3 +90,23 @@ def test_coset_major_transform_twisted_first_pass():
             for c in reversed(a):
                 want = (want * x + c) % M.P
             assert outs[b][j] == want
+
+
+def test_natural_order_coset_transforms_round_trip():
+    """EvaluationDomain::coeff_to_extended / extended_to_coeff in natural order (ezkl_hip_coset_ntt_*: zeta^(i mod 3) on the way in, zeta^-(i mod 3) / n
+    on the way out, fused into the first / last pass): 2^10 coefficients -> 2^12 evaluations on zeta <w_ext> -> the coefficients again"""
+    rnd = random.Random(14)
+    log_n, log_ext = 10, 12
+    w_ext = pow(GEN, 1 << (28 - log_ext), M.P)
+    zeta = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+    a = [rnd.randrange(M.P) for _ in range(1 << log_n)]
+    padded = a + [rnd.randrange(M.P) for _ in range((1 << log_ext) - (1 << log_n))]        # what lies beyond 2^in_log_len is read as zero
+    ev = M.transform(padded, log_ext, w_ext, in_log_len=log_n, coset_mode=1, zeta=zeta)
+    for j in rnd.sample(range(1 << log_ext), 3):
+        x = zeta * pow(w_ext, j, M.P) % M.P
+        want = 0
+        for c in reversed(a):
+            want = (want * x + c) % M.P
+        assert ev[j] == want
+    back = M.transform(ev, log_ext, pow(w_ext, -1, M.P), coset_mode=2, zeta=zeta)
+    assert back[:1 << log_n] == a and not any(back[1 << log_n:])

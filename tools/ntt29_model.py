@@ -229,8 +229,9 @@ def inter_table(log_n, log_m, log_r, w_n, twist=1, log_e=0, b=0, w_ext=None):
     return out
 
 
-def run_pass(src, n_out, log_n, radices, i, table, tw_inter, unit1, in_log_len=None, post=None):
-    """one launch of ntt_pass_kernel over one column: every tile of the grid, the kernel's own index arithmetic"""
+def run_pass(src, n_out, log_n, radices, i, table, tw_inter, unit1, in_log_len=None, post=None, coset_pre=None):
+    """one launch of ntt_pass_kernel over one column: every tile of the grid, the kernel's own index arithmetic.  post: None, one constant, or
+    three (output i is multiplied by post[i mod 3]); coset_pre: (zeta, zeta^2) -- input i of the first pass is multiplied by zeta^(i mod 3)"""
     log_r, npass = radices[i], len(radices)
     first, last = i == 0, i + 1 == len(radices)
     log_m = log_n - sum(radices[:i])
@@ -260,7 +261,10 @@ def run_pass(src, n_out, log_n, radices, i, table, tw_inter, unit1, in_log_len=N
             col = []
             for i1 in range(R):
                 addr = col_base(c) + (i1 << log_s)
-                col.append(src[addr] if (not first or addr < in_len) else 0)
+                v = src[addr] if (not first or addr < in_len) else 0
+                if first and coset_pre is not None and addr < in_len and addr % 3:
+                    v = value(mont_mul(unpack(v), limbs29(coset_pre[addr % 3 - 1] * R261 % P)))
+                col.append(v)
             rows = dit_column(col, log_r, table, unit1)
             for k1 in range(R):
                 x = rows[k1]
@@ -279,7 +283,8 @@ def run_pass(src, n_out, log_n, radices, i, table, tw_inter, unit1, in_log_len=N
                         shift += radices[p_]
                     oidx += k1 << shift
                     if post is not None:
-                        y = cond_sub_p(mont_mul(x, limbs29(post * R261 % P)))
+                        pc = post[oidx % 3] if isinstance(post, (list, tuple)) else post
+                        y = cond_sub_p(mont_mul(x, limbs29(pc * R261 % P)))
                     else:
                         y = canonical(x)
                     out[oidx] = pack(y)
@@ -287,15 +292,20 @@ def run_pass(src, n_out, log_n, radices, i, table, tw_inter, unit1, in_log_len=N
     return out
 
 
-def transform(a, log_n, w_n, inverse_scale=False, in_log_len=None):
-    """ntt_run_chunk, coset_mode 0: natural order in and out"""
+def transform(a, log_n, w_n, inverse_scale=False, in_log_len=None, coset_mode=0, zeta=None):
+    """ntt_run_chunk: natural order in and out.  coset_mode 1 = coeff_to_extended in natural order (input i times zeta^(i mod 3), zero-padded
+    from 2^in_log_len); 2 = extended_to_coeff (w_n is the inverse root; output i times zeta^-(i mod 3) / n)"""
     radices = plan_radices(log_n)
     table = stage_table(max(radices), pow(w_n, 1 << (log_n - max(radices)), P))
     cur, log_m = list(a), log_n
-    post = pow(1 << log_n, -1, P) if inverse_scale else None
+    post = pow(1 << log_n, -1, P) if (inverse_scale or coset_mode == 2) else None
+    if coset_mode == 2:
+        z2 = zeta * zeta % P                                   # zeta^-1 = zeta^2, zeta^-2 = zeta
+        post = [post, post * z2 % P, post * zeta % P]
+    pre = (zeta, zeta * zeta % P) if coset_mode == 1 else None
     for i, lr in enumerate(radices):
         tw = inter_table(log_n, log_m, lr, w_n) if i + 1 < len(radices) else None
-        cur = run_pass(cur, 1 << log_n, log_n, radices, i, table[:1 << lr], tw, True, in_log_len if i == 0 else None, post)
+        cur = run_pass(cur, 1 << log_n, log_n, radices, i, table[:1 << lr], tw, True, in_log_len if i == 0 else None, post, pre if i == 0 else None)
         log_m -= lr
     return cur
 
