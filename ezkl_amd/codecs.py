@@ -193,6 +193,45 @@ def write_proof_json(proof, instances, pretty_public_inputs=None, timestamp_ms=N
     return json.dumps(j, separators=(",", ":"))
 
 
+def rust_f64_to_string(x):
+    """`f64::to_string()` (Display): shortest digits that round-trip, never an exponent, no trailing ".0" -- what
+    GraphWitness::generate_rescaled_elements prints (src/graph/mod.rs:188, 204)"""
+    x = float(x)
+    if x != x: return "NaN"
+    if x in (float("inf"), float("-inf")): return "inf" if x > 0 else "-inf"
+    r = repr(x)
+    if "e" in r or "E" in r:
+        from decimal import Decimal
+        r = format(Decimal(r), "f")
+    if r.endswith(".0"): r = r[:-2]
+    return "-0" if r == "-0" else r
+
+
+def write_witness_json(inputs, outputs, input_scales, output_scales, processed_inputs=None, processed_params=None, processed_outputs=None,
+                       max_lookup_inputs=0, min_lookup_inputs=0, max_range_size=0, version="source - no compatibility guaranteed"):
+    """`GraphWitness::save` (src/graph/mod.rs:120-141, 174-244, as_json): serde_json, compact, fields in declaration order -- inputs /
+    outputs as 32-byte little-endian hex felts, pretty_elements (dequantized values as Rust prints an f64, felts as `{:?}` = "0x" + 64
+    big-endian hex digits), the processed_* module results ({"poseidon_hash": ..., "polycommit": [[{"x","y"}]]} or null), the lookup
+    statistics, the version string.  inputs / outputs: lists of lists of ints mod r."""
+    from . import ezkl_layout as _EL
+    R_ = _EL.R
+    def signed(v): return v if v < R_ // 2 else v - R_
+    def dbg(v): return "0x%064x" % (v % R_)
+    def resc(cols, scales): return [[rust_f64_to_string(signed(v % R_) / float(2.0 ** scales[i])) for v in col] for i, col in enumerate(cols)]
+    pretty = {"rescaled_inputs": resc(inputs, input_scales),
+              "inputs": [[dbg(v) for v in col] for col in inputs],
+              "processed_inputs": [], "processed_params": [], "processed_outputs": [],
+              "rescaled_outputs": resc(outputs, output_scales),
+              "outputs": [[dbg(v) for v in col] for col in outputs]}
+    j = {"inputs": [[felt_to_hex_le(v % R_) for v in col] for col in inputs],
+         "pretty_elements": pretty,
+         "outputs": [[felt_to_hex_le(v % R_) for v in col] for col in outputs],
+         "processed_inputs": processed_inputs, "processed_params": processed_params, "processed_outputs": processed_outputs,
+         "max_lookup_inputs": max_lookup_inputs, "min_lookup_inputs": min_lookup_inputs, "max_range_size": max_range_size,
+         "version": version}
+    return json.dumps(j, separators=(",", ":"))
+
+
 def read_witness_json(text):
     """GraphWitness (src/graph/mod.rs:120-141, loaded by `prove` at src/execute.rs:1584): inputs / outputs as 32-byte little-endian
     hex felts, the optional processed_* module results, and the lookup statistics -> ints"""

@@ -34,6 +34,7 @@ EZ_D bool g1a29_is_id(const g1a29_t& p) { return Fq29::limbs_zero(p.x) && Fq29::
 // factors already multiplied together
 //   PP = P^2, PPP = P PP, Q = U1 PP, X3 = R^2 - PPP - 2Q, Y3 = R (Q - X3) - S1 PPP, ZZ3 = zz PP, ZZZ3 = zzz PPP
 // bounds: P, R < 20p; U1 < 12p; S1 < 8p; zz, zzz < 4p.
+// S1 < 15p normalized (the accumulator's Y in the mixed addition; a product < 2p in the full one).
 EZ_D g1x29_t g1x29_add_tail(const f29_t& u1, const f29_t& s1, const f29_t& p, const f29_t& r, const f29_t& zz, const f29_t& zzz) {
     // ordered so that every input dies as early as possible (the accumulate kernel lives at 128 VGPRs)
     g1x29_t o;
@@ -42,14 +43,22 @@ EZ_D g1x29_t g1x29_add_tail(const f29_t& u1, const f29_t& s1, const f29_t& p, co
     const f29_t ppp = Fq29::mul(p, pp);                  // < 80/169 + 1  < 2p
     o.zzz = Fq29::mul(zzz, ppp);                         // < 2p
     const f29_t q = Fq29::mul(u1, pp);                   // < 60/169 + 1  < 2p
+#if !EZKL_FUSED_Y
     const f29_t e = Fq29::mul(s1, ppp);                  // < 30/169 + 1  < 2p
+#endif
     const f29_t rr = Fq29::sqr(r);                       // < 324/169 + 1 < 3p
     // X3 = rr + (4p - ppp) + 2 (4p - q) < 3 + 4 + 8 = 15p; limbs < 2^29 + 2^30 + 2^31, normalized right away
     const f29_t nq = Fq29::neg<1>(q);
     o.x = Fq29::normalize(Fq29::add(Fq29::add(rr, Fq29::neg<1>(ppp)), Fq29::add(nq, nq)));
     const f29_t d = Fq29::sub<3>(q, o.x);                // q + 16p - X3 < 18p, loose(3); needs X3 < 15p normalized
+#if EZKL_FUSED_Y
+    // Y3 = r d + (16p - s1) ppp in one reduction: limbs 1 x 3 + 2 x 1 = 5 < 6.1; value < (20*18 + 16*2) / 169 + 1 < 4p, normalized
+    // (tests/test_montmul29_asm.py interprets the generated instructions on these operand shapes)
+    o.y = Fq29::mul2add(r, d, Fq29::neg<3>(s1), ppp);
+#else
     const f29_t rd = Fq29::mul(r, d);                    // normalized x loose(3): < 18*18/169 + 1 < 3p
     o.y = Fq29::normalize(Fq29::sub<1>(rd, e));          // < 3 + 4 = 7p
+#endif
     return o;
 }
 // 2 (x, y) for an affine point != identity (mdbl-2008-s-1)
@@ -159,6 +168,130 @@ EZ_D g1x29_t g1x29_group_sum(g1x29_t acc, uint32_t width) {
     for (uint32_t s = width >> 1; s > 0; s >>= 1) acc = g1x29_add(acc, g1x29_shfl_xor(acc, s));
     return acc;
 }
+
+// ---- the quad-cooperative addition (round 5) ------------------------------------------------------------------------------------------
+// The reduce trees of the MSM are chains of DEPENDENT additions, each 14 products one after the other in one wave (9.3 us per level at one
+// wave per SIMD), and in a butterfly the lanes of the upper levels all hold the same operands anyway.  The 14 products of add-2008-s are
+// four dependency levels of 4, 4, 3, 3:
+//     1: U1 = X1 ZZ2    U2 = X2 ZZ1    S1 = Y1 ZZZ2    S2 = Y2 ZZZ1          -> P = U2 - U1, R = S2 - S1
+//     2: zz = ZZ1 ZZ2   zzz = ZZZ1 ZZZ2  PP = P P      RR = R R
+//     3: ZZ3 = zz PP    PPP = P PP     Q = U1 PP       (idle)                -> X3 = RR - PPP - 2Q
+//     4: (idle)         ZZZ3 = zzz PPP RD = R (Q - X3) E = S1 PPP            -> Y3 = RD - E
+// so the four lanes of a QUAD that hold bitwise the same a and b each run one product per level (lane q = the q-th column above) and pass
+// the results around with DPP quad permutes (a VALU move, no LDS): 4 products + ~260 moves / selects per addition instead of 14 products.
+// Bounds: exactly those of g1x29_add / g1x29_add_tail (same formulas, same operand ranges; the idle lanes multiply normalized values).
+// Special cases (an identity operand, P = 0: doubling or inverse) are decided for the whole WAVE: every lane then runs the plain addition,
+// which keeps the four copies of a quad identical.
+// The empty asm after every move keeps the compiler from FOLDING the move into the arithmetic that uses it: measured on gfx950
+// (ezkl_hip_ubench("coopcheck"), profiles/r05f_coopcheck.log) the folded form `v_subrev_u32_dpp d, m, t quad_perm:[3,3,3,3]` that
+// LLVM's DPP combiner builds for t - bcast<3>(m) returned t - m of the lane ITSELF in every lane (right only in lane 3) -- the plain
+// v_mov_b32_dpp is what every other broadcast of the addition compiled to, and those were all correct.
+template <int S>
+EZ_D f29_t f29_quad_bcast(const f29_t& x) {               // lane S of every quad to its four lanes
+    // a DPP read needs two wait states after the VALU write of its source; the compiler inserts them for code it can see, but the
+    // products are inline asm whose last instructions write the limbs -- the s_nop below sits between any such block and the moves
+    f29_t t = x, r;
+    asm volatile("s_nop 1" : "+v"(t.v[0]), "+v"(t.v[1]), "+v"(t.v[2]), "+v"(t.v[3]), "+v"(t.v[4]), "+v"(t.v[5]), "+v"(t.v[6]), "+v"(t.v[7]), "+v"(t.v[8]));
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)t.v[i], S * 0x55, 0xf, 0xf, true);
+        asm volatile("" : "+v"(r.v[i]));
+    }
+    return r;
+}
+EZ_D f29_t f29_sel(bool c, const f29_t& a, const f29_t& b) {
+    f29_t r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+EZ_D f29_t f29_sel4(uint32_t q, const f29_t& x0, const f29_t& x1, const f29_t& x2, const f29_t& x3) {
+    return f29_sel(q < 2, f29_sel(q == 0, x0, x1), f29_sel(q == 2, x2, x3));
+}
+template <int S>
+EZ_D g1x29_t g1x29_quad_bcast(const g1x29_t& p) {
+    g1x29_t r;
+    r.x = f29_quad_bcast<S>(p.x); r.y = f29_quad_bcast<S>(p.y); r.zz = f29_quad_bcast<S>(p.zz); r.zzz = f29_quad_bcast<S>(p.zzz);
+    return r;
+}
+// a + b where the four lanes of every quad hold bitwise the same a and the same b; so does the result.  `special` (wave-uniform): the
+// operands need the plain addition (an identity, or P = 0) and the returned value is meaningless -- the caller runs g1x29_add.
+EZ_D g1x29_t g1x29_add_quad(const g1x29_t& a, const g1x29_t& b, bool& special, uint32_t* dbg = nullptr) {
+    const uint32_t q = threadIdx.x & 3u;
+    g1x29_t o = a;
+    special = __any(g1x29_is_id(a) || g1x29_is_id(b)) != 0;
+    if (special) return o;
+    // level 1
+    const f29_t m1 = Fq29::mul(f29_sel4(q, a.x, b.x, a.y, b.y), f29_sel4(q, b.zz, a.zz, b.zzz, a.zzz));      // < 48/169 + 1 < 2p
+    const f29_t u1 = f29_quad_bcast<0>(m1), s1 = f29_quad_bcast<2>(m1);
+    const f29_t p = Fq29::normalize(Fq29::sub<1>(f29_quad_bcast<1>(m1), u1));                                // < 6p
+    const f29_t r = Fq29::normalize(Fq29::sub<1>(f29_quad_bcast<3>(m1), s1));                                // < 6p
+    special = __any(Fq29::is_zero_mod_p(p)) != 0;                                  // rare (doubling / inverse)
+    if (special) return o;
+    // level 2: zz (q0), zzz (q1), PP (q2), RR (q3)
+    const f29_t m2 = Fq29::mul(f29_sel4(q, a.zz, a.zzz, p, r), f29_sel4(q, b.zz, b.zzz, p, r));              // < 36/169 + 1 < 2p
+    const f29_t pp = f29_quad_bcast<2>(m2), rr = f29_quad_bcast<3>(m2);
+    // level 3: ZZ3 = zz PP (q0), PPP = P PP (q1), Q = U1 PP (q2), q3 idle (RR PP, unused)
+    const f29_t m3 = Fq29::mul(f29_sel(q == 1, p, f29_sel(q == 2, u1, m2)), pp);                             // < 2p
+    const f29_t ppp = f29_quad_bcast<1>(m3), qq = f29_quad_bcast<2>(m3);
+    const f29_t nq = Fq29::neg<1>(qq);
+    o.x = Fq29::normalize(Fq29::add(Fq29::add(rr, Fq29::neg<1>(ppp)), Fq29::add(nq, nq)));                   // < 2 + 4 + 8 = 14p
+    const f29_t d = Fq29::sub<3>(qq, o.x);                                                                   // < 18p, loose(3)
+    // level 4: q0 idle (zz PPP, unused), ZZZ3 = zzz PPP (q1), RD = R D (q2), E = S1 PPP (q3)
+    const f29_t m4 = Fq29::mul(f29_sel(q == 2, r, f29_sel(q == 3, s1, m2)), f29_sel(q == 2, d, ppp));        // < 6*18/169 + 1 < 2p
+    o.zz = f29_quad_bcast<0>(m3);
+    o.zzz = f29_quad_bcast<1>(m4);
+    o.y = Fq29::normalize(Fq29::sub<1>(f29_quad_bcast<2>(m4), f29_quad_bcast<3>(m4)));                       // < 2 + 4 = 6p
+    if (dbg) {                                   // ezkl_hip_ubench("coopcheck"): every intermediate, 9 limbs each
+        const f29_t* t[14] = {&m1, &u1, &s1, &p, &r, &m2, &pp, &rr, &m3, &ppp, &qq, &o.x, &d, &m4};
+        for (int k = 0; k < 14; k++)
+            for (int i = 0; i < 9; i++) dbg[9 * k + i] = t[k]->v[i];
+    }
+    return o;
+}
+// Butterfly sums with cooperative additions, ONE loop around one copy of the addition (it is ~1300 instructions, its plain fall-back with
+// the doubling ~6000): the group total of `width` lanes (a power of two in 4..64, aligned) in every lane; with BLOCK also across the four
+// waves of a 256-thread workgroup (sh: 9 * 4 uint4, one slot per wave; ends with a workgroup barrier).  Steps: the four DIFFERENT values
+// of a quad are summed by three additions the quad runs together -- (x0 + x1), (x2 + x3), their sum -- then one addition per butterfly
+// level 4, 8, ...; the block form then passes the four wave totals through LDS and sums them the same way (3 + 4 + 3 additions for 256
+// threads instead of 8 plain levels).
+template <bool BLOCK>
+EZ_D g1x29_t g1x29_coop_sum(g1x29_t acc, uint32_t width, uint4* sh) {
+    const uint32_t nlev = (31u - (uint32_t)__clz(width)) - 2u;       // butterfly levels above the quad
+    const uint32_t nsteps = 3u + nlev + (BLOCK ? 3u : 0u);
+    g1x29_t t0 = acc;
+#pragma unroll 1
+    for (uint32_t step = 0; step < nsteps; step++) {
+        uint32_t k = step;
+        if (BLOCK && step == 3u + nlev) {                            // the four wave totals -> one per lane of every quad
+            if ((threadIdx.x & 63) == 0) {
+                const uint32_t* s = acc.x.v;
+#pragma unroll
+                for (int i = 0; i < 9; i++) sh[i * 4 + (threadIdx.x >> 6)] = make_uint4(s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]);
+            }
+            __syncthreads();
+            uint32_t* d = acc.x.v;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const uint4 t = sh[i * 4 + (threadIdx.x & 3)];
+                d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
+            }
+            __syncthreads();
+        }
+        if (BLOCK && step >= 3u + nlev) k = step - (3u + nlev);
+        g1x29_t a, b;
+        if (k == 0) { a = g1x29_quad_bcast<0>(acc); b = g1x29_quad_bcast<1>(acc); }
+        else if (k == 1) { a = g1x29_quad_bcast<2>(acc); b = g1x29_quad_bcast<3>(acc); }
+        else if (k == 2) { a = t0; b = acc; }
+        else { a = acc; b = g1x29_shfl_xor(acc, 4u << (k - 3u)); }
+        bool special;
+        g1x29_t r = g1x29_add_quad(a, b, special);
+        if (special) r = g1x29_add(a, b);                            // wave-uniform
+        if (k == 0) t0 = r; else acc = r;
+    }
+    return acc;
+}
+EZ_D g1x29_t g1x29_group_sum_coop(const g1x29_t& acc, uint32_t width) { return g1x29_coop_sum<false>(acc, width, nullptr); }
 // sum over the 256 threads of a workgroup, valid in every thread; sh: 9 * 4 uint4 (plane layout, one slot per wave)
 EZ_D g1x29_t g1x29_block256_sum(g1x29_t acc, uint4* sh) {
     acc = g1x29_group_sum(acc, 64);
@@ -178,6 +311,33 @@ EZ_D g1x29_t g1x29_block256_sum(g1x29_t acc, uint4* sh) {
     }
     __syncthreads();
     return g1x29_group_sum(acc, 4);
+}
+#ifndef EZKL_COOP_BLOCK
+#define EZKL_COOP_BLOCK 0
+#endif
+EZ_D g1x29_t g1x29_block256_sum_coop(const g1x29_t& acc0, uint4* sh) {
+#if EZKL_COOP_BLOCK
+    return g1x29_coop_sum<true>(acc0, 64, sh);
+#else
+    // in-wave levels cooperative (3 + 4 additions), the four wave totals through LDS, the last two levels as plain butterflies
+    g1x29_t acc = g1x29_coop_sum<false>(acc0, 64, nullptr);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t* s = acc.x.v;
+#pragma unroll
+        for (int k = 0; k < 9; k++) sh[k * 4 + (threadIdx.x >> 6)] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+    }
+    __syncthreads();
+    {
+        uint32_t* d = acc.x.v;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const uint4 t = sh[k * 4 + (threadIdx.x & 3)];
+            d[4 * k] = t.x; d[4 * k + 1] = t.y; d[4 * k + 2] = t.z; d[4 * k + 3] = t.w;
+        }
+    }
+    __syncthreads();
+    return g1x29_group_sum(acc, 4);
+#endif
 }
 
 }  // namespace ezkl

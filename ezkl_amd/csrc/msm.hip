@@ -39,6 +39,15 @@
 
 namespace ezkl {
 
+// EZKL_MSM_PREFETCH=1 (default since round 5): the accumulate loop loads the next bucket end and the next-but-one payload one iteration ahead
+#ifndef EZKL_MSM_PREFETCH
+#define EZKL_MSM_PREFETCH 1
+#endif
+// EZKL_MSM_LEAN=1 (round 5; measured level with the default 0): the chain's three small memsets are done by the histogram kernel (one zeroed region), and the
+// partition scan runs in the LAST workgroup of the histogram scan (a ticket) instead of a launch of its own: 4 stream operations fewer
+#ifndef EZKL_MSM_LEAN
+#define EZKL_MSM_LEAN 0
+#endif
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
 static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workgroup stages in LDS (104 KiB): 1024 scalars x 13 windows
@@ -273,9 +282,13 @@ __device__ __forceinline__ bool msm_digit_step(fe_t& s, uint32_t neg, uint32_t c
 // staging area grouped by partition and writes them out in staged order (runs of one partition leave as whole cache lines).
 __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size_t n, size_t per_block, WinPlan wp,
                                                        uint32_t LB, uint32_t NP, uint32_t* wg_hist, uint32_t* wg_cnt,
-                                                       const fe_t* const* scal_list, size_t bstride) {
+                                                       const fe_t* const* scal_list, uint32_t* zero_base, uint32_t zero_words, size_t bstride) {
     BOFF(); BSH(wg_hist); BSH(wg_cnt);
     if (scal_list) scalars = scal_list[blockIdx.z];
+    if (zero_base) {                                                      // the chain's counters, bin totals and planes start at zero
+        BSH(zero_base);
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < zero_words; i += gridDim.x * 256) zero_base[i] = 0;
+    }
     __shared__ uint32_t lh[(1u << MSM_MAX_PART_BITS) + 1];
     const uint32_t NQ = NP + 1;                                           // + the bucket-0 partition
     for (uint32_t p = threadIdx.x; p < NQ; p += 256) lh[p] = 0;
@@ -308,7 +321,11 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
 // wg_hist[g][p] (G workgroups x NP partitions) -> in place, the exclusive prefix over g of column p; part_count[p] = column
 // total.  One workgroup per 32 columns: thread (c, j) sums the j-th chunk of G/32 rows of column c (a row segment of 32
 // columns is one 128-byte line), the 32 chunk sums of a column are scanned in LDS, then the rows are rewritten.
-__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count, size_t bstride) {
+__device__ __forceinline__ void msm_part_scan_body(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
+                                                   uint32_t* big_list, uint32_t* big_count, uint32_t* sh, bool coherent);
+// ticket != nullptr: the fused form -- the workgroup that finishes last also runs the partition scan (msm_part_scan_body)
+__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count, uint32_t* ticket,
+                                                             uint32_t* part_base, uint32_t* big_flag, uint32_t* big_list, uint32_t* big_count, size_t bstride) {
     BOFF(); BSH(wg_hist); BSH(part_count);
     __shared__ uint32_t sums[32][33];
     const uint32_t c = threadIdx.x & 31, j = threadIdx.x >> 5;
@@ -337,15 +354,25 @@ __global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, 
             run += v;
         }
     }
+    if (!ticket) return;
+    BSH(ticket); BSH(part_base); BSH(big_flag); BSH(big_list); BSH(big_count);
+    __shared__ uint32_t last;
+    __threadfence();                                   // this workgroup's part_count entries are visible device-wide before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    msm_part_scan_body(part_count, NP, part_base, big_flag, big_list, big_count, &sums[0][0], true);     // 32 x 33 words >= 1024
 }
 // exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs.  Also lists the oversized
 // ordinary partitions (big_flag[p] = 1 + slot, big_list[slot] = p, big_count[0] = how many asked for a slot).
-__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
-                                                             uint32_t* big_list, uint32_t* big_count, size_t bstride) {
-    BOFF(); BSH(part_count); BSH(part_base); BSH(big_flag); BSH(big_list); BSH(big_count);
-    __shared__ uint32_t sh[1024];
+__device__ __forceinline__ void msm_part_scan_body(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
+                                                   uint32_t* big_list, uint32_t* big_count, uint32_t* sh, bool coherent) {
     const uint32_t t = threadIdx.x;
-    const uint32_t v0 = 2 * t < NQ ? part_count[2 * t] : 0, v1 = 2 * t + 1 < NQ ? part_count[2 * t + 1] : 0;
+    // coherent: the counts were written by other workgroups of the SAME launch (the fused form): read them past this CU's cache
+    auto ldc = [&](uint32_t i) { return coherent ? __hip_atomic_load(part_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : part_count[i]; };
+    const uint32_t v0 = 2 * t < NQ ? ldc(2 * t) : 0, v1 = 2 * t + 1 < NQ ? ldc(2 * t + 1) : 0;
     sh[t] = v0 + v1;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -369,6 +396,12 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
         }
         big_flag[q - 1] = slot;
     }
+}
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
+                                                             uint32_t* big_list, uint32_t* big_count, size_t bstride) {
+    BOFF(); BSH(part_count); BSH(part_base); BSH(big_flag); BSH(big_list); BSH(big_count);
+    __shared__ uint32_t sh[1024];
+    msm_part_scan_body(part_count, NQ, part_base, big_flag, big_list, big_count, sh, false);
 }
 // One pass, one scalar per thread.  A workgroup first ranks its (up to MSM_PART_STAGE) pairs into LDS grouped by partition
 // (start[p] = exclusive scan of its own histogram row, cursors advanced with LDS atomics), then writes them out in staged order:
@@ -619,6 +652,48 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
         uint32_t mid = (lo + hi) >> 1;
         if (offsets[mid] <= k0) lo = mid; else hi = mid;
     }
+#if EZKL_MSM_PREFETCH
+    uint32_t b = lo, bin_end = offsets[b + 1];
+    // everything the next iteration needs is loaded ONE ITERATION AHEAD: the end of the bucket after this one, the payload of the pair
+    // after next (the address of the next gather) and the next table record -- no load sits on the path of the iteration that uses it
+    uint32_t end_next = offsets[b + 2 <= nb ? b + 2 : nb];
+    lane_first[t] = b;                          // the bucket holding this lane's first pair (msm_fixup_boundary_kernel)
+    bool started_before = offsets[b] < k0;
+    g1x29_t acc = g1x29_identity();
+    MsmRec nxt = msm_fetch(tab, vals[k0]);
+    uint32_t vn = k0 + 1 < k1 ? vals[k0 + 1] : 0u;
+    for (uint32_t k = k0; k < k1; k++) {
+        if (k == bin_end) {                     // bucket b is finished inside this lane
+            if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
+            acc = g1x29_identity();
+            started_before = false;
+            b++;
+            bin_end = end_next;
+            // an empty bucket follows: a few linear probes (the common case), then a binary search -- a sparse column
+            // (e.g. m(X): a handful of blinding rows scattered over 2^19 buckets) must not walk every empty bucket
+            if (bin_end == k) {
+                uint32_t probes = 1;
+                while (bin_end == k && probes < 4) { b++; bin_end = offsets[b + 1]; probes++; }
+                if (bin_end == k) {
+                    uint32_t lo2 = b + 1, hi2 = nb;          // offsets[lo2] == k, offsets[hi2] = total > k
+                    while (hi2 - lo2 > 1) {
+                        uint32_t mid = (lo2 + hi2) >> 1;
+                        if (offsets[mid] <= k) lo2 = mid; else hi2 = mid;
+                    }
+                    b = lo2;
+                    bin_end = offsets[b + 1];
+                }
+            }
+            end_next = offsets[b + 2 <= nb ? b + 2 : nb];
+        }
+        const MsmRec cur = nxt;
+        if (k + 1 < k1) {
+            nxt = msm_fetch(tab, vn);           // its address arrived an iteration ago; the record is used an iteration from now
+            vn = k + 2 < k1 ? vals[k + 2] : 0u;
+        }
+        acc = g1x29_add_mixed(acc, g1a29_unpack(cur.p), cur.neg);
+    }
+#else
     uint32_t b = lo, bin_end = offsets[b + 1];
     lane_first[t] = b;                          // the bucket holding this lane's first pair (msm_fixup_boundary_kernel)
     bool started_before = offsets[b] < k0;
@@ -647,6 +722,7 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
         if (k + 1 < k1) nxt = msm_fetch(tab, vals[k + 1]);   // prefetch: the gather latency hides under the add
         acc = g1x29_add_mixed(acc, g1a29_unpack(cur.p), cur.neg);
     }
+#endif
     if (k1 == bin_end) {
         if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
     } else {
@@ -686,7 +762,7 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
 // Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
 // (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
 __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const uint32_t* lane_first, g1x29_t* head,
-                                                               const uint32_t* chunk_list, const uint32_t* counts, uint32_t lmin, size_t bstride) {
+                                                               const uint32_t* chunk_list, const uint32_t* counts, uint32_t lmin, uint32_t coop, size_t bstride) {
     BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(chunk_list); BSH(counts);
     __shared__ uint4 sh[9 * 4];
     const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes, lmin);
@@ -696,12 +772,12 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* o
         const uint32_t stop = start + MSM_HEAVY_CHUNK - 1 < t2 ? start + MSM_HEAVY_CHUNK - 1 : t2;
         g1x29_t acc = g1x29_identity();
         for (uint32_t t = start + threadIdx.x; t <= stop; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
-        acc = g1x29_block256_sum(acc, sh);                          // ends with a workgroup barrier: every read of head[start..stop] is done
+        acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);   // ends with a workgroup barrier: every read of head[start..stop] is done
         if (threadIdx.x == 0) st_g1x29(head + start, acc);
     }
 }
 __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
-                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets, uint32_t lmin, size_t bstride) {
+                                                               const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets, uint32_t lmin, uint32_t coop, size_t bstride) {
     BOFF(); BSH(offsets); BSH(head); BSH(tail); BSH(heavy_list); BSH(counts); BSH(buckets);
     __shared__ uint4 sh[9 * 4];
     const uint32_t L = msm_lane_len(offsets, nb, nlanes, lmin);
@@ -710,7 +786,7 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* o
         uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
         g1x29_t acc = threadIdx.x == 0 ? ld_g1x29(tail + t1) : g1x29_identity();
         for (uint32_t t = t1 + 1 + threadIdx.x * MSM_HEAVY_CHUNK; t <= t2; t += 256 * MSM_HEAVY_CHUNK) acc = g1x29_add(acc, ld_g1x29(head + t));
-        acc = g1x29_block256_sum(acc, sh);
+        acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);
         if (threadIdx.x == 0) st_g1x29(buckets + b, acc);
     }
 }
@@ -748,7 +824,7 @@ __global__ __launch_bounds__(256, 2) void msm_reduce1_kernel(const g1x29_t* buck
 // (a few serial additions, then a shuffle tree).  The lane counts are chosen by the host so that the launch has at most one
 // wave per SIMD: these chains are latency-bound, and a second wave on a SIMD doubles the latency of both.
 __global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x29_t* partA, const g1x29_t* partT, ReduceGeom g, g1x29_t* SA, g1x29_t* T, uint32_t lanesA,
-                                                         uint32_t lanesT, uint32_t blocksA, size_t bstride) {
+                                                         uint32_t lanesT, uint32_t blocksA, uint32_t coop, size_t bstride) {
     BOFF(); BSH(partA); BSH(partT); BSH(SA); BSH(T);
     const bool isA = blockIdx.x < blocksA;
     const uint32_t lanes = isA ? lanesA : lanesT, per = 64 / lanes;
@@ -759,11 +835,11 @@ __global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x29_t* partA, c
         const g1x29_t* src = (isA ? partA : partT) + (size_t)o * G;
         for (uint32_t i = j; i < G; i += lanes) acc = g1x29_add(acc, ld_g1x29(src + i));
     }
-    acc = g1x29_group_sum(acc, lanes);
+    acc = (coop && lanes >= 4) ? g1x29_group_sum_coop(acc, lanes) : g1x29_group_sum(acc, lanes);   // uniform over the workgroup
     if (j == 0 && o < nout) st_g1x29((isA ? SA : T) + o, acc);
 }
 // one workgroup per plane: planes[0] = TOTAL; planes[1 + ws + j] = sum of the field sums whose digit has bit j
-__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes, size_t bstride) {
+__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes, uint32_t coop, size_t bstride) {
     BOFF(); BSH(SA); BSH(T); BSH(planes);
     __shared__ uint4 sh[9 * 4];
     uint32_t id = blockIdx.x, field = 0, j = 0;      // field 0: TOTAL, 1: A, 2: B, 3: C
@@ -786,7 +862,7 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, cons
         const uint32_t sh_bits = field == 2 ? j : g.wB + j;          // t = (dC << wB) | dB
         for (uint32_t k = threadIdx.x; k < nT / 2; k += 256) acc = g1x29_add(acc, ld_g1x29(T + with_bit(k, sh_bits)));
     }
-    acc = g1x29_block256_sum(acc, sh);
+    acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);
     if (threadIdx.x == 0) {
         const uint32_t ws = field == 1 ? g.wsA : field == 2 ? g.wsB : g.wsC;
         st_g1x29(planes + (field == 0 ? 0u : 1u + ws + j), acc);
@@ -948,6 +1024,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const uint32_t nlanes = cdiv(npairs, L);
     // device-side floor of the lane length (columns with few non-zero digits) and the cut count above which a bucket takes the heavy path
     static const uint32_t lmin = [] { const char* e = getenv("EZKL_MSM_LMIN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_LMIN); }();
+    // cooperative (quad) additions in the latency-bound trees (curve29.hpp: g1x29_add_quad); EZKL_MSM_COOP=0 restores the plain butterflies
+    static const uint32_t coop = [] { const char* e = getenv("EZKL_MSM_COOP"); return (uint32_t)(e ? atoi(e) : 7); }();   // bit 0: reduce2, 1: planes, 2: heavy
     static const uint32_t span_heavy = [] { const char* e = getenv("EZKL_MSM_SPAN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_SPAN_HEAVY); }();
     // ---- field geometry of the reduce phase (positions: pos = (bucket & (NP-1)) << LB | bucket >> PB) ----
     ReduceGeom rg;
@@ -988,16 +1066,19 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     size_t o_ent = carve(npairs * 8), o_vals = carve(npairs * 4), o_offs = carve(((size_t)nb + 1) * 4);
     const uint32_t NQ = NP + 1;                          // + bucket 0's own partition (msm_part_of)
     size_t o_pcnt = carve((NQ + 1) * 4), o_pbase = carve((NQ + 1) * 4), o_wgh = carve((size_t)sgrid * NQ * 4), o_wgc = carve((size_t)sgrid * NQ * 4);
-    size_t o_heavy = carve((size_t)nb * 4), o_hcnt = carve(256), o_chunks = carve(((size_t)nlanes + 1) * 4);
+    size_t o_heavy = carve((size_t)nb * 4), o_chunks = carve(((size_t)nlanes + 1) * 4);
     const size_t nbins = (size_t)1 << LB;
-    size_t o_bflag = carve((size_t)NP * 4), o_blist = carve(MSM_MAX_BIG * 4), o_btot = carve(MSM_MAX_BIG * nbins * 4),
+    // ONE region that starts every chain at zero: the counters (hcnt[0..2], the scan's ticket hcnt[3]), the bin totals of the multi-workgroup
+    // sort, the planes
+    size_t o_hcnt = carve(256), o_btot = carve(MSM_MAX_BIG * nbins * 4), o_planes = carve((size_t)nplanes * sizeof(g1x29_t));
+    const size_t zero_bytes = off - o_hcnt;
+    size_t o_bflag = carve((size_t)NP * 4), o_blist = carve(MSM_MAX_BIG * 4),
            o_boff = carve((size_t)MSM_MAX_BIG * MSM_BIG_BLOCKS * nbins * 4);
     size_t o_lfirst = carve((size_t)nlanes * 4);
     size_t o_bkt = carve((size_t)nb * sizeof(g1x29_t));
     size_t o_head = carve((size_t)nlanes * sizeof(g1x29_t)), o_tail = carve((size_t)nlanes * sizeof(g1x29_t));
     size_t o_partA = carve((size_t)n_partA * sizeof(g1x29_t)), o_partT = carve((size_t)n_partT * sizeof(g1x29_t));
     size_t o_SA = carve((size_t)nA * sizeof(g1x29_t)), o_T = carve((size_t)nT * sizeof(g1x29_t));
-    size_t o_planes = carve((size_t)nplanes * sizeof(g1x29_t));
     const size_t bstride = count > 1 ? off : 0;           // every MSM of the group owns one slab of this layout
     rc = slot_prepare(sl, off * count, count);
     if (rc) return rc;
@@ -1026,15 +1107,18 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
         EZ_HIP(hipEventRecord(m0, st));
     }
-    for (size_t j = 0; j < count; j++) {
-        EZ_HIP(hipMemsetAsync((uint8_t*)hcnt + j * bstride, 0, 12, st));
-        EZ_HIP(hipMemsetAsync((uint8_t*)btot + j * bstride, 0, MSM_MAX_BIG * nbins * 4, st));
-        EZ_HIP(hipMemsetAsync((uint8_t*)planes + j * bstride, 0, (size_t)nplanes * sizeof(g1x29_t), st));
-    }
-    // sort
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, bstride);
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, bstride);
+#if EZKL_MSM_LEAN
+    // sort: the histogram kernel zeroes the region above, the last workgroup of the histogram scan runs the partition scan
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, hcnt,
+                       (uint32_t)(zero_bytes / 4), bstride);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, hcnt + 3, pbase, bflag, blist, bcnt, bstride);
+#else
+    for (size_t j = 0; j < count; j++) EZ_HIP(hipMemsetAsync((uint8_t*)hcnt + j * bstride, 0, zero_bytes, st));
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, (uint32_t*)nullptr,
+                       0u, bstride);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, (uint32_t*)nullptr, pbase, bflag, blist, bcnt, bstride);
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1, 1, Z), dim3(1024), 0, st, pcnt, NQ, pbase, bflag, blist, bcnt, bstride);
+#endif
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid, 1, Z), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
                        LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals, scal_list, bstride);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP, 1, Z), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs, vals, bkt, bstride);
@@ -1054,8 +1138,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
         size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
         unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt, lmin, bstride);
-        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, lmin, bstride);
+        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt, lmin, coop & 4u, bstride);
+        hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, lmin, coop & 4u, bstride);
     }
     // reduce
     {
@@ -1068,10 +1152,23 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
             if (lanesT > 1 && waves(nT, lanesT) >= waves(nA, lanesA)) lanesT >>= 1; else if (lanesA > 1) lanesA >>= 1; else lanesT >>= 1;
         }
         const uint32_t blocksA = waves(nA, lanesA);
-        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT), 1, Z), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA, bstride);
-        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, bstride);
+        hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT), 1, Z), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA, coop & 1u, bstride);
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, coop & 2u, bstride);
     }
     EZ_HIP(hipGetLastError());
+    if (getenv("EZKL_MSM_DEBUG_PLANES")) {           // the planes of the cooperative and of the plain tree, side by side (first MSM of a group)
+        std::vector<uint32_t> pc((size_t)nplanes * 36), pp((size_t)nplanes * 36);
+        EZ_HIP(hipStreamSynchronize(st));
+        EZ_HIP(hipMemcpy(pc.data(), planes, pc.size() * 4, hipMemcpyDeviceToHost));
+        EZ_HIP(hipMemsetAsync(planes, 0, pc.size() * 4, st));
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, 1), dim3(256), 0, st, SA, TT, rg, planes, 0u, (size_t)0);
+        EZ_HIP(hipStreamSynchronize(st));
+        EZ_HIP(hipMemcpy(pp.data(), planes, pp.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < nplanes; k++) {
+            const h64::aff a = h64::to_affine(h64::from_limbs29_point(pc.data() + 36 * k)), b = h64::to_affine(h64::from_limbs29_point(pp.data() + 36 * k));
+            fprintf(stderr, "[msm planes] n=%zu plane %u: %s\n", n, k, memcmp(&a, &b, 64) ? "DIFFERS" : "same");
+        }
+    }
     if (getenv("EZKL_MSM_DEBUG")) {
         uint32_t hc = 0;
         EZ_HIP(hipMemcpyAsync(&hc, hcnt, 4, hipMemcpyDeviceToHost, st));

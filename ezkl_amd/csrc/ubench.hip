@@ -3,6 +3,8 @@
 #include "common.hpp"
 #include "curve.hpp"
 #include "montmul29_gen.hpp"
+#include "curve29.hpp"
+#include "host64.hpp"
 #include <string.h>
 #include <vector>
 #include <stdlib.h>
@@ -410,6 +412,61 @@ __global__ __launch_bounds__(64) void ub_ectree_v_kernel(g1x_t* io, uint32_t lim
     st_g1x(io + i, acc);
 }
 
+
+// ---- diagnostics of the quad-cooperative addition (curve29.hpp), one wave: out[lane] holds
+//   [0..3]   quad_bcast<0..3> of the lane id            [4] special flag of the cooperative addition
+//   [8..43]  a + b by g1x29_add      [44..79] a + b by g1x29_add_quad   (a, b = lanes 0 and 1 of the quad's points, so quad-uniform)
+//   [80..115] plain butterfly sum of the 64 points   [116..151] cooperative butterfly sum
+__global__ __launch_bounds__(64) void ub_coopcheck_kernel(const g1a_t* pts, uint32_t* out) {
+    const uint32_t l = threadIdx.x;
+    uint32_t* o = out + (size_t)l * 160;
+    o[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0x00, 0xf, 0xf, true);
+    o[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0x55, 0xf, 0xf, true);
+    o[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0xaa, 0xf, 0xf, true);
+    o[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)l, 0xff, 0xf, 0xf, true);
+    g1x29_t x = g1x29_add_mixed(g1x29_identity(), g1a29_unpack(ld_g1a(pts + l)), false);
+    x = g1x29_add(x, g1x29_add_mixed(g1x29_identity(), g1a29_unpack(ld_g1a(pts + 64 + l)), false));      // general ZZ
+    const g1x29_t a = g1x29_quad_bcast<0>(x), b = g1x29_quad_bcast<1>(x);
+    const g1x29_t plain = g1x29_add(a, b);
+    bool special;
+    const g1x29_t coop = g1x29_add_quad(a, b, special, out + 64 * 160 + (size_t)l * 128);
+    o[4] = special ? 1u : 0u;
+    {   // experiment: the broadcast-then-subtract of Y3, three ways, on a per-lane value v = limbs of (lane-dependent) x
+        const f29_t v = x.y;                                             // differs per lane
+        const f29_t b2 = f29_quad_bcast<2>(v), b3 = f29_quad_bcast<3>(v);
+        const f29_t y1 = Fq29::sub<1>(b2, b3);                           // DPP combined into the subtraction by the compiler
+        f29_t c2 = b2, c3 = b3;
+        for (int i = 0; i < 9; i++) { asm volatile("" : "+v"(c2.v[i])); asm volatile("" : "+v"(c3.v[i])); }     // moves kept apart
+        const f29_t y2 = Fq29::sub<1>(c2, c3);
+        f29_t s2, s3;
+        for (int i = 0; i < 9; i++) { s2.v[i] = __shfl(v.v[i], (l & ~3u) | 2u); s3.v[i] = __shfl(v.v[i], (l & ~3u) | 3u); }
+        const f29_t y3 = Fq29::sub<1>(s2, s3);
+        uint32_t* e = out + 64 * 360 + (size_t)l * 36;
+        for (int i = 0; i < 9; i++) { e[i] = y1.v[i]; e[9 + i] = y2.v[i]; e[18 + i] = y3.v[i]; e[27 + i] = v.v[i]; }
+    }
+    for (int i = 0; i < 36; i++) { out[64 * 160 + 64 * 128 + (size_t)l * 72 + i] = a.x.v[i]; out[64 * 160 + 64 * 128 + (size_t)l * 72 + 36 + i] = b.x.v[i]; }
+    for (int i = 0; i < 36; i++) { o[8 + i] = plain.x.v[i]; o[44 + i] = coop.x.v[i]; }
+    const g1x29_t s0 = g1x29_group_sum(x, 64), s1 = g1x29_group_sum_coop(x, 64);
+    for (int i = 0; i < 36; i++) { o[80 + i] = s0.x.v[i]; o[116 + i] = s1.x.v[i]; }
+}
+
+// widths 32 / 8 / 4 and the 256-thread block form: out[t] = 6 points of 36 words (plain, cooperative) x (32, 8, block)
+__global__ __launch_bounds__(256) void ub_coopcheck2_kernel(const g1a_t* pts, uint32_t* out, int with_identities) {
+    __shared__ uint4 sh[9 * 4];
+    const uint32_t t = threadIdx.x;
+    g1x29_t x = g1x29_add_mixed(g1x29_identity(), g1a29_unpack(ld_g1a(pts + t)), false);
+    x = g1x29_add(x, g1x29_add_mixed(g1x29_identity(), g1a29_unpack(ld_g1a(pts + 256 + t)), false));
+    if (with_identities && (t % 5 == 1 || (t >= 64 && t < 72))) x = g1x29_identity();
+    uint32_t* o = out + (size_t)t * 216;
+    const g1x29_t a0 = g1x29_group_sum(x, 32), a1 = g1x29_group_sum_coop(x, 32);
+    const g1x29_t b0 = g1x29_group_sum(x, 8), b1 = g1x29_group_sum_coop(x, 8);
+    if (t < 36) sh[t] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const g1x29_t c1 = g1x29_block256_sum_coop(x, sh);      // first, on cleared LDS: nothing left over from the plain form can help it
+    const g1x29_t c0 = g1x29_block256_sum(x, sh);
+    for (int i = 0; i < 36; i++) { o[i] = a0.x.v[i]; o[36 + i] = a1.x.v[i]; o[72 + i] = b0.x.v[i]; o[108 + i] = b1.x.v[i]; o[144 + i] = c0.x.v[i]; o[180 + i] = c1.x.v[i]; }
+}
+
 int ubench(Ctx* c, const char* which, double* out) {
     hipStream_t st = c->stream;
     hipEvent_t e0, e1;
@@ -581,6 +638,122 @@ int ubench(Ctx* c, const char* which, double* out) {
         }
         EZ_HIP(hipFree(buf));
         *out = ms * 1e3;
+        return EZKL_OK;
+    }
+    if (!strcmp(which, "coopcheck")) {          // result: a bit mask of what failed (0 = all good); details on stderr
+        const Bases* dummy = nullptr; (void)dummy;
+        g1a_t* pts = nullptr;
+        uint32_t* o = nullptr;
+        EZ_HIP(hipMalloc(&pts, 512 * sizeof(g1a_t)));
+        EZ_HIP(hipMalloc(&o, 64 * (160 + 128 + 72 + 36) * 4));
+        EZ_HIP(hipMemsetAsync(o, 0, 64 * (160 + 128 + 72 + 36) * 4, st));
+        {   // 128 points k G in the table's form (canonical x 2^261, y 2^261): built on the host
+            std::vector<g1a_t> h(512);
+            h64::aff g;
+            memset(&g, 0, sizeof g);
+            h64::fe one; { uint32_t w[8]; for (int q = 0; q < 8; q++) w[q] = Fq::one().v[q]; one = h64::from32(w); }
+            g.x = one; g.y = h64::add(one, one);
+            h64::xyzz acc = h64::from_affine(g), G = acc;
+            h64::fe k261; { uint32_t w[8]; for (int q = 0; q < 8; q++) w[q] = Fq29C::R261_32[q]; k261 = h64::from32(w); }   // canonical 2^261 mod p
+            for (int i = 0; i < 512; i++) {
+                h64::aff a = h64::to_affine(acc);                    // Montgomery (2^256) form of the affine coordinates
+                // table form = canonical value of x * 2^261: mont_mul(x_mont, k261_canonical) = x * 2^261 mod p as a canonical integer
+                h64::fe tx = h64::mul(a.x, k261), ty = h64::mul(a.y, k261);
+                memcpy(&h[i].x, &tx, 32); memcpy(&h[i].y, &ty, 32);
+                acc = h64::add(acc, G);
+                acc = h64::add(acc, G);                              // odd multiples apart so that no two inputs coincide
+                acc = h64::add(acc, G);
+            }
+            EZ_HIP(hipMemcpy(pts, h.data(), 512 * sizeof(g1a_t), hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(ub_coopcheck_kernel, dim3(1), dim3(64), 0, st, pts, o);
+        EZ_HIP(hipStreamSynchronize(st));
+        std::vector<uint32_t> h(64 * (160 + 128 + 72 + 36));
+        EZ_HIP(hipMemcpy(h.data(), o, h.size() * 4, hipMemcpyDeviceToHost));
+        uint32_t mask = 0;
+        {
+            uint32_t* o2 = nullptr;
+            EZ_HIP(hipMalloc(&o2, 256 * 216 * 4));
+            std::vector<uint32_t> h2(256 * 216);
+            for (int ident = 0; ident < 2; ident++) {
+                hipLaunchKernelGGL(ub_coopcheck2_kernel, dim3(1), dim3(256), 0, st, pts, o2, ident);
+                EZ_HIP(hipStreamSynchronize(st));
+                EZ_HIP(hipMemcpy(h2.data(), o2, h2.size() * 4, hipMemcpyDeviceToHost));
+                int bad[3] = {0, 0, 0};
+                for (uint32_t t = 0; t < 256; t++)
+                    for (int f = 0; f < 3; f++) {
+                        const h64::aff p0 = h64::to_affine(h64::from_limbs29_point(h2.data() + (size_t)t * 216 + 72 * f));
+                        const h64::aff p1 = h64::to_affine(h64::from_limbs29_point(h2.data() + (size_t)t * 216 + 72 * f + 36));
+                        if (memcmp(&p0, &p1, 64)) { if (!bad[f]) fprintf(stderr, "[coopcheck] identities=%d form %d (0: width 32, 1: width 8, 2: block): thread %u differs\n", ident, f, t); bad[f]++; }
+                    }
+                fprintf(stderr, "[coopcheck] identities=%d: width 32: %d bad, width 8: %d bad, block of 256: %d bad\n", ident, bad[0], bad[1], bad[2]);
+                if (bad[0] || bad[1] || bad[2]) mask |= 16u << ident;
+            }
+            EZ_HIP(hipFree(o2));
+        }
+        EZ_HIP(hipFree(pts)); EZ_HIP(hipFree(o));
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t* r = h.data() + (size_t)l * 160;
+            for (uint32_t sidx = 0; sidx < 4; sidx++)
+                if (r[sidx] != (l & ~3u) + sidx) { if (!(mask & 1)) fprintf(stderr, "[coopcheck] bcast<%u> lane %u got %u\n", sidx, l, r[sidx]); mask |= 1; }
+            if (r[4]) { if (!(mask & 2)) fprintf(stderr, "[coopcheck] lane %u: special flag set\n", l); mask |= 2; }
+            const h64::aff p0 = h64::to_affine(h64::from_limbs29_point(r + 8)), p1 = h64::to_affine(h64::from_limbs29_point(r + 44));
+            if (memcmp(&p0, &p1, 64)) {
+                if (!(mask & 4)) {
+                    fprintf(stderr, "[coopcheck] lane %u: add_quad != add (x %s, y %s)\n", l, memcmp(&p0.x, &p1.x, 32) ? "differs" : "same", memcmp(&p0.y, &p1.y, 32) ? "differs" : "same");
+                    for (int q = 0; q < 4; q++) {
+                        const h64::fe c0 = h64::from_limbs29(r + 8 + 9 * q), c1 = h64::from_limbs29(r + 44 + 9 * q);
+                        fprintf(stderr, "[coopcheck]   coordinate %d: %s\n", q, memcmp(&c0, &c1, 32) ? "differs" : "same residue");
+                    }
+                }
+                mask |= 4;
+            }
+            const h64::aff t0 = h64::to_affine(h64::from_limbs29_point(r + 80)), t1 = h64::to_affine(h64::from_limbs29_point(r + 116));
+            if (memcmp(&t0, &t1, 64)) { if (!(mask & 8)) fprintf(stderr, "[coopcheck] lane %u: cooperative butterfly sum != plain\n", l); mask |= 8; }
+        }
+        {   // the broadcast-subtract experiment: which forms agree with the host
+            int bad[3] = {0, 0, 0};
+            static const uint32_t SUBC1[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu, 0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t* e = h.data() + 64 * 360 + (size_t)l * 36;
+                const uint32_t* v2 = h.data() + 64 * 360 + (size_t)((l & ~3u) | 2u) * 36 + 27;
+                const uint32_t* v3 = h.data() + 64 * 360 + (size_t)((l & ~3u) | 3u) * 36 + 27;
+                for (int f = 0; f < 3; f++)
+                    for (int i = 0; i < 9; i++)
+                        if (e[9 * f + i] != v2[i] + (SUBC1[i] - v3[i])) { if (!bad[f]) fprintf(stderr, "[coopcheck] form %d lane %u limb %d: got %08x want %08x\n", f, l, i, e[9 * f + i], v2[i] + (SUBC1[i] - v3[i])); bad[f]++; }
+            }
+            fprintf(stderr, "[coopcheck] broadcast-subtract: combined %d bad, kept apart %d bad, shfl %d bad\n", bad[0], bad[1], bad[2]);
+        }
+        if (mask & 4) {
+            const uint32_t* r0 = h.data();
+            fprintf(stderr, "[coopcheck] plain.y:"); for (int i = 0; i < 9; i++) fprintf(stderr, " %08x", r0[8 + 9 + i]); fprintf(stderr, "\n");
+            fprintf(stderr, "[coopcheck] coop.y: "); for (int i = 0; i < 9; i++) fprintf(stderr, " %08x", r0[44 + 9 + i]); fprintf(stderr, "\n");
+            for (uint32_t q = 0; q < 4; q++) { fprintf(stderr, "[coopcheck] lane %u coop.y:", q); for (int i = 0; i < 9; i++) fprintf(stderr, " %08x", h[(size_t)q * 160 + 44 + 9 + i]); fprintf(stderr, "\n"); }
+            for (int k = 0; k < 14; k++) for (uint32_t q = 0; q < 4; q++) { fprintf(stderr, "[coopcheck] t%d[q%u]: ", k, q); for (int i = 0; i < 9; i++) fprintf(stderr, " %08x", h[64 * 160 + q * 128 + 9 * k + i]); fprintf(stderr, "\n"); }
+            for (uint32_t q = 0; q < 4; q++) { fprintf(stderr, "[coopcheck] m4[q%u]: ", q); for (int i = 0; i < 9; i++) fprintf(stderr, " %08x", h[64 * 160 + q * 128 + 9 * 13 + i]); fprintf(stderr, "\n"); }
+        }
+        if (mask & 4) {      // replay the levels of the first quad on the host and name the first intermediate that is wrong
+            static const char* names[14] = {"m1", "u1", "s1", "p", "r", "m2", "pp", "rr", "m3", "ppp", "qq", "x3", "d", "m4"};
+            const uint32_t* ab = h.data() + 64 * 160 + 64 * 128;
+            const h64::xyzz A = h64::from_limbs29_point(ab), Bp = h64::from_limbs29_point(ab + 36);
+            const h64::fe U1 = h64::mul(A.x, Bp.zz), U2 = h64::mul(Bp.x, A.zz), S1 = h64::mul(A.y, Bp.zzz), S2 = h64::mul(Bp.y, A.zzz);
+            const h64::fe P = h64::sub(U2, U1), Rr = h64::sub(S2, S1), PP = h64::sqr(P), RR = h64::sqr(Rr), ZZ = h64::mul(A.zz, Bp.zz), ZZZ = h64::mul(A.zzz, Bp.zzz);
+            const h64::fe PPP = h64::mul(P, PP), Q = h64::mul(U1, PP), X3 = h64::sub(h64::sub(RR, PPP), h64::dbl(Q)), D = h64::sub(Q, X3);
+            const h64::fe ZZ3 = h64::mul(ZZ, PP), ZZZ3 = h64::mul(ZZZ, PPP), RD = h64::mul(Rr, D), E = h64::mul(S1, PPP);
+            // expected value of intermediate k in lane q (nullptr: an idle lane, anything goes)
+            for (uint32_t q = 0; q < 4; q++) {
+                const uint32_t* dq = h.data() + 64 * 160 + (size_t)q * 128;
+                const h64::fe m1e[4] = {U1, U2, S1, S2}, m2e[4] = {ZZ, ZZZ, PP, RR}, m3e[4] = {ZZ3, PPP, Q, Q}, m4e[4] = {ZZZ3, ZZZ3, RD, E};
+                const h64::fe* want[14] = {&m1e[q], &U1, &S1, &P, &Rr, &m2e[q], &PP, &RR, q == 3 ? nullptr : &m3e[q], &PPP, &Q, &X3, &D, q == 0 ? nullptr : &m4e[q]};
+                for (int k = 0; k < 14; k++) {
+                    if (!want[k]) continue;
+                    const h64::fe got = h64::from_limbs29(dq + 9 * k);
+                    if (memcmp(&got, want[k], 32)) fprintf(stderr, "[coopcheck] lane %u: %s is wrong (limbs %08x %08x .. %08x)\n", q, names[k], dq[9 * k], dq[9 * k + 1], dq[9 * k + 8]);
+                }
+            }
+        }
+        fprintf(stderr, "[coopcheck] mask %u\n", mask);
+        *out = (double)mask;
         return EZKL_OK;
     }
     if (!strcmp(which, "gather64")) {

@@ -113,6 +113,53 @@ def gen(name, mod, square=False, ilp2=False):
     return "\n".join(o) + "\n"
 
 
+def gen_mul2(name, mod):
+    """r = (a b + c d) / 2^261 mod p with ONE reduction: column k sums a_i b_(k-i) + c_i d_(k-i) before the m p terms, 243 mads instead of
+    2 x 162 (and no subtraction / carry pass between two products).  Limb bound: 9 (A B + C D) 2^58 + 9 2^58 + carry < 2^64, i.e.
+    A B + C D < 6.1 in units of 2^29 per limb; value bound (alpha beta + gamma delta) / 169 + 1."""
+    p = [(mod >> (29 * i)) & MASK for i in range(9)]
+    pinv = (-pow(mod, -1, 1 << 29)) % (1 << 29)
+    A0, A1 = 16, 17
+    M = ["%%[r%d]" % i for i in range(9)]
+    SP = [16 + i for i in range(9)]
+    SINV, SMASK = 25, 26
+    L = []
+    for i in range(9):
+        L.append("s_mov_b32 s%d, 0x%08x" % (SP[i], p[i]))
+    L.append("s_mov_b32 s%d, 0x%08x" % (SINV, pinv))
+    L.append("s_mov_b32 s%d, 0x%08x" % (SMASK, MASK))
+    first = [True]
+
+    def mac(s0, s1):
+        src2 = "0" if first[0] else "v[%d:%d]" % (A0, A1)
+        first[0] = False
+        L.append("v_mad_u64_u32 v[%d:%d], vcc, %s, %s, %s" % (A0, A1, s0, s1, src2))
+
+    for k in range(17):
+        for i in range(max(0, k - 8), min(k, 8) + 1):
+            mac("%%[a%d]" % i, "%%[b%d]" % (k - i))
+            mac("%%[c%d]" % i, "%%[d%d]" % (k - i))
+        for i in (range(0, k) if k < 9 else range(k - 8, 9)):
+            mac(M[i], "s%d" % SP[k - i])
+        if k < 9:
+            L.append("v_mul_lo_u32 %s, v%d, s%d" % (M[k], A0, SINV))
+            L.append("v_and_b32 %s, s%d, %s" % (M[k], SMASK, M[k]))
+            mac(M[k], "s%d" % SP[0])
+        else:
+            L.append("v_and_b32 %%[r%d], s%d, v%d" % (k - 9, SMASK, A0))
+        L.append("v_lshrrev_b64 v[%d:%d], 29, v[%d:%d]" % (A0, A1, A0, A1))
+    L.append("v_mov_b32 %%[r8], v%d" % A0)
+    o = ["// %s: r = (a * b + c * d) / 2^261 mod p, limbs of 29 bits, one reduction; v16, v17 and s16..s26 clobbered" % name,
+         "__device__ __forceinline__ void %s(const uint32_t (&a)[9], const uint32_t (&b)[9], const uint32_t (&c)[9], const uint32_t (&d)[9], uint32_t (&r)[9]) {" % name]
+    body = "\n        ".join('"%s\\n\\t"' % l for l in L)
+    o.append("    asm(" + body)
+    o.append("        : " + ", ".join('[r%d] "=&v"(r[%d])' % (i, i) for i in range(9)))
+    o.append("        : " + ", ".join('[%s%d] "v"(%s[%d])' % (n, i, n, i) for n in "abcd" for i in range(9)))
+    o.append('        : "v16", "v17", ' + ", ".join('"s%d"' % s for s in range(16, 27)) + ', "vcc");')
+    o.append("}")
+    return "\n".join(o) + "\n"
+
+
 def consts(tag, mod):
     """limb tables for the lazy radix-2^29 arithmetic of field29.hpp"""
     def limbs29(x, n=9):
@@ -149,7 +196,7 @@ def consts(tag, mod):
 
 hdr = "// GENERATED by tools/gen_montmul29.py -- do not edit\n#pragma once\n#ifndef __HIPCC_RTC__            // hiprtc (the eval_h JIT) supplies the fixed-width types itself\n#include <stdint.h>\n#endif\nnamespace ezkl {\n"
 text = (hdr + consts("Fq", FQ) + consts("Fr", FR) + gen("mont_mul29_fq", FQ) + gen("mont_mul29_fr", FR) + gen("mont_sqr29_fq", FQ, True) + gen("mont_sqr29_fr", FR, True) +
-        gen("mont_mul29i_fq", FQ, ilp2=True) + gen("mont_sqr29i_fq", FQ, True, ilp2=True) + gen("mont_mul29i_fr", FR, ilp2=True) + "}  // namespace ezkl\n")
+        gen_mul2("mont_mul2add29_fq", FQ) + gen("mont_mul29i_fq", FQ, ilp2=True) + gen("mont_sqr29i_fq", FQ, True, ilp2=True) + gen("mont_mul29i_fr", FR, ilp2=True) + "}  // namespace ezkl\n")
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ezkl_amd", "csrc", "montmul29_gen.hpp")
 open(path, "w").write(text)
 print("wrote", path, len(text.splitlines()), "lines")
