@@ -250,35 +250,14 @@ EZ_D g1x29_t g1x29_add_quad(const g1x29_t& a, const g1x29_t& b, bool& special, u
     return o;
 }
 // Butterfly sums with cooperative additions, ONE loop around one copy of the addition (it is ~1300 instructions, its plain fall-back with
-// the doubling ~6000): the group total of `width` lanes (a power of two in 4..64, aligned) in every lane; with BLOCK also across the four
-// waves of a 256-thread workgroup (sh: 9 * 4 uint4, one slot per wave; ends with a workgroup barrier).  Steps: the four DIFFERENT values
-// of a quad are summed by three additions the quad runs together -- (x0 + x1), (x2 + x3), their sum -- then one addition per butterfly
-// level 4, 8, ...; the block form then passes the four wave totals through LDS and sums them the same way (3 + 4 + 3 additions for 256
-// threads instead of 8 plain levels).
-template <bool BLOCK>
-EZ_D g1x29_t g1x29_coop_sum(g1x29_t acc, uint32_t width, uint4* sh) {
-    const uint32_t nlev = (31u - (uint32_t)__clz(width)) - 2u;       // butterfly levels above the quad
-    const uint32_t nsteps = 3u + nlev + (BLOCK ? 3u : 0u);
+// the doubling ~6000): the group total of `width` lanes (a power of two in 4..64, aligned) in every lane.  Steps: the four DIFFERENT
+// values of a quad are summed by three additions the quad runs together -- (x0 + x1), (x2 + x3), their sum -- then one addition per
+// butterfly level 4, 8, ....  Measured in the MSM's reduce2 (1 plain + 7 cooperative levels): 73 -> 50 us (profiles/r05n_*).
+EZ_D g1x29_t g1x29_group_sum_coop(g1x29_t acc, uint32_t width) {
+    const uint32_t nsteps = 3u + (31u - (uint32_t)__clz(width)) - 2u;      // 3 inside the quad + the butterfly levels above it
     g1x29_t t0 = acc;
 #pragma unroll 1
-    for (uint32_t step = 0; step < nsteps; step++) {
-        uint32_t k = step;
-        if (BLOCK && step == 3u + nlev) {                            // the four wave totals -> one per lane of every quad
-            if ((threadIdx.x & 63) == 0) {
-                const uint32_t* s = acc.x.v;
-#pragma unroll
-                for (int i = 0; i < 9; i++) sh[i * 4 + (threadIdx.x >> 6)] = make_uint4(s[4 * i], s[4 * i + 1], s[4 * i + 2], s[4 * i + 3]);
-            }
-            __syncthreads();
-            uint32_t* d = acc.x.v;
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const uint4 t = sh[i * 4 + (threadIdx.x & 3)];
-                d[4 * i] = t.x; d[4 * i + 1] = t.y; d[4 * i + 2] = t.z; d[4 * i + 3] = t.w;
-            }
-            __syncthreads();
-        }
-        if (BLOCK && step >= 3u + nlev) k = step - (3u + nlev);
+    for (uint32_t k = 0; k < nsteps; k++) {
         g1x29_t a, b;
         if (k == 0) { a = g1x29_quad_bcast<0>(acc); b = g1x29_quad_bcast<1>(acc); }
         else if (k == 1) { a = g1x29_quad_bcast<2>(acc); b = g1x29_quad_bcast<3>(acc); }
@@ -291,7 +270,6 @@ EZ_D g1x29_t g1x29_coop_sum(g1x29_t acc, uint32_t width, uint4* sh) {
     }
     return acc;
 }
-EZ_D g1x29_t g1x29_group_sum_coop(const g1x29_t& acc, uint32_t width) { return g1x29_coop_sum<false>(acc, width, nullptr); }
 // sum over the 256 threads of a workgroup, valid in every thread; sh: 9 * 4 uint4 (plane layout, one slot per wave)
 EZ_D g1x29_t g1x29_block256_sum(g1x29_t acc, uint4* sh) {
     acc = g1x29_group_sum(acc, 64);
@@ -312,15 +290,12 @@ EZ_D g1x29_t g1x29_block256_sum(g1x29_t acc, uint4* sh) {
     __syncthreads();
     return g1x29_group_sum(acc, 4);
 }
-#ifndef EZKL_COOP_BLOCK
-#define EZKL_COOP_BLOCK 0
-#endif
+// block256_sum with the in-wave levels cooperative (3 + 4 additions instead of 6 plain levels); the four wave totals go through LDS and
+// the last two levels are plain butterflies.  (A fully cooperative form -- the wave totals summed by another quad_sum4 inside the same
+// loop -- was built and is exact in a stand-alone kernel, but produced wrong plane sums inside msm_planes_kernel / msm_fixup_heavy*
+// (every plane, ezkl_hip_ubench("coopcheck") + EZKL_MSM_DEBUG_PLANES, round 5); it would save ~8 us per MSM and was dropped.)
 EZ_D g1x29_t g1x29_block256_sum_coop(const g1x29_t& acc0, uint4* sh) {
-#if EZKL_COOP_BLOCK
-    return g1x29_coop_sum<true>(acc0, 64, sh);
-#else
-    // in-wave levels cooperative (3 + 4 additions), the four wave totals through LDS, the last two levels as plain butterflies
-    g1x29_t acc = g1x29_coop_sum<false>(acc0, 64, nullptr);
+    g1x29_t acc = g1x29_group_sum_coop(acc0, 64);
     if ((threadIdx.x & 63) == 0) {
         const uint32_t* s = acc.x.v;
 #pragma unroll
@@ -337,7 +312,6 @@ EZ_D g1x29_t g1x29_block256_sum_coop(const g1x29_t& acc0, uint4* sh) {
     }
     __syncthreads();
     return g1x29_group_sum(acc, 4);
-#endif
 }
 
 }  // namespace ezkl

@@ -409,3 +409,12 @@ def test_permutation_sigma_column(hip, k, m):
             assert fe_to_int(got[r]) == want
     with pytest.raises(Exception):
         B.permutation_sigma_dev(d_n.ptr, d_w.ptr, d_d.ptr, 0, k, out.ptr)
+
+
+def test_quad_cooperative_addition_on_the_device(hip):
+    """ezkl_hip_ubench("coopcheck") (csrc/ubench.hip): the quad-cooperative XYZZ addition of the MSM's reduce trees (curve29.hpp:
+    g1x29_add_quad) against the plain addition on the device, every intermediate of one quad replayed on the host -- DPP broadcasts,
+    one addition, the butterfly sums of 64 / 32 / 8 lanes and of a 256-thread workgroup, with and without identity operands.
+    0 = everything agreed; the bits name what did not (details on stderr)."""
+    from ezkl_amd import backend as B
+    assert B.ubench("coopcheck") == 0.0
