@@ -110,7 +110,7 @@ static inline fe mul(const fe& a, const fe& b) {
     return r;
 }
 static inline fe sqr(const fe& a) { return mul(a, a); }
-static inline fe inv(const fe& a) {     // a^(q-2)
+static inline fe inv_pow(const fe& a) {     // a^(q-2): 256 squarings + ~127 products, ~13 us (kept as the reference of tests/test_host64.py)
     fe e = Q, two = {{2, 0, 0, 0}};
     sub4(e, e, two);
     fe acc = ONE, base = a;
@@ -119,6 +119,35 @@ static inline fe inv(const fe& a) {     // a^(q-2)
         base = sqr(base);
     }
     return acc;
+}
+static inline fe r_cubed() {                 // R^3 mod q: R^2 by 256 modular doublings of R, then one Montgomery product
+    fe r2 = ONE;
+    for (int i = 0; i < 256; i++) r2 = dbl(r2);
+    return mul(r2, r2);
+}
+static const fe R3 = r_cubed();
+// a^-1 (Montgomery form in and out) by the binary extended Euclid on the integers: for A = a R it finds A^-1 = a^-1 R^-1, and one
+// Montgomery product with R^3 turns that into a^-1 R.  ~4 us instead of the 13 us of the exponentiation: every synchronous MSM ends
+// with one inversion on the host (to_affine), 1 % of a 2^20-point call.
+static inline fe inv(const fe& a) {
+    if (is_zero(a)) return a;
+    fe u = a, v = Q, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+    auto is_one = [](const fe& t) { return t.v[0] == 1 && (t.v[1] | t.v[2] | t.v[3]) == 0; };
+    auto shr1 = [](fe& t) {
+        t.v[0] = (t.v[0] >> 1) | (t.v[1] << 63); t.v[1] = (t.v[1] >> 1) | (t.v[2] << 63);
+        t.v[2] = (t.v[2] >> 1) | (t.v[3] << 63); t.v[3] >>= 1;
+    };
+    auto half = [&](fe& x) {                 // x / 2 mod q for x < q (x + q < 2^255: no carry out)
+        if (x.v[0] & 1) add4(x, x, Q);
+        shr1(x);
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u.v[0] & 1)) { shr1(u); half(x1); }
+        while (!(v.v[0] & 1)) { shr1(v); half(x2); }
+        if (geq(u, v)) { sub4(u, u, v); x1 = sub(x1, x2); }
+        else { sub4(v, v, u); x2 = sub(x2, x1); }
+    }
+    return mul(is_one(u) ? x1 : x2, R3);
 }
 
 static inline bool is_id(const xyzz& p) { return is_zero(p.zz); }

@@ -32,6 +32,7 @@
 #include "common.hpp"
 #include <deque>
 #include <thread>
+#include <chrono>
 #include "curve.hpp"
 #include "curve29.hpp"
 #include "host64.hpp"
@@ -662,6 +663,9 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
     g1x29_t acc = g1x29_identity();
     MsmRec nxt = msm_fetch(tab, vals[k0]);
     uint32_t vn = k0 + 1 < k1 ? vals[k0 + 1] : 0u;
+    // (round 5, measured and dropped: two pairs per loop iteration with the roles of the two record registers swapped -- 41 register
+    //  copies fewer per pair, but the 5.7 k-instruction body ran 2-10 % SLOWER (instruction cache); a "predicated" mixed addition that
+    //  computes the common path for every lane and overwrites the rare cases: slower as well.  profiles/r05q_msm_ab.log)
     for (uint32_t k = k0; k < k1; k++) {
         if (k == bin_end) {                     // bucket b is finished inside this lane
             if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
@@ -1235,8 +1239,27 @@ int msm_run(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, const fe
     if (rc) return rc;
     MsmSlot& sl = g_slots[0];
     if (sl.busy) return EZKL_ERR_INVALID;
+    static const bool host_timing = getenv("EZKL_MSM_HOST_TIMING") != nullptr;      // where a synchronous call spends its host time
+    if (!host_timing) {
+        if ((rc = msm_enqueue(c, sl, st, T, base_offset, &scalars, 1, n, true))) return rc;
+        return msm_finish(sl, out_host);
+    }
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    static double acc[3] = {0, 0, 0};
+    static int calls = 0;
+    const double t0 = now();
     if ((rc = msm_enqueue(c, sl, st, T, base_offset, &scalars, 1, n, true))) return rc;
-    return msm_finish(sl, out_host);
+    const double t1 = now();
+    EZ_HIP(hipEventSynchronize(sl.done));
+    const double t2 = now();
+    rc = msm_finish(sl, out_host);
+    const double t3 = now();
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2;
+    if (++calls % 50 == 0) {
+        fprintf(stderr, "[msm host] n=%zu per call: enqueue %.1f us, wait for the GPU %.1f us, host tail %.1f us\n", n, acc[0] / 50, acc[1] / 50, acc[2] / 50);
+        acc[0] = acc[1] = acc[2] = 0;
+    }
+    return rc;
 }
 
 // Concurrent callers (halo2 commits from rayon workers; VERDICT r01 "one global mutex serialises every call, including the host-side
@@ -1291,9 +1314,25 @@ int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const
     if (g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (n == 0) { memset(out_host, 0, 64); return EZKL_OK; }
     int k = -1;
+    static const bool host_timing = getenv("EZKL_MSM_HOST_TIMING") != nullptr;      // where a synchronous call spends its host time
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = host_timing ? now() : 0;
     int rc = msm_call_start(c, lk, b, base_offset, scalars, n, &k);
     if (rc) return rc;
-    return msm_call_finish(c, lk, k, out_host);
+    if (!host_timing) return msm_call_finish(c, lk, k, out_host);
+    static double acc[3] = {0, 0, 0};
+    static int calls = 0;
+    const double t1 = now();
+    (void)hipEventSynchronize(g_call_slots[k].done);
+    const double t2 = now();
+    rc = msm_call_finish(c, lk, k, out_host);
+    const double t3 = now();
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2;
+    if (++calls % 50 == 0) {
+        fprintf(stderr, "[msm host] n=%zu per call: enqueue %.1f us, wait for the GPU %.1f us, host tail %.1f us\n", n, acc[0] / 50, acc[1] / 50, acc[2] / 50);
+        acc[0] = acc[1] = acc[2] = 0;
+    }
+    return rc;
 }
 
 // `batch` independent MSMs against the same bases (the advice-column commits of one prover phase), pipelined
