@@ -3,6 +3,7 @@
 
     gen_srs(srs_path, logrows)                                                  execute.rs gen_srs -> pfsys::srs::gen_srs (srs.rs:13-16)
     setup(compiled_circuit, srs_path, vk_path, pk_path)                         execute.rs:1543-1572 -> pfsys::create_keys (mod.rs:376-400)
+    gen_witness(compiled_circuit, data, output, vk_path, srs_path)               execute.rs:577-660 -> GraphCircuit::forward (graph/mod.rs:1734-1849)
     prove(witness, compiled_circuit, pk_path, proof_path, srs_path, check_mode)  execute.rs:1575-1627 -> create_proof_circuit (mod.rs:404-489)
     verify(proof_path, compiled_circuit, pk_path, srs_path)                      execute.rs:1651-1722 -> verify_proof_circuit (mod.rs:557-590)
 
@@ -48,11 +49,13 @@ def _load_circuit(path):
                          total_assignments=st["total_assignments"], relu_last=relu_last), c
 
 
-def _mlp_of_graph(model):
+def _mlp_of_graph(model, any_visibility=False):
     """the op family ezkl_layout.MlpCircuit lays out, read off ezkl's node graph: Input -> (Einsum "mk,nk->mn" with a constant [n, k]
-    -> Add of a constant [1, n] -> LeakyReLU slope 0)*, private input and parameters at scale 0, public output"""
+    -> Add of a constant [1, n] -> LeakyReLU slope 0)*, private input and parameters at scale 0, public output.  any_visibility (the
+    forward pass of gen_witness, which lays nothing out): the visibilities are the caller's business"""
     nodes, vis = model["nodes"], model["visibility"]
-    if (vis["input"], vis["params"], vis["output"]) != ("Private", "Private", "Public") or len(model["inputs"]) != 1 or len(model["outputs"]) != 1:
+    if len(model["inputs"]) != 1 or len(model["outputs"]) != 1 or \
+            (not any_visibility and (vis["input"], vis["params"], vis["output"]) != ("Private", "Private", "Public")):
         raise ValueError("unsupported compiled circuit: visibility / arity")
     signed = lambda v: v if v < EL.R // 2 else v - EL.R
     def const(idx, dims_ok):
@@ -152,6 +155,131 @@ def setup(compiled_circuit, srs_path, vk_path, pk_path, sample_input=None):
     vk_len = 7 + 64 * (cs.n_fixed + len(cs.perm)) + cs.n_selectors * ((cs.n + 7) // 8)
     open(vk_path, "wb").write(data[:vk_len])                   # vk.key is the prefix of pk.key
     return dict(n_advice=cs.n_advice, n_fixed=cs.n_fixed, n_lookups=len(cs.lookups), degree=cs.degree, pk_bytes=len(data))
+
+
+def _rust_round(x):
+    """f64::round: half away from zero (Python's round() is half to even)"""
+    import math
+    return int(math.floor(x + 0.5)) if x >= 0 else -int(math.floor(-x + 0.5))
+
+
+def _quantize(v, scale, datum_type):
+    """FileSourceInner::{as_type, to_field} (src/graph/input.rs:85-111) -> quantize_float (src/graph/utilities.rs:53-69): the value as the
+    input's datum type would hold it (InputType::roundtrip, src/circuit/ops/mod.rs:112-141), times 2^scale, rounded half away from zero;
+    values beyond what an i128 holds at that scale are the reference's SigBitTruncationError"""
+    import struct
+    if isinstance(v, bool):
+        return 1 if v else 0
+    if isinstance(v, str):                                   # a field element, as hex (FileSourceInner::Field)
+        return codecs.felt_from_hex_le(v) % EL.R
+    x = float(v)
+    if datum_type in ("F32", "F16"):
+        x = struct.unpack("f", struct.pack("f", x))[0]
+    elif datum_type in ("Int", "TDim"):
+        x = float(int(x))
+    elif datum_type == "Bool":
+        if int(x) not in (0, 1):
+            raise ValueError("a Bool input must be 0 or 1")
+        x = float(int(x))
+    mult = 2.0 ** scale
+    if abs(x) > round((2.0 ** 127 - 1) / mult):
+        raise ValueError("SigBitTruncationError: the input does not fit the fixed-point representation")
+    return _rust_round(mult * x)
+
+
+def gen_witness(compiled_circuit, data, output=None, vk_path=None, srs_path=None):
+    """`ezkl gen-witness` (/root/reference/src/execute.rs:577-660 -> GraphCircuit::forward, src/graph/mod.rs:1734-1849; Python binding
+    src/bindings/python.rs:914-941): the compiled circuit + the input data (GraphData JSON: a path, a JSON string or a dict with
+    "input_data") -> the GraphWitness, written to `output` as the reference's witness.json and returned as a dict.
+
+    * inputs are quantized as load_graph_input does (datum-type round trip, times 2^scale, half away from zero);
+    * the forward pass is the integer arithmetic of the op family this package lays out (_mlp_of_graph: Einsum "mk,nk->mn", Add,
+      LeakyReLU slope 0 at scale 0) with the range checks the layout would make: a value outside (-base^legs, base^legs) where the
+      circuit decomposes it is the reference's decomposition error, here a ValueError; max_range_size = decomp_base - 1;
+    * KZGCommit visibility of the input / parameters / output ("polycommit"): PolyCommitChip::commit on the GPU (backend.polycommit_commit:
+      one commit_lagrange MSM per column of 2^k - (blinding factors + 1) values) -- needs srs_path, and like the reference a vk to know the
+      blinding factors (here: any file at vk_path; the count is read off the constraint system);  without an SRS the processed value stays
+      None, as in the reference ("SRS for poly commit does not exist (will be ignored)").  Hashed (Poseidon) visibility is refused.
+    The statistics fields are what the reference's dummy layout reports for this family: no lookups (0, 0), max_range_size."""
+    raw = open(compiled_circuit, "rb").read()
+    if raw[:1] == b"{":
+        j = json.loads(raw)
+        if j.get("model") != "mlp":
+            raise ValueError("unsupported compiled circuit: %r" % j.get("model"))
+        ra = j["run_args"]
+        weights, biases, relu_last = j["weights"], j["biases"], j.get("relu_last", True)
+        vis = dict(input=ra.get("input_visibility", "Private"), params=ra.get("param_visibility", "Private"), output=ra.get("output_visibility", "Public"))
+        in_scale = out_scale = 0
+        datum_type, input_decomp = "F32", True
+    else:
+        c = codecs.read_compiled_circuit(raw)
+        weights, biases, relu_last = _mlp_of_graph(c["model"], any_visibility=True)
+        ra, vis = c["settings"]["run_args"], c["model"]["visibility"]
+        in_node = c["model"]["nodes"][c["model"]["inputs"][0]]
+        in_scale, out_scale = c["settings"]["model_input_scales"][0], c["settings"]["model_output_scales"][0]
+        datum_type, input_decomp = in_node["opkind"].get("datum_type", "F32"), in_node["opkind"].get("decomp", True)
+    for what, v in vis.items():
+        if isinstance(v, dict):
+            raise ValueError("unsupported visibility: %s is Hashed (Poseidon modules are outside this package's scope)" % what)
+    base, legs = ra["decomp_base"], ra["decomp_legs"]
+    if isinstance(data, (bytes, str)) and os.path.exists(data):
+        data = open(data).read()
+    if isinstance(data, (bytes, str)):
+        data = json.loads(data)
+    cols = data["input_data"]
+    if len(cols) != 1 or len(cols[0]) != len(weights[0][0]):
+        raise ValueError("input data does not match the circuit's input shape")
+    x = [_quantize(v, in_scale, datum_type) for v in cols[0]]
+    signed = lambda v: v if v < EL.R // 2 else v - EL.R
+    x = [signed(v % EL.R) for v in x]
+    limit = base ** legs
+    ranged = False
+    def decomposed(vals, where):
+        nonlocal ranged
+        ranged = True
+        for v in vals:
+            if abs(v) >= limit:
+                raise ValueError("%s: %d exceeds the decomposition range (-%d^%d, %d^%d)" % (where, v, base, legs, base, legs))
+    inputs = list(x)
+    if input_decomp:
+        decomposed(x, "input")
+    for li, (W, bvec) in enumerate(zip(weights, biases)):
+        x = [sum(a * w for a, w in zip(x, row)) + bvec[o] for o, row in enumerate(W)]
+        if li + 1 < len(weights) or relu_last:
+            decomposed(x, "LeakyReLU input of layer %d" % li)
+            x = [v if v > 0 else 0 for v in x]
+    outputs = x
+    decomposed(outputs, "output")                        # `output` range-checks the outputs and the instance cells (layouts.rs:6740-6779)
+    processed = dict(input=None, params=None, output=None)
+    if any(v == "KZGCommit" for v in vis.values()):
+        have_srs = srs_path is not None and os.path.exists(srs_path)
+        if vk_path is not None and have_srs:
+            blinding = 5                 # vk.cs().blinding_factors() of this gate family: no advice column is queried at more than 3 rotations
+            srs = load_params_prover(srs_path, ra["logrows"])
+            params = B.ParamsKZG(ra["logrows"], srs["g"], srs["g_lagrange"])
+            try:
+                def commit(vals):
+                    msg = np.stack([np.frombuffer(((v % EL.R) * (1 << 256) % EL.R).to_bytes(32, "little"), np.uint64) for v in vals])
+                    pts = B.polycommit_commit(msg, blinding + 1, params)
+                    out = []
+                    for p in pts:
+                        xi, yi = (int.from_bytes(p[4 * h:4 * h + 4].tobytes(), "little") * pow(1 << 256, -1, B._Q) % B._Q for h in (0, 1))
+                        out.append({"x": codecs.felt_to_hex_le(xi), "y": codecs.felt_to_hex_le(yi)})
+                    return {"poseidon_hash": None, "polycommit": [out]}
+                if vis["input"] == "KZGCommit": processed["input"] = commit(inputs)
+                if vis["params"] == "KZGCommit": processed["params"] = commit([w for W in weights for row in W for w in row] + [b for bv in biases for b in bv])
+                if vis["output"] == "KZGCommit": processed["output"] = commit(outputs)
+            finally:
+                params.free()
+        else:
+            for what, v in vis.items():                      # the reference: a module result without its commitments
+                if v == "KZGCommit": processed[what] = {"poseidon_hash": None, "polycommit": None}
+    text = codecs.write_witness_json([[v % EL.R for v in inputs]], [[v % EL.R for v in outputs]], [in_scale], [out_scale],
+                                     processed_inputs=processed["input"], processed_params=processed["params"], processed_outputs=processed["output"],
+                                     max_lookup_inputs=0, min_lookup_inputs=0, max_range_size=(base - 1) if ranged else 0)
+    if output is not None:
+        open(output, "w").write(text)
+    return json.loads(text)
 
 
 def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_mode=CheckMode.UNSAFE, seed=0, recommit=False):

@@ -4,7 +4,7 @@
 Run in the build container only (needs /root/reference, which does not exist on the GPU box):
     python tests/golden/make_golden.py
 Outputs (committed): tests/golden/kzg_k6.srs, kzg_k1_public.srs, vk_k6.key, pk_k6_subset.npz, pk_k6.key, proof_k6.json,
-                     settings_k6.json, witness_k6.json, verifier_k6.code, model_k6.compiled
+                     settings_k6.json, witness_k6.json, input_k6.json, verifier_k6.code, model_k6.compiled
 
 Sources (read-only, data not code): /root/reference/tests/assets/{kzg,kzg1.srs,vk.key,pk.key}.
 What they pin:
@@ -34,6 +34,7 @@ shutil.copyfile(A + "vk.key", os.path.join(HERE, "vk_k6.key"))
 shutil.copyfile(A + "pk.key", os.path.join(HERE, "pk_k6.key"))
 shutil.copyfile(A + "settings.json", os.path.join(HERE, "settings_k6.json"))
 shutil.copyfile(A + "witness.json", os.path.join(HERE, "witness_k6.json"))
+shutil.copyfile(A + "input.json", os.path.join(HERE, "input_k6.json"))           # the GraphData `gen-witness` made witness.json from
 shutil.copyfile(A + "wasm.code", os.path.join(HERE, "verifier_k6.code"))
 shutil.copyfile(A + "model.compiled", os.path.join(HERE, "model_k6.compiled"))   # bincode of GraphCircuit: codecs.read_compiled_circuit
 import json

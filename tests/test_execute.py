@@ -98,3 +98,62 @@ def test_prove_with_a_larger_srs_file_downsizes(hip, tmp_path):
         assert X.verify(str(proof_path), str(compiled), str(vk_path), files[k])
         out[k] = (pk_path.read_bytes(), proof)
     assert out[6][0] == out[9][0] and out[6][1] == out[9][1]
+
+
+def test_config0_k8_gen_witness_setup_prove_verify_on_files(hip, tmp_path):
+    """BASELINE configs[0] (`examples/onnx/1l_relu`-sized plumbing case: k = 8, --decomp-base 128, below the GPU cutoff -- the reference
+    picks these values at /root/reference/src/graph/mod.rs:79,1690-1694): the whole command chain on FILES with the reference's names,
+    gen-srs -> gen-witness -> setup -> prove (SAFE) -> verify, on the fixture model's weights laid out at k = 8.  The runtime gate says
+    a fork would have sent this circuit to the CPU prover (k <= HIP_SMALL_K), exactly as ICICLE_SMALL_K does for icicle."""
+    import ezkl_amd
+    from ezkl_amd import codecs, execute as X
+    assert ezkl_amd.enabled(8) is False and ezkl_amd.enabled(9) == (os.environ.get("ENABLE_HIP_GPU") is not None)
+    ra = dict(json.load(open(os.path.join(FX.G, "settings_k6.json")))["run_args"], logrows=8)
+    assert ra["decomp_base"] == 128 and ra["decomp_legs"] == 2
+    compiled = tmp_path / "model.compiled.json"
+    compiled.write_text(json.dumps({"model": "mlp", "run_args": ra, "weights": [FIXTURE_W], "biases": [FIXTURE_B]}))
+    srs, wit = tmp_path / "kzg8.srs", tmp_path / "witness.json"
+    vk_path, pk_path, proof_path = tmp_path / "vk.key", tmp_path / "pk.key", tmp_path / "proof.json"
+    X.gen_srs(str(srs), 8, secret=0x5eed)
+    data = {"input_data": [[1.5417295, 0.5346153, 1.2172532]]}                        # the reference's tests/assets/input.json
+    w = X.gen_witness(str(compiled), data, output=str(wit))
+    assert w["inputs"] == json.load(open(os.path.join(FX.G, "witness_k6.json")))["inputs"] and w["max_range_size"] == 127
+    X.setup(str(compiled), str(srs), str(vk_path), str(pk_path))
+    proof = X.prove(str(wit), str(compiled), str(pk_path), str(proof_path), str(srs), X.CheckMode.SAFE)
+    assert X.verify(str(proof_path), str(compiled), str(vk_path), str(srs))
+    pj = codecs.read_proof_json(proof_path.read_text())
+    assert pj["proof"] == proof and pj["instances"] == [codecs.read_witness_json(wit.read_text())["outputs"][0]]
+    # another input, another witness, another proof; the old proof does not verify against the new instances
+    w2 = X.gen_witness(str(compiled), {"input_data": [[3.0, -1.0, 2.0]]}, output=str(tmp_path / "w2.json"))
+    assert w2["outputs"] != w["outputs"]
+    X.prove(str(tmp_path / "w2.json"), str(compiled), str(pk_path), str(tmp_path / "p2.json"), str(srs), X.CheckMode.SAFE)
+    assert X.verify(str(tmp_path / "p2.json"), str(compiled), str(vk_path), str(srs))
+    j = json.loads((tmp_path / "p2.json").read_text()); j["instances"] = json.loads(proof_path.read_text())["instances"]
+    (tmp_path / "p3.json").write_text(json.dumps(j))
+    assert not X.verify(str(tmp_path / "p3.json"), str(compiled), str(vk_path), str(srs))
+
+
+def test_gen_witness_kzg_visibility_commits_on_the_gpu(hip, tmp_path, golden_srs):
+    """KZGCommit ("polycommit") visibility: GraphModules::forward (src/graph/modules.rs:290-335) -> PolyCommitChip::commit
+    (src/circuit/modules/polycommit.rs:46-81) for the input and the output, on the GPU, against the oracle's MSM on the reference SRS"""
+    from oracle import binding as ob, pyref as pr
+    from ezkl_amd import execute as X, ezkl_layout as EL
+    import numpy as np
+    ra = dict(json.load(open(os.path.join(FX.G, "settings_k6.json")))["run_args"], input_visibility="KZGCommit", output_visibility="KZGCommit")
+    compiled = tmp_path / "model.compiled.json"
+    compiled.write_text(json.dumps({"model": "mlp", "run_args": ra, "weights": [FIXTURE_W], "biases": [FIXTURE_B]}))
+    srs_path = os.path.join(FX.G, "kzg_k6.srs")
+    w = X.gen_witness(str(compiled), {"input_data": [[2.0, 1.0, 1.0]]}, vk_path=os.path.join(FX.G, "vk_k6.key"), srs_path=srs_path)
+    srs = pr.parse_srs(open(srs_path, "rb").read())
+    gl = np.stack([np.frombuffer(b, np.uint64) for b in srs["g_lagrange"]])
+    mont = lambda v: np.frombuffer((v % EL.R * (1 << 256) % EL.R).to_bytes(32, "little"), np.uint64)
+    for key, vals in (("processed_inputs", [2, 1, 1]), ("processed_outputs", [int.from_bytes(bytes.fromhex(h), "little") for h in w["outputs"][0]])):
+        col = np.zeros((64, 4), np.uint64)
+        for i, v in enumerate(vals): col[i] = mont(v)
+        col[64 - 6:] = mont(1)                                        # blinding factors 5 + 1 unusable rows at Blind::default() = 1
+        want = ob.msm(col, gl)
+        wx, wy = (int.from_bytes(want[4 * h:4 * h + 4].tobytes(), "little") * pow(1 << 256, -1, pr.Q) % pr.Q for h in (0, 1))
+        got = w[key]["polycommit"]
+        assert len(got) == 1 and len(got[0]) == 1 and w[key]["poseidon_hash"] is None
+        assert (int.from_bytes(bytes.fromhex(got[0][0]["x"]), "little"), int.from_bytes(bytes.fromhex(got[0][0]["y"]), "little")) == (wx, wy)
+    assert w["processed_params"] is None and w["pretty_elements"]["processed_inputs"] == []
