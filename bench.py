@@ -33,6 +33,8 @@ SEED = 0x657a6b6c
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 MSM_BYTES_PER_POINT = 96       # 64 B base + 32 B scalar, each read once
 NTT_BYTES_PER_ELEM = 64        # read once + write once
+CLOCK_WARMUP_MSM = 150         # untimed steps before the contract's --warmup steps (an idle MI355X sits at ~600 MHz): reported as clock_warmup_steps
+CLOCK_WARMUP_NTT = 200
 
 
 def rand_fr(rng, n):
@@ -77,6 +79,8 @@ def main():
     from ezkl_amd import dist as D
     ezkl_amd.init(local_rank)
 
+    if os.environ.get("EZKL_BENCH_FAIL_RANK") == str(rank):          # test hook: this rank dies before its first collective (tests/test_plonk.py)
+        raise SystemExit("bench: rank %d asked to fail (EZKL_BENCH_FAIL_RANK)" % rank)
     n_msm, n_ntt = 1 << LOG_MSM, 1 << LOG_NTT
     rng = np.random.default_rng(SEED + rank)
     # ---- synthetic inputs, resident in HBM before any timed region ----
@@ -99,35 +103,73 @@ def main():
     def ntt_step():
         B.ntt_dev(col.ptr, LOG_NTT, dom.omega)
 
-    acc_ms, msm_ms = [], []
     # clock warm-up before the W contract warm-up steps: an idle MI355X sits at ~600 MHz (rocm-smi on the bench boxes) and a timed region of
     # K = 20 steps is 30 ms long -- 150 steps (~0.25 s) of the same MSM first, untimed, so that the K steps are measured at the clocks a prover runs at
     # (a fixed COUNT, not a duration: with N ranks every step ends in a collective, so every rank must run the same number of them)
-    for _ in range(150):
+    # These clock warm-up steps are reported in the JSON line (`clock_warmup_steps`), next to the contract's `warmup`.
+    for _ in range(CLOCK_WARMUP_MSM):
         msm_step()
     for _ in range(args.warmup):
         msm_step()
     barrier_sync()
+    # the kernel times of the K timed steps are read AFTER the region (ezkl_hip_kernel_ms_stats: every step records into an event pair of
+    # its own, on the stream the kernels run on), so the timed loop holds nothing but the steps
+    B.kernel_ms_stats("msm", reset=True); B.kernel_ms_stats("msm_accumulate", reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         result = msm_step()
-        acc_ms.append(B.last_kernel_ms("msm_accumulate"))
-        msm_ms.append(B.last_kernel_ms("msm"))
     barrier_sync()
     t_msm = time.perf_counter() - t0
+    (msm_sum, msm_cnt), (acc_sum, acc_cnt) = B.kernel_ms_stats("msm"), B.kernel_ms_stats("msm_accumulate")
+    msm_ms, acc_ms = [msm_sum / max(1, msm_cnt)], [acc_sum / max(1, acc_cnt)]
+    assert msm_cnt == args.steps and acc_cnt == args.steps, (msm_cnt, acc_cnt)
 
-    for _ in range(200):
+    # ... and the same K steps with TWO MSMs in flight (ezkl_hip_msm_g1_start_dev / _finish: step i + 1 is queued before step i is waited for,
+    # so the latency-bound sort / reduce kernels and the host tail of one step run under the accumulation of the other -- what a prover's
+    # commit phases do with their batches).  Reported beside the headline (roofline.msm_two_in_flight), never as `value`: the headline stays
+    # the synchronous step of rounds 1-4.  Single rank only (with N ranks every step ends in the fold's collective).
+    t_msm2 = None
+    if world == 1:
+        try:
+            tok = B.msm_g1_start_dev(bases, scalars.ptr, n_msm)
+            for _ in range(3):
+                nxt = B.msm_g1_start_dev(bases, scalars.ptr, n_msm); B.msm_g1_finish(tok); tok = nxt
+            B.msm_g1_finish(tok)
+            barrier_sync()
+            t0 = time.perf_counter()
+            tok = B.msm_g1_start_dev(bases, scalars.ptr, n_msm)
+            for i in range(args.steps):
+                nxt = B.msm_g1_start_dev(bases, scalars.ptr, n_msm) if i + 1 < args.steps else None
+                result2 = B.msm_g1_finish(tok)
+                tok = nxt
+            barrier_sync()
+            t_msm2 = time.perf_counter() - t0
+            if not (result2 == result).all():
+                raise SystemExit("bench: pipelined MSM result differs from the synchronous one")
+        except SystemExit:
+            raise
+        except Exception as e:                          # never lose the headline line to this leg
+            t_msm2 = None
+            print("bench: two-in-flight leg failed: %r" % (e,), file=sys.stderr)
+
+    # the NTT region: K transforms queued stream-ordered on the library stream, as a prover queues them (ezkl_hip_set_async), one
+    # barrier + synchronise at the end; the MSM region above is synchronous by nature (every step returns its point to the host)
+    for _ in range(CLOCK_WARMUP_NTT):
         ntt_step()
     for _ in range(args.warmup):
         ntt_step()
     barrier_sync()
-    ntt_ms = []
+    B.kernel_ms_stats("ntt", reset=True)
+    was_async = B.set_async(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ntt_step()
-        ntt_ms.append(B.last_kernel_ms("ntt"))
     barrier_sync()
     t_ntt = time.perf_counter() - t0
+    B.set_async(was_async)
+    ntt_sum, ntt_cnt = B.kernel_ms_stats("ntt")
+    ntt_ms = [ntt_sum / max(1, ntt_cnt)]
+    assert ntt_cnt == args.steps, ntt_cnt
 
     # batched commit (one prover phase: 4 independent 2^20-point columns per call, pipelined over streams)
     # (kept out of the default run so that rocprofv3's per-kernel averages of `python bench.py` are those of the
@@ -175,12 +217,22 @@ def main():
         achieved = MSM_BYTES_PER_POINT * n_msm / (acc_avg_ms * 1e-3) / 1e9
         # HBM traffic per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (the guide: never together with the
         # kernel trace), so bench.py cannot measure them itself; it reports the tracked reduction of those passes WITH its source label
-        traffic, traffic_source = None, None
+        traffic, traffic_source, ntt_traffic = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # PMC passes over THIS workload (tools/pmc_run.sh: the 2^20-point uniform MSM of the timed region)
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic, traffic_source = tj.get("msm_accumulate_kernel_bytes_per_launch"), "profiles/pmc_traffic.json: " + str(tj.get("source"))
+                # the passes are tied to the kernels they measured: tools/pmc_reduce.py stamps the commit and the SHA-256 of msm.hip / ntt.hip; a
+                # figure taken from other kernel sources than the ones this run executes is REFUSED (traffic = null, the reason in traffic_source)
+                stamp = tj.get("kernel_sources_sha256") or {}
+                label = "profiles/pmc_traffic.json: %s (commit %s)" % (tj.get("source"), tj.get("commit"))
+                if stamp.get("msm.hip") == _sha256_of("ezkl_amd/csrc/msm.hip"):
+                    traffic, traffic_source = tj.get("msm_accumulate_kernel_bytes_per_launch"), label
+                else:
+                    traffic_source = "refused: " + label + " was taken over another msm.hip than the one that ran (sha256 %s... vs %s...)" % (
+                        str(stamp.get("msm.hip"))[:12], _sha256_of("ezkl_amd/csrc/msm.hip")[:12])
+                if stamp.get("ntt.hip") == _sha256_of("ezkl_amd/csrc/ntt.hip"):
+                    ntt_traffic = tj.get("ntt_2p22_bytes_per_transform")
             except Exception:
                 traffic = None
         out = {
@@ -190,6 +242,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "clock_warmup_steps": {"msm": CLOCK_WARMUP_MSM, "ntt": CLOCK_WARMUP_NTT,
+                                   "note": "untimed steps of the same workload BEFORE the `warmup` steps, so that the K timed steps run at the clocks a prover runs at"},
             "ms_per_step": t_msm / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -202,7 +256,20 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": acc_avg_ms,
-                         "note": "integer-VALU bound, not HBM bound: see extra.modmul29_per_s (DESIGN.md §roofline)"},
+                         "note": "integer-VALU bound, not HBM bound: see roofline.product_peak (DESIGN.md §roofline)",
+                         # the other half of BASELINE.json's metric, where the driver's record keeps it: the 2^22-point NTT of the second timed region
+                         "ntt": {"metric": "BN254 Fr NTT elems/s (2^22 points per GPU)", "elems_per_s": world * n_ntt * args.steps / t_ntt,
+                                 "ms_per_step": t_ntt / args.steps * 1e3, "device_ms_per_transform": float(np.mean(ntt_ms)), "launches_per_transform": 3,
+                                 "bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * n_ntt / (float(np.mean(ntt_ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": NTT_BYTES_PER_ELEM * n_ntt / (float(np.mean(ntt_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic,
+                                 "steps_queued": "stream-ordered (ezkl_hip_set_async), one synchronise after the K steps"},
+                         # what the kernels are actually bound by, measured in this run (ezkl_hip_ubench): 254-bit Montgomery products per second with
+                         # every lane issuing the radix-2^29 product and nothing else; and the copy bandwidth this box reaches
+                         "product_peak": {"modmul29_per_s": modmul29, "modmul32_per_s": modmul, "hbm_copy_GBs": copy_bps / 1e9},
+                         "msm_device_ms": float(np.mean(msm_ms)),
+                         "msm_two_in_flight": ({"pts_per_s": n_msm * args.steps / t_msm2, "ms_per_step": t_msm2 / args.steps * 1e3,
+                                                "note": "the same K steps with step i + 1 queued before step i is waited for (ezkl_hip_msm_g1_start_dev / _finish); not the headline"}
+                                               if t_msm2 else None)},
             "extra": {"msm_device_ms": float(np.mean(msm_ms)), "ntt_elems_per_s": world * n_ntt * args.steps / t_ntt,
                       "ntt_ms_per_step": t_ntt / args.steps * 1e3, "ntt_device_ms": float(np.mean(ntt_ms)),
                       "ntt_achieved_GBs": NTT_BYTES_PER_ELEM * n_ntt / (float(np.mean(ntt_ms)) * 1e-3) / 1e9,
@@ -214,11 +281,21 @@ def main():
                                  "batch_matches_single": bool((bres[0] == B.msm_g1_dev(bases, scalars.ptr, n_msm)).all())})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
+            try:
+                out["cpu_baseline"]["ntt"] = cpu_baseline_ntt(B, dom)
+            except Exception as e:                       # never lose the headline line to this leg
+                out["cpu_baseline"]["ntt"] = {"error": repr(e)[:200]}
             out["prove"] = prove_leg()
             # BASELINE.json's metric leads with "ezkl prove wall-seconds (k = 20 MLP)": that number next to `value`, with the CPU prover of
             # the same run beside it (a CPU restatement on this box's host cores, not halo2) and whether the two proofs are the same bytes
             m20 = out["prove"].get("mlp_k20") or {}
-            out["prove_seconds_k20_mlp"] = {"gpu": m20.get("prove_seconds_gpu"), "cpu": m20.get("prove_seconds_cpu"), "cpu_threads": m20.get("cpu_threads"),
+            c20 = m20.get("cold") or {}
+            out["prove_seconds_k20_mlp"] = {"gpu": m20.get("prove_seconds_gpu"), "gpu_is": "best of %s warm proofs: SRS, key, window tables and JIT code resident, witness laid out in pinned memory" % len(m20.get("prove_seconds_gpu_runs") or []),
+                                            "gpu_runs": m20.get("prove_seconds_gpu_runs"), "gpu_first_of_process": m20.get("first_prove_seconds_gpu"),
+                                            # the CLI-equivalent one-shot: a FRESH process reads SRS + pk + witness files into HBM, proves once, writes proof.json
+                                            "cold": c20.get("cold_seconds"), "cold_first_ever": c20.get("first_ever_cold_seconds"), "cold_stages": c20.get("stages"),
+                                            "cold_same_proof_as_warm": c20.get("same_proof_as_warm"),
+                                            "cpu": m20.get("prove_seconds_cpu"), "cpu_threads": m20.get("cpu_threads"),
                                             "identical": m20.get("proofs_identical_gpu_cpu"), "verifier_accepts": m20.get("verifier_accepts"),
                                             "unit": "s", "higher_is_better": False, "error": m20.get("error")}
         # the three kernels that dominate the metric's own workload (the k = 20 MLP proof), each against the HBM roof: algorithmic bytes per
@@ -262,6 +339,17 @@ def main():
         rks.append(rk("msm_accumulate_kernel", "2^20-point MSM of the timed region (96 B per point)", MSM_BYTES_PER_POINT * n_msm, acc_avg_ms, traffic,
                       {"products_per_launch": 13 * n_msm * 10}))
         out["roofline_kernels"] = rks
+        out["roofline"]["kernels"] = rks                    # the same list where the driver's record keeps it
+        if "cpu_baseline" in out and "prove_seconds_k20_mlp" in out:
+            # BASELINE.json's leading metric with its CPU prover of the same run, where the driver's record keeps it; k = 22 and the other circuits beside it
+            pr_ = out.get("prove") or {}
+            brief = lambda d: {a: d.get(a) for a in ("prove_seconds_gpu", "prove_seconds_cpu", "cpu_threads", "proofs_identical_gpu_cpu", "verifier_accepts",
+                                                     "first_prove_seconds_gpu", "keygen_seconds_gpu", "hbm_in_use_gib_after_prove", "label", "error") if d.get(a) is not None}
+            out["cpu_baseline"]["prove_seconds_k20_mlp"] = out["prove_seconds_k20_mlp"]
+            out["cpu_baseline"]["prove_other_circuits"] = {name: brief(pr_[name]) for name in ("mlp_k22", "conv2d_mnist", "einsum", "mlp") if isinstance(pr_.get(name), dict)}
+            if isinstance(pr_.get("einsum"), dict):
+                out["cpu_baseline"]["prove_other_circuits"]["einsum"]["cold_seconds"] = pr_["einsum"].get("cold_seconds")
+            out["cpu_baseline"]["prove_skipped"] = pr_.get("skipped")
         if prove_multi is not None:
             out["prove"] = prove_multi
         if strong is not None:
@@ -313,7 +401,7 @@ def prove_leg():
       * `mlp`: the MLP at k = 17 (BASELINE configs[2]'s size), GPU and CPU."""
     import subprocess
     tool = os.path.join(ROOT, "tools", "prove_bench.py")
-    budget = float(os.environ.get("EZKL_BENCH_BUDGET_S", "150"))
+    budget = float(os.environ.get("EZKL_BENCH_BUDGET_S", "420"))
     left = lambda: budget - (time.time() - T_PROCESS_START)
     leg_seconds, skipped = {}, []
 
@@ -332,7 +420,7 @@ def prove_leg():
     def pick(j, keys):
         return {a: j.get(a) for a in keys if a in j}
 
-    common = ["circuit", "prove_seconds_gpu", "prove_seconds_gpu_runs", "first_prove_seconds_gpu", "prove_seconds_cpu", "cpu_threads", "verifier_accepts", "proof_bytes",
+    common = ["circuit", "cold", "prove_seconds_gpu", "prove_seconds_gpu_runs", "first_prove_seconds_gpu", "prove_seconds_cpu", "cpu_threads", "verifier_accepts", "proof_bytes",
               "keygen_seconds_gpu", "cpu_breakdown_seconds", "hbm_in_use_gib_after_prove", "hbm_pool_high_water_gib", "host_peak_rss_gib"]
 
     def shape(j, extra=()):
@@ -347,12 +435,35 @@ def prove_leg():
     try:
         if os.environ.get("EZKL_BENCH_MLP20", "1") != "0":
             with_cpu = os.environ.get("EZKL_BENCH_MLP20_CPU", "1") != "0" and left() > 95
-            j = child("mlp_k20", {"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned"] + (["--cpu"] if with_cpu else []), 600)
+            # + the cold one-shot of the metric's own circuit (artefact files -> a fresh process -> proof.json): ~30 s more
+            with_cold = os.environ.get("EZKL_BENCH_MLP20_COLD", "1") != "0" and left() > (95 if with_cpu else 25) + 40
+            j = child("mlp_k20", {"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned"] + (["--cpu"] if with_cpu else []) + (["--cold"] if with_cold else []), 900)
             out["mlp_k20"] = shape(j, ["sweep_kernel"])
             if not with_cpu:
                 skipped.append("mlp_k20 CPU prover")
+            if not with_cold:
+                skipped.append("mlp_k20 cold one-shot")
     except Exception as e:
         out["mlp_k20"] = {"error": repr(e)[:300]}
+    # 1b. BASELINE configs[4]'s size (nanoGPT-tiny, k = 22, SRS 2^22; /root/reference/tests/integration_tests.rs:172-181) as an MLP SURROGATE: the
+    #     MLP generator scaled to 5 blocks -> 30 advice columns, 20 lookup arguments, 32 permutation columns, ext 2^24 -- NOT the nanoGPT graph
+    #     (its op families are outside ezkl_layout.py).  The laid-out circuit ships as bench_cache/mlp_k22_s1_blocks5_fill25.npz (25 % of the
+    #     cells laid out, the column allocation of the full model: every kernel of the prover except the witness MSMs costs the same whatever
+    #     the cells hold); without the file the Python layout engine needs minutes, so the leg then runs only with EZKL_BENCH_K22=1.
+    #     ~75 s: 2^22-point SRS, key generation, first + 2 warm proofs, the Python verifier.  EZKL_BENCH_K22=0 skips it; =1 forces it;
+    #     EZKL_BENCH_K22_CPU=1 adds the CPU prover (tens of minutes).
+    k22 = os.environ.get("EZKL_BENCH_K22", "auto")
+    fill22 = os.environ.get("EZKL_BENCH_K22_FILL", "25")
+    have22 = os.path.exists(os.path.join(os.environ.get("EZKL_BENCH_CACHE", os.path.join(ROOT, "bench_cache")), "mlp_k22_s1_blocks5_fill%s.npz" % fill22))
+    if k22 == "1" or (k22 == "auto" and have22 and left() > 110):
+        try:
+            j = child("mlp_k22", {"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": fill22, "REPS": "2"},
+                      ["--pinned"] + (["--cpu"] if os.environ.get("EZKL_BENCH_K22_CPU") == "1" else []), 7200)
+            out["mlp_k22"] = dict(shape(j), label="MLP surrogate of configs[4] (k = 22, 30 advice columns, SRS 2^22): the size, not the nanoGPT graph")
+        except Exception as e:
+            out["mlp_k22"] = {"error": repr(e)[:300]}
+    else:
+        skipped.append("mlp_k22 (surrogate of configs[4])" + ("" if have22 else ": bench_cache/mlp_k22_s1_blocks5_fill%s.npz missing" % fill22))
     # 2. BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17 (~12 s with its CPU prover)
     if left() > 20:
         try:
@@ -367,7 +478,7 @@ def prove_leg():
     if left() > 45:
         try:
             cold = os.environ.get("EZKL_BENCH_COLD", "auto")
-            with_cold = cold == "1" or (cold == "auto" and left() > 75)
+            with_cold = cold == "1" or (cold == "auto" and left() > 75 + 120)      # the MLP legs (k = 20 cold above, k = 22 below) come first
             j = child("einsum", {"CIRCUIT": "einsum", "K": k_e}, ["--cpu"] + (["--cold"] if with_cold else []), 600)
             out["einsum"] = shape(j)
             out["einsum"].update({"cold_seconds": (j.get("cold") or {}).get("cold_seconds"), "cold": j.get("cold"), "cpu_prover": j.get("cpu_prover"),
@@ -386,17 +497,6 @@ def prove_leg():
             out["mlp"] = {"error": repr(e)[:300]}
     else:
         skipped.append("mlp k=17")
-    if os.environ.get("EZKL_BENCH_K22") == "1":
-        # BASELINE configs[4]'s shape (nanoGPT-tiny, k = 22, /root/reference/tests/integration_tests.rs:172-181): the MLP generator scaled to 5
-        # blocks -> 30-36 advice columns, 20-24 lookup arguments, ext 2^24.  Opt-in: the Python layout engine needs minutes per 10 M cells
-        # (EZKL_BENCH_K22_FILL = percent of the cells actually laid out, default 25; the column allocation is that of the full model) and
-        # the CPU prover beside it (EZKL_BENCH_K22_CPU=1) tens of minutes
-        try:
-            j = child("mlp_k22", {"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": os.environ.get("EZKL_BENCH_K22_FILL", "25"), "REPS": "2"},
-                      ["--pinned"] + (["--cpu"] if os.environ.get("EZKL_BENCH_K22_CPU") == "1" else []), 7200)
-            out["mlp_k22"] = shape(j)
-        except Exception as e:
-            out["mlp_k22"] = {"error": repr(e)[:300]}
     out["leg_seconds"] = leg_seconds
     out["skipped"] = skipped
     out["budget_seconds"] = budget
@@ -472,6 +572,44 @@ def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
                 "keygen_seconds_gpu": j["keygen_seconds_gpu"], "breakdown_seconds": j["prove_breakdown_seconds"]}
     except Exception as e:
         return {"error": repr(e)[:300]} if rank == 0 else None
+
+
+def _sha256_of(rel):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+    except OSError:
+        return "missing"
+
+
+def cpu_baseline_ntt(B, dom):
+    """BASELINE.md §3's CPU side of the NTT half of the metric: the C oracle (oracle/oracle.c: the restatement of halo2curves' best_fft and of
+    the EvaluationDomain wrappers, OpenMP) on the host cores -- one forward 2^22-point transform, one inverse (lagrange_to_coeff) and the
+    prover's coset form (coeff_to_extended 2^20 -> 2^22), best of 2 each (~10 s of CPU work); the forward transform is also the last parity check
+    of the NTT region (GPU transform of the same column == oracle's)."""
+    from oracle import binding as ob
+    rng = np.random.default_rng(SEED + 99)
+    a = rand_fr(rng, 1 << LOG_NTT)
+    w = ob.omega(LOG_NTT)
+    ob.fft(a[: 1 << 12].copy(), 12, ob.omega(12))               # start the OpenMP pool
+    def best(f, reps=2):
+        ts, r = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t0)
+        return min(ts), r
+    t_fwd, want = best(lambda: ob.fft(a, LOG_NTT, w))
+    d = B.DeviceBuffer.from_numpy(a)
+    B.ntt_dev(d.ptr, LOG_NTT, dom.omega)
+    if not (d.to_numpy(shape=(1 << LOG_NTT, 4)) == want).all():
+        raise SystemExit("bench: GPU NTT result differs from the CPU oracle")
+    t_inv, _ = best(lambda: ob.lagrange_to_coeff(a, LOG_NTT))
+    t_cos, _ = best(lambda: ob.coeff_to_extended(a[: 1 << 20], 20, 22))
+    n = 1 << LOG_NTT
+    return {"value": n / t_fwd, "unit": "elems/s", "cores": ob.num_threads(), "kind": "port",
+            "sample": "one forward 2^22-point transform of the timed workload's size, best of 2 (%.2f s each)" % t_fwd,
+            "inverse_2p22_elems_per_s": n / t_inv, "coset_2p20_to_2p22_elems_per_s": n / t_cos,
+            "seconds": {"forward_2p22": t_fwd, "lagrange_to_coeff_2p22": t_inv, "coeff_to_extended_2p20_to_2p22": t_cos},
+            "matches_gpu_result": True}
 
 
 def cpu_baseline(bases, scalars, n, gpu_result):

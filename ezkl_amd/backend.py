@@ -166,6 +166,21 @@ def msm_g1_dev(bases, scalars_ptr, n, offset=0, stream=None):
     return out
 
 
+def msm_g1_start_dev(bases, scalars_ptr, n, offset=0):
+    """the first half of msm_g1_dev: queues the MSM on a call slot of its own and returns a token (ezkl_hip_msm_g1_start_dev; at most four in
+    flight per context -- a fifth from the thread that holds all four raises EzklHipError with code EZKL_ERR_BUSY = -6)"""
+    tok = C.c_int(-1)
+    _l.check(_l.load().ezkl_hip_msm_g1_start_dev(bases.h, C.c_size_t(offset), _vp(scalars_ptr), C.c_size_t(n), C.byref(tok)), "ezkl_hip_msm_g1_start_dev")
+    return int(tok.value)
+
+
+def msm_g1_finish(token):
+    """waits for the MSM behind `token` and returns its affine point; a token is spent by its first finish"""
+    out = np.zeros(8, np.uint64)
+    _l.check(_l.load().ezkl_hip_msm_g1_finish(C.c_int(token), _p(out)), "ezkl_hip_msm_g1_finish")
+    return out
+
+
 def msm_g1_batch_dev(bases, scalar_ptrs, n, offset=0, stream=None):
     """batch of MSMs over resident scalar vectors (one commit phase); returns (batch, 8) affine points"""
     out = np.zeros((len(scalar_ptrs), 8), np.uint64)
@@ -755,6 +770,14 @@ def last_kernel_ms(which):
     return float(ms.value)
 
 
+def kernel_ms_stats(which, reset=False):
+    """(sum of device ms, number of regions) of every `which` region recorded since the last reset -- read AFTER a timed loop: the
+    regions of back-to-back calls each have an event pair of their own (ezkl_hip_kernel_ms_stats)"""
+    s, n = C.c_double(0), C.c_uint64(0)
+    _l.check(_l.load().ezkl_hip_kernel_ms_stats(which.encode(), C.byref(s), C.byref(n), C.c_int(1 if reset else 0)), "ezkl_hip_kernel_ms_stats")
+    return float(s.value), int(n.value)
+
+
 def ubench(which):
     out = C.c_double(0)
     _l.check(_l.load().ezkl_hip_ubench(which.encode(), C.byref(out)), "ezkl_hip_ubench")
@@ -920,6 +943,11 @@ def comm_alltoallv_dev(sends, recvs):
     sa = (_CommSeg * max(1, len(sends)))(*[_CommSeg(p, ptr, n) for p, ptr, n in sends])
     ra = (_CommSeg * max(1, len(recvs)))(*[_CommSeg(p, ptr, n) for p, ptr, n in recvs])
     _l.check(_l.load().ezkl_hip_comm_alltoallv_dev(sa, C.c_size_t(len(sends)), ra, C.c_size_t(len(recvs))), "ezkl_hip_comm_alltoallv_dev")
+
+
+def comm_available():
+    """librccl loads and exports every entry point the library communicator binds (no device touched, nothing called)"""
+    return _l.load().ezkl_hip_comm_available() == 0
 
 
 def comm_stats(reset=False):

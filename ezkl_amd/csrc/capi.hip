@@ -162,16 +162,33 @@ int arena_done(Ctx::Arena& a, hipStream_t st) {
     return EZKL_OK;
 }
 
-int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1) {
-    auto it = c->events.find(key);
-    if (it == c->events.end()) {
-        hipEvent_t a, b;
-        EZ_HIP(hipEventCreate(&a));
-        EZ_HIP(hipEventCreate(&b));
-        it = c->events.emplace(key, std::make_pair(a, b)).first;
+// adds the elapsed time of the oldest pending pair(s) to the ring's statistics: `all` = every pending pair (waits for them), otherwise
+// only as many as it takes to free the slot the next acquisition needs
+int ev_harvest(Ctx::EvRing& r, bool all) {
+    while (r.tail < r.head && (all || r.head - r.tail >= Ctx::EvRing::N)) {
+        const unsigned i = (unsigned)(r.tail % Ctx::EvRing::N);
+        float ms = 0;
+        EZ_HIP(hipEventSynchronize(r.e1[i]));
+        EZ_HIP(hipEventElapsedTime(&ms, r.e0[i], r.e1[i]));
+        r.sum_ms += ms;
+        r.count++;
+        r.tail++;
     }
-    *e0 = it->second.first;
-    *e1 = it->second.second;
+    return EZKL_OK;
+}
+int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1) {
+    Ctx::EvRing& r = c->events[key];
+    int rc = ev_harvest(r, false);
+    if (rc) return rc;
+    const unsigned i = (unsigned)(r.head % Ctx::EvRing::N);
+    if (!r.made[i]) {
+        EZ_HIP(hipEventCreate(&r.e0[i]));
+        EZ_HIP(hipEventCreate(&r.e1[i]));
+        r.made[i] = true;
+    }
+    *e0 = r.e0[i];
+    *e1 = r.e1[i];
+    r.head++;
     return EZKL_OK;
 }
 
@@ -309,6 +326,7 @@ const char* ezkl_hip_strerror(int code) {
     case EZKL_ERR_INVALID: return "invalid argument";
     case EZKL_ERR_NOMEM: return "out of device memory";
     case EZKL_ERR_UNSUPPORTED: return "unsupported";
+    case EZKL_ERR_BUSY: return "every slot is held by the calling thread";
     default: return "unknown error";
     }
 }
@@ -1109,9 +1127,26 @@ int ezkl_hip_last_kernel_ms(const char* which, float* out_ms) {
     if (!which || !out_ms) return EZKL_ERR_INVALID;
     EZ_CTX(c);
     auto it = c->events.find(which);
-    if (it == c->events.end()) return EZKL_ERR_INVALID;
-    EZ_HIP(hipEventSynchronize(it->second.second));
-    EZ_HIP(hipEventElapsedTime(out_ms, it->second.first, it->second.second));
+    if (it == c->events.end() || it->second.head == 0) return EZKL_ERR_INVALID;
+    const unsigned i = (unsigned)((it->second.head - 1) % Ctx::EvRing::N);
+    EZ_HIP(hipEventSynchronize(it->second.e1[i]));
+    EZ_HIP(hipEventElapsedTime(out_ms, it->second.e0[i], it->second.e1[i]));
+    return EZKL_OK;
+}
+int ezkl_hip_kernel_ms_stats(const char* which, double* sum_ms, uint64_t* count, int reset) {
+    if (!which) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    auto it = c->events.find(which);
+    if (it == c->events.end()) {                        // a region that has not run yet: empty statistics, not an error
+        if (sum_ms) *sum_ms = 0;
+        if (count) *count = 0;
+        return EZKL_OK;
+    }
+    int rc = ev_harvest(it->second, true);
+    if (rc) return rc;
+    if (sum_ms) *sum_ms = it->second.sum_ms;
+    if (count) *count = it->second.count;
+    if (reset) { it->second.sum_ms = 0; it->second.count = 0; }
     return EZKL_OK;
 }
 int ezkl_hip_ubench(const char* which, double* out) {

@@ -116,8 +116,10 @@ struct CopyDesc {
     uint64_t start;       // offset of this piece in the dense byte space of the launch (prefix sum of the pieces before it)
 };
 static constexpr uint32_t PACK_CHUNK = 32768;       // bytes per workgroup
-// every piece is a multiple of 16 bytes at 16-byte aligned addresses (field elements: 32 B); workgroup b copies dense bytes
-// [b * PACK_CHUNK, (b + 1) * PACK_CHUNK): it finds its first piece by bisection and walks on while the chunk spans several
+// workgroup b copies dense bytes [b * PACK_CHUNK, (b + 1) * PACK_CHUNK): it finds its first piece by bisection and walks on while the chunk
+// spans several.  The prover's pieces are multiples of 16 bytes at 16-byte aligned addresses (field elements: 32 B) and move as 16-byte
+// vectors; a piece (or the part of it inside this chunk) that is NOT so aligned moves byte by byte -- the wire format never depends on the
+// alignment a rank happens to see (a rank-local fallback to another format was a hang, not an error)
 __global__ __launch_bounds__(256) void comm_pack_kernel(const CopyDesc* desc, uint32_t n_desc, uint64_t total) {
     const uint64_t lo = (uint64_t)blockIdx.x * PACK_CHUNK, hi = lo + PACK_CHUNK < total ? lo + PACK_CHUNK : total;
     uint32_t a = 0, b = n_desc;                       // last piece with start <= lo
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(256) void comm_pack_kernel(const CopyDesc* desc, ui
         const CopyDesc ds = desc[d];
         if (ds.start >= hi) break;
         const uint64_t from = lo > ds.start ? lo - ds.start : 0, to = (hi - ds.start) < ds.bytes ? (hi - ds.start) : ds.bytes;
+        if ((((uintptr_t)(ds.src + from)) | ((uintptr_t)(ds.dst + from)) | (uintptr_t)(to - from)) & 15) {
+            const char* src = ds.src + from;
+            char* dst = ds.dst + from;
+            for (uint64_t i = threadIdx.x; i < to - from; i += 256) dst[i] = src[i];
+            continue;
+        }
         const uint4* src = (const uint4*)(ds.src + from);
         uint4* dst = (uint4*)(ds.dst + from);
         const uint32_t n16 = (uint32_t)((to - from) >> 4);
@@ -179,6 +187,11 @@ static int comm_launch_copies(const std::vector<CopyDesc>& d, uint64_t total, si
 
 using namespace ezkl;
 extern "C" {
+
+// does librccl load next to this library's HIP runtime, with every entry point comm.hip binds (ncclGetUniqueId, ncclCommInitRank,
+// ncclCommDestroy, ncclAllGather, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclGetErrorString)?  No device and no RCCL call is
+// made: a dry check for a build box / CI, and the first thing an 8-rank job can ask before it commits to the library communicator.
+int ezkl_hip_comm_available(void) { return rccl_load(); }
 
 int ezkl_hip_comm_unique_id(void* out128) {
     if (!out128) return EZKL_ERR_INVALID;
@@ -338,16 +351,13 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
     EZ_CTX(c);
     if (!g_comm.comm) return EZKL_ERR_INVALID;
     const int me = g_comm.rank, world = g_comm.world;
-    bool aligned = true;
     std::vector<uint64_t> tot_s(world, 0), tot_r(world, 0);
     for (size_t i = 0; i < n_sends; i++) {
         if (sends[i].peer < 0 || sends[i].peer >= world || (!sends[i].ptr && sends[i].bytes)) return EZKL_ERR_INVALID;
-        aligned &= !((uintptr_t)sends[i].ptr & 15) && !(sends[i].bytes & 15);
         tot_s[sends[i].peer] += sends[i].bytes;
     }
     for (size_t i = 0; i < n_recvs; i++) {
         if (recvs[i].peer < 0 || recvs[i].peer >= world || (!recvs[i].ptr && recvs[i].bytes)) return EZKL_ERR_INVALID;
-        aligned &= !((uintptr_t)recvs[i].ptr & 15) && !(recvs[i].bytes & 15);
         tot_r[recvs[i].peer] += recvs[i].bytes;
     }
     if (tot_s[me] != tot_r[me]) return EZKL_ERR_INVALID;
@@ -359,7 +369,7 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
     const int skip = via && *via == '1' ? -1 : me;    // the peer whose bytes are plain copies
     const char* unp = getenv("EZKL_COMM_UNPACKED");
     int rc = EZKL_OK;
-    if ((unp && *unp == '1') || !aligned) {
+    if (unp && *unp == '1') {                         // the environment is the same on every rank: the format is never a rank-local decision
         rc = alltoallv_unpacked(c, sends, n_sends, recvs, n_recvs, skip);
     } else {
         size_t slab = (size_t)128 << 20;              // per peer and direction; every rank must use the same value

@@ -19,9 +19,20 @@ struct Ctx {
     hipEvent_t order_event = nullptr;  // ezkl_hip_stream_wait_library
     int num_cus = 256;
     std::recursive_mutex mu;          // serialises calls on this device (halo2 calls from rayon workers)
-    // HIP event pairs recorded on the stream the kernels run on, one pair per measured region
-    // ("ntt", "coset_ntt", "msm", "msm_accumulate", ...); read back by ezkl_hip_last_kernel_ms
-    std::map<std::string, std::pair<hipEvent_t, hipEvent_t>> events;
+    // HIP event pairs recorded on the stream the kernels run on, per measured region ("ntt", "coset_ntt", "msm", "msm_accumulate", ...).
+    // A RING of pairs per region: every acquisition (ev_pair) gets a pair of its own, so regions recorded back to back -- or from two
+    // streams -- never re-record a pair that has not been read yet; a pair is harvested (elapsed time added to sum_ms / count) when the ring
+    // comes round to it or when the statistics are read (ezkl_hip_kernel_ms_stats).  ezkl_hip_last_kernel_ms reads the newest pair.
+    struct EvRing {
+        static constexpr unsigned N = 64;
+        hipEvent_t e0[N], e1[N];
+        bool made[N];
+        uint64_t head = 0, tail = 0;      // pairs [tail, head) are recorded and not harvested yet
+        double sum_ms = 0;
+        uint64_t count = 0;
+        EvRing() { for (unsigned i = 0; i < N; i++) { e0[i] = e1[i] = nullptr; made[i] = false; } }
+    };
+    std::map<std::string, EvRing> events;
     // Device arenas reused across calls (grown on demand, never shrunk).  `scratch` backs the NTT ping-pong buffer and
     // the sweep's spill area; `aux` backs the small helpers.  An arena remembers the stream and an event of its last
     // user: the next user on a DIFFERENT stream waits for that event first, so stream-ordered calls on caller streams
@@ -60,6 +71,7 @@ int set_hip_error(hipError_t e, const char* what, const char* file, int line);
 int arena_reserve(Ctx::Arena& a, size_t bytes, hipStream_t st, void** out);   // acquire for work on stream st
 int arena_done(Ctx::Arena& a, hipStream_t st);                               // mark the end of that work
 int ev_pair(Ctx* c, const char* key, hipEvent_t* e0, hipEvent_t* e1);
+int ev_harvest(Ctx::EvRing& r, bool all);
 // Pinned staging for small host arrays a call borrows: acquire a block (nullptr: none to be had -- copy from the caller's memory and
 // synchronise instead), fill it, queue the copy out of it on `st`, release it on `st` (the block is reused once that copy has run).
 uint8_t* staging_acquire(Ctx* c, size_t bytes, void** token);

@@ -58,6 +58,7 @@ static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane 
 static constexpr uint32_t MSM_LMIN = 8;             // shortest lane of the accumulate kernel
 static constexpr uint32_t MSM_MAX_BIG = 64;         // oversized partitions sorted by several workgroups each (the rest: one workgroup)
 static constexpr uint32_t MSM_BIG_BLOCKS = 64;      // workgroups per oversized partition
+static constexpr uint32_t MSM_BIG_ROWS = 8;         // rows of such workgroups in a launch: row r takes the oversized partitions r, r + 8, ...
 
 // Partition of a bucket in the first sorting pass: its low bits -- except bucket 0, which gets a partition of its own
 // (index 0; ordinary partition p is index p + 1).  Bucket 0 holds the digits +-1: every carry of the signed recoding into an
@@ -110,6 +111,8 @@ static MsmState& msm_state();
 #define g_slots (msm_state().slots)
 #define g_call_slots (msm_state().call_slots)
 #define g_call_claimed (msm_state().call_claimed)
+#define g_call_finishing (msm_state().call_finishing)
+#define g_call_owner (msm_state().call_owner)
 #define g_call_order_ev (msm_state().call_order_ev)
 #define g_copy_st (msm_state().copy_st)
 #define g_tail_pinned (msm_state().tail_pinned)
@@ -139,6 +142,7 @@ struct MsmSlot {
     uint8_t* scratch = nullptr;
     size_t scratch_bytes = 0;
     uint32_t* pinned = nullptr;       // per MSM of the group: 1 + 22 planes of 36 limbs (g1x29_t), 32 records apart
+    void* pinned_dev = nullptr;       // the same buffer as the device addresses it (hipHostGetDevicePointer): the planes kernel writes into it
     size_t pinned_msms = 0;
     const fe_t** list_pinned = nullptr;   // the group's scalar-column pointers, staged for the device
     hipEvent_t done = nullptr;
@@ -154,6 +158,8 @@ struct MsmState {
     MsmSlot slots[MSM_MAX_SLOTS];
     MsmSlot call_slots[MSM_CALL_SLOTS];
     bool call_claimed[MSM_CALL_SLOTS] = {false, false, false, false};
+    bool call_finishing[MSM_CALL_SLOTS] = {false, false, false, false};   // a finish is running outside the lock: a second finish of the token is refused
+    std::thread::id call_owner[MSM_CALL_SLOTS];
     hipEvent_t call_order_ev = nullptr;
     hipStream_t copy_st = nullptr;
     fe_t* tail_pinned = nullptr;
@@ -274,6 +280,35 @@ __device__ __forceinline__ bool msm_digit_step(fe_t& s, uint32_t neg, uint32_t c
     return raw != 0;
 }
 
+// inclusive prefix sum of one value per thread over the workgroup (blockDim.x a multiple of 64, at most 1024): shuffles inside the waves, the
+// <= 16 wave totals through `wsum` (>= 16 words of LDS), three barriers in all -- the Hillis-Steele loops this replaces took two barriers per
+// doubling step (20 for the 1024 threads of the partition pass, whose 16 waves are alone on their CU).  total = the sum over the workgroup.
+__device__ __forceinline__ uint32_t msm_block_scan(uint32_t v, uint32_t* wsum, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t s = lane < nw ? wsum[lane] : 0u;
+#pragma unroll
+        for (uint32_t d = 1; d < 16; d <<= 1) {
+            const uint32_t y = __shfl_up(s, d, 64);
+            if (lane >= d) s += y;
+        }
+        if (lane < nw) wsum[lane] = s;
+    }
+    __syncthreads();
+    total = wsum[nw - 1];
+    const uint32_t r = x + (wave ? wsum[wave - 1] : 0u);
+    __syncthreads();                                   // wsum may be reused by the caller
+    return r;
+}
+
 // ---- sort pass 1: partition (bucket, payload) pairs by the LOW bits of the bucket id -------------
 // (low bits are uniformly populated even when the top window or a skewed witness concentrates the bucket
 // values in a small numeric range, so the partitions stay balanced).  Buckets are stored at position
@@ -374,18 +409,12 @@ __device__ __forceinline__ void msm_part_scan_body(const uint32_t* part_count, u
     // coherent: the counts were written by other workgroups of the SAME launch (the fused form): read them past this CU's cache
     auto ldc = [&](uint32_t i) { return coherent ? __hip_atomic_load(part_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : part_count[i]; };
     const uint32_t v0 = 2 * t < NQ ? ldc(2 * t) : 0, v1 = 2 * t + 1 < NQ ? ldc(2 * t + 1) : 0;
-    sh[t] = v0 + v1;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = t >= d ? sh[t - d] : 0;
-        __syncthreads();
-        sh[t] += x;
-        __syncthreads();
-    }
-    const uint32_t excl = sh[t] - v0 - v1;
+    uint32_t total;
+    const uint32_t incl = msm_block_scan(v0 + v1, sh, total);
+    const uint32_t excl = incl - v0 - v1;
     if (2 * t < NQ) part_base[2 * t] = excl;
     if (2 * t + 1 < NQ) part_base[2 * t + 1] = excl + v0;
-    if (t == 1023) part_base[NQ] = sh[t];
+    if (t == 1023) part_base[NQ] = total;
 #pragma unroll
     for (uint32_t q = 2 * t; q < 2 * t + 2; q++) {
         if (q == 0 || q >= NQ) continue;                                 // index 0 is bucket 0's partition: never sorted
@@ -431,16 +460,8 @@ __global__ __launch_bounds__(1024) void msm_partition_kernel(const fe_t* scalars
         const uint32_t p = t * K + q;
         if (p < NQ) loc += wg_cnt[(size_t)blockIdx.x * NQ + p];
     }
-    tsum[t] = loc;
-    __syncthreads();
-    for (uint32_t d = 1; d < T; d <<= 1) {
-        uint32_t x = t >= d ? tsum[t - d] : 0;
-        __syncthreads();
-        tsum[t] += x;
-        __syncthreads();
-    }
-    const uint32_t total = tsum[T - 1];
-    uint32_t run = tsum[t] - loc;
+    uint32_t total;
+    uint32_t run = msm_block_scan(loc, tsum, total) - loc;
     for (uint32_t q = 0; q < K; q++) {
         const uint32_t p = t * K + q;
         if (p < NQ) {
@@ -497,15 +518,8 @@ __device__ __forceinline__ void msm_bins_scan(uint32_t* cnt, uint32_t* tsum, uin
         loc[q] = j < nbins ? cnt[j] : 0;
         s += loc[q];
     }
-    tsum[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 512; d <<= 1) {
-        uint32_t x = t >= d ? tsum[t - d] : 0;
-        __syncthreads();
-        tsum[t] += x;
-        __syncthreads();
-    }
-    uint32_t run = tsum[t] - s;
+    uint32_t total;
+    uint32_t run = msm_block_scan(s, tsum, total) - s;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         uint32_t j = t * 4 + q;
@@ -535,36 +549,32 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
     for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
     __syncthreads();
     if (staged) {
-        uint32_t e = beg + t;
-        for (; e + 3 * 512 < end; e += 4 * 512) {
-            uint32_t y0 = entries[e].y, y1 = entries[e + 512].y, y2 = entries[e + 1024].y, y3 = entries[e + 1536].y;
-            atomicAdd(&cnt[y0], 1u); atomicAdd(&cnt[y1], 1u); atomicAdd(&cnt[y2], 1u); atomicAdd(&cnt[y3], 1u);
+        // A partition of ordinary size (<= MSM_BINSORT_STAGE = 30 x 512 pairs) is read ONCE: every thread keeps its <= 30 pairs in registers
+        // between the counting pass and the ranking pass (round 5; the two passes used to read the 109 MB of pairs twice), all loads of a
+        // thread in flight at once.  It is ranked into LDS and leaves as one contiguous run (scattered 4-byte stores cost one L2 request each).
+        constexpr int PER = MSM_BINSORT_STAGE / 512;
+        uint2 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t e = beg + t + (uint32_t)q * 512u;
+            v[q] = e < end ? entries[e] : make_uint2(0u, 0xffffffffu);
         }
-        for (; e < end; e += 512) atomicAdd(&cnt[entries[e].y], 1u);
-    } else {
-        for (uint32_t e = beg + t; e < end; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
-    }
-    __syncthreads();
-    msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, true, offsets, buckets);
-    // four entries in flight per thread: the returning LDS atomics and the stores that depend on them overlap.  A partition of
-    // ordinary size is ranked into LDS and leaves as one contiguous run (the scattered 4-byte stores cost one L2 request each,
-    // like the partition pass's).  An oversized one that did not get a slot in the multi-workgroup sort below (more than
-    // MSM_MAX_BIG of them) is ranked straight into HBM, a whole wave of equal keys with one LDS atomic (msm_wave_rank).
-    if (staged) {
-        uint32_t e = beg + t;
-        for (; e + 3 * 512 < end; e += 4 * 512) {
-            uint2 v0 = entries[e], v1 = entries[e + 512], v2 = entries[e + 1024], v3 = entries[e + 1536];
-            uint32_t p0 = atomicAdd(&cnt[v0.y], 1u), p1 = atomicAdd(&cnt[v1.y], 1u), p2 = atomicAdd(&cnt[v2.y], 1u), p3 = atomicAdd(&cnt[v3.y], 1u);
-            stage[p0] = v0.x; stage[p1] = v1.x; stage[p2] = v2.x; stage[p3] = v3.x;
-        }
-        for (; e < end; e += 512) {
-            uint2 v = entries[e];
-            uint32_t pos = atomicAdd(&cnt[v.y], 1u);
-            stage[pos] = v.x;
-        }
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (v[q].y != 0xffffffffu) atomicAdd(&cnt[v[q].y], 1u);
+        __syncthreads();
+        msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, true, offsets, buckets);
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (v[q].y != 0xffffffffu) stage[atomicAdd(&cnt[v[q].y], 1u)] = v[q].x;
         __syncthreads();
         for (uint32_t i = t; i < end - beg; i += 512) vals[beg + i] = stage[i];
     } else {
+        // An oversized partition that did not get a slot in the multi-workgroup sort below (more than MSM_MAX_BIG of them) is ranked straight
+        // into HBM, a whole wave of equal keys with one LDS atomic (msm_wave_rank).
+        for (uint32_t e = beg + t; e < end; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
+        __syncthreads();
+        msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, true, offsets, buckets);
         for (uint32_t e = beg + t; e < end; e += 512) {
             const uint2 v = entries[e];
             vals[beg + msm_wave_rank(cnt, v.y)] = v.x;
@@ -582,21 +592,27 @@ __device__ __forceinline__ void msm_big_slice(uint32_t beg, uint32_t end, uint32
     s1 = s0 + chunk < end ? s0 + chunk : end;
     if (s0 > end) s0 = end;
 }
+// (round 5) both kernels run MSM_BIG_BLOCKS x MSM_BIG_ROWS workgroups that LOOP over the oversized partitions (row r takes partitions r,
+// r + MSM_BIG_ROWS, ...): the launch of an MSM without any (the common case) is 512 workgroups that read one counter and leave, not 4096,
+// and a skewed column still has two workgroups per CU at work.
 __global__ __launch_bounds__(512) void msm_bigsort_count_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
                                                                 const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off, size_t bstride) {
     BOFF(); BSH(entries); BSH(part_base); BSH(big_list); BSH(big_count); BSH(bin_total); BSH(block_off);
     __shared__ uint32_t cnt[2048];
-    const uint32_t y = blockIdx.y, t = threadIdx.x, nbins = 1u << LB;
-    if (y >= (big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG)) return;
-    const uint32_t p = big_list[y];
-    uint32_t s0, s1;
-    msm_big_slice(part_base[p + 1], part_base[p + 2], s0, s1);
-    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
-    __syncthreads();
-    for (uint32_t e = s0 + t; e < s1; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
-    __syncthreads();
-    for (uint32_t j = t; j < nbins; j += 512)                            // this workgroup's range inside bin j starts at the returned value
-        block_off[((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins + j] = cnt[j] ? atomicAdd(&bin_total[(size_t)y * nbins + j], cnt[j]) : 0u;
+    const uint32_t t = threadIdx.x, nbins = 1u << LB;
+    const uint32_t nbig = big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG;
+    for (uint32_t y = blockIdx.y; y < nbig; y += gridDim.y) {
+        const uint32_t p = big_list[y];
+        uint32_t s0, s1;
+        msm_big_slice(part_base[p + 1], part_base[p + 2], s0, s1);
+        for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
+        __syncthreads();
+        for (uint32_t e = s0 + t; e < s1; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
+        __syncthreads();
+        for (uint32_t j = t; j < nbins; j += 512)                            // this workgroup's range inside bin j starts at the returned value
+            block_off[((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins + j] = cnt[j] ? atomicAdd(&bin_total[(size_t)y * nbins + j], cnt[j]) : 0u;
+        __syncthreads();
+    }
 }
 __global__ __launch_bounds__(512) void msm_bigsort_scatter_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
                                                                   const uint32_t* big_count, const uint32_t* bin_total, const uint32_t* block_off,
@@ -604,20 +620,23 @@ __global__ __launch_bounds__(512) void msm_bigsort_scatter_kernel(const uint2* e
     BOFF(); BSH(entries); BSH(part_base); BSH(big_list); BSH(big_count); BSH(bin_total); BSH(block_off); BSH(offsets); BSH(vals); BSH(buckets);
     __shared__ uint32_t cnt[2048];
     __shared__ uint32_t tsum[512];
-    const uint32_t y = blockIdx.y, t = threadIdx.x, nbins = 1u << LB;
-    if (y >= (big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG)) return;
-    const uint32_t p = big_list[y], beg = part_base[p + 1];
-    uint32_t s0, s1;
-    msm_big_slice(beg, part_base[p + 2], s0, s1);
-    for (uint32_t j = t; j < nbins; j += 512) cnt[j] = bin_total[(size_t)y * nbins + j];
-    __syncthreads();
-    msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, blockIdx.x == 0, offsets, buckets);     // cnt[j] = start of bin j in the partition
-    const uint32_t* mine = block_off + ((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins;      // + this workgroup's range inside each bin
-    for (uint32_t j = t; j < nbins; j += 512) cnt[j] += mine[j];
-    __syncthreads();
-    for (uint32_t e = s0 + t; e < s1; e += 512) {
-        const uint2 v = entries[e];
-        vals[beg + msm_wave_rank(cnt, v.y)] = v.x;
+    const uint32_t t = threadIdx.x, nbins = 1u << LB;
+    const uint32_t nbig = big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG;
+    for (uint32_t y = blockIdx.y; y < nbig; y += gridDim.y) {
+        const uint32_t p = big_list[y], beg = part_base[p + 1];
+        uint32_t s0, s1;
+        msm_big_slice(beg, part_base[p + 2], s0, s1);
+        for (uint32_t j = t; j < nbins; j += 512) cnt[j] = bin_total[(size_t)y * nbins + j];
+        __syncthreads();
+        msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, blockIdx.x == 0, offsets, buckets);     // cnt[j] = start of bin j in the partition
+        const uint32_t* mine = block_off + ((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins;      // + this workgroup's range inside each bin
+        for (uint32_t j = t; j < nbins; j += 512) cnt[j] += mine[j];
+        __syncthreads();
+        for (uint32_t e = s0 + t; e < s1; e += 512) {
+            const uint2 v = entries[e];
+            vals[beg + msm_wave_rank(cnt, v.y)] = v.x;
+        }
+        __syncthreads();
     }
 }
 
@@ -843,7 +862,10 @@ __global__ __launch_bounds__(64) void msm_reduce2_kernel(const g1x29_t* partA, c
     if (j == 0 && o < nout) st_g1x29((isA ? SA : T) + o, acc);
 }
 // one workgroup per plane: planes[0] = TOTAL; planes[1 + ws + j] = sum of the field sums whose digit has bit j
-__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes, uint32_t coop, size_t bstride) {
+// planes_host (optional): the group's landing buffer in page-locked host memory, 32 records per MSM -- the plane sums are written THERE as
+// well, straight from the kernel (144 bytes per plane over PCIe), so the host tail needs no copy command after the last kernel
+__global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, const g1x29_t* T, ReduceGeom g, g1x29_t* planes, g1x29_t* planes_host, uint32_t coop,
+                                                         size_t bstride) {
     BOFF(); BSH(SA); BSH(T); BSH(planes);
     __shared__ uint4 sh[9 * 4];
     uint32_t id = blockIdx.x, field = 0, j = 0;      // field 0: TOTAL, 1: A, 2: B, 3: C
@@ -869,7 +891,9 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, cons
     acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);
     if (threadIdx.x == 0) {
         const uint32_t ws = field == 1 ? g.wsA : field == 2 ? g.wsB : g.wsC;
-        st_g1x29(planes + (field == 0 ? 0u : 1u + ws + j), acc);
+        const uint32_t slot = field == 0 ? 0u : 1u + ws + j;
+        st_g1x29(planes + slot, acc);
+        if (planes_host) st_g1x29(planes_host + (size_t)blockIdx.z * 32 + slot, acc);
     }
 }
 
@@ -939,6 +963,7 @@ static int slot_prepare(MsmSlot& sl, size_t bytes, size_t msms = 1) {
             sl.pinned = nullptr;
         }
         EZ_HIP(hipHostMalloc((void**)&sl.pinned, msms * 32 * sizeof(g1x29_t), hipHostMallocDefault));
+        EZ_HIP(hipHostGetDevicePointer(&sl.pinned_dev, sl.pinned, 0));
         sl.pinned_msms = msms;
     }
     if (bytes > sl.scratch_bytes) {
@@ -1030,6 +1055,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     static const uint32_t lmin = [] { const char* e = getenv("EZKL_MSM_LMIN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_LMIN); }();
     // cooperative (quad) additions in the latency-bound trees (curve29.hpp: g1x29_add_quad); EZKL_MSM_COOP=0 restores the plain butterflies
     static const uint32_t coop = [] { const char* e = getenv("EZKL_MSM_COOP"); return (uint32_t)(e ? atoi(e) : 7); }();   // bit 0: reduce2, 1: planes, 2: heavy
+    // the planes kernel writes its sums into the slot's page-locked landing buffer itself (EZKL_MSM_ZEROCOPY=0: a copy command after it, as before round 5)
+    static const bool zero_copy = [] { const char* e = getenv("EZKL_MSM_ZEROCOPY"); return !(e && atoi(e) == 0); }();
     static const uint32_t span_heavy = [] { const char* e = getenv("EZKL_MSM_SPAN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_SPAN_HEAVY); }();
     // ---- field geometry of the reduce phase (positions: pos = (bucket & (NP-1)) << LB | bucket >> PB) ----
     ReduceGeom rg;
@@ -1126,8 +1153,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid, 1, Z), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
                        LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals, scal_list, bstride);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP, 1, Z), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs, vals, bkt, bstride);
-    hipLaunchKernelGGL(msm_bigsort_count_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, bstride);
-    hipLaunchKernelGGL(msm_bigsort_scatter_kernel, dim3(MSM_BIG_BLOCKS, MSM_MAX_BIG, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, offs,
+    hipLaunchKernelGGL(msm_bigsort_count_kernel, dim3(MSM_BIG_BLOCKS, MSM_BIG_ROWS, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, bstride);
+    hipLaunchKernelGGL(msm_bigsort_scatter_kernel, dim3(MSM_BIG_BLOCKS, MSM_BIG_ROWS, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, offs,
                        vals, bkt, bstride);
     // accumulate
     if (timed) EZ_HIP(hipEventRecord(a0, st));
@@ -1157,7 +1184,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         }
         const uint32_t blocksA = waves(nA, lanesA);
         hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT), 1, Z), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA, coop & 1u, bstride);
-        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, coop & 2u, bstride);
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, zero_copy ? (g1x29_t*)sl.pinned_dev : (g1x29_t*)nullptr,
+                           coop & 2u, bstride);
     }
     EZ_HIP(hipGetLastError());
     if (getenv("EZKL_MSM_DEBUG_PLANES")) {           // the planes of the cooperative and of the plain tree, side by side (first MSM of a group)
@@ -1165,7 +1193,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         EZ_HIP(hipStreamSynchronize(st));
         EZ_HIP(hipMemcpy(pc.data(), planes, pc.size() * 4, hipMemcpyDeviceToHost));
         EZ_HIP(hipMemsetAsync(planes, 0, pc.size() * 4, st));
-        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, 1), dim3(256), 0, st, SA, TT, rg, planes, 0u, (size_t)0);
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, 1), dim3(256), 0, st, SA, TT, rg, planes, (g1x29_t*)nullptr, 0u, (size_t)0);
         EZ_HIP(hipStreamSynchronize(st));
         EZ_HIP(hipMemcpy(pp.data(), planes, pp.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < nplanes; k++) {
@@ -1180,7 +1208,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         fprintf(stderr, "[msm] n=%zu W=%u bits=%u L=%u nlanes=%u heavy=%u\n", n, W, bits, L, nlanes, hc);
     }
     if (timed) EZ_HIP(hipEventRecord(m1, st));
-    for (size_t j = 0; j < count; j++)
+    for (size_t j = 0; j < count && !zero_copy; j++)
         EZ_HIP(hipMemcpyAsync(sl.pinned + j * 32 * 36, (uint8_t*)planes + j * bstride, (size_t)nplanes * sizeof(g1x29_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipEventRecord(sl.done, st));
     sl.bits = bits;
@@ -1280,12 +1308,17 @@ int msm_call_start(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bas
         for (int i = 0; i < MSM_CALL_SLOTS && k < 0; i++)
             if (!g_call_claimed[i]) k = i;
         if (k >= 0) break;
+        bool all_mine = true;                         // ... unless they are all in THIS thread's hands: nobody else will ever finish one
+        for (int i = 0; i < MSM_CALL_SLOTS; i++) all_mine = all_mine && g_call_owner[i] == std::this_thread::get_id();
+        if (all_mine) return EZKL_ERR_BUSY;
         lk.unlock();                                  // every call slot is in another thread's hands: let one finish
         std::this_thread::yield();
         lk.lock();
     }
     MsmSlot& sl = g_call_slots[k];
     g_call_claimed[k] = true;
+    g_call_finishing[k] = false;
+    g_call_owner[k] = std::this_thread::get_id();
     rc = slot_prepare(sl, 0);
     if (!rc) {                                        // ordered after what the library stream has been asked to do so far (the scalar column)
         hipError_t e = hipSuccess;
@@ -1295,19 +1328,22 @@ int msm_call_start(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bas
         if (e != hipSuccess) rc = set_hip_error(e, "msm_call_start", __FILE__, __LINE__);
     }
     if (!rc) rc = msm_enqueue(c, sl, sl.st, T, base_offset, &scalars, 1, n, true);
-    if (rc) { g_call_claimed[k] = false; return rc; }
+    if (rc) { g_call_claimed[k] = false; g_call_owner[k] = std::thread::id(); return rc; }
     *slot_out = k;
     return EZKL_OK;
 }
 int msm_call_finish(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, int k, void* out_host) {
     (void)c;
-    if (k < 0 || k >= MSM_CALL_SLOTS || !g_call_claimed[k]) return EZKL_ERR_INVALID;
+    if (k < 0 || k >= MSM_CALL_SLOTS || !g_call_claimed[k] || g_call_finishing[k] || !g_call_slots[k].busy) return EZKL_ERR_INVALID;
     MsmSlot& sl = g_call_slots[k];
+    g_call_finishing[k] = true;                       // the token is spent: a second finish (this thread or another) is refused
     lk.unlock();
     const int rc = msm_finish(sl, out_host, false);   // GPU wait + host Horner: no library state touched
     lk.lock();
     sl.busy = false;
+    g_call_finishing[k] = false;
     g_call_claimed[k] = false;
+    g_call_owner[k] = std::thread::id();
     return rc;
 }
 int msm_run_concurrent(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bases* b, size_t base_offset, const fe_t* scalars, size_t n, void* out_host) {

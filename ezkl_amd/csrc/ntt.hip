@@ -18,6 +18,11 @@
 #include "field29.hpp"
 #include <string.h>
 
+// EZKL_NTT_SKIP_UNIT2=1 (round 5): the stage-2 butterflies of a plain column transform whose twiddle is w_4^0 = 1 take no product
+#ifndef EZKL_NTT_SKIP_UNIT2
+#define EZKL_NTT_SKIP_UNIT2 1
+#endif
+
 namespace ezkl {
 
 // workgroup sizes: 256 threads for tiles of 1024 elements (and single-pass transforms), 512 / 1024 for the 2048- / 4096-element tiles of radix 2^9 / 2^10 passes
@@ -59,6 +64,8 @@ struct PassArgs {
 // decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The product comes first, so t < 2p whatever v was, a value grows by at most 4p per stage (< 54p after the 11 stages of the largest tile,
 // far below the 1000p the product accepts) and limbs grow by at most 2 units of 2^29 per stage: the only range control is ONE carry
 // propagation per element at the end of a two-stage register group -- no comparison, no conditional subtraction inside the transform.
+// (Round 5: half of the stage-2 butterflies of a plain transform have the twiddle 1 as well and take a carry pass instead of the product;
+// values then stay below 82p.)
 // Elements are 8 x 32-bit words in HBM (the files' 2^256 Montgomery domain, untouched: the twiddles carry the 2^261 of the product) and
 // 9 limbs in LDS (four 8-byte planes + one 4-byte plane); the inter-pass product brings a value back below 2p for the work buffer, the last
 // pass subtracts floor(top limb / (p >> 232)) p and once more p conditionally.  The stage-1 twiddles of a plain transform are 1: no product.
@@ -109,6 +116,15 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
                     const f29_t v = x[i + half];
                     x[i + half] = Fr29::sub<2>(x[i], v);
                     x[i] = Fr29::add(x[i], v);
+#if EZKL_NTT_SKIP_UNIT2
+                } else if (unit1 && st == 2 && (i & 1u) == 0) {      // stage 2 (always the second stage of the group s = 1: o = 0, h = 1): w_4^0 = 1
+                    // every other butterfly of stage 2 multiplies by 1: ONE carry pass instead of the product (24 instructions for 206).  The
+                    // partner came out of stage 1 (below 15p, loose limbs), so the subtraction borrows 32p; values then stay below
+                    // 46p + 4p per later stage (82p after the 11 stages of the largest tile; tools/ntt29_model.py SKIP_UNIT2)
+                    const f29_t v = Fr29::normalize(x[i + half]);
+                    x[i + half] = Fr29::sub<4>(x[i], v);
+                    x[i] = Fr29::add(x[i], v);
+#endif
                 } else {
                     const uint32_t off = o + (i & (half - 1)) * h;
                     const f29_t w = ld_f29(tw + base + off);

@@ -998,9 +998,38 @@ static Fe vk_digest(const ProvingKey& pk) {
     auto h = keccak256(t.data(), t.size());
     return Fe::from_canonical(reduce_fr(from_be32(h.data())));
 }
+// Before a key is built or loaded: will it fit?  The resident key is (fixed + permutation columns) x (values + coefficients + this rank's
+// cosets of the extended domain) + l_0 / l_last / l_active / X on those cosets, 32 bytes per element; a proof then needs its witness
+// columns in the same three forms next to it.  At k = 22 / 30 advice columns that is 175 of the 288 GB; k = 23, or a wider circuit at
+// k = 22, does not fit ONE GPU -- and used to say so only when some hipMalloc deep inside keygen failed.  Now the call fails up front, with
+// the sizes and the way out (owner mode over more GPUs divides the coset term by the world size).
+static void check_key_fits(const ConstraintSystem& cs, uint32_t coset_count, const char* what) {
+    const uint64_t n = cs.n, cols = (uint64_t)cs.n_fixed + cs.perm.size();
+    const uint64_t key = (cols * (2 + (uint64_t)coset_count) + 4ull * coset_count) * n * 32;
+    const uint64_t E = 1ull << (cs.ext_k - cs.k);
+    const uint64_t witness = ((uint64_t)cs.n_advice + 3ull * cs.lookups.size() + cs.n_chunks + 2) * (2 + E) * n * 32;   // advice, m / phi / compressed inputs, z, h
+    size_t free_b = 0, total_b = 0, pool[4] = {0, 0, 0, 0};
+    if (ezkl_hip_mem_info(&free_b, &total_b) != EZKL_OK) return;            // no device: the first kernel call reports it
+    (void)ezkl_hip_pool_stats(pool);
+    const uint64_t avail = (uint64_t)free_b + pool[2];                      // parked blocks of the column pool are reusable
+    if (key + witness <= avail) return;
+    char msg[512];
+    snprintf(msg, sizeof msg,
+             "%s: the proving key of this circuit needs %.1f GiB resident on the device (%llu key columns x 2^%u rows, %u of %llu cosets of the extended "
+             "domain 2^%u) and a proof about %.1f GiB more for its witness columns; %.1f GiB are available of %.1f GiB. Shard the key over more GPUs "
+             "(owner mode, ezkl_prover_cs_set_shard_exchange: the coset term divides by the world size) or lower logrows.",
+             what, key / 1073741824.0, (unsigned long long)cols, cs.k, coset_count, (unsigned long long)E, cs.ext_k, witness / 1073741824.0,
+             avail / 1073741824.0, total_b / 1073741824.0);
+    throw Error(EZKL_ERR_NOMEM, msg);
+}
 static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies) {
     const uint32_t n = cs.n, k = cs.k;
     Backend be(k, n, g, nullptr, cs.shard);
+    {
+        uint32_t first = 0, count = 0;
+        be.key_range(cs.ext_k, first, count);
+        check_key_fits(cs, count, "keygen");
+    }
     auto pk = std::make_unique<ProvingKey>();
     pk->cs = &cs;
     // EZKL_PROVER_KEYGEN_TIMING=1: stage times on stderr
@@ -1132,15 +1161,20 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
         put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(pk.sigma_cosets);
     } else {
         // a key held by owner (a range of cosets): the file still gets the complete extended columns, recomputed from the coefficient forms
-        auto full = [&](const std::vector<Col>& polys) {
-            std::vector<Col> out;
-            for (auto& p_ : polys) out.push_back(be.coeff_to_extended(p_, cs.ext_k));
-            return out;
+        // ... ONE column at a time (coefficients -> extended -> natural order -> host -> freed): materialising every extended column first
+        // was 35-39 GB of HBM at k = 22 on the rank whose key had deliberately been cut to 1 / world
+        auto put_ext_from_polys = [&](const std::vector<Col>& polys) {
+            put_be32(o, (uint32_t)polys.size());
+            for (size_t i = 0; i < polys.size(); i++) put_be32(o, (uint32_t)ne);
+            for (auto& p_ : polys) {
+                Col ext = be.coeff_to_extended(p_, cs.ext_k);
+                put_poly(nat(ext), ne);
+            }
         };
         auto lagf = [&](uint32_t lo, uint32_t hi) { return be.coeff_to_extended(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
         put_poly(nat(lagf(0, 1)), ne); put_poly(nat(lagf(cs.usable, cs.usable + 1)), ne); put_poly(nat(lagf(0, cs.usable)), ne);
-        put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_vec(full(pk.fixed_polys));
-        put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(full(pk.sigma_polys));
+        put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_from_polys(pk.fixed_polys);
+        put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_from_polys(pk.sigma_polys);
     }
     return o;
 }

@@ -434,12 +434,29 @@ int lookup_multiplicity_batch(Ctx* c, hipStream_t st, const fe_t* const* inputs,
     fe_t** d_outs = const_cast<fe_t**>(d_tables + n_lookups);
     uint32_t* d_which = reinterpret_cast<uint32_t*>(d + n_ptr * 8);
     uint32_t *slots = d_which + n_items, *counts = slots + (size_t)n_lookups * cap, *missing = missing_dev ? missing_dev : counts + (size_t)n_lookups * cstride;
-    if (n_items) {
-        EZ_HIP(hipMemcpyAsync(d_inputs, inputs, (size_t)n_items * 8, hipMemcpyHostToDevice, st));
-        EZ_HIP(hipMemcpyAsync(d_which, which, (size_t)n_items * 4, hipMemcpyHostToDevice, st));
+    // the caller's pointer / index arrays are temporaries (std::vector, ctypes arrays) and the stream-ordered form returns without
+    // synchronising: they travel through ONE pinned block the library owns (the layout of the device block's head: inputs, tables, outs,
+    // which), as the gate programs' arguments do (evalh.hip); without a block the copies are synchronised before returning
+    const size_t head = n_ptr * 8 + (size_t)n_items * 4;
+    void* stg = nullptr;
+    uint8_t* H = staging_acquire(c, head, &stg);
+    bool copies_pending_on_caller_memory = false;
+    if (H) {
+        if (n_items) memcpy(H, inputs, (size_t)n_items * 8);
+        memcpy(H + (size_t)n_items * 8, tables, (size_t)n_lookups * 8);
+        memcpy(H + ((size_t)n_items + n_lookups) * 8, m_outs, (size_t)n_lookups * 8);
+        if (n_items) memcpy(H + n_ptr * 8, which, (size_t)n_items * 4);
+        EZ_HIP(hipMemcpyAsync(d, H, head, hipMemcpyHostToDevice, st));
+        if ((rc = staging_release(stg, st))) return rc;
+    } else {
+        if (n_items) {
+            EZ_HIP(hipMemcpyAsync(d_inputs, inputs, (size_t)n_items * 8, hipMemcpyHostToDevice, st));
+            EZ_HIP(hipMemcpyAsync(d_which, which, (size_t)n_items * 4, hipMemcpyHostToDevice, st));
+        }
+        EZ_HIP(hipMemcpyAsync(d_tables, tables, (size_t)n_lookups * 8, hipMemcpyHostToDevice, st));
+        EZ_HIP(hipMemcpyAsync(d_outs, m_outs, (size_t)n_lookups * 8, hipMemcpyHostToDevice, st));
+        copies_pending_on_caller_memory = true;
     }
-    EZ_HIP(hipMemcpyAsync(d_tables, tables, (size_t)n_lookups * 8, hipMemcpyHostToDevice, st));
-    EZ_HIP(hipMemcpyAsync(d_outs, m_outs, (size_t)n_lookups * 8, hipMemcpyHostToDevice, st));
     EZ_HIP(hipMemsetAsync(slots, 0xff, (size_t)n_lookups * cap * 4, st));
     EZ_HIP(hipMemsetAsync(counts, 0, ((size_t)n_lookups * cstride + (missing_dev ? 0 : 1)) * 4, st));
     if (usable) {
@@ -451,6 +468,7 @@ int lookup_multiplicity_batch(Ctx* c, hipStream_t st, const fe_t* const* inputs,
     hipLaunchKernelGGL(counts_to_fr_kernel, dim3(cdiv(n_rows, 256), n_lookups), dim3(256), 0, st, (const uint32_t*)counts, n_rows, cstride, (fe_t* const*)d_outs);
     hipError_t e = hipGetLastError();
     if (missing_dev) {
+        if (e == hipSuccess && copies_pending_on_caller_memory) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return set_hip_error(e, "lookup_multiplicity", __FILE__, __LINE__);
         return arena_done(c->aux, st);
     }

@@ -321,8 +321,12 @@ def verify(proof_path, compiled_circuit, vk_path=None, srs_path=None, recommit=F
     pr = codecs.read_proof_json(open(proof_path).read())
     srs = codecs.read_srs(open(srs_path, "rb").read())
     if recommit:
-        vk_len = 7 + 64 * (_plonk_cs(circuit).n_fixed + len(_plonk_cs(circuit).perm))
-        if os.path.getsize(vk_path) < 4 * vk_len:                               # a vk-only file has no polynomials to commit again
+        cs_ = _plonk_cs(circuit)
+        # the exact length of a vk.key of this constraint system (codecs.py): header, the fixed + permutation commitments AND the bit-packed
+        # selector rows (80 selectors at k = 20 are 10 MB: ADVICE r04 -- a bound without them let a vk-only file through to a later,
+        # misleading "proving key truncated")
+        vk_len = 7 + 64 * (cs_.n_fixed + len(cs_.perm)) + cs_.n_selectors * (((1 << cs_.k) + 7) // 8)
+        if os.path.getsize(vk_path) <= vk_len:                                  # a vk-only file has no polynomials to commit again
             raise ValueError("recommit=True needs the PROVING key file (its polynomials are committed again under this SRS); %s is a verifying key" % vk_path)
     if not recommit:
         return NV.verify_proof_vk(NV.NativeCircuit(_plonk_cs(circuit)), open(vk_path, "rb").read(), srs["g2"], srs["s_g2"], pr["proof"], pr["instances"])

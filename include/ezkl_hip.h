@@ -31,6 +31,7 @@ extern "C" {
 #define EZKL_ERR_INVALID (-3)     /* bad argument (null pointer, size out of range, bad program) */
 #define EZKL_ERR_NOMEM (-4)
 #define EZKL_ERR_UNSUPPORTED (-5)
+#define EZKL_ERR_BUSY (-6)        /* the calling thread already holds every slot of a bounded resource (ezkl_hip_msm_g1_start_dev: four per context) */
 
 typedef struct ezkl_bases_s* ezkl_bases_t;     /* device-resident G1 base set (SRS g or g_lagrange) */
 
@@ -150,7 +151,9 @@ int ezkl_hip_msm_g1_batch(ezkl_bases_t h, const void* const* scalars, size_t bat
 /* One MSM in two halves: start queues it behind what the library stream has been asked to do so far (the scalar column may still be in
  * the making there) and returns a token; finish waits and writes the 64-byte affine point.  In between the caller may issue any other
  * call of this header -- commit batches and upload phases included: the MSM runs on a call slot with its own stream and scratch.  At most
- * four may be in flight per context.  (The prover commits the vanishing argument's random polynomial, which depends on nothing but the
+ * four may be in flight per context: a fifth start WAITS while other threads hold the slots, and returns EZKL_ERR_BUSY when the calling
+ * thread itself holds all four (it could never finish one).  finish takes a token exactly once, from any thread; a token that is not in
+ * flight (never started, already finished, being finished by another thread) is EZKL_ERR_INVALID.  (The prover commits the vanishing argument's random polynomial, which depends on nothing but the
  * randomness, under the upload of the witness: halo2 draws it at the same place of the RNG stream either way.) */
 int ezkl_hip_msm_g1_start_dev(ezkl_bases_t h, size_t base_offset, const void* scalars_dev, size_t n, int* token);
 int ezkl_hip_msm_g1_finish(int token, void* out_affine);
@@ -355,9 +358,14 @@ int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes_per_rank);
  * windows) of the columns it transformed to the ranks that sweep those rows with ONE such call.  Wire format: a device gather kernel packs
  * each peer's stream into a slab (rounds of at most EZKL_COMM_SLAB_MB, default 128 MiB, per peer and direction; the same on every rank),
  * ONE ncclSend + ONE ncclRecv per peer and round inside one group (all xGMI links at once), a scatter kernel unpacks.  Bytes to the own
- * rank are copied by the same kernel.  EZKL_COMM_UNPACKED=1: one ncclSend / ncclRecv per segment (round 3; sizes must then agree pairwise).
+ * rank are copied by the same kernel.  Segments may have any address and length: 16-byte aligned pieces (the prover's field columns) move
+ * as vectors, others byte by byte, in the SAME wire format -- which format is used never depends on what one rank sees.  EZKL_COMM_UNPACKED=1
+ * (set it on every rank or on none): one ncclSend / ncclRecv per segment (round 3; sizes must then agree pairwise).
  * ezkl_hip_comm_stats: out[0] = exchanges, out[1] / out[2] = bytes sent to / received from other ranks, out[3] = microseconds of host wall
  * time inside the exchanges, out[4] / out[5] = ncclSend / ncclRecv operations issued, out[6] = rounds; reset != 0 clears them. */
+/* EZKL_OK when librccl can be loaded (from the directory of the HIP runtime this library is bound to) and exports every entry point the
+ * communicator binds; EZKL_ERR_UNSUPPORTED otherwise.  Touches no device and calls nothing in RCCL. */
+int ezkl_hip_comm_available(void);
 typedef struct { int peer; void* ptr; size_t bytes; } ezkl_comm_seg_t;
 int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs);
 int ezkl_hip_comm_stats(uint64_t out[8], int reset);
@@ -365,6 +373,10 @@ int ezkl_hip_comm_stats(uint64_t out[8], int reset);
 /* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
 /* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */
 int ezkl_hip_last_kernel_ms(const char* which, float* out_ms);
+/* sum and count of the device milliseconds of EVERY region `which` recorded since the last reset (each call records into an event pair
+ * of its own, a ring of 64 per region): a caller can queue K steps back to back and read their kernel times afterwards, without a host
+ * synchronisation inside its timed loop.  Waits for the pairs still in flight.  A region that never ran: sum 0, count 0. */
+int ezkl_hip_kernel_ms_stats(const char* which, double* sum_ms, uint64_t* count, int reset);
 /* microbenchmarks: which = "modmul" (Montgomery products/s), "mad64" (v_mad_u64_u32/s),
  * "copy" (HBM float4 copy bytes/s); result in *out (per second) */
 int ezkl_hip_ubench(const char* which, double* out);

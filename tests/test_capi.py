@@ -20,11 +20,20 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.SYMBOLS)
 
 
+def test_rccl_resolves_every_symbol_the_communicator_binds():
+    """comm.hip dlopens librccl next to the HIP runtime and dlsyms nine entry points; a missing library or symbol must show HERE (a build
+    box without a GPU), not in the first 8-rank run.  Nothing in RCCL is called and no device is touched."""
+    assert L.load().ezkl_hip_comm_available() == 0
+    maps = open("/proc/self/maps").read()
+    assert "librccl" in maps
+
+
 def test_strerror_and_version():
     lib = L.load()
     assert lib.ezkl_hip_strerror(0) == b"ok"
     assert b"no HIP device" in lib.ezkl_hip_strerror(-1)
     assert b"gfx950" in lib.ezkl_hip_version()
+    assert b"calling thread" in lib.ezkl_hip_strerror(-6)
 
 
 def test_runtime_gate(monkeypatch):

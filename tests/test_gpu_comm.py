@@ -74,6 +74,22 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
         finally:
             del os.environ["EZKL_COMM_SELF_VIA_RCCL"]; del os.environ["EZKL_COMM_SLAB_MB"]
         assert (np.concatenate([d_.to_numpy() for d_ in dst2]) == np.concatenate([s_.to_numpy() for s_ in src])).all()
+        # segments of ANY address and length take the same packed wire format (an unaligned segment used to switch THIS rank to the
+        # per-segment format while its aligned peers kept the slabs -- a hang): odd lengths at odd offsets through the slabs and RCCL
+        raw = B.DeviceBuffer.from_numpy(rng.integers(0, 255, 1 << 16, dtype=np.uint8))
+        out_ = B.DeviceBuffer.from_numpy(np.zeros(1 << 16, np.uint8))
+        segs = [(3, 1001), (1004 + 13, 7), (5000, 4096 + 5), (20001, 33)]                 # (offset, bytes): nothing 16-byte aligned
+        os.environ["EZKL_COMM_SELF_VIA_RCCL"] = "1"
+        B.comm_stats(reset=True)
+        try:
+            B.comm_alltoallv_dev([(0, raw.ptr + o, n_) for o, n_ in segs], [(0, out_.ptr + o + 1, n_) for o, n_ in segs])
+        finally:
+            del os.environ["EZKL_COMM_SELF_VIA_RCCL"]
+        st = B.comm_stats()
+        assert st["nccl_sends"] == 1 and st["nccl_recvs"] == 1 and st["rounds"] == 1, st          # the slab format, not one send per segment
+        a_, o_ = raw.to_numpy(dtype=np.uint8), out_.to_numpy(dtype=np.uint8)
+        for o, n_ in segs:
+            assert (o_[o + 1:o + 1 + n_] == a_[o:o + n_]).all(), (o, n_)
         # the C++ host prover over the library communicator: same bytes as the unsharded prover
         cs = TP.lookup_circuit(6)
         adv, fixed, copies = TP.lookup_witness(cs, 4)

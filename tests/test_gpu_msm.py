@@ -566,3 +566,39 @@ def test_g2_msm_matches_the_oracle_and_the_host_pairing_code(hip):
     benc = [enc(p) for p in base]
     got2 = B.msm_g2(np.stack([benc[i] for i in idx]), np.stack([fe_from_int(s) for s in sc2]))
     assert dec(got2) == want2
+
+
+def test_start_finish_tokens_busy_and_spent(hip):
+    """ezkl_hip_msm_g1_start_dev / _finish: four call slots per context -- a fifth start from the thread that holds all four is
+    EZKL_ERR_BUSY (-6), not an endless spin; a token is spent by its first finish (a second one, or one never started, is EZKL_ERR_INVALID);
+    the results are the synchronous call's; and the kernel-time statistics count every region exactly once"""
+    from ezkl_amd import backend as B
+    from ezkl_amd.lib import EzklHipError
+    n = 1 << 14
+    rng = np.random.default_rng(21)
+    pts = ob.gen_bases(SEED + 3, n)
+    bases = B.Bases(pts)
+    cols = [rand_fr(rng, n) for _ in range(4)]
+    devs = [B.DeviceBuffer.from_numpy(c) for c in cols]
+    want = [ob.msm(c, pts) for c in cols]
+    B.msm_g1_dev(bases, devs[0].ptr, n)                                  # tables
+    B.kernel_ms_stats("msm", reset=True)
+    toks = [B.msm_g1_start_dev(bases, d.ptr, n) for d in devs]
+    assert sorted(toks) == [0, 1, 2, 3]
+    with pytest.raises(EzklHipError) as e:
+        B.msm_g1_start_dev(bases, devs[0].ptr, n)
+    assert e.value.code == -6
+    got = {t: B.msm_g1_finish(t) for t in reversed(toks)}                 # any order
+    assert all((got[t] == w).all() for t, w in zip(toks, want))
+    for bad in (toks[0], 7, -1):
+        with pytest.raises(EzklHipError) as e:
+            B.msm_g1_finish(bad)
+        assert e.value.code == -3
+    t = B.msm_g1_start_dev(bases, devs[1].ptr, n)                         # the slots are free again
+    assert (B.msm_g1_finish(t) == want[1]).all()
+    total_ms, count = B.kernel_ms_stats("msm")
+    assert count == 5 and total_ms > 0
+    assert abs(B.last_kernel_ms("msm") - total_ms / 5) < total_ms         # the newest pair is readable on its own
+    assert B.kernel_ms_stats("msm", reset=True)[1] == 5 and B.kernel_ms_stats("msm") == (0.0, 0)
+    assert B.kernel_ms_stats("no such region") == (0.0, 0)
+    bases.free()

@@ -411,3 +411,44 @@ def test_bench_contract_two_ranks(hip):
     assert j["prove"]["sharding"] == "columns and arguments by owner"         # NTTs by columns, arguments by owner, one all-to-all for the sweep
     assert all(r["stats"]["exchange_bytes_received"] > 0 and r["stats"]["columns_transformed_here"] < r["stats"]["witness_columns"] for r in j["prove"]["per_rank"])
     assert j["prove"]["prove_seconds_gpu"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [8, 3])
+def test_bench_contract_eight_and_three_ranks_on_one_device(hip, world):
+    """first contact for the driver's 8-rank run, as far as one GPU allows: `bench.py --gpus N` under torchrun with N = 8
+    and a world that is not a power of two, every rank on GPU 0 over gloo: ONE JSON line, the whole-job value of N ranks, the strong-scaling
+    MSMs cut into N unequal point ranges, and the sharded end-to-end prove (k = 14 here: eight provers share one device) emitting the same
+    proof on every rank"""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="300", EZKL_BENCH_MULTI_MLP20="0", EZKL_BENCH_MULTI_K="14")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29570 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--share-device"], env=env, capture_output=True, text=True, timeout=900)
+    objs = json_lines(r.stdout)
+    assert len(objs) == 1, r.stderr[-2000:]
+    j = objs[0]
+    assert j["n_gpus"] == world and j["steps"] == 2 and j["scaling"] == "weak"
+    assert abs(j["value"] - world * (1 << 20) * 2 / (j["ms_per_step"] * 2e-3)) < 1e-3 * j["value"]
+    strong = j["extra"]["msm_strong_scaling"]
+    assert "error" not in strong and strong["2^20"]["points_per_rank"] in ((1 << 20) // world, (1 << 20) // world + 1)
+    p = j["prove"]
+    assert "error" not in p, p
+    assert p["n_gpus"] == world and p["all_ranks_same_proof"] is True and p["verifier_accepts"] is True
+    assert len(p["per_rank"]) == world
+
+
+@pytest.mark.gpu
+def test_bench_rank_failure_ends_the_job(hip):
+    """a rank that dies before the first collective must end the job, not hang it: torchrun tears the other ranks down and exits non-zero
+    well inside the timeout, and no JSON line is printed (EZKL_BENCH_FAIL_RANK is the test hook in bench.py)"""
+    import os, subprocess, sys, time
+    from conftest import ROOT
+    env = dict(os.environ, EZKL_BENCH_FAIL_RANK="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29569", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--backend", "gloo", "--share-device", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not json_lines(r.stdout)
+    assert time.time() - t0 < 300

@@ -18,14 +18,23 @@ if "msm" in what:
     bases = B.Bases.generate(0x657a6b6c, n)
     sc = B.DeviceBuffer.from_numpy(rand(n))
     for _ in range(150): B.msm_g1_dev(bases, sc.ptr, n)
-    B.synchronize(); t0 = time.perf_counter(); ms = []
-    for _ in range(steps): B.msm_g1_dev(bases, sc.ptr, n); ms.append(B.last_kernel_ms("msm"))
-    B.synchronize(); print("msm 2^20: wall %.4f ms/step, device %.4f ms (min %.4f)" % ((time.perf_counter() - t0) / steps * 1e3, np.mean(ms), np.min(ms)))
+    B.synchronize(); B.kernel_ms_stats("msm", reset=True); B.kernel_ms_stats("msm_accumulate", reset=True); t0 = time.perf_counter()
+    for _ in range(steps): B.msm_g1_dev(bases, sc.ptr, n)
+    B.synchronize(); wall = (time.perf_counter() - t0) / steps * 1e3
+    (ms, cnt), (acc, _) = B.kernel_ms_stats("msm"), B.kernel_ms_stats("msm_accumulate")
+    print("msm 2^20: wall %.4f ms/step, device %.4f ms, accumulate %.4f ms (%d steps)" % (wall, ms / cnt, acc / cnt, cnt))
 if "ntt" in what:
     k = 22
     dom = ezkl_amd.EvaluationDomain(2, k)
     col = B.DeviceBuffer.from_numpy(rand(1 << k))
     for _ in range(200): B.ntt_dev(col.ptr, k, dom.omega)
-    B.synchronize(); t0 = time.perf_counter(); ms = []
-    for _ in range(steps): B.ntt_dev(col.ptr, k, dom.omega); ms.append(B.last_kernel_ms("ntt"))
-    B.synchronize(); print("ntt 2^22: wall %.4f ms/step, device %.4f ms (min %.4f)" % ((time.perf_counter() - t0) / steps * 1e3, np.mean(ms), np.min(ms)))
+    B.synchronize(); B.kernel_ms_stats("ntt", reset=True); t0 = time.perf_counter()
+    for _ in range(steps): B.ntt_dev(col.ptr, k, dom.omega)
+    B.synchronize(); wall_sync = (time.perf_counter() - t0) / steps * 1e3
+    ms, cnt = B.kernel_ms_stats("ntt", reset=True)
+    was = B.set_async(True); t0 = time.perf_counter()                       # queued stream-ordered, one synchronise at the end (bench.py's NTT region)
+    for _ in range(steps): B.ntt_dev(col.ptr, k, dom.omega)
+    B.synchronize(); wall_async = (time.perf_counter() - t0) / steps * 1e3
+    B.set_async(was)
+    ms2, cnt2 = B.kernel_ms_stats("ntt")
+    print("ntt 2^22: wall %.4f ms/step synchronous, %.4f ms/step queued; device %.4f / %.4f ms (%d + %d steps)" % (wall_sync, wall_async, ms / cnt, ms2 / cnt2, cnt, cnt2))

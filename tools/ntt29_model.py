@@ -65,7 +65,8 @@ def subc(K):
     return c
 
 
-SUBC = {K: subc(K) for K in (2, 4, 8, 16)}
+SUBC = {K: subc(K) for K in (2, 4, 8, 16, 32)}
+SKIP_UNIT2 = True          # stage 2 of a plain transform: the twiddle of every other butterfly is w_4^0 = 1 -- no product (ntt.hip, round 5)
 
 
 def sub(a, b, K):
@@ -188,6 +189,12 @@ def dit_column(col, log_r, table, unit1, stats=None):
                     if unit1 and st == 1:
                         v = x[i + half]
                         lo = sub(x[i], v, 8)
+                    elif SKIP_UNIT2 and unit1 and st == 2 and (i & 1) == 0:
+                        # w_4^0 = 1: the partner came out of stage 1 (below 2^256 + 15p, loose limbs) -- one carry pass instead of a product,
+                        # and the subtraction borrows 32p
+                        assert s == 1 and off == 0
+                        v = normalize(x[i + half])
+                        lo = sub(x[i], v, 32)
                     else:
                         assert max(x[i + half]) < 6.1 * (1 << 29)
                         v = mont_mul(x[i + half], table[base + off])

@@ -12,8 +12,21 @@ re-calibrated IN THE SAME RUN with kernels of known byte counts:
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python $R/tools/pmc_probe.py
     python tools/pmc_reduce.py <fetch csv> <write csv> profiles/pmc_traffic.json "<label>"
 """
-import csv, json, sys
+import csv, hashlib, json, os, subprocess, sys
 from collections import defaultdict
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def stamp():
+    """what ties the figures to the kernels they were measured on: the SHA-256 of the kernel sources the probe's library was built from, and
+    the commit (bench.py refuses a figure whose msm.hip / ntt.hip hash differs from the tree it runs in)"""
+    sha = {f: hashlib.sha256(open(os.path.join(ROOT, "ezkl_amd", "csrc", f), "rb").read()).hexdigest() for f in ("msm.hip", "ntt.hip", "field29.hpp", "curve29.hpp")}
+    try:
+        commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    return sha, commit
 
 
 def load(path):
@@ -43,7 +56,10 @@ gather_bytes = 256 * 16 * 256 * 32 * 64.0
 gather_factor = gather_bytes / gath_f
 acc_f, acc_w = mean_last(fetch["ezkl::msm_accumulate_kernel"], 3), mean_last(write["ezkl::msm_accumulate_kernel"], 3)
 ntt_f, ntt_w = mean_last(fetch["ezkl::ntt_pass_kernel"], 9), mean_last(write["ezkl::ntt_pass_kernel"], 9)
+_sha, _commit = stamp()
 out = {
+    "kernel_sources_sha256": _sha,
+    "commit": _commit or os.environ.get("EZKL_COMMIT"),
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_probe.py, " + (sys.argv[4] if len(sys.argv) > 4 else ""),
     "units": "bytes per launch",
     "calibration": {"stream_copy_1GiB_FETCH_SIZE_bytes": copy_f, "stream_factor": stream_factor, "gather64_FETCH_SIZE_bytes": gath_f,
