@@ -292,6 +292,9 @@ def main():
             c20 = m20.get("cold") or {}
             out["prove_seconds_k20_mlp"] = {"gpu": m20.get("prove_seconds_gpu"), "gpu_is": "best of %s warm proofs: SRS, key, window tables and JIT code resident, witness laid out in pinned memory" % len(m20.get("prove_seconds_gpu_runs") or []),
                                             "gpu_runs": m20.get("prove_seconds_gpu_runs"), "gpu_first_of_process": m20.get("first_prove_seconds_gpu"),
+                                            # the same proof from the witness handed over as int64 IntegerRep columns (8 B per cell across PCIe, ezkl_prover_create_proof_fmt)
+                                            "gpu_integer_rep_advice": (m20.get("integer_rep_advice") or {}).get("prove_seconds_gpu"),
+                                            "gpu_integer_rep_advice_same_bytes": (m20.get("integer_rep_advice") or {}).get("same_proof_bytes"),
                                             # the CLI-equivalent one-shot: a FRESH process reads SRS + pk + witness files into HBM, proves once, writes proof.json
                                             "cold": c20.get("cold_seconds"), "cold_first_ever": c20.get("first_ever_cold_seconds"), "cold_stages": c20.get("stages"),
                                             "cold_same_proof_as_warm": c20.get("same_proof_as_warm"),
@@ -437,8 +440,8 @@ def prove_leg():
             with_cpu = os.environ.get("EZKL_BENCH_MLP20_CPU", "1") != "0" and left() > 95
             # + the cold one-shot of the metric's own circuit (artefact files -> a fresh process -> proof.json): ~30 s more
             with_cold = os.environ.get("EZKL_BENCH_MLP20_COLD", "1") != "0" and left() > (95 if with_cpu else 25) + 40
-            j = child("mlp_k20", {"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned"] + (["--cpu"] if with_cpu else []) + (["--cold"] if with_cold else []), 900)
-            out["mlp_k20"] = shape(j, ["sweep_kernel"])
+            j = child("mlp_k20", {"CIRCUIT": "mlp", "K": "20", "REPS": "3"}, ["--pinned", "--integer-rep"] + (["--cpu"] if with_cpu else []) + (["--cold"] if with_cold else []), 900)
+            out["mlp_k20"] = shape(j, ["sweep_kernel", "integer_rep_advice"])
             if not with_cpu:
                 skipped.append("mlp_k20 CPU prover")
             if not with_cold:

@@ -765,6 +765,17 @@ int ezkl_hip_upload_begin(const void* const* host_cols, void* const* dev_cols, s
     if (!rc) *out = reinterpret_cast<ezkl_upload_t>(u);
     return rc;
 }
+int ezkl_hip_upload_begin_fmt(const void* const* host_cols, const uint8_t* formats, void* const* dev_cols, size_t batch, size_t n, const void* const* tail_rows,
+                              size_t tail_start, size_t tail_count, ezkl_upload_t* out) {
+    if (!out || !upload_args_ok(host_cols, dev_cols, batch, tail_rows, tail_count)) return EZKL_ERR_INVALID;
+    for (size_t j = 0; formats && j < batch; j++)
+        if (formats[j] > EZKL_COLUMN_INT128) return EZKL_ERR_INVALID;
+    EZ_CTX(c);
+    MsmUpload* u = nullptr;
+    int rc = msm_upload_begin(c, (const fe_t* const*)host_cols, (fe_t* const*)dev_cols, batch, n, (const fe_t* const*)tail_rows, tail_start, tail_count, &u, formats);
+    if (!rc) *out = reinterpret_cast<ezkl_upload_t>(u);
+    return rc;
+}
 int ezkl_hip_upload_wait(ezkl_upload_t u, size_t column, void* stream) {
     if (!u || !stream) return EZKL_ERR_INVALID;
     EZ_CTX(c);

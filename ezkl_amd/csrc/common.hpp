@@ -131,7 +131,7 @@ int msm_run_batch(Ctx* c, hipStream_t st, const Bases* b, size_t base_offset, co
                   void* out_host, bool small_scalars = false);
 struct MsmUpload;
 int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails, size_t tail_start,
-                     size_t tail_count, MsmUpload** out);
+                     size_t tail_count, MsmUpload** out, const uint8_t* formats = nullptr);
 int msm_upload_wait(MsmUpload* u, size_t j, hipStream_t st);
 int msm_upload_commit(Ctx* c, MsmUpload* u, const Bases* b, size_t commit_first, size_t commit_count, void* out_host);
 int msm_upload_end(MsmUpload* u);

@@ -1397,6 +1397,7 @@ struct MsmUpload {
     std::vector<fe_t*> dev_cols;
     size_t n = 0;
     bool broken = false;
+    uint64_t* stage = nullptr;       // integer columns as they crossed PCIe (msm_expand_integer_rep_kernel reads them); freed by msm_upload_end
 };
 int msm_upload_end(MsmUpload* u) {
     if (!u || u != g_open_upload) return EZKL_ERR_INVALID;
@@ -1411,12 +1412,36 @@ int msm_upload_end(MsmUpload* u) {
             (void)hipEventDestroy(u->ev[j]);
         }
     g_open_upload = nullptr;
+    if (u->stage) (void)ezkl_hip_free(u->stage);     // back to the column pool; every expansion kernel has run (its column's event was waited for above)
     delete u;
     if (e != hipSuccess) return set_hip_error(e, "msm_upload_end", __FILE__, __LINE__);
     return EZKL_OK;
 }
+// ---- witness columns handed over as INTEGERS (ezkl's IntegerRep, /root/reference/src/fieldutils.rs:6-17: every cell of an ezkl advice column
+// is integer_rep_to_felt of an i128 -- the quantised tensor values -- before it becomes 32 bytes of Montgomery form).  PCIe is the
+// scarce link of the advice phase (12 columns x 32 MB at ~53 GB/s = 7 ms of a 67 ms proof), so a column may cross it as 8 or 16 bytes
+// per cell and is expanded HERE: x >= 0 -> x, x < 0 -> r - |x| (integer_rep_to_felt), then x * 2^256 mod r (one product per cell).
+// format: 0 = 32-byte Montgomery words (halo2's Vec<Fp>), 1 = int64, 2 = int128 (little-endian two's complement).
+__global__ __launch_bounds__(256) void msm_expand_integer_rep_kernel(const uint64_t* src, uint32_t words, fe_t* dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo = src[i * words], hi = words == 2 ? src[i * 2 + 1] : (uint64_t)((int64_t)lo >> 63);
+    const bool neg = (int64_t)hi < 0;
+    if (neg) {                                            // |x| (two's complement; IntegerRep::MIN = 2^127 is its own magnitude)
+        lo = ~lo + 1;
+        hi = ~hi + (lo == 0 ? 1 : 0);
+    }
+    fe_t v = Fr::zero();
+    v.v[0] = (uint32_t)lo; v.v[1] = (uint32_t)(lo >> 32); v.v[2] = (uint32_t)hi; v.v[3] = (uint32_t)(hi >> 32);
+    if (neg && (lo | hi)) {                               // r - |x|
+        uint32_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.v[k] = subb32(FrP::MOD[k], v.v[k], br);
+    }
+    st_fe(dst + i, Fr::to_mont(v));
+}
 int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols, size_t batch, size_t n, const fe_t* const* tails, size_t tail_start,
-                     size_t tail_count, MsmUpload** out) {
+                     size_t tail_count, MsmUpload** out, const uint8_t* formats) {
     if (g_open_upload || g_open_batch_fwd()) return EZKL_ERR_INVALID;
     if (n == 0 || tail_start + tail_count > n) return EZKL_ERR_INVALID;
     if (!g_copy_st) EZ_HIP(hipStreamCreateWithFlags(&g_copy_st, hipStreamNonBlocking));
@@ -1432,9 +1457,29 @@ int msm_upload_begin(Ctx* c, const fe_t* const* host_cols, fe_t* const* dev_cols
     u->ev.assign(batch, nullptr);
     u->dev_cols.assign(dev_cols, dev_cols + batch);
     g_open_upload = u;
+    size_t stage_words = 0, stage_off = 0;
+    for (size_t j = 0; formats && j < batch; j++) {
+        if (formats[j] > 2) { g_open_upload = nullptr; delete u; return EZKL_ERR_INVALID; }
+        stage_words += n * formats[j];
+    }
+    if (stage_words) {
+        // from the column pool (ezkl_hip_malloc: a block of this size is parked after the first proof; hipMalloc / hipFree would synchronise the device)
+        const int rc_ = ezkl_hip_malloc((void**)&u->stage, stage_words * 8);
+        if (rc_) { g_open_upload = nullptr; delete u; return rc_; }
+    }
     for (size_t j = 0; j < batch; j++) {
         hipError_t e = hipEventCreateWithFlags(&u->ev[j], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMemcpyAsync(dev_cols[j], host_cols[j], n * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);
+        const uint32_t words = formats ? formats[j] : 0;                 // 64-bit words per cell of an integer column (0: 32-byte field elements)
+        if (e == hipSuccess && words) {
+            // a staging block per integer column (expanding inside the destination column would race its own reads)
+            uint64_t* stage = u->stage + stage_off;
+            stage_off += n * words;
+            e = hipMemcpyAsync(stage, host_cols[j], n * words * 8, hipMemcpyHostToDevice, g_copy_st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(msm_expand_integer_rep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, g_copy_st, (const uint64_t*)stage, words, dev_cols[j], n);
+                e = hipGetLastError();
+            }
+        } else if (e == hipSuccess) e = hipMemcpyAsync(dev_cols[j], host_cols[j], n * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);
         if (e == hipSuccess && tails && tail_count) {
             memcpy(g_tail_pinned + j * tail_count, tails[j], tail_count * sizeof(fe_t));
             e = hipMemcpyAsync(dev_cols[j] + tail_start, g_tail_pinned + j * tail_count, tail_count * sizeof(fe_t), hipMemcpyHostToDevice, g_copy_st);

@@ -1916,7 +1916,8 @@ static int64_t centred(int64_t rot, int64_t n) {
     return r > n / 2 ? r - n : r;
 }
 static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_bases_t gl, const void* const* advice, ezkl_advice_fn advice_fn, void* advice_user,
-                                         const void* const* instances, const uint32_t* instance_lens, Rng& rng, double* timings) {
+                                         const void* const* instances, const uint32_t* instance_lens, Rng& rng, double* timings,
+                                         const uint8_t* advice_formats = nullptr) {
     ConstraintSystem& cs = *pk.cs;
     const uint32_t n = cs.n, k = cs.k, u = cs.usable;
     // the helper chains of a proof are hundreds of small device-only calls: queued on the library stream without a host round trip
@@ -2054,13 +2055,25 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             devp.push_back(adv_cols[c]->ptr());
         }
         for (auto& t : tails) tailp.push_back(t.data());
+        // what each host column holds (ezkl_hip_upload_begin_fmt): 32-byte Fp words, or the IntegerRep values they were made from
+        std::vector<uint8_t> fmts;
+        if (advice_formats) {
+            for (size_t j = 0; j < idxs.size(); j++) {
+                if (up_of[j] == SIZE_MAX) continue;
+                const uint8_t f = advice_formats[idxs[j]];
+                invalid(f > EZKL_COLUMN_INT128, "unknown advice column format");
+                invalid(f != EZKL_COLUMN_FP && advice_fn && !cs.advice_by_pointer, "integer advice columns need caller-owned buffers (direct pointers, or a by-pointer callback)");
+                fmts.push_back(f);
+            }
+        }
         std::vector<G1> commits(idxs.size());
         const bool by_batch = cs.shard.on() && cs.shard.full_bases;       // sharded with complete base sets: commit after the copies have landed
         {
             // the phase in steps (ezkl_hip_upload_commit_batch in one call): every copy is queued, the NTTs of column j are queued
             // behind ITS copy on the aux stream, then the commits run -- PCIe, MSMs and NTTs overlap
             ezkl_upload_t up = nullptr;
-            check(ezkl_hip_upload_begin(hostp.data(), devp.data(), hostp.size(), n, tailp.data(), u, n - u, &up), "ezkl_hip_upload_begin");
+            check(ezkl_hip_upload_begin_fmt(hostp.data(), fmts.empty() ? nullptr : fmts.data(), devp.data(), hostp.size(), n, tailp.data(), u, n - u, &up),
+                  "ezkl_hip_upload_begin_fmt");
             int rc = EZKL_OK;
             for (size_t j = 0; j < idxs.size(); j++)
                 if (topo.mine(j)) adv_forms[idxs[j]] = be.forms_alloc(cs.ext_k);     // before the copies are in flight
@@ -2992,6 +3005,12 @@ int ezkl_prover_pk_set_transcript_repr(ezkl_pk_t h, const void* repr) {
 int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, ezkl_advice_fn advice_fn, void* advice_user,
                              const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng, void* rng_user, uint64_t seed, void* proof_out,
                              size_t cap, size_t* proof_len, double* timings) {
+    return ezkl_prover_create_proof_fmt(pk, g, g_lagrange, advice, nullptr, advice_fn, advice_user, instances, instance_lens, rng, rng_user, seed, proof_out, cap,
+                                        proof_len, timings);
+}
+int ezkl_prover_create_proof_fmt(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, const uint8_t* advice_formats,
+                                 ezkl_advice_fn advice_fn, void* advice_user, const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng,
+                                 void* rng_user, uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings) {
     if (!pk || !g || !g_lagrange || !proof_len) return EZKL_ERR_INVALID;
     if (pk->pk->cs->n_instance && (!instances || !instance_lens)) return EZKL_ERR_INVALID;
     return guarded([&] {
@@ -3008,7 +3027,7 @@ int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagran
             invalid(world < 1, "sharded proving needs the same randomness on every rank: pass a seed or an rng callback, or shard over ezkl_hip_comm_init");
             check(ezkl_hip_comm_broadcast_host(r.key, sizeof r.key, 0), "ezkl_hip_comm_broadcast_host");
         }
-        std::vector<uint8_t> proof = create_proof(*pk->pk, g, g_lagrange, advice, advice_fn, advice_user, instances, instance_lens, r, timings);
+        std::vector<uint8_t> proof = create_proof(*pk->pk, g, g_lagrange, advice, advice_fn, advice_user, instances, instance_lens, r, timings, advice_formats);
         *proof_len = proof.size();
         if (proof.size() > cap || !proof_out) throw Error(EZKL_ERR_NOMEM, "proof buffer too small");
         std::memcpy(proof_out, proof.data(), proof.size());

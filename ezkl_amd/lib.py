@@ -12,7 +12,7 @@ SYMBOLS = [
     "ezkl_hip_memcpy_d2h", "ezkl_hip_bases_upload", "ezkl_hip_bases_prepare", "ezkl_hip_bases_free", "ezkl_hip_bases_len", "ezkl_hip_bases_generate",
     "ezkl_hip_bases_download", "ezkl_hip_bases_from_scalars", "ezkl_hip_bases_downsize", "ezkl_hip_msm_g2", "ezkl_hip_msm_g1",
     "ezkl_hip_msm_g1_dev", "ezkl_hip_msm_g1_start_dev", "ezkl_hip_msm_g1_finish", "ezkl_hip_msm_g1_batch", "ezkl_hip_msm_g1_batch_dev", "ezkl_hip_msm_g1_batch_small_dev", "ezkl_hip_g1_add_affine", "ezkl_hip_ntt", "ezkl_hip_ntt_dev",
-    "ezkl_hip_coset_ntt_batch", "ezkl_hip_coset_ntt_dev", "ezkl_hip_coeff_to_cosets_dev", "ezkl_hip_coeff_to_cosets_range_dev", "ezkl_hip_cosets_transpose_dev", "ezkl_hip_vec_op_dev", "ezkl_hip_vec_scale_dev", "ezkl_hip_permutation_sigma_dev", "ezkl_hip_vec_fill_dev", "ezkl_hip_host_malloc", "ezkl_hip_host_free", "ezkl_hip_upload_commit_batch", "ezkl_hip_upload_begin", "ezkl_hip_upload_wait", "ezkl_hip_upload_commit", "ezkl_hip_upload_end", "ezkl_hip_msm_batch_begin", "ezkl_hip_msm_batch_push_dev", "ezkl_hip_msm_batch_push_many_dev", "ezkl_hip_msm_batch_finish", "ezkl_hip_eval_poly_batch_dev", "ezkl_hip_lincomb_dev", "ezkl_hip_kate_division_dev", "ezkl_hip_chacha20_fr_dev",
+    "ezkl_hip_coset_ntt_batch", "ezkl_hip_coset_ntt_dev", "ezkl_hip_coeff_to_cosets_dev", "ezkl_hip_coeff_to_cosets_range_dev", "ezkl_hip_cosets_transpose_dev", "ezkl_hip_vec_op_dev", "ezkl_hip_vec_scale_dev", "ezkl_hip_permutation_sigma_dev", "ezkl_hip_vec_fill_dev", "ezkl_hip_host_malloc", "ezkl_hip_host_free", "ezkl_hip_upload_commit_batch", "ezkl_hip_upload_begin", "ezkl_hip_upload_begin_fmt", "ezkl_hip_upload_wait", "ezkl_hip_upload_commit", "ezkl_hip_upload_end", "ezkl_hip_msm_batch_begin", "ezkl_hip_msm_batch_push_dev", "ezkl_hip_msm_batch_push_many_dev", "ezkl_hip_msm_batch_finish", "ezkl_hip_eval_poly_batch_dev", "ezkl_hip_lincomb_dev", "ezkl_hip_kate_division_dev", "ezkl_hip_chacha20_fr_dev",
     "ezkl_hip_divide_by_vanishing_dev", "ezkl_hip_prefix_scan_dev", "ezkl_hip_eval_poly_dev", "ezkl_hip_lookup_multiplicity_dev", "ezkl_hip_lookup_multiplicity_acc_dev", "ezkl_hip_lookup_multiplicity_batch_dev", "ezkl_hip_batch_invert_dev", "ezkl_hip_eval_h_dev", "ezkl_hip_eval_h_check", "ezkl_hip_eval_h_schedule", "ezkl_hip_eval_h_prepare", "ezkl_hip_eval_h_jit_stats", "ezkl_hip_set_async", "ezkl_hip_stream_wait_library",
     "ezkl_hip_last_kernel_ms", "ezkl_hip_kernel_ms_stats", "ezkl_hip_ubench",
     "ezkl_hip_comm_available", "ezkl_hip_comm_unique_id", "ezkl_hip_comm_init", "ezkl_hip_comm_info", "ezkl_hip_comm_destroy", "ezkl_hip_comm_allgather_dev",

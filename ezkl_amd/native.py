@@ -16,7 +16,7 @@ _lib = None
 SYMBOLS = ["ezkl_prover_cs_parse", "ezkl_prover_cs_free", "ezkl_prover_cs_info", "ezkl_prover_cs_set_shard", "ezkl_prover_cs_set_shard_comm", "ezkl_prover_cs_set_shard_full_bases", "ezkl_prover_cs_set_advice_by_pointer", "ezkl_prover_cs_set_sweep_gather",
            "ezkl_prover_cs_sharded_sweeps", "ezkl_prover_cs_set_shard_exchange", "ezkl_prover_cs_shard_stats", "ezkl_prover_group_create", "ezkl_prover_group_size", "ezkl_prover_group_free",
            "ezkl_prover_group_load_srs", "ezkl_prover_group_keygen", "ezkl_prover_group_pk", "ezkl_prover_group_pk_read_file", "ezkl_prover_pk_residency", "ezkl_prover_group_create_proof", "ezkl_prover_keygen", "ezkl_prover_pk_free", "ezkl_prover_pk_sweep_stats", "ezkl_prover_pk_write", "ezkl_prover_pk_read", "ezkl_prover_pk_read_file", "ezkl_prover_pk_recommit", "ezkl_prover_pk_set_selectors", "ezkl_prover_pk_set_transcript_repr", "ezkl_prover_vk",
-           "ezkl_prover_create_proof", "ezkl_prover_verify_proof", "ezkl_prover_verify_proof_vk", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
+           "ezkl_prover_create_proof", "ezkl_prover_create_proof_fmt", "ezkl_prover_verify_proof", "ezkl_prover_verify_proof_vk", "ezkl_prover_g2_mul_generator", "ezkl_prover_keccak256", "ezkl_prover_last_error"]
 ADVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p))
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 FOLD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
@@ -374,13 +374,15 @@ def verify_proof_vk(circuit, vk_bytes, g2, s_g2, proof, instances=()):
 
 
 def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(), timings=None, check_mode="UNSAFE", g2=None, s_g2=None):
-    """advice_values: list of (n,4) Montgomery arrays, or a callable advice_values(phase, challenges) -> {column: array}
-    (second-phase advice); rng: object with .vec(m) -> (m,4) u64 Montgomery residues (None = the library's own
+    """advice_values: list of columns, or a callable advice_values(phase, challenges) -> {column: array} (second-phase advice).  A column
+    is an (n, 4) uint64 array of Montgomery words (halo2's Fp), or the INTEGERS its cells were made from (ezkl's IntegerRep,
+    src/fieldutils.rs:6-17): an (n,) int64 array, or an (n, 2) uint64 array of little-endian two's-complement 128-bit values -- 8 / 16
+    bytes per cell across PCIe instead of 32, expanded on the device (ezkl_prover_create_proof_fmt); the proof bytes are the same.  rng: object with .vec(m) -> (m,4) u64 Montgomery residues (None = the library's own
     generator, seeded with `seed`, 0 = OS entropy); instances: list of lists of ints.  Returns the proof bytes."""
     cs = pk.circuit.cs
     n = cs.n
     keep = []
-    adv_arr, adv_cb = None, C.cast(None, ADVICE_FN)
+    adv_arr, adv_cb, adv_fmt = None, C.cast(None, ADVICE_FN), None
     if callable(advice_values):
         _check(load().ezkl_prover_cs_set_advice_by_pointer(pk.circuit.h, 1), "ezkl_prover_cs_set_advice_by_pointer")
         def _cb(_user, phase, chal_ptr, n_chal, cols_ptr):
@@ -401,8 +403,21 @@ def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(
                 return 1
         adv_cb = ADVICE_FN(_cb)
     else:
-        keep = [np.ascontiguousarray(a, np.uint64) for a in advice_values]
+        fmts = []
+        for a in advice_values:
+            a = np.asarray(a)
+            if a.dtype == np.int64 and a.ndim == 1:
+                fmts.append(1); a = np.ascontiguousarray(a)
+            elif a.ndim == 2 and a.shape[1] == 2:
+                fmts.append(2); a = np.ascontiguousarray(a, np.uint64)
+            else:
+                fmts.append(0); a = np.ascontiguousarray(a, np.uint64)
+                assert a.size == 4 * n, "an advice column is 2^k x 32 bytes"
+            assert a.shape[0] == n
+            keep.append(a)
         adv_arr = _ptr_array(keep)
+        if any(fmts):
+            adv_fmt = (C.c_uint8 * len(fmts))(*fmts)
     rng_cb = C.cast(None, RNG_FN)
     if rng is not None:
         def _rng(_user, out_ptr, m):
@@ -415,8 +430,8 @@ def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(
     buf = (C.c_uint8 * cap)()
     plen = C.c_size_t(0)
     tm = (C.c_double * 12)()
-    _check(load().ezkl_prover_create_proof(pk.h, g.h, g_lagrange.h, adv_arr, adv_cb, None, _ptr_array(inst), lens, rng_cb, None, C.c_uint64(seed),
-                                           buf, C.c_size_t(cap), C.byref(plen), tm), "ezkl_prover_create_proof")
+    _check(load().ezkl_prover_create_proof_fmt(pk.h, g.h, g_lagrange.h, adv_arr, adv_fmt, adv_cb, None, _ptr_array(inst), lens, rng_cb, None, C.c_uint64(seed),
+                                               buf, C.c_size_t(cap), C.byref(plen), tm), "ezkl_prover_create_proof_fmt")
     if timings is not None:
         timings.update(dict(zip(STAGES, list(tm))))
     proof = bytes(buf[:plen.value])

@@ -191,6 +191,17 @@ int ezkl_hip_upload_commit_batch(ezkl_bases_t h, const void* const* host_cols, v
 typedef struct ezkl_upload_s* ezkl_upload_t;
 int ezkl_hip_upload_begin(const void* const* host_cols, void* const* dev_cols, size_t batch, size_t n, const void* const* tail_rows,
                           size_t tail_start, size_t tail_count, ezkl_upload_t* out_upload);
+/* begin with a FORMAT per host column: what crosses PCIe need not be 32 bytes per cell.  Every cell of an ezkl advice column is
+ * integer_rep_to_felt of an IntegerRep (i128: the quantised tensor value; /root/reference/src/fieldutils.rs:6-17) before halo2 sees it as an
+ * Fp, so a caller that still has the integers hands THOSE over -- 16 bytes per cell, or 8 when every value of the column fits an int64
+ * -- and the column is expanded on the device (x >= 0 -> x, x < 0 -> r - |x|, then the Montgomery form) as its copy lands; the device
+ * column, the blinding rows (tail_rows: always 32-byte Montgomery words) and the commitment are bit for bit those of the 32-byte form.
+ * formats == NULL: every column EZKL_COLUMN_FP (= ezkl_hip_upload_begin). */
+#define EZKL_COLUMN_FP 0        /* 32-byte Montgomery words, halo2curves' in-memory Fr */
+#define EZKL_COLUMN_INT64 1     /* int64_t per cell */
+#define EZKL_COLUMN_INT128 2    /* little-endian two's-complement 128-bit integer per cell (Rust's i128 = ezkl's IntegerRep) */
+int ezkl_hip_upload_begin_fmt(const void* const* host_cols, const uint8_t* formats, void* const* dev_cols, size_t batch, size_t n,
+                              const void* const* tail_rows, size_t tail_start, size_t tail_count, ezkl_upload_t* out_upload);
 int ezkl_hip_upload_wait(ezkl_upload_t upload, size_t column, void* stream);
 int ezkl_hip_upload_commit(ezkl_upload_t upload, ezkl_bases_t h, size_t commit_first, size_t commit_count, void* out_affine);
 int ezkl_hip_upload_end(ezkl_upload_t upload);

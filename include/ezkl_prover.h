@@ -194,6 +194,14 @@ typedef void (*ezkl_rng_fn)(void* user, void* out, size_t n_elems);
 int ezkl_prover_create_proof(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, ezkl_advice_fn advice_fn,
                              void* advice_user, const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng, void* rng_user,
                              uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings);
+/* The same with a FORMAT per advice column (EZKL_COLUMN_FP / _INT64 / _INT128 of ezkl_hip.h; advice_formats[c] for column c, NULL = all
+ * 32-byte Fp): every cell of an ezkl advice column is integer_rep_to_felt of an IntegerRep (/root/reference/src/fieldutils.rs:6-17), and a
+ * caller that hands the integers over moves 8 or 16 bytes per cell across PCIe instead of 32 -- the columns are expanded on the device as
+ * their copies land.  The proof is byte for byte the one made from the 32-byte columns.  Integer columns need caller-owned buffers: direct
+ * `advice` pointers, or a callback of a constraint system set to by-pointer advice. */
+int ezkl_prover_create_proof_fmt(ezkl_pk_t pk, ezkl_bases_t g, ezkl_bases_t g_lagrange, const void* const* advice, const uint8_t* advice_formats,
+                                 ezkl_advice_fn advice_fn, void* advice_user, const void* const* instances, const uint32_t* instance_lens, ezkl_rng_fn rng,
+                                 void* rng_user, uint64_t seed, void* proof_out, size_t cap, size_t* proof_len, double* timings);
 
 /* ---- verify_proof: the verifier of these proofs, on the host (pairing in csrc/prover/pairing.hpp) ----
  * /root/reference/src/pfsys/mod.rs:557-590 verify_proof_circuit, and the CheckMode::SAFE self-check of create_proof_circuit (:470-480:

@@ -459,3 +459,37 @@ def test_swap_proof_commitments_cross_check(hip, golden_srs):
     x1, y1 = P.point_to_ints(B.polycommit_commit(np.ascontiguousarray(adv[1][:u]), cs.n - u, params)[0])
     assert proof[64:128] != x1.to_bytes(32, "big") + y1.to_bytes(32, "big")
     params.free()
+
+
+@pytest.mark.gpu
+def test_integer_rep_advice_columns_give_the_same_proof(hip, golden_srs):
+    """ezkl_prover_create_proof_fmt: advice handed over as the INTEGERS its cells were made from (ezkl's IntegerRep i128,
+    /root/reference/src/fieldutils.rs:6-17) -- int64 columns (8 B per cell across PCIe) and 128-bit columns (16 B) -- is expanded on the
+    device to exactly the 32-byte Montgomery columns: same proof bytes, accepted by the verifier.  Then every edge of integer_rep_to_felt
+    (negative values, 0, +-1, the int64 and i128 extremes, IntegerRep::MIN) on columns that satisfy nothing: the bytes still agree."""
+    from oracle import verifier as V
+    from conftest import fe_from_int
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 9)
+    g, gl, pk = _native_setup(golden_srs, cs, fixed, copies)
+    want = N.create_proof(pk, g, gl, adv, rng=det_rng(3))
+    ints = [[P.from_mont(r) for r in col] for col in adv]
+    assert max(ints[0] + ints[1]) < 1 << 62 and max(ints[2]) < 1 << 127       # a, b fit int64; the accumulator column goes as 128-bit integers
+    def i128(vals):
+        return np.array([[(v % (1 << 128)) & 0xffffffffffffffff, (v % (1 << 128)) >> 64] for v in vals], np.uint64)
+    as_int = [np.array(ints[0], np.int64), np.array(ints[1], np.int64), i128(ints[2])]
+    assert N.create_proof(pk, g, gl, as_int, rng=det_rng(3)) == want
+    assert N.create_proof(pk, g, gl, [adv[0], as_int[1], i128(ints[2])], rng=det_rng(3)) == want              # formats mix per column
+    pk_g, vk_g = P.keygen(cs, P.GpuBackend(golden_srs["g"], golden_srs["g_lagrange"], cs.k), fixed, copies)
+    g1, g2, s_g2 = setup(golden_srs)
+    assert V.verify(vk_g, g1, g2, s_g2, want)
+    n = cs.n
+    edge64 = [0, 1, -1, 2, -2, (1 << 63) - 1, -(1 << 63), 12345, -12345, 1 << 62, -(1 << 62)]
+    edge128 = edge64 + [(1 << 127) - 1, -(1 << 127), (1 << 64), -(1 << 64), (1 << 100) + 7, -((1 << 100) + 7), (1 << 64) - 1, -((1 << 64) - 1)]
+    rng = np.random.default_rng(4)
+    c64 = (edge64 + [int(x) for x in rng.integers(-(1 << 62), 1 << 62, n)])[:n]
+    c128 = (edge128 + [int(x) * (1 << 40) * (-1 if i & 1 else 1) for i, x in enumerate(rng.integers(0, 1 << 62, n))])[:n]
+    mont = lambda vals: np.stack([fe_from_int(v % P.R) for v in vals])
+    ref = N.create_proof(pk, g, gl, [mont(c64), mont(c128), mont(c64[::-1])], rng=det_rng(8))
+    got = N.create_proof(pk, g, gl, [np.array(c64, np.int64), i128(c128), np.array(c64[::-1], np.int64)], rng=det_rng(8))
+    assert got == ref and ref != want

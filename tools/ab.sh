@@ -84,6 +84,12 @@ import sys, json
 j = json.loads(sys.stdin.read()); print('run $i SLOTS=$S value %.4g ms/step %.4f acc %.4f msm_dev %.4f ntt_dev %.4f modmul29 %.4g copy %.0f' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'], j['extra']['msm_device_ms'], j['extra']['ntt_device_ms'], j['extra']['modmul29_per_s'], j['extra']['hbm_copy_GBs']))"
     done; done
     rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power" | head -6 ;;
+  skew)
+    # witness-shaped columns (round 5): the lane-length floor and the cut count above which a bucket takes the whole-workgroup heavy path
+    run "defaults (LMIN=8 SPAN=16)" $M
+    for L in 16 32; do run "LMIN=$L" $M EZKL_MSM_LMIN=$L; done
+    for S in 32 64; do run "SPAN=$S" $M EZKL_MSM_SPAN=$S; done
+    run "LMIN=16 SPAN=32" $M EZKL_MSM_LMIN=16 EZKL_MSM_SPAN=32 ;;
   msmdebug)
     (cd "$R" && EZKL_MSM_DEBUG=1 CIRCUIT=mlp K=20 REPS=1 timeout 300 python tools/prove_bench.py --pinned) 2>&1 | grep "msm batch" | tail -12 ;;
   *) echo "unknown experiment '$1'"; exit 2 ;;

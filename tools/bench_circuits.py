@@ -87,6 +87,24 @@ def _unpack_cols(cols, gpu, pinned=False):
     return out
 
 
+def _limbs_to_int64(a):
+    """a column stored as canonical (n, 4) u64 limbs -> the int64 values it stands for (negatives are r - |x|), or None if a cell needs more
+    than 64 bits (such columns were stored as limbs because SOME cell of theirs did at pack time, or held r - x for a tiny x)"""
+    small = (a[:, 1:] == 0).all(axis=1) & (a[:, 0] < np.uint64(1 << 63))
+    out = np.zeros(a.shape[0], np.int64)
+    out[small] = a[small, 0].astype(np.int64)
+    rest = np.nonzero(~small)[0]
+    if len(rest) > (1 << 18):                        # mostly wide values: not an integer column
+        return None
+    for i in rest.tolist():
+        v = int.from_bytes(a[i].tobytes(), "little")
+        v = v if v <= (P.R >> 1) else v - P.R
+        if not -(1 << 63) <= v < (1 << 63):
+            return None
+        out[i] = v
+    return out
+
+
 def _cache_load(path, gpu):
     """plain data only: the constraint system as its EZCS blob (plonk.deserialize_cs), everything else as JSON -- the cache directory
     travels to the GPU box, so nothing in it is unpickled"""
@@ -95,10 +113,15 @@ def _cache_load(path, gpu):
         meta = json.loads(z["meta"].tobytes().decode())
         cs = P.deserialize_cs(z["cs"].tobytes())
         fixed = _unpack_cols([z["f%d" % i] for i in range(meta["n_fixed"])], gpu)
-        advice = _unpack_cols([z["a%d" % i] for i in range(meta["n_advice"])], gpu)
+        raw = [z["a%d" % i] for i in range(meta["n_advice"])]
+        advice = _unpack_cols(raw, gpu)
         copies = CopyPairs(z["copies"])
     instances = [[int(v) for v in col] for col in meta["instances"]]
-    return dict(cs=cs, fixed=fixed, copies=copies, advice=advice, instances=instances, info=dict(meta["info"], layout="read from " + os.path.basename(path)))
+    # the same advice columns as the integers they were laid out as (ezkl's IntegerRep before integer_rep_to_felt), for
+    # ezkl_prover_create_proof_fmt: None where a column holds values beyond 64 bits
+    advice_int = [c.astype(np.int64) if c.ndim == 1 else _limbs_to_int64(c) for c in raw]
+    return dict(cs=cs, fixed=fixed, copies=copies, advice=advice, advice_int=advice_int, instances=instances,
+                info=dict(meta["info"], layout="read from " + os.path.basename(path)))
 
 
 class CopyPairs:
