@@ -1322,9 +1322,16 @@ int msm_call_start(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bas
     rc = slot_prepare(sl, 0);
     if (!rc) {                                        // ordered after what the library stream has been asked to do so far (the scalar column)
         hipError_t e = hipSuccess;
-        if (!g_call_order_ev) e = hipEventCreateWithFlags(&g_call_order_ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(g_call_order_ev, c->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(sl.st, g_call_order_ev, 0);
+        // ... unless that stream is idle (round 5): then there is nothing to order behind, and the cross-queue event (a barrier packet on the
+        // slot's queue that waits for a signal of the library's) only delays the first kernel of a synchronous call
+        static const bool order_always = getenv("EZKL_MSM_ORDER_ALWAYS") != nullptr;       // A/B switch: the event whatever the stream's state
+        const hipError_t q = order_always ? hipErrorNotReady : hipStreamQuery(c->stream);
+        if (q != hipSuccess) {
+            (void)hipGetLastError();                       // hipErrorNotReady is not an error
+            if (!g_call_order_ev) e = hipEventCreateWithFlags(&g_call_order_ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(g_call_order_ev, c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sl.st, g_call_order_ev, 0);
+        }
         if (e != hipSuccess) rc = set_hip_error(e, "msm_call_start", __FILE__, __LINE__);
     }
     if (!rc) rc = msm_enqueue(c, sl, sl.st, T, base_offset, &scalars, 1, n, true);
