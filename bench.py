@@ -305,15 +305,20 @@ def main():
         # launch / the launch's HIP-event time measured in THIS run; `traffic` = PMC bytes per launch of the same kernel inside a proof
         # (tools/pmc_prove.sh: counters need their own rocprofv3 passes, so the tracked reduction is reported with its source)
         pk_, pm_ = {}, None
-        ppath = os.path.join(ROOT, "profiles", "r04_pmc_prove.json")
-        if not os.path.exists(ppath):
-            ppath = os.path.join(ROOT, "profiles", "r03_pmc_prove.json")
+        ppath = os.path.join(ROOT, "profiles", "r05_pmc_prove.json")
         if os.path.exists(ppath):
             try:
                 pm_ = json.load(open(ppath))
-                pk_ = pm_.get("kernels", {})
+                st_ = pm_.get("kernel_sources_sha256") or {}
+                # per kernel: the figure is kept only if the source file of THAT kernel is the one the PMC passes ran on
+                ok_ = {"ntt_pass_kernel": st_.get("ntt.hip") == _sha256_of("ezkl_amd/csrc/ntt.hip"),
+                       "msm_accumulate_kernel": st_.get("msm.hip") == _sha256_of("ezkl_amd/csrc/msm.hip")}
+                pk_ = {k_: v_ for k_, v_ in pm_.get("kernels", {}).items() if ok_.get(k_, True)}
+                if "evalh.hip" in st_ and st_.get("evalh.hip") != _sha256_of("ezkl_amd/csrc/evalh.hip"):
+                    pm_ = dict(pm_, evalh_jit_sweep={})
+                pm_["source"] = "%s (commit %s)" % (pm_.get("source"), pm_.get("commit"))
             except Exception:
-                pm_ = None
+                pm_, pk_ = None, {}
         def rk(kernel, workload, alg_bytes, ms, traffic, extra=None):
             d = {"kernel": kernel, "workload": workload, "bound": "hbm", "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms,
                  "achieved": (alg_bytes / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

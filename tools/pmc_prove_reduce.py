@@ -3,7 +3,9 @@
 separate runs, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB units; FETCH_SIZE counts half of a coalesced streaming read and
 64-byte gathers in full -- both factors re-calibrated in the same run with kernels of known byte counts).
     python tools/pmc_prove_reduce.py <fetch csv> <write csv> <out json> <label>"""
-import csv, json, os, sys
+import csv, hashlib, json, os, subprocess, sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 
 def load(path):
@@ -50,6 +52,12 @@ for name in list(out["kernels"]):                       # a templated kernel wit
     base = name.split("<")[0]
     if base != name and sum(1 for n_ in out["kernels"] if n_.split("<")[0] == base) == 1:
         out["kernels"][base] = out["kernels"][name]
+# what ties the figures to the kernels they were measured on (bench.py refuses them when msm.hip / ntt.hip / evalh.hip have changed since)
+out["kernel_sources_sha256"] = {f: hashlib.sha256(open(os.path.join(ROOT, "ezkl_amd", "csrc", f), "rb").read()).hexdigest() for f in ("msm.hip", "ntt.hip", "evalh.hip", "field29.hpp", "curve29.hpp")}
+try:
+    out["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("EZKL_COMMIT")
+except OSError:
+    out["commit"] = os.environ.get("EZKL_COMMIT")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for name, d in list(out["kernels"].items())[:14]:
     print("%-34s %5d launches  %10.1f MB per launch  %10.1f MB total" % (name, d["launches"], d["bytes_per_launch_mean"] / 1e6, d["bytes_total"] / 1e6))
