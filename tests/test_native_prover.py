@@ -493,3 +493,22 @@ def test_integer_rep_advice_columns_give_the_same_proof(hip, golden_srs):
     ref = N.create_proof(pk, g, gl, [mont(c64), mont(c128), mont(c64[::-1])], rng=det_rng(8))
     got = N.create_proof(pk, g, gl, [np.array(c64, np.int64), i128(c128), np.array(c64[::-1], np.int64)], rng=det_rng(8))
     assert got == ref and ref != want
+
+
+@pytest.mark.gpu
+def test_keygen_refuses_up_front_when_the_key_cannot_fit(hip, golden_srs, monkeypatch):
+    """a circuit whose key + witness columns cannot fit the device used to fail somewhere inside keygen with a bare
+    hipMalloc error.  keygen now estimates the resident bytes first and fails with the sizes (EZKL_ERR_NOMEM = -4); the test hook
+    EZKL_PROVER_ASSUME_FREE_GIB stands in for a full device"""
+    cs = mul_add_circuit(6)
+    adv, fixed, copies = witness(cs, 9)
+    from ezkl_amd import backend as B
+    g = B.Bases(golden_srs["g"])
+    monkeypatch.setenv("EZKL_PROVER_ASSUME_FREE_GIB", "0.00001")
+    with pytest.raises(Exception) as e:
+        N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    msg = str(e.value)
+    assert "GiB" in msg and "key columns" in msg and "owner mode" in msg, msg
+    monkeypatch.delenv("EZKL_PROVER_ASSUME_FREE_GIB")
+    pk = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)          # and with the real device it goes through
+    assert pk.vk()[2]
