@@ -28,7 +28,14 @@ EZ_D g1a29_t g1a29_unpack(const g1a_t& p) {
     r.y = Fq29::unpack(p.y);
     return r;
 }
-EZ_D bool g1a29_is_id(const g1a29_t& p) { return Fq29::limbs_zero(p.x) && Fq29::limbs_zero(p.y); }
+// (one OR over the 18 limbs: the short-circuit form `zero(x) && zero(y)` became two divergent mini-blocks with eight register copies each in
+// the accumulate loop)
+EZ_D bool g1a29_is_id(const g1a29_t& p) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= p.x.v[i] | p.y.v[i];
+    return o == 0;
+}
 
 // shared tail of the addition formulas: given U1 (= X1 scaled), S1, P = U2 - U1, R = S2 - S1 (both normalized), ZZ and ZZZ
 // factors already multiplied together

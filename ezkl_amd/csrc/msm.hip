@@ -49,6 +49,17 @@ namespace ezkl {
 #ifndef EZKL_MSM_LEAN
 #define EZKL_MSM_LEAN 0
 #endif
+// EZKL_MSM_RESET_ZZ=1 (round 5): a finished bucket resets only the accumulator's ZZ (the identity's encoding) instead of all 36 limbs
+// EZKL_MSM_FETCH_ALWAYS (round 5): 1 = the next table record is gathered unconditionally; 2 = the payload after next as well
+#ifndef EZKL_MSM_FETCH_ALWAYS
+#define EZKL_MSM_FETCH_ALWAYS 1
+#endif
+#ifndef EZKL_MSM_UNPACK_FIRST
+#define EZKL_MSM_UNPACK_FIRST 0
+#endif
+#ifndef EZKL_MSM_RESET_ZZ
+#define EZKL_MSM_RESET_ZZ 1
+#endif
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
 static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workgroup stages in LDS (104 KiB): 1024 scalars x 13 windows
@@ -535,12 +546,23 @@ __device__ __forceinline__ void msm_bins_scan(uint32_t* cnt, uint32_t* tsum, uin
     }
     __syncthreads();
 }
+__device__ __forceinline__ void msm_bigsort_count_body(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
+                                                       const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off, uint32_t* cnt, uint32_t bx,
+                                                       uint32_t by, uint32_t rows);
 __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, uint32_t NP,
-                                                          const uint32_t* big_flag, uint32_t* offsets, uint32_t* vals, g1x29_t* buckets, size_t bstride) {
+                                                          const uint32_t* big_flag, uint32_t* offsets, uint32_t* vals, g1x29_t* buckets,
+                                                          const uint32_t* big_list, const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off,
+                                                          size_t bstride) {
     BOFF(); BSH(entries); BSH(part_base); BSH(big_flag); BSH(offsets); BSH(vals); BSH(buckets);
     __shared__ uint32_t cnt[2048];
     __shared__ uint32_t tsum[512];
     extern __shared__ uint32_t stage[];                      // MSM_BINSORT_STAGE sorted payloads: written out as one contiguous run
+    if (blockIdx.x >= NP) {                                  // the counting half of the multi-workgroup sort of oversized partitions
+        BSH(big_list); BSH(big_count); BSH(bin_total); BSH(block_off);
+        const uint32_t w = blockIdx.x - NP;
+        msm_bigsort_count_body(entries, part_base, LB, big_list, big_count, bin_total, block_off, cnt, w % MSM_BIG_BLOCKS, w / MSM_BIG_BLOCKS, MSM_BIG_ROWS);
+        return;
+    }
     const uint32_t p = blockIdx.x, t = threadIdx.x, nbins = 1u << LB;
     const uint32_t beg = part_base[p + 1], end = part_base[p + 2];       // index 0 is bucket 0's own partition (msm_part_of)
     if (p == NP - 1 && t == 0) offsets[(size_t)NP * nbins] = end;
@@ -586,31 +608,32 @@ __global__ __launch_bounds__(512) void msm_binsort_kernel(const uint2* entries, 
 // walking 2^20 pairs took 1.3-1.5 ms).  They are sorted by MSM_BIG_BLOCKS workgroups each, in two kernels: every workgroup
 // histograms its slice and reserves, per bin, a range inside the bin with ONE global atomic (the order of pairs inside a bucket
 // is irrelevant); after the kernel boundary the bin totals are complete, every workgroup scans them and scatters its slice.
-__device__ __forceinline__ void msm_big_slice(uint32_t beg, uint32_t end, uint32_t& s0, uint32_t& s1) {
+__device__ __forceinline__ void msm_big_slice(uint32_t beg, uint32_t end, uint32_t& s0, uint32_t& s1, uint32_t bx) {
     const uint32_t chunk = (end - beg + MSM_BIG_BLOCKS - 1) / MSM_BIG_BLOCKS;
-    s0 = beg + blockIdx.x * chunk;
+    s0 = beg + bx * chunk;
     s1 = s0 + chunk < end ? s0 + chunk : end;
     if (s0 > end) s0 = end;
 }
 // (round 5) both kernels run MSM_BIG_BLOCKS x MSM_BIG_ROWS workgroups that LOOP over the oversized partitions (row r takes partitions r,
 // r + MSM_BIG_ROWS, ...): the launch of an MSM without any (the common case) is 512 workgroups that read one counter and leave, not 4096,
 // and a skewed column still has two workgroups per CU at work.
-__global__ __launch_bounds__(512) void msm_bigsort_count_kernel(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
-                                                                const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off, size_t bstride) {
-    BOFF(); BSH(entries); BSH(part_base); BSH(big_list); BSH(big_count); BSH(bin_total); BSH(block_off);
-    __shared__ uint32_t cnt[2048];
+// the counting half, for workgroup (bx, by) of MSM_BIG_BLOCKS x `rows`: since round 5 these workgroups ride at the END of the binsort launch
+// (they need nothing but the partition scan's output, like the binsort workgroups), one launch fewer per MSM
+__device__ __forceinline__ void msm_bigsort_count_body(const uint2* entries, const uint32_t* part_base, uint32_t LB, const uint32_t* big_list,
+                                                       const uint32_t* big_count, uint32_t* bin_total, uint32_t* block_off, uint32_t* cnt, uint32_t bx,
+                                                       uint32_t by, uint32_t rows) {
     const uint32_t t = threadIdx.x, nbins = 1u << LB;
     const uint32_t nbig = big_count[0] < MSM_MAX_BIG ? big_count[0] : MSM_MAX_BIG;
-    for (uint32_t y = blockIdx.y; y < nbig; y += gridDim.y) {
+    for (uint32_t y = by; y < nbig; y += rows) {
         const uint32_t p = big_list[y];
         uint32_t s0, s1;
-        msm_big_slice(part_base[p + 1], part_base[p + 2], s0, s1);
+        msm_big_slice(part_base[p + 1], part_base[p + 2], s0, s1, bx);
         for (uint32_t j = t; j < nbins; j += 512) cnt[j] = 0;
         __syncthreads();
         for (uint32_t e = s0 + t; e < s1; e += 512) (void)msm_wave_rank(cnt, entries[e].y);
         __syncthreads();
         for (uint32_t j = t; j < nbins; j += 512)                            // this workgroup's range inside bin j starts at the returned value
-            block_off[((size_t)y * MSM_BIG_BLOCKS + blockIdx.x) * nbins + j] = cnt[j] ? atomicAdd(&bin_total[(size_t)y * nbins + j], cnt[j]) : 0u;
+            block_off[((size_t)y * MSM_BIG_BLOCKS + bx) * nbins + j] = cnt[j] ? atomicAdd(&bin_total[(size_t)y * nbins + j], cnt[j]) : 0u;
         __syncthreads();
     }
 }
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(512) void msm_bigsort_scatter_kernel(const uint2* e
     for (uint32_t y = blockIdx.y; y < nbig; y += gridDim.y) {
         const uint32_t p = big_list[y], beg = part_base[p + 1];
         uint32_t s0, s1;
-        msm_big_slice(beg, part_base[p + 2], s0, s1);
+        msm_big_slice(beg, part_base[p + 2], s0, s1, blockIdx.x);
         for (uint32_t j = t; j < nbins; j += 512) cnt[j] = bin_total[(size_t)y * nbins + j];
         __syncthreads();
         msm_bins_scan(cnt, tsum, nbins, p, beg, part_base, blockIdx.x == 0, offsets, buckets);     // cnt[j] = start of bin j in the partition
@@ -688,7 +711,11 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
     for (uint32_t k = k0; k < k1; k++) {
         if (k == bin_end) {                     // bucket b is finished inside this lane
             if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
+#if EZKL_MSM_RESET_ZZ
+            acc.zz = Fq29::zero();              // the identity is ZZ = 0 whatever X, Y, ZZZ hold (g1x29_is_id): 9 moves instead of 36 at every bucket end
+#else
             acc = g1x29_identity();
+#endif
             started_before = false;
             b++;
             bin_end = end_next;
@@ -709,12 +736,39 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
             }
             end_next = offsets[b + 2 <= nb ? b + 2 : nb];
         }
+#if EZKL_MSM_UNPACK_FIRST
+        // the record that arrived is unpacked BEFORE the next gather is issued into the same registers (a gather issued first forces a copy
+        // of the 16 raw words: its destination may be written at any time); the next record is needed an iteration from now either way
+        g1a29_t cur_q = g1a29_unpack(nxt.p);
+        const bool cur_neg = nxt.neg;
+        // the limbs pass through an (empty) volatile asm that also clobbers memory: the unpack cannot sink below it, the gathers cannot rise above it
+        asm volatile("" : "+v"(cur_q.x.v[0]), "+v"(cur_q.x.v[1]), "+v"(cur_q.x.v[2]), "+v"(cur_q.x.v[3]), "+v"(cur_q.x.v[4]), "+v"(cur_q.x.v[5]),
+                          "+v"(cur_q.x.v[6]), "+v"(cur_q.x.v[7]), "+v"(cur_q.x.v[8]), "+v"(cur_q.y.v[0]), "+v"(cur_q.y.v[1]), "+v"(cur_q.y.v[2]),
+                          "+v"(cur_q.y.v[3]), "+v"(cur_q.y.v[4]), "+v"(cur_q.y.v[5]), "+v"(cur_q.y.v[6]), "+v"(cur_q.y.v[7]), "+v"(cur_q.y.v[8])
+                     :: "memory");
+#else
         const MsmRec cur = nxt;
+#endif
+#if EZKL_MSM_FETCH_ALWAYS
+        // no divergent region around the loads (round 5: the `if (k + 1 < k1)` around them cost 3.7 % of the kernel, 0.916 -> 0.886 ms,
+        // profiles/r05y_msm_ab.log): past the lane's last pair a record is fetched and never used
+        nxt = msm_fetch(tab, vn);
+#if EZKL_MSM_FETCH_ALWAYS > 1
+        vn = vals[k + 2 < total ? k + 2 : total - 1];     // ... and the payload load as well: the next lane's pair, or the last one
+#else
+        vn = k + 2 < k1 ? vals[k + 2] : 0u;
+#endif
+#else
         if (k + 1 < k1) {
             nxt = msm_fetch(tab, vn);           // its address arrived an iteration ago; the record is used an iteration from now
             vn = k + 2 < k1 ? vals[k + 2] : 0u;
         }
+#endif
+#if EZKL_MSM_UNPACK_FIRST
+        acc = g1x29_add_mixed(acc, cur_q, cur_neg);
+#else
         acc = g1x29_add_mixed(acc, g1a29_unpack(cur.p), cur.neg);
+#endif
     }
 #else
     uint32_t b = lo, bin_end = offsets[b + 1];
@@ -1133,10 +1187,20 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     g1x29_t* planes = (g1x29_t*)(S + o_planes);
 
     hipEvent_t m0 = nullptr, m1 = nullptr, a0 = nullptr, a1 = nullptr;
+    // EZKL_HIP_TIMING (read at every call): which event pairs a synchronous call records -- "all" (default): the whole chain ("msm") and the
+    // dominant kernel ("msm_accumulate"); "kernel": the dominant kernel only; "none".  An event record is a barrier packet with a timestamp on
+    // the stream: the four of a call cost ~15 us of a 1.31 ms step (profiles/r05aa_wall_probe.log), so a caller that only needs the
+    // kernel's time -- bench.py's timed region -- asks for two.
+    bool timed_chain = timed;
     if (timed) {
-        if ((rc = ev_pair(c, "msm", &m0, &m1))) return rc;
+        const char* tm = getenv("EZKL_HIP_TIMING");
+        if (tm && !strcmp(tm, "none")) timed = timed_chain = false;
+        else if (tm && !strcmp(tm, "kernel")) timed_chain = false;
+    }
+    if (timed) {
+        if (timed_chain && (rc = ev_pair(c, "msm", &m0, &m1))) return rc;
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
-        EZ_HIP(hipEventRecord(m0, st));
+        if (timed_chain) EZ_HIP(hipEventRecord(m0, st));
     }
 #if EZKL_MSM_LEAN
     // sort: the histogram kernel zeroes the region above, the last workgroup of the histogram scan runs the partition scan
@@ -1144,16 +1208,16 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
                        (uint32_t)(zero_bytes / 4), bstride);
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, hcnt + 3, pbase, bflag, blist, bcnt, bstride);
 #else
-    for (size_t j = 0; j < count; j++) EZ_HIP(hipMemsetAsync((uint8_t*)hcnt + j * bstride, 0, zero_bytes, st));
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, (uint32_t*)nullptr,
-                       0u, bstride);
+    // the chain's counters, bin totals and planes are zeroed by the histogram kernel (no memset command in front of the chain: round 5)
+    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, hcnt,
+                       (uint32_t)(zero_bytes / 4), bstride);
     hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, (uint32_t*)nullptr, pbase, bflag, blist, bcnt, bstride);
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1, 1, Z), dim3(1024), 0, st, pcnt, NQ, pbase, bflag, blist, bcnt, bstride);
 #endif
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid, 1, Z), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
                        LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals, scal_list, bstride);
-    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP, 1, Z), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs, vals, bkt, bstride);
-    hipLaunchKernelGGL(msm_bigsort_count_kernel, dim3(MSM_BIG_BLOCKS, MSM_BIG_ROWS, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, bstride);
+    hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP + MSM_BIG_BLOCKS * MSM_BIG_ROWS, 1, Z), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs,
+                       vals, bkt, blist, bcnt, btot, boff, bstride);
     hipLaunchKernelGGL(msm_bigsort_scatter_kernel, dim3(MSM_BIG_BLOCKS, MSM_BIG_ROWS, Z), dim3(512), 0, st, entries, pbase, LB, blist, bcnt, btot, boff, offs,
                        vals, bkt, bstride);
     // accumulate
@@ -1207,7 +1271,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         EZ_HIP(hipStreamSynchronize(st));
         fprintf(stderr, "[msm] n=%zu W=%u bits=%u L=%u nlanes=%u heavy=%u\n", n, W, bits, L, nlanes, hc);
     }
-    if (timed) EZ_HIP(hipEventRecord(m1, st));
+    if (timed_chain) EZ_HIP(hipEventRecord(m1, st));
     for (size_t j = 0; j < count && !zero_copy; j++)
         EZ_HIP(hipMemcpyAsync(sl.pinned + j * 32 * 36, (uint8_t*)planes + j * bstride, (size_t)nplanes * sizeof(g1x29_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipEventRecord(sl.done, st));

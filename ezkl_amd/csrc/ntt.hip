@@ -64,6 +64,9 @@ struct PassArgs {
 // decimation-in-TIME: t = w v, (u, v) <- (u + t, u - t + 4p).  The product comes first, so t < 2p whatever v was, a value grows by at most 4p per stage (< 54p after the 11 stages of the largest tile,
 // far below the 1000p the product accepts) and limbs grow by at most 2 units of 2^29 per stage: the only range control is ONE carry
 // propagation per element at the end of a two-stage register group -- no comparison, no conditional subtraction inside the transform.
+// (Round 5, measured and dropped: the work buffer and the inter-pass tables as UNPACKED 36-byte elements -- no pack / unpack between passes,
+// 2.6 % fewer VALU instructions -- ran 2 % SLOWER, 0.443-0.448 against 0.434-0.437 ms per 2^22 transform on one box: 36-byte elements are
+// nine dword accesses per lane at 4-byte alignment instead of two aligned 16-byte ones.  profiles/r05ac_ntt_ab.log)
 // (Round 5: half of the stage-2 butterflies of a plain transform have the twiddle 1 as well and take a carry pass instead of the product;
 // values then stay below 82p.)
 // Elements are 8 x 32-bit words in HBM (the files' 2^256 Montgomery domain, untouched: the twiddles carry the 2^261 of the product) and
@@ -490,10 +493,14 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
     const fe_t dom = ntt_domain_one();                      // constants that enter a product carry the product's domain
     const fe_t zeta = Fr::mul(fr_const(FrConst::ZETA), dom), zeta2 = Fr::mul(fr_const(FrConst::ZETA2), dom);
     uint32_t log_m = log_n;
-    hipEvent_t e0, e1;
-    rc = ev_pair(c, coset_mode ? "coset_ntt" : "ntt", &e0, &e1);
-    if (rc) return rc;
-    EZ_HIP(hipEventRecord(e0, st));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char* tmode = getenv("EZKL_HIP_TIMING");                      // "none": no event pair around the passes (include/ezkl_hip.h)
+    const bool timed = !(tmode && !strcmp(tmode, "none"));
+    if (timed) {
+        rc = ev_pair(c, coset_mode ? "coset_ntt" : "ntt", &e0, &e1);
+        if (rc) return rc;
+        EZ_HIP(hipEventRecord(e0, st));
+    }
     for (int i = 0; i < p->npass; i++) {
         PassArgs a;
         memset(&a, 0, sizeof a);
@@ -534,7 +541,7 @@ static int ntt_run_chunk(Ctx* c, hipStream_t st, const fe_t* in, fe_t* out, uint
         log_m -= a.log_r;
     }
     EZ_HIP(hipGetLastError());
-    EZ_HIP(hipEventRecord(e1, st));
+    if (timed) EZ_HIP(hipEventRecord(e1, st));
     if (work) return arena_done(scratch_arena(c, st), st);
     return EZKL_OK;
 }

@@ -580,7 +580,7 @@ def test_start_finish_tokens_busy_and_spent(hip):
     bases = B.Bases(pts)
     cols = [rand_fr(rng, n) for _ in range(4)]
     devs = [B.DeviceBuffer.from_numpy(c) for c in cols]
-    want = [ob.msm(c, pts) for c in cols]
+    want = want_pts = [ob.msm(c, pts) for c in cols]
     B.msm_g1_dev(bases, devs[0].ptr, n)                                  # tables
     B.kernel_ms_stats("msm", reset=True)
     toks = [B.msm_g1_start_dev(bases, d.ptr, n) for d in devs]
@@ -601,4 +601,15 @@ def test_start_finish_tokens_busy_and_spent(hip):
     assert abs(B.last_kernel_ms("msm") - total_ms / 5) < total_ms         # the newest pair is readable on its own
     assert B.kernel_ms_stats("msm", reset=True)[1] == 5 and B.kernel_ms_stats("msm") == (0.0, 0)
     assert B.kernel_ms_stats("no such region") == (0.0, 0)
+    # EZKL_HIP_TIMING (read at every call): which event pairs a synchronous MSM records
+    import os
+    for mode, want in (("kernel", (0, 2)), ("none", (0, 0)), ("all", (2, 2))):
+        B.kernel_ms_stats("msm", reset=True); B.kernel_ms_stats("msm_accumulate", reset=True)
+        os.environ["EZKL_HIP_TIMING"] = mode
+        try:
+            for _ in range(2):
+                assert (B.msm_g1_dev(bases, devs[2].ptr, n) == want_pts[2]).all()
+        finally:
+            del os.environ["EZKL_HIP_TIMING"]
+        assert (B.kernel_ms_stats("msm")[1], B.kernel_ms_stats("msm_accumulate")[1]) == want, mode
     bases.free()
