@@ -90,6 +90,12 @@ j = json.loads(sys.stdin.read()); print('run $i SLOTS=$S value %.4g ms/step %.4f
     for L in 16 32; do run "LMIN=$L" $M EZKL_MSM_LMIN=$L; done
     for S in 32 64; do run "SPAN=$S" $M EZKL_MSM_SPAN=$S; done
     run "LMIN=16 SPAN=32" $M EZKL_MSM_LMIN=16 EZKL_MSM_SPAN=32 ;;
+  skew2)
+    run "defaults (LMIN=8 SPAN=16)" $M
+    for S in 4 8; do run "SPAN=$S" $M EZKL_MSM_SPAN=$S; done
+    run "LMIN=16 SPAN=8" $M EZKL_MSM_LMIN=16 EZKL_MSM_SPAN=8
+    run "LMIN=24" $M EZKL_MSM_LMIN=24
+    run "defaults again" $M ;;
   msmdebug)
     (cd "$R" && EZKL_MSM_DEBUG=1 CIRCUIT=mlp K=20 REPS=1 timeout 300 python tools/prove_bench.py --pinned) 2>&1 | grep "msm batch" | tail -12 ;;
   *) echo "unknown experiment '$1'"; exit 2 ;;
