@@ -321,4 +321,28 @@ EZ_D g1x29_t g1x29_block256_sum_coop(const g1x29_t& acc0, uint4* sh) {
     return g1x29_group_sum(acc, 4);
 }
 
+// ... and with the four wave totals summed cooperatively as well (three additions inside every quad instead of two plain butterfly levels:
+// 11 us instead of 19 at one wave per SIMD).  EZKL_MSM_COOP bit 3 selects it in msm_planes_kernel: exact (all 20 planes equal the plain tree's,
+// results equal the oracle's) and worth 2 us of a 1.27 ms chain (profiles/r05aj_coop15.log), so it is not the default.
+EZ_D g1x29_t g1x29_block256_sum_coop_full(const g1x29_t& acc0, uint4* sh) {
+    g1x29_t acc = g1x29_group_sum_coop(acc0, 64);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t* s = acc.x.v;
+#pragma unroll
+        for (int k = 0; k < 9; k++) sh[k * 4 + (threadIdx.x >> 6)] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+    }
+    __syncthreads();
+    g1x29_t w;
+    {
+        uint32_t* d = w.x.v;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const uint4 t = sh[k * 4 + (threadIdx.x & 3)];
+            d[4 * k] = t.x; d[4 * k + 1] = t.y; d[4 * k + 2] = t.z; d[4 * k + 3] = t.w;
+        }
+    }
+    __syncthreads();
+    return g1x29_group_sum_coop(w, 4);
+}
+
 }  // namespace ezkl

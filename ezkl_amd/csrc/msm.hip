@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const g1x29_t* SA, cons
         const uint32_t sh_bits = field == 2 ? j : g.wB + j;          // t = (dC << wB) | dB
         for (uint32_t k = threadIdx.x; k < nT / 2; k += 256) acc = g1x29_add(acc, ld_g1x29(T + with_bit(k, sh_bits)));
     }
-    acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);
+    acc = (coop & 8u) ? g1x29_block256_sum_coop_full(acc, sh) : coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);
     if (threadIdx.x == 0) {
         const uint32_t ws = field == 1 ? g.wsA : field == 2 ? g.wsB : g.wsC;
         const uint32_t slot = field == 0 ? 0u : 1u + ws + j;
@@ -1249,7 +1249,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         const uint32_t blocksA = waves(nA, lanesA);
         hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT), 1, Z), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA, coop & 1u, bstride);
         hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, zero_copy ? (g1x29_t*)sl.pinned_dev : (g1x29_t*)nullptr,
-                           coop & 2u, bstride);
+                           coop & 10u, bstride);
     }
     EZ_HIP(hipGetLastError());
     if (getenv("EZKL_MSM_DEBUG_PLANES")) {           // the planes of the cooperative and of the plain tree, side by side (first MSM of a group)
