@@ -834,6 +834,77 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
     for (uint32_t u = t + 1; u <= t2; u++) acc = g1x29_add(acc, ld_g1x29(head + u));
     st_g1x29(buckets + b, acc);
 }
+// The same with the partials of a bucket summed by a SEGMENTED TREE inside the wave (round 5).  A witness-shaped column (small values: one
+// non-zero digit per scalar, lanes of 8 pairs) cuts almost every bucket 5-16 times, and the thread of a bucket's first boundary then folded up
+// to 16 partials one after the other while its neighbours -- the bucket's other boundaries -- idled: 180-290 us per column
+// (profiles/r04o_msm_columns_serial.txt).  Here the 64 boundaries of a wave run a segmented suffix sum: log2(longest run in the wave)
+// shuffle-and-add steps, every lane adding the lane d to its right when that lane belongs to the same bucket; the first boundary of a bucket
+// then holds the sum of all its partials inside the wave, adds the bucket's tail and -- when the bucket runs past the end of the wave -- the
+// few partials beyond it one by one.  A wave whose buckets are all cut once takes no step at all: the uniform case costs what it did.
+EZ_D g1x29_t g1x29_shfl_down(const g1x29_t& p, uint32_t d) {
+    g1x29_t r;
+    const uint32_t* s = p.x.v;
+    uint32_t* o = r.x.v;
+#pragma unroll
+    for (int k = 0; k < 36; k++) o[k] = __shfl_down(s[k], d);
+    return r;
+}
+__global__ __launch_bounds__(256) void msm_fixup_boundary_tree_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes,
+                                                                      const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
+                                                                      uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list, uint32_t lmin,
+                                                                      uint32_t span_heavy, size_t bstride) {
+    BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(tail); BSH(buckets); BSH(heavy_list); BSH(heavy_count); BSH(chunk_list);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t L = msm_lane_len(offsets, nb, nlanes, lmin);
+    const uint64_t k0 = (uint64_t)t * L;
+    bool cut = t < nlanes && k0 < offsets[nb];
+    uint32_t b = 0, t1 = 0, t2 = 0;
+    if (cut) {
+        b = lane_first[t];
+        const uint32_t beg = offsets[b], end = offsets[b + 1];
+        cut = beg < k0;                                                    // otherwise the bucket starts exactly on the boundary
+        t1 = beg / L; t2 = (end - 1) / L;
+    }
+    if (cut && t2 - t1 > span_heavy) {                                     // skewed witness: the whole-workgroup passes below
+        if (t == t1 + 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+        if ((t - t1 - 1) % MSM_HEAVY_CHUNK == 0) chunk_list[atomicAdd(heavy_count + 1, 1u)] = t;
+        cut = false;
+    }
+    // what is left of my bucket from this boundary on, inside this wave (0: not a boundary of a bucket that is folded here)
+    const uint32_t wave_last = t + (63u - lane);
+    const uint32_t run = cut ? (t2 < wave_last ? t2 : wave_last) - t + 1u : 0u;
+    uint32_t longest = run;
+#pragma unroll
+    for (uint32_t o = 32; o > 0; o >>= 1) {
+        const uint32_t m = __shfl_xor(longest, o);
+        longest = m > longest ? m : longest;
+    }
+    if (longest == 0) return;                                              // wave-uniform
+    if (longest <= 2) {                                                    // wave-uniform: nothing in this wave is cut more than twice -- the serial fold
+        if (!cut || t != t1 + 1) return;                                   // (uniform scalars: 26 pairs per bucket, 69 per lane)
+        g1x29_t acc = g1x29_add(ld_g1x29(tail + t1), ld_g1x29(head + t));
+        for (uint32_t u = t + 1; u <= t2; u++) acc = g1x29_add(acc, ld_g1x29(head + u));
+        st_g1x29(buckets + b, acc);
+        return;
+    }
+    g1x29_t v = cut ? ld_g1x29(head + t) : g1x29_identity();
+    uint32_t have = cut ? 1u : 0u;                                         // partials of my bucket summed into v so far (from t rightwards)
+#pragma unroll 1
+    for (uint32_t d = 1; d < longest; d <<= 1) {                          // wave-uniform trip count
+        const g1x29_t w = g1x29_shfl_down(v, d);
+        const uint32_t hw = __shfl_down(have, d);
+        // the lane d to my right continues my run exactly when I already hold d partials and my run is longer than that
+        if (have == d && run > d) {
+            v = g1x29_add(v, w);
+            have += hw;
+        }
+    }
+    if (!cut || t != t1 + 1) return;                                       // only the first boundary of a bucket writes it
+    g1x29_t acc = g1x29_add(ld_g1x29(tail + t1), v);
+    for (uint32_t u = t + run; u <= t2; u++) acc = g1x29_add(acc, ld_g1x29(head + u));   // the part of the bucket beyond this wave
+    st_g1x29(buckets + b, acc);
+}
 // Heavily skewed buckets (thousands of equal witness values -- a constant column is ONE bucket cut by every lane boundary).
 // Pass 1: one workgroup per chunk of MSM_HEAVY_CHUNK lane partials folds head[start .. start + chunk) into head[start].
 // Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
@@ -1226,8 +1297,15 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
                        lfirst, lmin, bstride);
     if (timed) EZ_HIP(hipEventRecord(a1, st));
     if (nlanes > 1)
-        hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
-                           heavy, hcnt, chunks, lmin, span_heavy, bstride);
+    {
+        static const bool tree = [] { const char* e = getenv("EZKL_MSM_FIXUP_TREE"); return !(e && atoi(e) == 0); }();      // 0: the serial fold of rounds 1-4
+        if (tree)
+            hipLaunchKernelGGL(msm_fixup_boundary_tree_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
+                               heavy, hcnt, chunks, lmin, span_heavy, bstride);
+        else
+            hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
+                               heavy, hcnt, chunks, lmin, span_heavy, bstride);
+    }
     {
         size_t max_heavy = nlanes / span_heavy + 1;
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);

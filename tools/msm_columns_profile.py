@@ -61,7 +61,7 @@ def reduce(db_path):
     ev = sorted((s, e, nm) for nm, s, e in cur.execute("select %s, start, end from kernels" % name_col))
     msms, curm = [], None
     for s, e, nm in ev:
-        short = nm.split("(")[0].replace("ezkl::", "").replace("void ", "")
+        short = nm.split("(")[0].replace("ezkl::", "").replace("void ", "").replace("msm_fixup_boundary_tree_kernel", "msm_fixup_boundary_kernel")
         if short == "msm_hist_kernel":
             curm = {}
             msms.append(curm)
