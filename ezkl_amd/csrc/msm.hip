@@ -825,7 +825,8 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t*
     if (beg >= k0) return;                                                 // the bucket starts exactly on the boundary: not cut
     const uint32_t t1 = beg / L, t2 = (end - 1) / L;
     if (t2 - t1 > span_heavy) {                                        // skewed witness: queue the bucket once, and one work item
-        if (t == t1 + 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;       // per chunk of MSM_HEAVY_CHUNK lane partials
+        // (a bucket of ONE chunk is finished by the first pass itself, tail included: no second pass for it -- round 5)
+        if (t == t1 + 1 && t2 - t1 > MSM_HEAVY_CHUNK) heavy_list[atomicAdd(heavy_count, 1u)] = b;       // per chunk of MSM_HEAVY_CHUNK lane partials
         if ((t - t1 - 1) % MSM_HEAVY_CHUNK == 0) chunk_list[atomicAdd(heavy_count + 1, 1u)] = t;
         return;
     }
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_tree_kernel(const uint
         t1 = beg / L; t2 = (end - 1) / L;
     }
     if (cut && t2 - t1 > span_heavy) {                                     // skewed witness: the whole-workgroup passes below
-        if (t == t1 + 1) heavy_list[atomicAdd(heavy_count, 1u)] = b;
+        if (t == t1 + 1 && t2 - t1 > MSM_HEAVY_CHUNK) heavy_list[atomicAdd(heavy_count, 1u)] = b;     // more than one chunk: the second pass
         if ((t - t1 - 1) % MSM_HEAVY_CHUNK == 0) chunk_list[atomicAdd(heavy_count + 1, 1u)] = t;
         cut = false;
     }
@@ -910,8 +911,9 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_tree_kernel(const uint
 // Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
 // (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
 __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const uint32_t* lane_first, g1x29_t* head,
-                                                               const uint32_t* chunk_list, const uint32_t* counts, uint32_t lmin, uint32_t coop, size_t bstride) {
-    BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(chunk_list); BSH(counts);
+                                                               const g1x29_t* tail, g1x29_t* buckets, const uint32_t* chunk_list, const uint32_t* counts, uint32_t lmin,
+                                                               uint32_t coop, size_t bstride) {
+    BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(tail); BSH(buckets); BSH(chunk_list); BSH(counts);
     __shared__ uint4 sh[9 * 4];
     const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes, lmin);
     for (uint32_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
@@ -921,7 +923,11 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* o
         g1x29_t acc = g1x29_identity();
         for (uint32_t t = start + threadIdx.x; t <= stop; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
         acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);   // ends with a workgroup barrier: every read of head[start..stop] is done
-        if (threadIdx.x == 0) st_g1x29(head + start, acc);
+        if (threadIdx.x == 0) {
+            const uint32_t t1 = offsets[b] / L;
+            if (t2 - t1 <= MSM_HEAVY_CHUNK) st_g1x29(buckets + b, g1x29_add(ld_g1x29(tail + t1), acc));     // the bucket's only chunk (start == t1 + 1): done here
+            else st_g1x29(head + start, acc);
+        }
     }
 }
 __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
@@ -1311,7 +1317,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
         size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
         unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
-        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, chunks, hcnt, lmin, coop & 4u, bstride);
+        hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt, chunks, hcnt, lmin, coop & 4u, bstride);
         hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, lmin, coop & 4u, bstride);
     }
     // reduce
