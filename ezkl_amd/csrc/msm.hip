@@ -920,14 +920,13 @@ __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* o
         const uint32_t start = chunk_list[ci], b = lane_first[start];
         const uint32_t t2 = (offsets[b + 1] - 1) / L;
         const uint32_t stop = start + MSM_HEAVY_CHUNK - 1 < t2 ? start + MSM_HEAVY_CHUNK - 1 : t2;
-        g1x29_t acc = g1x29_identity();
+        const uint32_t t1 = offsets[b] / L;
+        const bool whole = t2 - t1 <= MSM_HEAVY_CHUNK;                     // the bucket's only chunk (start == t1 + 1): finished here, tail included
+        // the tail enters as the LAST thread's first operand (that thread has the fewest partials of the chunk): no addition after the tree
+        g1x29_t acc = (whole && threadIdx.x == 255) ? ld_g1x29(tail + t1) : g1x29_identity();
         for (uint32_t t = start + threadIdx.x; t <= stop; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
         acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);   // ends with a workgroup barrier: every read of head[start..stop] is done
-        if (threadIdx.x == 0) {
-            const uint32_t t1 = offsets[b] / L;
-            if (t2 - t1 <= MSM_HEAVY_CHUNK) st_g1x29(buckets + b, g1x29_add(ld_g1x29(tail + t1), acc));     // the bucket's only chunk (start == t1 + 1): done here
-            else st_g1x29(head + start, acc);
-        }
+        if (threadIdx.x == 0) st_g1x29(whole ? buckets + b : head + start, acc);
     }
 }
 __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
