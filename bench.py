@@ -127,7 +127,9 @@ def main():
     os.environ.pop("EZKL_HIP_TIMING", None)
     acc_sum, acc_cnt = B.kernel_ms_stats("msm_accumulate")
     acc_ms = [acc_sum / max(1, acc_cnt)]
-    assert acc_cnt == args.steps and B.kernel_ms_stats("msm")[1] == 0, (acc_cnt,)
+    errors = []
+    if acc_cnt != args.steps or B.kernel_ms_stats("msm")[1] != 0:      # bookkeeping, never worth the headline line
+        errors.append("msm_accumulate event pairs harvested: %d for %d timed steps" % (acc_cnt, args.steps))
     for _ in range(max(5, args.steps // 2)):            # whole-chain device time (both event pairs recorded): outside the timed region
         msm_step()
     barrier_sync()
@@ -184,7 +186,8 @@ def main():
     B.set_async(was_async)
     ntt_sum, ntt_cnt = B.kernel_ms_stats("ntt")
     ntt_ms = [ntt_sum / max(1, ntt_cnt)]
-    assert ntt_cnt == max(5, args.steps // 2), ntt_cnt
+    if ntt_cnt != max(5, args.steps // 2):
+        errors.append("ntt event pairs harvested: %d for %d steps" % (ntt_cnt, max(5, args.steps // 2)))
 
     # batched commit (one prover phase: 4 independent 2^20-point columns per call, pipelined over streams)
     # (kept out of the default run so that rocprofv3's per-kernel averages of `python bench.py` are those of the
@@ -363,25 +366,110 @@ def main():
         rks.append(rk("msm_accumulate_kernel", "2^20-point MSM of the timed region (96 B per point)", MSM_BYTES_PER_POINT * n_msm, acc_avg_ms, traffic,
                       {"products_per_launch": 13 * n_msm * 10}))
         out["roofline_kernels"] = rks
-        out["roofline"]["kernels"] = rks                    # the same list where the driver's record keeps it
-        if "cpu_baseline" in out and "prove_seconds_k20_mlp" in out:
-            # BASELINE.json's leading metric with its CPU prover of the same run, where the driver's record keeps it; k = 22 and the other circuits beside it
-            pr_ = out.get("prove") or {}
-            brief = lambda d: {a: d.get(a) for a in ("prove_seconds_gpu", "prove_seconds_cpu", "cpu_threads", "proofs_identical_gpu_cpu", "verifier_accepts",
-                                                     "first_prove_seconds_gpu", "keygen_seconds_gpu", "hbm_in_use_gib_after_prove", "label", "error") if d.get(a) is not None}
-            out["cpu_baseline"]["prove_seconds_k20_mlp"] = out["prove_seconds_k20_mlp"]
-            out["cpu_baseline"]["prove_other_circuits"] = {name: brief(pr_[name]) for name in ("mlp_k22", "conv2d_mnist", "einsum", "mlp") if isinstance(pr_.get(name), dict)}
-            if isinstance(pr_.get("einsum"), dict):
-                out["cpu_baseline"]["prove_other_circuits"]["einsum"]["cold_seconds"] = pr_["einsum"].get("cold_seconds")
-            out["cpu_baseline"]["prove_skipped"] = pr_.get("skipped")
         if prove_multi is not None:
             out["prove"] = prove_multi
         if strong is not None:
             out["extra"]["msm_strong_scaling"] = strong
-        print(json.dumps(out), flush=True)
+        if errors:
+            out["errors"] = errors
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 6000        # the driver's record keeps the last 8 000 characters of stdout: the ONE line must fit with room to spare (round 5's 20 KB line was lost)
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (the line is a record, not a checkpoint); containers recursively"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(full):
+    """The ONE JSON line of the contract, cut down to the keys the contract reads -- everything else lives in
+    bench_full.json.  Pure function of the full record, so tests/test_bench_line.py can size it from canned records without a GPU."""
+    g = lambda d, *ks: ({k: d.get(k) for k in ks if d.get(k) is not None} if isinstance(d, dict) else None)
+    rf, cb = full.get("roofline") or {}, full.get("cpu_baseline")
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["clock_warmup_steps"] = g(full.get("clock_warmup_steps"), "msm", "ntt")
+    line["config"] = g(full.get("config"), "workload", "parallelism")
+    r = g(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "msm_device_ms")
+    r["traffic_source"] = (rf.get("traffic_source") or "")[:100] or None
+    r["ntt"] = g(rf.get("ntt"), "elems_per_s", "ms_per_step", "device_ms_per_transform", "launches_per_transform", "achieved", "frac", "traffic",
+                 "inverse_elems_per_s", "coset_2p20_to_2p22_elems_per_s")
+    for k in ("msm_witness_like", "msm_two_in_flight"):
+        if rf.get(k):
+            r[k] = g(rf[k], "pts_per_s", "ms_per_step", "accumulate_ms", "device_ms")
+    r["product_peak"] = rf.get("product_peak")
+    # the kernels of the metric's own workload, one short row each (the long form: bench_full.json roofline_kernels)
+    r["kernels"] = [dict(g(k_, "kernel", "avg_launch_ms", "achieved", "frac", "traffic"), valu_frac=(k_.get("valu") or {}).get("frac"))
+                    for k_ in (full.get("roofline_kernels") or [])]
+    line["roofline"] = r
+    p20 = g(full.get("prove_seconds_k20_mlp"), "gpu", "gpu_first_of_process", "cold", "cpu", "cpu_threads", "identical", "verifier_accepts", "error")
+    if cb is not None:
+        c = g(cb, "value", "unit", "cores", "kind", "matches_gpu_result")
+        c["sample"] = (cb.get("sample") or "")[:110]
+        c["ntt"] = g(cb.get("ntt"), "value", "unit", "cores", "inverse_2p22_elems_per_s", "coset_2p20_to_2p22_elems_per_s", "matches_gpu_result", "error")
+        if p20:
+            c["prove_seconds_k20_mlp"] = p20
+        line["cpu_baseline"] = c
+    if p20:
+        line["prove_seconds_k20_mlp"] = p20
+    pr = full.get("prove") or {}
+    if "n_gpus" in pr or "rccl_ranks_seen" in pr or ("error" in pr and full.get("n_gpus", 1) > 1):        # N > 1: the sharded proof of configs[3]
+        line["rccl_ranks_seen"] = pr.get("rccl_ranks_seen")
+        m = g(pr, "n_gpus", "sharding", "rccl_ranks_seen", "prove_seconds_gpu", "all_ranks_same_proof", "verifier_accepts", "exchange_ms_per_proof_max", "error")
+        c_ = pr.get("circuit")
+        m["circuit"] = str((c_.get("circuit") if isinstance(c_, dict) else c_) or "")[:60]
+        if isinstance(pr.get("mlp_k20"), dict):
+            m["mlp_k20"] = g(pr["mlp_k20"], "prove_seconds_gpu", "all_ranks_same_proof", "verifier_accepts", "rccl_ranks_seen", "error")
+        line["prove_multi"] = m
+    else:
+        brief = lambda d: g(d, "prove_seconds_gpu", "prove_seconds_cpu", "proofs_identical_gpu_cpu", "verifier_accepts", "hbm_in_use_gib_after_prove", "cold_seconds", "error")
+        others = {n: brief(pr[n]) for n in ("mlp_k22", "conv2d_mnist", "einsum", "mlp", "relu_k8") if isinstance(pr.get(n), dict)}
+        if others:
+            line["prove_other_circuits"] = others
+        if pr.get("skipped"):
+            line["prove_skipped"] = [str(x)[:60] for x in pr["skipped"]][:6]
+    if full.get("rccl_ranks_seen") is not None:
+        line["rccl_ranks_seen"] = full["rccl_ranks_seen"]
+    ss = (full.get("extra") or {}).get("msm_strong_scaling")
+    if ss:
+        line["msm_strong_scaling"] = {k: (g(v, "ms_per_msm", "pts_per_s") if isinstance(v, dict) else str(v)[:120]) for k, v in ss.items()}
+    if full.get("errors"):
+        line["errors"] = [str(e)[:120] for e in full["errors"]][:4]
+    line["full_record"] = "bench_full.json"
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    # belt and braces: whatever a leg put into the record, the line that goes out is short
+    for drop in ("prove_other_circuits", "msm_strong_scaling", "prove_multi", "prove_skipped"):
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        line.setdefault("dropped_for_size", []).append(drop)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(full):
+    """rank 0: the full record to bench_full.json (repo root, and gpurun_out/ when that exists so that it travels back from the GPU
+    box), the contract's line -- and nothing else -- to stdout"""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError as e:
+                print("bench: could not write %s/bench_full.json: %r" % (d, e), file=sys.stderr)
+    print(compact_line(full), flush=True)
 
 
 def strong_scaling(world, rank, dist, dev, B, D, torch, args, barrier_sync):
