@@ -43,6 +43,24 @@ def rand_fr(rng, n):
     return a
 
 
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+MONT_R = (1 << 256) % R_MOD
+
+
+def witness_like_fr(rng, n):
+    """SURVEY.md §8(d) / BASELINE.md §3 distribution (W): 70 % small signed values (|x| < 2^15 through integer_rep_to_felt,
+    /root/reference/src/fieldutils.rs:9-17), 20 % zero, 10 % uniform -- Montgomery residues, what an advice column holds"""
+    out = rand_fr(rng, n)
+    kind = rng.random(n)
+    lo = -(1 << 15) + 1
+    small = rng.integers(lo, 1 << 15, size=n)
+    table = np.frombuffer(b"".join(((v % R_MOD) * MONT_R % R_MOD).to_bytes(32, "little") for v in range(lo, 1 << 15)), np.uint64).reshape(-1, 4)
+    is_small = kind < 0.7
+    out[is_small] = table[small[is_small] - lo]
+    out[(kind >= 0.7) & (kind < 0.9)] = 0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +182,35 @@ def main():
             t_msm2 = None
             print("bench: two-in-flight leg failed: %r" % (e,), file=sys.stderr)
 
+    # ... and the second scalar distribution of the contract: (W) witness-like scalars -- what the advice
+    # columns a prover commits look like.  The same K synchronous steps over the same bases; reported beside the headline
+    # (roofline.msm_witness_like), checked against the oracle in the cpu_baseline leg.  Single rank only, like the leg above.
+    w_leg = None
+    if world == 1:
+        try:
+            scalars_w = B.DeviceBuffer.from_numpy(witness_like_fr(np.random.default_rng(SEED + 17), n_msm))
+            for _ in range(max(3, args.warmup)):
+                result_w = B.msm_g1_dev(bases, scalars_w.ptr, n_msm)
+            barrier_sync()
+            B.kernel_ms_stats("msm_accumulate", reset=True)
+            os.environ["EZKL_HIP_TIMING"] = "kernel"
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                result_w = B.msm_g1_dev(bases, scalars_w.ptr, n_msm)
+            barrier_sync()
+            t_w = time.perf_counter() - t0
+            os.environ.pop("EZKL_HIP_TIMING", None)
+            a_s, a_c = B.kernel_ms_stats("msm_accumulate")
+            B.kernel_ms_stats("msm", reset=True)
+            for _ in range(5):
+                B.msm_g1_dev(bases, scalars_w.ptr, n_msm)
+            barrier_sync()
+            m_s, m_c = B.kernel_ms_stats("msm")
+            w_leg = {"pts_per_s": n_msm * args.steps / t_w, "ms_per_step": t_w / args.steps * 1e3, "accumulate_ms": a_s / max(1, a_c),
+                     "device_ms": m_s / max(1, m_c), "distribution": "70 % |x| < 2^15 signed, 20 % zero, 10 % uniform (BASELINE.md §3 W)"}
+        except Exception as e:                          # never lose the headline line to this leg
+            errors.append("witness-like MSM leg failed: %r" % (e,))
+
     # the NTT region: K transforms queued stream-ordered on the library stream, as a prover queues them (ezkl_hip_set_async), one
     # barrier + synchronise at the end; the MSM region above is synchronous by nature (every step returns its point to the host)
     for _ in range(CLOCK_WARMUP_NTT):
@@ -188,6 +235,31 @@ def main():
     ntt_ms = [ntt_sum / max(1, ntt_cnt)]
     if ntt_cnt != max(5, args.steps // 2):
         errors.append("ntt event pairs harvested: %d for %d steps" % (ntt_cnt, max(5, args.steps // 2)))
+
+    # the other two forms BASELINE.md §3 names, on the GPU as on the CPU (cpu_baseline.ntt): the inverse transform (lagrange_to_coeff: omega^-1 and
+    # the 1/n scale) and the prover's coset form (coeff_to_extended: 2^20 coefficients, zeta twist, zero-extended to 2^22), queued the same way
+    ntt_forms = {}
+    try:
+        was_async = B.set_async(True)
+        os.environ["EZKL_HIP_TIMING"] = "none"
+        def timed(f):
+            for _ in range(max(3, args.warmup)):
+                f()
+            barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                f()
+            barrier_sync()
+            return (time.perf_counter() - t0) / args.steps
+        ntt_forms["inverse_elems_per_s"] = world * n_ntt / timed(lambda: B.ntt_dev(col.ptr, LOG_NTT, dom.omega_inv, inverse=True))
+        cos_out = B.DeviceBuffer(n_ntt * 32)
+        ntt_forms["coset_2p20_to_2p22_elems_per_s"] = world * n_ntt / timed(lambda: B.coset_ntt_dev(col.ptr, cos_out.ptr, 20, 22))
+        cos_out.free()
+    except Exception as e:
+        errors.append("inverse / coset NTT legs failed: %r" % (e,))
+    finally:
+        os.environ.pop("EZKL_HIP_TIMING", None)
+        B.set_async(was_async)
 
     # batched commit (one prover phase: 4 independent 2^20-point columns per call, pipelined over streams)
     # (kept out of the default run so that rocprofv3's per-kernel averages of `python bench.py` are those of the
@@ -280,12 +352,14 @@ def main():
                                  "ms_per_step": t_ntt / args.steps * 1e3, "device_ms_per_transform": float(np.mean(ntt_ms)), "launches_per_transform": 3,
                                  "bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * n_ntt / (float(np.mean(ntt_ms)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": NTT_BYTES_PER_ELEM * n_ntt / (float(np.mean(ntt_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": ntt_traffic,
+                                 "inverse_elems_per_s": ntt_forms.get("inverse_elems_per_s"), "coset_2p20_to_2p22_elems_per_s": ntt_forms.get("coset_2p20_to_2p22_elems_per_s"),
                                  "steps_queued": "stream-ordered (ezkl_hip_set_async), one synchronise after the K steps; no event records inside the timed region, device_ms_per_transform from steps right after it"},
                          # what the kernels are actually bound by, measured in this run (ezkl_hip_ubench): 254-bit Montgomery products per second with
                          # every lane issuing the radix-2^29 product and nothing else; and the copy bandwidth this box reaches
                          "product_peak": {"modmul29_per_s": modmul29, "modmul32_per_s": modmul, "hbm_copy_GBs": copy_bps / 1e9},
                          "msm_device_ms": float(np.mean(msm_ms)),
                          "timing_events": "timed region: one HIP event pair per step, around msm_accumulate_kernel (EZKL_HIP_TIMING=kernel); msm_device_ms from steps after the region with both pairs",
+                         "msm_witness_like": w_leg,
                          "msm_two_in_flight": ({"pts_per_s": n_msm * args.steps / t_msm2, "ms_per_step": t_msm2 / args.steps * 1e3,
                                                 "note": "the same K steps with step i + 1 queued before step i is waited for (ezkl_hip_msm_g1_start_dev / _finish); not the headline"}
                                                if t_msm2 else None)},
@@ -300,6 +374,13 @@ def main():
                                  "batch_matches_single": bool((bres[0] == B.msm_g1_dev(bases, scalars.ptr, n_msm)).all())})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(bases, scalars, n_msm, result)
+            if w_leg is not None:                        # the (W) result against the oracle on the same input
+                from oracle import binding as ob_
+                t0 = time.perf_counter()
+                same_w = bool((ob_.msm(scalars_w.to_numpy(shape=(n_msm, 4)), bases.download()) == result_w).all())
+                out["cpu_baseline"]["witness_like"] = {"value": n_msm / (time.perf_counter() - t0), "unit": "pts/s", "matches_gpu_result": same_w}
+                if not same_w:
+                    raise SystemExit("bench: GPU MSM result (witness-like scalars) differs from the CPU oracle")
             try:
                 out["cpu_baseline"]["ntt"] = cpu_baseline_ntt(B, dom)
             except Exception as e:                       # never lose the headline line to this leg
@@ -417,6 +498,7 @@ def compact_line(full):
     if cb is not None:
         c = g(cb, "value", "unit", "cores", "kind", "matches_gpu_result")
         c["sample"] = (cb.get("sample") or "")[:110]
+        c["witness_like"] = cb.get("witness_like")
         c["ntt"] = g(cb.get("ntt"), "value", "unit", "cores", "inverse_2p22_elems_per_s", "coset_2p20_to_2p22_elems_per_s", "matches_gpu_result", "error")
         if p20:
             c["prove_seconds_k20_mlp"] = p20

@@ -168,10 +168,15 @@ int ev_harvest(Ctx::EvRing& r, bool all) {
     while (r.tail < r.head && (all || r.head - r.tail >= Ctx::EvRing::N)) {
         const unsigned i = (unsigned)(r.tail % Ctx::EvRing::N);
         float ms = 0;
-        EZ_HIP(hipEventSynchronize(r.e1[i]));
-        EZ_HIP(hipEventElapsedTime(&ms, r.e0[i], r.e1[i]));
-        r.sum_ms += ms;
-        r.count++;
+        // a pair whose second event was never recorded (the call that took it returned on an error in between) is SKIPPED, not fatal: one
+        // transient failure must not leave the ring -- and every later timed call -- broken
+        if (hipEventSynchronize(r.e1[i]) == hipSuccess && hipEventElapsedTime(&ms, r.e0[i], r.e1[i]) == hipSuccess) {
+            r.sum_ms += ms;
+            r.count++;
+        } else {
+            (void)hipGetLastError();
+            r.skipped++;
+        }
         r.tail++;
     }
     return EZKL_OK;

@@ -29,7 +29,7 @@ struct Ctx {
         bool made[N];
         uint64_t head = 0, tail = 0;      // pairs [tail, head) are recorded and not harvested yet
         double sum_ms = 0;
-        uint64_t count = 0;
+        uint64_t count = 0, skipped = 0;   // skipped: pairs whose events could not be read (taken by a call that failed before recording them)
         EvRing() { for (unsigned i = 0; i < N; i++) { e0[i] = e1[i] = nullptr; made[i] = false; } }
     };
     std::map<std::string, EvRing> events;

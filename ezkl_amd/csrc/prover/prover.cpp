@@ -998,30 +998,37 @@ static Fe vk_digest(const ProvingKey& pk) {
     auto h = keccak256(t.data(), t.size());
     return Fe::from_canonical(reduce_fr(from_be32(h.data())));
 }
-// Before a key is built or loaded: will it fit?  The resident key is (fixed + permutation columns) x (values + coefficients + this rank's
-// cosets of the extended domain) + l_0 / l_last / l_active / X on those cosets, 32 bytes per element; a proof then needs its witness
-// columns in the same three forms next to it.  At k = 22 / 30 advice columns that is 175 of the 288 GB; k = 23, or a wider circuit at
-// k = 22, does not fit ONE GPU -- and used to say so only when some hipMalloc deep inside keygen failed.  Now the call fails up front, with
-// the sizes and the way out (owner mode over more GPUs divides the coset term by the world size).
+// Before a key is built or loaded (keygen, pk_read, pk_read_file): will it fit?  The resident key is (fixed + permutation columns) x (values
+// + coefficients + this rank's cosets of the extended domain) + l_0 / l_last / l_active / X on those cosets, 32 bytes per element.  At k = 22
+// / 30 advice columns that is 61 GB; k = 23, or a wider circuit at k = 22, does not fit ONE GPU -- and used to say so only when some hipMalloc
+// deep inside keygen failed.  Only the KEY term refuses the call: it is exact.  What a later proof needs for its witness columns (advice,
+// m / phi / compressed inputs, z, h in value + coefficient form and on this rank's share of the cosets -- in owner mode a rank holds the
+// forms of the columns it owns, about the same share) is an estimate and the caller may never prove with this key, so it is a warning on
+// stderr.  EZKL_PROVER_SKIP_FIT_CHECK=1 turns the check off; EZKL_PROVER_ASSUME_FREE_GIB=<x> (test hook) pretends the device has x GiB left.
 static void check_key_fits(const ConstraintSystem& cs, uint32_t coset_count, const char* what) {
+    if (const char* e = getenv("EZKL_PROVER_SKIP_FIT_CHECK")) if (*e && *e != '0') return;
     const uint64_t n = cs.n, cols = (uint64_t)cs.n_fixed + cs.perm.size();
     const uint64_t key = (cols * (2 + (uint64_t)coset_count) + 4ull * coset_count) * n * 32;
     const uint64_t E = 1ull << (cs.ext_k - cs.k);
-    const uint64_t witness = ((uint64_t)cs.n_advice + 3ull * cs.lookups.size() + cs.n_chunks + 2) * (2 + E) * n * 32;   // advice, m / phi / compressed inputs, z, h
+    const double share = (double)coset_count / (double)E;                   // 1 on one rank / replicated; 1 / world by owner
+    const uint64_t wcols = (uint64_t)cs.n_advice + 3ull * cs.lookups.size() + cs.n_chunks + 2;
+    const uint64_t witness = (uint64_t)((double)(wcols * (2 + E) * n * 32) * share);
     size_t free_b = 0, total_b = 0, pool[4] = {0, 0, 0, 0};
     if (ezkl_hip_mem_info(&free_b, &total_b) != EZKL_OK) return;            // no device: the first kernel call reports it
     (void)ezkl_hip_pool_stats(pool);
     uint64_t avail = (uint64_t)free_b + pool[2];                            // parked blocks of the column pool are reusable
-    if (const char* e = getenv("EZKL_PROVER_ASSUME_FREE_GIB")) avail = (uint64_t)(atof(e) * 1073741824.0);   // test hook: pretend the device has this much left
+    if (const char* e = getenv("EZKL_PROVER_ASSUME_FREE_GIB")) avail = (uint64_t)(atof(e) * 1073741824.0);
     if (key + witness <= avail) return;
-    char msg[512];
+    char msg[640];
     snprintf(msg, sizeof msg,
              "%s: the proving key of this circuit needs %.1f GiB resident on the device (%llu key columns x 2^%u rows, %u of %llu cosets of the extended "
              "domain 2^%u) and a proof about %.1f GiB more for its witness columns; %.1f GiB are available of %.1f GiB. Shard the key over more GPUs "
-             "(owner mode, ezkl_prover_cs_set_shard_exchange: the coset term divides by the world size) or lower logrows.",
+             "(owner mode, ezkl_prover_cs_set_shard_exchange: the coset term divides by the world size), lower logrows, or set "
+             "EZKL_PROVER_SKIP_FIT_CHECK=1 to try regardless.",
              what, key / 1073741824.0, (unsigned long long)cols, cs.k, coset_count, (unsigned long long)E, cs.ext_k, witness / 1073741824.0,
              avail / 1073741824.0, total_b / 1073741824.0);
-    throw Error(EZKL_ERR_NOMEM, msg);
+    if (key > avail) throw Error(EZKL_ERR_NOMEM, msg);
+    fprintf(stderr, "[ezkl_prover] warning: %s\n", msg);                    // the key fits; a proof with it may not
 }
 static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies) {
     const uint32_t n = cs.n, k = cs.k;
@@ -1181,6 +1188,7 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
 }
 static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* buf, size_t len) {
     Backend be(cs.k, cs.n, nullptr, nullptr);
+    check_key_fits(cs, 1u << (cs.ext_k - cs.k), "pk_read");   // the file's complete extended columns
     size_t off = 0;
     auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
     need(7);
@@ -1266,6 +1274,11 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     (void)madvise(map, len, MADV_SEQUENTIAL);
     const uint8_t* buf = (const uint8_t*)map;
     Backend be(cs.k, cs.n, nullptr, nullptr, cs.shard);       // owner mode: only the cosets this rank sweeps are computed and kept
+    {
+        uint32_t first = 0, count = 0;
+        be.key_range(cs.ext_k, first, count);
+        check_key_fits(cs, count, "pk_read_file");
+    }
     size_t off = 0;
     auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
     need(7);

@@ -173,8 +173,10 @@ def _quantize(v, scale, datum_type):
     if isinstance(v, str):                                   # a field element, as hex (FileSourceInner::Field)
         return codecs.felt_from_hex_le(v) % EL.R
     x = float(v)
-    if datum_type in ("F32", "F16"):
+    if datum_type == "F32":
         x = struct.unpack("f", struct.pack("f", x))[0]
+    elif datum_type == "F16":                                # through half precision, as InputType::roundtrip does (f16::from_f64)
+        x = float(np.float16(x))
     elif datum_type in ("Int", "TDim"):
         x = float(int(x))
     elif datum_type == "Bool":

@@ -406,14 +406,19 @@ def create_proof(pk, g, g_lagrange, advice_values, rng=None, seed=0, instances=(
         fmts = []
         for a in advice_values:
             a = np.asarray(a)
+            # the format follows from dtype AND shape; anything else is refused rather than reinterpreted (a mis-shaped Montgomery
+            # column taken for integers would prove a different witness)
             if a.dtype == np.int64 and a.ndim == 1:
                 fmts.append(1); a = np.ascontiguousarray(a)
-            elif a.ndim == 2 and a.shape[1] == 2:
-                fmts.append(2); a = np.ascontiguousarray(a, np.uint64)
+            elif a.dtype == np.uint64 and a.ndim == 2 and a.shape[1] == 2:
+                fmts.append(2); a = np.ascontiguousarray(a)
+            elif a.dtype == np.uint64 and a.size == 4 * n and (a.ndim == 1 or (a.ndim == 2 and a.shape[1] == 4)):
+                fmts.append(0); a = np.ascontiguousarray(a).reshape(n, 4)
             else:
-                fmts.append(0); a = np.ascontiguousarray(a, np.uint64)
-                assert a.size == 4 * n, "an advice column is 2^k x 32 bytes"
-            assert a.shape[0] == n
+                raise ValueError("advice column %d: expected (n, 4) uint64 Montgomery words, (n,) int64 or (n, 2) uint64 IntegerRep values with n = %d; got %s %s"
+                                 % (len(fmts), n, a.dtype, a.shape))
+            if a.shape[0] != n:
+                raise ValueError("advice column %d has %d rows, the circuit has %d" % (len(fmts), a.shape[0], n))
             keep.append(a)
         adv_arr = _ptr_array(keep)
         if any(fmts):

@@ -7,6 +7,8 @@ evaluate_h sizes the small-circuit tests do not reach.
 
   configs[2]  examples/conv2d_mnist at k = 17 (its own Config and layout, /root/reference/examples/conv2d_mnist/main.rs)
   configs[2]' the MLP over the ezkl gate set at k = 17 (the k = 20 circuit of the metric, three doublings smaller)
+  the metric  the MLP at k = 20 ("ezkl prove wall-seconds (k = 20 MLP)"): a k = 20 regression turns the suite red, not a bench field
+  configs[3]  the reference's accum_einsum_matmul bench circuit raised to k = 20: second-phase advice + two challenges (Freivalds)
 """
 import os
 import sys
@@ -23,15 +25,19 @@ G2 = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,k", [("conv", 17), ("mlp", 17)])
+@pytest.mark.parametrize("kind,k", [("conv", 17), ("mlp", 17), ("mlp", 20), ("einsum", 20)])
 def test_gpu_proof_equals_cpu_oracle_proof_at_bench_size(hip, kind, k):
     import bench_circuits as BC
     from ezkl_amd import backend as B, native as NV, plonk as P
     from oracle import pairing as E, verifier as V
     from oracle.cpu_backend import OracleBackend
-    assert os.path.exists(os.path.join(ROOT, "bench_cache", "%s_k%d_s1.npz" % (kind, k))), "the laid-out circuit ships with the repo"
+    if kind != "einsum":                                        # (the einsum witness depends on the proof's challenges: laid out per proof, 1.3 s)
+        assert os.path.exists(os.path.join(ROOT, "bench_cache", "%s_k%d_s1.npz" % (kind, k))), "the laid-out circuit ships with the repo"
     built = BC.build(kind, k, gpu=B)
-    assert "read from" in built["info"].get("layout", "")
+    if kind != "einsum":
+        assert "read from" in built["info"].get("layout", "")
+    else:
+        assert sum(built["cs"].advice_phase) == 3 and built["cs"].n_challenges == 2
     cs, fixed, copies, adv, instances = built["cs"], built["fixed"], built["copies"], built["advice"], built["instances"]
     assert cs.k == k
     s = 0x1234567890abcdef1234567890abcdef % P.R

@@ -113,6 +113,26 @@ def test_full_size_2_20(hip):
     bases.free()
 
 
+def test_full_size_2_20_witness_like(hip):
+    """BASELINE.md §3 distribution (W) at the full size of configs[1]: what the advice columns of a proof look like (one or two non-zero
+    digits per scalar, 20 % zeros, every carry of the signed recoding in bucket 0) -- the device-side lane length, the bucket-0 partition
+    and the boundary tree all take their skewed branches here.  Oracle check on all 2^20 points + the same column in a fused batch."""
+    from ezkl_amd import backend as B
+    n = 1 << 20
+    rng = np.random.default_rng(21)
+    bases = B.Bases.generate(SEED, n)
+    pts = bases.download()
+    s = witness_like(rng, n)
+    want = ob.msm(s, pts)
+    assert (B.msm_g1(bases, s) == want).all()
+    d = B.DeviceBuffer.from_numpy(s)
+    u = B.DeviceBuffer.from_numpy(rand_fr(rng, n))
+    got = B.msm_g1_batch_dev(bases, [d.ptr, u.ptr, d.ptr], n)
+    assert (got[0] == want).all() and (got[2] == want).all()
+    assert (got[1] == B.msm_g1_dev(bases, u.ptr, n)).all()
+    bases.free()
+
+
 @pytest.mark.parametrize("n,batch", [(1000, 7), (1 << 14, 5), (1 << 18, 4)])
 def test_batch_pipelined_matches_single(hip, n, batch):
     """one commit phase: `batch` columns against the same bases, pipelined over streams"""
@@ -277,8 +297,11 @@ def test_sparse_column_is_fast_and_correct(hip):
     got = B.msm_g1_dev(bases, d.ptr, n)
     dt = time.perf_counter() - t0
     assert (got == ob.msm(s, pts)).all()
-    # reported, not asserted: a parity test must not turn red on a busy box (the bound used to be 10 ms; a healthy run is ~0.3 ms)
-    print("sparse MSM of 2^%d points: %.2f ms%s" % (n.bit_length() - 1, dt * 1e3, "  (SLOW: > 10 ms)" if dt >= 0.01 else ""))
+    # a healthy run is ~0.3 ms; walking every empty bucket (the regression this guards: the empty-bucket binary search of the accumulate
+    # loop) costs hundreds of ms.  The bound is loose so that a busy box does not turn a parity test red: EZKL_TEST_PERF_STRICT=1 asks for 10 ms
+    import os
+    print("sparse MSM of 2^%d points: %.2f ms" % (n.bit_length() - 1, dt * 1e3))
+    assert dt < (0.01 if os.environ.get("EZKL_TEST_PERF_STRICT") == "1" else 0.1), "sparse column took %.1f ms" % (dt * 1e3)
     bases.free()
 
 
@@ -475,7 +498,9 @@ def test_concurrent_callers_overlap(hip):
     assert all((a == b).all() for a, b in zip(got, want))
     print("4 MSMs of 2^18: serial %.3f ms, 4 threads %.3f ms" % (t_serial * 1e3, t_par * 1e3))
     # the overlap is reported, not asserted (measured 0.73x; a wall-clock ratio can turn a correct build red on a busy box)
-    if t_par >= 1.25 * t_serial: print("NOTE: no overlap between concurrent callers in this run")
+    # concurrent callers must not serialise behind one another's host tails (call slots): loose bound, EZKL_TEST_PERF_STRICT=1 asks for 1.25 x
+    import os
+    assert t_par < (1.25 if os.environ.get("EZKL_TEST_PERF_STRICT") == "1" else 2.0) * t_serial, (t_par, t_serial)
 
 
 def test_params_downsize_matches_the_reference_srs_and_the_oracle(hip, golden_srs):

@@ -509,6 +509,24 @@ def test_keygen_refuses_up_front_when_the_key_cannot_fit(hip, golden_srs, monkey
         N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
     msg = str(e.value)
     assert "GiB" in msg and "key columns" in msg and "owner mode" in msg, msg
+    # the documented override: the check steps aside and the small key simply builds
+    monkeypatch.setenv("EZKL_PROVER_SKIP_FIT_CHECK", "1")
+    assert N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies).vk()[2]
+    monkeypatch.delenv("EZKL_PROVER_SKIP_FIT_CHECK")
     monkeypatch.delenv("EZKL_PROVER_ASSUME_FREE_GIB")
     pk = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)          # and with the real device it goes through
     assert pk.vk()[2]
+    # the key alone fits, key + the estimated witness columns do not: a warning, not a refusal (a keygen-only caller never proves).
+    # key = (cols (2 + E) + 4 E) n 32 bytes
+    E = 1 << (cs.ext_k - cs.k)
+    key_bytes = ((cs.n_fixed + len(cs.perm)) * (2 + E) + 4 * E) * (1 << cs.k) * 32
+    monkeypatch.setenv("EZKL_PROVER_ASSUME_FREE_GIB", repr((key_bytes + 64) / 2.0 ** 30))
+    assert N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies).vk()[2]
+    # the read paths check as well (they used to fail deep inside hipMalloc)
+    blob = pk.to_bytes()
+    monkeypatch.setenv("EZKL_PROVER_ASSUME_FREE_GIB", "0.00001")
+    with pytest.raises(Exception) as e:
+        N.NativeProvingKey.from_bytes(N.NativeCircuit(cs), blob)
+    assert "pk_read" in str(e.value) and "GiB" in str(e.value)
+    monkeypatch.delenv("EZKL_PROVER_ASSUME_FREE_GIB")
+    assert N.NativeProvingKey.from_bytes(N.NativeCircuit(cs), blob).vk()[2] == pk.vk()[2]
