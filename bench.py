@@ -544,13 +544,15 @@ def compact_line(full):
 def emit(full):
     """rank 0: the full record to bench_full.json (repo root, and gpurun_out/ when that exists so that it travels back from the GPU
     box), the contract's line -- and nothing else -- to stdout"""
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, "bench_full.json"), "w") as f:
-                    json.dump(full, f, indent=1)
-            except OSError as e:
-                print("bench: could not write %s/bench_full.json: %r" % (d, e), file=sys.stderr)
+    paths = [os.path.join(d, "bench_full.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    if os.environ.get("EZKL_BENCH_FULL"):                 # ... or exactly where the caller wants it (the tests)
+        paths = [os.environ["EZKL_BENCH_FULL"]]
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError as e:
+            print("bench: could not write %s: %r" % (path, e), file=sys.stderr)
     print(compact_line(full), flush=True)
 
 

@@ -945,6 +945,12 @@ def comm_alltoallv_dev(sends, recvs):
     _l.check(_l.load().ezkl_hip_comm_alltoallv_dev(sa, C.c_size_t(len(sends)), ra, C.c_size_t(len(recvs))), "ezkl_hip_comm_alltoallv_dev")
 
 
+def comm_selftest():
+    """ezkl_hip_comm_selftest: the library communicator tries out every collective shape the prover uses (a collective: every rank calls
+    it; ezkl_hip_comm_init already ran it unless EZKL_COMM_SELFTEST=0).  Raises EzklHipError with the failing status."""
+    _l.check(_l.load().ezkl_hip_comm_selftest(), "ezkl_hip_comm_selftest")
+
+
 def comm_available():
     """librccl loads and exports every entry point the library communicator binds (no device touched, nothing called)"""
     return _l.load().ezkl_hip_comm_available() == 0

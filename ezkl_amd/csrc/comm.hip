@@ -15,6 +15,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <rccl/rccl.h>
 
 namespace ezkl {
@@ -30,6 +31,7 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional: the watchdog uses it to release a stuck communicator
 };
 static RcclApi g_rccl;
 struct Comm {
@@ -46,8 +48,51 @@ struct Comm {
     void* desc_host = nullptr;      // pinned
     size_t desc_cap = 0;            // descriptors
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t wd_ev = nullptr;     // the watchdog's event (comm_wait)
+    bool broken = false;            // a collective timed out: every later call fails at once instead of hanging behind it
 };
 static Comm g_comm;
+
+// ---- watchdog: every collective is WAITED FOR with a deadline ---------------------------------------------------------------------------
+// A peer that died, took another branch or never arrived leaves the others inside a collective for ever: hipStreamSynchronize on the
+// communicator's stream does not come back, the job hangs until a driver's outer timeout kills it and nobody learns which call it was.
+// comm_wait records an event behind the queued work and polls it: past EZKL_COMM_TIMEOUT_S seconds (default 120; 0 = wait for ever) the
+// call names the collective on stderr, aborts the communicator (ncclCommAbort, so that the process can exit) and returns
+// EZKL_ERR_TIMEOUT -- a status code a caller can act on (libezkl_prover.so fails the proof on every rank: failures are collective).
+static double comm_timeout_s() {
+    const char* e = getenv("EZKL_COMM_TIMEOUT_S");
+    if (!e || !*e) return 120.0;
+    const double v = atof(e);
+    return v < 0 ? 120.0 : v;
+}
+static int comm_wait(const char* what) {
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;
+    const double limit = comm_timeout_s();
+    if (limit == 0.0) { EZ_HIP(hipStreamSynchronize(g_comm.st)); return EZKL_OK; }
+    if (!g_comm.wd_ev) EZ_HIP(hipEventCreateWithFlags(&g_comm.wd_ev, hipEventDisableTiming));
+    EZ_HIP(hipEventRecord(g_comm.wd_ev, g_comm.st));
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(g_comm.wd_ev);
+        if (q == hipSuccess) return EZKL_OK;
+        if (q != hipErrorNotReady) { EZ_HIP(q); }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > limit) break;
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.01 ? 20 : 500));   // spin for the common case, then back off
+    }
+    (void)hipGetLastError();
+    fprintf(stderr, "[ezkl_hip] rank %d of %d: %s did not complete within %.0f s (EZKL_COMM_TIMEOUT_S): a peer is missing or took another "
+                    "path; aborting the communicator\n", g_comm.rank, g_comm.world, what, limit);
+    g_comm.broken = true;
+    if (g_rccl.CommAbort && g_comm.comm) { (void)g_rccl.CommAbort(g_comm.comm); g_comm.comm = nullptr; }
+    return EZKL_ERR_TIMEOUT;
+}
+#define EZ_WAIT(what)                                                   \
+    do {                                                                \
+        int _w = comm_wait(what);                                       \
+        if (_w) return _w;                                              \
+    } while (0)
 
 static int rccl_load() {
     if (g_rccl.lib) return EZKL_OK;
@@ -88,6 +133,7 @@ static int rccl_load() {
     EZ_SYM(GroupEnd, "ncclGroupEnd")
     EZ_SYM(GetErrorString, "ncclGetErrorString")
 #undef EZ_SYM
+    *(void**)(&a.CommAbort) = dlsym(h, "ncclCommAbort");
     g_rccl = a;
     return EZKL_OK;
 }
@@ -192,6 +238,7 @@ extern "C" {
 // ncclCommDestroy, ncclAllGather, ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd, ncclGetErrorString)?  No device and no RCCL call is
 // made: a dry check for a build box / CI, and the first thing an 8-rank job can ask before it commits to the library communicator.
 int ezkl_hip_comm_available(void) { return rccl_load(); }
+int ezkl_hip_comm_selftest(void);
 
 int ezkl_hip_comm_unique_id(void* out128) {
     if (!out128) return EZKL_ERR_INVALID;
@@ -218,6 +265,14 @@ int ezkl_hip_comm_init(const void* id128, int world, int rank) {
     EZ_RCCL(g_rccl.CommInitRank(&g_comm.comm, world, id, rank));
     g_comm.world = world;
     g_comm.rank = rank;
+    // every rank tries the communicator out before anything depends on it (EZKL_COMM_SELFTEST=0 skips; the setting must be the same
+    // on every rank -- the self-test is a collective)
+    const char* stest = getenv("EZKL_COMM_SELFTEST");
+    if (!stest || *stest != '0') {
+        rc = ezkl_hip_comm_selftest();
+        if (rc) fprintf(stderr, "[ezkl_hip] rank %d of %d: communicator self-test failed (%d); the communicator is not usable\n", rank, world, rc);
+        return rc;
+    }
     return EZKL_OK;
 }
 
@@ -229,9 +284,12 @@ int ezkl_hip_comm_info(int* world, int* rank) {
 
 int ezkl_hip_comm_destroy(void) {
     EZ_CTX(c);
-    if (!g_comm.comm) return EZKL_OK;
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
-    EZ_RCCL(g_rccl.CommDestroy(g_comm.comm));
+    if (!g_comm.comm && !g_comm.broken) return EZKL_OK;
+    if (g_comm.comm) {
+        EZ_HIP(hipStreamSynchronize(g_comm.st));
+        EZ_RCCL(g_rccl.CommDestroy(g_comm.comm));
+    }
+    if (g_comm.wd_ev) (void)hipEventDestroy(g_comm.wd_ev);
     if (g_comm.stage) (void)hipFree(g_comm.stage);
     if (g_comm.slab_send) (void)hipFree(g_comm.slab_send);
     if (g_comm.slab_recv) (void)hipFree(g_comm.slab_recv);
@@ -251,7 +309,7 @@ int ezkl_hip_comm_allgather_dev(void* buf_dev, size_t total_bytes) {
     const size_t slice = total_bytes / (size_t)g_comm.world;
     EZ_HIP(hipStreamSynchronize(c->stream));
     EZ_RCCL(g_rccl.AllGather((const char*)buf_dev + slice * (size_t)g_comm.rank, buf_dev, slice, ncclUint8, g_comm.comm, g_comm.st));
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    EZ_WAIT("all_gather (device)");
     return EZKL_OK;
 }
 
@@ -272,7 +330,7 @@ int ezkl_hip_comm_fold_points(void* points_host, uint32_t count) {
     EZ_RCCL(g_rccl.AllGather(st + slice * (size_t)g_comm.rank, st, slice, ncclUint8, g_comm.comm, g_comm.st));
     std::vector<uint8_t> all(total);
     EZ_HIP(hipMemcpyAsync(all.data(), st, total, hipMemcpyDeviceToHost, g_comm.st));
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    EZ_WAIT("fold_points (all_gather of partial sums)");
     uint8_t* out = (uint8_t*)points_host;
     for (uint32_t j = 0; j < count; j++) {
         uint8_t acc[64];
@@ -299,7 +357,7 @@ int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root) {
     EZ_HIP(hipMemcpyAsync(st + bytes * (size_t)g_comm.rank, buf_host, bytes, hipMemcpyHostToDevice, g_comm.st));
     EZ_RCCL(g_rccl.AllGather(st + bytes * (size_t)g_comm.rank, st, bytes, ncclUint8, g_comm.comm, g_comm.st));
     EZ_HIP(hipMemcpyAsync(buf_host, st + bytes * (size_t)root, bytes, hipMemcpyDeviceToHost, g_comm.st));
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    EZ_WAIT("broadcast (host)");
     return EZKL_OK;
 }
 
@@ -318,7 +376,7 @@ int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes) {
     EZ_HIP(hipMemcpyAsync(st + bytes * (size_t)g_comm.rank, h + bytes * (size_t)g_comm.rank, bytes, hipMemcpyHostToDevice, g_comm.st));
     EZ_RCCL(g_rccl.AllGather(st + bytes * (size_t)g_comm.rank, st, bytes, ncclUint8, g_comm.comm, g_comm.st));
     EZ_HIP(hipMemcpyAsync(h, st, total, hipMemcpyDeviceToHost, g_comm.st));
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    EZ_WAIT("all_gather (host)");
     return EZKL_OK;
 }
 
@@ -343,7 +401,7 @@ static int alltoallv_unpacked(Ctx* c, const ezkl_comm_seg_t* sends, size_t n_sen
     for (size_t i = 0; i < n_recvs; i++)
         if (recvs[i].peer != skip && recvs[i].bytes) { EZ_RCCL(g_rccl.Recv(recvs[i].ptr, recvs[i].bytes, ncclUint8, recvs[i].peer, g_comm.comm, g_comm.st)); g_comm.stats[5]++; }
     EZ_RCCL(g_rccl.GroupEnd());
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    EZ_WAIT("all-to-all (one send / recv per segment)");
     return EZKL_OK;
 }
 int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
@@ -431,7 +489,7 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
                 rc = comm_descs_reserve(std::max(pack.size(), unpack.size()));
                 if (rc) return rc;
             }
-            if (!first_round) EZ_HIP(hipStreamSynchronize(g_comm.st));     // the pinned descriptor block of the last round has been read
+            if (!first_round) EZ_WAIT("packed all-to-all (a round)");      // the pinned descriptor block of the last round has been read
             first_round = false;
             rc = comm_launch_copies(pack, pack_total, 0);
             if (rc) return rc;
@@ -446,7 +504,7 @@ int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, co
             if (rc) return rc;
             g_comm.stats[6]++;
         }
-        EZ_HIP(hipStreamSynchronize(g_comm.st));
+        EZ_WAIT("packed all-to-all");
     }
     if (rc) return rc;
     g_comm.stats[0]++;
@@ -483,7 +541,94 @@ int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, con
         if (recv_len[p]) EZ_RCCL(g_rccl.Recv((char*)recv_dev + recv_off[p], recv_len[p], ncclUint8, p, g_comm.comm, g_comm.st));
     }
     EZ_RCCL(g_rccl.GroupEnd());
-    EZ_HIP(hipStreamSynchronize(g_comm.st));
+    EZ_WAIT("all-to-all (device)");
+    return EZKL_OK;
+}
+
+// The communicator tries itself out: every collective shape the prover uses, once, with contents that can be checked -- run by every
+// rank right after ezkl_hip_comm_init (which calls it unless EZKL_COMM_SELFTEST=0), so that a job learns in its first second, with a
+// message, what it would otherwise learn as a hang or a wrong proof minutes in:
+//   1. all_gather (device) of the rank ids: slice r must hold r on every rank;
+//   2. ONE packed all-to-all of odd-sized segments (17 + 13 r + 7 p bytes from r to p, two segments each, byte pattern f(r, p, i)) --
+//      sizes that are no multiple of 16 and differ per pair: the byte path of the pack kernel and the per-peer totals;
+//   3. fold_points: every rank contributes (r + 1) G as an affine point; the fold must be (world (world + 1) / 2) G -- the group law on the
+//      host after an all_gather of 64-byte partials, i.e. the "RCCL reduce of the bucket sums" of every sharded commitment.
+// Everything under the watchdog.  EZKL_OK, or the failing step on stderr and EZKL_ERR_INVALID (wrong data) / EZKL_ERR_TIMEOUT / EZKL_ERR_HIP.
+int ezkl_hip_comm_selftest(void) {
+    EZ_CTX(c);
+    if (!g_comm.comm) return EZKL_ERR_INVALID;
+    const int world = g_comm.world, me = g_comm.rank;
+    auto fail = [&](const char* what) {
+        fprintf(stderr, "[ezkl_hip] rank %d of %d: communicator self-test FAILED at: %s\n", me, world, what);
+        return EZKL_ERR_INVALID;
+    };
+    // 1. all_gather of rank ids
+    {
+        std::vector<uint32_t> ids((size_t)world * 4, 0xffffffffu);
+        for (int i = 0; i < 4; i++) ids[(size_t)me * 4 + i] = (uint32_t)me;
+        uint32_t* d = nullptr;
+        EZ_HIP(hipMalloc((void**)&d, ids.size() * 4));
+        EZ_HIP(hipMemcpy(d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+        int rc = ezkl_hip_comm_allgather_dev(d, ids.size() * 4);
+        if (!rc) EZ_HIP(hipMemcpy(ids.data(), d, ids.size() * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        if (rc) return rc;
+        for (int r = 0; r < world; r++)
+            for (int i = 0; i < 4; i++)
+                if (ids[(size_t)r * 4 + i] != (uint32_t)r) return fail("all_gather of rank ids");
+    }
+    // 2. packed all-to-all of odd-sized segments
+    {
+        auto seg_len = [](int from, int to) { return (size_t)(17 + 13 * from + 7 * to); };
+        auto pat = [](int from, int to, size_t i) { return (uint8_t)(31 * from + 17 * to + 7 * i + 3); };
+        size_t tot_s = 0, tot_r = 0;
+        for (int p = 0; p < world; p++) { tot_s += seg_len(me, p); tot_r += seg_len(p, me); }
+        std::vector<uint8_t> hs(tot_s), hr(tot_r, 0);
+        char *ds = nullptr, *dr = nullptr;
+        EZ_HIP(hipMalloc((void**)&ds, tot_s));
+        EZ_HIP(hipMalloc((void**)&dr, tot_r));
+        std::vector<ezkl_comm_seg_t> sends, recvs;
+        size_t os = 0, orr = 0;
+        for (int p = 0; p < world; p++) {
+            const size_t ls = seg_len(me, p), lr = seg_len(p, me);
+            for (size_t i = 0; i < ls; i++) hs[os + i] = pat(me, p, i);
+            sends.push_back({p, ds + os, 5});                    // two segments per peer: the stream, not the segment, is the unit
+            sends.push_back({p, ds + os + 5, ls - 5});
+            recvs.push_back({p, dr + orr, lr - 9});              // ... cut elsewhere on the receiving side
+            recvs.push_back({p, dr + orr + (lr - 9), 9});
+            os += ls; orr += lr;
+        }
+        EZ_HIP(hipMemcpy(ds, hs.data(), tot_s, hipMemcpyHostToDevice));
+        EZ_HIP(hipMemset(dr, 0, tot_r));
+        int rc = ezkl_hip_comm_alltoallv_dev(sends.data(), sends.size(), recvs.data(), recvs.size());
+        if (!rc) EZ_HIP(hipMemcpy(hr.data(), dr, tot_r, hipMemcpyDeviceToHost));
+        (void)hipFree(ds); (void)hipFree(dr);
+        if (rc) return rc;
+        orr = 0;
+        for (int p = 0; p < world; p++) {
+            const size_t lr = seg_len(p, me);
+            for (size_t i = 0; i < lr; i++)
+                if (hr[orr + i] != pat(p, me, i)) return fail("packed all-to-all of odd-sized segments");
+            orr += lr;
+        }
+    }
+    // 3. fold of partial points
+    {
+        uint8_t G[64], mine[64], want[64], zero[64];
+        memset(zero, 0, 64);
+        static const uint64_t g_xy[8] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full,      // 1 * 2^256 mod q
+                                         0xa6ba871b8b1e1b3aull, 0x14f1d651eb8e167bull, 0xccdd46def0f28c58ull, 0x1c14ef83340fbe5eull};     // 2 * 2^256 mod q
+        memcpy(G, g_xy, 64);                                     // the generator (1, 2), Montgomery form
+        auto mul_small = [&](unsigned m, uint8_t* out) {          // m G by repeated addition (m <= a few dozen)
+            memcpy(out, zero, 64);
+            for (unsigned i = 0; i < m; i++) g1_add_affine_host(out, G, out);
+        };
+        mul_small((unsigned)me + 1, mine);
+        mul_small((unsigned)(world * (world + 1) / 2), want);
+        int rc = ezkl_hip_comm_fold_points(mine, 1);
+        if (rc) return rc;
+        if (memcmp(mine, want, 64)) return fail("fold_points (all_gather of 64-byte partials + group law)");
+    }
     return EZKL_OK;
 }
 

@@ -40,26 +40,9 @@
 
 namespace ezkl {
 
-// EZKL_MSM_PREFETCH=1 (default since round 5): the accumulate loop loads the next bucket end and the next-but-one payload one iteration ahead
-#ifndef EZKL_MSM_PREFETCH
-#define EZKL_MSM_PREFETCH 1
-#endif
-// EZKL_MSM_LEAN=1 (round 5; measured level with the default 0): the chain's three small memsets are done by the histogram kernel (one zeroed region), and the
-// partition scan runs in the LAST workgroup of the histogram scan (a ticket) instead of a launch of its own: 4 stream operations fewer
-#ifndef EZKL_MSM_LEAN
-#define EZKL_MSM_LEAN 0
-#endif
-// EZKL_MSM_RESET_ZZ=1 (round 5): a finished bucket resets only the accumulator's ZZ (the identity's encoding) instead of all 36 limbs
-// EZKL_MSM_FETCH_ALWAYS (round 5): 1 = the next table record is gathered unconditionally; 2 = the payload after next as well
-#ifndef EZKL_MSM_FETCH_ALWAYS
-#define EZKL_MSM_FETCH_ALWAYS 1
-#endif
-#ifndef EZKL_MSM_UNPACK_FIRST
-#define EZKL_MSM_UNPACK_FIRST 0
-#endif
-#ifndef EZKL_MSM_RESET_ZZ
-#define EZKL_MSM_RESET_ZZ 1
-#endif
+// (The compile-time variants of rounds 4-5 -- the loop without the one-iteration-ahead loads, the fused "lean" chain, unpack-first, the full
+// accumulator reset, conditional gathers -- were measured and removed; their A/B logs are profiles/r05q_msm_ab.log, r05y_msm_ab.log and
+// DESIGN.md §4.1.  What is here is the one shipped form.)
 static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
 static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workgroup stages in LDS (104 KiB): 1024 scalars x 13 windows
@@ -368,11 +351,7 @@ __global__ __launch_bounds__(256) void msm_hist_kernel(const fe_t* scalars, size
 // wg_hist[g][p] (G workgroups x NP partitions) -> in place, the exclusive prefix over g of column p; part_count[p] = column
 // total.  One workgroup per 32 columns: thread (c, j) sums the j-th chunk of G/32 rows of column c (a row segment of 32
 // columns is one 128-byte line), the 32 chunk sums of a column are scanned in LDS, then the rows are rewritten.
-__device__ __forceinline__ void msm_part_scan_body(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
-                                                   uint32_t* big_list, uint32_t* big_count, uint32_t* sh, bool coherent);
-// ticket != nullptr: the fused form -- the workgroup that finishes last also runs the partition scan (msm_part_scan_body)
-__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count, uint32_t* ticket,
-                                                             uint32_t* part_base, uint32_t* big_flag, uint32_t* big_list, uint32_t* big_count, size_t bstride) {
+__global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, uint32_t G, uint32_t NP, uint32_t* part_count, size_t bstride) {
     BOFF(); BSH(wg_hist); BSH(part_count);
     __shared__ uint32_t sums[32][33];
     const uint32_t c = threadIdx.x & 31, j = threadIdx.x >> 5;
@@ -401,24 +380,13 @@ __global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, 
             run += v;
         }
     }
-    if (!ticket) return;
-    BSH(ticket); BSH(part_base); BSH(big_flag); BSH(big_list); BSH(big_count);
-    __shared__ uint32_t last;
-    __threadfence();                                   // this workgroup's part_count entries are visible device-wide before its ticket
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    msm_part_scan_body(part_count, NP, part_base, big_flag, big_list, big_count, &sums[0][0], true);     // 32 x 33 words >= 1024
 }
 // exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs.  Also lists the oversized
 // ordinary partitions (big_flag[p] = 1 + slot, big_list[slot] = p, big_count[0] = how many asked for a slot).
 __device__ __forceinline__ void msm_part_scan_body(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
-                                                   uint32_t* big_list, uint32_t* big_count, uint32_t* sh, bool coherent) {
+                                                   uint32_t* big_list, uint32_t* big_count, uint32_t* sh) {
     const uint32_t t = threadIdx.x;
-    // coherent: the counts were written by other workgroups of the SAME launch (the fused form): read them past this CU's cache
-    auto ldc = [&](uint32_t i) { return coherent ? __hip_atomic_load(part_count + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : part_count[i]; };
+    auto ldc = [&](uint32_t i) { return part_count[i]; };
     const uint32_t v0 = 2 * t < NQ ? ldc(2 * t) : 0, v1 = 2 * t + 1 < NQ ? ldc(2 * t + 1) : 0;
     uint32_t total;
     const uint32_t incl = msm_block_scan(v0 + v1, sh, total);
@@ -442,7 +410,7 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* par
                                                              uint32_t* big_list, uint32_t* big_count, size_t bstride) {
     BOFF(); BSH(part_count); BSH(part_base); BSH(big_flag); BSH(big_list); BSH(big_count);
     __shared__ uint32_t sh[1024];
-    msm_part_scan_body(part_count, NQ, part_base, big_flag, big_list, big_count, sh, false);
+    msm_part_scan_body(part_count, NQ, part_base, big_flag, big_list, big_count, sh);
 }
 // One pass, one scalar per thread.  A workgroup first ranks its (up to MSM_PART_STAGE) pairs into LDS grouped by partition
 // (start[p] = exclusive scan of its own histogram row, cursors advanced with LDS atomics), then writes them out in staged order:
@@ -695,7 +663,6 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
         uint32_t mid = (lo + hi) >> 1;
         if (offsets[mid] <= k0) lo = mid; else hi = mid;
     }
-#if EZKL_MSM_PREFETCH
     uint32_t b = lo, bin_end = offsets[b + 1];
     // everything the next iteration needs is loaded ONE ITERATION AHEAD: the end of the bucket after this one, the payload of the pair
     // after next (the address of the next gather) and the next table record -- no load sits on the path of the iteration that uses it
@@ -711,11 +678,7 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
     for (uint32_t k = k0; k < k1; k++) {
         if (k == bin_end) {                     // bucket b is finished inside this lane
             if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
-#if EZKL_MSM_RESET_ZZ
             acc.zz = Fq29::zero();              // the identity is ZZ = 0 whatever X, Y, ZZZ hold (g1x29_is_id): 9 moves instead of 36 at every bucket end
-#else
-            acc = g1x29_identity();
-#endif
             started_before = false;
             b++;
             bin_end = end_next;
@@ -736,70 +699,13 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
             }
             end_next = offsets[b + 2 <= nb ? b + 2 : nb];
         }
-#if EZKL_MSM_UNPACK_FIRST
-        // the record that arrived is unpacked BEFORE the next gather is issued into the same registers (a gather issued first forces a copy
-        // of the 16 raw words: its destination may be written at any time); the next record is needed an iteration from now either way
-        g1a29_t cur_q = g1a29_unpack(nxt.p);
-        const bool cur_neg = nxt.neg;
-        // the limbs pass through an (empty) volatile asm that also clobbers memory: the unpack cannot sink below it, the gathers cannot rise above it
-        asm volatile("" : "+v"(cur_q.x.v[0]), "+v"(cur_q.x.v[1]), "+v"(cur_q.x.v[2]), "+v"(cur_q.x.v[3]), "+v"(cur_q.x.v[4]), "+v"(cur_q.x.v[5]),
-                          "+v"(cur_q.x.v[6]), "+v"(cur_q.x.v[7]), "+v"(cur_q.x.v[8]), "+v"(cur_q.y.v[0]), "+v"(cur_q.y.v[1]), "+v"(cur_q.y.v[2]),
-                          "+v"(cur_q.y.v[3]), "+v"(cur_q.y.v[4]), "+v"(cur_q.y.v[5]), "+v"(cur_q.y.v[6]), "+v"(cur_q.y.v[7]), "+v"(cur_q.y.v[8])
-                     :: "memory");
-#else
         const MsmRec cur = nxt;
-#endif
-#if EZKL_MSM_FETCH_ALWAYS
         // no divergent region around the loads (round 5: the `if (k + 1 < k1)` around them cost 3.7 % of the kernel, 0.916 -> 0.886 ms,
         // profiles/r05y_msm_ab.log): past the lane's last pair a record is fetched and never used
         nxt = msm_fetch(tab, vn);
-#if EZKL_MSM_FETCH_ALWAYS > 1
-        vn = vals[k + 2 < total ? k + 2 : total - 1];     // ... and the payload load as well: the next lane's pair, or the last one
-#else
         vn = k + 2 < k1 ? vals[k + 2] : 0u;
-#endif
-#else
-        if (k + 1 < k1) {
-            nxt = msm_fetch(tab, vn);           // its address arrived an iteration ago; the record is used an iteration from now
-            vn = k + 2 < k1 ? vals[k + 2] : 0u;
-        }
-#endif
-#if EZKL_MSM_UNPACK_FIRST
-        acc = g1x29_add_mixed(acc, cur_q, cur_neg);
-#else
-        acc = g1x29_add_mixed(acc, g1a29_unpack(cur.p), cur.neg);
-#endif
-    }
-#else
-    uint32_t b = lo, bin_end = offsets[b + 1];
-    lane_first[t] = b;                          // the bucket holding this lane's first pair (msm_fixup_boundary_kernel)
-    bool started_before = offsets[b] < k0;
-    g1x29_t acc = g1x29_identity();
-    MsmRec nxt = msm_fetch(tab, vals[k0]);
-    for (uint32_t k = k0; k < k1; k++) {
-        if (k == bin_end) {                     // bucket b is finished inside this lane
-            if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
-            acc = g1x29_identity();
-            started_before = false;
-            // next non-empty bucket: a few linear probes (the common case), then a binary search -- a sparse column
-            // (e.g. m(X): a handful of blinding rows scattered over 2^19 buckets) must not walk every empty bucket
-            uint32_t probes = 0;
-            do { b++; bin_end = offsets[b + 1]; } while (bin_end == k && ++probes < 4);
-            if (bin_end == k) {
-                uint32_t lo2 = b + 1, hi2 = nb;          // offsets[lo2] == k, offsets[hi2] = total > k
-                while (hi2 - lo2 > 1) {
-                    uint32_t mid = (lo2 + hi2) >> 1;
-                    if (offsets[mid] <= k) lo2 = mid; else hi2 = mid;
-                }
-                b = lo2;
-                bin_end = offsets[b + 1];
-            }
-        }
-        const MsmRec cur = nxt;
-        if (k + 1 < k1) nxt = msm_fetch(tab, vals[k + 1]);   // prefetch: the gather latency hides under the add
         acc = g1x29_add_mixed(acc, g1a29_unpack(cur.p), cur.neg);
     }
-#endif
     if (k1 == bin_end) {
         if (started_before) st_g1x29(head + t, acc); else st_g1x29(buckets + b, acc);
     } else {
@@ -1229,7 +1135,7 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     size_t o_pcnt = carve((NQ + 1) * 4), o_pbase = carve((NQ + 1) * 4), o_wgh = carve((size_t)sgrid * NQ * 4), o_wgc = carve((size_t)sgrid * NQ * 4);
     size_t o_heavy = carve((size_t)nb * 4), o_chunks = carve(((size_t)nlanes + 1) * 4);
     const size_t nbins = (size_t)1 << LB;
-    // ONE region that starts every chain at zero: the counters (hcnt[0..2], the scan's ticket hcnt[3]), the bin totals of the multi-workgroup
+    // ONE region that starts every chain at zero: the counters (hcnt[0..2]), the bin totals of the multi-workgroup
     // sort, the planes
     size_t o_hcnt = carve(256), o_btot = carve(MSM_MAX_BIG * nbins * 4), o_planes = carve((size_t)nplanes * sizeof(g1x29_t));
     const size_t zero_bytes = off - o_hcnt;
@@ -1278,18 +1184,11 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if ((rc = ev_pair(c, "msm_accumulate", &a0, &a1))) return rc;
         if (timed_chain) EZ_HIP(hipEventRecord(m0, st));
     }
-#if EZKL_MSM_LEAN
-    // sort: the histogram kernel zeroes the region above, the last workgroup of the histogram scan runs the partition scan
-    hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, hcnt,
-                       (uint32_t)(zero_bytes / 4), bstride);
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, hcnt + 3, pbase, bflag, blist, bcnt, bstride);
-#else
     // the chain's counters, bin totals and planes are zeroed by the histogram kernel (no memset command in front of the chain: round 5)
     hipLaunchKernelGGL(msm_hist_kernel, dim3(sgrid, 1, Z), dim3(256), 0, st, scalars, n, per_block, wp, LB, NP, wghist, wgcnt, scal_list, hcnt,
                        (uint32_t)(zero_bytes / 4), bstride);
-    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, (uint32_t*)nullptr, pbase, bflag, blist, bcnt, bstride);
+    hipLaunchKernelGGL(msm_hist_scan_kernel, dim3(cdiv(NQ, 32), 1, Z), dim3(1024), 0, st, wghist, sgrid, NQ, pcnt, bstride);
     hipLaunchKernelGGL(msm_part_scan_kernel, dim3(1, 1, Z), dim3(1024), 0, st, pcnt, NQ, pbase, bflag, blist, bcnt, bstride);
-#endif
     hipLaunchKernelGGL(msm_partition_kernel, dim3(sgrid, 1, Z), dim3((unsigned)per_block), (3 * ((size_t)NQ + 1) + 2 * per_block * W) * 4, st, scalars, n, per_block, wp,
                        LB, NP, base_offset, T->n, pbase, wghist, wgcnt, entries, vals, scal_list, bstride);
     hipLaunchKernelGGL(msm_binsort_kernel, dim3(NP + MSM_BIG_BLOCKS * MSM_BIG_ROWS, 1, Z), dim3(512), MSM_BINSORT_STAGE * 4, st, entries, pbase, LB, NP, bflag, offs,

@@ -18,15 +18,8 @@
 #include "field29.hpp"
 #include <string.h>
 
-// EZKL_NTT_SKIP_UNIT2=1 (round 5): the stage-2 butterflies of a plain column transform whose twiddle is w_4^0 = 1 take no product
-// EZKL_NTT_LOAD_ALWAYS=1 (round 5, measured level and left off: profiles/r05ad_ntt_ab.log): the first pass's loads without a divergent region
-// per element -- the change that gave the MSM's accumulate loop 3.7 % gives this kernel nothing (four workgroups per CU hide the load phase)
-#ifndef EZKL_NTT_LOAD_ALWAYS
-#define EZKL_NTT_LOAD_ALWAYS 0
-#endif
-#ifndef EZKL_NTT_SKIP_UNIT2
-#define EZKL_NTT_SKIP_UNIT2 1
-#endif
+// (Round 5's compile-time variants are resolved: the stage-2 butterflies whose twiddle is w_4^0 = 1 take no product (kept); loads without a
+// divergent region per element were measured level and removed -- profiles/r05ad_ntt_ab.log.)
 
 namespace ezkl {
 
@@ -124,7 +117,6 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
                     const f29_t v = x[i + half];
                     x[i + half] = Fr29::sub<2>(x[i], v);
                     x[i] = Fr29::add(x[i], v);
-#if EZKL_NTT_SKIP_UNIT2
                 } else if (unit1 && st == 2 && (i & 1u) == 0) {      // stage 2 (always the second stage of the group s = 1: o = 0, h = 1): w_4^0 = 1
                     // every other butterfly of stage 2 multiplies by 1: ONE carry pass instead of the product (24 instructions for 206).  The
                     // partner came out of stage 1 (below 15p, loose limbs), so the subtraction borrows 32p; values then stay below
@@ -132,7 +124,6 @@ __device__ __forceinline__ void ntt_superstage29(uint2* data, uint32_t* d8, cons
                     const f29_t v = Fr29::normalize(x[i + half]);
                     x[i + half] = Fr29::sub<4>(x[i], v);
                     x[i] = Fr29::add(x[i], v);
-#endif
                 } else {
                     const uint32_t off = o + (i & (half - 1)) * h;
                     const f29_t w = ld_f29(tw + base + off);
@@ -189,20 +180,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(PassArgs a) {
         uint32_t c = e & (C - 1), i1 = e >> logC;
         size_t addr = col_base(c) + ((size_t)i1 << log_s);
         addr_out = addr;
-#if EZKL_NTT_LOAD_ALWAYS
-        // no divergent region around the loads (round 5): an element of the zero padding loads element 0 and is replaced by zero, so the
-        // loads of a thread's four elements are issued back to back instead of one masked region (with its own wait) per element
-        const bool pad = a.first && addr >= in_len;
-        uint32_t keep = pad ? 0u : 0xffffffffu;
-        asm volatile("" : "+v"(keep));                  // opaque to the optimiser: otherwise "load, then select" is turned back into "branch around the load"
-        fe_t v = ld_fe(in + (pad ? 0 : addr));
-#pragma unroll
-        for (int q = 0; q < 8; q++) v.v[q] &= keep;
-        return v;
-#else
         if (!a.first || addr < in_len) return ld_fe(in + addr);
         return Fr::zero();
-#endif
     };
     auto put_one = [&](uint32_t e, size_t addr, const fe_t& raw) {
         f29_t x = Fr29::unpack(raw);

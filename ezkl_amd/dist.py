@@ -273,3 +273,53 @@ def exchange_segments(sends, recvs, dist, device):
         cursor[peer] += nbytes
     for peer in range(world):
         assert cursor[peer] == len(got[peer]), "exchange: segment lists of ranks %d and %d do not match" % (peer, rank)
+
+
+def selftest(dist, device):
+    """The torch.distributed twin of ezkl_hip_comm_selftest (csrc/comm.hip), for provers whose exchanges go through the callbacks above
+    (gloo; ranks sharing one GPU): every rank calls it once after init_process_group, before anything depends on the group --
+      1. all_gather of the rank ids through allgather_host_bytes;
+      2. ONE all-to-all of odd-sized segments (17 + 13 r + 7 p bytes from r to p, two segments per peer, cut differently on the two sides)
+         through exchange_segments;
+      3. the fold of partial points: rank r contributes (r + 1) G, the fold must be (world (world + 1) / 2) G (fold_partials).
+    Raises RuntimeError naming the step on the rank that saw wrong data.  A missing peer is the process group's own timeout
+    (init_process_group(timeout=...)): torch raises instead of hanging."""
+    import ctypes
+    world, rank = dist.get_world_size(), dist.get_rank()
+
+    def fail(what):
+        raise RuntimeError("rank %d of %d: process-group self-test FAILED at: %s" % (rank, world, what))
+    per = 16
+    buf = (ctypes.c_uint8 * (world * per))(*([0xff] * (world * per)))
+    for i in range(per):
+        buf[rank * per + i] = rank
+    allgather_host_bytes(ctypes.addressof(buf), per, dist, device)
+    if any(buf[r * per + i] != r for r in range(world) for i in range(per)):
+        fail("all_gather of rank ids")
+    seg_len = lambda src, dst: 17 + 13 * src + 7 * dst
+    pat = lambda src, dst, n: ((31 * src + 17 * dst + 3 + 7 * np.arange(n)) % 256).astype(np.uint8)
+    keep, sends, recvs = [], [], []
+    for p in range(world):
+        ls, lr = seg_len(rank, p), seg_len(p, rank)
+        s_buf, r_buf = _b.DeviceBuffer(ls), _b.DeviceBuffer(lr)
+        keep += [s_buf, r_buf]
+        _b.memcpy_h2d(s_buf.ptr, pat(rank, p, ls))
+        _b.memcpy_h2d(r_buf.ptr, np.zeros(lr, np.uint8))
+        sends += [(p, s_buf.ptr, 5), (p, s_buf.ptr + 5, ls - 5)]
+        recvs += [(p, r_buf.ptr, lr - 9), (p, r_buf.ptr + (lr - 9), 9)]
+    exchange_segments(sends, recvs, dist, device)
+    for p in range(world):
+        lr = seg_len(p, rank)
+        if not (_b.memcpy_d2h(keep[2 * p + 1].ptr, lr) == pat(p, rank, lr)).all():
+            fail("all-to-all of odd-sized segments")
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    mont = lambda v: np.frombuffer((v * (1 << 256) % q).to_bytes(32, "little"), np.uint64)
+    G = np.concatenate([mont(1), mont(2)])
+    def times(m):
+        acc = np.zeros(8, np.uint64)
+        for _ in range(m):
+            acc = _b.g1_add_affine(acc, G)
+        return acc
+    if not (fold_partials(times(rank + 1), dist, device) == times(world * (world + 1) // 2)).all():
+        fail("fold of partial points")
+    return True

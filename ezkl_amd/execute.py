@@ -37,22 +37,26 @@ def _load_circuit(path):
             raise ValueError("unsupported compiled circuit: %r" % j.get("model"))
         ra = j["run_args"]
         return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], j["weights"], j["biases"], ra["decomp_base"], ra["decomp_legs"],
-                             total_assignments=j.get("total_assignments"), relu_last=j.get("relu_last", True)), j
+                             total_assignments=j.get("total_assignments"), relu_last=j.get("relu_last", True),
+                             n_inputs=j.get("n_inputs"), relu_first=j.get("relu_first", False)), j
     c = codecs.read_compiled_circuit(raw)
-    weights, biases, relu_last = _mlp_of_graph(c["model"])
+    weights, biases, relu_last, relu_first, n_inputs = _mlp_of_graph(c["model"])
     st, ra = c["settings"], c["settings"]["run_args"]
     want = [(-1, 1), (0, ra["decomp_base"] - 1)]
     if [tuple(x) for x in st["required_range_checks"]] != want or st["required_lookups"] or st["num_dynamic_lookups"] or st["num_shuffles"] \
             or st["einsum_params"]["equations"]:
         raise ValueError("unsupported compiled circuit: its settings ask for arguments outside the MLP family")
     return EL.MlpCircuit(ra["logrows"], ra["num_inner_cols"], weights, biases, ra["decomp_base"], ra["decomp_legs"],
-                         total_assignments=st["total_assignments"], relu_last=relu_last), c
+                         total_assignments=st["total_assignments"], relu_last=relu_last, n_inputs=n_inputs, relu_first=relu_first), c
 
 
 def _mlp_of_graph(model, any_visibility=False):
     """the op family ezkl_layout.MlpCircuit lays out, read off ezkl's node graph: Input -> (Einsum "mk,nk->mn" with a constant [n, k]
-    -> Add of a constant [1, n] -> LeakyReLU slope 0)*, private input and parameters at scale 0, public output.  any_visibility (the
-    forward pass of gen_witness, which lays nothing out): the visibilities are the caller's business"""
+    -> Add of a constant [1, n] -> LeakyReLU slope 0)*, private input and parameters at scale 0, public output.  A LeakyReLU slope 0 may
+    sit straight on the input, and the layer list may be EMPTY: Input -> LeakyReLU -> output is examples/onnx/1l_relu (BASELINE
+    configs[0]; with no Gemm nothing is rescaled, so that graph may carry any ONE scale -- ezkl's default input scale is 7).
+    any_visibility (the forward pass of gen_witness, which lays nothing out): the visibilities are the caller's business.
+    -> (weights, biases, relu_last, relu_first, n_inputs)"""
     nodes, vis = model["nodes"], model["visibility"]
     if len(model["inputs"]) != 1 or len(model["outputs"]) != 1 or \
             (not any_visibility and (vis["input"], vis["params"], vis["output"]) != ("Private", "Private", "Public")):
@@ -65,10 +69,20 @@ def _mlp_of_graph(model, any_visibility=False):
         q = op["quantized_values"]
         return [signed(v) for v in q["inner"]], q["dims"]
     cur = model["inputs"][0]
-    if nodes[cur]["opkind"]["kind"] != "Input" or any(n["out_scale"] != 0 for n in nodes.values()):
-        raise ValueError("unsupported compiled circuit: input node / non-zero scales")
     order = sorted(k for k in nodes if nodes[k]["opkind"]["kind"] == "Linear")
-    weights, biases, relu_last, i = [], [], False, 0
+    gemm_free = all(nodes[k]["opkind"]["op"] == "LeakyReLU" for k in order)
+    scales = {n["out_scale"] for n in nodes.values()}
+    if nodes[cur]["opkind"]["kind"] != "Input" or (scales != {0} and not (gemm_free and len(scales) == 1)):
+        raise ValueError("unsupported compiled circuit: input node / non-zero scales")
+    n_inputs = 1
+    for d in nodes[cur]["out_dims"]:
+        n_inputs *= d
+    weights, biases, relu_last, relu_first, i = [], [], False, False, 0
+    if order and nodes[order[0]]["opkind"]["op"] == "LeakyReLU":
+        n = nodes[order[0]]
+        if n["opkind"]["slope"] != 0.0 or n["inputs"] != [(cur, 0)]:
+            raise ValueError("unsupported compiled circuit: LeakyReLU with a slope")
+        cur, i, relu_first = order[0], 1, True
     while i < len(order):
         n = nodes[order[i]]
         if n["opkind"]["op"] != "Einsum" or n["opkind"]["equation"] != "mk,nk->mn" or n["inputs"][0] != (cur, 0):
@@ -87,9 +101,9 @@ def _mlp_of_graph(model, any_visibility=False):
             if n["opkind"]["slope"] != 0.0 or n["inputs"] != [(cur, 0)]:
                 raise ValueError("unsupported compiled circuit: LeakyReLU with a slope")
             cur, i, relu_last = order[i], i + 1, True
-    if model["outputs"][0] != (cur, 0) or not weights:
+    if model["outputs"][0] != (cur, 0) or not (weights or relu_first):
         raise ValueError("unsupported compiled circuit: output node")
-    return weights, biases, relu_last
+    return weights, biases, relu_last, relu_first, n_inputs
 
 
 G2_GENERATOR = ((0x1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed, 0x198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2),
@@ -142,7 +156,7 @@ def setup(compiled_circuit, srs_path, vk_path, pk_path, sample_input=None):
     """keygen_vk + keygen_pk on the GPU, keys written in halo2's raw-bytes layout"""
     circuit, j = _load_circuit(compiled_circuit)
     srs = load_params_prover(srs_path, circuit.k)
-    x = sample_input if sample_input is not None else [0] * len(circuit.weights[0][0])
+    x = sample_input if sample_input is not None else [0] * circuit.n_inputs
     cs, fixed, copies, reg = circuit.keygen_inputs(x)          # synthesis without witness values: selectors + copy constraints
     bg = B.Bases(srs["g"])
     try:
@@ -210,12 +224,13 @@ def gen_witness(compiled_circuit, data, output=None, vk_path=None, srs_path=None
             raise ValueError("unsupported compiled circuit: %r" % j.get("model"))
         ra = j["run_args"]
         weights, biases, relu_last = j["weights"], j["biases"], j.get("relu_last", True)
+        relu_first, n_inputs = j.get("relu_first", False), j.get("n_inputs", len(weights[0][0]) if weights else None)
         vis = dict(input=ra.get("input_visibility", "Private"), params=ra.get("param_visibility", "Private"), output=ra.get("output_visibility", "Public"))
-        in_scale = out_scale = 0
+        in_scale = out_scale = ra.get("input_scale", 0) if not weights else 0       # a Gemm-free graph keeps its input scale (ezkl's default: 7)
         datum_type, input_decomp = "F32", True
     else:
         c = codecs.read_compiled_circuit(raw)
-        weights, biases, relu_last = _mlp_of_graph(c["model"], any_visibility=True)
+        weights, biases, relu_last, relu_first, n_inputs = _mlp_of_graph(c["model"], any_visibility=True)
         ra, vis = c["settings"]["run_args"], c["model"]["visibility"]
         in_node = c["model"]["nodes"][c["model"]["inputs"][0]]
         in_scale, out_scale = c["settings"]["model_input_scales"][0], c["settings"]["model_output_scales"][0]
@@ -229,7 +244,7 @@ def gen_witness(compiled_circuit, data, output=None, vk_path=None, srs_path=None
     if isinstance(data, (bytes, str)):
         data = json.loads(data)
     cols = data["input_data"]
-    if len(cols) != 1 or len(cols[0]) != len(weights[0][0]):
+    if len(cols) != 1 or len(cols[0]) != n_inputs:
         raise ValueError("input data does not match the circuit's input shape")
     x = [_quantize(v, in_scale, datum_type) for v in cols[0]]
     signed = lambda v: v if v < EL.R // 2 else v - EL.R
@@ -245,6 +260,9 @@ def gen_witness(compiled_circuit, data, output=None, vk_path=None, srs_path=None
     inputs = list(x)
     if input_decomp:
         decomposed(x, "input")
+    if relu_first:
+        decomposed(x, "LeakyReLU input")
+        x = [v if v > 0 else 0 for v in x]
     for li, (W, bvec) in enumerate(zip(weights, biases)):
         x = [sum(a * w for a, w in zip(x, row)) + bvec[o] for o, row in enumerate(W)]
         if li + 1 < len(weights) or relu_last:
@@ -289,7 +307,7 @@ def prove(witness_path, compiled_circuit, pk_path, proof_path, srs_path, check_m
     reference's det-prove.  CheckMode.SAFE verifies the proof before returning it, as create_proof_circuit does."""
     w = codecs.read_witness_json(open(witness_path).read())
     circuit, j = _load_circuit(compiled_circuit)
-    if len(w["inputs"]) != 1 or len(w["inputs"][0]) != len(circuit.weights[0][0]):
+    if len(w["inputs"]) != 1 or len(w["inputs"][0]) != circuit.n_inputs:
         raise ValueError("witness does not match the circuit's input shape")
     signed = lambda v: v if v < EL.R // 2 else v - EL.R
     cs = circuit.gc.cs
@@ -344,5 +362,6 @@ def _plonk_cs(circuit):
     """the constraint system as keygen saw it: re-running `configure` + selector compression (halo2 does the same on load_pk,
     src/pfsys/mod.rs:627) -- a fresh synthesis pass without witness values gives the selector activations"""
     fresh = EL.MlpCircuit(circuit.k, circuit.w, circuit.weights, circuit.biases, circuit.base, circuit.legs,
-                          total_assignments=circuit.settings.total_assignments, relu_last=circuit.relu_last)
-    return fresh.keygen_inputs([0] * len(circuit.weights[0][0]))[0]
+                          total_assignments=circuit.settings.total_assignments, relu_last=circuit.relu_last, n_inputs=circuit.n_inputs,
+                          relu_first=circuit.relu_first)
+    return fresh.keygen_inputs([0] * circuit.n_inputs)[0]

@@ -565,14 +565,21 @@ class MlpCircuit(LayoutCircuit):
     batch 1 the einsum "mk,nk->mn" has one non-common index and is laid out with base ops, einsum/analysis.rs:165-184), private
     input and parameters, public output, inputs / outputs range-checked by decomposition (src/graph/model.rs:1132-1258)."""
 
-    def __init__(self, logrows, num_inner_cols, weights, biases, decomp_base, decomp_legs, total_assignments=None, relu_last=True):
+    def __init__(self, logrows, num_inner_cols, weights, biases, decomp_base, decomp_legs, total_assignments=None, relu_last=True,
+                 n_inputs=None, relu_first=False):
+        """relu_first / n_inputs: a LeakyReLU (slope 0) straight on the input, before any Gemm -- with no layers at all that is
+        examples/onnx/1l_relu (gen.py: nn.ReLU on a vector of 3), BASELINE configs[0]'s model; n_inputs is needed when there is no weight
+        matrix to read the input length from"""
         self.k, self.w = logrows, num_inner_cols
         self.weights = [[[int(v) for v in row] for row in W] for W in weights]
         self.biases = [[int(v) for v in b] for b in biases]
-        self.base, self.legs, self.relu_last = decomp_base, decomp_legs, relu_last
+        self.base, self.legs, self.relu_last, self.relu_first = decomp_base, decomp_legs, relu_last, bool(relu_first)
+        self.n_inputs = int(n_inputs) if n_inputs is not None else (len(self.weights[0][0]) if self.weights else None)
+        if self.n_inputs is None or (self.weights and len(self.weights[0][0]) != self.n_inputs):
+            raise ValueError("MlpCircuit: the input length is unknown or does not match the first weight matrix")
         if total_assignments is None:                  # the dummy layout pass of gen-settings: count the cells
             total_assignments = self._count_cells()
-        n_out = len(self.weights[-1])
+        n_out = len(self.weights[-1]) if self.weights else self.n_inputs
         # max_rows uses blinding factors = 5 (no gate queries 3+ rotations of a column)
         self.settings = EC.GraphSettings(logrows, num_inner_cols, total_assignments, total_const_size=4,
                                          required_range_checks=[(-1, 1), (0, decomp_base - 1)], model_instance_shapes=[[1, n_out]])
@@ -582,19 +589,23 @@ class MlpCircuit(LayoutCircuit):
         w, lg = self.w, self.legs
         def dec(m): return m * (lg + 1) + m + m * lg + m * (-(-lg // w) * w) + 2 * m
         def al(c): return -(-c // w) * w
-        c = dec(len(self.weights[0][0]))
+        c = dec(self.n_inputs)
+        if self.relu_first:
+            c += dec(self.n_inputs) + 6 * self.n_inputs
         for i, W in enumerate(self.weights):
             m, kk = len(W), len(W[0])
             c = al(c) + m * al(kk) + m
             if i + 1 < len(self.weights) or self.relu_last:
                 c += dec(m) + 6 * m
-        m = len(self.weights[-1])
+        m = len(self.weights[-1]) if self.weights else self.n_inputs
         return c + 2 * dec(m) + m + 64
 
     def synthesize(self, x, witness=True):
         reg = BaseRegion(self.gc, witness)
         vals = [Val(int(v)) for v in x]
         _, vals = reg.decompose(vals, self.base, self.legs)                     # input range check
+        if self.relu_first:
+            vals = reg.relu(vals, self.base, self.legs)
         for i, (W, b) in enumerate(zip(self.weights, self.biases)):
             outs = [reg.dot(vals, [Val(wv) for wv in row]) for row in W]           # einsum_with_base_ops: one dot per output
             vals = reg.pairwise(outs, [Val(bv) for bv in b], EC.ADD)

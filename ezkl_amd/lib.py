@@ -16,7 +16,7 @@ SYMBOLS = [
     "ezkl_hip_divide_by_vanishing_dev", "ezkl_hip_prefix_scan_dev", "ezkl_hip_eval_poly_dev", "ezkl_hip_lookup_multiplicity_dev", "ezkl_hip_lookup_multiplicity_acc_dev", "ezkl_hip_lookup_multiplicity_batch_dev", "ezkl_hip_batch_invert_dev", "ezkl_hip_eval_h_dev", "ezkl_hip_eval_h_check", "ezkl_hip_eval_h_schedule", "ezkl_hip_eval_h_prepare", "ezkl_hip_eval_h_jit_stats", "ezkl_hip_set_async", "ezkl_hip_stream_wait_library",
     "ezkl_hip_last_kernel_ms", "ezkl_hip_kernel_ms_stats", "ezkl_hip_ubench",
     "ezkl_hip_comm_available", "ezkl_hip_comm_unique_id", "ezkl_hip_comm_init", "ezkl_hip_comm_info", "ezkl_hip_comm_destroy", "ezkl_hip_comm_allgather_dev",
-    "ezkl_hip_comm_fold_points", "ezkl_hip_comm_broadcast_host", "ezkl_hip_comm_alltoall_dev", "ezkl_hip_comm_allgather_host", "ezkl_hip_comm_alltoallv_dev", "ezkl_hip_comm_stats",
+    "ezkl_hip_comm_fold_points", "ezkl_hip_comm_broadcast_host", "ezkl_hip_comm_alltoall_dev", "ezkl_hip_comm_allgather_host", "ezkl_hip_comm_alltoallv_dev", "ezkl_hip_comm_stats", "ezkl_hip_comm_selftest",
 ]
 
 

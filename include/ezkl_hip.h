@@ -31,6 +31,7 @@ extern "C" {
 #define EZKL_ERR_INVALID (-3)     /* bad argument (null pointer, size out of range, bad program) */
 #define EZKL_ERR_NOMEM (-4)
 #define EZKL_ERR_UNSUPPORTED (-5)
+#define EZKL_ERR_TIMEOUT (-7)     /* a collective did not complete within EZKL_COMM_TIMEOUT_S seconds (comm.hip's watchdog): the communicator is aborted */
 #define EZKL_ERR_BUSY (-6)        /* the calling thread already holds every slot of a bounded resource (ezkl_hip_msm_g1_start_dev: four per context) */
 
 typedef struct ezkl_bases_s* ezkl_bases_t;     /* device-resident G1 base set (SRS g or g_lagrange) */
@@ -380,6 +381,11 @@ int ezkl_hip_comm_available(void);
 typedef struct { int peer; void* ptr; size_t bytes; } ezkl_comm_seg_t;
 int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs);
 int ezkl_hip_comm_stats(uint64_t out[8], int reset);
+/* The communicator tries itself out -- an all_gather of rank ids, ONE packed all-to-all of odd-sized segments, one fold of partial points,
+ * each checked -- and fails with a message on stderr instead of hanging or proving wrongly later.  A collective: every rank calls it.
+ * ezkl_hip_comm_init runs it by default (EZKL_COMM_SELFTEST=0 on every rank skips).  Every collective of this section is waited for under a
+ * watchdog: past EZKL_COMM_TIMEOUT_S seconds (default 120, 0 = none) the call returns EZKL_ERR_TIMEOUT and the communicator is aborted. */
+int ezkl_hip_comm_selftest(void);
 
 /* ---- measurement hooks (used by bench.py; HIP events on the stream the kernels run on) ---- */
 /* after an msm/ntt call: average device milliseconds of the dominant kernel of the last call */

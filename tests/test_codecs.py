@@ -106,7 +106,7 @@ def test_compiled_circuit_reader_on_the_reference_model():
     kinds = {k: (n["opkind"]["kind"], n["opkind"].get("op")) for k, n in c["model"]["nodes"].items()}
     assert kinds == {0: ("Input", None), 1: ("Constant", None), 2: ("Linear", "Einsum"), 3: ("Constant", None), 4: ("Linear", "Add"), 6: ("Linear", "LeakyReLU")}
     assert c["model"]["nodes"][2]["opkind"]["equation"] == "mk,nk->mn" and c["model"]["outputs"] == [(6, 0)]
-    assert X._mlp_of_graph(c["model"]) == ([FIXTURE_W], [FIXTURE_B], True)
+    assert X._mlp_of_graph(c["model"]) == ([FIXTURE_W], [FIXTURE_B], True, False, 3)
     with pytest.raises(ValueError):
         codecs.read_compiled_circuit(open(os.path.join(GOLDEN, "model_k6.compiled"), "rb").read()[:700])
 

@@ -239,3 +239,83 @@ def test_exchange_callbacks_world3():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True), (2, True)]
+
+
+# ---- the process-group self-test (ezkl_amd/dist.py selftest: the torch.distributed twin of ezkl_hip_comm_selftest) at the driver's world size ----
+class _FakeBuffer:
+    count = 0
+
+    def __init__(self, nbytes):
+        _FakeBuffer.count += 1
+        self.ptr = _FakePtr(("buf", _FakeBuffer.count), 0)
+        _FakeDevice.mem[self.ptr.key] = np.zeros(nbytes, np.uint8)
+
+
+class _FakePtr:
+    """a `device pointer` that supports + offset, as the integer pointers of the real backend do"""
+
+    def __init__(self, key, off):
+        self.key, self.off = key, off
+
+    def __add__(self, d):
+        return _FakePtr(self.key, self.off + int(d))
+
+
+class _FakeBackend:
+    DeviceBuffer = _FakeBuffer
+
+    @staticmethod
+    def memcpy_d2h(ptr, n):
+        return _FakeDevice.mem[ptr.key][ptr.off:ptr.off + n].copy()
+
+    @staticmethod
+    def memcpy_h2d(ptr, arr):
+        _FakeDevice.mem[ptr.key][ptr.off:ptr.off + len(arr)] = arr
+
+    @staticmethod
+    def g1_add_affine(a, b):
+        from ezkl_amd import backend as B
+        return B.g1_add_affine(a, b)                      # the library's host-side group law (no device)
+
+
+def _selftest_worker(rank, world, port, q, sabotage):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ezkl_amd import dist as D
+    D._b = _FakeBackend
+    if sabotage and rank == 1:                           # one rank sends damaged bytes: every rank that receives from it must notice
+        real = _FakeBackend.memcpy_d2h
+        def bad(ptr, n):
+            a = real(ptr, n)
+            if n: a[n // 2] ^= 1
+            return a
+        _FakeBackend.memcpy_d2h = staticmethod(bad)
+    try:
+        ok = D.selftest(dist, torch.device("cpu"))
+        q.put((rank, bool(ok), ""))
+    except RuntimeError as e:
+        q.put((rank, False, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_process_group_selftest_world8_gloo():
+    """eight ranks (the driver's SCALE run) pass the self-test over gloo; with one rank sabotaged the failing step is
+    named instead of a wrong proof appearing later"""
+    for world, sabotage in ((8, False), (3, True)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = free_port()
+        procs = [ctx.Process(target=_selftest_worker, args=(r, world, port, q, sabotage)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        if not sabotage:
+            assert res == [(r, True, "") for r in range(world)]
+        else:
+            assert all(r[1] is False and "all-to-all of odd-sized segments" in r[2] for r in res), res

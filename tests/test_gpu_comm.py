@@ -111,3 +111,50 @@ def test_comm_world1_and_sharded_native_prover(hip, golden_srs):
     finally:
         B.comm_destroy()
     assert B.comm_info() == (0, 0)
+
+
+def test_comm_selftest_and_watchdog_world1(hip):
+    """(a) the communicator tries itself out -- ezkl_hip_comm_init runs ezkl_hip_comm_selftest (all_gather of rank ids, ONE
+    packed all-to-all of odd-sized segments, one fold of partial points) and it can be called again, also with the self bytes forced
+    through the slabs and ncclSend / ncclRecv; (b) every collective waits under a watchdog: with a deadline no transfer can meet the
+    call returns EZKL_ERR_TIMEOUT (-7) instead of hanging, later calls fail at once, and the process can destroy the communicator and
+    build a new one.  In a subprocess: the test poisons its communicator on purpose."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import ezkl_amd
+from ezkl_amd import backend as B
+ezkl_amd.init(0)
+B.comm_init(B.comm_unique_id(), 1, 0)            # runs the self-test
+B.comm_selftest()
+os.environ["EZKL_COMM_SELF_VIA_RCCL"] = "1"       # ... and once with the self bytes through the packed wire format and RCCL
+B.comm_selftest()
+os.environ.pop("EZKL_COMM_SELF_VIA_RCCL")
+sends_before = B.comm_stats()["nccl_sends"] if isinstance(B.comm_stats(), dict) and "nccl_sends" in B.comm_stats() else None
+pts = np.zeros((200000, 8), np.uint64)            # 12.8 MB up, gathered, 12.8 MB down: milliseconds
+os.environ["EZKL_COMM_TIMEOUT_S"] = "0.000001"
+try:
+    B.comm_fold_points(pts)
+    print("NO-TIMEOUT")
+except ezkl_amd.EzklHipError as e:
+    print("TIMEOUT-CODE", e.code if hasattr(e, "code") else e.args[0])
+try:
+    B.comm_allgather_host(np.zeros((1, 4), np.uint64))
+    print("STILL-USABLE")
+except ezkl_amd.EzklHipError as e:
+    print("BROKEN-CODE", e.code if hasattr(e, "code") else e.args[0])
+os.environ.pop("EZKL_COMM_TIMEOUT_S")
+B.comm_destroy()
+B.comm_init(B.comm_unique_id(), 1, 0)
+assert (B.comm_fold_points(pts[:3]) == 0).all()
+B.comm_destroy()
+print("REBUILT")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert "TIMEOUT-CODE -7" in out and "BROKEN-CODE -7" in out and "REBUILT" in out and "NO-TIMEOUT" not in out, out + r.stderr[-1500:]
+    assert "did not complete within" in r.stderr and "fold_points" in r.stderr

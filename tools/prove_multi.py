@@ -70,6 +70,10 @@ if world > 1:
     if comm_used:
         nc.set_shard_comm()                    # fold, gather, allgather_host and the all-to-all: the library's RCCL communicator
     else:
+        # the callbacks' process group tries itself out first (ezkl_amd/dist.py selftest: the twin of ezkl_hip_comm_selftest, which
+        # ezkl_hip_comm_init ran on the other branch): a wrong exchange must end the job here, with the step named, not as a rejected proof
+        from ezkl_amd import dist as D_
+        D_.selftest(dist, ddev)
         nc.set_shard(dist, ddev)
         if "--replicated" not in sys.argv:
             nc.set_shard_exchange(dist, ddev)
