@@ -305,6 +305,7 @@ int ezkl_hip_comm_destroy(void) {
 int ezkl_hip_comm_allgather_dev(void* buf_dev, size_t total_bytes) {
     if (!buf_dev) return EZKL_ERR_INVALID;
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm || total_bytes % (size_t)g_comm.world) return EZKL_ERR_INVALID;
     const size_t slice = total_bytes / (size_t)g_comm.world;
     EZ_HIP(hipStreamSynchronize(c->stream));
@@ -318,6 +319,7 @@ int ezkl_hip_comm_allgather_dev(void* buf_dev, size_t total_bytes) {
 int ezkl_hip_comm_fold_points(void* points_host, uint32_t count) {
     if (!points_host || count == 0) return count ? EZKL_ERR_INVALID : EZKL_OK;
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm) return EZKL_ERR_INVALID;
     const size_t slice = (size_t)count * 64, total = slice * (size_t)g_comm.world;
     if (g_comm.stage_bytes < total) {
@@ -346,6 +348,7 @@ int ezkl_hip_comm_fold_points(void* points_host, uint32_t count) {
 int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root) {
     if (!buf_host || bytes == 0 || bytes > 4096) return EZKL_ERR_INVALID;
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm || root < 0 || root >= g_comm.world) return EZKL_ERR_INVALID;
     const size_t total = bytes * (size_t)g_comm.world;
     if (g_comm.stage_bytes < total) {
@@ -364,6 +367,7 @@ int ezkl_hip_comm_broadcast_host(void* buf_host, size_t bytes, int root) {
 int ezkl_hip_comm_allgather_host(void* buf_host, size_t bytes) {
     if (!buf_host || bytes == 0 || bytes > ((size_t)1 << 24)) return EZKL_ERR_INVALID;
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm) return EZKL_ERR_INVALID;
     const size_t total = bytes * (size_t)g_comm.world;
     if (g_comm.stage_bytes < total) {
@@ -407,6 +411,7 @@ static int alltoallv_unpacked(Ctx* c, const ezkl_comm_seg_t* sends, size_t n_sen
 int ezkl_hip_comm_alltoallv_dev(const ezkl_comm_seg_t* sends, size_t n_sends, const ezkl_comm_seg_t* recvs, size_t n_recvs) {
     if ((n_sends && !sends) || (n_recvs && !recvs)) return EZKL_ERR_INVALID;
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm) return EZKL_ERR_INVALID;
     const int me = g_comm.rank, world = g_comm.world;
     std::vector<uint64_t> tot_s(world, 0), tot_r(world, 0);
@@ -528,6 +533,7 @@ int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, con
                                const size_t* recv_len) {
     if (!send_off || !send_len || !recv_off || !recv_len) return EZKL_ERR_INVALID;
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm) return EZKL_ERR_INVALID;
     EZ_HIP(hipStreamSynchronize(c->stream));
     const int me = g_comm.rank;
@@ -556,6 +562,7 @@ int ezkl_hip_comm_alltoall_dev(const void* send_dev, const size_t* send_off, con
 // Everything under the watchdog.  EZKL_OK, or the failing step on stderr and EZKL_ERR_INVALID (wrong data) / EZKL_ERR_TIMEOUT / EZKL_ERR_HIP.
 int ezkl_hip_comm_selftest(void) {
     EZ_CTX(c);
+    if (g_comm.broken) return EZKL_ERR_TIMEOUT;     // a collective timed out earlier: nothing runs behind it
     if (!g_comm.comm) return EZKL_ERR_INVALID;
     const int world = g_comm.world, me = g_comm.rank;
     auto fail = [&](const char* what) {

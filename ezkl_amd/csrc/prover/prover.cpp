@@ -494,7 +494,16 @@ struct Backend {
     };
     // lagrange -> (coefficients, extended cosets in COSET-MAJOR order: element b n + j = p(zeta w_ext^b omega^j)), stream-ordered on the aux
     // stream; `lagrange` must stay untouched until aux_sync()
-    Forms forms_alloc(uint32_t ext_k) const { return Forms{alloc(n), alloc((size_t)1 << ext_k)}; }
+    // stream_cosets (the degraded mode of a key that does not fit with its extended columns, ProvingKey::stream): no column keeps its
+    // extended form; the sweep rebuilds coset b of every column from the coefficients when it gets to unit b (coset_of)
+    bool stream_cosets = false;
+    Forms forms_alloc(uint32_t ext_k) const { return Forms{alloc(n), stream_cosets ? Col() : alloc((size_t)1 << ext_k)}; }
+    // coset b of coeff_to_extended(h): out[j] = h(zeta w_ext^b omega^j), n rows
+    Col coset_of(const Col& h, uint32_t ext_k, uint32_t b) const {
+        Col o = alloc(n);
+        check(ezkl_hip_coeff_to_cosets_range_dev(h->ptr(), o->ptr(), 1, n, n, k, ext_k, b, 1, nullptr), "ezkl_hip_coeff_to_cosets_range_dev");
+        return o;
+    }
     Forms forms_async(const Col& lagrange, uint32_t ext_k, const Forms* pre = nullptr) {
         Forms f = pre ? *pre : forms_alloc(ext_k);
         aux_keep.insert(aux_keep.end(), {lagrange, f.poly, f.coset});
@@ -506,7 +515,7 @@ struct Backend {
         const Fe winv = omega(k).inv();
         check(ezkl_hip_vec_scale_dev(lagrange->ptr(), one.v.data(), f.poly->ptr(), n, st), "ezkl_hip_vec_scale_dev");
         check(ezkl_hip_ntt_dev(f.poly->ptr(), k, winv.v.data(), 1, 1, n, st), "ezkl_hip_ntt_dev");
-        check(ezkl_hip_coeff_to_cosets_dev(f.poly->ptr(), f.coset->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, st), "ezkl_hip_coeff_to_cosets_dev");
+        if (f.coset) check(ezkl_hip_coeff_to_cosets_dev(f.poly->ptr(), f.coset->ptr(), 1, n, (size_t)1 << ext_k, k, ext_k, st), "ezkl_hip_coeff_to_cosets_dev");
         return f;
     }
     size_t commit_first() const { return shard.on() ? shard.lo : 0; }
@@ -975,6 +984,9 @@ struct ProvingKey {
     // coset_count), coset-major.  One rank / replicated provers: all E of them.  Owner mode: only the cosets this rank sweeps
     // (Backend::key_range) -- at k = 22 the 77 key columns of the 30-column circuit are 39 GB per GPU in full, 1 / world of that by owner
     uint32_t coset_first = 0, coset_count = 0;
+    // the degraded mode (EZKL_KEY_COSETS, check_key_fits): fixed_cosets / sigma_cosets hold NULL columns -- the key is values + coefficients
+    // (+ l_0 / l_last / l_active / X on the cosets: four columns) and create_proof streams the extended domain one coset at a time
+    bool stream = false;
     std::vector<G1> fixed_commitments, sigma_commitments;
     std::vector<uint8_t> selector_bits;      // n_selectors x n/8 bytes, bit-packed rows as in halo2's vk files (zero if the key was made here)
     Fe digest;
@@ -998,37 +1010,69 @@ static Fe vk_digest(const ProvingKey& pk) {
     auto h = keccak256(t.data(), t.size());
     return Fe::from_canonical(reduce_fr(from_be32(h.data())));
 }
-// Before a key is built or loaded (keygen, pk_read, pk_read_file): will it fit?  The resident key is (fixed + permutation columns) x (values
-// + coefficients + this rank's cosets of the extended domain) + l_0 / l_last / l_active / X on those cosets, 32 bytes per element.  At k = 22
-// / 30 advice columns that is 61 GB; k = 23, or a wider circuit at k = 22, does not fit ONE GPU -- and used to say so only when some hipMalloc
-// deep inside keygen failed.  Only the KEY term refuses the call: it is exact.  What a later proof needs for its witness columns (advice,
-// m / phi / compressed inputs, z, h in value + coefficient form and on this rank's share of the cosets -- in owner mode a rank holds the
-// forms of the columns it owns, about the same share) is an estimate and the caller may never prove with this key, so it is a warning on
-// stderr.  EZKL_PROVER_SKIP_FIT_CHECK=1 turns the check off; EZKL_PROVER_ASSUME_FREE_GIB=<x> (test hook) pretends the device has x GiB left.
-static void check_key_fits(const ConstraintSystem& cs, uint32_t coset_count, const char* what) {
-    if (const char* e = getenv("EZKL_PROVER_SKIP_FIT_CHECK")) if (*e && *e != '0') return;
+// Before a key is built or loaded (keygen, pk_read, pk_read_file): will it fit, and in which form?  -> true: the key is held STREAMED.
+// Resident (the fast form): (fixed + permutation columns) x (values + coefficients + this rank's cosets of the extended domain) + l_0 /
+// l_last / l_active / X on those cosets, 32 bytes per element -- at k = 22 / 30 advice columns 61 GB, and a proof holds its witness columns
+// (advice, m / phi / compressed inputs, z, h) in the same three forms next to it: 175 of the 288 GB.  k = 23, or a wider circuit at k = 22,
+// does not fit ONE GPU that way.  Streamed (the degraded form, one rank only): no column keeps its extended form -- the key is values +
+// coefficients, the proof's columns likewise, and the quotient sweep rebuilds coset b of every column from its coefficients when it
+// reaches unit b (one n-point transform per column and coset: for witness columns the very transforms the resident form runs earlier, for
+// key columns E more per proof).  Peak: 2 n per column + ONE coset of every column, instead of (2 + E) n per column.  The reference can
+// do without its resident cosets too: `precompute-coset` is a cargo FEATURE of its halo2 fork (/root/reference/Cargo.toml:218-226,257).
+//   EZKL_KEY_COSETS=auto (default): resident if key + estimated witness fit what the device has left, else streamed if that fits, else the
+//                   call fails up front with the sizes (EZKL_ERR_NOMEM) -- not somewhere inside a hipMalloc;
+//   EZKL_KEY_COSETS=resident: never stream (only the KEY term refuses: it is exact; the witness estimate is a warning on stderr -- the
+//                   caller may never prove with this key);     EZKL_KEY_COSETS=recompute: always stream (one rank).
+//   EZKL_PROVER_SKIP_FIT_CHECK=1: no check at all (resident unless recompute is asked for); EZKL_PROVER_ASSUME_FREE_GIB=<x> (test hook):
+//                   pretend the device has x GiB left.
+static bool check_key_fits(const ConstraintSystem& cs, uint32_t coset_count, const char* what, bool one_rank) {
+    const char* mode_e = getenv("EZKL_KEY_COSETS");
+    const std::string mode = mode_e && *mode_e ? mode_e : "auto";
+    invalid(mode != "auto" && mode != "resident" && mode != "recompute", "EZKL_KEY_COSETS must be auto, resident or recompute");
+    const uint64_t E = 1ull << (cs.ext_k - cs.k);
+    const bool can_stream = one_rank && E > 1;
+    invalid(mode == "recompute" && !one_rank, "EZKL_KEY_COSETS=recompute is the one-GPU degraded mode: a sharded prover divides the cosets by the world size instead");
+    if (mode == "recompute" && can_stream) return true;
+    if (const char* e = getenv("EZKL_PROVER_SKIP_FIT_CHECK")) if (*e && *e != '0') return false;
     const uint64_t n = cs.n, cols = (uint64_t)cs.n_fixed + cs.perm.size();
     const uint64_t key = (cols * (2 + (uint64_t)coset_count) + 4ull * coset_count) * n * 32;
-    const uint64_t E = 1ull << (cs.ext_k - cs.k);
     const double share = (double)coset_count / (double)E;                   // 1 on one rank / replicated; 1 / world by owner
     const uint64_t wcols = (uint64_t)cs.n_advice + 3ull * cs.lookups.size() + cs.n_chunks + 2;
     const uint64_t witness = (uint64_t)((double)(wcols * (2 + E) * n * 32) * share);
+    // streamed: two forms per column, ONE coset of every column at a time, h on the whole extended domain + its coefficients
+    const uint64_t key_s = (cols * 2 + 4ull * coset_count) * n * 32, witness_s = (wcols * 2 + (cols + wcols) + 2 * E) * n * 32;
     size_t free_b = 0, total_b = 0, pool[4] = {0, 0, 0, 0};
-    if (ezkl_hip_mem_info(&free_b, &total_b) != EZKL_OK) return;            // no device: the first kernel call reports it
+    if (ezkl_hip_mem_info(&free_b, &total_b) != EZKL_OK) return false;      // no device: the first kernel call reports it
     (void)ezkl_hip_pool_stats(pool);
     uint64_t avail = (uint64_t)free_b + pool[2];                            // parked blocks of the column pool are reusable
     if (const char* e = getenv("EZKL_PROVER_ASSUME_FREE_GIB")) avail = (uint64_t)(atof(e) * 1073741824.0);
-    if (key + witness <= avail) return;
-    char msg[640];
+    if (key + witness <= avail) return false;
+    const double G = 1073741824.0;
+    if (mode == "auto" && can_stream && key_s + witness_s <= avail) {
+        fprintf(stderr, "[ezkl_prover] %s: key %.1f GiB + witness about %.1f GiB do not fit the %.1f GiB available: the key is held STREAMED (values + "
+                        "coefficients, %.1f GiB; a proof about %.1f GiB more) and every proof rebuilds the extended domain one coset at a time\n",
+                what, key / G, witness / G, avail / G, key_s / G, witness_s / G);
+        return true;
+    }
+    char msg[800];
     snprintf(msg, sizeof msg,
              "%s: the proving key of this circuit needs %.1f GiB resident on the device (%llu key columns x 2^%u rows, %u of %llu cosets of the extended "
-             "domain 2^%u) and a proof about %.1f GiB more for its witness columns; %.1f GiB are available of %.1f GiB. Shard the key over more GPUs "
-             "(owner mode, ezkl_prover_cs_set_shard_exchange: the coset term divides by the world size), lower logrows, or set "
-             "EZKL_PROVER_SKIP_FIT_CHECK=1 to try regardless.",
-             what, key / 1073741824.0, (unsigned long long)cols, cs.k, coset_count, (unsigned long long)E, cs.ext_k, witness / 1073741824.0,
-             avail / 1073741824.0, total_b / 1073741824.0);
-    if (key > avail) throw Error(EZKL_ERR_NOMEM, msg);
-    fprintf(stderr, "[ezkl_prover] warning: %s\n", msg);                    // the key fits; a proof with it may not
+             "domain 2^%u) and a proof about %.1f GiB more for its witness columns (streamed, EZKL_KEY_COSETS: %.1f + %.1f GiB%s); %.1f GiB are available "
+             "of %.1f GiB. Shard the key over more GPUs (owner mode, ezkl_prover_cs_set_shard_exchange: the coset term divides by the world size), "
+             "lower logrows, or set EZKL_PROVER_SKIP_FIT_CHECK=1 to try regardless.",
+             what, key / G, (unsigned long long)cols, cs.k, coset_count, (unsigned long long)E, cs.ext_k, witness / G, key_s / G, witness_s / G,
+             one_rank ? "" : ", one rank only", avail / G, total_b / G);
+    // neither form fits with its proof: only a key that does not fit by ITSELF is refused -- the witness term is an estimate, and the
+    // caller may never prove with this key (keygen + pk_write).  The smaller form that still holds the key is taken.
+    if (key <= avail) {
+        fprintf(stderr, "[ezkl_prover] warning: %s\n", msg);
+        return false;
+    }
+    if (mode == "auto" && can_stream && key_s <= avail) {
+        fprintf(stderr, "[ezkl_prover] warning (key held streamed): %s\n", msg);
+        return true;
+    }
+    throw Error(EZKL_ERR_NOMEM, msg);
 }
 static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, const void* const* fixed_values, const uint32_t* copies, size_t n_copies) {
     const uint32_t n = cs.n, k = cs.k;
@@ -1036,10 +1080,11 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     {
         uint32_t first = 0, count = 0;
         be.key_range(cs.ext_k, first, count);
-        check_key_fits(cs, count, "keygen");
+        be.stream_cosets = check_key_fits(cs, count, "keygen", !be.topo.owners && !cs.shard.on());
     }
     auto pk = std::make_unique<ProvingKey>();
     pk->cs = &cs;
+    pk->stream = be.stream_cosets;
     // EZKL_PROVER_KEYGEN_TIMING=1: stage times on stderr
     const bool timing = getenv("EZKL_PROVER_KEYGEN_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -1053,7 +1098,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
     for (uint32_t c = 0; c < cs.n_fixed; c++) {
         pk->fixed_values.push_back(be.upload(fixed_values[c], n));
         pk->fixed_polys.push_back(be.lagrange_to_coeff(pk->fixed_values.back()));
-        pk->fixed_cosets.push_back(be.key_cosets(pk->fixed_polys.back(), cs.ext_k));
+        pk->fixed_cosets.push_back(pk->stream ? Col() : be.key_cosets(pk->fixed_polys.back(), cs.ext_k));
     }
     lap("fixed columns");
     // permutation: cycle structure over (colpos, row) cells numbered c * n + r; `nxt` is the cycle successor, `root` a
@@ -1097,7 +1142,7 @@ static std::unique_ptr<ProvingKey> keygen(ConstraintSystem& cs, ezkl_bases_t g, 
             check(ezkl_hip_permutation_sigma_dev(next->ptr(), pk->omega_col->ptr(), dpc->ptr(), (uint32_t)m, k, sig->ptr(), nullptr), "ezkl_hip_permutation_sigma_dev");
             pk->sigma_values.push_back(sig);
             pk->sigma_polys.push_back(be.lagrange_to_coeff(pk->sigma_values.back()));
-            pk->sigma_cosets.push_back(be.key_cosets(pk->sigma_polys.back(), cs.ext_k));
+            pk->sigma_cosets.push_back(pk->stream ? Col() : be.key_cosets(pk->sigma_polys.back(), cs.ext_k));
         }
     }
     lap("sigma gather + forms");
@@ -1163,12 +1208,12 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
         for (size_t i = 0; i < cols.size(); i++) put_be32(o, (uint32_t)ne);
         for (auto& c : cols) put_poly(nat(c), ne);
     };
-    if (pk.coset_count == (1u << (cs.ext_k - cs.k))) {
+    if (pk.coset_count == (1u << (cs.ext_k - cs.k)) && !pk.stream) {
         put_poly(nat(pk.l0), ne); put_poly(nat(pk.l_last), ne); put_poly(nat(pk.l_active), ne);
         put_vec(pk.fixed_values, n); put_vec(pk.fixed_polys, n); put_ext_vec(pk.fixed_cosets);
         put_vec(pk.sigma_values, n); put_vec(pk.sigma_polys, n); put_ext_vec(pk.sigma_cosets);
     } else {
-        // a key held by owner (a range of cosets): the file still gets the complete extended columns, recomputed from the coefficient forms
+        // a key held by owner (a range of cosets) or streamed (no extended columns at all): the file still gets the complete extended columns, recomputed from the coefficient forms
         // ... ONE column at a time (coefficients -> extended -> natural order -> host -> freed): materialising every extended column first
         // was 35-39 GB of HBM at k = 22 on the rank whose key had deliberately been cut to 1 / world
         auto put_ext_from_polys = [&](const std::vector<Col>& polys) {
@@ -1188,7 +1233,7 @@ static std::vector<uint8_t> pk_write(const ProvingKey& pk) {
 }
 static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* buf, size_t len) {
     Backend be(cs.k, cs.n, nullptr, nullptr);
-    check_key_fits(cs, 1u << (cs.ext_k - cs.k), "pk_read");   // the file's complete extended columns
+    const bool stream = check_key_fits(cs, 1u << (cs.ext_k - cs.k), "pk_read", !cs.shard.on());   // the file's complete extended columns
     size_t off = 0;
     auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
     need(7);
@@ -1242,10 +1287,24 @@ static std::unique_ptr<ProvingKey> pk_read(ConstraintSystem& cs, const uint8_t* 
     // extended columns: natural order in the file, coset-major in HBM
     auto cm = [&](const Col& c) { return be.cosets_reorder(c, cs.ext_k, false); };
     pk->l0 = cm(get_poly(ne)); pk->l_last = cm(get_poly(ne)); pk->l_active = cm(get_poly(ne));
-    get_vec(pk->fixed_values, cs.n_fixed, n); get_vec(pk->fixed_polys, cs.n_fixed, n); get_vec(pk->fixed_cosets, cs.n_fixed, ne);
-    get_vec(pk->sigma_values, cs.perm.size(), n); get_vec(pk->sigma_polys, cs.perm.size(), n); get_vec(pk->sigma_cosets, cs.perm.size(), ne);
-    for (auto& c : pk->fixed_cosets) c = cm(c);
-    for (auto& c : pk->sigma_cosets) c = cm(c);
+    // streamed key: the extended sections of the file are checked for their shape and passed over, never uploaded
+    auto skip_vec = [&](std::vector<Col>& cols, size_t count, size_t m) {
+        invalid(be32() != count, "vector of unexpected length in the key");
+        for (size_t i = 0; i < count; i++) invalid(be32() != m, "polynomial of unexpected length in the key");
+        for (size_t i = 0; i < count; i++) {
+            invalid(be32() != m, "polynomial of unexpected length in the key");
+            need(32 * m);
+            off += 32 * m;
+            cols.push_back(Col());
+        }
+    };
+    pk->stream = stream;
+    get_vec(pk->fixed_values, cs.n_fixed, n); get_vec(pk->fixed_polys, cs.n_fixed, n);
+    if (stream) skip_vec(pk->fixed_cosets, cs.n_fixed, ne); else get_vec(pk->fixed_cosets, cs.n_fixed, ne);
+    get_vec(pk->sigma_values, cs.perm.size(), n); get_vec(pk->sigma_polys, cs.perm.size(), n);
+    if (stream) skip_vec(pk->sigma_cosets, cs.perm.size(), ne); else get_vec(pk->sigma_cosets, cs.perm.size(), ne);
+    for (auto& c : pk->fixed_cosets) if (c) c = cm(c);
+    for (auto& c : pk->sigma_cosets) if (c) c = cm(c);
     invalid(off != len, "trailing bytes in the proving key");
     // derived columns that the file does not hold
     pk->omega_col = be.omega_powers();
@@ -1277,7 +1336,7 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     {
         uint32_t first = 0, count = 0;
         be.key_range(cs.ext_k, first, count);
-        check_key_fits(cs, count, "pk_read_file");
+        be.stream_cosets = check_key_fits(cs, count, "pk_read_file", !be.topo.owners && !cs.shard.on());
     }
     size_t off = 0;
     auto need = [&](size_t m) { invalid(off + m > len, "proving key truncated"); };
@@ -1289,6 +1348,7 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     invalid(nf != cs.n_fixed, "key has another number of fixed columns");
     off = 7;
     auto pk = std::make_unique<ProvingKey>();
+    pk->stream = be.stream_cosets;
     pk->cs = &cs;
     const size_t n = cs.n, ne = (size_t)1 << cs.ext_k, np = cs.perm.size();
     need(64 * (nf + np));
@@ -1418,11 +1478,11 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     {
         for (auto& v : pk->fixed_values) {
             pk->fixed_polys.push_back(be.lagrange_to_coeff(v));
-            pk->fixed_cosets.push_back(be.key_cosets(pk->fixed_polys.back(), cs.ext_k));
+            pk->fixed_cosets.push_back(pk->stream ? Col() : be.key_cosets(pk->fixed_polys.back(), cs.ext_k));
         }
         for (auto& v : pk->sigma_values) {
             pk->sigma_polys.push_back(be.lagrange_to_coeff(v));
-            pk->sigma_cosets.push_back(be.key_cosets(pk->sigma_polys.back(), cs.ext_k));
+            pk->sigma_cosets.push_back(pk->stream ? Col() : be.key_cosets(pk->sigma_polys.back(), cs.ext_k));
         }
     }
     auto lag = [&](uint32_t lo, uint32_t hi) { return be.key_cosets(be.lagrange_to_coeff(be.indicator(lo, hi)), cs.ext_k); };
@@ -1694,6 +1754,7 @@ struct Quotient {
     std::vector<Col> cols;         // coset-major extended columns (null: a witness column this rank does not own)
     std::vector<int> owner;        // per slot: the rank holding the column, -1 = resident on every rank (key columns, replicated provers)
     std::vector<uint8_t> key;      // per slot: a key column (holds cosets [pk.coset_first, +pk.coset_count) only)
+    std::vector<uint8_t> poly_form;// per slot: `cols` holds the COEFFICIENTS (streamed cosets): the sweep builds coset b of it per unit (Backend::coset_of)
     std::vector<Fe> chal;
 };
 // how many constraint terms go into one sweep kernel (EZKL_PROVER_SWEEP_TERMS; 0 = all in one kernel)
@@ -1729,23 +1790,27 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
                                  const std::vector<Col>& phi_cosets, const std::vector<Col>& inst_cosets, const std::vector<Fe>& user_chal,
                                  const std::vector<int>& adv_owner = {}, const std::vector<int>& z_owner = {}, const std::vector<int>& lk_owner = {},
                                  int inst_owner = -1) {
-    Quotient Q{{}, {}, {}, {}, {y, beta, gamma}};
+    // pk.stream: the caller hands COEFFICIENT forms in adv_cosets / z_cosets / m_cosets / phi_cosets, the key's come from *_polys
+    const bool stream = pk.stream;
+    Quotient Q{{}, {}, {}, {}, {}, {y, beta, gamma}};
     Q.chal.insert(Q.chal.end(), user_chal.begin(), user_chal.end());
     std::map<std::vector<uint32_t>, uint32_t> index;
     auto own = [](const std::vector<int>& v, uint32_t i) { return i < v.size() ? v[i] : -1; };
-    auto slot = [&](std::vector<uint32_t> name, const Col& h, int owner = -1, bool is_key = false) {
+    auto slot = [&](std::vector<uint32_t> name, const Col& h, int owner = -1, bool is_key = false, bool poly_form = false) {
         auto it = index.find(name);
         if (it != index.end()) return it->second;
         index[name] = (uint32_t)Q.cols.size();
         Q.cols.push_back(h);
         Q.owner.push_back(owner);
         Q.key.push_back(is_key ? 1 : 0);
+        Q.poly_form.push_back(poly_form ? 1 : 0);
         return (uint32_t)Q.cols.size() - 1;
     };
     enum : uint32_t { S_L0 = 100, S_LLAST, S_LACT, S_X, S_Z, S_SIGMA, S_PHI, S_M };
     auto col_slot = [&](uint32_t kind, uint32_t c) {
-        return kind == N_ADV ? slot({kind, c}, adv_cosets[c], own(adv_owner, c)) : kind == N_INST ? slot({kind, c}, inst_cosets[c], inst_owner)
-                                                                                                 : slot({kind, c}, pk.fixed_cosets[c], -1, true);
+        return kind == N_ADV    ? slot({kind, c}, adv_cosets[c], own(adv_owner, c), false, stream)
+               : kind == N_INST ? slot({kind, c}, inst_cosets[c], inst_owner)
+                                : slot({kind, c}, stream ? pk.fixed_polys[c] : pk.fixed_cosets[c], -1, true, stream);
     };
     // an emitter appends the terms of one gate / one permutation chunk / one lookup argument to the program it is handed; sub-expressions
     // are shared inside an emitter's program (Lowering's memo), never across programs
@@ -1757,7 +1822,7 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
                        s_x = slot({S_X}, pk.x_coset, -1, true);
         const uint32_t nz = (uint32_t)z_cosets.size();
         std::vector<uint32_t> zc;
-        for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j], own(z_owner, j)));
+        for (uint32_t j = 0; j < nz; j++) zc.push_back(slot({S_Z, j}, z_cosets[j], own(z_owner, j), false, stream));
         const uint32_t usable = cs.usable;
         emitters.push_back({[=](Program& prog, Lowering&, std::vector<Src>& terms) {
                                 const Src l0 = prog.column(s_l0), llast = prog.column(s_ll), one = prog.constant(Fe::one());
@@ -1773,7 +1838,7 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
             std::vector<uint32_t> v_slots, s_slots, bd_idx;
             for (uint32_t i = 0; i < chunk.size(); i++) {
                 v_slots.push_back(col_slot(chunk[i].first, chunk[i].second));
-                s_slots.push_back(slot({S_SIGMA, pos + i}, pk.sigma_cosets[pos + i], -1, true));
+                s_slots.push_back(slot({S_SIGMA, pos + i}, stream ? pk.sigma_polys[pos + i] : pk.sigma_cosets[pos + i], -1, true, stream));
                 Q.chal.push_back(beta * delta.pow(pos + i));
                 bd_idx.push_back((uint32_t)Q.chal.size() - 1);
             }
@@ -1799,7 +1864,8 @@ static Quotient quotient_program(const ConstraintSystem& cs, const ProvingKey& p
         const uint32_t theta_idx = (uint32_t)Q.chal.size() - 1;
         for (uint32_t i = 0; i < cs.lookups.size(); i++) {
             const Lookup* lk = &cs.lookups[i];
-            const uint32_t phi_s = slot({S_PHI, i}, phi_cosets[i], own(lk_owner, i)), m_s = slot({S_M, i}, m_cosets[i], own(lk_owner, i));
+            const uint32_t phi_s = slot({S_PHI, i}, phi_cosets[i], own(lk_owner, i), false, stream),
+                           m_s = slot({S_M, i}, m_cosets[i], own(lk_owner, i), false, stream);
             emitters.push_back({[=](Program& prog, Lowering& low, std::vector<Src>& terms) {
                                     const Src l0 = prog.column(s_l0), llast = prog.column(s_ll), lact = prog.column(s_la), BETA = prog.challenge(1),
                                               THETA = prog.challenge(theta_idx);
@@ -1951,6 +2017,8 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     be.recv_bytes = &cs.shard.stats[2];
     const Topo& topo = be.topo;
     const bool owners = topo.owners;
+    invalid(pk.stream && (owners || cs.shard.on()), "a streamed key (EZKL_KEY_COSETS) proves on one rank");
+    be.stream_cosets = pk.stream;
     for (auto& x : cs.shard.stats) x = 0;
     Stopwatch sw(timings);
     EvmTranscript T;
@@ -2267,8 +2335,10 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     sw.lap(5);
     Col hnum = be.zeros(ne);
     {
-        Quotient Q = quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal, adv_owner, z_owner, lk_owner,
-                                      inst_owner);
+        Quotient Q = pk.stream ? quotient_program(cs, pk, adv_polys, z_polys, beta, gamma, y, theta, m_polys, phi_polys, inst_cosets, user_chal, adv_owner, z_owner,
+                                                  lk_owner, inst_owner)
+                               : quotient_program(cs, pk, adv_cosets, z_cosets, beta, gamma, y, theta, m_cosets, phi_cosets, inst_cosets, user_chal, adv_owner, z_owner,
+                                                  lk_owner, inst_owner);
         // The sweep runs in UNITS of rows of one coset.  One rank: the E cosets.  Sharded by rows (set_sweep_gather, equal power-of-two
         // slices): max(E, world) units -- rank r sweeps E / world whole cosets, or, with more ranks than cosets, one of the
         // world / E row ranges of a coset -- and h is all_gathered (units are in rank order, so the shards are equal slices of the
@@ -2339,7 +2409,15 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
             void* out = Backend::at(hnum, (size_t)b * n + rlo);
             if (split == 1) {                                                     // a whole coset: the programs as they are
                 std::vector<const void*> ptrs;
-                for (size_t sl = 0; sl < ns; sl++) ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : (Q.cols[sl] ? Backend::at(Q.cols[sl], coset_row(sl, b)) : nullptr));
+                std::vector<Col> unit_cosets;                                     // streamed: coset b of every column that is held as coefficients
+                for (size_t sl = 0; sl < ns; sl++) {
+                    if (Q.poly_form[sl] && Q.cols[sl]) {
+                        unit_cosets.push_back(be.coset_of(Q.cols[sl], cs.ext_k, b));
+                        ptrs.push_back(unit_cosets.back()->ptr());
+                        continue;
+                    }
+                    ptrs.push_back(remote(sl) ? slab[un][sl]->ptr() : (Q.cols[sl] ? Backend::at(Q.cols[sl], coset_row(sl, b)) : nullptr));
+                }
                 for (auto& prog : Q.progs) prog.run_ptrs(ptrs, Q.chal, out);
             } else {                                                              // a row range: every (column, rotation) becomes a window at rotation 0
                 for (auto& prog : Q.progs) {
@@ -2955,9 +3033,9 @@ int ezkl_prover_pk_residency(ezkl_pk_t pk, uint64_t out[4]) {
     const ProvingKey& k_ = *pk->pk;
     const ConstraintSystem& cs = *k_.cs;
     const uint64_t E = 1ull << (cs.ext_k - cs.k), n = cs.n;
-    out[0] = k_.coset_first; out[1] = k_.coset_count; out[2] = E;
+    out[0] = k_.coset_first; out[1] = k_.stream ? 0 : k_.coset_count; out[2] = E;        // a streamed key holds NO coset of its fixed / permutation columns
     const uint64_t small = (uint64_t)(k_.fixed_values.size() + k_.fixed_polys.size() + k_.sigma_values.size() + k_.sigma_polys.size() + 1) * n * 32;
-    const uint64_t ext = (uint64_t)(k_.fixed_cosets.size() + k_.sigma_cosets.size() + 4) * k_.coset_count * n * 32;
+    const uint64_t ext = (uint64_t)((k_.stream ? 0 : k_.fixed_cosets.size() + k_.sigma_cosets.size()) + 4) * k_.coset_count * n * 32;
     out[3] = small + ext;
     return EZKL_OK;
 }

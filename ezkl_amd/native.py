@@ -215,10 +215,11 @@ class NativeProvingKey:
         return self
 
     def residency(self):
-        """dict(first_coset, cosets, E, key_bytes): what of the extended key columns this key holds in HBM (ezkl_prover_pk_residency)"""
+        """dict(first_coset, cosets, E, key_bytes, streamed): what of the extended key columns this key holds in HBM (ezkl_prover_pk_residency);
+        streamed (cosets == 0): the degraded mode -- values + coefficients only, the sweep rebuilds each coset (EZKL_KEY_COSETS)"""
         out = (C.c_uint64 * 4)()
         _check(load().ezkl_prover_pk_residency(self.h, out), "ezkl_prover_pk_residency")
-        return dict(first_coset=int(out[0]), cosets=int(out[1]), E=int(out[2]), key_bytes=int(out[3]))
+        return dict(first_coset=int(out[0]), cosets=int(out[1]), E=int(out[2]), key_bytes=int(out[3]), streamed=int(out[1]) == 0)
 
     def sweep_stats(self):
         """per extended row of this key's quotient sweep: (instructions, Montgomery products, column slots, kernels)"""

@@ -530,3 +530,70 @@ def test_keygen_refuses_up_front_when_the_key_cannot_fit(hip, golden_srs, monkey
     assert "pk_read" in str(e.value) and "GiB" in str(e.value)
     monkeypatch.delenv("EZKL_PROVER_ASSUME_FREE_GIB")
     assert N.NativeProvingKey.from_bytes(N.NativeCircuit(cs), blob).vk()[2] == pk.vk()[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make", ["lookup", "instance_phase", "random10"])
+def test_streamed_key_proves_the_same_bytes(hip, golden_srs, monkeypatch, tmp_path, make):
+    """VERDICT r05 item 6, the one-GPU degraded mode: EZKL_KEY_COSETS=recompute holds the key as values + coefficients only (no extended
+    column of a fixed / permutation polynomial, none of a witness column either) and the quotient sweep rebuilds coset b of every column
+    from its coefficients when it reaches unit b.  Same witness + randomness => the SAME proof bytes as the resident key, the same key file,
+    and the three ways to get a key (keygen, pk_read, pk_read_file) all honour the mode.  `auto` picks it when the resident form does not
+    fit what the device has left (EZKL_PROVER_ASSUME_FREE_GIB stands in for a full device)."""
+    from ezkl_amd import backend as B
+    if make == "lookup":
+        k, cs = 6, lookup_circuit(6)
+        adv, fixed, copies = lookup_witness(cs, 4)
+        inst = []
+    elif make == "instance_phase":
+        k, cs = 6, instance_phase_circuit(6)
+        adv, fixed, copies, inst = instance_phase_witness(cs, 3)
+    else:
+        k = 10
+        cs, adv, fixed, copies = random_circuit(34, k=10)
+        inst = []
+    if k == 6:
+        g, gl = B.Bases(golden_srs["g"]), B.Bases(golden_srs["g_lagrange"])
+    else:
+        g, gl = B.gen_srs(k, 0xabcdef12345)
+    kw = dict(instances=inst) if inst else {}
+    pk = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    want = N.create_proof(pk, g, gl, adv, rng=det_rng(7), **kw)
+    data = pk.to_bytes()
+    res = pk.residency()
+    assert res["streamed"] is False and res["cosets"] == res["E"]
+    monkeypatch.setenv("EZKL_KEY_COSETS", "recompute")
+    pk_s = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    rs = pk_s.residency()
+    assert rs["streamed"] is True and rs["key_bytes"] < res["key_bytes"]
+    n_key_cols = cs.n_fixed + len(cs.perm)
+    assert res["key_bytes"] - rs["key_bytes"] == n_key_cols * res["E"] * (1 << k) * 32          # exactly the extended key columns
+    assert pk_s.vk()[2] == pk.vk()[2]
+    assert N.create_proof(pk_s, g, gl, adv, rng=det_rng(7), **kw) == want
+    assert pk_s.to_bytes() == data                                                                   # the file still gets complete extended columns
+    pk_b = N.NativeProvingKey.from_bytes(N.NativeCircuit(cs), data)
+    assert pk_b.residency()["streamed"] and N.create_proof(pk_b, g, gl, adv, rng=det_rng(7), **kw) == want
+    path = tmp_path / "pk.key"
+    path.write_bytes(data)
+    pk_f = N.NativeProvingKey.from_file(N.NativeCircuit(cs), str(path))
+    assert pk_f.residency()["streamed"] and N.create_proof(pk_f, g, gl, adv, rng=det_rng(7), **kw) == want
+    # a streamed key is a one-rank mode: a sharded circuit refuses it
+    monkeypatch.setenv("EZKL_KEY_COSETS", "bogus")
+    with pytest.raises(RuntimeError):
+        N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    # auto: resident when it fits, streamed when only that fits, refused when not even the streamed KEY fits
+    monkeypatch.setenv("EZKL_KEY_COSETS", "auto")
+    assert N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies).residency()["streamed"] is False
+    E_, nn = res["E"], 1 << k
+    wcols = cs.n_advice + 3 * len(cs.lookups) + cs.n_chunks + 2
+    resident_need = res["key_bytes"] - nn * 32 + wcols * (2 + E_) * nn * 32                            # (key_bytes counts omega_col: one column more)
+    streamed_need = (n_key_cols * 2 + 4 * E_) * nn * 32 + (wcols * 2 + n_key_cols + wcols + 2 * E_) * nn * 32
+    assert streamed_need < resident_need
+    monkeypatch.setenv("EZKL_PROVER_ASSUME_FREE_GIB", repr((streamed_need + resident_need) / 2 / 2.0 ** 30))
+    pk_a = N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
+    assert pk_a.residency()["streamed"] is True
+    monkeypatch.delenv("EZKL_PROVER_ASSUME_FREE_GIB")
+    assert N.create_proof(pk_a, g, gl, adv, rng=det_rng(7), **kw) == want
+    monkeypatch.setenv("EZKL_PROVER_ASSUME_FREE_GIB", "0.0000001")
+    with pytest.raises(Exception, match="GiB"):
+        N.NativeProvingKey(N.NativeCircuit(cs), g, fixed, copies)
