@@ -78,6 +78,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if rank != 0:
+        # stdout belongs to rank 0's ONE line: whatever the libraries of the other ranks print at C level (RCCL's banner, gloo's
+        # connection notes) goes to stderr instead of sharing the pipe the driver parses
+        os.dup2(2, 1)
     dist = None
     if args.share_device:
         local_rank = 0
