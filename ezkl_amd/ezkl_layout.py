@@ -97,6 +97,17 @@ class EinsumMatmulCircuit:
         assert all(v.num_blocks() == 1 for v in self.einsums.inputs + self.einsums.outputs), "column overflow (duplication) is not laid out here"
         assert num_inner_cols == 1, "one inner column, as in the reference bench"
 
+    @classmethod
+    def over(cls, gc, length):
+        """the same layout over the Freivalds columns of an existing GraphConfig (BaseConfig::configure_einsums), written into the
+        caller's region next to its other ops (TransformerSurrogateCircuit)"""
+        self = cls.__new__(cls)
+        self.k, self.len, self.w = gc.settings.logrows, length, 1
+        self.cs, self.einsums, self.const_cols = gc.cs, gc.base.einsums, gc.const_cols
+        self.reduction_length = 3 * length * length + 2 * length
+        assert all(v.num_blocks() == 1 and v.num_inner_cols == 1 for v in self.einsums.inputs + self.einsums.outputs)
+        return self
+
     # ---- the pieces of assign_einsum -------------------------------------------------------------------------------
     def _assign(self, region, var, vals, live):
         """region.assign_einsum: vals (list of Val) go to rows coord.. of `var`; a previously assigned value is copy-constrained,
@@ -143,13 +154,14 @@ class EinsumMatmulCircuit:
             region.coord += len(chunk)
         return results
 
-    def synthesize(self, a, b, challenges=None):
+    def synthesize(self, a, b, challenges=None, region=None):
         """a, b: len x len integer arrays (values mod r).  challenges=None: first phase (first-phase columns, selectors, copies);
-        else the two challenges: everything.  Returns the Region."""
+        else the two challenges: everything.  Returns the Region (a fresh one unless the caller hands its own)."""
         L = self.len
         cur = 0 if challenges is None else 1
         c0, c1 = (0, 0) if challenges is None else challenges
-        region = Region(self.cs, self.k)
+        if region is None:
+            region = Region(self.cs, self.k)
         E = self.einsums
         A = [[Val(int(a[i][j])) for j in range(L)] for i in range(L)]
         B = [[Val(int(b[j][kk])) for kk in range(L)] for j in range(L)]
@@ -509,6 +521,36 @@ class BaseRegion(Region):
         self.increment(len(w))
         return out
 
+    def _lookup_any(self, table_sel, input_sels, table_rows, picks):
+        """the two sides of a lookup_any argument of BaseConfig::_configure_any (chip.rs:619-833): `table_rows` (3-tuples) go to the three
+        single-column table VarTensors at the dynamic coordinate with the table selector on; `picks` go to (input 0, input 1, output) at
+        the linear coordinate -- one tuple per cell position -- with that position's input selector on"""
+        tabs = self.gc.advices[3:6]
+        dyn = getattr(self, "dyn", 0)
+        for r, tri in enumerate(table_rows):
+            for t in range(3):
+                col = tabs[t].inner[0][0]
+                assert dyn + r < tabs[t].col_size, "dynamic table column overflow"
+                if self.witness:
+                    self.column(col)[dyn + r] = int(tri[t]) % R
+            self.enable(table_sel, dyn + r)
+        self.dyn = dyn + len(table_rows)
+        vars3 = [self.inputs[0], self.inputs[1], self.output]
+        for j, tri in enumerate(picks):
+            x, y, z = self.inputs[0].cartesian_coord(self.linear + j)
+            for t in range(3):
+                self.put(vars3[t], self.linear + j, Val(int(tri[t])))
+            self.enable(input_sels[(0, (x, y))], z)
+        self.increment(len(picks))
+
+    def dynamic_lookup(self, table_rows, picks):
+        """layouts.rs `dynamic_lookup`: every pick is a row of the table (a gather / embedding lookup)"""
+        self._lookup_any(self.base.dynamic_table_selectors[0], self.base.dynamic_lookup_selectors, table_rows, picks)
+
+    def shuffle(self, rows, order):
+        """layouts.rs `shuffles`: the inputs are the rows of the reference side in another order (sort / transpose)"""
+        self._lookup_any(self.base.shuffle_output_selectors[0], self.base.shuffle_input_selectors, rows, [rows[i] for i in order])
+
     def constrain_instance(self, vals, inst_col, inst_offset=0):
         """Layouter::constrain_instance: the cells are tied to the instance column directly (what a hand-written halo2 circuit does)"""
         for t, v in enumerate(vals):
@@ -722,3 +764,251 @@ class SumProdCircuit(LayoutCircuit):
         reg.finish(self.gc.const_cols)
         self.outputs = [v.v for v in outs]
         return reg
+
+
+class _CopyArray:
+    """copy constraints as the (count, 4) uint32 array the native keygen takes (native._copies_array reads `.array`); iterable as pairs
+    for the Python keygen of small circuits"""
+
+    def __init__(self, array):
+        self.array = np.ascontiguousarray(array, np.uint32).reshape(-1, 4)
+
+    def __len__(self):
+        return self.array.shape[0]
+
+    def __iter__(self):
+        for a, b, c, d in self.array.tolist():
+            yield (a, b), (c, d)
+
+
+class TransformerSurrogateCircuit:
+    """A SURROGATE for BASELINE configs[4] (examples/onnx/nanoGPT at k = 22, /root/reference/tests/integration_tests.rs:172-181) that
+    switches on the argument families a transformer circuit switches on and the MLP surrogate does not -- NOT the nanoGPT graph (its
+    layout is ezkl's Model::layout, 6.8k lines of Rust: SURVEY.md §2 #5, out of scope):
+      * the base gates over three model VarTensors (dot, sum, pairwise, decomposition range checks) -- attention scores, an MLP;
+      * THREE static lookup tables over (-32768, 32768) (exp and reciprocal for a softmax, rsqrt for a layer norm:
+        BaseConfig::configure_lookup, chip.rs:452-615), one mv-lookup argument per (table, block, inner column);
+      * a DYNAMIC lookup (an embedding gather) and a SHUFFLE (a transpose), whose table side is advice x selector (chip.rs:619-833);
+      * an einsum contraction with Freivalds RLC gates: SECOND-PHASE advice columns and two challenges (chip/einsum/mod.rs:487-783).
+    One UNIT -- all of the above on a vector of d values and an L x L matmul -- is laid out by the layout engine on the real
+    configuration; the unit is then repeated down every column and in every block with numpy (gates are row-local, copy constraints
+    move with their tile, the lookup arguments are multiset statements over all rows), so the circuit is FULL (every tile is a valid
+    witness of the same statement) without minutes of Python per cell and without a laid-out circuit in the repository.  Only the first
+    tile's outputs are tied to the instance column."""
+
+    def __init__(self, logrows, blocks=4, num_inner_cols=1, d=16, einsum_len=16, decomp_base=16384, decomp_legs=2, lookup_max=None, seed=1):
+        import math
+        assert num_inner_cols == 1, "the Freivalds layout here is the reference bench's: one inner column"
+        self.k, self.w, self.d, self.L = logrows, num_inner_cols, d, einsum_len
+        self.base, self.legs = decomp_base, decomp_legs
+        n = 1 << logrows
+        lm = self.lookup_max = lookup_max or min(32768, n // 8)
+        room = n - min(64, n // 8)                                                     # rows of a column that are certainly usable
+        cap_model = int((blocks - 0.1) * num_inner_cols * room)
+        self.tables = [("exp", lambda x: int(round(math.exp(min(x, 0) / (lm / 8.0)) * 256))),
+                       ("recip", lambda x: int(round((lm * 16.0) / max(x, 1)))),
+                       ("rsqrt", lambda x: int(round(256.0 / math.sqrt(max(x, 1)))))]
+        self.settings = EC.GraphSettings(logrows, num_inner_cols, cap_model, total_const_size=64, required_range_checks=[(-1, 1), (0, decomp_base - 1)],
+                                         required_lookups=self.tables, lookup_range=(-lm, lm), model_instance_shapes=[[1, d]],
+                                         total_dynamic_col_size=room // 2, num_dynamic_lookups=1, total_shuffle_col_size=room // 2 - 2, num_shuffles=1,
+                                         einsum_reduction_length=room, einsum_max_output_axes=2)
+        self.gc = EC.GraphConfig(self.settings)
+        assert self.gc.advices[0].num_blocks() == blocks and all(v.num_blocks() == 1 for v in self.gc.advices[3:6])
+        self.blocks = blocks
+        self.ein = EinsumMatmulCircuit.over(self.gc, einsum_len)
+        rng = np.random.default_rng(seed)
+        self.x = rng.integers(-9, 10, d).tolist()
+        self.Wq = rng.integers(-3, 4, (d, d)).tolist()
+        self.W2 = rng.integers(-3, 4, (d, d)).tolist()
+        self.b2 = rng.integers(-5, 6, d).tolist()
+        self.emb = [(i, int(rng.integers(-50, 50)), int(rng.integers(-50, 50))) for i in range(8)]          # (token, two embedding coordinates)
+        self.tokens = rng.integers(0, 8, 2 * d).tolist()
+        self.perm_rows = [(i, int(rng.integers(1, 99)), int(rng.integers(1, 99))) for i in range(8)]
+        self.perm = rng.permutation(8).tolist()
+        self.A = rng.integers(-8, 8, (einsum_len, einsum_len))
+        self.B = rng.integers(-8, 8, (einsum_len, einsum_len))
+
+    # ---- one unit ---------------------------------------------------------------------------------------------------------------------
+    def _unit(self, witness=True):
+        reg = BaseRegion(self.gc, witness)
+        signed = lambda v: v if v < R // 2 else v - R
+        clamp = lambda v: max(-self.lookup_max, min(self.lookup_max, v))
+        d = self.d
+        _, x = reg.decompose([Val(v) for v in self.x], self.base, self.legs)                  # input range check
+        # attention scores -> softmax: exp lookup, sum, reciprocal lookup, scaling
+        q = [reg.dot(x, [Val(w_) for w_ in row]) for row in self.Wq]
+        e = reg.nonlinearity([Val(clamp(signed(v.v))) for v in q], "exp")
+        tot = reg.sum(e)
+        inv = reg.nonlinearity([Val(clamp(signed(tot.v)))], "recip")
+        reg.pairwise(e, [inv[0]] * d, EC.MULT)
+        # layer norm: sum of squares, rsqrt lookup, scaling
+        ss = reg.dot(x, x)
+        rs = reg.nonlinearity([Val(clamp(signed(ss.v)))], "rsqrt")
+        reg.pairwise(x, [rs[0]] * d, EC.MULT)
+        # MLP: Gemm + bias + ReLU (sign by decomposition)
+        outs = [reg.dot(x, [Val(w_) for w_ in row]) for row in self.W2]
+        h = reg.pairwise(outs, [Val(b) for b in self.b2], EC.ADD)
+        h = reg.relu(h, self.base, self.legs)
+        # embedding gather (dynamic lookup) and a transpose (shuffle)
+        reg.dynamic_lookup(self.emb, [self.emb[t] for t in self.tokens])
+        reg.shuffle(self.perm_rows, self.perm)
+        return reg, h
+
+    def _einsum(self, reg, challenges):
+        return self.ein.synthesize(self.A, self.B, challenges, region=reg)
+
+    # ---- the tiling --------------------------------------------------------------------------------------------------------------------
+    def _geometry(self, reg):
+        gc, w = self.gc, self.w
+        assert reg.linear < gc.advices[0].block_size(), "the unit must fit one block"
+        rows = max(-(-reg.linear // w), getattr(reg, "dyn", 0), reg.coord) + 1
+        return rows, reg.usable // rows
+
+    def build(self, gpu=None, tiles=None, as_ints=False):
+        """-> dict(cs, fixed, copies, advice (callable(phase, challenges) -> {column: Montgomery array}), instances, info): the inputs of
+        keygen and create_proof.  tiles: repeat the unit this many times down the rows (default: as many as fit).  as_ints: the advice
+        callback returns lists of canonical ints (the MockProver's input) instead of Montgomery arrays."""
+        gc, cs0, n = self.gc, self.gc.cs, 1 << self.k
+        reg, h = self._unit(witness=True)
+        self._einsum(reg, None)
+        reg.output_equals_instance(h, gc.instance, 0, self.base, self.legs)
+        reg.finish(gc.const_cols)
+        U, T = self._geometry(reg)
+        if tiles is not None:
+            T = min(T, tiles)
+        B = self.blocks
+        # columns and selectors that exist per block (the model VarTensors and everything keyed by (block, inner column))
+        colmap = {}                                                             # block-0 advice column -> [column in block b]
+        for v in gc.advices[0:3]:
+            for y in range(self.w):
+                colmap[v.inner[0][y].index] = [v.inner[b][y].index for b in range(B)]
+        selmap = {}
+        def per_block(dct, rekey):
+            for key, s0 in dct.items():
+                blk = rekey(key, None)
+                if blk == 0:
+                    selmap[s0.index] = [dct[rekey(key, b)].index for b in range(B)]
+        base = gc.base
+        per_block(base.selectors, lambda k_, b: k_[1] if b is None else (k_[0], b, k_[2]))
+        per_block(base.static_selectors, lambda k_, b: k_[1] if b is None else (k_[0], b, k_[2]))
+        per_block(base.range_selectors, lambda k_, b: k_[1] if b is None else (k_[0], b, k_[2]))
+        per_block(base.dynamic_lookup_selectors, lambda k_, b: k_[1][0] if b is None else (k_[0], (b, k_[1][1])))
+        per_block(base.shuffle_input_selectors, lambda k_, b: k_[1][0] if b is None else (k_[0], (b, k_[1][1])))
+        # selector activations, tiled
+        acts = [None] * len(cs0.selectors)
+        def tiled_rows(a):
+            out = np.zeros(n, bool)
+            out[:T * U] = np.tile(a[:U], T)
+            return out
+        for si, a in enumerate(reg.activations):
+            if a is None or not a[:U].any():
+                continue
+            assert not a[U:].any()
+            for sb in selmap.get(si, [si]):
+                acts[sb] = tiled_rows(a)
+        sel_cols = cs0.compress_selectors(acts)
+        if n <= 1 << 12:
+            sel_cols = [c.tolist() for c in sel_cols]
+        cs = cs0.to_plonk(self.k)
+        tabs = gc.table_columns()
+        n_pre = cs.n_fixed - len(sel_cols)
+        fixed = [tabs.get(c) or reg.fixed.get(c) or [0] * n for c in range(n_pre)] + list(sel_cols)
+        # copy constraints, tiled: cells of per-block columns move with (block, tile), cells of the other advice columns with the tile,
+        # constants stay, the instance column belongs to the first tile
+        pos = {kc: i for i, kc in enumerate(cs.perm)}
+        kinds = {"adv": 0, "fix": 1, "inst": 2}
+        unit = np.array([[kinds[a[0]], a[1], a[2], kinds[b[0]], b[1], b[2]] for a, b in reg.copies], np.int64).reshape(-1, 6)
+        has_inst = (unit[:, 0] == 2) | (unit[:, 3] == 2)
+        first_tile, unit = unit, unit[~has_inst]
+        lut = {b: np.arange(max(len(cs0.advice), 1), dtype=np.int64) for b in range(B)}
+        for c0, cb in colmap.items():
+            for b in range(B):
+                lut[b][c0] = cb[b]
+        perm_adv = np.full(len(cs0.advice), -1, np.int64)
+        perm_fix = np.full(cs.n_fixed + 1, -1, np.int64)
+        perm_inst = np.full(max(cs.n_instance, 1), -1, np.int64)
+        for (kind, c), i in pos.items():
+            (perm_adv if kind == "adv" else perm_fix if kind == "fix" else perm_inst)[c] = i
+        per_blk = np.zeros(len(cs0.advice), bool)
+        per_blk[list(colmap)] = True
+        def place(cells, b, t):
+            """cells: (m, 3) kind / column / row -> (m, 2) permutation position / row of the copy in tile (b, t)"""
+            kind, col, row = cells[:, 0], cells[:, 1], cells[:, 2]
+            adv = kind == 0
+            colb = np.where(adv, lut[b][np.where(adv, col, 0)], col)
+            p_ = np.where(adv, perm_adv[np.where(adv, colb, 0)], np.where(kind == 1, perm_fix[np.where(kind == 1, col, 0)], perm_inst[np.where(kind == 2, col, 0)]))
+            assert (p_ >= 0).all(), "a copied cell lies in a column without equality enabled"
+            return np.stack([p_, np.where(adv, row + t * U, row)], 1)
+        chunks = [np.concatenate([place(first_tile[:, 0:3], 0, 0), place(first_tile[:, 3:6], 0, 0)], 1)]
+        touches_blk = per_blk[np.where(unit[:, 0] == 0, unit[:, 1], 0)] & (unit[:, 0] == 0) | per_blk[np.where(unit[:, 3] == 0, unit[:, 4], 0)] & (unit[:, 3] == 0)
+        for b in range(B):
+            sub = unit if b == 0 else unit[touches_blk]                        # copies among shared columns only: once per tile, not once per block
+            for t in range(T):
+                if b == 0 and t == 0:
+                    continue
+                chunks.append(np.concatenate([place(sub[:, 0:3], b, t), place(sub[:, 3:6], b, t)], 1))
+        copies = _CopyArray(np.concatenate(chunks))
+        # advice: unit columns as canonical limbs, tiled; second-phase columns per proof (they depend on the challenges)
+        self._U, self._T, self._colmap = U, T, colmap
+        def tiled_col(vals):
+            if as_ints:
+                return list(vals[:U]) * T + [0] * (n - T * U)
+            limbs = ints_to_limbs(vals[:U])
+            out = np.zeros((n, 4), np.uint64)
+            out[:T * U] = np.tile(limbs, (T, 1))
+            return out
+        phase_of = {c.index: c.phase for c in cs0.advice}
+        def columns_of(region, phase):
+            cols = {}
+            for ci, vals in region.advice.items():
+                if phase_of[ci] != phase:
+                    continue
+                t_ = tiled_col(vals)
+                for cb in colmap.get(ci, [ci]):
+                    cols[cb] = t_
+            for c in cs0.advice:
+                if c.phase == phase and c.index not in cols:
+                    cols[c.index] = [0] * n if as_ints else np.zeros((n, 4), np.uint64)
+            return cols
+        first = columns_of(reg, 0)
+        cache = {}
+        def advice(phase, challenges):
+            key = (phase, tuple(challenges))
+            if key not in cache:
+                if phase == 0:
+                    cols = first
+                else:
+                    r2 = Region(cs0, self.k)
+                    self._einsum(r2, tuple(challenges[:2]))
+                    cols = columns_of(r2, 1)
+                idx = sorted(cols)
+                cache[key] = cols if as_ints else dict(zip(idx, limbs_to_mont([cols[i] for i in idx], gpu)))
+            return cache[key]
+        info = dict(circuit="transformer-shaped SURROGATE of configs[4] (not the nanoGPT graph): attention scores + softmax (exp, recip tables) + "
+                            "layer norm (rsqrt table) + MLP + embedding gather (dynamic lookup) + transpose (shuffle) + %d x %d Freivalds einsum, "
+                            "one unit of %d rows tiled %d x %d times, k=%d" % (self.L, self.L, U, T, B, self.k),
+                    unit_rows=U, tiles=T, blocks=B, cells_used=int(reg.linear) * T * B)
+        self.outputs = [v.v for v in h]
+        return dict(cs=cs, fixed=fixed, copies=copies, advice=advice, instances=[self.outputs], info=info)
+
+
+def limbs_to_mont(cols, gpu=None):
+    """(n, 4) canonical limb arrays -> Montgomery arrays (on the device when a backend is given: one product by R^2 per element)"""
+    if gpu is None:
+        M = (1 << 256) % R
+        out = []
+        for a in cols:
+            ints = [int.from_bytes(a[i].tobytes(), "little") for i in range(a.shape[0])]
+            out.append(np.frombuffer(b"".join((v * M % R).to_bytes(32, "little") for v in ints), np.uint64).reshape(-1, 4).copy())
+        return out
+    r2 = P.to_mont((1 << 256) % R)
+    out = []
+    for a in cols:
+        buf = gpu.DeviceBuffer.from_numpy(np.ascontiguousarray(a))
+        gpu.vec_scale(buf.ptr, r2, buf.ptr, a.shape[0])
+        pa = gpu.PinnedArray((a.shape[0], 4))             # page-locked: what a prover's synthesis should fill (uploads at PCIe speed)
+        pa.array[:] = buf.to_numpy(shape=(a.shape[0], 4))
+        _PINNED.append(pa)
+        out.append(pa.array)
+        buf.free()
+    return out

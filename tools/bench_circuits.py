@@ -156,7 +156,7 @@ def _cache_store(path, cs, fixed_raw, copies, adv_raw, instances, info):
 def build(kind, k, gpu=None, seed=1, **kw):
     """-> dict(cs, fixed (Montgomery arrays), copies, advice (list of arrays, or callable(phase, challenges)), instances, info)"""
     d = _cache_dir()
-    if d is None or kind == "einsum":                # the einsum witness depends on the proof's challenges: laid out per proof
+    if d is None or kind in ("einsum", "transformer"):   # the second-phase witness depends on the proof's challenges: laid out per proof
         return _build(kind, k, gpu, seed, None, **kw)
     os.makedirs(d, exist_ok=True)
     tag = "_".join([kind, "k%d" % k, "s%d" % seed] + ["%s%s" % (a, kw[a]) for a in sorted(kw) if kw[a] is not None])
@@ -200,6 +200,15 @@ def _build(kind, k, gpu, seed, store, **kw):
             return cache[key]
         info = dict(circuit="accum_einsum_matmul (benches/accum_einsum_matmul.rs) ij,jk->ik len %d, Freivalds, k=%d" % (L, k), rows_used=rows)
         return dict(cs=cs, fixed=EL.cols_to_mont(fixed, gpu), copies=copies, advice=advice, instances=[], info=info)
+    if kind == "transformer":
+        # the transformer-shaped SURROGATE of BASELINE configs[4] (ezkl_layout.TransformerSurrogateCircuit): static lookup tables, a dynamic
+        # lookup, a shuffle, Freivalds einsum with second-phase advice -- one unit laid out, tiled with numpy: no cache file, ~25 s at k = 22
+        small = k < 16                                 # test sizes: tables and decompositions that fit 2^k rows
+        c = EL.TransformerSurrogateCircuit(k, blocks=kw.get("blocks") or 4, d=kw.get("width") or (64 if not small else 4),
+                                           einsum_len=kw.get("length") or (48 if not small else 3), decomp_base=kw.get("base") or (16384 if not small else 16),
+                                           lookup_max=None if not small else (1 << k) // 16, seed=seed)
+        b = c.build(gpu=gpu)
+        return dict(cs=b["cs"], fixed=EL.cols_to_mont(b["fixed"], gpu), copies=b["copies"], advice=b["advice"], instances=b["instances"], info=b["info"])
     if kind == "mlp":
         layers, N, blocks, fill = kw.get("layers", 9), kw.get("width"), kw.get("blocks") or 2, kw.get("fill")
         # decomposition base of the range checks (ezkl's default 16384, src/lib.rs:257-260).  A table of `base` rows is split over
