@@ -519,8 +519,9 @@ def compact_line(full):
             m["mlp_k20"] = g(pr["mlp_k20"], "prove_seconds_gpu", "all_ranks_same_proof", "verifier_accepts", "rccl_ranks_seen", "error")
         line["prove_multi"] = m
     else:
-        brief = lambda d: g(d, "prove_seconds_gpu", "prove_seconds_cpu", "proofs_identical_gpu_cpu", "verifier_accepts", "hbm_in_use_gib_after_prove", "cold_seconds", "error")
-        others = {n: brief(pr[n]) for n in ("mlp_k22", "conv2d_mnist", "einsum", "mlp", "relu_k8") if isinstance(pr.get(n), dict)}
+        brief = lambda d: g(d, "prove_seconds_gpu", "prove_seconds_cpu", "proofs_identical_gpu_cpu", "verifier_accepts", "hbm_in_use_gib_after_prove",
+                            "hbm_pool_high_water_gib", "same_proof_as_resident", "cold_seconds", "error")
+        others = {n: brief(pr[n]) for n in ("transformer_k22", "transformer_k22_streamed", "mlp_k22", "conv2d_mnist", "einsum", "mlp") if isinstance(pr.get(n), dict)}
         if others:
             line["prove_other_circuits"] = others
         if pr.get("skipped"):
@@ -645,25 +646,34 @@ def prove_leg():
                 skipped.append("mlp_k20 cold one-shot")
     except Exception as e:
         out["mlp_k20"] = {"error": repr(e)[:300]}
-    # 1b. BASELINE configs[4]'s size (nanoGPT-tiny, k = 22, SRS 2^22; /root/reference/tests/integration_tests.rs:172-181) as an MLP SURROGATE: the
-    #     MLP generator scaled to 5 blocks -> 30 advice columns, 20 lookup arguments, 32 permutation columns, ext 2^24 -- NOT the nanoGPT graph
-    #     (its op families are outside ezkl_layout.py).  The laid-out circuit ships as bench_cache/mlp_k22_s1_blocks5_fill25.npz (25 % of the
-    #     cells laid out, the column allocation of the full model: every kernel of the prover except the witness MSMs costs the same whatever
-    #     the cells hold); without the file the Python layout engine needs minutes, so the leg then runs only with EZKL_BENCH_K22=1.
-    #     ~75 s: 2^22-point SRS, key generation, first + 2 warm proofs, the Python verifier.  EZKL_BENCH_K22=0 skips it; =1 forces it;
-    #     EZKL_BENCH_K22_CPU=1 adds the CPU prover (tens of minutes).
+    # 1b. BASELINE configs[4]'s size (nanoGPT-tiny, k = 22, SRS 2^22; /root/reference/tests/integration_tests.rs:172-181) as a transformer-SHAPED
+    #     SURROGATE (ezkl_layout.TransformerSurrogateCircuit -- NOT the nanoGPT graph, whose layout is ezkl's Model::layout): three static lookup
+    #     tables (softmax / layer norm), a dynamic lookup, a shuffle, a Freivalds einsum with second-phase advice and two challenges, degree 6
+    #     -> the extended domain is 2^25.  One unit is laid out and tiled with numpy: a FULL circuit in ~10 s, no laid-out file in the
+    #     repository.  Two children: the key resident (210 GiB of columns at the peak) and the one-GPU degraded mode EZKL_KEY_COSETS=recompute
+    #     (72 GiB: the sweep rebuilds one coset at a time) -- same proof bytes.  ~45 s + ~35 s.  EZKL_BENCH_K22=0 skips, =1 forces;
+    #     EZKL_BENCH_K22=mlp runs the round-5 MLP surrogate instead (needs bench_cache/mlp_k22_s1_blocks5_fill25.npz, no longer shipped).
     k22 = os.environ.get("EZKL_BENCH_K22", "auto")
-    fill22 = os.environ.get("EZKL_BENCH_K22_FILL", "25")
-    have22 = os.path.exists(os.path.join(os.environ.get("EZKL_BENCH_CACHE", os.path.join(ROOT, "bench_cache")), "mlp_k22_s1_blocks5_fill%s.npz" % fill22))
-    if k22 == "1" or (k22 == "auto" and have22 and left() > 110):
+    if k22 == "mlp":
         try:
-            j = child("mlp_k22", {"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": fill22, "REPS": "2"},
-                      ["--pinned"] + (["--cpu"] if os.environ.get("EZKL_BENCH_K22_CPU") == "1" else []), 7200)
+            j = child("mlp_k22", {"CIRCUIT": "mlp", "K": "22", "MLP_BLOCKS": "5", "MLP_FILL": os.environ.get("EZKL_BENCH_K22_FILL", "25"), "REPS": "2"}, ["--pinned"], 7200)
             out["mlp_k22"] = dict(shape(j), label="MLP surrogate of configs[4] (k = 22, 30 advice columns, SRS 2^22): the size, not the nanoGPT graph")
         except Exception as e:
             out["mlp_k22"] = {"error": repr(e)[:300]}
+    elif k22 == "1" or (k22 == "auto" and left() > 110):
+        try:
+            j = child("transformer_k22", {"CIRCUIT": "transformer", "K": "22", "REPS": "2", "EZKL_KEY_COSETS": "auto"}, [], 1200)
+            out["transformer_k22"] = dict(shape(j, ["proof_sha256"]), label="transformer-shaped surrogate of configs[4] (k = 22, ext 2^25, 28 lookups, second-phase advice): not the nanoGPT graph")
+            if k22 == "1" or left() > 70:
+                js = child("transformer_k22_streamed", {"CIRCUIT": "transformer", "K": "22", "REPS": "1", "EZKL_KEY_COSETS": "recompute"}, [], 1200)
+                out["transformer_k22_streamed"] = dict(shape(js, ["proof_sha256"]), label="the same proof with the key streamed (EZKL_KEY_COSETS=recompute)",
+                                                       same_proof_as_resident=js.get("proof_sha256") == j.get("proof_sha256"))
+            else:
+                skipped.append("transformer_k22 streamed key")
+        except Exception as e:
+            out.setdefault("transformer_k22", {})["error"] = repr(e)[:300]
     else:
-        skipped.append("mlp_k22 (surrogate of configs[4])" + ("" if have22 else ": bench_cache/mlp_k22_s1_blocks5_fill%s.npz missing" % fill22))
+        skipped.append("transformer_k22 (surrogate of configs[4])")
     # 2. BASELINE configs[2] as the reference states it: examples/conv2d_mnist at k = 17 (~12 s with its CPU prover)
     if left() > 20:
         try:
