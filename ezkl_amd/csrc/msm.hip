@@ -716,32 +716,7 @@ __global__ __launch_bounds__(256, 3) void msm_accumulate_kernel(const g1a_t* tab
 // ~26 pairs per bucket and ~69 per lane nearly every boundary cuts a bucket, so the waves are full).  The common case,
 // a bucket cut once, is one addition; a bucket cut a few times is folded serially by its first boundary; anything
 // longer (a skewed witness) is queued for msm_fixup_heavy{1,2}_kernel.
-__global__ __launch_bounds__(256) void msm_fixup_boundary_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes,
-                                                                 const uint32_t* lane_first, const g1x29_t* head, const g1x29_t* tail, g1x29_t* buckets,
-                                                                 uint32_t* heavy_list, uint32_t* heavy_count, uint32_t* chunk_list, uint32_t lmin,
-                                                                 uint32_t span_heavy, size_t bstride) {
-    BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(tail); BSH(buckets); BSH(heavy_list); BSH(heavy_count); BSH(chunk_list);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x + 1;          // boundary between lanes t-1 and t
-    if (t >= nlanes) return;
-    const uint32_t L = msm_lane_len(offsets, nb, nlanes, lmin);
-    const uint64_t k0 = (uint64_t)t * L;
-    if (k0 >= offsets[nb]) return;
-    const uint32_t b = lane_first[t];
-    const uint32_t beg = offsets[b], end = offsets[b + 1];
-    if (beg >= k0) return;                                                 // the bucket starts exactly on the boundary: not cut
-    const uint32_t t1 = beg / L, t2 = (end - 1) / L;
-    if (t2 - t1 > span_heavy) {                                        // skewed witness: queue the bucket once, and one work item
-        // (a bucket of ONE chunk is finished by the first pass itself, tail included: no second pass for it -- round 5)
-        if (t == t1 + 1 && t2 - t1 > MSM_HEAVY_CHUNK) heavy_list[atomicAdd(heavy_count, 1u)] = b;       // per chunk of MSM_HEAVY_CHUNK lane partials
-        if ((t - t1 - 1) % MSM_HEAVY_CHUNK == 0) chunk_list[atomicAdd(heavy_count + 1, 1u)] = t;
-        return;
-    }
-    if (t != t1 + 1) return;                                               // a later boundary of a bucket cut several times
-    g1x29_t acc = g1x29_add(ld_g1x29(tail + t1), ld_g1x29(head + t));
-    for (uint32_t u = t + 1; u <= t2; u++) acc = g1x29_add(acc, ld_g1x29(head + u));
-    st_g1x29(buckets + b, acc);
-}
-// The same with the partials of a bucket summed by a SEGMENTED TREE inside the wave (round 5).  A witness-shaped column (small values: one
+// The partials of a bucket are summed by a SEGMENTED TREE inside the wave (round 5; the serial kernel of rounds 1-4 is gone: profiles/r05ar_tree{0,1}_msm_columns_serial.txt).  A witness-shaped column (small values: one
 // non-zero digit per scalar, lanes of 8 pairs) cuts almost every bucket 5-16 times, and the thread of a bucket's first boundary then folded up
 // to 16 partials one after the other while its neighbours -- the bucket's other boundaries -- idled: 180-290 us per column
 // (profiles/r04o_msm_columns_serial.txt).  Here the 64 boundaries of a wave run a segmented suffix sum: log2(longest run in the wave)
@@ -1089,10 +1064,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const uint32_t nlanes = cdiv(npairs, L);
     // device-side floor of the lane length (columns with few non-zero digits) and the cut count above which a bucket takes the heavy path
     static const uint32_t lmin = [] { const char* e = getenv("EZKL_MSM_LMIN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_LMIN); }();
-    // cooperative (quad) additions in the latency-bound trees (curve29.hpp: g1x29_add_quad); EZKL_MSM_COOP=0 restores the plain butterflies
-    static const uint32_t coop = [] { const char* e = getenv("EZKL_MSM_COOP"); return (uint32_t)(e ? atoi(e) : 7); }();   // bit 0: reduce2, 1: planes, 2: heavy
-    // the planes kernel writes its sums into the slot's page-locked landing buffer itself (EZKL_MSM_ZEROCOPY=0: a copy command after it, as before round 5)
-    static const bool zero_copy = [] { const char* e = getenv("EZKL_MSM_ZEROCOPY"); return !(e && atoi(e) == 0); }();
+    // cooperative (quad) additions in the latency-bound trees (curve29.hpp: g1x29_add_quad) -- bit 0: reduce2, 1: planes, 2: heavy; bit 3 (the
+    // planes kernel's four wave totals cooperatively as well) was measured level and stays off (profiles/r05aj_coop15.log)
+    constexpr uint32_t coop = 7;
+    // (the planes kernel writes its sums into the slot's page-locked landing buffer itself: no copy command after it)
     static const uint32_t span_heavy = [] { const char* e = getenv("EZKL_MSM_SPAN"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 1 && v <= 4096 ? v : (int)MSM_SPAN_HEAVY); }();
     // ---- field geometry of the reduce phase (positions: pos = (bucket & (NP-1)) << LB | bucket >> PB) ----
     ReduceGeom rg;
@@ -1202,13 +1177,8 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     if (timed) EZ_HIP(hipEventRecord(a1, st));
     if (nlanes > 1)
     {
-        static const bool tree = [] { const char* e = getenv("EZKL_MSM_FIXUP_TREE"); return !(e && atoi(e) == 0); }();      // 0: the serial fold of rounds 1-4
-        if (tree)
-            hipLaunchKernelGGL(msm_fixup_boundary_tree_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
-                               heavy, hcnt, chunks, lmin, span_heavy, bstride);
-        else
-            hipLaunchKernelGGL(msm_fixup_boundary_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
-                               heavy, hcnt, chunks, lmin, span_heavy, bstride);
+        hipLaunchKernelGGL(msm_fixup_boundary_tree_kernel, dim3(cdiv(nlanes - 1, 256), 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt,
+                           heavy, hcnt, chunks, lmin, span_heavy, bstride);
     }
     {
         size_t max_heavy = nlanes / span_heavy + 1;
@@ -1230,23 +1200,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         }
         const uint32_t blocksA = waves(nA, lanesA);
         hipLaunchKernelGGL(msm_reduce2_kernel, dim3(blocksA + waves(nT, lanesT), 1, Z), dim3(64), 0, st, partA, partT, rg, SA, TT, lanesA, lanesT, blocksA, coop & 1u, bstride);
-        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, zero_copy ? (g1x29_t*)sl.pinned_dev : (g1x29_t*)nullptr,
+        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, Z), dim3(256), 0, st, SA, TT, rg, planes, (g1x29_t*)sl.pinned_dev,
                            coop & 10u, bstride);
     }
     EZ_HIP(hipGetLastError());
-    if (getenv("EZKL_MSM_DEBUG_PLANES")) {           // the planes of the cooperative and of the plain tree, side by side (first MSM of a group)
-        std::vector<uint32_t> pc((size_t)nplanes * 36), pp((size_t)nplanes * 36);
-        EZ_HIP(hipStreamSynchronize(st));
-        EZ_HIP(hipMemcpy(pc.data(), planes, pc.size() * 4, hipMemcpyDeviceToHost));
-        EZ_HIP(hipMemsetAsync(planes, 0, pc.size() * 4, st));
-        hipLaunchKernelGGL(msm_planes_kernel, dim3(nplanes, 1, 1), dim3(256), 0, st, SA, TT, rg, planes, (g1x29_t*)nullptr, 0u, (size_t)0);
-        EZ_HIP(hipStreamSynchronize(st));
-        EZ_HIP(hipMemcpy(pp.data(), planes, pp.size() * 4, hipMemcpyDeviceToHost));
-        for (uint32_t k = 0; k < nplanes; k++) {
-            const h64::aff a = h64::to_affine(h64::from_limbs29_point(pc.data() + 36 * k)), b = h64::to_affine(h64::from_limbs29_point(pp.data() + 36 * k));
-            fprintf(stderr, "[msm planes] n=%zu plane %u: %s\n", n, k, memcmp(&a, &b, 64) ? "DIFFERS" : "same");
-        }
-    }
     if (getenv("EZKL_MSM_DEBUG")) {
         uint32_t hc = 0;
         EZ_HIP(hipMemcpyAsync(&hc, hcnt, 4, hipMemcpyDeviceToHost, st));
@@ -1254,8 +1211,6 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         fprintf(stderr, "[msm] n=%zu W=%u bits=%u L=%u nlanes=%u heavy=%u\n", n, W, bits, L, nlanes, hc);
     }
     if (timed_chain) EZ_HIP(hipEventRecord(m1, st));
-    for (size_t j = 0; j < count && !zero_copy; j++)
-        EZ_HIP(hipMemcpyAsync(sl.pinned + j * 32 * 36, (uint8_t*)planes + j * bstride, (size_t)nplanes * sizeof(g1x29_t), hipMemcpyDeviceToHost, st));
     EZ_HIP(hipEventRecord(sl.done, st));
     sl.bits = bits;
     sl.count = (uint32_t)count;
@@ -1276,10 +1231,9 @@ static int msm_run_groups(Ctx* c, MsmTable* T, size_t base_offset, const fe_t* c
     // groups -- G, then half of what is left, ... down to single columns -- so that what remains to be done after the last copy has landed
     // is the short chain of one column, not of a full group: twelve advice columns go as 6 + 3 + 2 + 1 (the groups start at 3.6, 5.4, 6.6
     // and 7.2 ms and overlap on their slots) instead of 6 + 6 (the second group could not start before 7.2 ms and then ran for ~3 ms).
-    static const bool taper = getenv("EZKL_MSM_NO_TAPER") == nullptr;
     for (size_t j0 = 0; j0 < batch && !rc; gi++) {
         size_t cnt = batch - j0 < G ? batch - j0 : G;
-        if (wait_ev && taper && j0 > 0) {
+        if (wait_ev && j0 > 0) {
             const size_t left = batch - j0;
             cnt = left <= 2 ? 1 : std::min(G, (left + 1) / 2);
         }
@@ -1370,8 +1324,7 @@ int msm_call_start(Ctx* c, std::unique_lock<std::recursive_mutex>& lk, const Bas
         hipError_t e = hipSuccess;
         // ... unless that stream is idle (round 5): then there is nothing to order behind, and the cross-queue event (a barrier packet on the
         // slot's queue that waits for a signal of the library's) only delays the first kernel of a synchronous call
-        static const bool order_always = getenv("EZKL_MSM_ORDER_ALWAYS") != nullptr;       // A/B switch: the event whatever the stream's state
-        const hipError_t q = order_always ? hipErrorNotReady : hipStreamQuery(c->stream);
+        const hipError_t q = hipStreamQuery(c->stream);
         if (q != hipSuccess) {
             (void)hipGetLastError();                       // hipErrorNotReady is not an error
             if (!g_call_order_ev) e = hipEventCreateWithFlags(&g_call_order_ev, hipEventDisableTiming);

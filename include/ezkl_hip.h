@@ -34,6 +34,38 @@ extern "C" {
 #define EZKL_ERR_TIMEOUT (-7)     /* a collective did not complete within EZKL_COMM_TIMEOUT_S seconds (comm.hip's watchdog): the communicator is aborted */
 #define EZKL_ERR_BUSY (-6)        /* the calling thread already holds every slot of a bounded resource (ezkl_hip_msm_g1_start_dev: four per context) */
 
+
+/* ---- environment: every variable libezkl_hip.so and libezkl_prover.so read, in ONE place (round 6: the A/B switches of rounds 3-5 --
+ *      EZKL_MSM_PREFETCH / LEAN / FETCH_ALWAYS / UNPACK_FIRST / RESET_ZZ / COOP / ZEROCOPY / ORDER_ALWAYS / NO_TAPER / FIXUP_TREE /
+ *      DEBUG_PLANES, EZKL_NTT_LOAD_ALWAYS / SKIP_UNIT2 -- are gone from the sources; their measurements are in profiles/).  All are read
+ *      in-process (getenv); unset = the default.  A fork exposes the first group, the rest is for whoever works on the library.
+ *
+ *  gate and modes (what a deployment sets)
+ *   ENABLE_HIP_GPU            unset   the runtime gate, as ENABLE_ICICLE_GPU: ezkl_hip_enabled(k) is 0 without it
+ *   HIP_SMALL_K               8       circuits with k <= this stay on the CPU prover, as ICICLE_SMALL_K
+ *   LOCAL_RANK                unset   ezkl_hip_init(-1): one context on this device instead of one per visible device
+ *   EZKL_KEY_COSETS           auto    auto | resident | recompute: how a proving key is held (ezkl_prover.h: the streamed / degraded mode)
+ *   EZKL_PROVER_SKIP_FIT_CHECK unset  1: no up-front HBM fit check at keygen / key load
+ *   EZKL_COMM_TIMEOUT_S       120     watchdog of every collective (0: none): EZKL_ERR_TIMEOUT instead of a hang
+ *   EZKL_COMM_SELFTEST        1       0: ezkl_hip_comm_init does not run ezkl_hip_comm_selftest (same value on every rank)
+ *   EZKL_COMM_SLAB_MB         128     bytes per peer and round of the packed all-to-all (same value on every rank)
+ *   EZKL_HIP_CACHE_DIR        ~/.cache/ezkl_hip   where compiled sweep kernels are kept ("off": nowhere)
+ *   EZKL_HIP_POOL_CAP_GB      25 % of the device, at least what is live x 1.5   floor of the column pool's footprint bound
+ *   EZKL_PK_READ_THREADS      4       reader threads of ezkl_prover_pk_read_file
+ *   EZKL_HIP_LIB / EZKL_PROVER_LIB    (Python bindings) another build of the two libraries
+ *  measurement
+ *   EZKL_HIP_TIMING           all     all | kernel | none: which HIP event pairs a timed call records (ezkl_hip_kernel_ms_stats)
+ *   EZKL_MSM_HOST_TIMING, EZKL_PROVER_KEYGEN_TIMING     host-side stage times on stderr
+ *   EZKL_HIP_DEBUG, EZKL_MSM_DEBUG, EZKL_HIP_JIT_DEBUG, EZKL_HIP_JIT_DUMP=<file>     diagnostics on stderr / the generated sweep source
+ *  tuning knobs whose defaults are the measured optimum (tools/ab.sh sweeps them)
+ *   EZKL_MSM_SLOTS 4 | EZKL_MSM_GROUP / _SMALL 6 / _BIG 4 | EZKL_MSM_L (device-chosen) | EZKL_MSM_LMIN 8 | EZKL_MSM_SPAN 16 | EZKL_MSM_E 8
+ *   EZKL_NTT_MAXR 8 (9 / 10: 2048- / 4096-element tiles) | EZKL_PROVER_SWEEP_TERMS 0 | EZKL_PROVER_SWEEP_INSTRS 640
+ *  comparison switches kept because tests or the multi-rank fallbacks use them
+ *   EZKL_EVALH_MODE=interp (the sweep interpreter instead of the JIT kernel), EZKL_EVALH_NO_SCHEDULE, EZKL_COMM_UNPACKED=1 (one send / recv per
+ *   segment), EZKL_COMM_SELF_VIA_RCCL=1 (world 1 through the wire format), EZKL_GATHER_HOST, EZKL_MSM_SERIAL_CALLS, EZKL_HIP_POOL_SYNC,
+ *   EZKL_PROVER_SYNC_CALLS, EZKL_PROVER_MERGED_COMMITS=1, EZKL_PROVER_NO_EARLY_RANDOM, EZKL_PROVER_NO_SUM_SCATTER,
+ *   EZKL_PROVER_ASSUME_FREE_GIB=<x> (test hook of the fit check) ---- */
+
 typedef struct ezkl_bases_s* ezkl_bases_t;     /* device-resident G1 base set (SRS g or g_lagrange) */
 
 /* ---- device management: replaces icicle try_load_and_set_backend_device("CUDA") + warmup(),

@@ -39,10 +39,11 @@ for JOB in "$@"; do
       echo "bench.py rc=$? wall $(( $(date +%s) - TB )) s" >> "$O/${TAG}_bench.log"
       grep '^{"metric' "$O/${TAG}_bench.log" | python -c "
 import sys, json
-j = json.loads(sys.stdin.read()); p = j.get('prove', {})
-print('value %.4g %s  ms/step %.4f  roofline.frac %.4f  ntt %.4g el/s' % (j['value'], j['unit'], j['ms_per_step'], j['roofline']['frac'], j['extra']['ntt_elems_per_s']))
-print('prove_seconds_k20_mlp', j.get('prove_seconds_k20_mlp')); print('legs', p.get('leg_seconds'), 'skipped', p.get('skipped'))"
-      tail -3 "$O/${TAG}_bench.log" | cut -c1-300 ;;
+j = json.loads(sys.stdin.read()); r = j['roofline']
+print('line %d bytes  value %.4g %s  ms/step %.4f  roofline.frac %.4f  ntt %.4g el/s (inverse %.4g, coset %.4g)  W %s' % (len(json.dumps(j, separators=(',', ':'))), j['value'], j['unit'], j['ms_per_step'], r['frac'], r['ntt']['elems_per_s'], r['ntt'].get('inverse_elems_per_s') or 0, r['ntt'].get('coset_2p20_to_2p22_elems_per_s') or 0, r.get('msm_witness_like')))
+print('prove_seconds_k20_mlp', j.get('prove_seconds_k20_mlp')); print('others', j.get('prove_other_circuits'), 'skipped', j.get('prove_skipped'), 'errors', j.get('errors'))"
+      cp "$R/bench_full.json" "$O/${TAG}_bench_full.json" 2>/dev/null
+      tail -1 "$O/${TAG}_bench.log" ;;
     bench2)
       (cd "$R" && timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --share-device) > "$O/${TAG}_bench2.log" 2>&1
       grep '^{"metric' "$O/${TAG}_bench2.log" | cut -c1-600 ;;
