@@ -47,7 +47,7 @@ static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
 static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workgroup stages in LDS (104 KiB): 1024 scalars x 13 windows
 static constexpr uint32_t MSM_BINSORT_STAGE = 15360;  // payloads a sort workgroup stages in LDS (60 KiB): 2 workgroups per CU
-static constexpr uint32_t MSM_HEAVY_CHUNK = 1024;    // lane partials folded by one workgroup in the first heavy pass
+static constexpr uint32_t MSM_HEAVY_CHUNK = 256;     // lane partials folded by one WAVE in the first heavy pass (four serial additions per lane + the wave tree)
 static constexpr uint32_t MSM_DIGIT_E = 8;          // serial elements per lane in the first reduce stage
 static constexpr uint32_t MSM_LMIN = 8;             // shortest lane of the accumulate kernel
 static constexpr uint32_t MSM_MAX_BIG = 64;         // oversized partitions sorted by several workgroups each (the rest: one workgroup)
@@ -788,40 +788,44 @@ __global__ __launch_bounds__(256) void msm_fixup_boundary_tree_kernel(const uint
     st_g1x29(buckets + b, acc);
 }
 // Heavily skewed buckets (thousands of equal witness values -- a constant column is ONE bucket cut by every lane boundary).
-// Pass 1: one workgroup per chunk of MSM_HEAVY_CHUNK lane partials folds head[start .. start + chunk) into head[start].
-// Pass 2: one workgroup per heavy bucket folds tail[t1] and the chunk sums.  A 2^20-point column of one repeated value
-// (196 k lane partials) is 192 chunk sums: two short passes instead of one workgroup walking 768 partials per thread.
+// Pass 1: one WAVE per chunk of MSM_HEAVY_CHUNK lane partials folds head[start .. start + chunk) into head[start] -- or, for a bucket of one
+// chunk (almost all of them: the medium buckets of a witness column, 17-256 partials), finishes the bucket, tail included.
+// Pass 2: one workgroup per bucket of SEVERAL chunks folds tail[t1] and the chunk sums.
+// (Until round 6 a chunk was 1024 partials folded by a whole 256-thread workgroup, one per CU at this kernel's register count: a witness
+// column's hundreds of medium buckets queued behind each other, 62-229 us per advice column and 8.5 ms of a k = 20 MLP proof's kernel time
+// (profiles/r05au_msm_columns_serial.txt, r05az_timeline.txt).  A wave needs no LDS and no barrier, four chunks run per workgroup, and the
+// tree is the cooperative wave sum alone.)
 __global__ __launch_bounds__(256) void msm_fixup_heavy1_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const uint32_t* lane_first, g1x29_t* head,
                                                                const g1x29_t* tail, g1x29_t* buckets, const uint32_t* chunk_list, const uint32_t* counts, uint32_t lmin,
                                                                uint32_t coop, size_t bstride) {
     BOFF(); BSH(offsets); BSH(lane_first); BSH(head); BSH(tail); BSH(buckets); BSH(chunk_list); BSH(counts);
-    __shared__ uint4 sh[9 * 4];
     const uint32_t nchunks = counts[1], L = msm_lane_len(offsets, nb, nlanes, lmin);
-    for (uint32_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t ci = blockIdx.x * 4u + wave; ci < nchunks; ci += gridDim.x * 4u) {           // wave-uniform
         const uint32_t start = chunk_list[ci], b = lane_first[start];
         const uint32_t t2 = (offsets[b + 1] - 1) / L;
         const uint32_t stop = start + MSM_HEAVY_CHUNK - 1 < t2 ? start + MSM_HEAVY_CHUNK - 1 : t2;
         const uint32_t t1 = offsets[b] / L;
         const bool whole = t2 - t1 <= MSM_HEAVY_CHUNK;                     // the bucket's only chunk (start == t1 + 1): finished here, tail included
-        // the tail enters as the LAST thread's first operand (that thread has the fewest partials of the chunk): no addition after the tree
-        g1x29_t acc = (whole && threadIdx.x == 255) ? ld_g1x29(tail + t1) : g1x29_identity();
-        for (uint32_t t = start + threadIdx.x; t <= stop; t += 256) acc = g1x29_add(acc, ld_g1x29(head + t));
-        acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);   // ends with a workgroup barrier: every read of head[start..stop] is done
-        if (threadIdx.x == 0) st_g1x29(whole ? buckets + b : head + start, acc);
+        // the tail enters as the LAST lane's first operand (that lane has the fewest partials of the chunk): no addition after the tree
+        g1x29_t acc = (whole && lane == 63u) ? ld_g1x29(tail + t1) : g1x29_identity();
+        for (uint32_t t = start + lane; t <= stop; t += 64) acc = g1x29_add(acc, ld_g1x29(head + t));
+        acc = coop ? g1x29_group_sum_coop(acc, 64) : g1x29_group_sum(acc, 64);   // every lane's reads of head[start..stop] precede the sum it feeds
+        if (lane == 0) st_g1x29(whole ? buckets + b : head + start, acc);
     }
 }
 __global__ __launch_bounds__(256) void msm_fixup_heavy2_kernel(const uint32_t* offsets, uint32_t nb, uint32_t nlanes, const g1x29_t* head, const g1x29_t* tail,
                                                                const uint32_t* heavy_list, const uint32_t* counts, g1x29_t* buckets, uint32_t lmin, uint32_t coop, size_t bstride) {
     BOFF(); BSH(offsets); BSH(head); BSH(tail); BSH(heavy_list); BSH(counts); BSH(buckets);
-    __shared__ uint4 sh[9 * 4];
     const uint32_t L = msm_lane_len(offsets, nb, nlanes, lmin);
-    for (uint32_t h = blockIdx.x; h < counts[0]; h += gridDim.x) {
-        uint32_t b = heavy_list[h];
-        uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
-        g1x29_t acc = threadIdx.x == 0 ? ld_g1x29(tail + t1) : g1x29_identity();
-        for (uint32_t t = t1 + 1 + threadIdx.x * MSM_HEAVY_CHUNK; t <= t2; t += 256 * MSM_HEAVY_CHUNK) acc = g1x29_add(acc, ld_g1x29(head + t));
-        acc = coop ? g1x29_block256_sum_coop(acc, sh) : g1x29_block256_sum(acc, sh);
-        if (threadIdx.x == 0) st_g1x29(buckets + b, acc);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t h = blockIdx.x * 4u + wave; h < counts[0]; h += gridDim.x * 4u) {            // one WAVE per bucket of several chunks (wave-uniform)
+        const uint32_t b = heavy_list[h];
+        const uint32_t t1 = offsets[b] / L, t2 = (offsets[b + 1] - 1) / L;
+        g1x29_t acc = lane == 63u ? ld_g1x29(tail + t1) : g1x29_identity();
+        for (uint32_t t = t1 + 1 + lane * MSM_HEAVY_CHUNK; t <= t2; t += 64 * MSM_HEAVY_CHUNK) acc = g1x29_add(acc, ld_g1x29(head + t));
+        acc = coop ? g1x29_group_sum_coop(acc, 64) : g1x29_group_sum(acc, 64);
+        if (lane == 0) st_g1x29(buckets + b, acc);
     }
 }
 
@@ -1182,9 +1186,11 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     }
     {
         size_t max_heavy = nlanes / span_heavy + 1;
-        unsigned hb = (unsigned)(max_heavy < (size_t)c->num_cus * 4 ? max_heavy : (size_t)c->num_cus * 4);
+        const size_t heavy_wgs = (max_heavy + 3) / 4;                           // four buckets (waves) per workgroup
+        unsigned hb = (unsigned)(heavy_wgs < (size_t)c->num_cus * 4 ? heavy_wgs : (size_t)c->num_cus * 4);
         size_t max_chunks = nlanes / MSM_HEAVY_CHUNK + max_heavy;
-        unsigned cb = (unsigned)(max_chunks < (size_t)c->num_cus * 4 ? max_chunks : (size_t)c->num_cus * 4);
+        const size_t chunk_wgs = (max_chunks + 3) / 4;                         // four chunks (waves) per workgroup
+        unsigned cb = (unsigned)(chunk_wgs < (size_t)c->num_cus * 4 ? chunk_wgs : (size_t)c->num_cus * 4);
         hipLaunchKernelGGL(msm_fixup_heavy1_kernel, dim3(cb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, lfirst, head, tail, bkt, chunks, hcnt, lmin, coop & 4u, bstride);
         hipLaunchKernelGGL(msm_fixup_heavy2_kernel, dim3(hb, 1, Z), dim3(256), 0, st, offs, nb, nlanes, head, tail, heavy, hcnt, bkt, lmin, coop & 4u, bstride);
     }
