@@ -374,7 +374,7 @@ static uint32_t ntt_max_radix() {
     static const uint32_t v = [] {
         const char* e = getenv("EZKL_NTT_MAXR");
         const int x = e ? atoi(e) : 0;
-        return (uint32_t)(x >= 6 && x <= 10 ? x : 8);
+        return (uint32_t)(x >= 6 && x <= 11 ? x : 8);
     }();
     return v;
 }
@@ -393,7 +393,9 @@ static void plan_radices(uint32_t log_n, NttPlan* p) {
     for (int i = 0; i < np; i++) p->log_radix[i] = base + ((uint32_t)i < extra ? 1 : 0);
 }
 // tile of a multi-pass plan's pass of radix 2^r: at least 1024 elements, 4 columns
-static uint32_t pass_log_tile(uint32_t log_r) { return log_r + 2 > NTT_LOG_TILE ? log_r + 2 : NTT_LOG_TILE; }
+// (radix 2^11 -- EZKL_NTT_MAXR=11, a 2^22 transform in TWO passes -- keeps the 72 KiB tile of the single-pass transforms: ONE column per tile,
+//  32-byte row segments; measured in round 6, profiles/r06j_ntt_maxr.log)
+static uint32_t pass_log_tile(uint32_t log_r) { return log_r >= 11 ? log_r : (log_r + 2 > NTT_LOG_TILE ? log_r + 2 : NTT_LOG_TILE); }
 static void launch_pass(const PassArgs& a, uint32_t tiles, unsigned blocks_y, size_t lds, hipStream_t st) {
     if (a.npass > 1 && a.log_tile == 12) hipLaunchKernelGGL(ntt_pass_kernel<1024>, dim3(tiles, blocks_y), dim3(1024), lds, st, a);
     else if (a.npass > 1 && a.log_tile == 11) hipLaunchKernelGGL(ntt_pass_kernel<512>, dim3(tiles, blocks_y), dim3(512), lds, st, a);
