@@ -409,7 +409,7 @@ def main():
         # launch / the launch's HIP-event time measured in THIS run; `traffic` = PMC bytes per launch of the same kernel inside a proof
         # (tools/pmc_prove.sh: counters need their own rocprofv3 passes, so the tracked reduction is reported with its source)
         pk_, pm_ = {}, None
-        ppath = os.path.join(ROOT, "profiles", "r05_pmc_prove.json")
+        ppath = os.path.join(ROOT, "profiles", "r06_pmc_prove.json")
         if os.path.exists(ppath):
             try:
                 pm_ = json.load(open(ppath))
