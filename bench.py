@@ -350,7 +350,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": acc_avg_ms,
-                         "note": "integer-VALU bound, not HBM bound: see roofline.product_peak (DESIGN.md §roofline)",
+                         "note": "integer-VALU bound, not HBM bound: see roofline.product_peak (NOTEBOOK.md §roofline)",
                          # the other half of BASELINE.json's metric, where the driver's record keeps it: the 2^22-point NTT of the second timed region
                          "ntt": {"metric": "BN254 Fr NTT elems/s (2^22 points per GPU)", "elems_per_s": world * n_ntt * args.steps / t_ntt,
                                  "ms_per_step": t_ntt / args.steps * 1e3, "device_ms_per_transform": float(np.mean(ntt_ms)), "launches_per_transform": 3,
@@ -447,7 +447,7 @@ def main():
             rks.append(rk("evalh_jit", "quotient sweep of the k = 20 MLP key: one coset of 2^20 rows, %d columns read + 1 written (32 B each)" % sk["columns"],
                           sk["algorithmic_bytes_per_launch"], sk["avg_launch_ms"], (pm_ or {}).get("evalh_jit_sweep", {}).get("bytes_per_launch_mean"),
                           {"products_per_launch": sk.get("products_per_launch"), "products_per_row": sk.get("products_per_row")}))
-        # W = 13 signed-digit windows: n W mixed XYZZ additions of 8M + 2S = 10 products each
+        # W = 13 signed-digit windows (NOTEBOOK.md §4.1): n W mixed XYZZ additions of 8M + 2S = 10 products each
         rks.append(rk("msm_accumulate_kernel", "2^20-point MSM of the timed region (96 B per point)", MSM_BYTES_PER_POINT * n_msm, acc_avg_ms, traffic,
                       {"products_per_launch": 13 * n_msm * 10}))
         out["roofline_kernels"] = rks

@@ -132,7 +132,7 @@ def write_pk(pk):
 
 class ProvingKeyDevice:
     """Device-resident image of the pk columns evaluate_h reads: l0 / l_last / l_active_row, fixed and permutation
-    polynomials and their extended cosets, one HBM column each (field-SoA)."""
+    polynomials and their extended cosets, one HBM column each (field-SoA, NOTEBOOK.md §3)."""
 
     def __init__(self, pk):
         self.k = pk["vk"]["k"]

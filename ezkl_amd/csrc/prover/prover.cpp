@@ -1403,7 +1403,7 @@ static std::unique_ptr<ProvingKey> pk_read_file(ConstraintSystem& cs, const char
     // File -> HBM as a pipeline: a few reader threads pread their sections into page-locked buffers (one copy out of the page cache,
     // no page fault per 4 KiB as through the mapping) and check them (canonical residues: the top limb decides all but 2^-60 of the
     // cases), this thread uploads each buffer as it fills (PCIe at the pinned rate).  Measured on the k = 20 MLP key (34 sections of
-    // 32 MiB inside a 7.8 GB file): DESIGN.md §4.7.
+    // 32 MiB inside a 7.8 GB file): NOTEBOOK.md §4.7.
     {
         const size_t bytes = 32 * n, N = sections.size();
         for (auto& sec : sections) (void)posix_fadvise(fd, (off_t)sec.off, (off_t)bytes, POSIX_FADV_WILLNEED);   // a key not in the page cache: read ahead
@@ -2241,7 +2241,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     // z CAN be committed while the lookup arguments' helper chains (inversions, scans) run: EZKL_PROVER_MERGED_COMMITS=1.  Built and
     // measured (k = 20 MLP, 8 proofs each): 84.3-86.5 ms merged against 83.1-84.8 ms one phase after the other, same bytes -- the z MSMs
     // and the helper chains compete for the same integer ALUs (the auxiliary stream's NTTs already fill what the MSM tails leave), so
-    // the default stays one phase after the other
+    // the default stays one phase after the other (NOTEBOOK.md §4.1.2)
     const char* merged_env = getenv("EZKL_PROVER_MERGED_COMMITS");
     const bool merged_commit = merged_env && *merged_env == '1' && !cs.shard.on() && nl > 0 && !cs.perm.empty();
     Backend::OpenCommit zphi;

@@ -11,7 +11,7 @@ Compatibility with the zkonduit halo2 fork (its source is not on disk): the proo
 reference's proofs (points 64 B BE, scalars 32 B BE), and the protocol is pinned on the one executable piece of halo2 the reference
 ships -- the compiled Solidity verifier tests/assets/wasm.code: with its verifying-key constants replaced by this key's, the
 reference's bytecode derives the same eight challenges, evaluates the same 200 quotient terms and ACCEPTS the proofs written here
-(tests/test_evm_verifier.py).  What stays unpinned is the 32-byte vk digest (halo2 hashes the Debug text of its
+(tests/test_evm_verifier.py; NOTEBOOK.md §2.1).  What stays unpinned is the 32-byte vk digest (halo2 hashes the Debug text of its
 constraint system); this module binds keccak256 of the serialised constraint system + the commitments in its place.
 
 Covered: custom gates, the permutation argument (chunked), mv-lookup (logUp) arguments with theta-compressed tuples,

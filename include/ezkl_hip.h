@@ -57,7 +57,7 @@ extern "C" {
  *   EZKL_HIP_TIMING           all     all | kernel | none: which HIP event pairs a timed call records (ezkl_hip_kernel_ms_stats)
  *   EZKL_MSM_HOST_TIMING, EZKL_PROVER_KEYGEN_TIMING     host-side stage times on stderr
  *   EZKL_HIP_DEBUG, EZKL_MSM_DEBUG, EZKL_HIP_JIT_DEBUG, EZKL_HIP_JIT_DUMP=<file>     diagnostics on stderr / the generated sweep source
- *  tuning knobs whose defaults are the measured optimum (tools/ab.sh sweeps them)
+ *  tuning knobs whose defaults are the measured optimum (NOTEBOOK.md §4; tools/ab.sh sweeps them)
  *   EZKL_MSM_SLOTS 4 | EZKL_MSM_GROUP / _SMALL 6 / _BIG 4 | EZKL_MSM_L (device-chosen) | EZKL_MSM_LMIN 8 | EZKL_MSM_SPAN 16 | EZKL_MSM_E 8
  *   EZKL_NTT_MAXR 8 (9 / 10: 2048- / 4096-element tiles) | EZKL_PROVER_SWEEP_TERMS 0 | EZKL_PROVER_SWEEP_INSTRS 640
  *  comparison switches kept because tests or the multi-rank fallbacks use them

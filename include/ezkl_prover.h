@@ -16,7 +16,7 @@
  * is the one the reference's own generated EVM verifier checks: tests/test_evm_verifier.py runs that bytecode
  * (/root/reference/tests/assets/wasm.code) with its verifying-key constants replaced by this library's key and it accepts the proofs
  * ezkl_prover_create_proof writes on the GPU -- same challenges, same quotient terms, same SHPLONK (halo2's query order, first-set
- * normalisation), real pairing.  Not pinnable: halo2's vk digest (a hash of Debug text); the 32-byte digest here
+ * normalisation), real pairing (NOTEBOOK.md §2.1).  Not pinnable: halo2's vk digest (a hash of Debug text); the 32-byte digest here
  * binds the serialised constraint system + the commitments.  The bytes are identical to those of the Python restatement
  * ezkl_amd/plonk.py under the same randomness (tests/test_native_prover.py).
  */

@@ -95,7 +95,7 @@ def _run(mode, world, circuit, k):
 
 @pytest.mark.parametrize("world,circuit,k", [(2, "mlp", 9), (4, "mlp", 10), (2, "fixture", 6)])
 def test_group_of_contexts_on_one_device_same_bytes(hip, world, circuit, k):
-    """(k = 20 with 2 and 4 contexts: tools/prove_group.py, DESIGN.md §5.2 -- too slow for the suite)"""
+    """(k = 20 with 2 and 4 contexts: tools/prove_group.py, NOTEBOOK.md §5.2 -- too slow for the suite)"""
     j = _run("same-device", world, circuit, k)
     assert j["world"] == world and j["contexts"] == world
     assert j["same_bytes"] and j["repeatable"] and j["verifier_accepts"] and j["fresh_randomness_differs"] and j["fresh_verifies"]

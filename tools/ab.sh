@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab.sh <experiment> -- the A/B experiments of round 4 behind DESIGN.md §4.1.3 / §4.3 (one script, one `run` helper; each line of
+# tools/ab.sh <experiment> -- the A/B experiments of round 4 behind NOTEBOOK.md §4.1.3 / §4.3 (one script, one `run` helper; each line of
 # output is one setting: best proof times of REPS proofs, the stage times of the best one, the proof hash -- identical everywhere).
 #   bash tools/run.sh <tag> ab:<experiment>     on the GPU box; the log lands in gpurun_out/<tag>_ab_<experiment>.log
 # experiments: group (fused-group sizes, k = 20 MLP) | circuits (general-scalar groups across the bench circuits) | hwq (hardware queues)

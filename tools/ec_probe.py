@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Latency probes for chains of dependent point additions (ezkl_hip_ubench "ecadd<iters><mode>"):
+"""Latency probes for chains of dependent point additions (ezkl_hip_ubench "ecadd<iters><mode>"; NOTEBOOK.md §4.1):
 w = one wave, q = one wave per CU, h = one wave per SIMD, f = four waves per SIMD; t/u/v/x = tree variants that separate the
 cost of lane exchange from the cost of a partial EXEC mask (the finding: masked-off lanes make the chain 2.3x slower)."""
 import os, sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-to-device copy rates seen through the C ABI: blocking copies from pageable / page-locked memory into pooled blocks,
-with and without a device synchronisation before each copy (PCIe note)."""
+with and without a device synchronisation before each copy (NOTEBOOK.md §6, PCIe note)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

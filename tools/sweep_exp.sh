@@ -1,4 +1,4 @@
-# quotient-sweep JIT code-generation experiment: EZKL_EVALH_{NO_SCHEDULE,WAVES,BARRIER,R29} on the MLP circuit
+# quotient-sweep JIT code-generation experiment (NOTEBOOK.md §4.3): EZKL_EVALH_{NO_SCHEDULE,WAVES,BARRIER,R29} on the MLP circuit
 #   CFGS='A=1,B=2 C=3' bash tools/sweep_exp.sh   (configurations separated by spaces, assignments inside one by commas)
 export EZKL_HIP_CACHE_DIR=off
 for cfg in ${CFGS:-X=1}; do

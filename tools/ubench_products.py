@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""VERDICT r03 item 3 -- "a faster field product": the measured table behind DESIGN.md §4.0.
+"""VERDICT r03 item 3 -- "a faster field product": the measured table behind NOTEBOOK.md §4.0.
 
   * issue probes (8 independent chains per lane, 4096 iterations): v_mad_u64_u32, v_fma_f64, the two interleaved 4 + 4 (co-issue would
     show as more lane-ops/s than either alone), v_lshl_add_u64 (one-instruction 64-bit add), v_add_f64;
