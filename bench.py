@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true", help="only the two timed regions of the contract (uniform 2^20 MSM, 2^22 NTT): no two-in-flight, "
+                    "witness-like, inverse / coset legs -- what tools/profile_bench.sh profiles, so that rocprofv3's per-kernel averages are those of the headline")
     ap.add_argument("--with-batch", action="store_true", help="also time the pipelined 4-column batch commit (extra.msm_batch4_*)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for 1-GPU plumbing tests)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
@@ -163,7 +165,7 @@ def main():
     # commit phases do with their batches).  Reported beside the headline (roofline.msm_two_in_flight), never as `value`: the headline stays
     # the synchronous step of rounds 1-4.  Single rank only (with N ranks every step ends in the fold's collective).
     t_msm2 = None
-    if world == 1:
+    if world == 1 and not args.no_side_legs:
         try:
             tok = B.msm_g1_start_dev(bases, scalars.ptr, n_msm)
             for _ in range(3):
@@ -190,7 +192,7 @@ def main():
     # columns a prover commits look like.  The same K synchronous steps over the same bases; reported beside the headline
     # (roofline.msm_witness_like), checked against the oracle in the cpu_baseline leg.  Single rank only, like the leg above.
     w_leg = None
-    if world == 1:
+    if world == 1 and not args.no_side_legs:
         try:
             scalars_w = B.DeviceBuffer.from_numpy(witness_like_fr(np.random.default_rng(SEED + 17), n_msm))
             for _ in range(max(3, args.warmup)):
@@ -242,8 +244,10 @@ def main():
 
     # the other two forms BASELINE.md §3 names, on the GPU as on the CPU (cpu_baseline.ntt): the inverse transform (lagrange_to_coeff: omega^-1 and
     # the 1/n scale) and the prover's coset form (coeff_to_extended: 2^20 coefficients, zeta twist, zero-extended to 2^22), queued the same way
-    ntt_forms = {}
+    ntt_forms, was_async = {}, None
     try:
+        if args.no_side_legs:
+            raise StopIteration
         was_async = B.set_async(True)
         os.environ["EZKL_HIP_TIMING"] = "none"
         def timed(f):
@@ -259,11 +263,14 @@ def main():
         cos_out = B.DeviceBuffer(n_ntt * 32)
         ntt_forms["coset_2p20_to_2p22_elems_per_s"] = world * n_ntt / timed(lambda: B.coset_ntt_dev(col.ptr, cos_out.ptr, 20, 22))
         cos_out.free()
+    except StopIteration:
+        pass
     except Exception as e:
         errors.append("inverse / coset NTT legs failed: %r" % (e,))
     finally:
         os.environ.pop("EZKL_HIP_TIMING", None)
-        B.set_async(was_async)
+        if was_async is not None:
+            B.set_async(was_async)
 
     # batched commit (one prover phase: 4 independent 2^20-point columns per call, pipelined over streams)
     # (kept out of the default run so that rocprofv3's per-kernel averages of `python bench.py` are those of the
