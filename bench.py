@@ -80,10 +80,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if rank != 0:
-        # stdout belongs to rank 0's ONE line: whatever the libraries of the other ranks print at C level (RCCL's banner, gloo's
-        # connection notes) goes to stderr instead of sharing the pipe the driver parses
-        os.dup2(2, 1)
+    # stdout belongs to rank 0's ONE line and to nothing else.  Libraries print at C level into the same pipe (RCCL's five-line banner is
+    # buffered by stdio and comes out at process exit, i.e. AFTER the line; gloo notes its connections): file descriptor 1 of every rank is
+    # pointed at stderr for the whole run, and rank 0 writes its line to the ORIGINAL stdout at the very end (emit)
+    global _LINE_FD
+    sys.stdout.flush()
+    if rank == 0:
+        _LINE_FD = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if args.share_device:
         local_rank = 0
@@ -470,6 +474,7 @@ def main():
         dist.destroy_process_group()
 
 
+_LINE_FD = None          # rank 0: the process's original stdout (main points fd 1 at stderr for everything else)
 LINE_LIMIT = 6000        # the driver's record keeps the last 8 000 characters of stdout: the ONE line must fit with room to spare (round 5's 20 KB line was lost)
 
 
@@ -565,7 +570,11 @@ def emit(full):
                 json.dump(full, f, indent=1)
         except OSError as e:
             print("bench: could not write %s: %r" % (path, e), file=sys.stderr)
-    print(compact_line(full), flush=True)
+    line = compact_line(full)
+    if _LINE_FD is not None:
+        os.write(_LINE_FD, (line + "\n").encode())
+    else:
+        print(line, flush=True)
 
 
 def strong_scaling(world, rank, dist, dev, B, D, torch, args, barrier_sync):
