@@ -527,8 +527,9 @@ def compact_line(full):
         m = g(pr, "n_gpus", "sharding", "rccl_ranks_seen", "prove_seconds_gpu", "all_ranks_same_proof", "verifier_accepts", "exchange_ms_per_proof_max", "error")
         c_ = pr.get("circuit")
         m["circuit"] = str((c_.get("circuit") if isinstance(c_, dict) else c_) or "")[:60]
-        if isinstance(pr.get("mlp_k20"), dict):
-            m["mlp_k20"] = g(pr["mlp_k20"], "prove_seconds_gpu", "all_ranks_same_proof", "verifier_accepts", "rccl_ranks_seen", "error")
+        for sub in ("mlp_k20", "transformer_k22"):
+            if isinstance(pr.get(sub), dict):
+                m[sub] = g(pr[sub], "prove_seconds_gpu", "all_ranks_same_proof", "verifier_accepts", "rccl_ranks_seen", "exchange_ms_per_proof_max", "error")
         line["prove_multi"] = m
     else:
         brief = lambda d: g(d, "prove_seconds_gpu", "prove_seconds_cpu", "proofs_identical_gpu_cpu", "verifier_accepts", "hbm_in_use_gib_after_prove",
@@ -747,6 +748,15 @@ def prove_leg_multi(world, rank, local_rank, args):
         m = _prove_multi_one(world, rank, local_rank, args, "mlp", "20", 2)
         if rank == 0 and out is not None:
             out["mlp_k20"] = m
+        ok = _all_ranks_agree(world, rank, m is not None and "error" not in m)
+    # ... and BASELINE configs[4]: "k = 22, SRS 2^22, 8 x MI355X with NTT + MSM both sharded" -- the transformer-shaped surrogate (every rank
+    # builds the same tiled circuit in ~10 s; degree 6: eight cosets of the extended domain 2^25, one per rank at N = 8; every witness column
+    # transformed and committed by its owner, the key's cosets by owner).  EZKL_BENCH_MULTI_K22=<k> picks another size (the one-device tests), 0 skips.
+    k22 = os.environ.get("EZKL_BENCH_MULTI_K22", "22")
+    if ok and circuit == "einsum" and k22 != "0":
+        t_ = _prove_multi_one(world, rank, local_rank, args, "transformer", k22, 3)
+        if rank == 0 and out is not None:
+            out["transformer_k22"] = t_
     return out
 
 
@@ -780,7 +790,7 @@ def _prove_multi_one(world, rank, local_rank, args, circuit, k, port_offset):
     if os.environ.get("EZKL_BENCH_MULTI_MODE") == "replicated":
         cmd.append("--replicated")
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300" if circuit != "mlp" else "600")))  # the MLP may have to be laid out first
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=int(os.environ.get("EZKL_BENCH_PROVE_TIMEOUT", "300" if circuit == "einsum" else "600")))  # the MLP may have to be laid out first; the k = 22 surrogate is built and keyed per rank
         if rank != 0:
             return None
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

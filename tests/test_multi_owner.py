@@ -1,7 +1,9 @@
 """SURVEY.md §8(e) in the C++ host prover: columns and arguments BY OWNER (include/ezkl_prover.h "multi-GPU, the full form").  N ranks
 sharing the one GPU of the test box, gloo moving the data through the prover's exchange callbacks, must emit the bytes of the one-rank
 proof -- on the reference's fixture circuit (35 lookups, 32 permutation columns, 8 cosets), on an MLP over the ezkl gate set (4 cosets)
-and on the reference's einsum bench circuit (second-phase advice; 2 cosets, so 4 ranks sweep ROW RANGES of a coset with halo rows)."""
+and on the reference's einsum bench circuit (second-phase advice; 2 cosets, so 4 ranks sweep ROW RANGES of a coset with halo rows), and on
+the transformer-shaped surrogate of configs[4] (static + dynamic lookups, a shuffle, Freivalds einsum with second-phase advice, an instance
+column; degree 6: 8 cosets) -- the circuit `bench.py --gpus N` proves at k = 22 with NTTs and MSMs both sharded."""
 import json
 import os
 import subprocess
@@ -27,7 +29,7 @@ def _run(env, world, port, extra=()):
     return objs[-1]
 
 
-@pytest.mark.parametrize("circuit,k", [("fixture", 6), ("mlp", 10), ("einsum", 10)])
+@pytest.mark.parametrize("circuit,k", [("fixture", 6), ("mlp", 10), ("einsum", 10), ("transformer", 11)])
 def test_owner_sharded_native_prover_same_bytes(hip, circuit, k):
     env = {"CIRCUIT": circuit, "K": str(k), "MLP_BASE": "128"}     # small range-check tables: 16 lookups instead of the default base's 137 at k = 10
     one = _run(env, 1, 0)

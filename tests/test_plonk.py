@@ -395,7 +395,7 @@ def test_bench_contract_two_ranks(hip, tmp_path):
     verifier (its details in the full record, bench_full.json)"""
     import json, os, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="200", EZKL_BENCH_MULTI_MLP20="0", EZKL_BENCH_FULL=str(tmp_path / "full.json"))
+    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="200", EZKL_BENCH_MULTI_MLP20="0", EZKL_BENCH_MULTI_K22="11", EZKL_BENCH_FULL=str(tmp_path / "full.json"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--backend", "gloo", "--share-device"], env=env, capture_output=True, text=True, timeout=900)
@@ -412,6 +412,8 @@ def test_bench_contract_two_ranks(hip, tmp_path):
     assert r.stdout.count("\n") == 1 and r.stdout.startswith("{") and len(r.stdout) < 6000, r.stdout[:300]
     assert "rccl_ranks_seen" in j and j["prove_multi"]["verifier_accepts"] is True and j["prove_multi"]["n_gpus"] == 2
     assert j["prove_multi"]["all_ranks_same_proof"] is True and j["prove_multi"]["prove_seconds_gpu"] > 0
+    t22 = j["prove_multi"]["transformer_k22"]               # configs[4]'s surrogate, here at k = 11 (two ranks share the device)
+    assert t22["all_ranks_same_proof"] is True and t22["verifier_accepts"] is True and t22["prove_seconds_gpu"] > 0
     full = json.load(open(tmp_path / "full.json"))
     assert full["value"] == pytest.approx(j["value"], rel=1e-4)
     assert full["prove"]["sharded_sweeps"] >= 2 and "accum_einsum_matmul" in full["prove"]["circuit"]["circuit"]
@@ -428,7 +430,8 @@ def test_bench_contract_eight_and_three_ranks_on_one_device(hip, world, tmp_path
     proof on every rank"""
     import json, os, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="300", EZKL_BENCH_MULTI_MLP20="0", EZKL_BENCH_MULTI_K="14", EZKL_BENCH_FULL=str(tmp_path / "full.json"))
+    env = dict(os.environ, EZKL_BENCH_PROVE_TIMEOUT="300", EZKL_BENCH_MULTI_MLP20="0", EZKL_BENCH_MULTI_K="14", EZKL_BENCH_MULTI_K22="0",
+               EZKL_BENCH_FULL=str(tmp_path / "full.json"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                         "--master-port", str(29570 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
                         "--backend", "gloo", "--share-device"], env=env, capture_output=True, text=True, timeout=900)
@@ -454,7 +457,7 @@ def test_bench_rank_failure_ends_the_job(hip):
     well inside the timeout, and no JSON line is printed (EZKL_BENCH_FAIL_RANK is the test hook in bench.py)"""
     import os, subprocess, sys, time
     from conftest import ROOT
-    env = dict(os.environ, EZKL_BENCH_FAIL_RANK="1")
+    env = dict(os.environ, EZKL_BENCH_FAIL_RANK="1", EZKL_BENCH_MULTI_K22="0")
     t0 = time.time()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29569", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
