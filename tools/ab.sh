@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 6: EZKL_MSM_COOP / ZEROCOPY / ORDER_ALWAYS / NO_TAPER / FIXUP_TREE and the compile-time EZKL_MSM_* / EZKL_NTT_* variants were removed from the
+#  sources after their measurements -- the experiments below that name them are history; their logs are in profiles/.)
 # tools/ab.sh <experiment> -- the A/B experiments of round 4 behind NOTEBOOK.md §4.1.3 / §4.3 (one script, one `run` helper; each line of
 # output is one setting: best proof times of REPS proofs, the stage times of the best one, the proof hash -- identical everywhere).
 #   bash tools/run.sh <tag> ab:<experiment>     on the GPU box; the log lands in gpurun_out/<tag>_ab_<experiment>.log
