@@ -482,6 +482,8 @@ def _r(x, sig=5):
     """floats to `sig` significant digits (the line is a record, not a checkpoint); containers recursively"""
     if isinstance(x, float):
         return float("%.*g" % (sig, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, str):
+        return x if len(x) <= 200 else x[:197] + "..."       # no string of a leg (an error text, a label) may grow the line
     if isinstance(x, dict):
         return {k: _r(v, sig) for k, v in x.items()}
     if isinstance(x, (list, tuple)):

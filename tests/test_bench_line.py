@@ -70,3 +70,25 @@ def test_emit_prints_one_line_and_keeps_the_full_record(tmp_path, capsys, monkey
     out = capsys.readouterr().out
     assert out.count("\n") == 1 and len(out) < bench.LINE_LIMIT
     assert json.load(open(tmp_path / "bench_full.json"))["prove"]["mlp_k20"]["prove_seconds_gpu"] == full["prove"]["mlp_k20"]["prove_seconds_gpu"]
+
+
+def test_multi_rank_line_carries_the_three_sharded_proofs():
+    """N > 1: configs[3] (einsum, MLP k = 20) and configs[4] (the transformer surrogate at k = 22) each with what a SCALE run is checked by --
+    seconds, same proof on every rank, verifier, rccl_ranks_seen -- and still a short line"""
+    full = _record("r05ax_bench_world8.json")
+    full["n_gpus"] = 8
+    sub = {"prove_seconds_gpu": 0.31, "all_ranks_same_proof": True, "verifier_accepts": True, "rccl_ranks_seen": 8, "exchange_ms_per_proof_max": 4.2,
+           "per_rank": [{"stats": {"x": "y" * 400}}] * 8}
+    full["prove"]["rccl_ranks_seen"] = 8
+    full["prove"]["mlp_k20"] = dict(sub)
+    full["prove"]["transformer_k22"] = dict(sub, prove_seconds_gpu=0.25)
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    assert line["rccl_ranks_seen"] == 8
+    pm = line["prove_multi"]
+    assert pm["mlp_k20"]["rccl_ranks_seen"] == 8 and pm["transformer_k22"]["prove_seconds_gpu"] == 0.25 and "per_rank" not in pm["transformer_k22"]
+    # a leg that failed shows its error, shortened
+    full["prove"]["transformer_k22"] = {"error": "z" * 3000}
+    line = json.loads(bench.compact_line(full))
+    assert len(line["prove_multi"]["transformer_k22"]["error"]) == 200 and len(bench.compact_line(full)) < bench.LINE_LIMIT
