@@ -620,38 +620,6 @@ struct Backend {
     std::vector<G1> commit_columns(ezkl_bases_t b, const std::vector<Col>& hs, bool small) const {
         return topo.owners ? commit_owned(b, hs, small) : commit_with(b, hs, small);
     }
-    // A commit batch fed as its columns become final (ezkl_hip_msm_batch_*): push() returns once the MSMs are queued behind the library
-    // stream, so the helper chain of the NEXT argument runs while they do.  One prover on one GPU only (no shard callbacks).
-    struct OpenCommit {
-        ezkl_msm_batch_t h = nullptr;
-        size_t count = 0;
-        std::vector<Col> keep;                     // the pushed columns, alive until the batch is finished
-        OpenCommit() = default;
-        OpenCommit(const OpenCommit&) = delete;
-        ~OpenCommit() {                            // unwinding: close the library's batch, whatever it holds
-            if (h) {
-                std::vector<G1> sink(count ? count : 1);
-                (void)ezkl_hip_msm_batch_finish(h, sink.data(), sink.size());
-            }
-        }
-    };
-    void commit_begin(OpenCommit& oc, ezkl_bases_t b) const { check(ezkl_hip_msm_batch_begin(b, 0, n, &oc.h), "ezkl_hip_msm_batch_begin"); }
-    void commit_push(OpenCommit& oc, const std::vector<Col>& hs) const {
-        std::vector<const void*> ptrs;
-        for (auto& c : hs) { ptrs.push_back(c->ptr()); oc.keep.push_back(c); }
-        if (ptrs.empty()) return;
-        check(ezkl_hip_msm_batch_push_many_dev(oc.h, ptrs.data(), ptrs.size()), "ezkl_hip_msm_batch_push_many_dev");
-        oc.count += ptrs.size();
-    }
-    std::vector<G1> commit_finish(OpenCommit& oc) const {
-        std::vector<G1> out(oc.count ? oc.count : 1);
-        ezkl_msm_batch_t h = oc.h;
-        oc.h = nullptr;
-        check(ezkl_hip_msm_batch_finish(h, out.data(), out.size()), "ezkl_hip_msm_batch_finish");
-        out.resize(oc.count);
-        oc.keep.clear();
-        return out;
-    }
     // owner mode: the commitment of the SUM over ranks of a per-rank partial polynomial (SHPLONK's h and L: linear in the polynomials
     // each rank owns).  A reduce-scatter by point ranges: rank r receives rows [r n / world, (r + 1) n / world) of every other rank's
     // partial through the exchange (one segment per peer and direction: 32 n / world bytes), adds them to its own, commits that slice
@@ -2237,14 +2205,9 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
     // 3. beta, gamma
     const Fe beta = T.squeeze_challenge(), gamma = T.squeeze_challenge();
     // 4. permutation grand products, chained across chunks: chunk j on its owner
-    // One prover on one GPU: the z and the phi depend on the same challenges and no challenge is drawn between their commitments, so the
-    // z CAN be committed while the lookup arguments' helper chains (inversions, scans) run: EZKL_PROVER_MERGED_COMMITS=1.  Built and
-    // measured (k = 20 MLP, 8 proofs each): 84.3-86.5 ms merged against 83.1-84.8 ms one phase after the other, same bytes -- the z MSMs
-    // and the helper chains compete for the same integer ALUs (the auxiliary stream's NTTs already fill what the MSM tails leave), so
-    // the default stays one phase after the other (NOTEBOOK.md §4.1.2)
-    const char* merged_env = getenv("EZKL_PROVER_MERGED_COMMITS");
-    const bool merged_commit = merged_env && *merged_env == '1' && !cs.shard.on() && nl > 0 && !cs.perm.empty();
-    Backend::OpenCommit zphi;
+    // (The z could be committed WHILE the lookup arguments' helper chains run -- no challenge is drawn between the two commit batches.  Built and
+    // measured in round 4: 84.3-86.5 ms merged against 83.1-84.8 ms one phase after the other on the k = 20 MLP, same bytes: the MSMs and the
+    // helper chains compete for the same integer ALUs.  The experiment is gone from the source; NOTEBOOK.md §4.1.2 has it.)
     std::vector<Col> zs;
     std::vector<Backend::Forms> z_forms;
     std::vector<int> z_owner;
@@ -2268,12 +2231,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
         for (size_t j = 0; j < zs.size(); j++)
             if (zs[j]) { z_forms[j] = be.forms_async(zs[j], cs.ext_k); cs.shard.stats[0]++; cs.shard.stats[3]++; }
-        if (merged_commit) {                       // queued now, collected after the lookup sums below have been computed next to them
-            be.commit_begin(zphi, gl);
-            be.commit_push(zphi, zs);
-        } else {
-            for (auto& p : be.commit_columns(gl, zs, false)) T.write_point(p);
-        }
+        for (auto& p : be.commit_columns(gl, zs, false)) T.write_point(p);
         cs.shard.stats[1] += zs.size();
     }
     sw.lap(2);
@@ -2296,12 +2254,7 @@ static std::vector<uint8_t> create_proof(ProvingKey& pk, ezkl_bases_t g, ezkl_ba
         }
         for (auto& st : lk)
             if (st.mine) { st.phi_forms = be.forms_async(st.phi, cs.ext_k); cs.shard.stats[0]++; }
-        if (merged_commit) {
-            be.commit_push(zphi, phis);
-            for (auto& p : be.commit_finish(zphi)) T.write_point(p);      // push order = transcript order: the z, then the phi
-        } else {
-            for (auto& p : be.commit_columns(gl, phis, false)) T.write_point(p);
-        }
+        for (auto& p : be.commit_columns(gl, phis, false)) T.write_point(p);
     }
     sw.lap(3);
     // 5. vanishing argument: random polynomial (every rank expands the same keystream: a replicated column);  6. y

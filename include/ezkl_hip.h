@@ -37,7 +37,7 @@ extern "C" {
 
 /* ---- environment: every variable libezkl_hip.so and libezkl_prover.so read, in ONE place (round 6: the A/B switches of rounds 3-5 --
  *      EZKL_MSM_PREFETCH / LEAN / FETCH_ALWAYS / UNPACK_FIRST / RESET_ZZ / COOP / ZEROCOPY / ORDER_ALWAYS / NO_TAPER / FIXUP_TREE /
- *      DEBUG_PLANES, EZKL_NTT_LOAD_ALWAYS / SKIP_UNIT2 -- are gone from the sources; their measurements are in profiles/).  All are read
+ *      DEBUG_PLANES, EZKL_NTT_LOAD_ALWAYS / SKIP_UNIT2, EZKL_PROVER_MERGED_COMMITS -- are gone from the sources; their measurements are in profiles/).  All are read
  *      in-process (getenv); unset = the default.  A fork exposes the first group, the rest is for whoever works on the library.
  *
  *  gate and modes (what a deployment sets)
@@ -63,7 +63,7 @@ extern "C" {
  *  comparison switches kept because tests or the multi-rank fallbacks use them
  *   EZKL_EVALH_MODE=interp (the sweep interpreter instead of the JIT kernel), EZKL_EVALH_NO_SCHEDULE, EZKL_COMM_UNPACKED=1 (one send / recv per
  *   segment), EZKL_COMM_SELF_VIA_RCCL=1 (world 1 through the wire format), EZKL_GATHER_HOST, EZKL_MSM_SERIAL_CALLS, EZKL_HIP_POOL_SYNC,
- *   EZKL_PROVER_SYNC_CALLS, EZKL_PROVER_MERGED_COMMITS=1, EZKL_PROVER_NO_EARLY_RANDOM, EZKL_PROVER_NO_SUM_SCATTER,
+ *   EZKL_PROVER_SYNC_CALLS, EZKL_PROVER_NO_EARLY_RANDOM, EZKL_PROVER_NO_SUM_SCATTER,
  *   EZKL_PROVER_ASSUME_FREE_GIB=<x> (test hook of the fit check) ---- */
 
 typedef struct ezkl_bases_s* ezkl_bases_t;     /* device-resident G1 base set (SRS g or g_lagrange) */
