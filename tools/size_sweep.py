@@ -35,3 +35,12 @@ for k in (12, 14, 16, 17, 18, 20, 22):
     print("k=%2d  msm single %.3f ms (%.2e pts/s)  batch %.3f ms (%.2e pts/s) | ntt single %.3f ms (%.2e el/s)  batch %.3f ms (%.2e el/s)"
           % (k, single * 1e3, n / single, batch * 1e3, n / batch, ntt1, n / ntt1 * 1e3, nttb, n / nttb * 1e3), flush=True)
     bases.free()
+# BASELINE.md §3's last NTT scaling point: 2^24 (four passes); no MSM at this size (the bench's base sets stop at 2^22)
+k = 24
+n = 1 << k
+d = ezkl_amd.EvaluationDomain(2, k)
+col = B.DeviceBuffer.from_numpy(rand(n))
+for _ in range(5):
+    B.ntt_dev(col.ptr, k, d.omega)
+t = B.last_kernel_ms("ntt")
+print("k=24  ntt single %.3f ms (%.2e el/s)" % (t, n / t * 1e3), flush=True)
