@@ -43,7 +43,7 @@ namespace ezkl {
 // (The compile-time variants of rounds 4-5 -- the loop without the one-iteration-ahead loads, the fused "lean" chain, unpack-first, the full
 // accumulator reset, conditional gathers -- were measured and removed; their A/B logs are profiles/r05q_msm_ab.log, r05y_msm_ab.log and
 // DESIGN.md §4.1.  What is here is the one shipped form.)
-static constexpr uint32_t MSM_MAX_PART_BITS = 10;   // <= 1024 partitions in the first sorting pass
+static constexpr uint32_t MSM_MAX_PART_BITS = 12;   // <= 4096 partitions in the first sorting pass (1024 up to 2^20 points: msm_part_bits)
 static constexpr uint32_t MSM_SPAN_HEAVY = 16;      // buckets cut by more lane boundaries than this are folded by a whole workgroup
 static constexpr uint32_t MSM_PART_STAGE = 13312;     // pairs a partition workgroup stages in LDS (104 KiB): 1024 scalars x 13 windows
 static constexpr uint32_t MSM_BINSORT_STAGE = 15360;  // payloads a sort workgroup stages in LDS (60 KiB): 2 workgroups per CU
@@ -381,29 +381,39 @@ __global__ __launch_bounds__(1024) void msm_hist_scan_kernel(uint32_t* wg_hist, 
         }
     }
 }
-// exclusive scan of <= 2048 partition counts (two per thread); part_base[NQ] = the number of pairs.  Also lists the oversized
+// exclusive scan of <= 5120 partition counts (five per thread); part_base[NQ] = the number of pairs.  Also lists the oversized
 // ordinary partitions (big_flag[p] = 1 + slot, big_list[slot] = p, big_count[0] = how many asked for a slot).
 __device__ __forceinline__ void msm_part_scan_body(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
                                                    uint32_t* big_list, uint32_t* big_count, uint32_t* sh) {
     const uint32_t t = threadIdx.x;
-    auto ldc = [&](uint32_t i) { return part_count[i]; };
-    const uint32_t v0 = 2 * t < NQ ? ldc(2 * t) : 0, v1 = 2 * t + 1 < NQ ? ldc(2 * t + 1) : 0;
+    constexpr uint32_t PER = 5;                                          // 5 x 1024 threads >= 4097 partitions
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t i = PER * t + q;
+        v[q] = i < NQ ? part_count[i] : 0;
+        sum += v[q];
+    }
     uint32_t total;
-    const uint32_t incl = msm_block_scan(v0 + v1, sh, total);
-    const uint32_t excl = incl - v0 - v1;
-    if (2 * t < NQ) part_base[2 * t] = excl;
-    if (2 * t + 1 < NQ) part_base[2 * t + 1] = excl + v0;
+    uint32_t run = msm_block_scan(sum, sh, total) - sum;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t i = PER * t + q;
+        if (i < NQ) part_base[i] = run;
+        run += v[q];
+    }
     if (t == 1023) part_base[NQ] = total;
 #pragma unroll
-    for (uint32_t q = 2 * t; q < 2 * t + 2; q++) {
-        if (q == 0 || q >= NQ) continue;                                 // index 0 is bucket 0's partition: never sorted
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t i = PER * t + q;
+        if (i == 0 || i >= NQ) continue;                                 // index 0 is bucket 0's partition: never sorted
         uint32_t slot = 0;
-        if ((q == 2 * t ? v0 : v1) > MSM_BINSORT_STAGE) {
+        if (v[q] > MSM_BINSORT_STAGE) {
             slot = atomicAdd(big_count, 1u);
-            if (slot < MSM_MAX_BIG) big_list[slot] = q - 1;
+            if (slot < MSM_MAX_BIG) big_list[slot] = i - 1;
             slot = slot < MSM_MAX_BIG ? slot + 1 : 0;
         }
-        big_flag[q - 1] = slot;
+        big_flag[i - 1] = slot;
     }
 }
 __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* part_count, uint32_t NQ, uint32_t* part_base, uint32_t* big_flag,
@@ -1047,7 +1057,12 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     const uint32_t W = wp.W, bits = wp.cmax() - 1;
     const uint32_t nb = 1u << bits;
     const size_t npairs = n * W;
-    const uint32_t PB = bits < MSM_MAX_PART_BITS ? bits : MSM_MAX_PART_BITS, LB = bits - PB, NP = 1u << PB;
+    // partitions of the first sorting pass: 1024, or as many more (<= 4096) as it takes to keep a partition inside the second pass's LDS
+    // stage -- beyond 2^20 points a partition of the 1024 outgrew it and the second pass fell back to scattered stores (0.9 of the 6 ms of
+    // a 2^22-point MSM: profiles/r06u_size_sweep.log, tools/msm22_profile.py)
+    uint32_t PB = bits < 10 ? bits : 10;
+    while (PB < bits && PB < MSM_MAX_PART_BITS && (npairs >> PB) > (size_t)MSM_BINSORT_STAGE * 9 / 10) PB++;
+    const uint32_t LB = bits - PB, NP = 1u << PB;
     // ---- lane length for the accumulate kernel: fill the resident lanes an integer number of times ----
     int& acc_blocks_per_cu = msm_state().acc_blocks_per_cu;
     if (!acc_blocks_per_cu) {
@@ -1057,7 +1072,10 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
         if (acc_blocks_per_cu < 1) acc_blocks_per_cu = 1;
     }
     const size_t resident = (size_t)acc_blocks_per_cu * 256 * c->num_cus;
-    size_t rounds = npairs / (resident * 40);          // 40..80 pairs per lane: few cut buckets, whole waves of work
+    // 40..80 pairs per lane at 2^20 points: few cut buckets, whole waves of work.  Larger MSMs have more pairs per BUCKET (104 at 2^22), and a lane
+    // shorter than a bucket cuts every bucket several times (the boundary fold was 0.52 of a 2^22-point MSM's 6 ms): the lanes grow with the load
+    const size_t load = npairs >> bits, per_lane = load * 9 / 10 > 40 ? load * 9 / 10 : 40;
+    size_t rounds = npairs / (resident * per_lane);
     if (rounds < 1) rounds = 1;
     uint32_t L = (uint32_t)((npairs + resident * rounds - 1) / (resident * rounds));
     if (L < 8) L = 8;
@@ -1101,6 +1119,11 @@ static int msm_enqueue(Ctx* c, MsmSlot& sl, hipStream_t st, MsmTable* T, size_t 
     // ---- sort geometry: sgrid workgroups, each owning per_block consecutive scalars ----
     // (one scalar per thread of the partition pass; all of a workgroup's pairs must fit its LDS staging area)
     size_t per_block = MSM_PART_STAGE / W / 64 * 64;
+    {
+        const size_t lds_words = (144u << 10) / 4, fixed = 3 * ((size_t)NP + 2);       // the partition kernel's 144 KiB: three arrays of NQ + 1 words, then 2 W words per scalar
+        const size_t fit = lds_words > fixed ? (lds_words - fixed) / (2 * (size_t)W) / 64 * 64 : 64;
+        if (per_block > fit) per_block = fit;
+    }
     if (per_block > 1024) per_block = 1024;
     if (per_block < 64) per_block = 64;
     const unsigned sgrid = cdiv(n, per_block);
